@@ -1,0 +1,245 @@
+"""ORACLE (test infrastructure, not product code): CPU restatement of the reference's
+sampler loops `sampler/dpm_solver.py` (DPM-Solver++ multistep) and `sampler/uni_pc.py`
+(UniPC B(h) multistep) together with their noise schedule and model wrapper.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this
+file.  It follows the reference op-for-op in float32 torch arithmetic (same order of
+operations, same x0 -> noise -> x0 round trip through the model wrapper), so its
+outputs agree with the imported reference to float32 rounding.  Pinned by
+tools/make_golden.py -> tests/golden/sampler_*.npz (captured from the imported
+reference; the reference has no tests of its own: SURVEY.md §4).
+
+File:line citations are relative to the reference checkout.
+"""
+import torch
+
+
+def piecewise_linear(x, xp, yp):
+    """interpolate_fn, sampler/dpm_solver.py:1253-1292 (dup uni_pc.py:679-718): piecewise
+    linear through (xp, yp) (xp ascending), linear extrapolation with the outermost
+    segment beyond either end.  x: [N]; xp, yp: [K]."""
+    K = xp.shape[0]
+    i = torch.searchsorted(xp, x.contiguous(), right=False) - 1
+    i = i.clamp(0, K - 2)
+    x0, x1, y0, y1 = xp[i], xp[i + 1], yp[i], yp[i + 1]
+    return y0 + (x - x0) * (y1 - y0) / (x1 - x0)
+
+
+class Schedule:
+    """NoiseScheduleVP('discrete', betas=...), sampler/dpm_solver.py:6-167 and
+    sampler/uni_pc.py:6-152.  `clip` reproduces dpm_solver's numerical_clip_alpha
+    (:114-125, lambda clipped at -5.1); uni_pc has no clip."""
+
+    def __init__(self, betas, clip=False, dtype=torch.float32):
+        log_alphas = 0.5 * torch.log(1 - betas).cumsum(dim=0)
+        if clip:
+            log_sigmas = 0.5 * torch.log(1.0 - torch.exp(2.0 * log_alphas))
+            lambs = log_alphas - log_sigmas
+            idx = int(torch.searchsorted(torch.flip(lambs, [0]), torch.tensor(-5.1, dtype=lambs.dtype)))
+            if idx > 0:
+                log_alphas = log_alphas[:-idx]
+        self.T = 1.0
+        self.log_alpha_array = log_alphas.to(dtype)
+        self.total_N = self.log_alpha_array.shape[0]
+        self.t_array = torch.linspace(0.0, 1.0, self.total_N + 1)[1:].to(dtype)
+
+    def log_alpha(self, t):   # marginal_log_mean_coeff
+        return piecewise_linear(t.reshape(-1), self.t_array, self.log_alpha_array)
+
+    def alpha(self, t):       # marginal_alpha
+        return torch.exp(self.log_alpha(t))
+
+    def sigma(self, t):       # marginal_std
+        return torch.sqrt(1.0 - torch.exp(2.0 * self.log_alpha(t)))
+
+    def lam(self, t):         # marginal_lambda
+        la = self.log_alpha(t)
+        return la - 0.5 * torch.log(1.0 - torch.exp(2.0 * la))
+
+    def inverse_lambda(self, lamb):
+        log_alpha = -0.5 * torch.logaddexp(torch.zeros((1,)), -2.0 * lamb)
+        return piecewise_linear(log_alpha.reshape(-1), torch.flip(self.log_alpha_array, [0]),
+                                torch.flip(self.t_array, [0]))
+
+
+def _bcast(v, x):
+    return v.reshape((-1,) + (1,) * (x.dim() - 1))
+
+
+def wrap_x_start_model(model, ns):
+    """model_wrapper(model, ns, model_type='x_start') followed by the solver's
+    data_prediction_fn: t_input = (t - 1/N) * N (dpm_solver.py:271-280); noise =
+    (x - alpha_t * x0) / sigma_t (:290-292); x0 = (x - sigma_t * noise) / alpha_t (:433-442).
+    The broadcast over batch is the dpm_solver form (expand_dims); uni_pc.py:189-191 omits
+    it and only runs at B=1 where both forms coincide."""
+    def data_prediction(x, t):
+        tb = t.expand(x.shape[0])
+        t_input = (tb - 1.0 / ns.total_N) * ns.total_N
+        out = model(x, t_input)
+        a, s = ns.alpha(tb), ns.sigma(tb)
+        noise = (x - _bcast(a, x) * out) / _bcast(s, x)
+        a1, s1 = ns.alpha(t), ns.sigma(t)
+        return (x - s1 * noise) / a1
+    return data_prediction
+
+
+def time_steps(ns, skip_type, t_T, t_0, N):
+    """get_time_steps, dpm_solver.py:453-480."""
+    if skip_type == "time_uniform":
+        return torch.linspace(t_T, t_0, N + 1)
+    if skip_type == "time_quadratic":
+        return torch.linspace(t_T ** 0.5, t_0 ** 0.5, N + 1).pow(2)
+    if skip_type == "logSNR":
+        lT = ns.lam(torch.tensor(t_T))
+        l0 = ns.lam(torch.tensor(t_0))
+        return ns.inverse_lambda(torch.linspace(lT.item(), l0.item(), N + 1))
+    raise ValueError("Unsupported skip_type %r" % (skip_type,))
+
+
+# ----------------------------------------------------------------------------- DPM-Solver++
+def _dpmpp_update(ns, x, m_list, t_list, t, order):
+    """multistep_dpm_solver_update for algorithm_type='dpmsolver++', solver_type='dpmsolver':
+    first (:547-580), second (:796-831), third (:854-889) order."""
+    t0 = t_list[-1]
+    lam0, lam_t = ns.lam(t0), ns.lam(t)
+    sig0, sig_t = ns.sigma(t0), ns.sigma(t)
+    alpha_t = torch.exp(ns.log_alpha(t))
+    h = lam_t - lam0
+    phi_1 = torch.expm1(-h)
+    if order == 1:
+        return sig_t / sig0 * x - alpha_t * phi_1 * m_list[-1]
+    if order == 2:
+        m1, m0 = m_list[-2], m_list[-1]
+        h_0 = lam0 - ns.lam(t_list[-2])
+        r0 = h_0 / h
+        D1_0 = (1.0 / r0) * (m0 - m1)
+        return (sig_t / sig0) * x - (alpha_t * phi_1) * m0 - 0.5 * (alpha_t * phi_1) * D1_0
+    if order == 3:
+        m2, m1, m0 = m_list
+        lam1, lam2 = ns.lam(t_list[-2]), ns.lam(t_list[-3])
+        h_1, h_0 = lam1 - lam2, lam0 - lam1
+        r0, r1 = h_0 / h, h_1 / h
+        D1_0 = (1.0 / r0) * (m0 - m1)
+        D1_1 = (1.0 / r1) * (m1 - m2)
+        D1 = D1_0 + (r0 / (r0 + r1)) * (D1_0 - D1_1)
+        D2 = (1.0 / (r0 + r1)) * (D1_0 - D1_1)
+        phi_2 = phi_1 / h + 1.0
+        phi_3 = phi_2 / h - 0.5
+        return (sig_t / sig0) * x - (alpha_t * phi_1) * m0 + (alpha_t * phi_2) * D1 - (alpha_t * phi_3) * D2
+    raise ValueError("Solver order must be 1 or 2 or 3, got %r" % (order,))
+
+
+def dpm_solver_pp_sample(model, betas, x, steps=20, order=2, skip_type="time_uniform",
+                         lower_order_final=True, return_intermediate=False):
+    """DPM_Solver(model_fn, ns, 'dpmsolver++').sample(x, steps, order, skip_type,
+    method='multistep'), dpm_solver.py:1047-1245 (multistep branch :1171-1213).
+    `model(x, t_input)` is the raw x0-prediction network."""
+    ns = Schedule(betas, clip=True)
+    fn = wrap_x_start_model(model, ns)
+    t_0, t_T = 1.0 / ns.total_N, ns.T
+    assert steps >= order
+    ts = time_steps(ns, skip_type, t_T, t_0, steps)
+    inter = []
+    t = ts[0]
+    t_list, m_list = [t], [fn(x, t)]
+    for step in range(1, order):
+        t = ts[step]
+        x = _dpmpp_update(ns, x, m_list, t_list, t, step)
+        inter.append(x)
+        t_list.append(t)
+        m_list.append(fn(x, t))
+    for step in range(order, steps + 1):
+        t = ts[step]
+        step_order = min(order, steps + 1 - step) if (lower_order_final and steps < 10) else order
+        x = _dpmpp_update(ns, x, m_list, t_list, t, step_order)
+        inter.append(x)
+        t_list = t_list[1:] + [t]
+        m_list = m_list[1:] + [None]
+        if step < steps:
+            m_list[-1] = fn(x, t)
+    return (x, inter) if return_intermediate else x
+
+
+# ----------------------------------------------------------------------------- UniPC
+def _unipc_bh_update(ns, fn, x, m_list, t_list, t, order, variant, use_corrector):
+    """multistep_uni_pc_bh_update with predict_x0=True, uni_pc.py:471-588."""
+    t = t.reshape(-1)
+    t0 = t_list[-1]
+    lam0, lam_t = ns.lam(t0), ns.lam(t)
+    m0 = m_list[-1]
+    sig0, sig_t = ns.sigma(t0), ns.sigma(t)
+    alpha_t = torch.exp(ns.log_alpha(t))
+    h = lam_t - lam0
+    rks, D1s = [], []
+    for i in range(1, order):
+        rk = (ns.lam(t_list[-(i + 1)]) - lam0) / h
+        rks.append(rk)
+        D1s.append((m_list[-(i + 1)] - m0) / rk)
+    rks.append(1.0)
+    rks = torch.tensor([float(r) for r in rks])
+    hh = -h
+    h_phi_1 = torch.expm1(hh)
+    h_phi_k = h_phi_1 / hh - 1
+    B_h = hh if variant == "bh1" else torch.expm1(hh)
+    R, b = [], []
+    fact = 1
+    for i in range(1, order + 1):
+        R.append(torch.pow(rks, i - 1))
+        b.append(h_phi_k * fact / B_h)
+        fact *= (i + 1)
+        h_phi_k = h_phi_k / hh - 1 / fact
+    R = torch.stack(R)
+    b = torch.cat(b)
+    rhos_p = None
+    if D1s:
+        D1s = torch.stack(D1s, dim=1)
+        rhos_p = torch.tensor([0.5]) if order == 2 else torch.linalg.solve(R[:-1, :-1], b[:-1])
+    else:
+        D1s = None
+    if use_corrector:
+        rhos_c = torch.tensor([0.5]) if order == 1 else torch.linalg.solve(R, b)
+    x_t_ = sig_t / sig0 * x - alpha_t * h_phi_1 * m0
+    pred = torch.einsum("k,bkct->bct", rhos_p, D1s) if D1s is not None else 0
+    x_t = x_t_ - alpha_t * B_h * pred
+    m_t = None
+    if use_corrector:
+        m_t = fn(x_t, t)
+        corr = torch.einsum("k,bkct->bct", rhos_c[:-1], D1s) if D1s is not None else 0
+        x_t = x_t_ - alpha_t * B_h * (corr + rhos_c[-1] * (m_t - m0))
+    return x_t, m_t
+
+
+def unipc_sample(model, betas, x, steps=20, order=2, skip_type="time_uniform", variant="bh2",
+                 lower_order_final=True, return_intermediate=False):
+    """UniPC(model_fn, ns, variant=...).sample(x, steps, order, skip_type, 'multistep'),
+    uni_pc.py:590-672."""
+    ns = Schedule(betas, clip=False)
+    fn = wrap_x_start_model(model, ns)
+    t_0, t_T = 1.0 / ns.total_N, ns.T
+    assert steps >= order
+    ts = time_steps(ns, skip_type, t_T, t_0, steps)
+    inter = []
+    t = ts[0]
+    t_list, m_list = [t], [fn(x, t)]
+    for step in range(1, order):
+        t = ts[step]
+        x, m_x = _unipc_bh_update(ns, fn, x, m_list, t_list, t, step, variant, True)
+        inter.append(x)
+        t_list.append(t)
+        m_list.append(m_x)
+    for step in range(order, steps + 1):
+        t = ts[step]
+        step_order = min(order, steps + 1 - step) if lower_order_final else order
+        x, m_x = _unipc_bh_update(ns, fn, x, m_list, t_list, t, step_order, variant, step != steps)
+        inter.append(x)
+        t_list = t_list[1:] + [t]
+        m_list = m_list[1:] + [None]
+        if step < steps:
+            m_list[-1] = m_x
+    return (x, inter) if return_intermediate else x
+
+
+def standin_model(x, t_input):
+    """Analytic stand-in network for sampler known-answer tests:
+    x0 = tanh(x/2) * (1 + 1e-6 * tau)."""
+    return torch.tanh(x / 2) * (1 + 1e-6 * t_input.reshape((-1,) + (1,) * (x.dim() - 1)))
