@@ -1,0 +1,110 @@
+// Internal declarations shared by the kernel translation units and the engine.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef unsigned short bf16_t;   // raw bfloat16 bits
+
+// ---------------------------------------------------------------------------------------
+// Implicit-GEMM parameters.  One launch computes
+//     out[m, n] = epilogue( sum over K-segments/taps/channels of  A(m, k) * W[n, k] )
+// on channels-last fp32 activations.  Row m = (b, t) of the output; the A operand is
+// gathered on the fly (conv taps, stride, nearest upsample, channel-concat of two source
+// tensors) and passed through a prologue (GroupNorm/temb affine + SiLU, or LayerNorm).
+// ---------------------------------------------------------------------------------------
+enum { PRO_NONE = 0, PRO_AFFINE_SILU = 1, PRO_AFFINE = 2, PRO_LN = 3 };
+enum { EPI_STORE = 0, EPI_RESIDUAL = 1, EPI_GEGLU = 2, EPI_STORE_NCT = 3 };
+enum { UP_NONE = 0, UP_X2 = 1, UP_SIZE = 2 };
+
+struct GemmSeg {
+  const float* a0;     // [B*T_in, c0]
+  const float* a1;     // [B*T_in, c1] or null (channel concat [a0 | a1])
+  const float* p0;     // PRO_AFFINE*: scale[B, c0+c1];  PRO_LN: mean[B*T_in]
+  const float* p1;     // PRO_AFFINE*: shift[B, c0+c1];  PRO_LN: rstd[B*T_in]
+  int c0, c1;          // channel counts, multiples of 32
+  int taps;            // 1 or 3
+  int pad;             // left padding in frames
+  int pro;             // PRO_*
+  int nkt;             // k-tiles of this segment = taps * (c0+c1) / 32
+};
+
+struct GemmParams {
+  GemmSeg seg[2];
+  int nseg;
+  int B, T_out, T_in, T_virt;   // T_virt: length after the (virtual) nearest upsample
+  int stride;
+  int up_mode;                  // UP_*
+  float up_scale;               // UP_SIZE: (float)T_in / T_virt, as ATen computes it
+  const bf16_t* w_hi;           // [N_pad, Kp] bf16, row n = output channel, k contiguous
+  const bf16_t* w_lo;           // low-order split (null in bf16 mode)
+  int Kp;                       // packed K = 32 * total k-tiles
+  int N_pad;                    // rows present in w_hi/w_lo (multiple of 64)
+  const float* bias;            // [N] (GEGLU: [2*N_out] in packed order) or null
+  int M, N;                     // output rows, GEMM columns (GEGLU: packed 2*N_out)
+  int epi;                      // EPI_*
+  const float* res;             // EPI_RESIDUAL: [M, ldres]
+  int ldres;
+  float* out;                   // [M, ldo]  (EPI_STORE_NCT: [B, N, T_out])
+  int ldo;
+};
+
+struct AttnParams {
+  const float* q; const float* k; const float* v; const float* bias; float* o;
+  int ldq, ldk, ldv, ldo;       // row strides (floats); head h occupies columns [h*d, h*d+d)
+  int B, H, Tq, Tk, d;
+  float scale;
+};
+
+// launchers (each enqueues on `st` and returns hipGetLastError())
+hipError_t launch_gemm(const GemmParams& p, int precision, hipStream_t st);
+hipError_t gemm_init();   // one-time kernel attribute setup (call outside stream capture)
+hipError_t launch_attention(const AttnParams& p, hipStream_t st);
+
+// misc kernels (kernels_misc.hip)
+hipError_t launch_pack_input(const float* x, int cx, const float* cond, int cc, float* out, int cpad, int B, int T,
+                             hipStream_t st);
+// GroupNorm statistics of the channel-concat [a0 | a1] -> part[B, nchunk, G, 2] (double sum, sumsq)
+hipError_t launch_gn_partial(const float* a0, int c0, const float* a1, int c1, double* part, int B, int T, int G,
+                             int nchunk, hipStream_t st);
+// combine partials -> per-(b,c) affine: scale = rstd*gamma*(1+ts), shift = (beta-mean*rstd*gamma)*(1+ts)+tb
+// ts/tb = temb scale/shift rows [B, ld_t] (null -> 0); optional raw mean/rstd outputs [B,G]
+hipError_t launch_gn_finalize(const double* part, int nchunk, const float* gamma, const float* beta,
+                              const float* tscale, const float* tshift, int ld_t, float* scale, float* shift,
+                              float* mean_out, float* rstd_out, int B, int T, int C, int G, float eps,
+                              hipStream_t st);
+hipError_t launch_ln_stats(const float* x, float* mean, float* rstd, int M, int C, float eps, hipStream_t st);
+// out[m,n] = act_out( sum_k act_in(in[m,k]) * W[n,k] + b[n] ) + add[m,n];  fp32, small M
+hipError_t launch_small_linear(const float* in, int ldin, const float* W, const float* b, const float* add,
+                               float* out, int ldo, int M, int K, int N, int silu_in, int silu_out,
+                               hipStream_t st);
+hipError_t launch_timestep_sincos(const float* t, float* out, int B, int dim, hipStream_t st);
+hipError_t launch_layernorm_rows(const float* x, const float* g, const float* b, float* out, int M, int C,
+                                 float eps, hipStream_t st);
+// attention pooling pieces (reference embeddings.py:499-546)
+hipError_t launch_mean_token(float* seq, const float* pos, int B, int L, int D, hipStream_t st);
+hipError_t launch_pool_attn(const float* q, const float* kv, float* out, int B, int S, int D, int heads,
+                            hipStream_t st);
+hipError_t launch_layernorm_rows_into(const float* x, const float* g, const float* b, float* out, int M, int C,
+                                      float eps, int rows_per_batch, int out_rows_per_batch, int out_row_off,
+                                      hipStream_t st);
+// weight packing: src fp32 -> bf16 hi/lo [N_pad, Kp]
+struct PackSpec {
+  const float* src;   // source weight
+  int N;              // rows (output channels) in src
+  int kind;           // 0: linear [N, C];  1: conv [N, C, taps]
+  int C, taps;        // source channel count / taps
+  int c_pad;          // channels per tap in the packed layout (>= C, multiple of 32)
+  int k_off;          // first packed k of this piece
+  int n_off;          // first packed row of this piece
+  const float* kscale; // optional per-source-channel multiplier (LayerNorm gamma fold) or null
+  int geglu;          // 1: permute rows so [a(32) | gate(32)] alternate per 64-row block
+};
+hipError_t launch_pack_weight(const PackSpec& s, bf16_t* hi, bf16_t* lo, int Kp, hipStream_t st);
+// bias'[n] = bias[n] + sum_c W[n,c]*beta[c]   (LayerNorm beta fold), rows permuted like geglu packing
+hipError_t launch_fold_bias(const float* W, const float* bias, const float* beta, float* out, int N, int C,
+                            int n_off, int geglu, hipStream_t st);
+hipError_t launch_copy_f32(const float* src, float* dst, int64_t n, hipStream_t st);
+hipError_t launch_fill_f32(float* dst, float v, int64_t n, hipStream_t st);
+// sampler update: out = c[0]*x + c[1]*m0 + c[2]*m1 + c[3]*m2 + c[4]*m3 (coefficient row of 8 floats on device)
+hipError_t launch_lincomb(float* out, const float* x, const float* m0, const float* m1, const float* m2,
+                          const float* m3, const float* coef, int64_t n, hipStream_t st);

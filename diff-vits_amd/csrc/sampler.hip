@@ -1,0 +1,486 @@
+// Sampler plans and loops behind dv_sampler_* (include/dvits_hip.h).
+//
+// The reference evaluates every schedule scalar with ~35 tiny tensor ops per look-up inside
+// the loop (sampler/dpm_solver.py:1253-1292 interpolate_fn, called ~12x per step).  Nothing in
+// those scalars depends on tensor data, so here the whole multistep loop is compiled ONCE on
+// the host in fp64 into a list of events
+//     EVAL : m[slot] = model(x or x_pred, t_input)
+//     COMB : x or x_pred = c0*x + sum_k c_k * m[slot_k]
+// (DPM-Solver++ orders 1-3: dpm_solver.py:547-580, 796-831, 854-889; UniPC bh1/bh2 orders 1-3:
+// uni_pc.py:471-588; loops dpm_solver.py:1171-1213 and uni_pc.py:606-658), and executed as
+// steps x (UNet schedule + one fused lincomb kernel), captured into a hipGraph.
+//
+// Deviation from the reference, documented in DESIGN.md: the x0 -> noise -> x0 round trip of
+// model_wrapper/data_prediction_fn (dpm_solver.py:290-292, 433-442) is algebraically the
+// identity and is not replayed.
+#include "../../include/dvits_hip.h"
+#include "dv_common.h"
+
+#include <array>
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+int dv_fail(int code, const char* fmt, ...);
+struct dv_unet;
+int dv_unet_enqueue(dv_unet* u, const float* x, int cx, const float* cond, const float* t, float* y, hipStream_t st);
+int dv_unet_dims(const dv_unet* u, int* B, int* T, int* cin, int* cout, int64_t* gen);
+
+#define HIPCHK(expr)                                                                                  \
+  do {                                                                                                \
+    hipError_t _e = (expr);                                                                           \
+    if (_e != hipSuccess)                                                                             \
+      return dv_fail(DV_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+  } while (0)
+
+namespace {
+
+// NoiseScheduleVP('discrete', betas) — dpm_solver.py:6-167 / uni_pc.py:6-152.  The arrays are
+// built in float32 exactly as the reference stores them, then evaluated in fp64.
+struct Schedule {
+  std::vector<double> t_arr, la_arr;   // keypoints (float32 values widened)
+  int total_N = 0;
+  void init(const float* betas, int n, bool clip) {
+    std::vector<float> la(n);
+    float acc = 0.f;
+    for (int i = 0; i < n; ++i) {
+      acc += logf(1.0f - betas[i]);       // torch.log(1 - betas).cumsum(0), float32
+      la[i] = 0.5f * acc;
+    }
+    if (clip) {                            // numerical_clip_alpha, dpm_solver.py:114-125
+      // lambdas are decreasing in i; count trailing entries with lambda < -5.1
+      int idx = 0;
+      for (int i = n - 1; i >= 0; --i) {
+        const float ls = 0.5f * logf(1.0f - expf(2.0f * la[i]));
+        if (la[i] - ls < -5.1f) ++idx; else break;
+      }
+      if (idx > 0) la.resize(n - idx);
+    }
+    total_N = (int)la.size();
+    la_arr.assign(la.begin(), la.end());
+    t_arr.resize(total_N);
+    // torch.linspace(0, 1, N+1)[1:], float32 (symmetric fill as ATen does)
+    const int pts = total_N + 1;
+    const float step = 1.0f / (float)(pts - 1);
+    for (int i = 1; i < pts; ++i) {
+      const float v = (i < pts / 2) ? fmaf(step, (float)i, 0.0f) : fmaf(-step, (float)(pts - i - 1), 1.0f);
+      t_arr[i - 1] = (double)v;
+    }
+  }
+  static double interp(double x, const std::vector<double>& xp, const std::vector<double>& yp, bool flipped) {
+    // piecewise linear with outermost-segment extrapolation (interpolate_fn)
+    const int K = (int)xp.size();
+    auto X = [&](int i) { return flipped ? xp[K - 1 - i] : xp[i]; };
+    auto Y = [&](int i) { return flipped ? yp[K - 1 - i] : yp[i]; };
+    int lo = 0, hi = K;                    // first index with X(i) >= x
+    while (lo < hi) { int mid = (lo + hi) / 2; if (X(mid) < x) lo = mid + 1; else hi = mid; }
+    int i = lo - 1;
+    if (i < 0) i = 0;
+    if (i > K - 2) i = K - 2;
+    return Y(i) + (x - X(i)) * (Y(i + 1) - Y(i)) / (X(i + 1) - X(i));
+  }
+  double log_alpha(double t) const { return interp(t, t_arr, la_arr, false); }
+  double alpha(double t) const { return exp(log_alpha(t)); }
+  double sigma(double t) const { return sqrt(1.0 - exp(2.0 * log_alpha(t))); }
+  double lambda(double t) const { const double la = log_alpha(t); return la - 0.5 * log(1.0 - exp(2.0 * la)); }
+  double inverse_lambda(double lamb) const {
+    // log_alpha = -0.5 * logaddexp(0, -2 lamb); interpolate t on the flipped arrays
+    const double a = -2.0 * lamb;
+    const double lae = -0.5 * (a > 0 ? a + log1p(exp(-a)) : log1p(exp(a)));
+    return interp(lae, la_arr, t_arr, true);
+  }
+};
+
+struct Event {
+  int type;          // 0 EVAL, 1 COMB
+  int src;           // EVAL: 0 = x, 1 = x_pred
+  int eval_idx;      // EVAL: index into t_input
+  int dst;           // EVAL: history slot;  COMB: 0 = x, 1 = x_pred
+  int coef;          // COMB: row of the coefficient table
+  int slots[4];      // COMB: history slots of the m terms (-1 = unused)
+};
+
+// solve A x = b (n <= 3), Gaussian elimination with partial pivoting
+bool solve_small(int n, double A[3][3], double b[3], double x[3]) {
+  for (int c = 0; c < n; ++c) {
+    int piv = c;
+    for (int r = c + 1; r < n; ++r) if (fabs(A[r][c]) > fabs(A[piv][c])) piv = r;
+    if (fabs(A[piv][c]) < 1e-300) return false;
+    if (piv != c) { for (int k = 0; k < n; ++k) std::swap(A[c][k], A[piv][k]); std::swap(b[c], b[piv]); }
+    for (int r = c + 1; r < n; ++r) {
+      const double f = A[r][c] / A[c][c];
+      for (int k = c; k < n; ++k) A[r][k] -= f * A[c][k];
+      b[r] -= f * b[c];
+    }
+  }
+  for (int r = n - 1; r >= 0; --r) {
+    double s = b[r];
+    for (int k = r + 1; k < n; ++k) s -= A[r][k] * x[k];
+    x[r] = s / A[r][r];
+  }
+  return true;
+}
+
+}  // namespace
+
+struct dv_plan {
+  int solver = 0, steps = 0, order = 0, skip = 0, lof = 1;
+  Schedule ns;
+  std::vector<double> timesteps;      // steps + 1
+  std::vector<double> t_input;        // per EVAL
+  std::vector<Event> ev;
+  std::vector<std::array<float, 8>> coefs;
+  int n_slots = 0;
+  // device state
+  float* d_coefs = nullptr;
+  float* d_tin = nullptr; int tin_B = 0;
+  float* xp = nullptr; std::vector<float*> m; int64_t buf_numel = 0;
+  // graph cache
+  hipGraphExec_t exec = nullptr; hipStream_t cap_stream = nullptr;
+  struct { dv_unet* u = nullptr; int64_t gen = -1; float* x = nullptr; const float* cond = nullptr; } key;
+};
+
+static int build_plan(dv_plan* p) {
+  const Schedule& ns = p->ns;
+  const int N = p->steps, order = p->order;
+  const double t_0 = 1.0 / ns.total_N, t_T = 1.0;
+  // ---- time grid (get_time_steps, dpm_solver.py:453-480), float32 as the reference stores it
+  p->timesteps.resize(N + 1);
+  auto linspace32 = [&](float a, float b, std::vector<double>& out) {
+    const int pts = N + 1;
+    const float step = (b - a) / (float)(pts - 1);
+    for (int i = 0; i < pts; ++i)   // ATen's vectorised fill rounds once per element (fma)
+      out[i] = (double)((i < pts / 2) ? fmaf(step, (float)i, a) : fmaf(-step, (float)(pts - i - 1), b));
+  };
+  if (p->skip == DV_SKIP_TIME_UNIFORM) linspace32((float)t_T, (float)t_0, p->timesteps);
+  else if (p->skip == DV_SKIP_TIME_QUADRATIC) {
+    linspace32((float)sqrt(t_T), (float)sqrt(t_0), p->timesteps);
+    for (auto& v : p->timesteps) { const float f = (float)v; v = (double)(f * f); }
+  } else if (p->skip == DV_SKIP_LOGSNR) {
+    std::vector<double> lam(N + 1);
+    const float lT = (float)ns.lambda(t_T), l0 = (float)ns.lambda(t_0);
+    const int pts = N + 1;
+    const float step = (l0 - lT) / (float)(pts - 1);
+    for (int i = 0; i < pts; ++i) lam[i] = (double)((i < pts / 2) ? fmaf(step, (float)i, lT) : fmaf(-step, (float)(pts - i - 1), l0));
+    for (int i = 0; i <= N; ++i) p->timesteps[i] = (double)(float)ns.inverse_lambda(lam[i]);
+  } else return dv_fail(DV_ERR_INVALID, "Unsupported skip_type %d", p->skip);
+
+  auto t_in = [&](double t) {   // get_model_input_time, float32 arithmetic (dpm_solver.py:271-280)
+    const float tf = (float)t;
+    return (double)((tf - (float)(1.0 / ns.total_N)) * (float)ns.total_N);
+  };
+  auto add_eval = [&](int src, double t, int slot) {
+    Event e{}; e.type = 0; e.src = src; e.eval_idx = (int)p->t_input.size(); e.dst = slot;
+    p->t_input.push_back(t_in(t));
+    p->ev.push_back(e);
+  };
+  auto add_comb = [&](int dst, double c0, const std::vector<std::pair<int, double>>& terms) {
+    Event e{}; e.type = 1; e.dst = dst; e.coef = (int)p->coefs.size();
+    std::array<float, 8> row{};
+    row[0] = (float)c0;
+    for (int k = 0; k < 4; ++k) e.slots[k] = -1;
+    int k = 0;
+    for (auto& t : terms) { e.slots[k] = t.first; row[1 + k] = (float)t.second; ++k; }
+    p->coefs.push_back(row);
+    p->ev.push_back(e);
+  };
+  const std::vector<double>& ts = p->timesteps;
+  std::vector<int> hist;            // history slots, newest first
+  std::vector<double> htime;        // their times
+  const bool unipc = p->solver != DV_SOLVER_DPMPP;
+  p->n_slots = unipc ? order + 1 : order;
+  auto free_slot = [&]() {
+    for (int s = 0; s < p->n_slots; ++s) {
+      bool used = false;
+      for (int h : hist) used |= (h == s);
+      if (!used) return s;
+    }
+    return -1;
+  };
+  auto push_hist = [&](int slot, double t) {
+    hist.insert(hist.begin(), slot);
+    htime.insert(htime.begin(), t);
+    if ((int)hist.size() > order) { hist.pop_back(); htime.pop_back(); }
+  };
+
+  if (!unipc) {
+    // ---------------- DPM-Solver++ multistep ----------------
+    auto update = [&](double t, int ord) {
+      const double t0 = htime[0];
+      const double lam0 = ns.lambda(t0), lam_t = ns.lambda(t);
+      const double h = lam_t - lam0, phi_1 = expm1(-h);
+      const double c0 = ns.sigma(t) / ns.sigma(t0), a = ns.alpha(t);
+      if (ord == 1) { add_comb(0, c0, {{hist[0], -a * phi_1}}); return; }
+      if (ord == 2) {
+        const double r0 = (lam0 - ns.lambda(htime[1])) / h;
+        add_comb(0, c0, {{hist[0], -a * phi_1 * (1.0 + 0.5 / r0)}, {hist[1], 0.5 * a * phi_1 / r0}});
+        return;
+      }
+      const double lam1 = ns.lambda(htime[1]), lam2 = ns.lambda(htime[2]);
+      const double r0 = (lam0 - lam1) / h, r1 = (lam1 - lam2) / h;
+      const double a0 = 1.0 / r0, a1 = 1.0 / r1, g = r0 / (r0 + r1), e = 1.0 / (r0 + r1);
+      const double phi_2 = phi_1 / h + 1.0, phi_3 = phi_2 / h - 0.5;
+      const double P2 = a * phi_2, P3 = a * phi_3;
+      add_comb(0, c0, {{hist[0], -a * phi_1 + P2 * (1 + g) * a0 - P3 * e * a0},
+                       {hist[1], -P2 * (1 + g) * a0 - P2 * g * a1 + P3 * e * a0 + P3 * e * a1},
+                       {hist[2], P2 * g * a1 - P3 * e * a1}});
+    };
+    add_eval(0, ts[0], 0);
+    push_hist(0, ts[0]);
+    for (int step = 1; step < order; ++step) {
+      update(ts[step], step);
+      int s = free_slot();
+      add_eval(0, ts[step], s);
+      push_hist(s, ts[step]);
+    }
+    for (int step = order; step <= N; ++step) {
+      const int so = (p->lof && N < 10) ? std::min(order, N + 1 - step) : order;
+      update(ts[step], so);
+      if (step < N) {
+        // the new evaluation overwrites the oldest history entry (no longer needed)
+        int s;
+        if ((int)hist.size() == order) { s = hist.back(); hist.pop_back(); htime.pop_back(); }
+        else s = free_slot();
+        add_eval(0, ts[step], s);
+        push_hist(s, ts[step]);
+      }
+    }
+  } else {
+    // ---------------- UniPC multistep, B(h) variants, x0-prediction ----------------
+    const bool bh1 = p->solver == DV_SOLVER_UNIPC_BH1;
+    auto do_step = [&](double t, int ord, bool corr) -> int {
+      const double t0 = htime[0];
+      const double lam0 = ns.lambda(t0), lam_t = ns.lambda(t);
+      const double h = lam_t - lam0, hh = -h;
+      const double a = ns.alpha(t), c0 = ns.sigma(t) / ns.sigma(t0);
+      const double h_phi_1 = expm1(hh);
+      const double B_h = bh1 ? hh : expm1(hh);
+      double rks[3];
+      for (int i = 1; i < ord; ++i) rks[i - 1] = (ns.lambda(htime[i]) - lam0) / h;
+      rks[ord - 1] = 1.0;
+      double R[3][3], b[3];
+      {
+        double h_phi_k = h_phi_1 / hh - 1.0, fact = 1.0;
+        for (int i = 1; i <= ord; ++i) {
+          for (int j = 0; j < ord; ++j) R[i - 1][j] = pow(rks[j], i - 1);
+          b[i - 1] = h_phi_k * fact / B_h;
+          fact *= (i + 1);
+          h_phi_k = h_phi_k / hh - 1.0 / fact;
+        }
+      }
+      double rho_p[3] = {0, 0, 0}, rho_c[3] = {0, 0, 0};
+      if (ord == 2) rho_p[0] = 0.5;
+      else if (ord == 3) {
+        double A2[3][3], b2[3];
+        for (int i = 0; i < 2; ++i) { for (int j = 0; j < 2; ++j) A2[i][j] = R[i][j]; b2[i] = b[i]; }
+        if (!solve_small(2, A2, b2, rho_p)) return dv_fail(DV_ERR_INVALID, "UniPC predictor system is singular");
+      }
+      if (corr) {
+        if (ord == 1) rho_c[0] = 0.5;
+        else {
+          double A3[3][3], b3[3];
+          for (int i = 0; i < ord; ++i) { for (int j = 0; j < ord; ++j) A3[i][j] = R[i][j]; b3[i] = b[i]; }
+          if (!solve_small(ord, A3, b3, rho_c)) return dv_fail(DV_ERR_INVALID, "UniPC corrector system is singular");
+        }
+      }
+      // predictor
+      {
+        std::vector<std::pair<int, double>> terms;
+        double cm0 = -a * h_phi_1;
+        for (int k = 1; k < ord; ++k) cm0 += a * B_h * rho_p[k - 1] / rks[k - 1];
+        terms.push_back({hist[0], cm0});
+        for (int k = 1; k < ord; ++k) terms.push_back({hist[k], -a * B_h * rho_p[k - 1] / rks[k - 1]});
+        add_comb(corr ? 1 : 0, c0, terms);
+      }
+      if (corr) {
+        const int s = free_slot();
+        add_eval(1, t, s);
+        std::vector<std::pair<int, double>> terms;
+        double cm0 = -a * h_phi_1 + a * B_h * rho_c[ord - 1];
+        for (int k = 1; k < ord; ++k) cm0 += a * B_h * rho_c[k - 1] / rks[k - 1];
+        terms.push_back({hist[0], cm0});
+        for (int k = 1; k < ord; ++k) terms.push_back({hist[k], -a * B_h * rho_c[k - 1] / rks[k - 1]});
+        terms.push_back({s, -a * B_h * rho_c[ord - 1]});
+        add_comb(0, c0, terms);
+        push_hist(s, t);
+      }
+      return DV_OK;
+    };
+    add_eval(0, ts[0], 0);
+    push_hist(0, ts[0]);
+    for (int step = 1; step < order; ++step) {
+      int rc = do_step(ts[step], step, true);
+      if (rc != DV_OK) return rc;
+    }
+    for (int step = order; step <= N; ++step) {
+      const int so = p->lof ? std::min(order, N + 1 - step) : order;
+      int rc = do_step(ts[step], so, step != N);
+      if (rc != DV_OK) return rc;
+    }
+  }
+  return DV_OK;
+}
+
+extern "C" int dv_sampler_plan(int32_t solver, const float* betas, int32_t n_betas, int32_t steps, int32_t order,
+                               int32_t skip_type, int32_t lower_order_final, dv_plan** out) {
+  if (!betas || !out || n_betas < 2) return dv_fail(DV_ERR_INVALID, "dv_sampler_plan: bad argument");
+  if (solver < DV_SOLVER_DPMPP || solver > DV_SOLVER_UNIPC_BH2) return dv_fail(DV_ERR_INVALID, "unknown solver %d", solver);
+  if (order < 1 || order > 3) return dv_fail(DV_ERR_INVALID, "Solver order must be 1 or 2 or 3, got %d", order);
+  if (steps < order) return dv_fail(DV_ERR_INVALID, "steps (%d) must be >= order (%d)", steps, order);
+  dv_plan* p = new dv_plan();
+  p->solver = solver; p->steps = steps; p->order = order; p->skip = skip_type; p->lof = lower_order_final;
+  p->ns.init(betas, n_betas, solver == DV_SOLVER_DPMPP);
+  int rc = build_plan(p);
+  if (rc != DV_OK) { delete p; return rc; }
+  *out = p;
+  return DV_OK;
+}
+
+static void plan_drop_graph(dv_plan* p) {
+  if (p->exec) { (void)hipGraphExecDestroy(p->exec); p->exec = nullptr; }
+  p->key.u = nullptr; p->key.gen = -1; p->key.x = nullptr; p->key.cond = nullptr;
+}
+
+extern "C" void dv_plan_destroy(dv_plan* p) {
+  if (!p) return;
+  (void)hipDeviceSynchronize();
+  plan_drop_graph(p);
+  if (p->cap_stream) (void)hipStreamDestroy(p->cap_stream);
+  if (p->d_coefs) (void)hipFree(p->d_coefs);
+  if (p->d_tin) (void)hipFree(p->d_tin);
+  if (p->xp) (void)hipFree(p->xp);
+  for (float* b : p->m) (void)hipFree(b);
+  delete p;
+}
+
+extern "C" int dv_plan_info(const dv_plan* p, int32_t* nfe, double* t_input, double* timesteps) {
+  if (!p) return dv_fail(DV_ERR_INVALID, "dv_plan_info: null plan");
+  if (nfe) *nfe = (int32_t)p->t_input.size();
+  if (t_input) memcpy(t_input, p->t_input.data(), p->t_input.size() * sizeof(double));
+  if (timesteps) memcpy(timesteps, p->timesteps.data(), p->timesteps.size() * sizeof(double));
+  return DV_OK;
+}
+
+// number of events / coefficient rows, for tests
+extern "C" int dv_plan_coefs(const dv_plan* p, int32_t* n_rows, float* rows8) {
+  if (!p) return dv_fail(DV_ERR_INVALID, "dv_plan_coefs: null plan");
+  if (n_rows) *n_rows = (int32_t)p->coefs.size();
+  if (rows8) memcpy(rows8, p->coefs.data(), p->coefs.size() * 8 * sizeof(float));
+  return DV_OK;
+}
+
+// events as rows of 9 int32: type, src, eval_idx, dst, coef, slot0, slot1, slot2, slot3
+extern "C" int dv_plan_events(const dv_plan* p, int32_t* n_events, int32_t* ev9, int32_t* n_slots) {
+  if (!p) return dv_fail(DV_ERR_INVALID, "dv_plan_events: null plan");
+  if (n_events) *n_events = (int32_t)p->ev.size();
+  if (n_slots) *n_slots = p->n_slots;
+  if (ev9) {
+    for (size_t i = 0; i < p->ev.size(); ++i) {
+      const Event& e = p->ev[i];
+      int32_t* r = ev9 + i * 9;
+      r[0] = e.type; r[1] = e.src; r[2] = e.eval_idx; r[3] = e.dst; r[4] = e.coef;
+      for (int k = 0; k < 4; ++k) r[5 + k] = e.type == 1 ? e.slots[k] : -1;
+    }
+  }
+  return DV_OK;
+}
+
+static int plan_buffers(dv_plan* p, int64_t numel, int B) {
+  if (!p->d_coefs) {
+    HIPCHK(hipMalloc((void**)&p->d_coefs, p->coefs.size() * 8 * sizeof(float)));
+    HIPCHK(hipMemcpy(p->d_coefs, p->coefs.data(), p->coefs.size() * 8 * sizeof(float), hipMemcpyHostToDevice));
+  }
+  if (p->buf_numel != numel) {
+    plan_drop_graph(p);
+    HIPCHK(hipDeviceSynchronize());
+    if (p->xp) (void)hipFree(p->xp);
+    for (float* b : p->m) (void)hipFree(b);
+    p->m.clear(); p->xp = nullptr;
+    HIPCHK(hipMalloc((void**)&p->xp, numel * sizeof(float)));
+    for (int s = 0; s < p->n_slots; ++s) {
+      float* b = nullptr;
+      HIPCHK(hipMalloc((void**)&b, numel * sizeof(float)));
+      p->m.push_back(b);
+    }
+    p->buf_numel = numel;
+  }
+  if (B > 0 && p->tin_B != B) {
+    plan_drop_graph(p);
+    HIPCHK(hipDeviceSynchronize());
+    if (p->d_tin) (void)hipFree(p->d_tin);
+    const size_t nfe = p->t_input.size();
+    std::vector<float> h(nfe * B);
+    for (size_t e = 0; e < nfe; ++e)
+      for (int b = 0; b < B; ++b) h[e * B + b] = (float)p->t_input[e];
+    HIPCHK(hipMalloc((void**)&p->d_tin, h.size() * sizeof(float)));
+    HIPCHK(hipMemcpy(p->d_tin, h.data(), h.size() * sizeof(float), hipMemcpyHostToDevice));
+    p->tin_B = B;
+  }
+  return DV_OK;
+}
+
+template <typename EvalFn>
+static int run_events(dv_plan* p, float* x, int64_t numel, EvalFn eval, hipStream_t st) {
+  for (const Event& e : p->ev) {
+    if (e.type == 0) {
+      int rc = eval(e.src == 0 ? x : p->xp, e.eval_idx, p->m[e.dst]);
+      if (rc != DV_OK) return rc;
+    } else {
+      const float* ms[4];
+      for (int k = 0; k < 4; ++k) ms[k] = e.slots[k] >= 0 ? p->m[e.slots[k]] : nullptr;
+      hipError_t he = launch_lincomb(e.dst == 0 ? x : p->xp, x, ms[0], ms[1], ms[2], ms[3], p->d_coefs + (size_t)e.coef * 8,
+                                     numel, st);
+      if (he != hipSuccess) return dv_fail(DV_ERR_HIP, "lincomb launch failed: %s", hipGetErrorString(he));
+    }
+  }
+  return DV_OK;
+}
+
+extern "C" int dv_sampler_run(dv_plan* p, dv_unet* u, float* x_inout, const float* cond, void* stream) {
+  if (!p || !u || !x_inout) return dv_fail(DV_ERR_INVALID, "dv_sampler_run: null argument");
+  int B, T, cin, cout; int64_t gen;
+  if (!dv_unet_dims(u, &B, &T, &cin, &cout, &gen)) return dv_fail(DV_ERR_STATE, "dv_sampler_run: unet not prepared / cond not set");
+  if (cin > cout && !cond) return dv_fail(DV_ERR_INVALID, "dv_sampler_run: cond is required (in_channels > out_channels)");
+  const int64_t numel = (int64_t)B * cout * T;
+  int rc = plan_buffers(p, numel, B);
+  if (rc != DV_OK) return rc;
+  hipStream_t st = (hipStream_t)stream;
+  auto eval = [&](hipStream_t s) {
+    return [=](const float* src, int idx, float* dst) {
+      return dv_unet_enqueue(u, src, cout, cond, p->d_tin + (size_t)idx * B, dst, s);
+    };
+  };
+  const char* ng = getenv("DVITS_NO_GRAPH");
+  if (ng && ng[0] == '1') return run_events(p, x_inout, numel, eval(st), st);
+
+  if (!(p->exec && p->key.u == u && p->key.gen == gen && p->key.x == x_inout && p->key.cond == cond)) {
+    plan_drop_graph(p);
+    if (!p->cap_stream) HIPCHK(hipStreamCreateWithFlags(&p->cap_stream, hipStreamNonBlocking));
+    hipGraph_t graph = nullptr;
+    HIPCHK(hipStreamBeginCapture(p->cap_stream, hipStreamCaptureModeThreadLocal));
+    rc = run_events(p, x_inout, numel, eval(p->cap_stream), p->cap_stream);
+    hipError_t ce = hipStreamEndCapture(p->cap_stream, &graph);
+    if (rc != DV_OK) { if (graph) (void)hipGraphDestroy(graph); return rc; }
+    if (ce != hipSuccess) return dv_fail(DV_ERR_HIP, "hipStreamEndCapture failed: %s", hipGetErrorString(ce));
+    hipError_t ie = hipGraphInstantiate(&p->exec, graph, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(graph);
+    if (ie != hipSuccess) { p->exec = nullptr; return dv_fail(DV_ERR_HIP, "hipGraphInstantiate failed: %s", hipGetErrorString(ie)); }
+    p->key.u = u; p->key.gen = gen; p->key.x = x_inout; p->key.cond = cond;
+  }
+  HIPCHK(hipGraphLaunch(p->exec, st));
+  return DV_OK;
+}
+
+extern "C" int dv_sampler_run_custom(dv_plan* p, dv_model_fn fn, void* user, float* x_inout, int64_t numel, void* stream) {
+  if (!p || !fn || !x_inout || numel <= 0) return dv_fail(DV_ERR_INVALID, "dv_sampler_run_custom: bad argument");
+  int rc = plan_buffers(p, numel, 0);
+  if (rc != DV_OK) return rc;
+  hipStream_t st = (hipStream_t)stream;
+  auto eval = [&](const float* src, int idx, float* dst) {
+    int r = fn(user, src, p->t_input[idx], dst, (void*)st);
+    return r == 0 ? DV_OK : dv_fail(DV_ERR_INVALID, "model callback failed with %d", r);
+  };
+  return run_events(p, x_inout, numel, eval, st);
+}

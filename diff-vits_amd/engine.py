@@ -1,0 +1,146 @@
+"""Python handle on the native denoiser engine (libdvits_hip.so) for one
+`UNet1DConditionModel` instance: pushes the module's parameters through the C ABI,
+prepares the kernel schedule for the current (B, T, L) and runs forwards on the current
+HIP stream.  torch is used only for device memory and streams.
+"""
+import ctypes as C
+import os
+
+import torch
+
+from . import _lib
+
+_PRECISIONS = {"bf16x3": _lib.PREC_BF16X3, "bf16": _lib.PREC_BF16}
+
+
+def default_precision():
+    return os.environ.get("DVITS_PRECISION", "bf16x3")
+
+
+class UNetEngine:
+    def __init__(self, module):
+        self.module = module
+        cfg = module.config
+        chans = tuple(cfg["block_out_channels"])
+        c = _lib.UNetCfg()
+        c.in_channels = cfg["in_channels"]
+        c.out_channels = cfg["out_channels"]
+        c.n_levels = len(chans)
+        for i, ch in enumerate(chans):
+            c.block_out_channels[i] = ch
+        c.layers_per_block = cfg["layers_per_block"]
+        c.num_heads = cfg["attention_head_dim"]
+        c.cross_attention_dim = cfg["cross_attention_dim"]
+        c.norm_num_groups = cfg["norm_num_groups"]
+        c.add_embed_heads = cfg["addition_embed_type_num_heads"]
+        c.norm_eps = cfg["norm_eps"]
+        self.in_channels, self.out_channels = c.in_channels, c.out_channels
+        self.cross_dim = c.cross_attention_dim
+        self.n_up = len(chans) - 1
+        self._h = C.c_void_p()
+        _lib.check(_lib.lib().dv_unet_create(C.byref(c), C.byref(self._h)), "dv_unet_create")
+        self._weight_sig = None
+        self._prepared = None
+        self.precision = None
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None) and self._h.value:
+                _lib.lib().dv_unet_destroy(self._h)
+                self._h = C.c_void_p()
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------------ weights
+    def sync_weights(self, precision=None):
+        """Hand the module's current parameters to the engine if they changed since the last
+        call (load_state_dict / .to() / in-place updates bump the version counters)."""
+        precision = precision or self.precision or default_precision()
+        if precision not in _PRECISIONS:
+            raise ValueError("precision must be one of %s" % sorted(_PRECISIONS))
+        sd = self.module.state_dict()
+        sig = tuple((k, v.data_ptr(), v._version, str(v.device)) for k, v in sd.items())
+        if sig != self._weight_sig:
+            L = _lib.lib()
+            for name, t in sd.items():
+                if not t.is_cuda:
+                    raise RuntimeError("backend='hip' needs the module on a GPU (parameter %s is on %s); "
+                                       "call .to('cuda') or construct with backend='torch'" % (name, t.device))
+                t32 = t.detach().to(torch.float32).contiguous()
+                shape = (C.c_int64 * t32.dim())(*t32.shape)
+                _lib.check(L.dv_unet_set_weight(self._h, name.encode(), _lib.ptr(t32), shape, t32.dim()),
+                           "dv_unet_set_weight(%s)" % name)
+            torch.cuda.synchronize()
+            self._weight_sig = sig
+            self._prepared = None
+        if precision != self.precision:
+            self.precision = precision
+            self._prepared = None
+
+    # ------------------------------------------------------------------ schedule
+    def prepare(self, B, T, L, force_upsample_size=None):
+        if force_upsample_size is None:
+            # reference unet_1d_condition.py:789-797: tests BOTH the channel and the frame axis
+            up = 2 ** self.n_up
+            force_upsample_size = (self.in_channels % up != 0) or (T % up != 0)
+        key = (B, T, L, self.precision, bool(force_upsample_size))
+        if key != self._prepared:
+            _lib.check(_lib.lib().dv_unet_prepare(self._h, B, T, L, _PRECISIONS[self.precision],
+                                                  int(bool(force_upsample_size))), "dv_unet_prepare")
+            self._prepared = key
+        return key
+
+    def set_cond(self, enc, bias=None):
+        """Hoisted, step-invariant conditioning: enc [B, L, D]; bias additive [B,1,L] / [B,L] or None."""
+        enc = enc.detach().to(torch.float32).contiguous()
+        if bias is not None:
+            bias = bias.detach().to(torch.float32).reshape(enc.shape[0], enc.shape[1]).contiguous()
+        self._cond_keepalive = (enc, bias)
+        _lib.check(_lib.lib().dv_unet_set_cond(self._h, _lib.ptr(enc), _lib.ptr(bias), _lib.stream_ptr()),
+                   "dv_unet_set_cond")
+
+    def eval(self, x, cond, t, out=None):
+        """One denoiser evaluation with the conditioning set by set_cond.
+        x [B, cx, T] (+ cond [B, in_channels - cx, T]) channels-first; t [B] float32."""
+        B, cx, T = x.shape
+        if out is None:
+            out = torch.empty((B, self.out_channels, T), device=x.device, dtype=torch.float32)
+        _lib.check(_lib.lib().dv_unet_forward(self._h, _lib.ptr(x), cx, _lib.ptr(cond), _lib.ptr(t), _lib.ptr(out),
+                                              _lib.stream_ptr()), "dv_unet_forward")
+        return out
+
+    # ------------------------------------------------------------------ module-level forward
+    def forward(self, sample, timesteps, enc, bias):
+        """UNet1DConditionModel.forward on GPU tensors (reference unet_1d_condition.py:743-1037)."""
+        if not sample.is_cuda:
+            raise RuntimeError("backend='hip' needs GPU tensors; got sample on %s (use backend='torch' for CPU)"
+                               % sample.device)
+        B, cin, T = sample.shape
+        if cin != self.in_channels:
+            raise RuntimeError("expected %d input channels, got %d" % (self.in_channels, cin))
+        if enc.shape[0] != B or enc.shape[2] != self.cross_dim:
+            raise RuntimeError("encoder_hidden_states must be [B=%d, L, %d], got %s" % (B, self.cross_dim, tuple(enc.shape)))
+        self.prepare(B, T, enc.shape[1])
+        self.set_cond(enc.to(sample.device), None if bias is None else bias.to(sample.device))
+        x = sample.detach().to(torch.float32).contiguous()
+        t = timesteps.detach().to(device=sample.device, dtype=torch.float32).contiguous()
+        y = self.eval(x, None, t)
+        return y if sample.dtype == torch.float32 else y.to(sample.dtype)
+
+    def stats(self):
+        n, f = C.c_int64(), C.c_double()
+        _lib.check(_lib.lib().dv_unet_stats(self._h, C.byref(n), C.byref(f)), "dv_unet_stats")
+        return n.value, f.value
+
+    def probe(self, name):
+        """Named intermediate [B, T, C] of the last forward (needs DVITS_KEEP_INTERMEDIATES=1)."""
+        dims = (C.c_int64 * 3)()
+        _lib.check(_lib.lib().dv_unet_probe(self._h, name.encode(), None, 0, dims), "dv_unet_probe")
+        out = torch.empty(tuple(dims), dtype=torch.float32)
+        _lib.check(_lib.lib().dv_unet_probe(self._h, name.encode(), C.c_void_p(out.data_ptr()), out.numel(), dims),
+                   "dv_unet_probe")
+        return out
+
+    @property
+    def handle(self):
+        return self._h

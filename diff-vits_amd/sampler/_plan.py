@@ -1,0 +1,251 @@
+"""Shared machinery of the two sampler mirrors: the compiled loop (`dv_sampler_plan`, host
+fp64 tables from libdvits_hip.so), its execution with an arbitrary Python callable (torch
+ops on whatever device the tensors live on) and its native execution (hipGraph replay of
+UNet schedule + fused update kernels) when the model is this package's UNet.
+"""
+import ctypes as C
+import importlib
+
+import numpy as np
+import torch
+
+
+def _lib():
+    return importlib.import_module("diff_vits_amd._lib")
+
+
+class NoiseScheduleBase:
+    """`NoiseScheduleVP('discrete', betas=... | alphas_cumprod=...)` (reference
+    sampler/dpm_solver.py:6-167, sampler/uni_pc.py:6-152).  Arrays are stored in float32 like
+    the reference; the look-ups interpolate them in float64 on the host."""
+
+    clip_lambda = None   # dpm_solver clips log-SNR at -5.1 (numerical_clip_alpha :114-125); uni_pc does not
+
+    def __init__(self, schedule="discrete", betas=None, alphas_cumprod=None, continuous_beta_0=0.1,
+                 continuous_beta_1=20.0, dtype=torch.float32):
+        if schedule != "discrete":
+            raise ValueError("Unsupported noise schedule {}. This build supports schedule='discrete' "
+                             "(the diffusion sampling path)".format(schedule))
+        self.schedule = schedule
+        if betas is not None:
+            b = torch.as_tensor(betas).detach().to("cpu", torch.float32)
+            log_alphas = 0.5 * torch.log(1 - b).cumsum(dim=0)
+        else:
+            assert alphas_cumprod is not None
+            ac = torch.as_tensor(alphas_cumprod).detach().to("cpu", torch.float32)
+            log_alphas = 0.5 * torch.log(ac)
+            b = 1 - torch.cat([ac[:1], ac[1:] / ac[:-1]])
+        self._betas = b.numpy().astype(np.float32)
+        if self.clip_lambda is not None:
+            log_sigmas = 0.5 * torch.log(1.0 - torch.exp(2.0 * log_alphas))
+            lambs = log_alphas - log_sigmas
+            idx = int(torch.searchsorted(torch.flip(lambs, [0]), torch.tensor(self.clip_lambda, dtype=lambs.dtype)))
+            if idx > 0:
+                log_alphas = log_alphas[:-idx]
+        self.T = 1.0
+        self.log_alpha_array = log_alphas.reshape((1, -1)).to(dtype=dtype)
+        self.total_N = self.log_alpha_array.shape[1]
+        self.t_array = torch.linspace(0.0, 1.0, self.total_N + 1)[1:].reshape((1, -1)).to(dtype=dtype)
+        self._xp = self.t_array[0].double().numpy()
+        self._yp = self.log_alpha_array[0].double().numpy()
+
+    @staticmethod
+    def _interp(x, xp, yp):
+        i = np.clip(np.searchsorted(xp, x, side="left") - 1, 0, len(xp) - 2)
+        return yp[i] + (x - xp[i]) * (yp[i + 1] - yp[i]) / (xp[i + 1] - xp[i])
+
+    def _la(self, t):
+        return self._interp(np.asarray(torch.as_tensor(t).detach().cpu().double().reshape(-1)), self._xp, self._yp)
+
+    @staticmethod
+    def _like(v, t):
+        t = torch.as_tensor(t)
+        dt = t.dtype if t.is_floating_point() else torch.float32
+        return torch.as_tensor(v, dtype=dt, device=t.device)
+
+    def marginal_log_mean_coeff(self, t):
+        return self._like(self._la(t), t)
+
+    def marginal_alpha(self, t):
+        return self._like(np.exp(self._la(t)), t)
+
+    def marginal_std(self, t):
+        return self._like(np.sqrt(1.0 - np.exp(2.0 * self._la(t))), t)
+
+    def marginal_lambda(self, t):
+        la = self._la(t)
+        return self._like(la - 0.5 * np.log(1.0 - np.exp(2.0 * la)), t)
+
+    def inverse_lambda(self, lamb):
+        lam = np.asarray(torch.as_tensor(lamb).detach().cpu().double().reshape(-1))
+        la = -0.5 * np.logaddexp(0.0, -2.0 * lam)
+        return self._like(self._interp(la, self._yp[::-1], self._xp[::-1]), lamb)
+
+
+def wrap_model(model, noise_schedule, model_type="noise", model_kwargs={}, guidance_type="uncond", condition=None,
+               unconditional_condition=None, guidance_scale=1.0, classifier_fn=None, classifier_kwargs={}):
+    """`model_wrapper(...)` (reference sampler/dpm_solver.py:170-334): returns the
+    noise-prediction function `model_fn(x, t_continuous)` the solvers take.  The closure also
+    carries the raw model and its kwargs so the solver can evaluate the x0-prediction
+    directly instead of converting x0 -> noise -> x0."""
+    if model_type not in ("noise", "x_start", "v", "score"):
+        raise AssertionError("model_type must be one of noise / x_start / v / score")
+    if guidance_type != "uncond":
+        raise ValueError("guidance_type=%r is not supported on this path (the reference call sites use 'uncond')"
+                         % (guidance_type,))
+    ns = noise_schedule
+
+    def expand(v, x):
+        return v.reshape((-1,) + (1,) * (x.dim() - 1))
+
+    def t_input(t_continuous):
+        return (t_continuous - 1.0 / ns.total_N) * ns.total_N
+
+    def model_fn(x, t_continuous):
+        out = model(x, t_input(t_continuous), **model_kwargs)
+        if model_type == "noise":
+            return out
+        alpha_t = ns.marginal_alpha(t_continuous).to(x)
+        sigma_t = ns.marginal_std(t_continuous).to(x)
+        if model_type == "x_start":
+            return (x - expand(alpha_t, x) * out) / expand(sigma_t, x)
+        if model_type == "v":
+            return expand(alpha_t, x) * out + expand(sigma_t, x) * x
+        return -expand(sigma_t, x) * out
+
+    model_fn._dv = dict(model=model, model_type=model_type, model_kwargs=model_kwargs, noise_schedule=ns)
+    return model_fn
+
+
+class Plan:
+    """Compiled multistep loop: events + fp64-derived coefficient rows."""
+
+    def __init__(self, solver, betas, steps, order, skip_type, lower_order_final):
+        L = _lib()
+        if skip_type not in L.SKIP:
+            raise ValueError("Unsupported skip_type {}, need to be 'logSNR' or 'time_uniform' or 'time_quadratic'"
+                             .format(skip_type))
+        betas = np.ascontiguousarray(betas, dtype=np.float32)
+        self._h = C.c_void_p()
+        L.check(L.lib().dv_sampler_plan(solver, betas.ctypes.data_as(C.c_void_p), len(betas), steps, order,
+                                        L.SKIP[skip_type], int(bool(lower_order_final)), C.byref(self._h)),
+                "dv_sampler_plan")
+        nfe = C.c_int32()
+        L.check(L.lib().dv_plan_info(self._h, C.byref(nfe), None, None), "dv_plan_info")
+        self.nfe = nfe.value
+        self.t_input = np.zeros(self.nfe, dtype=np.float64)
+        self.timesteps = np.zeros(steps + 1, dtype=np.float64)
+        L.check(L.lib().dv_plan_info(self._h, None, self.t_input.ctypes.data_as(C.c_void_p),
+                                     self.timesteps.ctypes.data_as(C.c_void_p)), "dv_plan_info")
+        n = C.c_int32()
+        L.check(L.lib().dv_plan_coefs(self._h, C.byref(n), None), "dv_plan_coefs")
+        self.coefs = np.zeros((n.value, 8), dtype=np.float32)
+        L.check(L.lib().dv_plan_coefs(self._h, None, self.coefs.ctypes.data_as(C.c_void_p)), "dv_plan_coefs")
+        ne, ns = C.c_int32(), C.c_int32()
+        L.check(L.lib().dv_plan_events(self._h, C.byref(ne), None, C.byref(ns)), "dv_plan_events")
+        self.events = np.zeros((ne.value, 9), dtype=np.int32)
+        self.n_slots = ns.value
+        L.check(L.lib().dv_plan_events(self._h, None, self.events.ctypes.data_as(C.c_void_p), None), "dv_plan_events")
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None) and self._h.value:
+                _lib().lib().dv_plan_destroy(self._h)
+                self._h = C.c_void_p()
+        except Exception:
+            pass
+
+    @property
+    def handle(self):
+        return self._h
+
+    def run_python(self, x, data_model):
+        """Execute the loop with torch ops; `data_model(x, eval_idx)` returns the x0 prediction."""
+        hist = [None] * self.n_slots
+        xp = None
+        for typ, src, eidx, dst, coef, s0, s1, s2, s3 in self.events.tolist():
+            if typ == 0:
+                hist[dst] = data_model(x if src == 0 else xp, eidx)
+            else:
+                c = self.coefs[coef]
+                out = float(c[0]) * x
+                for k, s in enumerate((s0, s1, s2, s3)):
+                    if s >= 0:
+                        out = out + float(c[1 + k]) * hist[s]
+                if dst == 0:
+                    x = out
+                else:
+                    xp = out
+        return x
+
+
+class NativeUNetModel:
+    """Opt-in marker for the fully native loop: pass an instance as `model` to `model_wrapper`
+    (model_type='x_start').  It is also a plain callable `(x, t_input) -> x0`, so every other
+    solver path keeps working.  Holds this package's UNet (backend='hip'), the channel-concat
+    condition `cond` [B, in-out, T] and the cross-attention inputs."""
+
+    def __init__(self, unet, cond, encoder_hidden_states, encoder_attention_mask=None):
+        self.unet, self.cond, self.enc, self.mask = unet, cond, encoder_hidden_states, encoder_attention_mask
+
+    def __call__(self, x, t_input, **kwargs):
+        sample = x if self.cond is None else torch.cat([x, self.cond], dim=1)
+        return self.unet(sample, t_input, self.enc, encoder_attention_mask=self.mask).sample
+
+    def run_plan(self, plan, x):
+        """hipGraph replay of the whole loop (dv_sampler_run).  Returns a new tensor."""
+        L = _lib()
+        eng = self.unet.hip_engine()
+        B, C_, T = x.shape
+        eng.prepare(B, T, self.enc.shape[1])
+        bias = self.unet._bias_from_mask(self.mask, torch.float32)
+        eng.set_cond(self.enc, bias)
+        key = (x.shape, x.device)
+        if getattr(self, "_xbuf_key", None) != key:
+            self._xbuf = torch.empty(x.shape, device=x.device, dtype=torch.float32)
+            self._xbuf_key = key
+        self._xbuf.copy_(x)
+        cond = None if self.cond is None else self.cond.detach().to(torch.float32).contiguous()
+        self._cond_keepalive = cond
+        L.check(L.lib().dv_sampler_run(plan.handle, eng.handle, L.ptr(self._xbuf), L.ptr(cond), L.stream_ptr()),
+                "dv_sampler_run")
+        return self._xbuf.clone()
+
+
+def sample_with_plan(plan, model_fn, noise_schedule, x):
+    """Run a compiled loop for a solver-level `model_fn` (noise prediction, as returned by
+    model_wrapper or supplied by the user)."""
+    info = getattr(model_fn, "_dv", None)
+    ns = noise_schedule
+    B = x.shape[0]
+    with torch.no_grad():
+        if info is not None and info["model_type"] == "x_start":
+            raw = info["model"]
+            if isinstance(raw, NativeUNetModel) and x.is_cuda and raw.unet.backend == "hip" and not info["model_kwargs"]:
+                return raw.run_plan(plan, x)
+            kwargs = info["model_kwargs"]
+
+            def data_model(xx, eidx):
+                t_in = torch.full((B,), float(plan.t_input[eidx]), device=xx.device, dtype=torch.float32)
+                return raw(xx, t_in, **kwargs)
+        else:
+            # arbitrary noise-prediction callable: x0 = (x - sigma_t * eps) / alpha_t
+            # (reference data_prediction_fn, dpm_solver.py:433-442)
+            eval_t = _eval_times(plan)
+
+            def data_model(xx, eidx):
+                t = torch.full((B,), float(eval_t[eidx]), device=xx.device, dtype=torch.float32)
+                noise = model_fn(xx, t)
+                a = float(ns.marginal_alpha(torch.tensor([eval_t[eidx]], dtype=torch.float64))[0])
+                s = float(ns.marginal_std(torch.tensor([eval_t[eidx]], dtype=torch.float64))[0])
+                return (xx - s * noise) / a
+        return plan.run_python(x, data_model)
+
+
+def _eval_times(plan):
+    """Continuous time of each model evaluation (inverse of t_input = (t - 1/N) * N is not
+    needed: evaluations happen at the grid points in order; UniPC evaluates at the step's
+    end time, DPM-Solver++ at the step's start)."""
+    # EVAL k of both loops is at timesteps[k] (k-th grid point): DPM++ evaluates at ts[0..N-1],
+    # UniPC at ts[0] and then at ts[1..N-1] (the corrector's evaluation point).
+    return plan.timesteps[: plan.nfe]

@@ -1,0 +1,59 @@
+"""UniPC mirror of the reference `sampler/uni_pc.py` (public symbols `NoiseScheduleVP`,
+`model_wrapper`, `UniPC`; reference model3.py:1162 imports exactly these).
+
+Same execution model as `dpm_solver.py` in this package: the multistep B(h) predictor-corrector
+loop (reference uni_pc.py:471-588, 590-672) is compiled on the host into linear-combination
+coefficients and replayed natively or around a Python callable.  Unlike the reference's
+'x_start' wrapper (uni_pc.py:189-191, which only broadcasts correctly at B == 1) the batch
+broadcast here is the intended per-sample one; at B == 1 both coincide.
+"""
+from ._plan import NativeUNetModel, NoiseScheduleBase, Plan, sample_with_plan, wrap_model
+
+__all__ = ["NoiseScheduleVP", "model_wrapper", "UniPC", "NativeUNetModel"]
+
+_SOLVERS = {"bh1": 1, "bh2": 2}
+
+
+class NoiseScheduleVP(NoiseScheduleBase):
+    """Discrete VP schedule without log-SNR clipping (reference uni_pc.py:6-152)."""
+    clip_lambda = None
+
+
+model_wrapper = wrap_model
+
+
+class UniPC:
+    def __init__(self, model_fn, noise_schedule, algorithm_type="data_prediction", correcting_x0_fn=None,
+                 correcting_xt_fn=None, thresholding_max_val=1.0, dynamic_thresholding_ratio=0.995, variant="bh1"):
+        assert algorithm_type in ["data_prediction", "noise_prediction"]
+        if algorithm_type != "data_prediction":
+            raise ValueError("algorithm_type='noise_prediction' is outside this build's scope")
+        if correcting_x0_fn is not None or correcting_xt_fn is not None:
+            raise ValueError("correcting_x0_fn / correcting_xt_fn are not supported on this path")
+        if variant not in _SOLVERS:
+            raise NotImplementedError("variant %r (supported: 'bh1', 'bh2')" % (variant,))
+        self.model_fn = model_fn
+        self.noise_schedule = noise_schedule
+        self.variant = variant
+        self.predict_x0 = True
+        self._plans = {}
+
+    def _plan(self, steps, order, skip_type, lower_order_final):
+        key = (steps, order, skip_type, bool(lower_order_final))
+        if key not in self._plans:
+            self._plans[key] = Plan(_SOLVERS[self.variant], self.noise_schedule._betas, steps, order, skip_type,
+                                    lower_order_final)
+        return self._plans[key]
+
+    def sample(self, x, steps=20, t_start=None, t_end=None, order=2, skip_type="time_uniform", method="multistep",
+               lower_order_final=True, denoise_to_zero=False, atol=0.0078, rtol=0.05, return_intermediate=False):
+        """x_T -> x_0 (reference uni_pc.py:590-672).  NFE == steps."""
+        if method != "multistep":
+            raise ValueError("Got wrong method {}".format(method))
+        if order not in (1, 2, 3):
+            raise ValueError("UniPC order must be 1, 2 or 3 in this build, got {}".format(order))
+        if denoise_to_zero or return_intermediate or t_start is not None or t_end is not None:
+            raise ValueError("denoise_to_zero, return_intermediate and custom t_start/t_end are not supported")
+        assert steps >= order
+        plan = self._plan(steps, order, skip_type, lower_order_final)
+        return sample_with_plan(plan, self.model_fn, self.noise_schedule, x)

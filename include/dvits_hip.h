@@ -1,0 +1,172 @@
+/*
+ * dvits_hip.h — C ABI of libdvits_hip.so, the MI355X (gfx950) engine under the
+ * diff-vits diffusion-sampling path.
+ *
+ * The reference (adelacvg/diff-vits) has no FFI layer: its boundary for this path is
+ * the Python surface
+ *     unet1d/unet_1d_condition.py:743-1037   UNet1DConditionModel.forward
+ *     sampler/dpm_solver.py:1047-1245         DPM_Solver.sample  (multistep, dpmsolver++)
+ *     sampler/uni_pc.py:590-672               UniPC.sample       (multistep, bh1/bh2)
+ * The Python mirror classes in diff-vits_amd/{unet1d,sampler}/ keep that surface and
+ * bind the entry points below through ctypes (diff-vits_amd/_lib.py); INTEGRATION.md
+ * shows the stub.  Plain pointers and sizes only: no torch types cross this boundary.
+ *
+ * Conventions
+ *   - every function returns 0 on success, a negative dv_status otherwise;
+ *     dv_last_error() returns a thread-local message for the last failure.
+ *   - all tensor pointers are DEVICE pointers to contiguous float32 unless noted.
+ *     The caller owns inputs/outputs; the library owns packed weights and workspace.
+ *   - `stream` is a hipStream_t passed as void* (NULL = the default stream).  Work is
+ *     enqueued asynchronously on it; nothing here synchronises the device except
+ *     dv_unet_prepare / dv_*_destroy / dv_sampler_graph_build.
+ *   - handles are not thread-safe; distinct handles are independent.
+ */
+#ifndef DVITS_HIP_H
+#define DVITS_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+  DV_OK = 0,
+  DV_ERR_INVALID = -1,      /* bad argument / unsupported configuration */
+  DV_ERR_HIP = -2,          /* a HIP runtime call failed */
+  DV_ERR_STATE = -3,        /* call order violated (e.g. forward before prepare) */
+  DV_ERR_MISSING_WEIGHT = -4
+} dv_status;
+
+/* Contraction precision (SURVEY.md §7 "Accuracy vs bf16"):
+ *   DV_PREC_BF16X3: split-bf16, 3 MFMA products per tile, fp32 accumulate — the parity mode
+ *   DV_PREC_BF16  : single bf16 product — fast mode, ~7e-3 rel. error, reported separately */
+typedef enum { DV_PREC_BF16X3 = 0, DV_PREC_BF16 = 1 } dv_precision;
+
+/* Constructor keywords of UNet1DConditionModel that shape the network
+ * (reference unet_1d_condition.py:151-203; diffusion values model3.py:887-896). */
+typedef struct {
+  int32_t in_channels;            /* C + cond channels, e.g. 208 */
+  int32_t out_channels;           /* C, e.g. 80 */
+  int32_t n_levels;               /* len(block_out_channels), 2..6 */
+  int32_t block_out_channels[6];
+  int32_t layers_per_block;       /* 2 */
+  int32_t num_heads;              /* `attention_head_dim` keyword (= head count) */
+  int32_t cross_attention_dim;    /* encoder_hidden_states feature dim */
+  int32_t norm_num_groups;        /* 8 */
+  int32_t add_embed_heads;        /* addition_embed_type_num_heads, 64 */
+  float   norm_eps;               /* 1e-5 */
+} dv_unet_cfg;
+
+typedef struct dv_unet dv_unet;
+typedef struct dv_plan dv_plan;
+
+const char* dv_last_error(void);
+/* Library/version probe: returns e.g. "dvits_hip 0.1 gfx950". */
+const char* dv_version(void);
+
+/* ---- denoiser: UNet1DConditionModel ------------------------------------------------ */
+
+/* Replaces UNet1DConditionModel.__init__ (unet_1d_condition.py:151-607). */
+int dv_unet_create(const dv_unet_cfg* cfg, dv_unet** out);
+void dv_unet_destroy(dv_unet* u);
+
+/* Hand over one state-dict tensor under its reference name, e.g.
+ * "down_blocks.1.attentions.0.transformer_blocks.0.attn2.to_k.weight"
+ * (replaces load_state_dict, tts_infer.py:75-81).  `dev_ptr` is float32, contiguous,
+ * shape[ndim]; the data is copied (the caller keeps ownership). */
+int dv_unet_set_weight(dv_unet* u, const char* name, const void* dev_ptr, const int64_t* shape, int32_t ndim);
+
+/* Pack weights for `precision`, build the kernel schedule for (B, T, L) and allocate the
+ * workspace arena.  Must be called after all weights are set and again whenever B/T/L,
+ * the precision or the weights change.  `force_upsample_size` = the reference's
+ * forward_upsample_size flag (unet_1d_condition.py:789-797), computed by the caller from
+ * the shape of `sample`. */
+int dv_unet_prepare(dv_unet* u, int32_t B, int32_t T, int32_t L, int32_t precision, int32_t force_upsample_size);
+
+/* Step-invariant conditioning (hoisted out of the sampler loop): pooled-text embedding
+ * add_embedding(enc) (unet_1d_condition.py:869-870), the 16 cross-attention K/V
+ * projections (attention_processor.py:1016-1017) and the additive mask bias (:816-818).
+ * enc: [B, L, cross_attention_dim]; mask_bias: [B, L] additive (0 / -10000) or NULL. */
+int dv_unet_set_cond(dv_unet* u, const float* enc, const float* mask_bias, void* stream);
+
+/* One denoiser evaluation = UNet1DConditionModel.forward (unet_1d_condition.py:743-1037).
+ *   x    : [B, cx, T]            first cx input channels (channels-first, as the reference)
+ *   cond : [B, in_channels-cx, T] remaining input channels, or NULL when cx == in_channels
+ *   t    : [B] float32 timesteps (fractional allowed)
+ *   y    : [B, out_channels, T]  output
+ * Passing x and cond separately avoids materialising torch.cat([x, cond]) (model3.py:908). */
+int dv_unet_forward(dv_unet* u, const float* x, int32_t cx, const float* cond, const float* t, float* y,
+                    void* stream);
+
+/* Number of kernel launches one forward enqueues, and algorithmic FLOPs (2*MAC of all
+ * contractions) of one forward at the prepared shape — for the roofline report. */
+int dv_unet_stats(dv_unet* u, int64_t* n_launch, double* flops);
+
+/* Debug/parity probe: copy a named intermediate activation (channels-last [B, T, C]) of the
+ * last forward to the host.  Available only when dv_unet_prepare ran with the environment
+ * variable DVITS_KEEP_INTERMEDIATES=1 (buffers are then never reused).  dims[3] = {B, T, C};
+ * host_out may be NULL to query dims.  Names follow the reference module paths, e.g.
+ * "conv_in", "emb", "down_blocks.0.resnets.0", "down_blocks.0.attentions.0",
+ * "mid_block.resnets.1", "up_blocks.1.upsamplers.0". */
+int dv_unet_probe(dv_unet* u, const char* name, float* host_out, int64_t capacity, int64_t* dims);
+
+/* ---- sampler: DPM-Solver++ / UniPC multistep loops --------------------------------- */
+
+typedef enum { DV_SOLVER_DPMPP = 0, DV_SOLVER_UNIPC_BH1 = 1, DV_SOLVER_UNIPC_BH2 = 2 } dv_solver;
+typedef enum { DV_SKIP_TIME_UNIFORM = 0, DV_SKIP_TIME_QUADRATIC = 1, DV_SKIP_LOGSNR = 2 } dv_skip;
+
+/* Host fp64 precompute of every schedule scalar of the loop
+ * (NoiseScheduleVP + get_time_steps + the multistep coefficient algebra:
+ * dpm_solver.py:6-167, 453-480, 547-592, 796-904; uni_pc.py:471-588).
+ * betas: HOST float32[n_betas] (the reference's `self.betas`, model3.py:990). */
+int dv_sampler_plan(int32_t solver, const float* betas, int32_t n_betas, int32_t steps, int32_t order,
+                    int32_t skip_type, int32_t lower_order_final, dv_plan** out);
+void dv_plan_destroy(dv_plan* p);
+
+/* Introspection for tests: number of model evaluations, and the plan's tables.
+ * t_input[nfe] = timestep fed to the network at each evaluation;
+ * timesteps[steps+1] = continuous-time grid. */
+int dv_plan_info(const dv_plan* p, int32_t* nfe, double* t_input, double* timesteps);
+
+/* The compiled loop, for host-side execution with an arbitrary Python callable and for tests:
+ * coefficient rows (8 floats each: c0 for x, c1..c4 for the history terms) and events
+ * (9 int32 each: type 0=EVAL/1=COMB, src 0=x/1=x_pred, eval_idx, dst (EVAL: history slot;
+ * COMB: 0=x/1=x_pred), coef row, slot0..slot3 (-1 = unused)).  *n_slots = number of
+ * history buffers the loop needs. */
+int dv_plan_coefs(const dv_plan* p, int32_t* n_rows, float* rows8);
+int dv_plan_events(const dv_plan* p, int32_t* n_events, int32_t* ev9, int32_t* n_slots);
+
+/* Run the whole loop: x_inout [B, C, T] is x_T on entry and x_0 on exit; cond
+ * [B, in_channels-C, T] is the channel-concat condition.  dv_unet_set_cond must have been
+ * called.  The first call for a given (plan, unet shape) captures the loop into a
+ * hipGraph; later calls replay it. */
+int dv_sampler_run(dv_plan* p, dv_unet* u, float* x_inout, const float* cond, void* stream);
+
+/* Same loop with a caller-supplied model instead of the UNet, for sampler known-answer
+ * tests: model(user, x_dev, t_input_host, out_dev) must enqueue out = f(x, t) on `stream`. */
+typedef int (*dv_model_fn)(void* user, const float* x, double t_input, float* out, void* stream);
+int dv_sampler_run_custom(dv_plan* p, dv_model_fn fn, void* user, float* x_inout, int64_t numel, void* stream);
+
+/* ---- single-operator entry points (parity tests of each kernel through the C ABI) ---- */
+
+/* y[B,Cout,T_out] = conv1d(act(x)) on channels-first tensors, through the implicit-GEMM
+ * kernel: k = 1 or 3, stride 1/2, padding (k-1)/2, optional nearest upsample to `up_T`
+ * frames first (0 = none).  w: [Cout, Cin, k] float32, bias [Cout] or NULL. */
+int dv_op_conv1d(const float* x, const float* w, const float* bias, float* y, int32_t B, int32_t Cin, int32_t T,
+                 int32_t Cout, int32_t k, int32_t stride, int32_t up_T, int32_t precision, void* stream);
+/* y[M,N] = x[M,K] @ w[N,K]^T + bias */
+int dv_op_linear(const float* x, const float* w, const float* bias, float* y, int32_t M, int32_t K, int32_t N,
+                 int32_t precision, void* stream);
+/* GroupNorm statistics over a channels-last tensor x[B*T, C]: mean/rstd [B, groups]. */
+int dv_op_group_stats(const float* x, float* mean, float* rstd, int32_t B, int32_t T, int32_t C, int32_t groups,
+                      float eps, void* stream);
+/* softmax(q k^T * d^-0.5 + bias) v on [B, T, H*d] tensors (heads interleaved on the last
+ * axis as the reference's .view(B,-1,H,d)); bias [B, Tk] additive or NULL. */
+int dv_op_attention(const float* q, const float* k, const float* v, const float* bias, float* o, int32_t B,
+                    int32_t H, int32_t Tq, int32_t Tk, int32_t d, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DVITS_HIP_H */

@@ -1,0 +1,111 @@
+"""GPU parity of each HIP kernel through the C ABI (dv_op_*), against plain fp32 torch-CPU ops
+on the same seeded inputs.  Tolerances: bf16x3 contractions 1e-4 relative L2 (measured ~1e-5,
+SURVEY.md §7); fp32-MFMA attention and statistics 1e-5."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import rel_l2
+
+pytestmark = pytest.mark.gpu
+
+
+def _lib():
+    from diff_vits_amd import _lib as L
+    return L
+
+
+def _dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def _synth(name, shape, scale=1.0):
+    from diff_vits_amd import synth
+    return synth.normal(99, name, shape) * np.float32(scale)
+
+
+@pytest.mark.parametrize("B,Cin,T,Cout,k,stride,up_T", [
+    (2, 64, 50, 96, 3, 1, 0),        # plain k3, ragged M
+    (1, 208, 256, 128, 3, 1, 0),     # conv_in shape: Cin padded 208 -> 224
+    (2, 128, 64, 128, 1, 1, 0),      # 1x1
+    (2, 96, 37, 96, 3, 2, 0),        # stride-2 downsample, odd T
+    (2, 64, 19, 64, 3, 1, 37),       # nearest upsample to explicit size, then k3
+    (2, 64, 20, 64, 3, 1, 40),       # x2 upsample
+    (8, 128, 1024, 128, 3, 1, 0),    # BASELINE config-2 level-0 shape (128x128 tiles)
+    (1, 512, 16, 80, 3, 1, 0),       # N not a multiple of the tile (conv_out-like)
+])
+@pytest.mark.parametrize("prec", [0, 1])
+def test_conv1d(B, Cin, T, Cout, k, stride, up_T, prec):
+    L = _lib()
+    x = _synth("x", (B, Cin, T))
+    w = _synth("w", (Cout, Cin, k), 1.0 / np.sqrt(Cin * k))
+    b = _synth("b", (Cout,), 0.1)
+    xt = torch.from_numpy(x)
+    if up_T:
+        xt = F.interpolate(xt, size=up_T, mode="nearest")
+    ref = F.conv1d(xt, torch.from_numpy(w), torch.from_numpy(b), stride=stride, padding=(k - 1) // 2)
+    y = torch.empty(ref.shape, device="cuda")
+    dx, dw, db = _dev(x), _dev(w), _dev(b)      # keep the device tensors alive across the call
+    L.check(L.lib().dv_op_conv1d(L.ptr(dx), L.ptr(dw), L.ptr(db), L.ptr(y), B, Cin, T, Cout, k, stride,
+                                 up_T, prec, None), "dv_op_conv1d")
+    torch.cuda.synchronize()
+    err = rel_l2(y.cpu().numpy(), ref.numpy())
+    assert err < (1e-4 if prec == 0 else 2e-2), err
+
+
+@pytest.mark.parametrize("M,K,N", [(100, 128, 384), (8192, 128, 1024), (1024, 2048, 512), (33, 32, 17)])
+def test_linear(M, K, N):
+    L = _lib()
+    x, w, b = _synth("x", (M, K)), _synth("w", (N, K), 1 / np.sqrt(K)), _synth("b", (N,), 0.1)
+    ref = F.linear(torch.from_numpy(x), torch.from_numpy(w), torch.from_numpy(b))
+    y = torch.empty((M, N), device="cuda")
+    dx, dw, db = _dev(x), _dev(w), _dev(b)
+    L.check(L.lib().dv_op_linear(L.ptr(dx), L.ptr(dw), L.ptr(db), L.ptr(y), M, K, N, 0, None), "dv_op_linear")
+    torch.cuda.synchronize()
+    assert rel_l2(y.cpu().numpy(), ref.numpy()) < 1e-4
+
+
+@pytest.mark.parametrize("B,T,C,G", [(2, 40, 32, 8), (8, 1024, 128, 8), (2, 100, 896, 8), (3, 7, 1024, 8), (2, 300, 96, 8)])
+def test_group_stats(B, T, C, G):
+    L = _lib()
+    x = _synth("x", (B, T, C)) + np.float32(0.7)
+    mean = torch.empty((B, G), device="cuda")
+    rstd = torch.empty((B, G), device="cuda")
+    dx = _dev(x)
+    L.check(L.lib().dv_op_group_stats(L.ptr(dx), L.ptr(mean), L.ptr(rstd), B, T, C, G, 1e-5, None), "dv_op_group_stats")
+    torch.cuda.synchronize()
+    xg = x.astype(np.float64).reshape(B, T, G, C // G)
+    m = xg.mean(axis=(1, 3))
+    v = xg.var(axis=(1, 3))
+    assert np.abs(mean.cpu().numpy() - m).max() < 1e-5
+    assert rel_l2(rstd.cpu().numpy(), 1 / np.sqrt(v + 1e-5)) < 1e-5
+
+
+@pytest.mark.parametrize("B,H,Tq,Tk,d,masked", [
+    (2, 8, 40, 40, 4, False), (2, 8, 100, 50, 16, True), (1, 8, 1024, 1024, 16, False), (2, 8, 512, 256, 32, True),
+    (2, 8, 256, 256, 48, False), (2, 8, 128, 256, 64, True), (2, 8, 37, 60, 8, True), (1, 8, 64, 33, 12, False),
+])
+def test_attention(B, H, Tq, Tk, d, masked):
+    L = _lib()
+    q, k, v = _synth("q", (B, Tq, H * d)), _synth("k", (B, Tk, H * d)), _synth("v", (B, Tk, H * d))
+    bias = None
+    if masked:
+        bias = np.zeros((B, Tk), dtype=np.float32)
+        for b in range(B):
+            bias[b, max(1, Tk - 7 * (b + 1)):] = -10000.0
+    tq = torch.from_numpy(q).view(B, Tq, H, d).transpose(1, 2)
+    tk = torch.from_numpy(k).view(B, Tk, H, d).transpose(1, 2)
+    tv = torch.from_numpy(v).view(B, Tk, H, d).transpose(1, 2)
+    am = None if bias is None else torch.from_numpy(bias)[:, None, None, :].expand(B, H, 1, Tk)
+    ref = F.scaled_dot_product_attention(tq.double(), tk.double(), tv.double(),
+                                         attn_mask=None if am is None else am.double()).transpose(1, 2).reshape(B, Tq, H * d)
+    o = torch.empty((B, Tq, H * d), device="cuda")
+    dq, dk, dv = _dev(q), _dev(k), _dev(v)
+    dbias = None if bias is None else _dev(bias)
+    L.check(L.lib().dv_op_attention(L.ptr(dq), L.ptr(dk), L.ptr(dv), L.ptr(dbias), L.ptr(o), B, H, Tq, Tk, d, None),
+            "dv_op_attention")
+    torch.cuda.synchronize()
+    assert rel_l2(o.cpu().numpy(), ref.numpy()) < 1e-5
