@@ -1,0 +1,203 @@
+#!/usr/bin/env python3
+"""Headline benchmark: mel-frames/sec of the 50-step DPM-Solver++(2M) sampler on synthetic
+(B=8 per GPU, C=80, T=1024, L=256) — BASELINE.json configs[1] — on N MI355X GPUs of one node.
+
+A "step" is one complete sampler run (50 denoiser evaluations + 50 fused updates) over one
+batch per GPU.  One JSON line is printed by rank 0 (contract in the task description), with
+`roofline` (dominant kernel = the implicit-GEMM family, timed live with HIP events) and
+`cpu_baseline` (the oracle restatement timed on the host cores; bounded sample).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+import diff_vits_amd  # noqa: E402,F401
+from diff_vits_amd import shard, synth  # noqa: E402
+from diff_vits_amd.sampler import dpm_solver  # noqa: E402
+from diff_vits_amd.unet1d.unet_1d_condition import UNet1DConditionModel  # noqa: E402
+
+UNET_KW = dict(in_channels=208, out_channels=80, block_out_channels=(128, 256, 384, 512), norm_num_groups=8,
+               cross_attention_dim=128, attention_head_dim=8, addition_embed_type="text",
+               resnet_time_scale_shift="scale_shift")
+PEAK_TFLOPS = {"bf16x3": 2500.0 / 3.0, "bf16": 2500.0}     # dense bf16 MFMA peak (MI355X_MICROARCH.md); x3 = 3 products
+
+
+def flops_model(B, T, L):
+    """Algorithmic FLOPs of one denoiser forward, closed form fitted in SURVEY.md §8(d)."""
+    return B * (31.67e6 * T + 4349.0 * T * T + 7286.0 * T * L + 2.23e6 * L + 0.04e9)
+
+
+def build_model(device, precision):
+    with torch.device("meta"):
+        shapes = {k: tuple(v.shape) for k, v in UNet1DConditionModel(**UNET_KW).state_dict().items()}
+    sd = {k: torch.from_numpy(v) for k, v in synth.make_state_dict(shapes, seed=1234).items()}
+    m = UNet1DConditionModel(backend="hip", **UNET_KW).eval()
+    m.load_state_dict(sd)
+    m = m.to(device)
+    m.hip_engine(precision)
+    return m, sd
+
+
+def cpu_baseline(sd, B, T, L, solver_steps, sample_steps=4):
+    """Oracle (CPU restatement of the reference, oracle/) on the host cores: `sample_steps` of the
+    `solver_steps` DPM-Solver++ steps at the bench shape, scaled linearly (NFE == steps)."""
+    from oracle import sampler_ref, unet_ref
+    cfg = unet_ref.default_config()
+    x, cond, enc, mask = map(torch.from_numpy, synth.make_inputs(B, 80, T, L, seed=1234))
+    betas = torch.from_numpy(synth.make_betas())
+    model = unet_ref.diffusion_model_fn(sd, cfg, cond, enc, mask)
+    with torch.no_grad():
+        model(x, torch.full((B,), 500.0))                       # warm-up (allocator, oneDNN primitives)
+        t0 = time.perf_counter()
+        sampler_ref.dpm_solver_pp_sample(model, betas, x, sample_steps, 2)
+        dt = time.perf_counter() - t0
+    full = dt * solver_steps / sample_steps
+    return {"value": B * T / full, "unit": "mel-frames/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": "%d of %d DPM-Solver++ steps at B=%d,T=%d,L=%d on torch-CPU fp32 (%.1f s), scaled x%.1f"
+                      % (sample_steps, solver_steps, B, T, L, dt, solver_steps / sample_steps),
+            "seconds_sampled": dt}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3, help="timed sampler runs")
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batch", type=int, default=8, help="utterances per GPU")
+    ap.add_argument("--frames", type=int, default=1024)
+    ap.add_argument("--prompt", type=int, default=256)
+    ap.add_argument("--solver-steps", type=int, default=50)
+    ap.add_argument("--precision", default=os.environ.get("DVITS_PRECISION", "bf16x3"), choices=["bf16x3", "bf16"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (args.gpus, world))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    B, T, L, S = args.batch, args.frames, args.prompt, args.solver_steps
+    model, sd = build_model(dev, args.precision)
+
+    # synthetic inputs: this rank's noise/content shard is generated locally (zero traffic); the
+    # conditioning of the whole job lives on rank 0 and is broadcast over RCCL before every run
+    x_np, cond_np, _, _ = synth.make_inputs(B, 80, T, L, seed=1234 + rank)
+    x_T = torch.from_numpy(x_np).to(dev)
+    cond = torch.from_numpy(cond_np).to(dev)
+    G = world * B
+    if rank == 0:
+        enc_all = np.concatenate([synth.make_inputs(B, 80, 8, L, seed=1234 + r)[2] for r in range(world)])
+        enc_g = torch.from_numpy(enc_all).to(dev)
+    else:
+        enc_g = torch.empty((G, L, 128), device=dev)
+    mask_g = torch.ones((G, L), dtype=torch.bool, device=dev)
+
+    ns = dpm_solver.NoiseScheduleVP("discrete", betas=torch.from_numpy(synth.make_betas()))
+    state = {}
+
+    def run_local(x, c, enc, mask):
+        native = state.get("native")
+        if native is None:
+            native = state["native"] = dpm_solver.NativeUNetModel(model, c, enc, mask)
+            fn = dpm_solver.model_wrapper(native, ns, model_type="x_start")
+            state["solver"] = dpm_solver.DPM_Solver(fn, ns, algorithm_type="dpmsolver++")
+        native.cond, native.enc, native.mask = c, enc, mask
+        return state["solver"].sample(x, steps=S, order=2, skip_type="time_uniform", method="multistep")
+
+    def one_run():
+        return shard.sharded_sample(run_local, x_T, cond, enc_g, mask_g)
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    with torch.no_grad():
+        for _ in range(args.warmup):
+            out = one_run()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            out = one_run()
+        barrier()
+        dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
+        dt = float(tt.item())
+    assert torch.isfinite(out).all()
+
+    if rank != 0:
+        if world > 1:
+            torch.distributed.destroy_process_group()
+        return
+
+    frames_per_s = G * T * args.steps / dt
+    result = {
+        "metric": "mel_frames_per_sec_50step_dpmsolver", "value": frames_per_s, "unit": "mel-frames/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "%s (bf16 MFMA operands%s, fp32 accumulate / fp32 activations)" % (
+            args.precision, " split hi+lo, 3 products" if args.precision == "bf16x3" else ""),
+        "data": "synthetic",
+        "config": {"workload": "B=%d/GPU, C=80, T=%d, L=%d, %d-step DPM-Solver++(2M) multistep, UNet1DConditionModel "
+                               "(128,256,384,512), seeded random-init weights" % (B, T, L, S),
+                   "global_batch": G, "parallelism": "dp%d (batch-sharded, RCCL broadcast of conditioning + all-gather of mels)" % world},
+    }
+
+    # ---- roofline of the dominant kernel family (implicit GEMM), timed live with HIP events ----
+    if not args.no_roofline:
+        eng = model.hip_engine()
+        t_dev = torch.full((B,), 500.0, device=dev)
+        reps = 5
+        agg = {}
+        with torch.no_grad():
+            eng.profile_forward(x_T, cond, t_dev)                # warm
+            for _ in range(reps):
+                for kind, fl, ms in eng.profile_forward(x_T, cond, t_dev):
+                    a = agg.setdefault(kind, [0, 0.0, 0.0])
+                    a[0] += 1
+                    a[1] += fl
+                    a[2] += ms
+        n_launch, flops_fwd = eng.stats()
+        g = agg["gemm"]
+        peak = PEAK_TFLOPS[args.precision]
+        achieved = g[1] / (g[2] * 1e-3) / 1e12
+        fwd_ms = 1e3 * dt / args.steps / S
+        result["roofline"] = {
+            "bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
+            "traffic": None,
+            "kernel": "k_gemm<*> (implicit-GEMM conv1d/linear, all tile instantiations)",
+            "flops_per_launch": g[1] / g[0], "avg_launch_us": 1e3 * g[2] / g[0], "launches_per_forward": g[0] // reps,
+            "per_kind_ms_per_forward": {k: v[2] / reps for k, v in agg.items()},
+            "per_kind_launches": {k: v[0] // reps for k, v in agg.items()},
+            "forward": {"launches": n_launch, "algorithmic_gflop": flops_model(B, T, L) / 1e9,
+                        "engine_counted_gflop": flops_fwd / 1e9, "ms_in_graph": fwd_ms,
+                        "tflops": flops_model(B, T, L) / (fwd_ms * 1e-3) / 1e12,
+                        "frac_of_peak": flops_model(B, T, L) / (fwd_ms * 1e-3) / 1e12 / peak},
+        }
+    if not args.no_cpu_baseline:
+        result["cpu_baseline"] = cpu_baseline(sd, B, T, L, S)
+        result["speedup_vs_cpu_baseline"] = frames_per_s / result["cpu_baseline"]["value"] / world
+    print(json.dumps(result))
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

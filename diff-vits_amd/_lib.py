@@ -36,6 +36,9 @@ SIGNATURES = {
     "dv_unet_set_cond": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "dv_unet_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "dv_unet_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_double)]),
+    "dv_unet_forward_timed": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                        C.c_void_p, C.c_int32]),
+    "dv_unet_op_info": (C.c_int, [C.c_void_p, C.c_int32, C.c_char_p, C.POINTER(C.c_double)]),
     "dv_unet_probe": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.c_int64, C.POINTER(C.c_int64)]),
     "dv_sampler_plan": (C.c_int, [C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                   C.POINTER(C.c_void_p)]),
@@ -75,6 +78,12 @@ def lib():
             raise RuntimeError("libdvits_hip.so not found at %s — run `python -c 'import __graft_entry__ as g; "
                                "g.build()'` (or `make -C diff-vits_amd/csrc`) first; there is no fallback path"
                                % LIB_PATH)
+        # torch's bundled HIP runtime must be THE runtime of the process (same SONAME as /opt/rocm's):
+        # import torch first and pin its libamdhip64 so the loader resolves our NEEDED entry to it
+        import torch
+        bundled = os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so")
+        if os.path.exists(bundled):
+            C.CDLL(bundled, mode=C.RTLD_GLOBAL)
         handle = C.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(handle, name)       # AttributeError if the symbol is not exported

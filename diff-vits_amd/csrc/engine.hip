@@ -119,6 +119,8 @@ struct dv_unet {
   std::map<std::string, PackedW> packed;
   char* slab = nullptr; size_t slab_bytes = 0;
   std::vector<OpFn> step_ops, cond_ops;
+  struct OpMeta { const char* kind; double flops; };
+  std::vector<OpMeta> step_meta;          // parallel to step_ops (profiling / roofline report)
   std::vector<Probe> probes;
   double flops = 0;
   bool keep_intermediates = false;
@@ -134,7 +136,7 @@ static void unet_release_prepared(dv_unet* u) {
   u->packed.clear();
   if (u->slab) (void)hipFree(u->slab);
   u->slab = nullptr; u->slab_bytes = 0;
-  u->step_ops.clear(); u->cond_ops.clear(); u->probes.clear();
+  u->step_ops.clear(); u->cond_ops.clear(); u->probes.clear(); u->step_meta.clear();
   u->prepared = false; u->cond_set = false; u->flops = 0;
 }
 
@@ -219,7 +221,14 @@ struct Builder {
     size_t off = dry ? (reinterpret_cast<size_t>(p) - 0x1000) : (size_t)(reinterpret_cast<const char*>(p) - u->slab);
     arena.release(off);
   }
-  void emit(std::vector<OpFn>& ops, OpFn f) { if (!dry) ops.push_back(std::move(f)); }
+  const char* cur_kind = "misc";
+  double cur_flops = 0;
+  void emit(std::vector<OpFn>& ops, OpFn f) {
+    if (dry) return;
+    ops.push_back(std::move(f));
+    if (&ops == &u->step_ops) u->step_meta.push_back({cur_kind, cur_flops});
+    cur_kind = "misc"; cur_flops = 0;
+  }
   void probe(const std::string& name, const float* p, int T_, int C_) {
     if (!dry && u->keep_intermediates) u->probes.push_back(Probe{name, const_cast<float*>(p), T_, C_});
   }
@@ -288,7 +297,8 @@ struct Builder {
     g.B = B;
     for (int s = 0; s < g.nseg; ++s) g.seg[s].nkt = g.seg[s].taps * (g.seg[s].c0 + g.seg[s].c1) / 32;
     const int p = prec;
-    u->flops += dry ? 0.0 : 2.0 * (double)g.M * (double)(g.epi == EPI_GEGLU ? g.N : g.N) * (double)k_real;
+    cur_kind = "gemm"; cur_flops = 2.0 * (double)g.M * (double)g.N * (double)k_real;
+    u->flops += dry ? 0.0 : cur_flops;
     emit(ops, [g, p](hipStream_t st) { return launch_gemm(g, p, st); });
   }
 
@@ -303,7 +313,9 @@ struct Builder {
     const float* gamma = W(pre + ".weight");
     const float* beta = W(pre + ".bias");
     const int Bn = B;
+    cur_kind = "gn_partial";
     emit(ops, [=](hipStream_t st) { return launch_gn_partial(a0.p, a0.C, a1.p, a1.C, part, Bn, Tn, G, nchunk, st); });
+    cur_kind = "gn_finalize";
     emit(ops, [=](hipStream_t st) {
       return launch_gn_finalize(part, nchunk, gamma, beta, tscale, tshift, ld_t, af.scale, af.shift, nullptr, nullptr, Bn,
                                 Tn, C, G, eps, st);
@@ -370,6 +382,7 @@ struct Builder {
   Stats ln_stats(std::vector<OpFn>& ops, Act x) {
     const int M = B * x.T, C = x.C;
     Stats s{alloc((size_t)M), alloc((size_t)M)};
+    cur_kind = "ln_stats";
     emit(ops, [=](hipStream_t st) { return launch_ln_stats(x.p, s.mean, s.rstd, M, C, 1e-5f, st); });
     return s;
   }
@@ -380,7 +393,8 @@ struct Builder {
     a.q = q; a.k = k; a.v = v; a.bias = bias; a.o = o; a.ldq = ldq; a.ldk = ldkv; a.ldv = ldkv; a.ldo = ldo;
     a.B = B; a.H = u->cfg.num_heads; a.Tq = Tq; a.Tk = Tk; a.d = C / u->cfg.num_heads;
     a.scale = 1.0f / sqrtf((float)a.d);
-    if (!dry) u->flops += 4.0 * B * a.H * (double)Tq * Tk * a.d;
+    cur_kind = "attn"; cur_flops = 4.0 * B * a.H * (double)Tq * Tk * a.d;
+    if (!dry) u->flops += cur_flops;
     emit(ops, [a](hipStream_t st) { return launch_attention(a, st); });
   }
 
@@ -700,7 +714,8 @@ struct Builder {
       g.w_hi = wo->hi; g.w_lo = wo->lo; g.Kp = wo->Kp; g.N_pad = wo->N_pad; g.bias = wo->bias; g.B = B;
       g.seg[0].nkt = 3 * C0 / 32;
       const int pr = prec;
-      if (!dry) u->flops += 2.0 * g.M * (double)co * 3 * C0;
+      cur_kind = "gemm"; cur_flops = 2.0 * g.M * (double)co * 3 * C0;
+      if (!dry) u->flops += cur_flops;
       emit(S, [g, pr, uu](hipStream_t st) { GemmParams gg = g; gg.out = uu->io.y; return launch_gemm(gg, pr, st); });
       release(af.scale); release(af.shift); release(h.p);
     }
@@ -785,6 +800,35 @@ int dv_unet_enqueue(dv_unet* u, const float* x, int cx, const float* cond, const
 extern "C" int dv_unet_forward(dv_unet* u, const float* x, int32_t cx, const float* cond, const float* t, float* y, void* stream) {
   if (!u || !x || !t || !y) return dv_fail(DV_ERR_INVALID, "dv_unet_forward: null argument");
   return dv_unet_enqueue(u, x, cx, cond, t, y, (hipStream_t)stream);
+}
+
+extern "C" int dv_unet_forward_timed(dv_unet* u, const float* x, int32_t cx, const float* cond, const float* t, float* y,
+                                     void* stream, float* ms_per_op, int32_t capacity) {
+  if (!u || !x || !t || !y || !ms_per_op) return dv_fail(DV_ERR_INVALID, "dv_unet_forward_timed: null argument");
+  if (!u->prepared || !u->cond_set) return dv_fail(DV_ERR_STATE, "forward before prepare/set_cond");
+  const int n = (int)u->step_ops.size();
+  if (capacity < n) return dv_fail(DV_ERR_INVALID, "ms_per_op capacity %d < %d ops", capacity, n);
+  hipStream_t st = (hipStream_t)stream;
+  u->io.x = x; u->io.cx = cx; u->io.cond = cond; u->io.t = t; u->io.y = y;
+  std::vector<hipEvent_t> ev(n + 1);
+  for (auto& e : ev) HIPCHK(hipEventCreate(&e));
+  HIPCHK(hipEventRecord(ev[0], st));
+  for (int i = 0; i < n; ++i) {
+    hipError_t e = u->step_ops[i](st);
+    if (e != hipSuccess) return dv_fail(DV_ERR_HIP, "op %d failed: %s", i, hipGetErrorString(e));
+    HIPCHK(hipEventRecord(ev[i + 1], st));
+  }
+  HIPCHK(hipStreamSynchronize(st));
+  for (int i = 0; i < n; ++i) HIPCHK(hipEventElapsedTime(&ms_per_op[i], ev[i], ev[i + 1]));
+  for (auto& e : ev) (void)hipEventDestroy(e);
+  return DV_OK;
+}
+
+extern "C" int dv_unet_op_info(dv_unet* u, int32_t index, char* kind16, double* flops) {
+  if (!u || !u->prepared || index < 0 || index >= (int)u->step_meta.size()) return dv_fail(DV_ERR_INVALID, "dv_unet_op_info: bad index");
+  if (kind16) { strncpy(kind16, u->step_meta[index].kind, 15); kind16[15] = 0; }
+  if (flops) *flops = u->step_meta[index].flops;
+  return DV_OK;
 }
 
 extern "C" int dv_unet_stats(dv_unet* u, int64_t* n_launch, double* flops) {

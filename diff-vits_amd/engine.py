@@ -132,6 +132,21 @@ class UNetEngine:
         _lib.check(_lib.lib().dv_unet_stats(self._h, C.byref(n), C.byref(f)), "dv_unet_stats")
         return n.value, f.value
 
+    def profile_forward(self, x, cond, t):
+        """One eager forward with HIP events around every launch -> list of (kind, flops, ms)."""
+        n, _ = self.stats()
+        ms = (C.c_float * n)()
+        out = torch.empty((x.shape[0], self.out_channels, x.shape[2]), device=x.device, dtype=torch.float32)
+        _lib.check(_lib.lib().dv_unet_forward_timed(self._h, _lib.ptr(x), x.shape[1], _lib.ptr(cond), _lib.ptr(t),
+                                                    _lib.ptr(out), _lib.stream_ptr(), ms, n), "dv_unet_forward_timed")
+        rows = []
+        kind = C.create_string_buffer(16)
+        fl = C.c_double()
+        for i in range(n):
+            _lib.check(_lib.lib().dv_unet_op_info(self._h, i, kind, C.byref(fl)), "dv_unet_op_info")
+            rows.append((kind.value.decode(), fl.value, float(ms[i])))
+        return rows
+
     def probe(self, name):
         """Named intermediate [B, T, C] of the last forward (needs DVITS_KEEP_INTERMEDIATES=1)."""
         dims = (C.c_int64 * 3)()

@@ -103,6 +103,14 @@ int dv_unet_forward(dv_unet* u, const float* x, int32_t cx, const float* cond, c
  * contractions) of one forward at the prepared shape — for the roofline report. */
 int dv_unet_stats(dv_unet* u, int64_t* n_launch, double* flops);
 
+/* Measurement aid for bench.py: one forward with a HIP event pair around every launch of the
+ * schedule (eager, not graph-replayed); ms_per_op[i] = elapsed ms of launch i.
+ * dv_unet_op_info gives launch i's kernel family ("gemm", "attn", "gn_partial", "gn_finalize",
+ * "ln_stats", "misc") and its algorithmic FLOPs (0 for non-contractions). */
+int dv_unet_forward_timed(dv_unet* u, const float* x, int32_t cx, const float* cond, const float* t, float* y,
+                          void* stream, float* ms_per_op, int32_t capacity);
+int dv_unet_op_info(dv_unet* u, int32_t index, char* kind16, double* flops);
+
 /* Debug/parity probe: copy a named intermediate activation (channels-last [B, T, C]) of the
  * last forward to the host.  Available only when dv_unet_prepare ran with the environment
  * variable DVITS_KEEP_INTERMEDIATES=1 (buffers are then never reused).  dims[3] = {B, T, C};
