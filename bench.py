@@ -169,7 +169,7 @@ def main():
         with torch.no_grad():
             eng.profile_forward(x_T, cond, t_dev)                # warm
             for _ in range(reps):
-                for kind, fl, ms in eng.profile_forward(x_T, cond, t_dev):
+                for kind, fl, ms, _ in eng.profile_forward(x_T, cond, t_dev):
                     a = agg.setdefault(kind, [0, 0.0, 0.0])
                     a[0] += 1
                     a[1] += fl

@@ -119,7 +119,7 @@ struct dv_unet {
   std::map<std::string, PackedW> packed;
   char* slab = nullptr; size_t slab_bytes = 0;
   std::vector<OpFn> step_ops, cond_ops;
-  struct OpMeta { const char* kind; double flops; };
+  struct OpMeta { const char* kind; double flops; std::string desc; };
   std::vector<OpMeta> step_meta;          // parallel to step_ops (profiling / roofline report)
   std::vector<Probe> probes;
   double flops = 0;
@@ -223,11 +223,12 @@ struct Builder {
   }
   const char* cur_kind = "misc";
   double cur_flops = 0;
+  std::string cur_desc;
   void emit(std::vector<OpFn>& ops, OpFn f) {
     if (dry) return;
     ops.push_back(std::move(f));
-    if (&ops == &u->step_ops) u->step_meta.push_back({cur_kind, cur_flops});
-    cur_kind = "misc"; cur_flops = 0;
+    if (&ops == &u->step_ops) u->step_meta.push_back({cur_kind, cur_flops, cur_desc});
+    cur_kind = "misc"; cur_flops = 0; cur_desc.clear();
   }
   void probe(const std::string& name, const float* p, int T_, int C_) {
     if (!dry && u->keep_intermediates) u->probes.push_back(Probe{name, const_cast<float*>(p), T_, C_});
@@ -298,6 +299,12 @@ struct Builder {
     for (int s = 0; s < g.nseg; ++s) g.seg[s].nkt = g.seg[s].taps * (g.seg[s].c0 + g.seg[s].c1) / 32;
     const int p = prec;
     cur_kind = "gemm"; cur_flops = 2.0 * (double)g.M * (double)g.N * (double)k_real;
+    {
+      char buf[128];
+      snprintf(buf, sizeof(buf), "M=%d N=%d K=%d taps=%d nseg=%d pro=%d epi=%d stride=%d up=%d", g.M, g.N, k_real, g.seg[0].taps,
+               g.nseg, g.seg[0].pro, g.epi, g.stride, g.up_mode);
+      cur_desc = buf;
+    }
     u->flops += dry ? 0.0 : cur_flops;
     emit(ops, [g, p](hipStream_t st) { return launch_gemm(g, p, st); });
   }
@@ -314,6 +321,11 @@ struct Builder {
     const float* beta = W(pre + ".bias");
     const int Bn = B;
     cur_kind = "gn_partial";
+    {
+      char buf[96];
+      snprintf(buf, sizeof(buf), "T=%d C=%d nchunk=%d", Tn, C, nchunk);
+      cur_desc = buf;
+    }
     emit(ops, [=](hipStream_t st) { return launch_gn_partial(a0.p, a0.C, a1.p, a1.C, part, Bn, Tn, G, nchunk, st); });
     cur_kind = "gn_finalize";
     emit(ops, [=](hipStream_t st) {
@@ -394,6 +406,11 @@ struct Builder {
     a.B = B; a.H = u->cfg.num_heads; a.Tq = Tq; a.Tk = Tk; a.d = C / u->cfg.num_heads;
     a.scale = 1.0f / sqrtf((float)a.d);
     cur_kind = "attn"; cur_flops = 4.0 * B * a.H * (double)Tq * Tk * a.d;
+    {
+      char buf[96];
+      snprintf(buf, sizeof(buf), "Tq=%d Tk=%d d=%d H=%d", Tq, Tk, a.d, a.H);
+      cur_desc = buf;
+    }
     if (!dry) u->flops += cur_flops;
     emit(ops, [a](hipStream_t st) { return launch_attention(a, st); });
   }
@@ -824,9 +841,10 @@ extern "C" int dv_unet_forward_timed(dv_unet* u, const float* x, int32_t cx, con
   return DV_OK;
 }
 
-extern "C" int dv_unet_op_info(dv_unet* u, int32_t index, char* kind16, double* flops) {
+extern "C" int dv_unet_op_info(dv_unet* u, int32_t index, char* kind16, double* flops, char* desc128) {
   if (!u || !u->prepared || index < 0 || index >= (int)u->step_meta.size()) return dv_fail(DV_ERR_INVALID, "dv_unet_op_info: bad index");
   if (kind16) { strncpy(kind16, u->step_meta[index].kind, 15); kind16[15] = 0; }
+  if (desc128) { strncpy(desc128, u->step_meta[index].desc.c_str(), 127); desc128[127] = 0; }
   if (flops) *flops = u->step_meta[index].flops;
   return DV_OK;
 }

@@ -49,7 +49,12 @@ __device__ __forceinline__ float silu_f(float v) { return v / (1.0f + __expf(-v)
 
 __device__ __forceinline__ float gelu_erf(float v) { return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f)); }
 
-template <int WM, int WN, int FM, int FN, int NSPLIT>
+// PRO = prologue family of segment 0, a compile-time choice so that the hot loop has no
+// control flow around its loads (every global load of a k-tile is issued back to back and
+// waited for once): 0 none, 1 per-(batch,channel) affine (+SiLU when seg.pro says so),
+// 3 LayerNorm (per-row mean/rstd, loaded once before the loop).  Segment 1 (the 1x1 shortcut
+// folded into conv2) never has a prologue.
+template <int WM, int WN, int FM, int FN, int NSPLIT, int PRO>
 __global__ __launch_bounds__(256) void k_gemm(const GemmParams p) {
   constexpr int BM = WM * FM * 32, BN = WN * FN * 32;
   constexpr bool SPLIT = NSPLIT == 3;
@@ -79,14 +84,21 @@ __global__ __launch_bounds__(256) void k_gemm(const GemmParams p) {
   const int a_row = tid >> 3;           // 0..31 within a pass
   const int a_kq = tid & 7;             // float4 column within the 32-wide k-tile
   int row_b[APASS], row_t[APASS];
-  bool row_ok[APASS];
+  unsigned row_ok = 0;
+  float ln_sc[APASS], ln_sh[APASS];
 #pragma unroll
   for (int i = 0; i < APASS; ++i) {
     int m = m0 + i * 32 + a_row;
-    row_ok[i] = m < p.M;
-    m = row_ok[i] ? m : 0;
+    const bool ok = m < p.M;
+    row_ok |= (ok ? 1u : 0u) << i;
+    m = ok ? m : 0;
     row_b[i] = m / p.T_out;
     row_t[i] = m - row_b[i] * p.T_out;
+    if (PRO == PRO_LN) {                // 1x1, stride 1: source row == output row
+      const float mu = p.seg[0].p0[m], rs = p.seg[0].p1[m];
+      ln_sc[i] = rs;
+      ln_sh[i] = -mu * rs;
+    }
   }
   const int b_row = tid >> 2;           // 0..63 within a pass
   const int b_ch = tid & 3;             // 16-byte chunk within the 64-byte k-tile row
@@ -95,10 +107,11 @@ __global__ __launch_bounds__(256) void k_gemm(const GemmParams p) {
   float4 ra[APASS], rsc[APASS], rsh[APASS];
   u32x4 rbh[BPASS], rbl[BPASS];
   unsigned valid_mask = 0;
-  int cur_pro = PRO_NONE;
+  bool cur_seg0 = true;
   // running decode of the k-tile being loaded
   int ld_seg = 0, ld_tap = 0, ld_cc = 0;
   const int total_kt = p.seg[0].nkt + (p.nseg > 1 ? p.seg[1].nkt : 0);
+  const bool act_silu = p.seg[0].pro == PRO_AFFINE_SILU;
 
   auto load_tile = [&](int kt) {
     const GemmSeg& s = p.seg[ld_seg];
@@ -107,29 +120,26 @@ __global__ __launch_bounds__(256) void k_gemm(const GemmParams p) {
     const float* src = first ? s.a0 : s.a1;
     const int ld = first ? s.c0 : s.c1;
     const int col = (first ? ld_cc : ld_cc - s.c0) + a_kq * 4;
-    cur_pro = s.pro;
+    cur_seg0 = ld_seg == 0;
+    // affine table offset; for segment-1 tiles a valid dummy offset (values ignored at convert time)
+    const int aff_c = (cur_seg0 ? ld_cc : 0) + a_kq * 4;
+    const int ctot0 = p.seg[0].c0 + p.seg[0].c1;
     valid_mask = 0;
 #pragma unroll
     for (int i = 0; i < APASS; ++i) {
       const int ts = row_t[i] * p.stride + ld_tap - s.pad;
-      const bool ok = row_ok[i] && ts >= 0 && ts < p.T_virt;
+      const bool ok = ((row_ok >> i) & 1u) && ts >= 0 && ts < p.T_virt;
       int st = ts;
-      if (p.up_mode == UP_X2) st = ts >> 1;
-      else if (p.up_mode == UP_SIZE) st = min((int)floorf((float)ts * p.up_scale), p.T_in - 1);
-      st = ok ? st : 0;
+      st = p.up_mode == UP_X2 ? (ts >> 1) : st;
+      st = p.up_mode == UP_SIZE ? min((int)floorf((float)ts * p.up_scale), p.T_in - 1) : st;
+      st = ok ? st : 0;                                  // clamp: the load is unconditional
       const size_t srow = (size_t)row_b[i] * p.T_in + st;
-      if (ok) {
-        ra[i] = *reinterpret_cast<const float4*>(src + srow * ld + col);
-        valid_mask |= 1u << i;
-        if (s.pro == PRO_AFFINE_SILU || s.pro == PRO_AFFINE) {
-          const size_t o = (size_t)row_b[i] * ctot + ld_cc + a_kq * 4;
-          rsc[i] = *reinterpret_cast<const float4*>(s.p0 + o);
-          rsh[i] = *reinterpret_cast<const float4*>(s.p1 + o);
-        } else if (s.pro == PRO_LN) {
-          const float mu = s.p0[srow], rs = s.p1[srow];
-          rsc[i] = make_float4(rs, rs, rs, rs);
-          rsh[i] = make_float4(-mu * rs, -mu * rs, -mu * rs, -mu * rs);
-        }
+      ra[i] = *reinterpret_cast<const float4*>(src + srow * ld + col);
+      valid_mask |= (ok ? 1u : 0u) << i;
+      if (PRO == PRO_AFFINE_SILU) {
+        const size_t o = (size_t)row_b[i] * ctot0 + aff_c;
+        rsc[i] = *reinterpret_cast<const float4*>(p.seg[0].p0 + o);
+        rsh[i] = *reinterpret_cast<const float4*>(p.seg[0].p1 + o);
       }
     }
 #pragma unroll
@@ -154,19 +164,22 @@ __global__ __launch_bounds__(256) void k_gemm(const GemmParams p) {
     char* b_lo = b_hi + B_BYTES;
 #pragma unroll
     for (int i = 0; i < APASS; ++i) {
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (valid_mask & (1u << i)) {
-        v = ra[i];
-        if (cur_pro != PRO_NONE) {
+      float4 v = ra[i];
+      if (PRO == PRO_AFFINE_SILU) {
+        if (cur_seg0) {
           v.x = fmaf(v.x, rsc[i].x, rsh[i].x);
           v.y = fmaf(v.y, rsc[i].y, rsh[i].y);
           v.z = fmaf(v.z, rsc[i].z, rsh[i].z);
           v.w = fmaf(v.w, rsc[i].w, rsh[i].w);
-          if (cur_pro == PRO_AFFINE_SILU) {
-            v.x = silu_f(v.x); v.y = silu_f(v.y); v.z = silu_f(v.z); v.w = silu_f(v.w);
-          }
+          if (act_silu) { v.x = silu_f(v.x); v.y = silu_f(v.y); v.z = silu_f(v.z); v.w = silu_f(v.w); }
         }
+      } else if (PRO == PRO_LN) {
+        v.x = fmaf(v.x, ln_sc[i], ln_sh[i]);
+        v.y = fmaf(v.y, ln_sc[i], ln_sh[i]);
+        v.z = fmaf(v.z, ln_sc[i], ln_sh[i]);
+        v.w = fmaf(v.w, ln_sc[i], ln_sh[i]);
       }
+      if (!((valid_mask >> i) & 1u)) v = make_float4(0.f, 0.f, 0.f, 0.f);   // conv zero padding / rows >= M
       uint2 hi, lo;
       split4<SPLIT>(v, hi, lo);
       const int off = (i * 32 + a_row) * ROWB + a_kq * 8;
@@ -283,43 +296,62 @@ __global__ __launch_bounds__(256) void k_gemm(const GemmParams p) {
   }
 }
 
-template <int WM, int WN, int FM, int FN, int NSPLIT>
+template <int WM, int WN, int FM, int FN, int NSPLIT, int PRO>
 struct GemmCfg {
   static constexpr int BM = WM * FM * 32, BN = WN * FN * 32;
   static constexpr int SMEM = 2 * (BM + BN) * ROWB * (NSPLIT == 3 ? 2 : 1);
   // > 64 KiB of dynamic LDS needs the attribute; set once, outside any stream capture
   static hipError_t init() {
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm<WM, WN, FM, FN, NSPLIT>),
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm<WM, WN, FM, FN, NSPLIT, PRO>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
   }
   static hipError_t launch(const GemmParams& p, hipStream_t st) {
     const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
-    hipLaunchKernelGGL((k_gemm<WM, WN, FM, FN, NSPLIT>), dim3(tiles), dim3(256), SMEM, st, p);
+    hipLaunchKernelGGL((k_gemm<WM, WN, FM, FN, NSPLIT, PRO>), dim3(tiles), dim3(256), SMEM, st, p);
     return hipGetLastError();
+  }
+};
+
+template <int WM, int WN, int FM, int FN>
+struct GemmTile {
+  static hipError_t init() {
+    hipError_t e;
+    if ((e = GemmCfg<WM, WN, FM, FN, 3, PRO_NONE>::init()) != hipSuccess) return e;
+    if ((e = GemmCfg<WM, WN, FM, FN, 3, PRO_AFFINE_SILU>::init()) != hipSuccess) return e;
+    if ((e = GemmCfg<WM, WN, FM, FN, 3, PRO_LN>::init()) != hipSuccess) return e;
+    if ((e = GemmCfg<WM, WN, FM, FN, 1, PRO_NONE>::init()) != hipSuccess) return e;
+    if ((e = GemmCfg<WM, WN, FM, FN, 1, PRO_AFFINE_SILU>::init()) != hipSuccess) return e;
+    return GemmCfg<WM, WN, FM, FN, 1, PRO_LN>::init();
+  }
+  static hipError_t launch(const GemmParams& p, bool x3, hipStream_t st) {
+    const int pro = p.seg[0].pro == PRO_AFFINE ? PRO_AFFINE_SILU : p.seg[0].pro;   // affine family
+    if (x3) {
+      if (pro == PRO_NONE) return GemmCfg<WM, WN, FM, FN, 3, PRO_NONE>::launch(p, st);
+      if (pro == PRO_LN) return GemmCfg<WM, WN, FM, FN, 3, PRO_LN>::launch(p, st);
+      return GemmCfg<WM, WN, FM, FN, 3, PRO_AFFINE_SILU>::launch(p, st);
+    }
+    if (pro == PRO_NONE) return GemmCfg<WM, WN, FM, FN, 1, PRO_NONE>::launch(p, st);
+    if (pro == PRO_LN) return GemmCfg<WM, WN, FM, FN, 1, PRO_LN>::launch(p, st);
+    return GemmCfg<WM, WN, FM, FN, 1, PRO_AFFINE_SILU>::launch(p, st);
   }
 };
 
 hipError_t gemm_init() {
   hipError_t e;
-  if ((e = GemmCfg<2, 2, 2, 2, 3>::init()) != hipSuccess) return e;
-  if ((e = GemmCfg<2, 2, 2, 2, 1>::init()) != hipSuccess) return e;
-  if ((e = GemmCfg<4, 1, 1, 2, 3>::init()) != hipSuccess) return e;
-  if ((e = GemmCfg<4, 1, 1, 2, 1>::init()) != hipSuccess) return e;
-  if ((e = GemmCfg<2, 2, 1, 1, 3>::init()) != hipSuccess) return e;
-  return GemmCfg<2, 2, 1, 1, 1>::init();
+  if ((e = GemmTile<2, 2, 2, 2>::init()) != hipSuccess) return e;
+  if ((e = GemmTile<4, 1, 1, 2>::init()) != hipSuccess) return e;
+  return GemmTile<2, 2, 1, 1>::init();
 }
 
 // Tile choice: the denoiser's GEMMs are small (M = B*T_l <= 8192, N = 128..4096), so the
-// first concern is filling 256 CUs; 128x128 tiles only when they still give >= 2 waves of
-// workgroups per CU-set, else 64x64.  GEGLU needs both halves of a 64-column block in one
-// wave (FN == 2): 128x128 or 128x64 (4x1 waves).
+// first concern is filling 256 CUs; 128x128 tiles only when they still give >= 1.5 workgroups
+// per CU, else 64x64.  GEGLU needs both halves of a 64-column block in one wave (FN == 2):
+// 128x128 or 128x64 (4x1 waves).
 hipError_t launch_gemm(const GemmParams& p, int precision, hipStream_t st) {
   const int big_tiles = ((p.M + 127) / 128) * ((p.N + 127) / 128);
   const bool x3 = precision == 0;
-  if (p.epi == EPI_GEGLU) {
-    if (big_tiles >= 384) return x3 ? GemmCfg<2, 2, 2, 2, 3>::launch(p, st) : GemmCfg<2, 2, 2, 2, 1>::launch(p, st);
-    return x3 ? GemmCfg<4, 1, 1, 2, 3>::launch(p, st) : GemmCfg<4, 1, 1, 2, 1>::launch(p, st);
-  }
-  if (big_tiles >= 384) return x3 ? GemmCfg<2, 2, 2, 2, 3>::launch(p, st) : GemmCfg<2, 2, 2, 2, 1>::launch(p, st);
-  return x3 ? GemmCfg<2, 2, 1, 1, 3>::launch(p, st) : GemmCfg<2, 2, 1, 1, 1>::launch(p, st);
+  if (p.nseg > 1 && p.seg[1].pro != PRO_NONE) return hipErrorInvalidValue;
+  if (big_tiles >= 384) return GemmTile<2, 2, 2, 2>::launch(p, x3, st);
+  if (p.epi == EPI_GEGLU) return GemmTile<4, 1, 1, 2>::launch(p, x3, st);
+  return GemmTile<2, 2, 1, 1>::launch(p, x3, st);
 }

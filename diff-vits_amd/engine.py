@@ -133,7 +133,7 @@ class UNetEngine:
         return n.value, f.value
 
     def profile_forward(self, x, cond, t):
-        """One eager forward with HIP events around every launch -> list of (kind, flops, ms)."""
+        """One eager forward with HIP events around every launch -> list of (kind, flops, ms, desc)."""
         n, _ = self.stats()
         ms = (C.c_float * n)()
         out = torch.empty((x.shape[0], self.out_channels, x.shape[2]), device=x.device, dtype=torch.float32)
@@ -141,10 +141,11 @@ class UNetEngine:
                                                     _lib.ptr(out), _lib.stream_ptr(), ms, n), "dv_unet_forward_timed")
         rows = []
         kind = C.create_string_buffer(16)
+        desc = C.create_string_buffer(128)
         fl = C.c_double()
         for i in range(n):
-            _lib.check(_lib.lib().dv_unet_op_info(self._h, i, kind, C.byref(fl)), "dv_unet_op_info")
-            rows.append((kind.value.decode(), fl.value, float(ms[i])))
+            _lib.check(_lib.lib().dv_unet_op_info(self._h, i, kind, C.byref(fl), desc), "dv_unet_op_info")
+            rows.append((kind.value.decode(), fl.value, float(ms[i]), desc.value.decode()))
         return rows
 
     def probe(self, name):

@@ -106,10 +106,10 @@ int dv_unet_stats(dv_unet* u, int64_t* n_launch, double* flops);
 /* Measurement aid for bench.py: one forward with a HIP event pair around every launch of the
  * schedule (eager, not graph-replayed); ms_per_op[i] = elapsed ms of launch i.
  * dv_unet_op_info gives launch i's kernel family ("gemm", "attn", "gn_partial", "gn_finalize",
- * "ln_stats", "misc") and its algorithmic FLOPs (0 for non-contractions). */
+ * "ln_stats", "misc"), its algorithmic FLOPs (0 for non-contractions) and a shape description. */
 int dv_unet_forward_timed(dv_unet* u, const float* x, int32_t cx, const float* cond, const float* t, float* y,
                           void* stream, float* ms_per_op, int32_t capacity);
-int dv_unet_op_info(dv_unet* u, int32_t index, char* kind16, double* flops);
+int dv_unet_op_info(dv_unet* u, int32_t index, char* kind16, double* flops, char* desc128);
 
 /* Debug/parity probe: copy a named intermediate activation (channels-last [B, T, C]) of the
  * last forward to the host.  Available only when dv_unet_prepare ran with the environment
