@@ -8,24 +8,20 @@ typedef unsigned short bf16_t;   // raw bfloat16 bits
 // ---------------------------------------------------------------------------------------
 // Implicit-GEMM parameters.  One launch computes
 //     out[m, n] = epilogue( sum over K-segments/taps/channels of  A(m, k) * W[n, k] )
-// on channels-last fp32 activations.  Row m = (b, t) of the output; the A operand is
-// gathered on the fly (conv taps, stride, nearest upsample, channel-concat of two source
-// tensors) and passed through a prologue (GroupNorm/temb affine + SiLU, or LayerNorm).
+// Row m = (b, t) of the output; the A operand is gathered on the fly (conv taps, stride,
+// nearest upsample, channel-concat of two source tensors) from activations that their
+// producers already stored as split bf16 planes (hi = bf16(x), lo = bf16(x - hi)).
 // ---------------------------------------------------------------------------------------
-enum { PRO_NONE = 0, PRO_AFFINE_SILU = 1, PRO_AFFINE = 2, PRO_LN = 3 };
 enum { EPI_STORE = 0, EPI_RESIDUAL = 1, EPI_GEGLU = 2, EPI_STORE_NCT = 3 };
 enum { UP_NONE = 0, UP_X2 = 1, UP_SIZE = 2 };
 
 struct GemmSeg {
-  const float* a0;     // [B*T_in, c0]
-  const float* a1;     // [B*T_in, c1] or null (channel concat [a0 | a1])
-  const float* p0;     // PRO_AFFINE*: scale[B, c0+c1];  PRO_LN: mean[B*T_in]
-  const float* p1;     // PRO_AFFINE*: shift[B, c0+c1];  PRO_LN: rstd[B*T_in]
+  const bf16_t* a0_hi; const bf16_t* a0_lo;   // [B*T_in, c0] planes
+  const bf16_t* a1_hi; const bf16_t* a1_lo;   // [B*T_in, c1] planes or null (channel concat [a0 | a1])
   int c0, c1;          // channel counts, multiples of 32
   int taps;            // 1 or 3
   int pad;             // left padding in frames
-  int pro;             // PRO_*
-  int nkt;             // k-tiles of this segment = taps * (c0+c1) / 32
+  int nkt;             // k-tiles of this segment = taps * (c0+c1) / BK   (set by the launcher)
 };
 
 struct GemmParams {
@@ -37,19 +33,25 @@ struct GemmParams {
   float up_scale;               // UP_SIZE: (float)T_in / T_virt, as ATen computes it
   const bf16_t* w_hi;           // [N_pad, Kp] bf16, row n = output channel, k contiguous
   const bf16_t* w_lo;           // low-order split (null in bf16 mode)
-  int Kp;                       // packed K = 32 * total k-tiles
-  int N_pad;                    // rows present in w_hi/w_lo (multiple of 64)
-  const float* bias;            // [N] (GEGLU: [2*N_out] in packed order) or null
+  int Kp;                       // packed K
+  int N_pad;                    // rows present in w_hi/w_lo (multiple of 128)
+  const float* bias;            // [N] (GEGLU: packed order) or null
   int M, N;                     // output rows, GEMM columns (GEGLU: packed 2*N_out)
   int epi;                      // EPI_*
-  const float* res;             // EPI_RESIDUAL: [M, ldres]
+  const float* res;             // EPI_RESIDUAL: [M, ldres] fp32
   int ldres;
-  float* out;                   // [M, ldo]  (EPI_STORE_NCT: [B, N, T_out])
+  float* out;                   // fp32 output [M, ldo] or null  (EPI_STORE_NCT: [B, N, T_out], required)
+  bf16_t* out_hi;               // split-plane output [M, ldo] or null
+  bf16_t* out_lo;
   int ldo;
+  float* stats;                 // [ceil(M/32), N, 2] per 32-row block column (sum, sumsq) or null
+  const bf16_t* zero_page;      // >= 16 bytes of zeros (source of padded / out-of-range rows)
 };
 
 struct AttnParams {
-  const float* q; const float* k; const float* v; const float* bias; float* o;
+  const float* q; const float* k; const float* v; const float* bias;
+  float* o;                     // fp32 output or null
+  bf16_t* o_hi; bf16_t* o_lo;   // split-plane output (consumed by the to_out GEMM) or null
   int ldq, ldk, ldv, ldo;       // row strides (floats); head h occupies columns [h*d, h*d+d)
   int B, H, Tq, Tk, d;
   float scale;
@@ -61,8 +63,28 @@ hipError_t gemm_init();   // one-time kernel attribute setup (call outside strea
 hipError_t launch_attention(const AttnParams& p, hipStream_t st);
 
 // misc kernels (kernels_misc.hip)
-hipError_t launch_pack_input(const float* x, int cx, const float* cond, int cc, float* out, int cpad, int B, int T,
-                             hipStream_t st);
+// (B,C,T) x | cond -> channels-last split planes [B*T, cpad] (zero padded)
+hipError_t launch_pack_input(const float* x, int cx, const float* cond, int cc, bf16_t* out_hi, bf16_t* out_lo, int cpad,
+                             int B, int T, hipStream_t st);
+// fp32 [n] -> split planes
+hipError_t launch_split(const float* in, bf16_t* hi, bf16_t* lo, int64_t n, hipStream_t st);
+// GroupNorm (+temb scale/shift) (+SiLU) of the channel concat [a0 | a1] -> split planes [B*T, c0+c1].
+// Statistics come either from the producers' per-32-row-block column sums (slab0/slab1, T % 32 == 0) or
+// from a precomputed per-(batch,channel) affine (scale_in/shift_in).  raw_hi/raw_lo (optional): split
+// planes of the un-normalised input (operand of the folded 1x1 shortcut).
+struct GnApplyParams {
+  const float* a0; const float* a1; int c0, c1;
+  const float* slab0; const float* slab1;
+  const float* scale_in; const float* shift_in;
+  const float* gamma; const float* beta; float eps; int groups;
+  const float* tscale; const float* tshift; int ld_t;
+  int silu;
+  bf16_t* out_hi; bf16_t* out_lo; bf16_t* raw_hi; bf16_t* raw_lo;
+  int B, T;
+};
+hipError_t launch_gn_apply(const GnApplyParams& p, hipStream_t st);
+// LayerNorm rows (no affine: gamma/beta are folded into the consumer's weights) -> split planes
+hipError_t launch_ln_apply(const float* x, bf16_t* hi, bf16_t* lo, int M, int C, float eps, hipStream_t st);
 // GroupNorm statistics of the channel-concat [a0 | a1] -> part[B, nchunk, G, 2] (double sum, sumsq)
 hipError_t launch_gn_partial(const float* a0, int c0, const float* a1, int c1, double* part, int B, int T, int G,
                              int nchunk, hipStream_t st);

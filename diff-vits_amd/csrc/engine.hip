@@ -102,7 +102,7 @@ struct PackedW {
   int Kp = 0, N = 0, N_pad = 0;
 };
 
-struct Act { float* p = nullptr; int C = 0, T = 0; };   // channels-last [B*T, C]
+struct Act { float* p = nullptr; int C = 0, T = 0; float* stat = nullptr; };   // channels-last fp32 [B*T, C] (+ GN stat slab)
 
 typedef std::function<hipError_t(hipStream_t)> OpFn;
 
@@ -118,6 +118,7 @@ struct dv_unet {
   std::vector<void*> owned;                  // hipMalloc'ed (packed weights, tables)
   std::map<std::string, PackedW> packed;
   char* slab = nullptr; size_t slab_bytes = 0;
+  bf16_t* zero_page = nullptr;               // 256 zero bytes: source of padded rows for the LDS-DMA
   std::vector<OpFn> step_ops, cond_ops;
   struct OpMeta { const char* kind; double flops; std::string desc; };
   std::vector<OpMeta> step_meta;          // parallel to step_ops (profiling / roofline report)
@@ -133,6 +134,7 @@ struct dv_unet {
 static void unet_release_prepared(dv_unet* u) {
   for (void* p : u->owned) (void)hipFree(p);
   u->owned.clear();
+  u->zero_page = nullptr;
   u->packed.clear();
   if (u->slab) (void)hipFree(u->slab);
   u->slab = nullptr; u->slab_bytes = 0;
@@ -292,54 +294,103 @@ struct Builder {
   }
 
   // ---- op emitters
+  struct Planes { bf16_t* hi = nullptr; bf16_t* lo = nullptr; };
+  Planes alloc_planes(size_t elems) {
+    Planes pl;
+    pl.hi = reinterpret_cast<bf16_t*>(alloc((elems + 1) / 2));
+    if (prec == DV_PREC_BF16X3) pl.lo = reinterpret_cast<bf16_t*>(alloc((elems + 1) / 2));
+    return pl;
+  }
+  void release(const Planes& pl) { if (pl.hi) release((const void*)pl.hi); if (pl.lo) release((const void*)pl.lo); }
+  // per-32-row-block column sums of a GEMM output (GroupNorm statistics for its consumer)
+  float* alloc_stat(int Tn, int C) { return (Tn % 32 == 0) ? alloc((size_t)(B * Tn / 32) * C * 2) : nullptr; }
+
   void gemm(std::vector<OpFn>& ops, GemmParams g, const PackedW* pw, int k_real) {
     g.w_hi = pw->hi; g.w_lo = pw->lo; g.Kp = pw->Kp; g.N_pad = pw->N_pad;
     if (!g.bias) g.bias = pw->bias;
     g.B = B;
-    for (int s = 0; s < g.nseg; ++s) g.seg[s].nkt = g.seg[s].taps * (g.seg[s].c0 + g.seg[s].c1) / 32;
+    g.zero_page = u->zero_page;
     const int p = prec;
     cur_kind = "gemm"; cur_flops = 2.0 * (double)g.M * (double)g.N * (double)k_real;
     {
       char buf[128];
-      snprintf(buf, sizeof(buf), "M=%d N=%d K=%d taps=%d nseg=%d pro=%d epi=%d stride=%d up=%d", g.M, g.N, k_real, g.seg[0].taps,
-               g.nseg, g.seg[0].pro, g.epi, g.stride, g.up_mode);
+      snprintf(buf, sizeof(buf), "M=%d N=%d K=%d taps=%d nseg=%d epi=%d stride=%d up=%d%s", g.M, g.N, k_real, g.seg[0].taps,
+               g.nseg, g.epi, g.stride, g.up_mode, g.stats ? " +stats" : "");
       cur_desc = buf;
     }
     u->flops += dry ? 0.0 : cur_flops;
     emit(ops, [g, p](hipStream_t st) { return launch_gemm(g, p, st); });
   }
 
-  struct Affine { float* scale; float* shift; };
-  // GroupNorm (+ optional temb scale/shift) of [a0 | a1] -> per-(b,c) affine for the consumer GEMM
-  Affine gn_affine(std::vector<OpFn>& ops, Act a0, Act a1, const std::string& pre, float eps, const float* tscale,
-                   const float* tshift, int ld_t) {
-    const int G = u->cfg.norm_num_groups, C = a0.C + a1.C, Tn = a0.T;
-    const int nchunk = std::max(1, std::min(64, (Tn + 63) / 64));
-    double* part = reinterpret_cast<double*>(alloc((size_t)B * nchunk * G * 2 * 2));
-    Affine af{alloc((size_t)B * C), alloc((size_t)B * C)};
-    const float* gamma = W(pre + ".weight");
-    const float* beta = W(pre + ".bias");
-    const int Bn = B;
-    cur_kind = "gn_partial";
-    {
-      char buf[96];
-      snprintf(buf, sizeof(buf), "T=%d C=%d nchunk=%d", Tn, C, nchunk);
-      cur_desc = buf;
-    }
-    emit(ops, [=](hipStream_t st) { return launch_gn_partial(a0.p, a0.C, a1.p, a1.C, part, Bn, Tn, G, nchunk, st); });
-    cur_kind = "gn_finalize";
-    emit(ops, [=](hipStream_t st) {
-      return launch_gn_finalize(part, nchunk, gamma, beta, tscale, tshift, ld_t, af.scale, af.shift, nullptr, nullptr, Bn,
-                                Tn, C, G, eps, st);
-    });
-    release(part);
-    return af;
+  static GemmSeg seg(Planes a0, int c0, Planes a1, int c1, int taps, int pad) {
+    GemmSeg s{};
+    s.a0_hi = a0.hi; s.a0_lo = a0.lo; s.a1_hi = a1.hi; s.a1_lo = a1.lo;
+    s.c0 = c0; s.c1 = c1; s.taps = taps; s.pad = pad;
+    return s;
   }
 
-  static GemmSeg seg(Act a0, Act a1, int taps, int pad, int pro, const float* p0, const float* p1) {
-    GemmSeg s{};
-    s.a0 = a0.p; s.a1 = a1.p; s.c0 = a0.C; s.c1 = a1.C; s.taps = taps; s.pad = pad; s.pro = pro; s.p0 = p0; s.p1 = p1;
-    return s;
+  // GroupNorm (+ temb scale/shift) (+ SiLU) of [a0 | a1] -> split planes [B*T, C] for the consumer GEMM.
+  // Fast path: statistics from the producers' epilogue slabs (a0.stat / a1.stat), one launch.
+  // General path (T % 32 != 0): k_gn_partial + k_gn_finalize build the per-(b,c) affine first.
+  Planes norm_apply(std::vector<OpFn>& ops, Act a0, Act a1, const std::string& pre, float eps, const float* tscale,
+                    const float* tshift, int ld_t, bool silu, Planes* raw_out) {
+    const int G = u->cfg.norm_num_groups, C = a0.C + a1.C, Tn = a0.T;
+    GnApplyParams gp{};
+    gp.a0 = a0.p; gp.a1 = a1.p; gp.c0 = a0.C; gp.c1 = a1.C;
+    gp.gamma = W(pre + ".weight"); gp.beta = W(pre + ".bias"); gp.eps = eps; gp.groups = G;
+    gp.tscale = tscale; gp.tshift = tshift; gp.ld_t = ld_t; gp.silu = silu ? 1 : 0;
+    gp.B = B; gp.T = Tn;
+    float* sc = nullptr; float* sh = nullptr;
+    const bool fast = a0.stat && (a1.C == 0 || a1.stat);
+    if (fast) { gp.slab0 = a0.stat; gp.slab1 = a1.stat; }
+    else {
+      const int nchunk = std::max(1, std::min(64, (Tn + 63) / 64));
+      double* part = reinterpret_cast<double*>(alloc((size_t)B * nchunk * G * 2 * 2));
+      sc = alloc((size_t)B * C); sh = alloc((size_t)B * C);
+      const int Bn = B;
+      const float* gamma = gp.gamma; const float* beta = gp.beta;
+      cur_kind = "gn_partial";
+      emit(ops, [=](hipStream_t st) { return launch_gn_partial(a0.p, a0.C, a1.p, a1.C, part, Bn, Tn, G, nchunk, st); });
+      cur_kind = "gn_finalize";
+      emit(ops, [=](hipStream_t st) {
+        return launch_gn_finalize(part, nchunk, gamma, beta, tscale, tshift, ld_t, sc, sh, nullptr, nullptr, Bn, Tn, C, G, eps, st);
+      });
+      release(part);
+      gp.scale_in = sc; gp.shift_in = sh;
+    }
+    Planes out = alloc_planes((size_t)B * Tn * C);
+    gp.out_hi = out.hi; gp.out_lo = out.lo;
+    if (raw_out) { *raw_out = alloc_planes((size_t)B * Tn * C); gp.raw_hi = raw_out->hi; gp.raw_lo = raw_out->lo; }
+    cur_kind = "gn_apply";
+    {
+      char buf[96];
+      snprintf(buf, sizeof(buf), "T=%d C=%d%s%s", Tn, C, fast ? " slab" : " table", raw_out ? " +raw" : "");
+      cur_desc = buf;
+    }
+    emit(ops, [gp](hipStream_t st) { return launch_gn_apply(gp, st); });
+    if (sc) { release(sc); release(sh); }
+    return out;
+  }
+
+  Planes ln_apply(std::vector<OpFn>& ops, const float* x, int M, int C) {
+    Planes out = alloc_planes((size_t)M * C);
+    cur_kind = "ln_apply";
+    emit(ops, [=](hipStream_t st) { return launch_ln_apply(x, out.hi, out.lo, M, C, 1e-5f, st); });
+    return out;
+  }
+
+  Planes split(std::vector<OpFn>& ops, const float* x, size_t n) {
+    Planes out = alloc_planes(n);
+    cur_kind = "split";
+    emit(ops, [=](hipStream_t st) { return launch_split(x, out.hi, out.lo, (int64_t)n, st); });
+    return out;
+  }
+
+  GemmParams gp_base(int Tn, int M, int N) {
+    GemmParams g{};
+    g.nseg = 1; g.T_out = g.T_in = g.T_virt = Tn; g.stride = 1; g.up_mode = UP_NONE;
+    g.M = M; g.N = N; g.epi = EPI_STORE; g.ldo = N; g.ldres = N;
+    return g;
   }
 
   // temb projection table offsets
@@ -347,41 +398,49 @@ struct Builder {
   int tproj_total = 0;
   float* tproj = nullptr;    // [B, tproj_total]
 
+  // ResnetBlock2D (reference resnet.py:591-641): apply(norm1) -> conv1 -> apply(norm2, temb) -> conv2 (+1x1
+  // shortcut as a second K-segment | + identity residual)
   Act resnet(std::vector<OpFn>& ops, const std::string& p, Act x0, Act x1, int cout) {
     const int cin = x0.C + x1.C, Tn = x0.T, M = B * Tn;
     const float eps = u->cfg.norm_eps;
-    Affine a1 = gn_affine(ops, x0, x1, p + "norm1", eps, nullptr, nullptr, 0);
+    const bool shortcut = has(p + "conv_shortcut.weight");
+    Planes raw;
+    Planes n1 = norm_apply(ops, x0, x1, p + "norm1", eps, nullptr, nullptr, 0, true, shortcut ? &raw : nullptr);
     const PackedW* w1 = pack(p + "conv1", cout, 3 * cin, {{p + "conv1.weight", 1, cin, 3, cin, 0, 0, "", 0}},
                              {{p + "conv1.bias", "", "", "", cout, 0, 0, 0}});
     if (!w1) return Act{};
-    Act h{alloc((size_t)M * cout), cout, Tn};
-    GemmParams g{};
-    g.seg[0] = seg(x0, x1, 3, 1, PRO_AFFINE_SILU, a1.scale, a1.shift);
-    g.nseg = 1; g.T_out = g.T_in = g.T_virt = Tn; g.stride = 1; g.up_mode = UP_NONE;
-    g.M = M; g.N = cout; g.epi = EPI_STORE; g.out = h.p; g.ldo = cout;
-    gemm(ops, g, w1, 3 * cin);
-    release(a1.scale); release(a1.shift);
+    Act h{};
+    h.p = alloc((size_t)M * cout); h.C = cout; h.T = Tn; h.stat = alloc_stat(Tn, cout);
+    {
+      GemmParams g = gp_base(Tn, M, cout);
+      g.seg[0] = seg(n1, cin, Planes{}, 0, 3, 1);
+      g.out = h.p; g.stats = h.stat;
+      gemm(ops, g, w1, 3 * cin);
+    }
+    release(n1);
     probe(p + "conv1", h.p, Tn, cout);
 
     const int toff = tproj_off[p];
-    Affine a2 = gn_affine(ops, h, Act{}, p + "norm2", eps, tproj + toff, tproj + toff + cout, tproj_total);
-    const bool shortcut = has(p + "conv_shortcut.weight");
+    Planes n2 = norm_apply(ops, h, Act{}, p + "norm2", eps, tproj + toff, tproj + toff + cout, tproj_total, true, nullptr);
+    release(h.p); if (h.stat) release(h.stat);
     const int K2 = 3 * cout + (shortcut ? cin : 0);
     std::vector<Piece> pcs = {{p + "conv2.weight", 1, cout, 3, cout, 0, 0, "", 0}};
     std::vector<BiasPiece> bps = {{p + "conv2.bias", shortcut ? p + "conv_shortcut.bias" : "", "", "", cout, 0, 0, 0}};
     if (shortcut) pcs.push_back({p + "conv_shortcut.weight", 1, cin, 1, cin, 3 * cout, 0, "", 0});
     const PackedW* w2 = pack(p + "conv2", cout, K2, pcs, bps);
     if (!w2) return Act{};
-    Act out{alloc((size_t)M * cout), cout, Tn};
-    GemmParams g2{};
-    g2.seg[0] = seg(h, Act{}, 3, 1, PRO_AFFINE_SILU, a2.scale, a2.shift);
-    g2.nseg = 1;
-    if (shortcut) { g2.seg[1] = seg(x0, x1, 1, 0, PRO_NONE, nullptr, nullptr); g2.nseg = 2; g2.epi = EPI_STORE; }
-    else { g2.epi = EPI_RESIDUAL; g2.res = x0.p; g2.ldres = cout; }
-    g2.T_out = g2.T_in = g2.T_virt = Tn; g2.stride = 1; g2.up_mode = UP_NONE;
-    g2.M = M; g2.N = cout; g2.out = out.p; g2.ldo = cout;
-    gemm(ops, g2, w2, K2);
-    release(a2.scale); release(a2.shift); release(h.p);
+    Act out{};
+    out.p = alloc((size_t)M * cout); out.C = cout; out.T = Tn; out.stat = alloc_stat(Tn, cout);
+    {
+      GemmParams g = gp_base(Tn, M, cout);
+      g.seg[0] = seg(n2, cout, Planes{}, 0, 3, 1);
+      if (shortcut) { g.seg[1] = seg(raw, cin, Planes{}, 0, 1, 0); g.nseg = 2; }
+      else { g.epi = EPI_RESIDUAL; g.res = x0.p; g.ldres = cout; }
+      g.out = out.p; g.stats = out.stat;
+      gemm(ops, g, w2, K2);
+    }
+    release(n2);
+    if (shortcut) release(raw);
     probe(p.substr(0, p.size() - 1), out.p, Tn, cout);
     return out;
   }
@@ -390,19 +449,12 @@ struct Builder {
   std::map<std::string, float*> cross_kv;
   float* mask_bias = nullptr;    // [B, L]
 
-  struct Stats { float* mean; float* rstd; };
-  Stats ln_stats(std::vector<OpFn>& ops, Act x) {
-    const int M = B * x.T, C = x.C;
-    Stats s{alloc((size_t)M), alloc((size_t)M)};
-    cur_kind = "ln_stats";
-    emit(ops, [=](hipStream_t st) { return launch_ln_stats(x.p, s.mean, s.rstd, M, C, 1e-5f, st); });
-    return s;
-  }
-
-  void attention(std::vector<OpFn>& ops, const float* q, int ldq, const float* k, const float* v, int ldkv, const float* bias,
-                 float* o, int ldo, int Tq, int Tk, int C) {
+  Planes attention(std::vector<OpFn>& ops, const float* q, int ldq, const float* k, const float* v, int ldkv, const float* bias,
+                   int Tq, int Tk, int C) {
+    Planes o = alloc_planes((size_t)B * Tq * C);
     AttnParams a{};
-    a.q = q; a.k = k; a.v = v; a.bias = bias; a.o = o; a.ldq = ldq; a.ldk = ldkv; a.ldv = ldkv; a.ldo = ldo;
+    a.q = q; a.k = k; a.v = v; a.bias = bias; a.o = nullptr; a.o_hi = o.hi; a.o_lo = o.lo;
+    a.ldq = ldq; a.ldk = ldkv; a.ldv = ldkv; a.ldo = C;
     a.B = B; a.H = u->cfg.num_heads; a.Tq = Tq; a.Tk = Tk; a.d = C / u->cfg.num_heads;
     a.scale = 1.0f / sqrtf((float)a.d);
     cur_kind = "attn"; cur_flops = 4.0 * B * a.H * (double)Tq * Tk * a.d;
@@ -413,20 +465,13 @@ struct Builder {
     }
     if (!dry) u->flops += cur_flops;
     emit(ops, [a](hipStream_t st) { return launch_attention(a, st); });
+    return o;
   }
 
-  GemmParams lin(Act x, int pro, const float* p0, const float* p1, int N, int epi, const float* res, float* out, int ldo) {
-    GemmParams g{};
-    g.seg[0] = seg(x, Act{}, 1, 0, pro, p0, p1);
-    g.nseg = 1; g.T_out = g.T_in = g.T_virt = x.T; g.stride = 1; g.up_mode = UP_NONE;
-    g.M = B * x.T; g.N = N; g.epi = epi; g.res = res; g.ldres = N; g.out = out; g.ldo = ldo;
-    return g;
-  }
-
+  // Transformer2DModel + BasicTransformerBlock (reference transformer_1d.py:191-326, attention.py:130-203)
   Act transformer(std::vector<OpFn>& ops, const std::string& p, Act x) {
     const int C = x.C, Tn = x.T, M = B * Tn, D = u->cfg.cross_attention_dim;
     const std::string tb = p + "transformer_blocks.0.";
-    Affine ga = gn_affine(ops, x, Act{}, p + "norm", 1e-6f, nullptr, nullptr, 0);
     const PackedW* w_in = pack(p + "proj_in", C, C, {{p + "proj_in.weight", 1, C, 1, C, 0, 0, "", 0}},
                                {{p + "proj_in.bias", "", "", "", C, 0, 0, 0}});
     const PackedW* w_qkv = pack(tb + "qkv1", 3 * C, C,
@@ -451,75 +496,99 @@ struct Builder {
     if (!w_in || !w_qkv || !w_o1 || !w_q2 || !w_o2 || !w_gg || !w_ff || !w_out) return Act{};
     (void)D;
 
-    Act h{alloc((size_t)M * C), C, Tn};
-    gemm(ops, lin(x, PRO_AFFINE, ga.scale, ga.shift, C, EPI_STORE, nullptr, h.p, C), w_in, C);
-    release(ga.scale); release(ga.shift);
-    probe(p + "proj_in", h.p, Tn, C);
+    // GN(eps 1e-6) -> 1x1 proj_in
+    Planes gn = norm_apply(ops, x, Act{}, p + "norm", 1e-6f, nullptr, nullptr, 0, false, nullptr);
+    float* h = alloc((size_t)M * C);
+    { GemmParams g = gp_base(Tn, M, C); g.seg[0] = seg(gn, C, Planes{}, 0, 1, 0); g.out = h; gemm(ops, g, w_in, C); }
+    release(gn);
+    probe(p + "proj_in", h, Tn, C);
 
     // self-attention
-    Stats s1 = ln_stats(ops, h);
+    Planes l1 = ln_apply(ops, h, M, C);
     float* qkv = alloc((size_t)M * 3 * C);
-    gemm(ops, lin(h, PRO_LN, s1.mean, s1.rstd, 3 * C, EPI_STORE, nullptr, qkv, 3 * C), w_qkv, C);
-    release(s1.mean); release(s1.rstd);
-    float* ao = alloc((size_t)M * C);
-    attention(ops, qkv, 3 * C, qkv + C, qkv + 2 * C, 3 * C, nullptr, ao, C, Tn, Tn, C);
+    { GemmParams g = gp_base(Tn, M, 3 * C); g.seg[0] = seg(l1, C, Planes{}, 0, 1, 0); g.out = qkv; gemm(ops, g, w_qkv, C); }
+    release(l1);
+    Planes ao = attention(ops, qkv, 3 * C, qkv + C, qkv + 2 * C, 3 * C, nullptr, Tn, Tn, C);
     release(qkv);
-    Act h2{alloc((size_t)M * C), C, Tn};
-    gemm(ops, lin(Act{ao, C, Tn}, PRO_NONE, nullptr, nullptr, C, EPI_RESIDUAL, h.p, h2.p, C), w_o1, C);
-    release(ao); release(h.p);
-    probe(tb + "attn1", h2.p, Tn, C);
+    float* h2 = alloc((size_t)M * C);
+    {
+      GemmParams g = gp_base(Tn, M, C); g.seg[0] = seg(ao, C, Planes{}, 0, 1, 0);
+      g.epi = EPI_RESIDUAL; g.res = h; g.out = h2; gemm(ops, g, w_o1, C);
+    }
+    release(ao); release(h);
+    probe(tb + "attn1", h2, Tn, C);
 
     // cross-attention (K/V hoisted: projected once per set_cond)
-    Stats s2 = ln_stats(ops, h2);
+    Planes l2 = ln_apply(ops, h2, M, C);
     float* q2 = alloc((size_t)M * C);
-    gemm(ops, lin(h2, PRO_LN, s2.mean, s2.rstd, C, EPI_STORE, nullptr, q2, C), w_q2, C);
-    release(s2.mean); release(s2.rstd);
+    { GemmParams g = gp_base(Tn, M, C); g.seg[0] = seg(l2, C, Planes{}, 0, 1, 0); g.out = q2; gemm(ops, g, w_q2, C); }
+    release(l2);
     float* kv = cross_kv[p];
-    ao = alloc((size_t)M * C);
-    attention(ops, q2, C, kv, kv + C, 2 * C, mask_bias, ao, C, Tn, L, C);
+    ao = attention(ops, q2, C, kv, kv + C, 2 * C, mask_bias, Tn, L, C);
     release(q2);
-    Act h3{alloc((size_t)M * C), C, Tn};
-    gemm(ops, lin(Act{ao, C, Tn}, PRO_NONE, nullptr, nullptr, C, EPI_RESIDUAL, h2.p, h3.p, C), w_o2, C);
-    release(ao); release(h2.p);
-    probe(tb + "attn2", h3.p, Tn, C);
+    float* h3 = alloc((size_t)M * C);
+    {
+      GemmParams g = gp_base(Tn, M, C); g.seg[0] = seg(ao, C, Planes{}, 0, 1, 0);
+      g.epi = EPI_RESIDUAL; g.res = h2; g.out = h3; gemm(ops, g, w_o2, C);
+    }
+    release(ao); release(h2);
+    probe(tb + "attn2", h3, Tn, C);
 
-    // GEGLU feed-forward
-    Stats s3 = ln_stats(ops, h3);
-    float* gg = alloc((size_t)M * 4 * C);
-    gemm(ops, lin(h3, PRO_LN, s3.mean, s3.rstd, 8 * C, EPI_GEGLU, nullptr, gg, 4 * C), w_gg, C);
-    release(s3.mean); release(s3.rstd);
-    Act h4{alloc((size_t)M * C), C, Tn};
-    gemm(ops, lin(Act{gg, 4 * C, Tn}, PRO_NONE, nullptr, nullptr, C, EPI_RESIDUAL, h3.p, h4.p, C), w_ff, 4 * C);
-    release(gg); release(h3.p);
-    probe(tb + "ff", h4.p, Tn, C);
+    // GEGLU feed-forward: the GEGLU product and the FF output only feed GEMMs -> split planes only
+    Planes l3 = ln_apply(ops, h3, M, C);
+    Planes gg = alloc_planes((size_t)M * 4 * C);
+    {
+      GemmParams g = gp_base(Tn, M, 8 * C); g.seg[0] = seg(l3, C, Planes{}, 0, 1, 0);
+      g.epi = EPI_GEGLU; g.out_hi = gg.hi; g.out_lo = gg.lo; g.ldo = 4 * C; gemm(ops, g, w_gg, C);
+    }
+    release(l3);
+    Planes h4 = alloc_planes((size_t)M * C);
+    float* h4f = u->keep_intermediates ? alloc((size_t)M * C) : nullptr;
+    {
+      GemmParams g = gp_base(Tn, M, C); g.seg[0] = seg(gg, 4 * C, Planes{}, 0, 1, 0);
+      g.epi = EPI_RESIDUAL; g.res = h3; g.out = h4f; g.out_hi = h4.hi; g.out_lo = h4.lo; gemm(ops, g, w_ff, 4 * C);
+    }
+    release(gg); release(h3);
+    if (h4f) probe(tb + "ff", h4f, Tn, C);
 
-    Act out{alloc((size_t)M * C), C, Tn};
-    gemm(ops, lin(h4, PRO_NONE, nullptr, nullptr, C, EPI_RESIDUAL, x.p, out.p, C), w_out, C);
-    release(h4.p);
+    Act out{};
+    out.p = alloc((size_t)M * C); out.C = C; out.T = Tn; out.stat = alloc_stat(Tn, C);
+    {
+      GemmParams g = gp_base(Tn, M, C); g.seg[0] = seg(h4, C, Planes{}, 0, 1, 0);
+      g.epi = EPI_RESIDUAL; g.res = x.p; g.out = out.p; g.stats = out.stat; gemm(ops, g, w_out, C);
+    }
+    release(h4);
     probe(p.substr(0, p.size() - 1), out.p, Tn, C);
     return out;
   }
 
+  // Downsample2D / Upsample2D (reference resnet.py:138-223): stride-2 conv, or nearest upsample folded
+  // into the conv's row gather
   Act resample(std::vector<OpFn>& ops, const std::string& p, Act x, bool down, int T_target) {
     const int C = x.C;
     const PackedW* w = pack(p + "conv", C, 3 * C, {{p + "conv.weight", 1, C, 3, C, 0, 0, "", 0}},
                             {{p + "conv.bias", "", "", "", C, 0, 0, 0}});
     if (!w) return Act{};
-    GemmParams g{};
-    g.seg[0] = seg(x, Act{}, 3, 1, PRO_NONE, nullptr, nullptr);
-    g.nseg = 1; g.T_in = x.T;
+    Planes xs = split(ops, x.p, (size_t)B * x.T * C);
+    GemmParams g = gp_base(x.T, 0, C);
+    g.seg[0] = seg(xs, C, Planes{}, 0, 3, 1);
+    g.T_in = x.T;
     if (down) { g.T_virt = x.T; g.stride = 2; g.up_mode = UP_NONE; g.T_out = (x.T + 2 - 3) / 2 + 1; }
     else {
       g.stride = 1; g.T_out = g.T_virt = T_target;
       if (u->force_up) { g.up_mode = UP_SIZE; g.up_scale = (float)x.T / (float)T_target; }
       else g.up_mode = UP_X2;
     }
-    Act out{alloc((size_t)B * g.T_out * C), C, g.T_out};
-    g.M = B * g.T_out; g.N = C; g.epi = EPI_STORE; g.out = out.p; g.ldo = C;
+    Act out{};
+    out.p = alloc((size_t)B * g.T_out * C); out.C = C; out.T = g.T_out; out.stat = alloc_stat(g.T_out, C);
+    g.M = B * g.T_out; g.out = out.p; g.stats = out.stat;
     gemm(ops, g, w, 3 * C);
+    release(xs);
     probe(p.substr(0, p.size() - 1), out.p, g.T_out, C);
     return out;
   }
+
+  void release_act(const Act& a) { if (a.p) release(a.p); if (a.stat) release(a.stat); }
 
   // ---- whole network
   int build() {
@@ -556,6 +625,13 @@ struct Builder {
         (void)hipMemcpyAsync(Wt + (size_t)tproj_off[r.first] * E, w->p, w->numel * 4, hipMemcpyDeviceToDevice, pack_stream);
         (void)hipMemcpyAsync(bt + tproj_off[r.first], b->p, b->numel * 4, hipMemcpyDeviceToDevice, pack_stream);
       }
+      if (!u->zero_page) {
+        void* z = nullptr;
+        if (hipMalloc(&z, 256) != hipSuccess) return dv_fail(DV_ERR_HIP, "hipMalloc(zero page) failed");
+        (void)hipMemsetAsync(z, 0, 256, pack_stream);
+        u->owned.push_back(z);
+        u->zero_page = reinterpret_cast<bf16_t*>(z);
+      }
     }
 
     // ---------- persistent buffers (live across calls: allocated first, never released) ----------
@@ -587,8 +663,14 @@ struct Builder {
                                 {{a + "pool.k_proj.weight", 0, D, 1, D, 0, 0, "", 0}, {a + "pool.v_proj.weight", 0, D, 1, D, 0, D, "", 0}},
                                 {{a + "pool.k_proj.bias", "", "", "", D, 0, 0, 0}, {a + "pool.v_proj.bias", "", "", "", D, 0, D, 0}});
       if (!wkv) return dv_fail(DV_ERR_MISSING_WEIGHT, "%s", err.c_str());
+      Planes seqs = split(K, seq, (size_t)B * (L + 1) * D);
       float* kvp = alloc((size_t)B * (L + 1) * 2 * D);
-      gemm(K, lin(Act{seq, D, L + 1}, PRO_NONE, nullptr, nullptr, 2 * D, EPI_STORE, nullptr, kvp, 2 * D), wkv, D);
+      {
+        GemmParams g = gp_base(L + 1, B * (L + 1), 2 * D);
+        g.seg[0] = seg(seqs, D, Planes{}, 0, 1, 0);
+        g.out = kvp;
+        gemm(K, g, wkv, D);
+      }
       float* qp = alloc((size_t)B * D);
       const float* wq = W(a + "pool.q_proj.weight"); const float* bq = W(a + "pool.q_proj.bias");
       emit(K, [=](hipStream_t st) { return launch_small_linear(seq, (Ln + 1) * D, wq, bq, nullptr, qp, D, Bn, D, D, 0, 0, st); });
@@ -600,25 +682,22 @@ struct Builder {
       emit(K, [=](hipStream_t st) { return launch_small_linear(pooled, D, wp, bp, nullptr, pe, E, Bn, D, E, 0, 0, st); });
       const float* n2w = W(a + "norm2.weight"); const float* n2b = W(a + "norm2.bias");
       emit(K, [=](hipStream_t st) { return launch_layernorm_rows(pe, n2w, n2b, aug_emb, Bn, E, 1e-5f, st); });
-      release(seq); release(kvp); release(qp); release(pooled); release(pe);
-      // cross-attention K/V projections of every transformer block
+      release(seq); release(seqs); release(kvp); release(qp); release(pooled); release(pe);
+      // cross-attention K/V projections of every transformer block: split the encoder states once
+      Planes encs = alloc_planes((size_t)B * L * D);
+      emit(K, [=](hipStream_t st) { return launch_split(uu->io.enc, encs.hi, encs.lo, (int64_t)Bn * Ln * D, st); });
       for (auto& x : xformers) {
         const std::string tb = x.first + "transformer_blocks.0.";
         const int C = x.second;
         const PackedW* w = pack(tb + "kv2", 2 * C, D,
                                 {{tb + "attn2.to_k.weight", 0, D, 1, D, 0, 0, "", 0}, {tb + "attn2.to_v.weight", 0, D, 1, D, 0, C, "", 0}}, {});
         if (!w) return dv_fail(DV_ERR_MISSING_WEIGHT, "%s", err.c_str());
-        GemmParams g{};
-        g.seg[0].a0 = nullptr;   // patched at enqueue time from io.enc
-        g.seg[0].c0 = D; g.seg[0].taps = 1; g.seg[0].pro = PRO_NONE;
-        g.nseg = 1; g.T_out = g.T_in = g.T_virt = L; g.stride = 1; g.up_mode = UP_NONE;
-        g.M = B * L; g.N = 2 * C; g.epi = EPI_STORE; g.out = cross_kv[x.first]; g.ldo = 2 * C;
-        g.w_hi = w->hi; g.w_lo = w->lo; g.Kp = w->Kp; g.N_pad = w->N_pad; g.bias = nullptr; g.B = B;
-        g.seg[0].nkt = D / 32;
-        const int pr = prec;
-        if (!dry) u->flops += 0;   // step-invariant: not counted per forward
-        emit(K, [g, pr, uu](hipStream_t st) { GemmParams gg = g; gg.seg[0].a0 = uu->io.enc; return launch_gemm(gg, pr, st); });
+        GemmParams g = gp_base(L, B * L, 2 * C);
+        g.seg[0] = seg(encs, D, Planes{}, 0, 1, 0);
+        g.out = cross_kv[x.first];
+        gemm(K, g, w, D);
       }
+      release(encs);
     }
 
     // ---------- step schedule ----------
@@ -639,22 +718,22 @@ struct Builder {
       probe("emb", emb, 1, E);
     }
     const int cin = c.in_channels, cpad = rup(cin, 32);
-    Act xin{alloc((size_t)B * T * cpad), cpad, T};
+    Planes xin = alloc_planes((size_t)B * T * cpad);
     emit(S, [=](hipStream_t st) {
-      return launch_pack_input(uu->io.x, uu->io.cx, uu->io.cond, cin - uu->io.cx, xin.p, cpad, Bn, Tn, st);
+      return launch_pack_input(uu->io.x, uu->io.cx, uu->io.cond, cin - uu->io.cx, xin.hi, xin.lo, cpad, Bn, Tn, st);
     });
     const PackedW* wci = pack("conv_in", C0, 3 * cpad, {{"conv_in.weight", 1, cin, 3, cpad, 0, 0, "", 0}},
                               {{"conv_in.bias", "", "", "", C0, 0, 0, 0}});
     if (!wci) return dv_fail(DV_ERR_MISSING_WEIGHT, "%s", err.c_str());
-    Act h{alloc((size_t)B * T * C0), C0, T};
+    Act h{};
+    h.p = alloc((size_t)B * T * C0); h.C = C0; h.T = T; h.stat = alloc_stat(T, C0);
     {
-      GemmParams g{};
-      g.seg[0] = seg(xin, Act{}, 3, 1, PRO_NONE, nullptr, nullptr);
-      g.nseg = 1; g.T_out = g.T_in = g.T_virt = T; g.stride = 1; g.up_mode = UP_NONE;
-      g.M = B * T; g.N = C0; g.epi = EPI_STORE; g.out = h.p; g.ldo = C0;
+      GemmParams g = gp_base(T, B * T, C0);
+      g.seg[0] = seg(xin, cpad, Planes{}, 0, 3, 1);
+      g.out = h.p; g.stats = h.stat;
       gemm(S, g, wci, 3 * cin);
     }
-    release(xin.p);
+    release(xin);
     probe("conv_in", h.p, T, C0);
 
     std::vector<Act> skips{h};
@@ -667,7 +746,7 @@ struct Builder {
         if (attn) {
           Act a = transformer(S, bp + "attentions." + std::to_string(j) + ".", r);
           if (!a.p) return dv_fail(DV_ERR_MISSING_WEIGHT, "%s", err.c_str());
-          release(r.p);
+          release_act(r);
           r = a;
         }
         h = r;
@@ -684,12 +763,11 @@ struct Builder {
       if (!r0.p) return dv_fail(DV_ERR_MISSING_WEIGHT, "%s", err.c_str());
       Act a = transformer(S, "mid_block.attentions.0.", r0);
       if (!a.p) return dv_fail(DV_ERR_MISSING_WEIGHT, "%s", err.c_str());
-      release(r0.p);
+      release_act(r0);
       h = resnet(S, "mid_block.resnets.1.", a, Act{}, a.C);
       if (!h.p) return dv_fail(DV_ERR_MISSING_WEIGHT, "%s", err.c_str());
-      release(a.p);
+      release_act(a);
     }
-    bool h_is_skip = false;   // the mid output is not a skip tensor
     for (int i = 0; i < n; ++i) {
       const std::string bp = "up_blocks." + std::to_string(i) + ".";
       const bool attn = i > 0, last = i == n - 1;
@@ -699,42 +777,42 @@ struct Builder {
         skips.pop_back();
         Act r = resnet(S, bp + "resnets." + std::to_string(j) + ".", h, sk, cout);
         if (!r.p) return dv_fail(DV_ERR_MISSING_WEIGHT, "%s", err.c_str());
-        if (!h_is_skip) release(h.p);
-        release(sk.p);
+        release_act(h);
+        release_act(sk);
         if (attn) {
           Act a = transformer(S, bp + "attentions." + std::to_string(j) + ".", r);
           if (!a.p) return dv_fail(DV_ERR_MISSING_WEIGHT, "%s", err.c_str());
-          release(r.p);
+          release_act(r);
           r = a;
         }
         h = r;
-        h_is_skip = false;
       }
       if (!last) {
         Act up = resample(S, bp + "upsamplers.0.", h, false, skips.back().T);
         if (!up.p) return dv_fail(DV_ERR_MISSING_WEIGHT, "%s", err.c_str());
-        release(h.p);
+        release_act(h);
         h = up;
       }
     }
     // conv_norm_out -> SiLU -> conv_out, written channels-first straight into y
     {
-      Affine af = gn_affine(S, h, Act{}, "conv_norm_out", c.norm_eps, nullptr, nullptr, 0);
+      Planes nf = norm_apply(S, h, Act{}, "conv_norm_out", c.norm_eps, nullptr, nullptr, 0, true, nullptr);
+      release_act(h);
       const int co = c.out_channels;
       const PackedW* wo = pack("conv_out", co, 3 * C0, {{"conv_out.weight", 1, C0, 3, C0, 0, 0, "", 0}},
                                {{"conv_out.bias", "", "", "", co, 0, 0, 0}});
       if (!wo) return dv_fail(DV_ERR_MISSING_WEIGHT, "%s", err.c_str());
-      GemmParams g{};
-      g.seg[0] = seg(h, Act{}, 3, 1, PRO_AFFINE_SILU, af.scale, af.shift);
-      g.nseg = 1; g.T_out = g.T_in = g.T_virt = T; g.stride = 1; g.up_mode = UP_NONE;
-      g.M = B * T; g.N = co; g.epi = EPI_STORE_NCT; g.out = nullptr; g.ldo = co;
+      GemmParams g = gp_base(T, B * T, co);
+      g.seg[0] = seg(nf, C0, Planes{}, 0, 3, 1);
+      g.epi = EPI_STORE_NCT; g.ldo = co;
       g.w_hi = wo->hi; g.w_lo = wo->lo; g.Kp = wo->Kp; g.N_pad = wo->N_pad; g.bias = wo->bias; g.B = B;
-      g.seg[0].nkt = 3 * C0 / 32;
+      g.zero_page = u->zero_page;
       const int pr = prec;
       cur_kind = "gemm"; cur_flops = 2.0 * g.M * (double)co * 3 * C0;
+      cur_desc = "conv_out (NCT store)";
       if (!dry) u->flops += cur_flops;
       emit(S, [g, pr, uu](hipStream_t st) { GemmParams gg = g; gg.out = uu->io.y; return launch_gemm(gg, pr, st); });
-      release(af.scale); release(af.shift); release(h.p);
+      release(nf);
     }
     if (!err.empty()) return dv_fail(DV_ERR_MISSING_WEIGHT, "%s", err.c_str());
     return DV_OK;
@@ -879,27 +957,39 @@ extern "C" int dv_unet_probe(dv_unet* u, const char* name, float* host_out, int6
 }
 
 // ----------------------------------------------------------------------------- single-operator entry points
+// scratch for the single-operator entry points
+struct OpScratch {
+  std::vector<void*> ptrs;
+  ~OpScratch() { for (void* p : ptrs) (void)hipFree(p); }
+  template <typename T> T* get(size_t bytes, hipStream_t st, bool zero) {
+    void* p = nullptr;
+    if (hipMalloc(&p, bytes ? bytes : 16) != hipSuccess) return nullptr;
+    ptrs.push_back(p);
+    if (zero) (void)hipMemsetAsync(p, 0, bytes ? bytes : 16, st);
+    return reinterpret_cast<T*>(p);
+  }
+};
+
 extern "C" int dv_op_conv1d(const float* x, const float* w, const float* bias, float* y, int32_t B, int32_t Cin, int32_t T,
                             int32_t Cout, int32_t k, int32_t stride, int32_t up_T, int32_t precision, void* stream) {
   if (!x || !w || !y || (k != 1 && k != 3) || (stride != 1 && stride != 2)) return dv_fail(DV_ERR_INVALID, "dv_op_conv1d: bad argument");
   hipStream_t st = (hipStream_t)stream;
   HIPCHK(gemm_init());
+  const bool x3 = precision == DV_PREC_BF16X3;
   const int cpad = rup(Cin, 32), Kp = k * cpad, Npad = rup(Cout, 128);
-  float* xin = nullptr; bf16_t* hi = nullptr; bf16_t* lo = nullptr;
-  HIPCHK(hipMalloc((void**)&xin, (size_t)B * T * cpad * 4));
-  HIPCHK(hipMalloc((void**)&hi, (size_t)Npad * Kp * 2));
-  HIPCHK(hipMemsetAsync(hi, 0, (size_t)Npad * Kp * 2, st));
-  if (precision == DV_PREC_BF16X3) {
-    HIPCHK(hipMalloc((void**)&lo, (size_t)Npad * Kp * 2));
-    HIPCHK(hipMemsetAsync(lo, 0, (size_t)Npad * Kp * 2, st));
-  }
-  HIPCHK(launch_pack_input(x, Cin, nullptr, 0, xin, cpad, B, T, st));
+  OpScratch sc;
+  bf16_t* xh = sc.get<bf16_t>((size_t)B * T * cpad * 2, st, false);
+  bf16_t* xl = x3 ? sc.get<bf16_t>((size_t)B * T * cpad * 2, st, false) : nullptr;
+  bf16_t* hi = sc.get<bf16_t>((size_t)Npad * Kp * 2, st, true);
+  bf16_t* lo = x3 ? sc.get<bf16_t>((size_t)Npad * Kp * 2, st, true) : nullptr;
+  bf16_t* zp = sc.get<bf16_t>(256, st, true);
+  if (!xh || !hi || !zp || (x3 && (!xl || !lo))) return dv_fail(DV_ERR_HIP, "dv_op_conv1d: hipMalloc failed");
+  HIPCHK(launch_pack_input(x, Cin, nullptr, 0, xh, xl, cpad, B, T, st));
   PackSpec s{};
   s.src = w; s.N = Cout; s.kind = 1; s.C = Cin; s.taps = k; s.c_pad = cpad; s.k_off = 0; s.n_off = 0;
   HIPCHK(launch_pack_weight(s, hi, lo, Kp, st));
   GemmParams g{};
-  g.seg[0].a0 = xin; g.seg[0].c0 = cpad; g.seg[0].taps = k; g.seg[0].pad = (k - 1) / 2; g.seg[0].pro = PRO_NONE;
-  g.seg[0].nkt = k * cpad / 32;
+  g.seg[0].a0_hi = xh; g.seg[0].a0_lo = xl; g.seg[0].c0 = cpad; g.seg[0].taps = k; g.seg[0].pad = (k - 1) / 2;
   g.nseg = 1; g.B = B; g.T_in = T;
   g.T_virt = up_T > 0 ? up_T : T;
   g.up_mode = up_T > 0 ? UP_SIZE : UP_NONE;
@@ -907,10 +997,9 @@ extern "C" int dv_op_conv1d(const float* x, const float* w, const float* bias, f
   g.stride = stride;
   g.T_out = (g.T_virt + 2 * g.seg[0].pad - k) / stride + 1;
   g.w_hi = hi; g.w_lo = lo; g.Kp = Kp; g.N_pad = Npad; g.bias = bias;
-  g.M = B * g.T_out; g.N = Cout; g.epi = EPI_STORE_NCT; g.out = y; g.ldo = Cout;
+  g.M = B * g.T_out; g.N = Cout; g.epi = EPI_STORE_NCT; g.out = y; g.ldo = Cout; g.zero_page = zp;
   HIPCHK(launch_gemm(g, precision, st));
   HIPCHK(hipStreamSynchronize(st));
-  (void)hipFree(xin); (void)hipFree(hi); if (lo) (void)hipFree(lo);
   return DV_OK;
 }
 
@@ -919,25 +1008,26 @@ extern "C" int dv_op_linear(const float* x, const float* w, const float* bias, f
   if (!x || !w || !y || K % 32 != 0) return dv_fail(DV_ERR_INVALID, "dv_op_linear: K must be a multiple of 32");
   hipStream_t st = (hipStream_t)stream;
   HIPCHK(gemm_init());
+  const bool x3 = precision == DV_PREC_BF16X3;
   const int Npad = rup(N, 128);
-  bf16_t* hi = nullptr; bf16_t* lo = nullptr;
-  HIPCHK(hipMalloc((void**)&hi, (size_t)Npad * K * 2));
-  HIPCHK(hipMemsetAsync(hi, 0, (size_t)Npad * K * 2, st));
-  if (precision == DV_PREC_BF16X3) {
-    HIPCHK(hipMalloc((void**)&lo, (size_t)Npad * K * 2));
-    HIPCHK(hipMemsetAsync(lo, 0, (size_t)Npad * K * 2, st));
-  }
+  OpScratch sc;
+  bf16_t* xh = sc.get<bf16_t>((size_t)M * K * 2, st, false);
+  bf16_t* xl = x3 ? sc.get<bf16_t>((size_t)M * K * 2, st, false) : nullptr;
+  bf16_t* hi = sc.get<bf16_t>((size_t)Npad * K * 2, st, true);
+  bf16_t* lo = x3 ? sc.get<bf16_t>((size_t)Npad * K * 2, st, true) : nullptr;
+  bf16_t* zp = sc.get<bf16_t>(256, st, true);
+  if (!xh || !hi || !zp || (x3 && (!xl || !lo))) return dv_fail(DV_ERR_HIP, "dv_op_linear: hipMalloc failed");
+  HIPCHK(launch_split(x, xh, xl, (int64_t)M * K, st));
   PackSpec s{};
   s.src = w; s.N = N; s.kind = 0; s.C = K; s.taps = 1; s.c_pad = K;
   HIPCHK(launch_pack_weight(s, hi, lo, K, st));
   GemmParams g{};
-  g.seg[0].a0 = x; g.seg[0].c0 = K; g.seg[0].taps = 1; g.seg[0].pro = PRO_NONE; g.seg[0].nkt = K / 32;
+  g.seg[0].a0_hi = xh; g.seg[0].a0_lo = xl; g.seg[0].c0 = K; g.seg[0].taps = 1;
   g.nseg = 1; g.B = 1; g.T_in = g.T_out = g.T_virt = M; g.stride = 1;
   g.w_hi = hi; g.w_lo = lo; g.Kp = K; g.N_pad = Npad; g.bias = bias;
-  g.M = M; g.N = N; g.epi = EPI_STORE; g.out = y; g.ldo = N;
+  g.M = M; g.N = N; g.epi = EPI_STORE; g.out = y; g.ldo = N; g.zero_page = zp;
   HIPCHK(launch_gemm(g, precision, st));
   HIPCHK(hipStreamSynchronize(st));
-  (void)hipFree(hi); if (lo) (void)hipFree(lo);
   return DV_OK;
 }
 
@@ -960,7 +1050,7 @@ extern "C" int dv_op_attention(const float* q, const float* k, const float* v, c
                                int32_t H, int32_t Tq, int32_t Tk, int32_t d, void* stream) {
   if (!q || !k || !v || !o) return dv_fail(DV_ERR_INVALID, "dv_op_attention: null argument");
   AttnParams a{};
-  a.q = q; a.k = k; a.v = v; a.bias = bias; a.o = o;
+  a.q = q; a.k = k; a.v = v; a.bias = bias; a.o = o; a.o_hi = nullptr; a.o_lo = nullptr;
   a.ldq = a.ldk = a.ldv = a.ldo = H * d;
   a.B = B; a.H = H; a.Tq = Tq; a.Tk = Tk; a.d = d; a.scale = 1.0f / sqrtf((float)d);
   hipError_t e = launch_attention(a, (hipStream_t)stream);

@@ -126,16 +126,29 @@ __global__ __launch_bounds__(64 * NW) void k_attention(const AttnParams p) {
   const float l_tot = l_run + __shfl_xor(l_run, 32);
   const float inv = 1.0f / l_tot;
   if (q_ok) {
-    float* op = p.o + ((size_t)b * p.Tq + qi) * p.ldo + h * d;
+    const size_t obase = ((size_t)b * p.Tq + qi) * p.ldo + h * d;
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const int dv = nb * 32 + 8 * g + 4 * lh;
         if (dv < d) {
-          float4 v = make_float4(o[nb][4 * g] * inv, o[nb][4 * g + 1] * inv, o[nb][4 * g + 2] * inv,
-                                 o[nb][4 * g + 3] * inv);
-          *reinterpret_cast<float4*>(op + dv) = v;
+          const float4 v = make_float4(o[nb][4 * g] * inv, o[nb][4 * g + 1] * inv, o[nb][4 * g + 2] * inv,
+                                       o[nb][4 * g + 3] * inv);
+          if (p.o) *reinterpret_cast<float4*>(p.o + obase + dv) = v;
+          if (p.o_hi) {   // split bf16 planes for the to_out GEMM: hi = rne(v), lo = rne(v - hi)
+            uint2 hh, ll;
+            asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(hh.x) : "v"(v.x), "v"(v.y));
+            asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(hh.y) : "v"(v.z), "v"(v.w));
+            *reinterpret_cast<uint2*>(p.o_hi + obase + dv) = hh;
+            if (p.o_lo) {
+              const float rx = v.x - __uint_as_float(hh.x << 16), ry = v.y - __uint_as_float(hh.x & 0xffff0000u);
+              const float rz = v.z - __uint_as_float(hh.y << 16), rw = v.w - __uint_as_float(hh.y & 0xffff0000u);
+              asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(ll.x) : "v"(rx), "v"(ry));
+              asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(ll.y) : "v"(rz), "v"(rw));
+              *reinterpret_cast<uint2*>(p.o_lo + obase + dv) = ll;
+            }
+          }
         }
       }
   }

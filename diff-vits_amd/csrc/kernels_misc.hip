@@ -27,9 +27,28 @@ __device__ __forceinline__ float wave_max(float v) {
 // engine is channels-last.  32x32 LDS-transposed tiles: reads coalesced along T, writes
 // along C.
 // ---------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned pk_bf16(float lo, float hi) {
+  unsigned r;
+  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+  return r;
+}
+// 4 floats -> 4 bf16 hi (uint2) + 4 bf16 lo (uint2), hi = rne(x), lo = rne(x - hi)
+__device__ __forceinline__ void split4(const float4 v, uint2& hi, uint2& lo) {
+  hi.x = pk_bf16(v.x, v.y);
+  hi.y = pk_bf16(v.z, v.w);
+  lo.x = pk_bf16(v.x - __uint_as_float(hi.x << 16), v.y - __uint_as_float(hi.x & 0xffff0000u));
+  lo.y = pk_bf16(v.z - __uint_as_float(hi.y << 16), v.w - __uint_as_float(hi.y & 0xffff0000u));
+}
+__device__ __forceinline__ void split1(float v, bf16_t& hi, bf16_t& lo) {
+  const unsigned h = pk_bf16(v, 0.f);
+  hi = (bf16_t)(h & 0xffffu);
+  lo = (bf16_t)(pk_bf16(v - __uint_as_float(h << 16), 0.f) & 0xffffu);
+}
+
 __global__ __launch_bounds__(256) void k_pack_input(const float* __restrict__ x, int cx,
                                                      const float* __restrict__ cond, int cc,
-                                                     float* __restrict__ out, int cpad, int T) {
+                                                     bf16_t* __restrict__ out_hi, bf16_t* __restrict__ out_lo,
+                                                     int cpad, int T) {
   __shared__ float tile[32][33];
   const int b = blockIdx.z, c0 = blockIdx.y * 32, t0 = blockIdx.x * 32;
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // ty 0..7
@@ -47,14 +66,136 @@ __global__ __launch_bounds__(256) void k_pack_input(const float* __restrict__ x,
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int t = t0 + ty + i * 8, c = c0 + tx;
-    if (t < T && c < cpad) out[((size_t)b * T + t) * cpad + c] = tile[tx][ty + i * 8];
+    if (t < T && c < cpad) {
+      bf16_t h, l;
+      split1(tile[tx][ty + i * 8], h, l);
+      const size_t o = ((size_t)b * T + t) * cpad + c;
+      out_hi[o] = h;
+      if (out_lo) out_lo[o] = l;
+    }
   }
 }
 
-hipError_t launch_pack_input(const float* x, int cx, const float* cond, int cc, float* out, int cpad, int B, int T,
-                             hipStream_t st) {
+hipError_t launch_pack_input(const float* x, int cx, const float* cond, int cc, bf16_t* out_hi, bf16_t* out_lo, int cpad,
+                             int B, int T, hipStream_t st) {
   dim3 grid((T + 31) / 32, (cpad + 31) / 32, B);
-  hipLaunchKernelGGL(k_pack_input, grid, dim3(256), 0, st, x, cx, cond, cc, out, cpad, T);
+  hipLaunchKernelGGL(k_pack_input, grid, dim3(256), 0, st, x, cx, cond, cc, out_hi, out_lo, cpad, T);
+  return hipGetLastError();
+}
+
+__global__ void k_split(const float* __restrict__ in, bf16_t* __restrict__ hi, bf16_t* __restrict__ lo, int64_t n4) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+    uint2 h, l;
+    split4(reinterpret_cast<const float4*>(in)[i], h, l);
+    reinterpret_cast<uint2*>(hi)[i] = h;
+    if (lo) reinterpret_cast<uint2*>(lo)[i] = l;
+  }
+}
+hipError_t launch_split(const float* in, bf16_t* hi, bf16_t* lo, int64_t n, hipStream_t st) {
+  if (n % 4 != 0) return hipErrorInvalidValue;
+  const int64_t n4 = n / 4;
+  const int blocks = (int)((n4 + 255) / 256 < 4096 ? (n4 + 255) / 256 : 4096);
+  hipLaunchKernelGGL(k_split, dim3(blocks > 0 ? blocks : 1), dim3(256), 0, st, in, hi, lo, n4);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------
+// GroupNorm apply (reference F.group_norm + temb scale/shift + SiLU: resnet.py:594-631,
+// transformer_1d.py:257, unet_1d_condition.py:1030-1031) -> split bf16 planes for the consumer GEMM.
+// Each workgroup handles a run of frames of one batch item: (1) it derives the per-channel affine of
+// that batch item - from the producers' per-32-row-block column sums (fp64 reduction over row blocks
+// and over the group's channels) or from a precomputed table - into LDS; (2) it streams its rows:
+// y = act(x*scale + shift) -> hi/lo planes, 16-byte loads, 8-byte stores.
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_gn_apply(const GnApplyParams p, int rows_per_block) {
+  extern __shared__ float sm[];          // scale[ctot] | shift[ctot] | (double) group sums
+  const int ctot = p.c0 + p.c1, G = p.groups, cg = ctot / G;
+  float* s_scale = sm;
+  float* s_shift = sm + ctot;
+  double* s_gs = reinterpret_cast<double*>(sm + 2 * ctot);      // [G][2]
+  double* s_cs = s_gs + 2 * G;                                  // [ctot][2] per-channel sums
+  const int b = blockIdx.y, tid = threadIdx.x;
+  if (p.scale_in) {
+    for (int c = tid; c < ctot; c += 256) {
+      s_scale[c] = p.scale_in[(size_t)b * ctot + c];
+      s_shift[c] = p.shift_in[(size_t)b * ctot + c];
+    }
+  } else {
+    const int RB = p.T >> 5;             // 32-row blocks per batch item (T % 32 == 0)
+    for (int c = tid; c < ctot; c += 256) {
+      const bool first = c < p.c0;
+      const float2* slab = reinterpret_cast<const float2*>(first ? p.slab0 : p.slab1);
+      const int ld = first ? p.c0 : p.c1, cc = first ? c : c - p.c0;
+      double s1 = 0, s2 = 0;
+      for (int rb = 0; rb < RB; ++rb) {
+        const float2 v = slab[(size_t)(b * RB + rb) * ld + cc];
+        s1 += v.x;
+        s2 += v.y;
+      }
+      s_cs[2 * c] = s1;
+      s_cs[2 * c + 1] = s2;
+    }
+    __syncthreads();
+    if (tid < G) {
+      double s1 = 0, s2 = 0;
+      for (int c = tid * cg; c < (tid + 1) * cg; ++c) { s1 += s_cs[2 * c]; s2 += s_cs[2 * c + 1]; }
+      const double n = (double)cg * (double)p.T;
+      const double mean = s1 / n;
+      double var = s2 / n - mean * mean;
+      var = var > 0 ? var : 0;
+      s_gs[2 * tid] = mean;
+      s_gs[2 * tid + 1] = 1.0 / sqrt(var + (double)p.eps);
+    }
+    __syncthreads();
+    for (int c = tid; c < ctot; c += 256) {
+      const int g = c / cg;
+      const float a = (float)s_gs[2 * g + 1] * p.gamma[c];
+      const float sh = p.beta[c] - (float)s_gs[2 * g] * a;
+      const float ts = p.tscale ? 1.0f + p.tscale[(size_t)b * p.ld_t + c] : 1.0f;
+      const float tb = p.tshift ? p.tshift[(size_t)b * p.ld_t + c] : 0.0f;
+      s_scale[c] = a * ts;
+      s_shift[c] = fmaf(sh, ts, tb);
+    }
+  }
+  __syncthreads();
+  const int ncol4 = ctot >> 2;
+  const int t0 = blockIdx.x * rows_per_block, t1 = min(p.T, t0 + rows_per_block);
+  const int total = (t1 - t0) * ncol4;
+  for (int i = tid; i < total; i += 256) {
+    const int r = i / ncol4, j = i - r * ncol4, c = j * 4;
+    const size_t row = (size_t)b * p.T + t0 + r;
+    const bool first = c < p.c0;
+    const float4 v = *reinterpret_cast<const float4*>(first ? p.a0 + row * p.c0 + c : p.a1 + row * p.c1 + (c - p.c0));
+    const float4 sc = *reinterpret_cast<const float4*>(s_scale + c);
+    const float4 sh = *reinterpret_cast<const float4*>(s_shift + c);
+    float4 y;
+    y.x = fmaf(v.x, sc.x, sh.x); y.y = fmaf(v.y, sc.y, sh.y); y.z = fmaf(v.z, sc.z, sh.z); y.w = fmaf(v.w, sc.w, sh.w);
+    if (p.silu) {
+      y.x = y.x / (1.0f + __expf(-y.x)); y.y = y.y / (1.0f + __expf(-y.y));
+      y.z = y.z / (1.0f + __expf(-y.z)); y.w = y.w / (1.0f + __expf(-y.w));
+    }
+    uint2 h, l;
+    split4(y, h, l);
+    const size_t o = (row * ctot + c) >> 2;
+    reinterpret_cast<uint2*>(p.out_hi)[o] = h;
+    if (p.out_lo) reinterpret_cast<uint2*>(p.out_lo)[o] = l;
+    if (p.raw_hi) {
+      split4(v, h, l);
+      reinterpret_cast<uint2*>(p.raw_hi)[o] = h;
+      if (p.raw_lo) reinterpret_cast<uint2*>(p.raw_lo)[o] = l;
+    }
+  }
+}
+
+hipError_t launch_gn_apply(const GnApplyParams& p, hipStream_t st) {
+  const int ctot = p.c0 + p.c1;
+  if (ctot % 4 != 0 || p.c0 % 4 != 0 || ctot % p.groups != 0 || p.groups > 64) return hipErrorInvalidValue;
+  if (!p.scale_in && (p.T % 32 != 0 || !p.slab0 || (p.c1 && !p.slab1))) return hipErrorInvalidValue;
+  // ~64 KB of activations per workgroup
+  int rpb = (16384 + ctot - 1) / ctot;
+  rpb = rpb < 4 ? 4 : rpb;
+  const size_t smem = (size_t)2 * ctot * 4 + (size_t)(2 * p.groups + 2 * ctot) * 8;
+  hipLaunchKernelGGL(k_gn_apply, dim3((p.T + rpb - 1) / rpb, p.B), dim3(256), smem, st, p, rpb);
   return hipGetLastError();
 }
 
@@ -258,6 +399,58 @@ static hipError_t launch_layernorm_rows_ex(const float* x, const float* g, const
 hipError_t launch_layernorm_rows(const float* x, const float* g, const float* b, float* out, int M, int C,
                                  float eps, hipStream_t st) {
   return launch_layernorm_rows_ex(x, g, b, out, M, C, eps, M, M, 0, st);
+}
+
+// LayerNorm rows -> split planes (reference attention.py:157,176,189; gamma/beta live in the consumer
+// GEMM's packed weights/bias): one wave per row, two-pass statistics on register-resident values.
+__global__ __launch_bounds__(256) void k_ln_apply(const float* __restrict__ x, bf16_t* __restrict__ hi,
+                                                   bf16_t* __restrict__ lo, int M, int C, float eps) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (row >= M) return;
+  const float* xr = x + (size_t)row * C;
+  float4 v[8];
+  const int n4 = C >> 2;
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int j = lane + i * 64;
+    v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (j < n4) {
+      v[i] = *reinterpret_cast<const float4*>(xr + j * 4);
+      s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+    }
+  }
+  const float mu = wave_sum(s) / (float)C;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int j = lane + i * 64;
+    if (j < n4) {
+      const float a = v[i].x - mu, b = v[i].y - mu, c = v[i].z - mu, d = v[i].w - mu;
+      q += (a * a + b * b) + (c * c + d * d);
+    }
+  }
+  const float rs = 1.0f / sqrtf(wave_sum(q) / (float)C + eps);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int j = lane + i * 64;
+    if (j < n4) {
+      float4 y;
+      y.x = (v[i].x - mu) * rs; y.y = (v[i].y - mu) * rs; y.z = (v[i].z - mu) * rs; y.w = (v[i].w - mu) * rs;
+      uint2 h, l;
+      split4(y, h, l);
+      const size_t o = ((size_t)row * C >> 2) + j;
+      reinterpret_cast<uint2*>(hi)[o] = h;
+      if (lo) reinterpret_cast<uint2*>(lo)[o] = l;
+    }
+  }
+}
+
+hipError_t launch_ln_apply(const float* x, bf16_t* hi, bf16_t* lo, int M, int C, float eps, hipStream_t st) {
+  if (C % 4 != 0 || C > 2048) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(k_ln_apply, dim3((M + 3) / 4), dim3(256), 0, st, x, hi, lo, M, C, eps);
+  return hipGetLastError();
 }
 
 // ---------------------------------------------------------------------------------------
