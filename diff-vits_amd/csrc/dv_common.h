@@ -55,6 +55,7 @@ struct AttnParams {
   int ldq, ldk, ldv, ldo;       // row strides (floats); head h occupies columns [h*d, h*d+d)
   int B, H, Tq, Tk, d;
   float scale;
+  int nsplit;                   // 3: split-bf16 (hi*hi + lo*hi + hi*lo), 1: single bf16 product
 };
 
 // launchers (each enqueues on `st` and returns hipGetLastError())
@@ -83,6 +84,8 @@ struct GnApplyParams {
   int B, T;
 };
 hipError_t launch_gn_apply(const GnApplyParams& p, hipStream_t st);
+// slabs -> per-(batch, channel) scale/shift table [B, c0+c1]
+hipError_t launch_gn_table(const GnApplyParams& p, float* scale, float* shift, hipStream_t st);
 // LayerNorm rows (no affine: gamma/beta are folded into the consumer's weights) -> split planes
 hipError_t launch_ln_apply(const float* x, bf16_t* hi, bf16_t* lo, int M, int C, float eps, hipStream_t st);
 // GroupNorm statistics of the channel-concat [a0 | a1] -> part[B, nchunk, G, 2] (double sum, sumsq)

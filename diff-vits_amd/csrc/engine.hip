@@ -342,11 +342,16 @@ struct Builder {
     gp.B = B; gp.T = Tn;
     float* sc = nullptr; float* sh = nullptr;
     const bool fast = a0.stat && (a1.C == 0 || a1.stat);
-    if (fast) { gp.slab0 = a0.stat; gp.slab1 = a1.stat; }
-    else {
+    sc = alloc((size_t)B * C); sh = alloc((size_t)B * C);
+    if (fast) {
+      gp.slab0 = a0.stat; gp.slab1 = a1.stat;
+      GnApplyParams tp = gp;
+      cur_kind = "gn_table";
+      emit(ops, [tp, sc, sh](hipStream_t st) { return launch_gn_table(tp, sc, sh, st); });
+      gp.slab0 = gp.slab1 = nullptr;
+    } else {
       const int nchunk = std::max(1, std::min(64, (Tn + 63) / 64));
       double* part = reinterpret_cast<double*>(alloc((size_t)B * nchunk * G * 2 * 2));
-      sc = alloc((size_t)B * C); sh = alloc((size_t)B * C);
       const int Bn = B;
       const float* gamma = gp.gamma; const float* beta = gp.beta;
       cur_kind = "gn_partial";
@@ -356,8 +361,8 @@ struct Builder {
         return launch_gn_finalize(part, nchunk, gamma, beta, tscale, tshift, ld_t, sc, sh, nullptr, nullptr, Bn, Tn, C, G, eps, st);
       });
       release(part);
-      gp.scale_in = sc; gp.shift_in = sh;
     }
+    gp.scale_in = sc; gp.shift_in = sh;
     Planes out = alloc_planes((size_t)B * Tn * C);
     gp.out_hi = out.hi; gp.out_lo = out.lo;
     if (raw_out) { *raw_out = alloc_planes((size_t)B * Tn * C); gp.raw_hi = raw_out->hi; gp.raw_lo = raw_out->lo; }
@@ -457,6 +462,7 @@ struct Builder {
     a.ldq = ldq; a.ldk = ldkv; a.ldv = ldkv; a.ldo = C;
     a.B = B; a.H = u->cfg.num_heads; a.Tq = Tq; a.Tk = Tk; a.d = C / u->cfg.num_heads;
     a.scale = 1.0f / sqrtf((float)a.d);
+    a.nsplit = prec == DV_PREC_BF16X3 ? 3 : 1;
     cur_kind = "attn"; cur_flops = 4.0 * B * a.H * (double)Tq * Tk * a.d;
     {
       char buf[96];
@@ -1052,7 +1058,7 @@ extern "C" int dv_op_attention(const float* q, const float* k, const float* v, c
   AttnParams a{};
   a.q = q; a.k = k; a.v = v; a.bias = bias; a.o = o; a.o_hi = nullptr; a.o_lo = nullptr;
   a.ldq = a.ldk = a.ldv = a.ldo = H * d;
-  a.B = B; a.H = H; a.Tq = Tq; a.Tk = Tk; a.d = d; a.scale = 1.0f / sqrtf((float)d);
+  a.B = B; a.H = H; a.Tq = Tq; a.Tk = Tk; a.d = d; a.scale = 1.0f / sqrtf((float)d); a.nsplit = 3;
   hipError_t e = launch_attention(a, (hipStream_t)stream);
   if (e != hipSuccess) return dv_fail(DV_ERR_HIP, "attention launch failed: %s (d must be a multiple of 4, <= 64)", hipGetErrorString(e));
   return DV_OK;

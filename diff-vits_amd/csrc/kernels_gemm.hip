@@ -20,6 +20,9 @@
 //               squares of the result (GroupNorm statistics for the consumer, no extra pass)
 #include "dv_common.h"
 
+#include <cstdio>
+#include <cstdlib>
+
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 
@@ -323,14 +326,29 @@ hipError_t gemm_init() {
 // else 64x64.  GEGLU needs both halves of a 64-column block in one wave (FN == 2): 128x128 or
 // 128x64 (4x1 waves).  BK = 64 (128-byte rows, half the barriers) for the 64-row tiles whenever
 // every K-segment's channel counts are multiples of 64.
+// Tunables (env DVITS_GEMM_CFG="big,mid,bk64"): workgroup-count thresholds for the 128x128 and 128x64
+// tiles and whether 64-deep k-tiles are used when the channel counts allow.
+struct GemmTune { int big = 384, mid = 1 << 30, bk64 = 1; };
+static const GemmTune& gemm_tune() {
+  static GemmTune t = [] {
+    GemmTune v;
+    if (const char* e = getenv("DVITS_GEMM_CFG")) sscanf(e, "%d,%d,%d", &v.big, &v.mid, &v.bk64);
+    return v;
+  }();
+  return t;
+}
+
 hipError_t launch_gemm(const GemmParams& pin, int precision, hipStream_t st) {
   GemmParams p = pin;
+  const GemmTune& tune = gemm_tune();
   const int big_tiles = ((p.M + 127) / 128) * ((p.N + 127) / 128);
+  const int mid_tiles = ((p.M + 127) / 128) * ((p.N + 63) / 64);
   const bool x3 = precision == 0;
-  bool k64 = true;
+  bool k64 = tune.bk64 != 0;
   for (int s = 0; s < p.nseg; ++s) k64 = k64 && p.seg[s].c0 % 64 == 0 && p.seg[s].c1 % 64 == 0;
   if (!p.zero_page || (x3 && !p.w_lo)) return hipErrorInvalidValue;
-  const bool big = big_tiles >= 384;
+  const bool big = big_tiles >= tune.big;
+  const bool mid = !big && (p.epi == EPI_GEGLU || mid_tiles >= tune.mid);
   const int bk = (!big && k64) ? 64 : 32;
   for (int s = 0; s < p.nseg; ++s) {
     if (p.seg[s].c0 % 32 != 0 || p.seg[s].c1 % 32 != 0) return hipErrorInvalidValue;
@@ -338,9 +356,9 @@ hipError_t launch_gemm(const GemmParams& pin, int precision, hipStream_t st) {
   }
   if (big) return GemmTile<128, 128, 32, 2, 2>::launch(p, x3, st);
   if (bk == 64) {
-    if (p.epi == EPI_GEGLU) return GemmTile<128, 64, 64, 4, 1>::launch(p, x3, st);
+    if (mid) return GemmTile<128, 64, 64, 4, 1>::launch(p, x3, st);
     return GemmTile<64, 64, 64, 2, 2>::launch(p, x3, st);
   }
-  if (p.epi == EPI_GEGLU) return GemmTile<128, 64, 32, 4, 1>::launch(p, x3, st);
+  if (mid) return GemmTile<128, 64, 32, 4, 1>::launch(p, x3, st);
   return GemmTile<64, 64, 32, 2, 2>::launch(p, x3, st);
 }

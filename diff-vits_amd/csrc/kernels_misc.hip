@@ -126,17 +126,36 @@ __global__ __launch_bounds__(256) void k_gn_apply(const GnApplyParams p, int row
       const bool first = c < p.c0;
       const float2* slab = reinterpret_cast<const float2*>(first ? p.slab0 : p.slab1);
       const int ld = first ? p.c0 : p.c1, cc = first ? c : c - p.c0;
+      const float2* src = slab + (size_t)b * RB * ld + cc;
       double s1 = 0, s2 = 0;
-      for (int rb = 0; rb < RB; ++rb) {
-        const float2 v = slab[(size_t)(b * RB + rb) * ld + cc];
-        s1 += v.x;
-        s2 += v.y;
+      int rb = 0;
+      for (; rb + 4 <= RB; rb += 4) {          // 4 independent loads in flight
+        const float2 v0 = src[(size_t)rb * ld], v1 = src[(size_t)(rb + 1) * ld];
+        const float2 v2 = src[(size_t)(rb + 2) * ld], v3 = src[(size_t)(rb + 3) * ld];
+        s1 += ((double)v0.x + (double)v1.x) + ((double)v2.x + (double)v3.x);
+        s2 += ((double)v0.y + (double)v1.y) + ((double)v2.y + (double)v3.y);
       }
+      for (; rb < RB; ++rb) { const float2 v = src[(size_t)rb * ld]; s1 += v.x; s2 += v.y; }
       s_cs[2 * c] = s1;
       s_cs[2 * c + 1] = s2;
     }
     __syncthreads();
-    if (tid < G) {
+    // group reduction: 256/G threads per group (a power of two <= 64 for G = 4..64), shuffle tree
+    const int tpg = 256 / G;
+    if (256 % G == 0 && tpg <= 64 && (tpg & (tpg - 1)) == 0) {
+      const int g = tid / tpg, sub = tid % tpg;
+      double s1 = 0, s2 = 0;
+      for (int c = g * cg + sub; c < (g + 1) * cg; c += tpg) { s1 += s_cs[2 * c]; s2 += s_cs[2 * c + 1]; }
+      for (int o = tpg >> 1; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }
+      if (sub == 0) {
+        const double n = (double)cg * (double)p.T;
+        const double mean = s1 / n;
+        double var = s2 / n - mean * mean;
+        var = var > 0 ? var : 0;
+        s_gs[2 * g] = mean;
+        s_gs[2 * g + 1] = 1.0 / sqrt(var + (double)p.eps);
+      }
+    } else if (tid < G) {
       double s1 = 0, s2 = 0;
       for (int c = tid * cg; c < (tid + 1) * cg; ++c) { s1 += s_cs[2 * c]; s2 += s_cs[2 * c + 1]; }
       const double n = (double)cg * (double)p.T;
@@ -187,13 +206,79 @@ __global__ __launch_bounds__(256) void k_gn_apply(const GnApplyParams p, int row
   }
 }
 
+// Per-(batch, channel) affine from the producers' slabs, one workgroup per batch item: the streaming
+// apply kernel below then runs with the table (thousands of small workgroups, no redundant reduction).
+__global__ __launch_bounds__(256) void k_gn_table(const GnApplyParams p, float* __restrict__ scale,
+                                                   float* __restrict__ shift) {
+  extern __shared__ float sm[];
+  const int ctot = p.c0 + p.c1, G = p.groups, cg = ctot / G;
+  double* s_gs = reinterpret_cast<double*>(sm);            // [G][2]
+  double* s_cs = s_gs + 2 * G;                            // [ctot][2]
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const int RB = p.T >> 5;
+  for (int c = tid; c < ctot; c += 256) {
+    const bool first = c < p.c0;
+    const float2* slab = reinterpret_cast<const float2*>(first ? p.slab0 : p.slab1);
+    const int ld = first ? p.c0 : p.c1, cc = first ? c : c - p.c0;
+    const float2* src = slab + (size_t)b * RB * ld + cc;
+    double s1 = 0, s2 = 0;
+    int rb = 0;
+    for (; rb + 4 <= RB; rb += 4) {
+      const float2 v0 = src[(size_t)rb * ld], v1 = src[(size_t)(rb + 1) * ld];
+      const float2 v2 = src[(size_t)(rb + 2) * ld], v3 = src[(size_t)(rb + 3) * ld];
+      s1 += ((double)v0.x + (double)v1.x) + ((double)v2.x + (double)v3.x);
+      s2 += ((double)v0.y + (double)v1.y) + ((double)v2.y + (double)v3.y);
+    }
+    for (; rb < RB; ++rb) { const float2 v = src[(size_t)rb * ld]; s1 += v.x; s2 += v.y; }
+    s_cs[2 * c] = s1;
+    s_cs[2 * c + 1] = s2;
+  }
+  __syncthreads();
+  const int tpg = 256 / G;
+  if (256 % G == 0 && tpg <= 64 && (tpg & (tpg - 1)) == 0) {
+    const int g = tid / tpg, sub = tid % tpg;
+    double s1 = 0, s2 = 0;
+    for (int c = g * cg + sub; c < (g + 1) * cg; c += tpg) { s1 += s_cs[2 * c]; s2 += s_cs[2 * c + 1]; }
+    for (int o = tpg >> 1; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }
+    if (sub == 0) { s_gs[2 * g] = s1; s_gs[2 * g + 1] = s2; }
+  } else if (tid < G) {
+    double s1 = 0, s2 = 0;
+    for (int c = tid * cg; c < (tid + 1) * cg; ++c) { s1 += s_cs[2 * c]; s2 += s_cs[2 * c + 1]; }
+    s_gs[2 * tid] = s1; s_gs[2 * tid + 1] = s2;
+  }
+  __syncthreads();
+  for (int c = tid; c < ctot; c += 256) {
+    const int g = c / cg;
+    const double n = (double)cg * (double)p.T;
+    const double mean = s_gs[2 * g] / n;
+    double var = s_gs[2 * g + 1] / n - mean * mean;
+    var = var > 0 ? var : 0;
+    const float rstd = (float)(1.0 / sqrt(var + (double)p.eps));
+    const float a = rstd * p.gamma[c];
+    const float sh = p.beta[c] - (float)mean * a;
+    const float ts = p.tscale ? 1.0f + p.tscale[(size_t)b * p.ld_t + c] : 1.0f;
+    const float tb = p.tshift ? p.tshift[(size_t)b * p.ld_t + c] : 0.0f;
+    scale[(size_t)b * ctot + c] = a * ts;
+    shift[(size_t)b * ctot + c] = fmaf(sh, ts, tb);
+  }
+}
+
+hipError_t launch_gn_table(const GnApplyParams& p, float* scale, float* shift, hipStream_t st) {
+  const int ctot = p.c0 + p.c1;
+  if (p.T % 32 != 0 || !p.slab0 || (p.c1 && !p.slab1) || ctot % p.groups != 0 || p.groups > 64) return hipErrorInvalidValue;
+  const size_t smem = (size_t)(2 * p.groups + 2 * ctot) * 8;
+  hipLaunchKernelGGL(k_gn_table, dim3(p.B), dim3(256), smem, st, p, scale, shift);
+  return hipGetLastError();
+}
+
 hipError_t launch_gn_apply(const GnApplyParams& p, hipStream_t st) {
   const int ctot = p.c0 + p.c1;
   if (ctot % 4 != 0 || p.c0 % 4 != 0 || ctot % p.groups != 0 || p.groups > 64) return hipErrorInvalidValue;
   if (!p.scale_in && (p.T % 32 != 0 || !p.slab0 || (p.c1 && !p.slab1))) return hipErrorInvalidValue;
-  // ~64 KB of activations per workgroup
-  int rpb = (16384 + ctot - 1) / ctot;
-  rpb = rpb < 4 ? 4 : rpb;
+  // with a precomputed table the kernel is a pure stream: ~16 KB of activations per workgroup;
+  // with in-kernel statistics amortise the slab reduction over ~64 KB
+  int rpb = ((p.scale_in ? 4096 : 16384) + ctot - 1) / ctot;
+  rpb = rpb < 2 ? 2 : rpb;
   const size_t smem = (size_t)2 * ctot * 4 + (size_t)(2 * p.groups + 2 * ctot) * 8;
   hipLaunchKernelGGL(k_gn_apply, dim3((p.T + rpb - 1) / rpb, p.B), dim3(256), smem, st, p, rpb);
   return hipGetLastError();
@@ -462,34 +547,41 @@ hipError_t launch_ln_apply(const float* x, bf16_t* hi, bf16_t* lo, int M, int C,
 __global__ __launch_bounds__(256) void k_small_linear(const float* __restrict__ in, int ldin,
                                                        const float* __restrict__ W, const float* __restrict__ bias,
                                                        const float* __restrict__ add, float* __restrict__ out,
-                                                       int ldo, int M, int K, int N, int silu_in, int silu_out) {
-  const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
-  const int lane = threadIdx.x & 63;
-  if (n >= N) return;
-  const float* w = W + (size_t)n * K;
-  for (int m0 = 0; m0 < M; m0 += 8) {
-    float acc[8];
+                                                       int ldo, int M, int K, int N, int silu_in, int silu_out,
+                                                       int cols_per_wave) {
+  extern __shared__ float s_in[];        // [M][K] activated input rows, staged once per workgroup
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int i = tid; i < M * K; i += 256) {
+    const int m = i / K, k = i - m * K;
+    float xv = in[(size_t)m * ldin + k];
+    if (silu_in) xv = xv / (1.0f + __expf(-xv));
+    s_in[i] = xv;
+  }
+  __syncthreads();
+  const int n_base = (blockIdx.x * 4 + wave) * cols_per_wave;
+  for (int cw = 0; cw < cols_per_wave; ++cw) {
+    const int n = n_base + cw;
+    if (n >= N) return;
+    const float* w = W + (size_t)n * K;
+    for (int m0 = 0; m0 < M; m0 += 8) {
+      float acc[8];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) acc[i] = 0.f;
-    for (int k = lane; k < K; k += 64) {
-      const float wv = w[k];
+      for (int i = 0; i < 8; ++i) acc[i] = 0.f;
+      for (int k = lane; k < K; k += 64) {
+        const float wv = w[k];
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+          if (m0 + i < M) acc[i] = fmaf(s_in[(m0 + i) * K + k], wv, acc[i]);
+      }
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
-        if (m0 + i < M) {
-          float xv = in[(size_t)(m0 + i) * ldin + k];
-          if (silu_in) xv = xv / (1.0f + __expf(-xv));
-          acc[i] = fmaf(xv, wv, acc[i]);
+        const float sum = wave_sum(acc[i]);
+        if (lane == 0 && m0 + i < M) {
+          float v = sum + (bias ? bias[n] : 0.f);
+          if (silu_out) v = v / (1.0f + __expf(-v));
+          if (add) v += add[(size_t)(m0 + i) * ldo + n];
+          out[(size_t)(m0 + i) * ldo + n] = v;
         }
-      }
-    }
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const float s = wave_sum(acc[i]);
-      if (lane == 0 && m0 + i < M) {
-        float v = s + (bias ? bias[n] : 0.f);
-        if (silu_out) v = v / (1.0f + __expf(-v));
-        if (add) v += add[(size_t)(m0 + i) * ldo + n];
-        out[(size_t)(m0 + i) * ldo + n] = v;
       }
     }
   }
@@ -498,8 +590,13 @@ __global__ __launch_bounds__(256) void k_small_linear(const float* __restrict__ 
 hipError_t launch_small_linear(const float* in, int ldin, const float* W, const float* b, const float* add,
                                float* out, int ldo, int M, int K, int N, int silu_in, int silu_out,
                                hipStream_t st) {
-  hipLaunchKernelGGL(k_small_linear, dim3((N + 3) / 4), dim3(256), 0, st, in, ldin, W, b, add, out, ldo, M, K, N,
-                     silu_in, silu_out);
+  const size_t smem = (size_t)M * K * sizeof(float);
+  if (smem > 64 * 1024) return hipErrorInvalidValue;
+  // ~1024 workgroups at most: wide outputs (the batched time_emb_proj) take several columns per wave
+  int cpw = (N + 4095) / 4096;
+  cpw = cpw < 1 ? 1 : cpw;
+  hipLaunchKernelGGL(k_small_linear, dim3((N + 4 * cpw - 1) / (4 * cpw)), dim3(256), smem, st, in, ldin, W, b, add,
+                     out, ldo, M, K, N, silu_in, silu_out, cpw);
   return hipGetLastError();
 }
 

@@ -20,6 +20,7 @@ def main():
     ap.add_argument("--prompt", type=int, default=256)
     ap.add_argument("--precision", default="bf16x3")
     ap.add_argument("--reps", type=int, default=5)
+    ap.add_argument("--summary", action="store_true", help="per-kernel-family totals only")
     a = ap.parse_args()
     dev = torch.device("cuda", 0)
     model, _ = bench.build_model(dev, a.precision)
@@ -37,7 +38,17 @@ def main():
             e[2] += ms
     rows = sorted(agg.items(), key=lambda kv: -kv[1][2])
     tot = sum(v[2] for v in agg.values()) / a.reps
-    print("total %.3f ms per forward (event-timed, eager)" % tot)
+    print("total %.3f ms per forward (event-timed, eager)  DVITS_GEMM_CFG=%s" % (tot, os.environ.get("DVITS_GEMM_CFG", "default")))
+    fam = {}
+    for (kind, desc), (n, fl, ms) in agg.items():
+        f = fam.setdefault(kind, [0, 0.0, 0.0])
+        f[0] += n // a.reps
+        f[1] += ms / a.reps
+        f[2] += fl * (n // a.reps)
+    for k, (n, ms, fl) in sorted(fam.items(), key=lambda kv: -kv[1][1]):
+        print("  %-12s launches=%4d  %8.3f ms  %7.1f TF/s" % (k, n, ms, fl / (ms * 1e-3) / 1e12 if fl else 0.0))
+    if a.summary:
+        return
     for (kind, desc), (n, fl, ms) in rows:
         per = ms / n
         print("%-11s %-62s x%-3d %8.1f us  %7.1f TF/s  %5.1f%%" % (kind, desc, n // a.reps, per * 1e3,
