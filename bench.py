@@ -76,6 +76,8 @@ def main():
     ap.add_argument("--prompt", type=int, default=256)
     ap.add_argument("--solver-steps", type=int, default=50)
     ap.add_argument("--precision", default=os.environ.get("DVITS_PRECISION", "bf16x3"), choices=["bf16x3", "bf16"])
+    ap.add_argument("--streams", type=int, default=int(os.environ.get("DVITS_BENCH_STREAMS", "1")),
+                    help="split the per-GPU batch into this many concurrent sub-batches (own engine + HIP stream each)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
@@ -92,7 +94,12 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     B, T, L, S = args.batch, args.frames, args.prompt, args.solver_steps
+    NS = max(1, args.streams)
+    if B % NS != 0:
+        raise SystemExit("--batch must be divisible by --streams")
     model, sd = build_model(dev, args.precision)
+    replicas = [model] + [build_model(dev, args.precision)[0] for _ in range(NS - 1)]
+    streams = [torch.cuda.Stream(device=dev) for _ in range(NS)] if NS > 1 else [None]
 
     # synthetic inputs: this rank's noise/content shard is generated locally (zero traffic); the
     # conditioning of the whole job lives on rank 0 and is broadcast over RCCL before every run
@@ -110,14 +117,30 @@ def main():
     ns = dpm_solver.NoiseScheduleVP("discrete", betas=torch.from_numpy(synth.make_betas()))
     state = {}
 
-    def run_local(x, c, enc, mask):
-        native = state.get("native")
+    def run_sub(i, x, c, enc, mask):
+        key = ("native", i)
+        native = state.get(key)
         if native is None:
-            native = state["native"] = dpm_solver.NativeUNetModel(model, c, enc, mask)
+            native = state[key] = dpm_solver.NativeUNetModel(replicas[i], c, enc, mask)
             fn = dpm_solver.model_wrapper(native, ns, model_type="x_start")
-            state["solver"] = dpm_solver.DPM_Solver(fn, ns, algorithm_type="dpmsolver++")
+            state[("solver", i)] = dpm_solver.DPM_Solver(fn, ns, algorithm_type="dpmsolver++")
         native.cond, native.enc, native.mask = c, enc, mask
-        return state["solver"].sample(x, steps=S, order=2, skip_type="time_uniform", method="multistep")
+        return state[("solver", i)].sample(x, steps=S, order=2, skip_type="time_uniform", method="multistep")
+
+    def run_local(x, c, enc, mask):
+        if NS == 1:
+            return run_sub(0, x, c, enc, mask)
+        bs = B // NS
+        cur = torch.cuda.current_stream()
+        outs = []
+        for i in range(NS):
+            sl = slice(i * bs, (i + 1) * bs)
+            streams[i].wait_stream(cur)
+            with torch.cuda.stream(streams[i]):
+                outs.append(run_sub(i, x[sl].contiguous(), c[sl].contiguous(), enc[sl].contiguous(), mask[sl].contiguous()))
+        for i in range(NS):
+            cur.wait_stream(streams[i])
+        return torch.cat(outs, dim=0)
 
     def one_run():
         return shard.sharded_sample(run_local, x_T, cond, enc_g, mask_g)
@@ -157,19 +180,21 @@ def main():
         "data": "synthetic",
         "config": {"workload": "B=%d/GPU, C=80, T=%d, L=%d, %d-step DPM-Solver++(2M) multistep, UNet1DConditionModel "
                                "(128,256,384,512), seeded random-init weights" % (B, T, L, S),
-                   "global_batch": G, "parallelism": "dp%d (batch-sharded, RCCL broadcast of conditioning + all-gather of mels)" % world},
+                   "global_batch": G, "concurrent_sub_batches_per_gpu": NS, "parallelism": "dp%d (batch-sharded, RCCL broadcast of conditioning + all-gather of mels)" % world},
     }
 
     # ---- roofline of the dominant kernel family (implicit GEMM), timed live with HIP events ----
     if not args.no_roofline:
         eng = model.hip_engine()
-        t_dev = torch.full((B,), 500.0, device=dev)
+        bsub = B // NS
+        t_dev = torch.full((bsub,), 500.0, device=dev)
+        xs_, cs_ = x_T[:bsub].contiguous(), cond[:bsub].contiguous()
         reps = 5
         agg = {}
         with torch.no_grad():
-            eng.profile_forward(x_T, cond, t_dev)                # warm
+            eng.profile_forward(xs_, cs_, t_dev)                # warm
             for _ in range(reps):
-                for kind, fl, ms, _ in eng.profile_forward(x_T, cond, t_dev):
+                for kind, fl, ms, _ in eng.profile_forward(xs_, cs_, t_dev):
                     a = agg.setdefault(kind, [0, 0.0, 0.0])
                     a[0] += 1
                     a[1] += fl

@@ -84,8 +84,6 @@ struct GnApplyParams {
   int B, T;
 };
 hipError_t launch_gn_apply(const GnApplyParams& p, hipStream_t st);
-// slabs -> per-(batch, channel) scale/shift table [B, c0+c1]
-hipError_t launch_gn_table(const GnApplyParams& p, float* scale, float* shift, hipStream_t st);
 // LayerNorm rows (no affine: gamma/beta are folded into the consumer's weights) -> split planes
 hipError_t launch_ln_apply(const float* x, bf16_t* hi, bf16_t* lo, int M, int C, float eps, hipStream_t st);
 // GroupNorm statistics of the channel-concat [a0 | a1] -> part[B, nchunk, G, 2] (double sum, sumsq)

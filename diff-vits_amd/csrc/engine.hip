@@ -342,16 +342,11 @@ struct Builder {
     gp.B = B; gp.T = Tn;
     float* sc = nullptr; float* sh = nullptr;
     const bool fast = a0.stat && (a1.C == 0 || a1.stat);
-    sc = alloc((size_t)B * C); sh = alloc((size_t)B * C);
-    if (fast) {
-      gp.slab0 = a0.stat; gp.slab1 = a1.stat;
-      GnApplyParams tp = gp;
-      cur_kind = "gn_table";
-      emit(ops, [tp, sc, sh](hipStream_t st) { return launch_gn_table(tp, sc, sh, st); });
-      gp.slab0 = gp.slab1 = nullptr;
-    } else {
+    if (fast) { gp.slab0 = a0.stat; gp.slab1 = a1.stat; }
+    else {
       const int nchunk = std::max(1, std::min(64, (Tn + 63) / 64));
       double* part = reinterpret_cast<double*>(alloc((size_t)B * nchunk * G * 2 * 2));
+      sc = alloc((size_t)B * C); sh = alloc((size_t)B * C);
       const int Bn = B;
       const float* gamma = gp.gamma; const float* beta = gp.beta;
       cur_kind = "gn_partial";
@@ -361,8 +356,8 @@ struct Builder {
         return launch_gn_finalize(part, nchunk, gamma, beta, tscale, tshift, ld_t, sc, sh, nullptr, nullptr, Bn, Tn, C, G, eps, st);
       });
       release(part);
+      gp.scale_in = sc; gp.shift_in = sh;
     }
-    gp.scale_in = sc; gp.shift_in = sh;
     Planes out = alloc_planes((size_t)B * Tn * C);
     gp.out_hi = out.hi; gp.out_lo = out.lo;
     if (raw_out) { *raw_out = alloc_planes((size_t)B * Tn * C); gp.raw_hi = raw_out->hi; gp.raw_lo = raw_out->lo; }

@@ -47,8 +47,9 @@ __device__ __forceinline__ void wait_vmcnt() {
 }
 
 template <int BM, int BN, int BK, int WM, int WN, int NSPLIT>
-__global__ __launch_bounds__(256) void k_gemm(const GemmParams p) {
+__global__ __launch_bounds__(64 * WM * WN) void k_gemm(const GemmParams p) {
   constexpr int FM = BM / (WM * 32), FN = BN / (WN * 32);
+  constexpr int NWV = WM * WN;                       // waves per workgroup (1, 2 or 4)
   constexpr bool SPLIT = NSPLIT == 3;
   constexpr int NPL = SPLIT ? 2 : 1;                 // planes per operand
   constexpr int ROWB = BK * 2;                       // LDS row pitch (bytes), unpadded
@@ -57,9 +58,9 @@ __global__ __launch_bounds__(256) void k_gemm(const GemmParams p) {
   constexpr int A_PL = BM * ROWB, B_PL = BN * ROWB;  // bytes per plane tile
   constexpr int STAGE = (A_PL + B_PL) * NPL;
   constexpr int NSTAGE = 3;
-  constexpr int A_IPW = BM / RPI / 4, B_IPW = BN / RPI / 4;   // DMA instructions per wave per plane
+  constexpr int A_IPW = BM / RPI / NWV, B_IPW = BN / RPI / NWV;   // DMA instructions per wave per plane
   constexpr int LPT = (A_IPW + B_IPW) * NPL;         // DMA instructions per thread per k-tile
-  static_assert(BM % (RPI * 4) == 0 && BN % (RPI * 4) == 0, "tile rows must split over 4 waves");
+  static_assert(BM % (RPI * NWV) == 0 && BN % (RPI * NWV) == 0, "tile rows must split over the waves");
   extern __shared__ __attribute__((aligned(1024))) char smem[];
 
   const int tid = threadIdx.x;
@@ -87,7 +88,7 @@ __global__ __launch_bounds__(256) void k_gemm(const GemmParams p) {
   unsigned arow_ok = 0;
 #pragma unroll
   for (int q = 0; q < A_IPW; ++q) {
-    const int r = (q * 4 + wave) * RPI + l_row;       // row within the A tile
+    const int r = (q * NWV + wave) * RPI + l_row;     // row within the A tile
     int m = m0 + r;
     const bool ok = m < p.M;
     arow_ok |= (ok ? 1u : 0u) << q;
@@ -99,7 +100,7 @@ __global__ __launch_bounds__(256) void k_gemm(const GemmParams p) {
   size_t b_off[B_IPW];
 #pragma unroll
   for (int q = 0; q < B_IPW; ++q) {
-    const int r = (q * 4 + wave) * RPI + l_row;
+    const int r = (q * NWV + wave) * RPI + l_row;
     b_off[q] = ((size_t)(n0 + r) * p.Kp + (l_slot ^ swz(r)) * 8) * 2;   // byte offset at kt = 0
   }
 
@@ -124,7 +125,7 @@ __global__ __launch_bounds__(256) void k_gemm(const GemmParams p) {
       st = p.up_mode == UP_X2 ? (ts >> 1) : st;
       st = p.up_mode == UP_SIZE ? min((int)floorf((float)ts * p.up_scale), p.T_in - 1) : st;
       const size_t e = ((size_t)arow_b[q] * p.T_in + st) * ld + col + a_chunk[q] * 8;
-      const unsigned dst = st_base + (unsigned)(((q * 4 + wave) * RPI) * ROWB);
+      const unsigned dst = st_base + (unsigned)(((q * NWV + wave) * RPI) * ROWB);
       // conv zero padding / rows >= M read a 16-byte zero page instead
       glds16(ok ? (const void*)(src_hi + e) : (const void*)p.zero_page, dst);
       if (SPLIT) glds16(ok ? (const void*)(src_lo + e) : (const void*)p.zero_page, dst + A_PL);
@@ -132,7 +133,7 @@ __global__ __launch_bounds__(256) void k_gemm(const GemmParams p) {
 #pragma unroll
     for (int q = 0; q < B_IPW; ++q) {
       const size_t o = b_off[q] + (size_t)kt * (BK * 2);
-      const unsigned dst = st_base + (unsigned)(NPL * A_PL + ((q * 4 + wave) * RPI) * ROWB);
+      const unsigned dst = st_base + (unsigned)(NPL * A_PL + ((q * NWV + wave) * RPI) * ROWB);
       glds16(reinterpret_cast<const char*>(p.w_hi) + o, dst);
       if (SPLIT) glds16(reinterpret_cast<const char*>(p.w_lo) + o, dst + B_PL);
     }
@@ -296,7 +297,7 @@ struct GemmCfg {
   }
   static hipError_t launch(const GemmParams& p, hipStream_t st) {
     const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
-    hipLaunchKernelGGL((k_gemm<BM, BN, BK, WM, WN, NSPLIT>), dim3(tiles), dim3(256), SMEM, st, p);
+    hipLaunchKernelGGL((k_gemm<BM, BN, BK, WM, WN, NSPLIT>), dim3(tiles), dim3(64 * WM * WN), SMEM, st, p);
     return hipGetLastError();
   }
 };
@@ -312,27 +313,52 @@ struct GemmTile {
   }
 };
 
+// tile menu, largest first; *G variants keep a 64-column block inside one wave (FN == 2) for GEGLU
+template <int BK> struct Tiles {
+  using T0 = GemmTile<128, 128, 32, 2, 2>;
+  using T1 = GemmTile<128, 64, BK, 4, 1>;
+  using T2 = GemmTile<64, 64, BK, 2, 2>;
+  using T2G = GemmTile<64, 64, BK, 2, 1>;
+  using T3 = GemmTile<64, 32, BK, 2, 1>;
+  using T4 = GemmTile<32, 32, BK, 1, 1>;
+  using T4G = GemmTile<32, 64, BK, 1, 1>;
+  static hipError_t init() {
+    hipError_t e;
+    if ((e = T0::init()) != hipSuccess) return e;
+    if ((e = T1::init()) != hipSuccess) return e;
+    if ((e = T2::init()) != hipSuccess) return e;
+    if ((e = T2G::init()) != hipSuccess) return e;
+    if ((e = T3::init()) != hipSuccess) return e;
+    if ((e = T4::init()) != hipSuccess) return e;
+    return T4G::init();
+  }
+  static hipError_t launch(const GemmParams& p, bool x3, int min_wg, hipStream_t st) {
+    auto cnt = [&](int bm, int bn) { return ((p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn); };
+    if (p.epi == EPI_GEGLU) {
+      if (cnt(128, 64) >= min_wg) return T1::launch(p, x3, st);
+      if (cnt(64, 64) >= min_wg) return T2G::launch(p, x3, st);
+      return T4G::launch(p, x3, st);
+    }
+    if (cnt(64, 64) >= min_wg) return T2::launch(p, x3, st);
+    if (cnt(64, 32) >= min_wg) return T3::launch(p, x3, st);
+    return T4::launch(p, x3, st);
+  }
+};
+
 hipError_t gemm_init() {
-  hipError_t e;
-  if ((e = GemmTile<128, 128, 32, 2, 2>::init()) != hipSuccess) return e;
-  if ((e = GemmTile<128, 64, 32, 4, 1>::init()) != hipSuccess) return e;
-  if ((e = GemmTile<64, 64, 32, 2, 2>::init()) != hipSuccess) return e;
-  if ((e = GemmTile<128, 64, 64, 4, 1>::init()) != hipSuccess) return e;
-  return GemmTile<64, 64, 64, 2, 2>::init();
+  hipError_t e = Tiles<32>::init();
+  return e != hipSuccess ? e : Tiles<64>::init();
 }
 
-// Tile choice: the denoiser's GEMMs are small (M = B*T_l <= 8192, N = 128..4096), so the first
-// concern is filling 256 CUs; 128x128 tiles only when they still give >= 1.5 workgroups per CU,
-// else 64x64.  GEGLU needs both halves of a 64-column block in one wave (FN == 2): 128x128 or
-// 128x64 (4x1 waves).  BK = 64 (128-byte rows, half the barriers) for the 64-row tiles whenever
-// every K-segment's channel counts are multiples of 64.
-// Tunables (env DVITS_GEMM_CFG="big,mid,bk64"): workgroup-count thresholds for the 128x128 and 128x64
-// tiles and whether 64-deep k-tiles are used when the channel counts allow.
-struct GemmTune { int big = 384, mid = 1 << 30, bk64 = 1; };
+// Tunables (env DVITS_GEMM_CFG="big,min_wg,bk64"): workgroup-count threshold for the 128x128x32 tile,
+// minimum workgroups wanted from the smaller tiles, and whether 64-deep k-tiles are used when the channel
+// counts allow.  The denoiser's GEMMs are small (M = B*T_l <= 8192, N = 128..4096): filling 256 CUs with
+// >= 1-2 workgroups each matters more than tile efficiency.
+struct GemmTune { int big = 384, min_wg = 256, bk64 = 1; };
 static const GemmTune& gemm_tune() {
   static GemmTune t = [] {
     GemmTune v;
-    if (const char* e = getenv("DVITS_GEMM_CFG")) sscanf(e, "%d,%d,%d", &v.big, &v.mid, &v.bk64);
+    if (const char* e = getenv("DVITS_GEMM_CFG")) sscanf(e, "%d,%d,%d", &v.big, &v.min_wg, &v.bk64);
     return v;
   }();
   return t;
@@ -342,23 +368,17 @@ hipError_t launch_gemm(const GemmParams& pin, int precision, hipStream_t st) {
   GemmParams p = pin;
   const GemmTune& tune = gemm_tune();
   const int big_tiles = ((p.M + 127) / 128) * ((p.N + 127) / 128);
-  const int mid_tiles = ((p.M + 127) / 128) * ((p.N + 63) / 64);
   const bool x3 = precision == 0;
   bool k64 = tune.bk64 != 0;
   for (int s = 0; s < p.nseg; ++s) k64 = k64 && p.seg[s].c0 % 64 == 0 && p.seg[s].c1 % 64 == 0;
   if (!p.zero_page || (x3 && !p.w_lo)) return hipErrorInvalidValue;
   const bool big = big_tiles >= tune.big;
-  const bool mid = !big && (p.epi == EPI_GEGLU || mid_tiles >= tune.mid);
   const int bk = (!big && k64) ? 64 : 32;
   for (int s = 0; s < p.nseg; ++s) {
     if (p.seg[s].c0 % 32 != 0 || p.seg[s].c1 % 32 != 0) return hipErrorInvalidValue;
     p.seg[s].nkt = p.seg[s].taps * (p.seg[s].c0 + p.seg[s].c1) / bk;
   }
-  if (big) return GemmTile<128, 128, 32, 2, 2>::launch(p, x3, st);
-  if (bk == 64) {
-    if (mid) return GemmTile<128, 64, 64, 4, 1>::launch(p, x3, st);
-    return GemmTile<64, 64, 64, 2, 2>::launch(p, x3, st);
-  }
-  if (mid) return GemmTile<128, 64, 32, 4, 1>::launch(p, x3, st);
-  return GemmTile<64, 64, 32, 2, 2>::launch(p, x3, st);
+  if (big) return Tiles<32>::T0::launch(p, x3, st);
+  if (bk == 64) return Tiles<64>::launch(p, x3, tune.min_wg, st);
+  return Tiles<32>::launch(p, x3, tune.min_wg > 0 ? tune.min_wg : 1, st);
 }

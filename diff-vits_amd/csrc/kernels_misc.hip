@@ -122,20 +122,33 @@ __global__ __launch_bounds__(256) void k_gn_apply(const GnApplyParams p, int row
     }
   } else {
     const int RB = p.T >> 5;             // 32-row blocks per batch item (T % 32 == 0)
-    for (int c = tid; c < ctot; c += 256) {
+    // per-channel sums over the row blocks, all 256 threads busy: channels with fewer than 256 lanes
+    // split their row-block range over nsub lanes
+    const int nsub = ctot >= 256 ? 1 : 256 / ctot;
+    double* s_part = s_cs + 2 * ctot;    // [nsub][ctot][2]
+    for (int item = tid; item < ctot * nsub; item += 256) {
+      const int sub = item / ctot, c = item - sub * ctot;
       const bool first = c < p.c0;
       const float2* slab = reinterpret_cast<const float2*>(first ? p.slab0 : p.slab1);
       const int ld = first ? p.c0 : p.c1, cc = first ? c : c - p.c0;
       const float2* src = slab + (size_t)b * RB * ld + cc;
+      const int r0 = sub * RB / nsub, r1 = (sub + 1) * RB / nsub;
       double s1 = 0, s2 = 0;
-      int rb = 0;
-      for (; rb + 4 <= RB; rb += 4) {          // 4 independent loads in flight
+      int rb = r0;
+      for (; rb + 4 <= r1; rb += 4) {          // 4 independent loads in flight
         const float2 v0 = src[(size_t)rb * ld], v1 = src[(size_t)(rb + 1) * ld];
         const float2 v2 = src[(size_t)(rb + 2) * ld], v3 = src[(size_t)(rb + 3) * ld];
         s1 += ((double)v0.x + (double)v1.x) + ((double)v2.x + (double)v3.x);
         s2 += ((double)v0.y + (double)v1.y) + ((double)v2.y + (double)v3.y);
       }
-      for (; rb < RB; ++rb) { const float2 v = src[(size_t)rb * ld]; s1 += v.x; s2 += v.y; }
+      for (; rb < r1; ++rb) { const float2 v = src[(size_t)rb * ld]; s1 += v.x; s2 += v.y; }
+      s_part[2 * item] = s1;
+      s_part[2 * item + 1] = s2;
+    }
+    __syncthreads();
+    for (int c = tid; c < ctot; c += 256) {
+      double s1 = 0, s2 = 0;
+      for (int sub = 0; sub < nsub; ++sub) { s1 += s_part[2 * (sub * ctot + c)]; s2 += s_part[2 * (sub * ctot + c) + 1]; }
       s_cs[2 * c] = s1;
       s_cs[2 * c + 1] = s2;
     }
@@ -206,80 +219,16 @@ __global__ __launch_bounds__(256) void k_gn_apply(const GnApplyParams p, int row
   }
 }
 
-// Per-(batch, channel) affine from the producers' slabs, one workgroup per batch item: the streaming
-// apply kernel below then runs with the table (thousands of small workgroups, no redundant reduction).
-__global__ __launch_bounds__(256) void k_gn_table(const GnApplyParams p, float* __restrict__ scale,
-                                                   float* __restrict__ shift) {
-  extern __shared__ float sm[];
-  const int ctot = p.c0 + p.c1, G = p.groups, cg = ctot / G;
-  double* s_gs = reinterpret_cast<double*>(sm);            // [G][2]
-  double* s_cs = s_gs + 2 * G;                            // [ctot][2]
-  const int b = blockIdx.x, tid = threadIdx.x;
-  const int RB = p.T >> 5;
-  for (int c = tid; c < ctot; c += 256) {
-    const bool first = c < p.c0;
-    const float2* slab = reinterpret_cast<const float2*>(first ? p.slab0 : p.slab1);
-    const int ld = first ? p.c0 : p.c1, cc = first ? c : c - p.c0;
-    const float2* src = slab + (size_t)b * RB * ld + cc;
-    double s1 = 0, s2 = 0;
-    int rb = 0;
-    for (; rb + 4 <= RB; rb += 4) {
-      const float2 v0 = src[(size_t)rb * ld], v1 = src[(size_t)(rb + 1) * ld];
-      const float2 v2 = src[(size_t)(rb + 2) * ld], v3 = src[(size_t)(rb + 3) * ld];
-      s1 += ((double)v0.x + (double)v1.x) + ((double)v2.x + (double)v3.x);
-      s2 += ((double)v0.y + (double)v1.y) + ((double)v2.y + (double)v3.y);
-    }
-    for (; rb < RB; ++rb) { const float2 v = src[(size_t)rb * ld]; s1 += v.x; s2 += v.y; }
-    s_cs[2 * c] = s1;
-    s_cs[2 * c + 1] = s2;
-  }
-  __syncthreads();
-  const int tpg = 256 / G;
-  if (256 % G == 0 && tpg <= 64 && (tpg & (tpg - 1)) == 0) {
-    const int g = tid / tpg, sub = tid % tpg;
-    double s1 = 0, s2 = 0;
-    for (int c = g * cg + sub; c < (g + 1) * cg; c += tpg) { s1 += s_cs[2 * c]; s2 += s_cs[2 * c + 1]; }
-    for (int o = tpg >> 1; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }
-    if (sub == 0) { s_gs[2 * g] = s1; s_gs[2 * g + 1] = s2; }
-  } else if (tid < G) {
-    double s1 = 0, s2 = 0;
-    for (int c = tid * cg; c < (tid + 1) * cg; ++c) { s1 += s_cs[2 * c]; s2 += s_cs[2 * c + 1]; }
-    s_gs[2 * tid] = s1; s_gs[2 * tid + 1] = s2;
-  }
-  __syncthreads();
-  for (int c = tid; c < ctot; c += 256) {
-    const int g = c / cg;
-    const double n = (double)cg * (double)p.T;
-    const double mean = s_gs[2 * g] / n;
-    double var = s_gs[2 * g + 1] / n - mean * mean;
-    var = var > 0 ? var : 0;
-    const float rstd = (float)(1.0 / sqrt(var + (double)p.eps));
-    const float a = rstd * p.gamma[c];
-    const float sh = p.beta[c] - (float)mean * a;
-    const float ts = p.tscale ? 1.0f + p.tscale[(size_t)b * p.ld_t + c] : 1.0f;
-    const float tb = p.tshift ? p.tshift[(size_t)b * p.ld_t + c] : 0.0f;
-    scale[(size_t)b * ctot + c] = a * ts;
-    shift[(size_t)b * ctot + c] = fmaf(sh, ts, tb);
-  }
-}
-
-hipError_t launch_gn_table(const GnApplyParams& p, float* scale, float* shift, hipStream_t st) {
-  const int ctot = p.c0 + p.c1;
-  if (p.T % 32 != 0 || !p.slab0 || (p.c1 && !p.slab1) || ctot % p.groups != 0 || p.groups > 64) return hipErrorInvalidValue;
-  const size_t smem = (size_t)(2 * p.groups + 2 * ctot) * 8;
-  hipLaunchKernelGGL(k_gn_table, dim3(p.B), dim3(256), smem, st, p, scale, shift);
-  return hipGetLastError();
-}
-
 hipError_t launch_gn_apply(const GnApplyParams& p, hipStream_t st) {
   const int ctot = p.c0 + p.c1;
   if (ctot % 4 != 0 || p.c0 % 4 != 0 || ctot % p.groups != 0 || p.groups > 64) return hipErrorInvalidValue;
   if (!p.scale_in && (p.T % 32 != 0 || !p.slab0 || (p.c1 && !p.slab1))) return hipErrorInvalidValue;
-  // with a precomputed table the kernel is a pure stream: ~16 KB of activations per workgroup;
-  // with in-kernel statistics amortise the slab reduction over ~64 KB
-  int rpb = ((p.scale_in ? 4096 : 16384) + ctot - 1) / ctot;
-  rpb = rpb < 2 ? 2 : rpb;
-  const size_t smem = (size_t)2 * ctot * 4 + (size_t)(2 * p.groups + 2 * ctot) * 8;
+  // ~512 workgroups: every workgroup re-derives its batch item's statistics from the slab (L2-resident,
+  // <= 32 row blocks), then streams its rows
+  int rpb = (p.B * p.T + 511) / 512;
+  rpb = rpb < 4 ? 4 : (rpb > 64 ? 64 : rpb);
+  const int nsub = ctot >= 256 ? 1 : 256 / ctot;
+  const size_t smem = (size_t)2 * ctot * 4 + (size_t)(2 * p.groups + 2 * ctot + 2 * ctot * nsub) * 8;
   hipLaunchKernelGGL(k_gn_apply, dim3((p.T + rpb - 1) / rpb, p.B), dim3(256), smem, st, p, rpb);
   return hipGetLastError();
 }
