@@ -46,10 +46,14 @@ __device__ __forceinline__ void wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-template <int BM, int BN, int BK, int WM, int WN, int NSPLIT>
-__global__ __launch_bounds__(64 * WM * WN) void k_gemm(const GemmParams p) {
+// KS = 2 doubles the waves of a workgroup (two per SIMD): both groups stage every k-tile together and each
+// multiplies half of its 16-deep k-steps, so one wave's MFMAs overlap the other's address math and DMA issue;
+// the two partial accumulators are added through LDS before the epilogue.
+template <int BM, int BN, int BK, int WM, int WN, int NSPLIT, int KS>
+__global__ __launch_bounds__(64 * WM * WN * KS) void k_gemm(const GemmParams p) {
   constexpr int FM = BM / (WM * 32), FN = BN / (WN * 32);
-  constexpr int NWV = WM * WN;                       // waves per workgroup (1, 2 or 4)
+  constexpr int NWQ = WM * WN;                       // waves per k-group (1, 2 or 4)
+  constexpr int NWV = NWQ * KS;                      // waves per workgroup
   constexpr bool SPLIT = NSPLIT == 3;
   constexpr int NPL = SPLIT ? 2 : 1;                 // planes per operand
   constexpr int ROWB = BK * 2;                       // LDS row pitch (bytes), unpadded
@@ -57,7 +61,7 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm(const GemmParams p) {
   constexpr int RPI = 64 / CPR;                      // rows per wave-instruction
   constexpr int A_PL = BM * ROWB, B_PL = BN * ROWB;  // bytes per plane tile
   constexpr int STAGE = (A_PL + B_PL) * NPL;
-  constexpr int NSTAGE = 3;
+  constexpr int NSTAGE = (4 * STAGE <= 160 * 1024) ? 4 : 3;   // LDS ring depth: NSTAGE-1 tiles in flight
   constexpr int A_IPW = BM / RPI / NWV, B_IPW = BN / RPI / NWV;   // DMA instructions per wave per plane
   constexpr int LPT = (A_IPW + B_IPW) * NPL;         // DMA instructions per thread per k-tile
   static_assert(BM % (RPI * NWV) == 0 && BN % (RPI * NWV) == 0, "tile rows must split over the waves");
@@ -66,7 +70,8 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm(const GemmParams p) {
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave / WN, wn = wave % WN;
+  const int kgrp = wave / NWQ, wq = wave % NWQ;
+  const int wm = wq / WN, wn = wq % WN;
   const unsigned smem_base = (unsigned)(size_t)smem;   // LDS byte address of the ring
 
   // XCD-aware tile order: consecutive tile ids (same A rows, neighbouring N) share an L2.
@@ -160,7 +165,8 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm(const GemmParams p) {
     const char* b_hi = base + NPL * A_PL;
     const char* b_lo = b_hi + B_PL;
 #pragma unroll
-    for (int ks = 0; ks < BK / 16; ++ks) {
+    for (int ks0 = 0; ks0 < BK / 16 / KS; ++ks0) {
+      const int ks = kgrp * (BK / 16 / KS) + ks0;
       const int chunk = ks * 2 + lh;
       bf16x8 ah[FM], al[FM], bh[FN], bl[FN];
 #pragma unroll
@@ -190,15 +196,58 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm(const GemmParams p) {
     }
   };
 
-  // ---- main loop: wait(tile kt) -> barrier -> issue(tile kt+2) -> compute(tile kt) ----
-  issue(0);
-  if (total_kt > 1) issue(1);
+  // residual operand of small tiles: fetched before the k-loop so its latency hides under it
+  constexpr bool PRE_RES = FM * FN <= 2;
+  float rpre[PRE_RES ? FM * FN * 16 : 1];
+  if (PRE_RES && p.epi == EPI_RESIDUAL) {
+#pragma unroll
+    for (int j = 0; j < FN; ++j) {
+      const int n = n0 + (wn * FN + j) * 32 + l31;
+      const int nn = n < p.N ? n : 0;
+#pragma unroll
+      for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int m = min(m0 + (wm * FM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh, p.M - 1);
+          rpre[(j * FM + i) * 16 + r] = p.res[(size_t)m * p.ldres + nn];
+        }
+    }
+  }
+
+  // ---- main loop: wait(tile kt) -> barrier -> issue(tile kt+NSTAGE-1) -> compute(tile kt) ----
+  // NSTAGE-1 tiles are in flight; the counted vmcnt leaves the younger ones outstanding across the barrier
+#pragma unroll
+  for (int t = 0; t < NSTAGE - 1; ++t)
+    if (t < total_kt) issue(t);
   for (int kt = 0; kt < total_kt; ++kt) {
-    if (kt + 1 < total_kt) wait_vmcnt<LPT>();        // tile kt+1 may stay in flight
+    const int younger = min(NSTAGE - 2, total_kt - 1 - kt);   // tiles issued after kt that may stay in flight
+    if (younger >= 2) wait_vmcnt<2 * LPT>();
+    else if (younger == 1) wait_vmcnt<LPT>();
     else wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();                    // tile kt visible; every wave is done with tile kt-1
-    if (kt + 2 < total_kt) issue(kt + 2);            // overwrites the stage tile kt-1 was read from
+    if (kt + NSTAGE - 1 < total_kt) issue(kt + NSTAGE - 1);   // overwrites the stage tile kt-1 was read from
     compute(kt);
+  }
+
+  if (KS == 2) {   // add the two k-groups' partial accumulators through LDS (lane-linear, conflict-free)
+    __builtin_amdgcn_s_barrier();                    // every wave is done reading the ring
+    float* red = reinterpret_cast<float*>(smem);
+    if (kgrp == 1) {
+#pragma unroll
+      for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) red[((i * FN + j) * 16 + r) * (64 * NWQ) + wq * 64 + lane] = acc[i][j][r];
+    }
+    __syncthreads();
+    if (kgrp == 1) return;
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+      for (int j = 0; j < FN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] += red[((i * FN + j) * 16 + r) * (64 * NWQ) + wq * 64 + lane];
   }
 
   // ---- epilogue ----
@@ -247,8 +296,11 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm(const GemmParams p) {
       if (p.epi == EPI_RESIDUAL) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const int m = min(mrow0 + (r & 3) + 8 * (r >> 2) + 4 * lh, p.M - 1);
-          rv[r] = p.res[(size_t)m * p.ldres + nn];
+          if (PRE_RES) rv[r] = rpre[(j * FM + i) * 16 + r];
+          else {
+            const int m = min(mrow0 + (r & 3) + 8 * (r >> 2) + 4 * lh, p.M - 1);
+            rv[r] = p.res[(size_t)m * p.ldres + nn];
+          }
         }
       }
       float s1 = 0.f, s2 = 0.f;
@@ -287,37 +339,40 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm(const GemmParams p) {
   }
 }
 
-template <int BM, int BN, int BK, int WM, int WN, int NSPLIT>
+template <int BM, int BN, int BK, int WM, int WN, int NSPLIT, int KS>
 struct GemmCfg {
-  static constexpr int SMEM = 3 * (BM + BN) * BK * 2 * (NSPLIT == 3 ? 2 : 1);
+  static constexpr int STAGE_B = (BM + BN) * BK * 2 * (NSPLIT == 3 ? 2 : 1);
+  static constexpr int SMEM = ((4 * STAGE_B <= 160 * 1024) ? 4 : 3) * STAGE_B;
   // > 64 KiB of dynamic LDS needs the attribute; set once, outside any stream capture
   static hipError_t init() {
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm<BM, BN, BK, WM, WN, NSPLIT>),
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm<BM, BN, BK, WM, WN, NSPLIT, KS>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
   }
   static hipError_t launch(const GemmParams& p, hipStream_t st) {
     const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
-    hipLaunchKernelGGL((k_gemm<BM, BN, BK, WM, WN, NSPLIT>), dim3(tiles), dim3(64 * WM * WN), SMEM, st, p);
+    hipLaunchKernelGGL((k_gemm<BM, BN, BK, WM, WN, NSPLIT, KS>), dim3(tiles), dim3(64 * WM * WN * KS), SMEM, st, p);
     return hipGetLastError();
   }
 };
 
-template <int BM, int BN, int BK, int WM, int WN>
+template <int BM, int BN, int BK, int WM, int WN, int KS = 1>
 struct GemmTile {
   static hipError_t init() {
-    hipError_t e = GemmCfg<BM, BN, BK, WM, WN, 3>::init();
-    return e != hipSuccess ? e : GemmCfg<BM, BN, BK, WM, WN, 1>::init();
+    hipError_t e = GemmCfg<BM, BN, BK, WM, WN, 3, KS>::init();
+    return e != hipSuccess ? e : GemmCfg<BM, BN, BK, WM, WN, 1, KS>::init();
   }
   static hipError_t launch(const GemmParams& p, bool x3, hipStream_t st) {
-    return x3 ? GemmCfg<BM, BN, BK, WM, WN, 3>::launch(p, st) : GemmCfg<BM, BN, BK, WM, WN, 1>::launch(p, st);
+    return x3 ? GemmCfg<BM, BN, BK, WM, WN, 3, KS>::launch(p, st) : GemmCfg<BM, BN, BK, WM, WN, 1, KS>::launch(p, st);
   }
 };
 
 // tile menu, largest first; *G variants keep a 64-column block inside one wave (FN == 2) for GEGLU
 template <int BK> struct Tiles {
-  using T0 = GemmTile<128, 128, 32, 2, 2>;
-  using T1 = GemmTile<128, 64, BK, 4, 1>;
-  using T2 = GemmTile<64, 64, BK, 2, 2>;
+  using T0 = GemmTile<128, 128, 32, 2, 2, 2>;
+  using T0S = GemmTile<128, 128, 32, 2, 2, 1>;
+  using T1 = GemmTile<128, 64, BK, 4, 1, (BK == 64 ? 2 : 1)>;
+  using T2 = GemmTile<64, 64, BK, 2, 2, (BK == 64 ? 2 : 1)>;   // 8 waves at BK = 64 (k-split pairs)
+  using T2S = GemmTile<64, 64, BK, 2, 2, 1>;
   using T2G = GemmTile<64, 64, BK, 2, 1>;
   using T3 = GemmTile<64, 32, BK, 2, 1>;
   using T4 = GemmTile<32, 32, BK, 1, 1>;
@@ -325,21 +380,23 @@ template <int BK> struct Tiles {
   static hipError_t init() {
     hipError_t e;
     if ((e = T0::init()) != hipSuccess) return e;
+    if ((e = T0S::init()) != hipSuccess) return e;
     if ((e = T1::init()) != hipSuccess) return e;
     if ((e = T2::init()) != hipSuccess) return e;
+    if ((e = T2S::init()) != hipSuccess) return e;
     if ((e = T2G::init()) != hipSuccess) return e;
     if ((e = T3::init()) != hipSuccess) return e;
     if ((e = T4::init()) != hipSuccess) return e;
     return T4G::init();
   }
-  static hipError_t launch(const GemmParams& p, bool x3, int min_wg, hipStream_t st) {
+  static hipError_t launch(const GemmParams& p, bool x3, int min_wg, bool ksplit, hipStream_t st) {
     auto cnt = [&](int bm, int bn) { return ((p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn); };
     if (p.epi == EPI_GEGLU) {
       if (cnt(128, 64) >= min_wg) return T1::launch(p, x3, st);
       if (cnt(64, 64) >= min_wg) return T2G::launch(p, x3, st);
       return T4G::launch(p, x3, st);
     }
-    if (cnt(64, 64) >= min_wg) return T2::launch(p, x3, st);
+    if (cnt(64, 64) >= min_wg) return ksplit ? T2::launch(p, x3, st) : T2S::launch(p, x3, st);
     if (cnt(64, 32) >= min_wg) return T3::launch(p, x3, st);
     return T4::launch(p, x3, st);
   }
@@ -354,11 +411,11 @@ hipError_t gemm_init() {
 // minimum workgroups wanted from the smaller tiles, and whether 64-deep k-tiles are used when the channel
 // counts allow.  The denoiser's GEMMs are small (M = B*T_l <= 8192, N = 128..4096): filling 256 CUs with
 // >= 1-2 workgroups each matters more than tile efficiency.
-struct GemmTune { int big = 384, min_wg = 256, bk64 = 1; };
+struct GemmTune { int big = 384, min_wg = 128, bk64 = 1, ksplit = 1; };
 static const GemmTune& gemm_tune() {
   static GemmTune t = [] {
     GemmTune v;
-    if (const char* e = getenv("DVITS_GEMM_CFG")) sscanf(e, "%d,%d,%d", &v.big, &v.min_wg, &v.bk64);
+    if (const char* e = getenv("DVITS_GEMM_CFG")) sscanf(e, "%d,%d,%d,%d", &v.big, &v.min_wg, &v.bk64, &v.ksplit);
     return v;
   }();
   return t;
@@ -378,7 +435,7 @@ hipError_t launch_gemm(const GemmParams& pin, int precision, hipStream_t st) {
     if (p.seg[s].c0 % 32 != 0 || p.seg[s].c1 % 32 != 0) return hipErrorInvalidValue;
     p.seg[s].nkt = p.seg[s].taps * (p.seg[s].c0 + p.seg[s].c1) / bk;
   }
-  if (big) return Tiles<32>::T0::launch(p, x3, st);
-  if (bk == 64) return Tiles<64>::launch(p, x3, tune.min_wg, st);
-  return Tiles<32>::launch(p, x3, tune.min_wg > 0 ? tune.min_wg : 1, st);
+  if (big) return tune.ksplit ? Tiles<32>::T0::launch(p, x3, st) : Tiles<32>::T0S::launch(p, x3, st);
+  if (bk == 64) return Tiles<64>::launch(p, x3, tune.min_wg, tune.ksplit != 0, st);
+  return Tiles<32>::launch(p, x3, tune.min_wg > 0 ? tune.min_wg : 1, false, st);
 }
