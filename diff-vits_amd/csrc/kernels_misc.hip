@@ -108,98 +108,62 @@ hipError_t launch_split(const float* in, bf16_t* hi, bf16_t* lo, int64_t n, hipS
 // y = act(x*scale + shift) -> hi/lo planes, 16-byte loads, 8-byte stores.
 // ---------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_gn_apply(const GnApplyParams p, int rows_per_block) {
-  extern __shared__ float sm[];          // scale[ctot] | shift[ctot] | (double) group sums
+  // grid = (frame chunks, groups, batch): a workgroup normalises `rows_per_block` frames of ONE group
+  // (cg channels) of one batch item, so it only reduces that group's slice of the statistics slab
+  __shared__ float s_scale[512], s_shift[512];
+  __shared__ double s_red[8];
   const int ctot = p.c0 + p.c1, G = p.groups, cg = ctot / G;
-  float* s_scale = sm;
-  float* s_shift = sm + ctot;
-  double* s_gs = reinterpret_cast<double*>(sm + 2 * ctot);      // [G][2]
-  double* s_cs = s_gs + 2 * G;                                  // [ctot][2] per-channel sums
-  const int b = blockIdx.y, tid = threadIdx.x;
+  const int g = blockIdx.y, b = blockIdx.z, tid = threadIdx.x;
+  const int cbase = g * cg;
   if (p.scale_in) {
-    for (int c = tid; c < ctot; c += 256) {
-      s_scale[c] = p.scale_in[(size_t)b * ctot + c];
-      s_shift[c] = p.shift_in[(size_t)b * ctot + c];
+    for (int c = tid; c < cg; c += 256) {
+      s_scale[c] = p.scale_in[(size_t)b * ctot + cbase + c];
+      s_shift[c] = p.shift_in[(size_t)b * ctot + cbase + c];
     }
   } else {
     const int RB = p.T >> 5;             // 32-row blocks per batch item (T % 32 == 0)
-    // per-channel sums over the row blocks, all 256 threads busy: channels with fewer than 256 lanes
-    // split their row-block range over nsub lanes
-    const int nsub = ctot >= 256 ? 1 : 256 / ctot;
-    double* s_part = s_cs + 2 * ctot;    // [nsub][ctot][2]
-    for (int item = tid; item < ctot * nsub; item += 256) {
-      const int sub = item / ctot, c = item - sub * ctot;
+    double s1 = 0, s2 = 0;
+    for (int item = tid; item < cg * RB; item += 256) {
+      const int rb = item / cg, c = cbase + (item - rb * cg);
       const bool first = c < p.c0;
       const float2* slab = reinterpret_cast<const float2*>(first ? p.slab0 : p.slab1);
       const int ld = first ? p.c0 : p.c1, cc = first ? c : c - p.c0;
-      const float2* src = slab + (size_t)b * RB * ld + cc;
-      const int r0 = sub * RB / nsub, r1 = (sub + 1) * RB / nsub;
-      double s1 = 0, s2 = 0;
-      int rb = r0;
-      for (; rb + 4 <= r1; rb += 4) {          // 4 independent loads in flight
-        const float2 v0 = src[(size_t)rb * ld], v1 = src[(size_t)(rb + 1) * ld];
-        const float2 v2 = src[(size_t)(rb + 2) * ld], v3 = src[(size_t)(rb + 3) * ld];
-        s1 += ((double)v0.x + (double)v1.x) + ((double)v2.x + (double)v3.x);
-        s2 += ((double)v0.y + (double)v1.y) + ((double)v2.y + (double)v3.y);
-      }
-      for (; rb < r1; ++rb) { const float2 v = src[(size_t)rb * ld]; s1 += v.x; s2 += v.y; }
-      s_part[2 * item] = s1;
-      s_part[2 * item + 1] = s2;
+      const float2 v = slab[(size_t)(b * RB + rb) * ld + cc];
+      s1 += v.x;
+      s2 += v.y;
     }
+    s1 = wave_sum_d(s1);
+    s2 = wave_sum_d(s2);
+    if ((tid & 63) == 0) { s_red[(tid >> 6) * 2] = s1; s_red[(tid >> 6) * 2 + 1] = s2; }
     __syncthreads();
-    for (int c = tid; c < ctot; c += 256) {
-      double s1 = 0, s2 = 0;
-      for (int sub = 0; sub < nsub; ++sub) { s1 += s_part[2 * (sub * ctot + c)]; s2 += s_part[2 * (sub * ctot + c) + 1]; }
-      s_cs[2 * c] = s1;
-      s_cs[2 * c + 1] = s2;
-    }
-    __syncthreads();
-    // group reduction: 256/G threads per group (a power of two <= 64 for G = 4..64), shuffle tree
-    const int tpg = 256 / G;
-    if (256 % G == 0 && tpg <= 64 && (tpg & (tpg - 1)) == 0) {
-      const int g = tid / tpg, sub = tid % tpg;
-      double s1 = 0, s2 = 0;
-      for (int c = g * cg + sub; c < (g + 1) * cg; c += tpg) { s1 += s_cs[2 * c]; s2 += s_cs[2 * c + 1]; }
-      for (int o = tpg >> 1; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }
-      if (sub == 0) {
-        const double n = (double)cg * (double)p.T;
-        const double mean = s1 / n;
-        double var = s2 / n - mean * mean;
-        var = var > 0 ? var : 0;
-        s_gs[2 * g] = mean;
-        s_gs[2 * g + 1] = 1.0 / sqrt(var + (double)p.eps);
-      }
-    } else if (tid < G) {
-      double s1 = 0, s2 = 0;
-      for (int c = tid * cg; c < (tid + 1) * cg; ++c) { s1 += s_cs[2 * c]; s2 += s_cs[2 * c + 1]; }
-      const double n = (double)cg * (double)p.T;
-      const double mean = s1 / n;
-      double var = s2 / n - mean * mean;
-      var = var > 0 ? var : 0;
-      s_gs[2 * tid] = mean;
-      s_gs[2 * tid + 1] = 1.0 / sqrt(var + (double)p.eps);
-    }
-    __syncthreads();
-    for (int c = tid; c < ctot; c += 256) {
-      const int g = c / cg;
-      const float a = (float)s_gs[2 * g + 1] * p.gamma[c];
-      const float sh = p.beta[c] - (float)s_gs[2 * g] * a;
-      const float ts = p.tscale ? 1.0f + p.tscale[(size_t)b * p.ld_t + c] : 1.0f;
-      const float tb = p.tshift ? p.tshift[(size_t)b * p.ld_t + c] : 0.0f;
+    const double t1 = (s_red[0] + s_red[2]) + (s_red[4] + s_red[6]);
+    const double t2 = (s_red[1] + s_red[3]) + (s_red[5] + s_red[7]);
+    const double n = (double)cg * (double)p.T;
+    const double mean = t1 / n;
+    double var = t2 / n - mean * mean;
+    var = var > 0 ? var : 0;
+    const float rstd = (float)(1.0 / sqrt(var + (double)p.eps));
+    for (int c = tid; c < cg; c += 256) {
+      const int cc = cbase + c;
+      const float a = rstd * p.gamma[cc];
+      const float sh = p.beta[cc] - (float)mean * a;
+      const float ts = p.tscale ? 1.0f + p.tscale[(size_t)b * p.ld_t + cc] : 1.0f;
+      const float tb = p.tshift ? p.tshift[(size_t)b * p.ld_t + cc] : 0.0f;
       s_scale[c] = a * ts;
       s_shift[c] = fmaf(sh, ts, tb);
     }
   }
   __syncthreads();
-  const int ncol4 = ctot >> 2;
-  const int t0 = blockIdx.x * rows_per_block, t1 = min(p.T, t0 + rows_per_block);
-  const int total = (t1 - t0) * ncol4;
+  const int ncol4 = cg >> 2;
+  const int t0 = blockIdx.x * rows_per_block, t1r = min(p.T, t0 + rows_per_block);
+  const int total = (t1r - t0) * ncol4;
   for (int i = tid; i < total; i += 256) {
-    const int r = i / ncol4, j = i - r * ncol4, c = j * 4;
+    const int r = i / ncol4, j = i - r * ncol4, c = cbase + j * 4;
     const size_t row = (size_t)b * p.T + t0 + r;
     const bool first = c < p.c0;
     const float4 v = *reinterpret_cast<const float4*>(first ? p.a0 + row * p.c0 + c : p.a1 + row * p.c1 + (c - p.c0));
-    const float4 sc = *reinterpret_cast<const float4*>(s_scale + c);
-    const float4 sh = *reinterpret_cast<const float4*>(s_shift + c);
+    const float4 sc = *reinterpret_cast<const float4*>(s_scale + j * 4);
+    const float4 sh = *reinterpret_cast<const float4*>(s_shift + j * 4);
     float4 y;
     y.x = fmaf(v.x, sc.x, sh.x); y.y = fmaf(v.y, sc.y, sh.y); y.z = fmaf(v.z, sc.z, sh.z); y.w = fmaf(v.w, sc.w, sh.w);
     if (p.silu) {
@@ -221,15 +185,16 @@ __global__ __launch_bounds__(256) void k_gn_apply(const GnApplyParams p, int row
 
 hipError_t launch_gn_apply(const GnApplyParams& p, hipStream_t st) {
   const int ctot = p.c0 + p.c1;
-  if (ctot % 4 != 0 || p.c0 % 4 != 0 || ctot % p.groups != 0 || p.groups > 64) return hipErrorInvalidValue;
+  if (ctot % p.groups != 0) return hipErrorInvalidValue;
+  const int cg = ctot / p.groups;
+  if (cg % 4 != 0 || p.c0 % 4 != 0 || cg > 512 || p.groups > 64) return hipErrorInvalidValue;
   if (!p.scale_in && (p.T % 32 != 0 || !p.slab0 || (p.c1 && !p.slab1))) return hipErrorInvalidValue;
-  // ~512 workgroups: every workgroup re-derives its batch item's statistics from the slab (L2-resident,
-  // <= 32 row blocks), then streams its rows
-  int rpb = (p.B * p.T + 511) / 512;
-  rpb = rpb < 4 ? 4 : (rpb > 64 ? 64 : rpb);
-  const int nsub = ctot >= 256 ? 1 : 256 / ctot;
-  const size_t smem = (size_t)2 * ctot * 4 + (size_t)(2 * p.groups + 2 * ctot + 2 * ctot * nsub) * 8;
-  hipLaunchKernelGGL(k_gn_apply, dim3((p.T + rpb - 1) / rpb, p.B), dim3(256), smem, st, p, rpb);
+  // ~1024 workgroups: (frame chunks) x groups x batch
+  int chunks = 1024 / (p.groups * p.B);
+  chunks = chunks < 1 ? 1 : chunks;
+  int rpb = (p.T + chunks - 1) / chunks;
+  rpb = rpb < 4 ? 4 : rpb;
+  hipLaunchKernelGGL(k_gn_apply, dim3((p.T + rpb - 1) / rpb, p.groups, p.B), dim3(256), 0, st, p, rpb);
   return hipGetLastError();
 }
 
