@@ -99,6 +99,7 @@ struct RawW { float* p = nullptr; std::vector<int64_t> shape; size_t numel = 0; 
 
 struct PackedW {
   bf16_t* hi = nullptr; bf16_t* lo = nullptr; float* bias = nullptr;
+  float* u = nullptr;           // sum_k gamma[k]*W[n,k] (fused-LayerNorm consumers), packed row order
   int Kp = 0, N = 0, N_pad = 0;
 };
 
@@ -203,6 +204,7 @@ struct Builder {
   int B, T, L, prec;
   std::string err;
   hipStream_t pack_stream = nullptr;
+  bool fuse_ln = [] { const char* e = getenv("DVITS_FUSE_LN"); return e && e[0] == '1'; }();
 
   // ---- weights
   const RawW* raw(const std::string& name) {
@@ -265,6 +267,16 @@ struct Builder {
       s.kscale = pc.kscale.empty() ? nullptr : W(pc.kscale);
       if ((size_t)s.N * s.C * s.taps != r->numel) { err = "weight shape mismatch: " + pc.w; return nullptr; }
       if (launch_pack_weight(s, pw.hi, pw.lo, Kp, pack_stream) != hipSuccess) { err = "pack_weight launch failed"; return nullptr; }
+      if (s.kscale) {   // LayerNorm-folded piece: u[n] = sum_c gamma[c] * W[n, c]
+        if (!pw.u) {
+          if (hipMalloc((void**)&pw.u, (size_t)pw.N_pad * 4) != hipSuccess) { err = "hipMalloc(u) failed"; return nullptr; }
+          u->owned.push_back(pw.u);
+          (void)hipMemsetAsync(pw.u, 0, (size_t)pw.N_pad * 4, pack_stream);
+        }
+        if (launch_fold_bias(r->p, nullptr, s.kscale, pw.u, s.N, s.C, pc.n_off, pc.geglu, pack_stream) != hipSuccess) {
+          err = "fold(u) launch failed"; return nullptr;
+        }
+      }
     }
     if (!biases.empty()) {
       if (hipMalloc((void**)&pw.bias, (size_t)pw.N_pad * 4) != hipSuccess) { err = "hipMalloc(bias) failed"; return nullptr; }
@@ -497,52 +509,84 @@ struct Builder {
     if (!w_in || !w_qkv || !w_o1 || !w_q2 || !w_o2 || !w_gg || !w_ff || !w_out) return Act{};
     (void)D;
 
+    // Two ways to feed the three LayerNorms: (default) k_ln_apply writes normalised split planes for the
+    // consumer GEMM; (DVITS_FUSE_LN=1) the producer GEMM also emits raw planes + per-row partial statistics
+    // and the consumer finishes the normalisation in its epilogue.  Measured in round 1: the fused epilogues
+    // cost as much as the launches they remove (226 vs 236 ms per 50-step run), so the default stays unfused.
+    const int nblk = C / 32;
+    struct LnIn { Planes pl; float* stat = nullptr; };
+    auto ln_produce = [&](GemmParams& g) {   // producer side (fused mode only)
+      LnIn in;
+      if (!fuse_ln) return in;
+      in.pl = alloc_planes((size_t)M * C);
+      in.stat = alloc((size_t)M * nblk * 2);
+      g.out_hi = in.pl.hi; g.out_lo = in.pl.lo; g.rowstat_out = in.stat;
+      return in;
+    };
+    auto ln_consume = [&](GemmParams& g, LnIn& in, const float* x32, const PackedW* w) {
+      if (!fuse_ln) in.pl = ln_apply(ops, x32, M, C);
+      else { g.ln_stat = in.stat; g.ln_nblk = nblk; g.ln_u = w->u; g.ln_eps = 1e-5f; }
+      g.seg[0] = seg(in.pl, C, Planes{}, 0, 1, 0);
+    };
+    auto ln_release = [&](LnIn& in) { release(in.pl); if (in.stat) release(in.stat); };
+
     // GN(eps 1e-6) -> 1x1 proj_in
     Planes gn = norm_apply(ops, x, Act{}, p + "norm", 1e-6f, nullptr, nullptr, 0, false, nullptr);
     float* h = alloc((size_t)M * C);
-    { GemmParams g = gp_base(Tn, M, C); g.seg[0] = seg(gn, C, Planes{}, 0, 1, 0); g.out = h; gemm(ops, g, w_in, C); }
+    LnIn l1;
+    {
+      GemmParams g = gp_base(Tn, M, C); g.seg[0] = seg(gn, C, Planes{}, 0, 1, 0);
+      g.out = h; l1 = ln_produce(g); gemm(ops, g, w_in, C);
+    }
     release(gn);
     probe(p + "proj_in", h, Tn, C);
 
     // self-attention
-    Planes l1 = ln_apply(ops, h, M, C);
     float* qkv = alloc((size_t)M * 3 * C);
-    { GemmParams g = gp_base(Tn, M, 3 * C); g.seg[0] = seg(l1, C, Planes{}, 0, 1, 0); g.out = qkv; gemm(ops, g, w_qkv, C); }
-    release(l1);
+    {
+      GemmParams g = gp_base(Tn, M, 3 * C);
+      g.out = qkv; ln_consume(g, l1, h, w_qkv); gemm(ops, g, w_qkv, C);
+    }
+    ln_release(l1);
     Planes ao = attention(ops, qkv, 3 * C, qkv + C, qkv + 2 * C, 3 * C, nullptr, Tn, Tn, C);
     release(qkv);
     float* h2 = alloc((size_t)M * C);
+    LnIn l2;
     {
       GemmParams g = gp_base(Tn, M, C); g.seg[0] = seg(ao, C, Planes{}, 0, 1, 0);
-      g.epi = EPI_RESIDUAL; g.res = h; g.out = h2; gemm(ops, g, w_o1, C);
+      g.epi = EPI_RESIDUAL; g.res = h; g.out = h2; l2 = ln_produce(g);
+      gemm(ops, g, w_o1, C);
     }
     release(ao); release(h);
     probe(tb + "attn1", h2, Tn, C);
 
     // cross-attention (K/V hoisted: projected once per set_cond)
-    Planes l2 = ln_apply(ops, h2, M, C);
     float* q2 = alloc((size_t)M * C);
-    { GemmParams g = gp_base(Tn, M, C); g.seg[0] = seg(l2, C, Planes{}, 0, 1, 0); g.out = q2; gemm(ops, g, w_q2, C); }
-    release(l2);
+    {
+      GemmParams g = gp_base(Tn, M, C);
+      g.out = q2; ln_consume(g, l2, h2, w_q2); gemm(ops, g, w_q2, C);
+    }
+    ln_release(l2);
     float* kv = cross_kv[p];
     ao = attention(ops, q2, C, kv, kv + C, 2 * C, mask_bias, Tn, L, C);
     release(q2);
     float* h3 = alloc((size_t)M * C);
+    LnIn l3;
     {
       GemmParams g = gp_base(Tn, M, C); g.seg[0] = seg(ao, C, Planes{}, 0, 1, 0);
-      g.epi = EPI_RESIDUAL; g.res = h2; g.out = h3; gemm(ops, g, w_o2, C);
+      g.epi = EPI_RESIDUAL; g.res = h2; g.out = h3; l3 = ln_produce(g);
+      gemm(ops, g, w_o2, C);
     }
     release(ao); release(h2);
     probe(tb + "attn2", h3, Tn, C);
 
     // GEGLU feed-forward: the GEGLU product and the FF output only feed GEMMs -> split planes only
-    Planes l3 = ln_apply(ops, h3, M, C);
     Planes gg = alloc_planes((size_t)M * 4 * C);
     {
-      GemmParams g = gp_base(Tn, M, 8 * C); g.seg[0] = seg(l3, C, Planes{}, 0, 1, 0);
-      g.epi = EPI_GEGLU; g.out_hi = gg.hi; g.out_lo = gg.lo; g.ldo = 4 * C; gemm(ops, g, w_gg, C);
+      GemmParams g = gp_base(Tn, M, 8 * C);
+      g.epi = EPI_GEGLU; g.out_hi = gg.hi; g.out_lo = gg.lo; g.ldo = 4 * C; ln_consume(g, l3, h3, w_gg); gemm(ops, g, w_gg, C);
     }
-    release(l3);
+    ln_release(l3);
     Planes h4 = alloc_planes((size_t)M * C);
     float* h4f = u->keep_intermediates ? alloc((size_t)M * C) : nullptr;
     {

@@ -214,6 +214,22 @@ __global__ __launch_bounds__(64 * WM * WN * KS) void k_gemm(const GemmParams p) 
     }
   }
 
+  // fused LayerNorm (consumer side): per-row mean / rstd of this tile's rows from the producer's partials
+  __shared__ float2 s_ln[BM];
+  if (p.ln_stat) {
+    for (int r = tid; r < BM; r += 64 * NWV) {
+      const int m = min(m0 + r, p.M - 1);
+      const float2* src = reinterpret_cast<const float2*>(p.ln_stat) + (size_t)m * p.ln_nblk;
+      float s1 = 0.f, s2 = 0.f;
+      for (int k = 0; k < p.ln_nblk; ++k) { const float2 v = src[k]; s1 += v.x; s2 += v.y; }
+      const float inv_c = 1.0f / (float)(p.ln_nblk * 32);
+      const float mean = s1 * inv_c;
+      const float var = fmaxf(s2 * inv_c - mean * mean, 0.f);
+      s_ln[r] = make_float2(mean, 1.0f / sqrtf(var + p.ln_eps));
+    }
+    __syncthreads();
+  }
+
   // ---- main loop: wait(tile kt) -> barrier -> issue(tile kt+NSTAGE-1) -> compute(tile kt) ----
   // NSTAGE-1 tiles are in flight; the counted vmcnt leaves the younger ones outstanding across the barrier
 #pragma unroll
@@ -260,14 +276,23 @@ __global__ __launch_bounds__(64 * WM * WN * KS) void k_gemm(const GemmParams p) 
       if (ncol < p.N) {
         const float ba = p.bias ? p.bias[ncol] : 0.f;
         const float bg = p.bias ? p.bias[ncol + 32] : 0.f;
+        const float ua = p.ln_stat ? p.ln_u[ncol] : 0.f;
+        const float ug = p.ln_stat ? p.ln_u[ncol + 32] : 0.f;
 #pragma unroll
         for (int i = 0; i < FM; ++i)
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
-            const int m = m0 + (wm * FM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            const int rl = (wm * FM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            const int m = m0 + rl;
             if (m < p.M) {
-              const float a = acc[i][0][r] + ba;
-              const float g = acc[i][1][r] + bg;
+              float a = acc[i][0][r], g = acc[i][1][r];
+              if (p.ln_stat) {
+                const float2 st = s_ln[rl];
+                a = st.y * (a - st.x * ua);
+                g = st.y * (g - st.x * ug);
+              }
+              a += ba;
+              g += bg;
               const float v = a * gelu_erf(g);
               const size_t o = (size_t)m * p.ldo + oc;
               if (p.out) p.out[o] = v;
@@ -288,6 +313,7 @@ __global__ __launch_bounds__(64 * WM * WN * KS) void k_gemm(const GemmParams p) 
     const bool n_ok = n < p.N;
     const int nn = n_ok ? n : 0;
     const float bv = p.bias ? p.bias[nn] : 0.f;
+    const float un = p.ln_stat ? p.ln_u[nn] : 0.f;
 #pragma unroll
     for (int i = 0; i < FM; ++i) {
       const int mrow0 = m0 + (wm * FM + i) * 32;
@@ -304,13 +330,18 @@ __global__ __launch_bounds__(64 * WM * WN * KS) void k_gemm(const GemmParams p) 
         }
       }
       float s1 = 0.f, s2 = 0.f;
+      float vv[16];
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int m = mrow0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        const int rl = (wm * FM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        const int m = m0 + rl;
         const bool ok = m < p.M && n_ok;
-        float v = acc[i][j][r] + bv;
+        float v = acc[i][j][r];
+        if (p.ln_stat) { const float2 st = s_ln[rl]; v = st.y * (v - st.x * un); }
+        v += bv;
         if (p.epi == EPI_RESIDUAL) v += rv[r];
         v = ok ? v : 0.f;
+        vv[r] = v;
         s1 += v;
         s2 += v * v;
         if (!ok) continue;
@@ -325,6 +356,19 @@ __global__ __launch_bounds__(64 * WM * WN * KS) void k_gemm(const GemmParams p) 
             p.out_hi[o] = (bf16_t)(hb & 0xffffu);
             if (p.out_lo) p.out_lo[o] = (bf16_t)(cvt_pk_bf16(v - __uint_as_float(hb << 16), 0.f) & 0xffffu);
           }
+        }
+      }
+      if (p.rowstat_out) {   // row partials over this fragment's 32 columns (LayerNorm of the consumer)
+        const int nblk_total = (p.N + 31) >> 5;
+        const int cb = (n0 + (wn * FN + j) * 32) >> 5;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          float a = vv[r], q = vv[r] * vv[r];
+#pragma unroll
+          for (int o = 1; o < 32; o <<= 1) { a += __shfl_xor(a, o); q += __shfl_xor(q, o); }
+          const int m = mrow0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+          if (l31 == 0 && m < p.M && cb < nblk_total)
+            reinterpret_cast<float2*>(p.rowstat_out)[(size_t)m * nblk_total + cb] = make_float2(a, q);
         }
       }
       if (p.stats) {   // column sums over this 32-row block (the two lane halves hold 16 rows each)

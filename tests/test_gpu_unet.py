@@ -293,3 +293,20 @@ def test_config5_c100_shard_equivalence():
         full = run(slice(0, 4))
         parts = torch.cat([run(slice(0, 2)), run(slice(2, 4))], 0)
     assert rel_l2(parts.cpu().numpy(), full.cpu().numpy()) < 1e-5
+
+
+def test_unet_fused_layernorm_mode(gold):
+    """DVITS_FUSE_LN=1: LayerNorm finished in the consumer GEMM's epilogue from the producer's per-row
+    partial statistics (an alternative schedule kept for tuning); same parity bar."""
+    os.environ["DVITS_FUSE_LN"] = "1"
+    try:
+        m, kw, sd, sample, t, enc, mask = _build("oddT")
+        with torch.no_grad():
+            y = m(torch.from_numpy(sample).cuda(), torch.from_numpy(t).cuda(), torch.from_numpy(enc).cuda(),
+                  encoder_attention_mask=torch.from_numpy(mask).cuda()).sample
+        n_launch, _ = m.hip_engine().stats()
+    finally:
+        os.environ.pop("DVITS_FUSE_LN", None)
+    assert rel_l2(y.cpu().numpy(), gold("unet_oddT.npz")["y"]) < 2e-4
+    m2, *_ = _build("oddT")
+    assert m2.hip_engine().prepare(2, 100, 50) and m2.hip_engine().stats()[0] == n_launch + 48
