@@ -41,6 +41,26 @@ __device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst) {
   asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
                : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
 }
+#ifdef DV_GEMM_TRACE
+// development build only (make trace): per-workgroup s_memtime stamps of the kernel's phases
+__device__ unsigned long long g_gemm_trace[8192 * 16];
+#define DV_TRACE(i) do { if (threadIdx.x == 0 && blockIdx.x < 8192) g_gemm_trace[blockIdx.x * 16 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+extern "C" int dv_debug_gemm_trace(unsigned long long* host, int n_wg) {
+  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_gemm_trace), (size_t)n_wg * 16 * sizeof(unsigned long long));
+}
+extern "C" int dv_debug_gemm_trace_clear() {
+  void* d = nullptr;
+  hipError_t e = hipGetSymbolAddress(&d, HIP_SYMBOL(g_gemm_trace));
+  return (int)(e != hipSuccess ? e : hipMemset(d, 0, sizeof(g_gemm_trace)));
+}
+#else
+#define DV_TRACE(i) do {} while (0)
+#endif
+__device__ __forceinline__ void glds4(const void* gsrc, unsigned lds_dst) {   // 4 bytes per lane
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
@@ -67,6 +87,16 @@ __global__ __launch_bounds__(64 * WM * WN * KS) void k_gemm(const GemmParams p) 
   static_assert(BM % (RPI * NWV) == 0 && BN % (RPI * NWV) == 0, "tile rows must split over the waves");
   extern __shared__ __attribute__((aligned(1024))) char smem[];
 
+  DV_TRACE(0);
+#ifdef DV_GEMM_TRACE
+  if (threadIdx.x == 0 && blockIdx.x < 8192) {
+    unsigned xcc, hw;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+    g_gemm_trace[blockIdx.x * 16 + 6] = ((unsigned long long)xcc << 32) | hw;
+    g_gemm_trace[blockIdx.x * 16 + 7] = wall_clock64();
+  }
+#endif
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -84,6 +114,9 @@ __global__ __launch_bounds__(64 * WM * WN * KS) void k_gemm(const GemmParams p) 
   }
   const int m0 = (bid / n_tiles_n) * BM;
   const int n0 = (bid % n_tiles_n) * BN;
+#ifdef DV_GEMM_TRACE
+  if (m0 + n0 >= 0) DV_TRACE(8);    // first kernel-argument dependent value is available
+#endif
 
   // ---- per-lane DMA geometry: lane -> (row within the instruction's RPI rows, LDS chunk slot) ----
   const int l_row = lane / CPR, l_slot = lane % CPR;
@@ -109,31 +142,38 @@ __global__ __launch_bounds__(64 * WM * WN * KS) void k_gemm(const GemmParams p) 
     b_off[q] = ((size_t)(n0 + r) * p.Kp + (l_slot ^ swz(r)) * 8) * 2;   // byte offset at kt = 0
   }
 
-  // running decode of the k-tile being issued
-  int ld_seg = 0, ld_tap = 0, ld_cc = 0;
+  // Source of the k-tile being issued, kept in wave-uniform registers and advanced incrementally: the segment
+  // descriptor (kernel-argument memory) is only re-read when a source tensor / tap is exhausted, never on the
+  // per-tile path (a scalar load there sits on every wave's critical path right after the barrier).
   const int total_kt = p.seg[0].nkt + (p.nseg > 1 ? p.seg[1].nkt : 0);
+  int ld_seg = 0, ld_tap = 0, ld_half = 0;
+  const bf16_t* cur_hi; const bf16_t* cur_lo;
+  int cur_ld, cur_col, cur_toff;
+  auto enter = [&]() {
+    const GemmSeg& sg = p.seg[ld_seg];
+    cur_hi = ld_half ? sg.a1_hi : sg.a0_hi;
+    cur_lo = ld_half ? sg.a1_lo : sg.a0_lo;
+    cur_ld = ld_half ? sg.c1 : sg.c0;
+    cur_col = 0;
+    cur_toff = ld_tap - sg.pad;
+  };
+  enter();
+  DV_TRACE(9);     // row geometry done
 
   auto issue = [&](int kt) {
-    const GemmSeg& s = p.seg[ld_seg];
-    const int ctot = s.c0 + s.c1;
-    const bool first = ld_cc < s.c0;
-    const bf16_t* src_hi = first ? s.a0_hi : s.a1_hi;
-    const bf16_t* src_lo = first ? s.a0_lo : s.a1_lo;
-    const int ld = first ? s.c0 : s.c1;
-    const int col = first ? ld_cc : ld_cc - s.c0;
     const unsigned st_base = smem_base + (unsigned)((kt % NSTAGE) * STAGE);
 #pragma unroll
     for (int q = 0; q < A_IPW; ++q) {
-      const int ts = arow_t[q] * p.stride + ld_tap - s.pad;
+      const int ts = arow_t[q] * p.stride + cur_toff;
       const bool ok = ((arow_ok >> q) & 1u) && ts >= 0 && ts < p.T_virt;
       int st = ts;
       st = p.up_mode == UP_X2 ? (ts >> 1) : st;
       st = p.up_mode == UP_SIZE ? min((int)floorf((float)ts * p.up_scale), p.T_in - 1) : st;
-      const size_t e = ((size_t)arow_b[q] * p.T_in + st) * ld + col + a_chunk[q] * 8;
+      const size_t e = ((size_t)arow_b[q] * p.T_in + st) * cur_ld + cur_col + a_chunk[q] * 8;
       const unsigned dst = st_base + (unsigned)(((q * NWV + wave) * RPI) * ROWB);
       // conv zero padding / rows >= M read a 16-byte zero page instead
-      glds16(ok ? (const void*)(src_hi + e) : (const void*)p.zero_page, dst);
-      if (SPLIT) glds16(ok ? (const void*)(src_lo + e) : (const void*)p.zero_page, dst + A_PL);
+      glds16(ok ? (const void*)(cur_hi + e) : (const void*)p.zero_page, dst);
+      if (SPLIT) glds16(ok ? (const void*)(cur_lo + e) : (const void*)p.zero_page, dst + A_PL);
     }
 #pragma unroll
     for (int q = 0; q < B_IPW; ++q) {
@@ -142,10 +182,15 @@ __global__ __launch_bounds__(64 * WM * WN * KS) void k_gemm(const GemmParams p) 
       glds16(reinterpret_cast<const char*>(p.w_hi) + o, dst);
       if (SPLIT) glds16(reinterpret_cast<const char*>(p.w_lo) + o, dst + B_PL);
     }
-    ld_cc += BK;
-    if (ld_cc == ctot) {
-      ld_cc = 0;
-      if (++ld_tap == s.taps) { ld_tap = 0; ++ld_seg; }
+    cur_col += BK;
+    if (cur_col == cur_ld) {     // wave-uniform, once per (source tensor, tap)
+      const GemmSeg& sg = p.seg[ld_seg];
+      if (ld_half == 0 && sg.c1 > 0) ld_half = 1;
+      else {
+        ld_half = 0;
+        if (++ld_tap == sg.taps) { ld_tap = 0; ++ld_seg; }
+      }
+      if (ld_seg < p.nseg) enter();
     }
   };
 
@@ -183,16 +228,40 @@ __global__ __launch_bounds__(64 * WM * WN * KS) void k_gemm(const GemmParams p) 
         bh[j] = *reinterpret_cast<const bf16x8*>(b_hi + off);
         if (SPLIT) bl[j] = *reinterpret_cast<const bf16x8*>(b_lo + off);
       }
+      // weights as the first operand: the accumulator is the TRANSPOSED tile, lane = output row m,
+      // registers = 16 output columns in runs of 4 -> 16-byte epilogue loads / stores per lane.
+      // Term-major order: consecutive MFMAs write different accumulators.
+      if (SPLIT) {
+#pragma unroll
+        for (int i = 0; i < FM; ++i)
+#pragma unroll
+          for (int j = 0; j < FN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh[j], al[i], acc[i][j], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < FM; ++i)
+#pragma unroll
+          for (int j = 0; j < FN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bl[j], ah[i], acc[i][j], 0, 0, 0);
+      }
 #pragma unroll
       for (int i = 0; i < FM; ++i)
 #pragma unroll
-        for (int j = 0; j < FN; ++j) {
-          if (SPLIT) {
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
-          }
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
-        }
+        for (int j = 0; j < FN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh[j], ah[i], acc[i][j], 0, 0, 0);
+    }
+  };
+
+  // accumulator fragment (i, j), lane (l31, lh), register r = 4*g + e  holds
+  //   row m = m0 + (wm*FM+i)*32 + l31,  column n = n0 + (wn*FN+j)*32 + 8*g + 4*lh + e
+  // vector (16-byte) epilogue accesses need every row pitch and N to be a multiple of 4
+  const bool vec4 = ((p.N | p.ldo | (p.epi == EPI_RESIDUAL ? p.ldres : 0)) & 3) == 0;
+  auto load4 = [&](const float* base, size_t row_off, int nb, float* dst) {   // dst[0..3] = base[row_off + nb + e]
+    if (vec4) {
+      const float4 v = nb < p.N ? *reinterpret_cast<const float4*>(base + row_off + nb) : make_float4(0.f, 0.f, 0.f, 0.f);
+      dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w;
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) dst[e] = nb + e < p.N ? base[row_off + nb + e] : 0.f;
     }
   };
 
@@ -201,16 +270,13 @@ __global__ __launch_bounds__(64 * WM * WN * KS) void k_gemm(const GemmParams p) 
   float rpre[PRE_RES ? FM * FN * 16 : 1];
   if (PRE_RES && p.epi == EPI_RESIDUAL) {
 #pragma unroll
-    for (int j = 0; j < FN; ++j) {
-      const int n = n0 + (wn * FN + j) * 32 + l31;
-      const int nn = n < p.N ? n : 0;
+    for (int i = 0; i < FM; ++i) {
+      const size_t ro = (size_t)min(m0 + (wm * FM + i) * 32 + l31, p.M - 1) * p.ldres;
 #pragma unroll
-      for (int i = 0; i < FM; ++i)
+      for (int j = 0; j < FN; ++j)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int m = min(m0 + (wm * FM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh, p.M - 1);
-          rpre[(j * FM + i) * 16 + r] = p.res[(size_t)m * p.ldres + nn];
-        }
+        for (int g = 0; g < 4; ++g)
+          load4(p.res, ro, n0 + (wn * FN + j) * 32 + 8 * g + 4 * lh, &rpre[(j * FM + i) * 16 + 4 * g]);
     }
   }
 
@@ -230,21 +296,39 @@ __global__ __launch_bounds__(64 * WM * WN * KS) void k_gemm(const GemmParams p) 
     __syncthreads();
   }
 
-  // ---- main loop: wait(tile kt) -> barrier -> issue(tile kt+NSTAGE-1) -> compute(tile kt) ----
+  // bias of this tile's columns -> LDS by DMA, oldest in the queue: landed before the first tile's wait returns
+  __shared__ __attribute__((aligned(16))) float s_bias[BN < 64 ? 64 : BN];
+  if (wave < (BN + 63) / 64) {
+    const int n = min(n0 + wave * 64 + lane, p.N - 1);
+    glds4(p.bias ? (const void*)(p.bias + n) : (const void*)p.zero_page, (unsigned)(size_t)s_bias + wave * 256);
+  }
+
+  // ---- main loop: wait(tile kt) -> barrier -> compute(tile kt) -> issue(tile kt+NSTAGE-1) ----
   // NSTAGE-1 tiles are in flight; the counted vmcnt leaves the younger ones outstanding across the barrier
+  DV_TRACE(10);    // residual prefetch / LayerNorm rows / bias DMA issued
 #pragma unroll
-  for (int t = 0; t < NSTAGE - 1; ++t)
+  for (int t = 0; t < NSTAGE - 1; ++t) {
     if (t < total_kt) issue(t);
+#ifdef DV_GEMM_TRACE
+    if (t == 0) DV_TRACE(11);
+#endif
+  }
+  DV_TRACE(1);
   for (int kt = 0; kt < total_kt; ++kt) {
     const int younger = min(NSTAGE - 2, total_kt - 1 - kt);   // tiles issued after kt that may stay in flight
     if (younger >= 2) wait_vmcnt<2 * LPT>();
     else if (younger == 1) wait_vmcnt<LPT>();
     else wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();                    // tile kt visible; every wave is done with tile kt-1
-    if (kt + NSTAGE - 1 < total_kt) issue(kt + NSTAGE - 1);   // overwrites the stage tile kt-1 was read from
-    compute(kt);
+#ifdef DV_GEMM_TRACE
+    if (kt == 0) DV_TRACE(2);
+#endif
+    compute(kt);                                     // LDS reads + MFMAs first: they run on while ...
+    if (kt + NSTAGE - 1 < total_kt) issue(kt + NSTAGE - 1);   // ... the next DMA's addresses are formed; it overwrites
+                                                     // the stage tile kt-1 was read from (all waves are past it)
   }
 
+  DV_TRACE(3);
   if (KS == 2) {   // add the two k-groups' partial accumulators through LDS (lane-linear, conflict-free)
     __builtin_amdgcn_s_barrier();                    // every wave is done reading the ring
     float* red = reinterpret_cast<float*>(smem);
@@ -267,120 +351,173 @@ __global__ __launch_bounds__(64 * WM * WN * KS) void k_gemm(const GemmParams p) 
   }
 
   // ---- epilogue ----
+  DV_TRACE(4);
+  // store 4 consecutive columns of one row: fp32 and/or split bf16 planes
+  auto store4 = [&](size_t o, int nb, const float* v) {
+    if (vec4) {
+      if (nb >= p.N) return;
+      if (p.out) *reinterpret_cast<float4*>(p.out + o) = make_float4(v[0], v[1], v[2], v[3]);
+      if (p.out_hi) {
+        const unsigned h01 = cvt_pk_bf16(v[0], v[1]), h23 = cvt_pk_bf16(v[2], v[3]);
+        *reinterpret_cast<uint2*>(p.out_hi + o) = make_uint2(h01, h23);
+        if (p.out_lo) {
+          const unsigned l01 = cvt_pk_bf16(v[0] - __uint_as_float(h01 << 16), v[1] - __uint_as_float(h01 & 0xffff0000u));
+          const unsigned l23 = cvt_pk_bf16(v[2] - __uint_as_float(h23 << 16), v[3] - __uint_as_float(h23 & 0xffff0000u));
+          *reinterpret_cast<uint2*>(p.out_lo + o) = make_uint2(l01, l23);
+        }
+      }
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        if (nb + e >= p.N) continue;
+        if (p.out) p.out[o + e] = v[e];
+        if (p.out_hi) {
+          const unsigned hb = cvt_pk_bf16(v[e], 0.f);
+          p.out_hi[o + e] = (bf16_t)(hb & 0xffffu);
+          if (p.out_lo) p.out_lo[o + e] = (bf16_t)(cvt_pk_bf16(v[e] - __uint_as_float(hb << 16), 0.f) & 0xffffu);
+        }
+      }
+    }
+  };
+
   if (p.epi == EPI_GEGLU) {
     // packed column order: per 64-column block, [32 x a | 32 x gate]  (needs FN == 2 per wave)
     if constexpr (FN == 2) {
       const int blk = (n0 + wn * 64) >> 6;          // 64-column block index
-      const int oc = blk * 32 + l31;                // output column
-      const int ncol = n0 + wn * 64 + l31;          // packed column of `a`
-      if (ncol < p.N) {
-        const float ba = p.bias ? p.bias[ncol] : 0.f;
-        const float bg = p.bias ? p.bias[ncol + 32] : 0.f;
-        const float ua = p.ln_stat ? p.ln_u[ncol] : 0.f;
-        const float ug = p.ln_stat ? p.ln_u[ncol + 32] : 0.f;
+      const int nca = n0 + wn * 64 + 4 * lh;        // packed column of `a` for g = 0, e = 0
+      float ba[16], bg[16], ua[16], ug[16];
 #pragma unroll
-        for (int i = 0; i < FM; ++i)
+      for (int g = 0; g < 4; ++g) {
+        const int nb = nca + 8 * g;
 #pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int rl = (wm * FM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-            const int m = m0 + rl;
-            if (m < p.M) {
-              float a = acc[i][0][r], g = acc[i][1][r];
-              if (p.ln_stat) {
-                const float2 st = s_ln[rl];
-                a = st.y * (a - st.x * ua);
-                g = st.y * (g - st.x * ug);
-              }
-              a += ba;
-              g += bg;
-              const float v = a * gelu_erf(g);
-              const size_t o = (size_t)m * p.ldo + oc;
-              if (p.out) p.out[o] = v;
-              if (p.out_hi) {
-                const unsigned hb = cvt_pk_bf16(v, 0.f);
-                p.out_hi[o] = (bf16_t)(hb & 0xffffu);
-                if (p.out_lo) p.out_lo[o] = (bf16_t)(cvt_pk_bf16(v - __uint_as_float(hb << 16), 0.f) & 0xffffu);
-              }
+        for (int e = 0; e < 4; ++e) {
+          const bool ok = nb + e < p.N;
+          ba[4 * g + e] = s_bias[wn * 64 + 8 * g + 4 * lh + e];
+          bg[4 * g + e] = s_bias[wn * 64 + 32 + 8 * g + 4 * lh + e];
+          ua[4 * g + e] = (p.ln_stat && ok) ? p.ln_u[nb + e] : 0.f;
+          ug[4 * g + e] = (p.ln_stat && ok) ? p.ln_u[nb + e + 32] : 0.f;
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < FM; ++i) {
+        const int rl = (wm * FM + i) * 32 + l31;
+        const int m = m0 + rl;
+        if (m >= p.M) continue;
+        const float2 st = p.ln_stat ? s_ln[rl] : make_float2(0.f, 1.f);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          float v[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int r = 4 * g + e;
+            float a = acc[i][0][r], gt = acc[i][1][r];
+            if (p.ln_stat) {
+              a = st.y * (a - st.x * ua[r]);
+              gt = st.y * (gt - st.x * ug[r]);
             }
+            v[e] = (a + ba[r]) * gelu_erf(gt + bg[r]);
           }
+          // output column of packed `a` column nb: 32 per 64-column block; nb < N  <=>  oc-run inside N/2
+          store4((size_t)m * p.ldo + blk * 32 + 8 * g + 4 * lh, nca + 8 * g, v);
+        }
       }
     }
+    DV_TRACE(5);
     return;
   }
 #pragma unroll
   for (int j = 0; j < FN; ++j) {
-    const int n = n0 + (wn * FN + j) * 32 + l31;
-    const bool n_ok = n < p.N;
-    const int nn = n_ok ? n : 0;
-    const float bv = p.bias ? p.bias[nn] : 0.f;
-    const float un = p.ln_stat ? p.ln_u[nn] : 0.f;
+    const int nf = n0 + (wn * FN + j) * 32 + 4 * lh;   // column of g = 0, e = 0
+    float bv[16], un[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int n = nf + 8 * (r >> 2) + (r & 3);
+      bv[r] = s_bias[(wn * FN + j) * 32 + 4 * lh + 8 * (r >> 2) + (r & 3)];
+      un[r] = (p.ln_stat && n < p.N) ? p.ln_u[n] : 0.f;
+    }
 #pragma unroll
     for (int i = 0; i < FM; ++i) {
       const int mrow0 = m0 + (wm * FM + i) * 32;
-      // residual operand: all 16 loads issued back to back (clamped, unconditional), one wait
+      const int rl = (wm * FM + i) * 32 + l31;
+      const int m = m0 + rl;
+      const bool m_ok = m < p.M;
+      const int mc = m_ok ? m : p.M - 1;
+      // residual operand: 4 x 16-byte loads issued back to back (clamped row), one wait
       float rv[16];
       if (p.epi == EPI_RESIDUAL) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          if (PRE_RES) rv[r] = rpre[(j * FM + i) * 16 + r];
-          else {
-            const int m = min(mrow0 + (r & 3) + 8 * (r >> 2) + 4 * lh, p.M - 1);
-            rv[r] = p.res[(size_t)m * p.ldres + nn];
+        for (int g = 0; g < 4; ++g) {
+          if (PRE_RES) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) rv[4 * g + e] = rpre[(j * FM + i) * 16 + 4 * g + e];
+          } else {
+            load4(p.res, (size_t)mc * p.ldres, nf + 8 * g, &rv[4 * g]);
           }
         }
       }
-      float s1 = 0.f, s2 = 0.f;
+      const float2 st = p.ln_stat ? s_ln[rl] : make_float2(0.f, 1.f);
       float vv[16];
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int rl = (wm * FM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        const int m = m0 + rl;
-        const bool ok = m < p.M && n_ok;
+        const int n = nf + 8 * (r >> 2) + (r & 3);
         float v = acc[i][j][r];
-        if (p.ln_stat) { const float2 st = s_ln[rl]; v = st.y * (v - st.x * un); }
-        v += bv;
+        if (p.ln_stat) v = st.y * (v - st.x * un[r]);
+        v += bv[r];
         if (p.epi == EPI_RESIDUAL) v += rv[r];
-        v = ok ? v : 0.f;
-        vv[r] = v;
-        s1 += v;
-        s2 += v * v;
-        if (!ok) continue;
-        if (p.epi == EPI_STORE_NCT) {
+        vv[r] = (m_ok && n < p.N) ? v : 0.f;
+      }
+      if (p.epi == EPI_STORE_NCT) {
+        // [B, N, T_out]: the 32 lanes of a half-wave write 32 consecutive frames of one channel
+        if (m_ok) {
           const int b = m / p.T_out, t = m - b * p.T_out;
-          p.out[((size_t)b * p.N + n) * p.T_out + t] = v;
-        } else {
-          const size_t o = (size_t)m * p.ldo + n;
-          if (p.out) p.out[o] = v;
-          if (p.out_hi) {
-            const unsigned hb = cvt_pk_bf16(v, 0.f);
-            p.out_hi[o] = (bf16_t)(hb & 0xffffu);
-            if (p.out_lo) p.out_lo[o] = (bf16_t)(cvt_pk_bf16(v - __uint_as_float(hb << 16), 0.f) & 0xffffu);
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int n = nf + 8 * (r >> 2) + (r & 3);
+            if (n < p.N) p.out[((size_t)b * p.N + n) * p.T_out + t] = vv[r];
           }
         }
+      } else if (m_ok) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) store4((size_t)m * p.ldo + nf + 8 * g, nf + 8 * g, &vv[4 * g]);
       }
       if (p.rowstat_out) {   // row partials over this fragment's 32 columns (LayerNorm of the consumer)
         const int nblk_total = (p.N + 31) >> 5;
         const int cb = (n0 + (wn * FN + j) * 32) >> 5;
+        float a = 0.f, q = 0.f;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          float a = vv[r], q = vv[r] * vv[r];
-#pragma unroll
-          for (int o = 1; o < 32; o <<= 1) { a += __shfl_xor(a, o); q += __shfl_xor(q, o); }
-          const int m = mrow0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-          if (l31 == 0 && m < p.M && cb < nblk_total)
-            reinterpret_cast<float2*>(p.rowstat_out)[(size_t)m * nblk_total + cb] = make_float2(a, q);
-        }
+        for (int r = 0; r < 16; ++r) { a += vv[r]; q += vv[r] * vv[r]; }
+        a += __shfl_xor(a, 32);
+        q += __shfl_xor(q, 32);
+        if (lh == 0 && m_ok && cb < nblk_total)
+          reinterpret_cast<float2*>(p.rowstat_out)[(size_t)m * nblk_total + cb] = make_float2(a, q);
       }
-      if (p.stats) {   // column sums over this 32-row block (the two lane halves hold 16 rows each)
-        s1 += __shfl_xor(s1, 32);
-        s2 += __shfl_xor(s2, 32);
-        if (lh == 0 && n_ok && mrow0 < p.M) {
-          float2* dst = reinterpret_cast<float2*>(p.stats) + (size_t)(mrow0 >> 5) * p.N + n;
-          *dst = make_float2(s1, s2);
+      if (p.stats) {
+        // column sums over this 32-row block: 16 values per lane summed across the 32 lanes of each half by a
+        // halving butterfly (8 + 4 + 2 + 1 exchanges, then one add with the neighbour lane)
+        float s1[16], s2[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { s1[r] = vv[r]; s2[r] = vv[r] * vv[r]; }
+#pragma unroll
+        for (int w = 8; w >= 1; w >>= 1) {
+          const bool up = (l31 & (2 * w)) != 0;      // lane keeps the upper half of its 2w values
+#pragma unroll
+          for (int k = 0; k < w; ++k) {
+            const float k1 = up ? s1[k + w] : s1[k], x1 = up ? s1[k] : s1[k + w];
+            const float k2 = up ? s2[k + w] : s2[k], x2 = up ? s2[k] : s2[k + w];
+            s1[k] = k1 + __shfl_xor(x1, 2 * w);
+            s2[k] = k2 + __shfl_xor(x2, 2 * w);
+          }
         }
+        s1[0] += __shfl_xor(s1[0], 1);
+        s2[0] += __shfl_xor(s2[0], 1);
+        const int r = (l31 >> 1) & 15;               // bit 4 -> r bit 3, ... bit 1 -> r bit 0
+        const int n = nf + 8 * (r >> 2) + (r & 3);
+        if ((l31 & 1) == 0 && n < p.N && mrow0 < p.M)
+          reinterpret_cast<float2*>(p.stats)[(size_t)(mrow0 >> 5) * p.N + n] = make_float2(s1[0], s2[0]);
       }
     }
   }
+  DV_TRACE(5);
 }
 
 template <int BM, int BN, int BK, int WM, int WN, int NSPLIT, int KS>
