@@ -22,6 +22,7 @@
 
 #include <cstdio>
 #include <cstdlib>
+#include <type_traits>
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
@@ -97,6 +98,10 @@ __global__ __launch_bounds__(64 * WM * WN * KS) void k_gemm(const GemmParams p) 
     g_gemm_trace[blockIdx.x * 16 + 7] = wall_clock64();
   }
 #endif
+  // touch one field of every 64-byte line of the argument block up front: the scalar loads go out together and
+  // miss once in parallel, instead of one dependent miss per line as the prologue reaches each field
+  asm volatile("" ::"s"(p.seg[0].a0_hi), "s"(p.seg[1].a0_hi), "s"(p.seg[1].pad), "s"(p.T_in), "s"(p.w_hi), "s"(p.M),
+               "s"(p.res), "s"(p.out_hi), "s"(p.zero_page), "s"(p.ln_u));
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -160,8 +165,11 @@ __global__ __launch_bounds__(64 * WM * WN * KS) void k_gemm(const GemmParams p) 
   enter();
   DV_TRACE(9);     // row geometry done
 
-  auto issue = [&](int kt) {
-    const unsigned st_base = smem_base + (unsigned)((kt % NSTAGE) * STAGE);
+  // One k-tile's DMA = LPT wave-instructions per thread ("units"): A rows (hi, lo plane) then B rows (hi, lo).
+  // prep_a() forms the A source addresses of the tile being issued; issue_unit() sends one unit; advance()
+  // moves the source state to the next k-tile.  The main loop spreads the units between its MFMA groups.
+  const void* asrc[A_IPW * NPL];
+  auto prep_a = [&]() {
 #pragma unroll
     for (int q = 0; q < A_IPW; ++q) {
       const int ts = arow_t[q] * p.stride + cur_toff;
@@ -170,18 +178,24 @@ __global__ __launch_bounds__(64 * WM * WN * KS) void k_gemm(const GemmParams p) 
       st = p.up_mode == UP_X2 ? (ts >> 1) : st;
       st = p.up_mode == UP_SIZE ? min((int)floorf((float)ts * p.up_scale), p.T_in - 1) : st;
       const size_t e = ((size_t)arow_b[q] * p.T_in + st) * cur_ld + cur_col + a_chunk[q] * 8;
-      const unsigned dst = st_base + (unsigned)(((q * NWV + wave) * RPI) * ROWB);
       // conv zero padding / rows >= M read a 16-byte zero page instead
-      glds16(ok ? (const void*)(cur_hi + e) : (const void*)p.zero_page, dst);
-      if (SPLIT) glds16(ok ? (const void*)(cur_lo + e) : (const void*)p.zero_page, dst + A_PL);
+      asrc[q * NPL] = ok ? (const void*)(cur_hi + e) : (const void*)p.zero_page;
+      if (SPLIT) asrc[q * NPL + 1] = ok ? (const void*)(cur_lo + e) : (const void*)p.zero_page;
     }
-#pragma unroll
-    for (int q = 0; q < B_IPW; ++q) {
+  };
+  auto issue_unit = [&](int kt, int u) {
+    const unsigned st_base = smem_base + (unsigned)((kt % NSTAGE) * STAGE);
+    if (u < A_IPW * NPL) {
+      const int q = u / NPL, pl = u % NPL;
+      glds16(asrc[u], st_base + (unsigned)(((q * NWV + wave) * RPI) * ROWB + pl * A_PL));
+    } else {
+      const int q = (u - A_IPW * NPL) / NPL, pl = (u - A_IPW * NPL) % NPL;
       const size_t o = b_off[q] + (size_t)kt * (BK * 2);
-      const unsigned dst = st_base + (unsigned)(NPL * A_PL + ((q * NWV + wave) * RPI) * ROWB);
-      glds16(reinterpret_cast<const char*>(p.w_hi) + o, dst);
-      if (SPLIT) glds16(reinterpret_cast<const char*>(p.w_lo) + o, dst + B_PL);
+      glds16(reinterpret_cast<const char*>(pl ? p.w_lo : p.w_hi) + o,
+             st_base + (unsigned)(NPL * A_PL + ((q * NWV + wave) * RPI) * ROWB + pl * B_PL));
     }
+  };
+  auto advance = [&]() {
     cur_col += BK;
     if (cur_col == cur_ld) {     // wave-uniform, once per (source tensor, tap)
       const GemmSeg& sg = p.seg[ld_seg];
@@ -193,6 +207,12 @@ __global__ __launch_bounds__(64 * WM * WN * KS) void k_gemm(const GemmParams p) 
       if (ld_seg < p.nseg) enter();
     }
   };
+  auto issue = [&](int kt) {     // whole tile at once (prologue)
+    prep_a();
+#pragma unroll
+    for (int u = 0; u < LPT; ++u) issue_unit(kt, u);
+    advance();
+  };
 
   f32x16 acc[FM][FN];
 #pragma unroll
@@ -203,52 +223,64 @@ __global__ __launch_bounds__(64 * WM * WN * KS) void k_gemm(const GemmParams p) 
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   const int l31 = lane & 31, lh = lane >> 5;
-  auto compute = [&](int kt) {
+  // One k-tile of work for this wave: all operand fragments are read first, then the MFMAs go out in groups of
+  // FM*FN (one product term of one 16-deep k-step: consecutive MFMAs write different accumulators) and, when
+  // ISSUE, the DMA units of tile kt+NSTAGE-1 are spread between the groups: a wave blocked in the (slow, 64 B/clk
+  // per CU) vector-memory issue then has MFMAs in flight instead of serialising a DMA phase after an MFMA phase.
+  // Weights are the FIRST MFMA operand: the accumulator is the TRANSPOSED tile, lane = output row m,
+  // registers = 16 output columns in runs of 4 -> 16-byte epilogue loads / stores per lane.
+  constexpr int NKS = BK / 16 / KS;                  // 16-deep k-steps per wave per k-tile
+  constexpr int NTERM = SPLIT ? 3 : 1;
+  constexpr int NCH = NKS * NTERM;                   // MFMA groups per k-tile
+  auto step = [&](int kt, auto issue_tag) {
+    constexpr bool ISSUE = decltype(issue_tag)::value;
     const char* base = smem + (kt % NSTAGE) * STAGE;
     const char* a_hi = base;
     const char* a_lo = base + A_PL;
     const char* b_hi = base + NPL * A_PL;
     const char* b_lo = b_hi + B_PL;
+    bf16x8 ah[NKS][FM], al[NKS][FM], bh[NKS][FN], bl[NKS][FN];
 #pragma unroll
-    for (int ks0 = 0; ks0 < BK / 16 / KS; ++ks0) {
-      const int ks = kgrp * (BK / 16 / KS) + ks0;
-      const int chunk = ks * 2 + lh;
-      bf16x8 ah[FM], al[FM], bh[FN], bl[FN];
+    for (int ks0 = 0; ks0 < NKS; ++ks0) {
+      const int chunk = (kgrp * NKS + ks0) * 2 + lh;
 #pragma unroll
       for (int i = 0; i < FM; ++i) {
         const int row = (wm * FM + i) * 32 + l31;
         const int off = row * ROWB + ((chunk ^ swz(row)) << 4);
-        ah[i] = *reinterpret_cast<const bf16x8*>(a_hi + off);
-        if (SPLIT) al[i] = *reinterpret_cast<const bf16x8*>(a_lo + off);
+        ah[ks0][i] = *reinterpret_cast<const bf16x8*>(a_hi + off);
+        if (SPLIT) al[ks0][i] = *reinterpret_cast<const bf16x8*>(a_lo + off);
       }
 #pragma unroll
       for (int j = 0; j < FN; ++j) {
         const int row = (wn * FN + j) * 32 + l31;
         const int off = row * ROWB + ((chunk ^ swz(row)) << 4);
-        bh[j] = *reinterpret_cast<const bf16x8*>(b_hi + off);
-        if (SPLIT) bl[j] = *reinterpret_cast<const bf16x8*>(b_lo + off);
+        bh[ks0][j] = *reinterpret_cast<const bf16x8*>(b_hi + off);
+        if (SPLIT) bl[ks0][j] = *reinterpret_cast<const bf16x8*>(b_lo + off);
       }
-      // weights as the first operand: the accumulator is the TRANSPOSED tile, lane = output row m,
-      // registers = 16 output columns in runs of 4 -> 16-byte epilogue loads / stores per lane.
-      // Term-major order: consecutive MFMAs write different accumulators.
-      if (SPLIT) {
+    }
 #pragma unroll
-        for (int i = 0; i < FM; ++i)
-#pragma unroll
-          for (int j = 0; j < FN; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh[j], al[i], acc[i][j], 0, 0, 0);
-#pragma unroll
-        for (int i = 0; i < FM; ++i)
-#pragma unroll
-          for (int j = 0; j < FN; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bl[j], ah[i], acc[i][j], 0, 0, 0);
-      }
+    for (int c = 0; c < NCH; ++c) {
+      const int ks0 = c / NTERM, term = c % NTERM;
 #pragma unroll
       for (int i = 0; i < FM; ++i)
 #pragma unroll
-        for (int j = 0; j < FN; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh[j], ah[i], acc[i][j], 0, 0, 0);
+        for (int j = 0; j < FN; ++j) {
+          if (SPLIT && term == 0)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh[ks0][j], al[ks0][i], acc[i][j], 0, 0, 0);
+          else if (SPLIT && term == 1)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bl[ks0][j], ah[ks0][i], acc[i][j], 0, 0, 0);
+          else
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh[ks0][j], ah[ks0][i], acc[i][j], 0, 0, 0);
+        }
+      if (ISSUE) {
+        __builtin_amdgcn_sched_barrier(0);
+        if (c == 0) prep_a();
+#pragma unroll
+        for (int u = c * LPT / NCH; u < (c + 1) * LPT / NCH; ++u) issue_unit(kt + NSTAGE - 1, u);
+        __builtin_amdgcn_sched_barrier(0);
+      }
     }
+    if (ISSUE) advance();
   };
 
   // accumulator fragment (i, j), lane (l31, lh), register r = 4*g + e  holds
@@ -303,7 +335,7 @@ __global__ __launch_bounds__(64 * WM * WN * KS) void k_gemm(const GemmParams p) 
     glds4(p.bias ? (const void*)(p.bias + n) : (const void*)p.zero_page, (unsigned)(size_t)s_bias + wave * 256);
   }
 
-  // ---- main loop: wait(tile kt) -> barrier -> compute(tile kt) -> issue(tile kt+NSTAGE-1) ----
+  // ---- main loop: wait(tile kt) -> barrier -> multiply tile kt with the DMA of tile kt+NSTAGE-1 interleaved ----
   // NSTAGE-1 tiles are in flight; the counted vmcnt leaves the younger ones outstanding across the barrier
   DV_TRACE(10);    // residual prefetch / LayerNorm rows / bias DMA issued
 #pragma unroll
@@ -314,18 +346,27 @@ __global__ __launch_bounds__(64 * WM * WN * KS) void k_gemm(const GemmParams p) 
 #endif
   }
   DV_TRACE(1);
-  for (int kt = 0; kt < total_kt; ++kt) {
-    const int younger = min(NSTAGE - 2, total_kt - 1 - kt);   // tiles issued after kt that may stay in flight
-    if (younger >= 2) wait_vmcnt<2 * LPT>();
-    else if (younger == 1) wait_vmcnt<LPT>();
-    else wait_vmcnt<0>();
+  // steady state: tile kt+NSTAGE-1 is issued while tile kt is multiplied; NSTAGE-2 younger tiles stay in flight
+  const int n_steady = total_kt - (NSTAGE - 1);
+  int kt = 0;
+  for (; kt < n_steady; ++kt) {
+    wait_vmcnt<(NSTAGE - 2) * LPT>();
     __builtin_amdgcn_s_barrier();                    // tile kt visible; every wave is done with tile kt-1
 #ifdef DV_GEMM_TRACE
     if (kt == 0) DV_TRACE(2);
 #endif
-    compute(kt);                                     // LDS reads + MFMAs first: they run on while ...
-    if (kt + NSTAGE - 1 < total_kt) issue(kt + NSTAGE - 1);   // ... the next DMA's addresses are formed; it overwrites
-                                                     // the stage tile kt-1 was read from (all waves are past it)
+    step(kt, std::true_type{});                      // DMA overwrites the stage tile kt-1 was read from
+  }
+  for (; kt < total_kt; ++kt) {                      // drain: nothing left to issue
+    const int younger = min(NSTAGE - 2, total_kt - 1 - kt);
+    if (younger >= 2) wait_vmcnt<2 * LPT>();
+    else if (younger == 1) wait_vmcnt<LPT>();
+    else wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+#ifdef DV_GEMM_TRACE
+    if (kt == 0) DV_TRACE(2);
+#endif
+    step(kt, std::false_type{});
   }
 
   DV_TRACE(3);
