@@ -52,6 +52,10 @@ __global__ __launch_bounds__(64 * NW) void k_attention(const AttnParams p) {
   const int qi = blockIdx.x * (32 * NW) + wave * 32 + l31;
   const bool q_ok = qi < p.Tq;
 
+  // scores are kept in the log2 domain (q pre-scaled by d^-1/2 * log2 e, key bias by log2 e): the softmax
+  // exponentials are bare v_exp_f32
+  constexpr float LOG2E = 1.44269504088896340736f;
+  const float qscale = p.scale * LOG2E;
   // ---- Q fragments (B operand of K Q^T): lane (query, lh) holds channels ks*16 + lh*8 .. +8 ----
   bf16x8 qh[KS], ql[KS];
   {
@@ -62,8 +66,8 @@ __global__ __launch_bounds__(64 * NW) void k_attention(const AttnParams p) {
       float4 a = make_float4(0.f, 0.f, 0.f, 0.f), c2 = a;
       if (q_ok && c < d) a = *reinterpret_cast<const float4*>(qp + c);
       if (q_ok && c + 4 < d) c2 = *reinterpret_cast<const float4*>(qp + c + 4);
-      a.x *= p.scale; a.y *= p.scale; a.z *= p.scale; a.w *= p.scale;
-      c2.x *= p.scale; c2.y *= p.scale; c2.z *= p.scale; c2.w *= p.scale;
+      a.x *= qscale; a.y *= qscale; a.z *= qscale; a.w *= qscale;
+      c2.x *= qscale; c2.y *= qscale; c2.z *= qscale; c2.w *= qscale;
       u32x4 hw, lw;
       hw.x = apk(a.x, a.y); hw.y = apk(a.z, a.w); hw.z = apk(c2.x, c2.y); hw.w = apk(c2.z, c2.w);
       lw.x = apk(a.x - bf_lo(hw.x), a.y - bf_hi(hw.x)); lw.y = apk(a.z - bf_lo(hw.y), a.w - bf_hi(hw.y));
@@ -99,7 +103,7 @@ __global__ __launch_bounds__(64 * NW) void k_attention(const AttnParams p) {
     }
     if (tid < 32) {
       const int key = kt0 + tid;
-      rbias = (key < p.Tk) ? (p.bias ? p.bias[(size_t)b * p.Tk + key] : 0.f) : -1e30f;
+      rbias = (key < p.Tk) ? (p.bias ? p.bias[(size_t)b * p.Tk + key] * LOG2E : 0.f) : -1e30f;
     }
   };
   auto store_tile = [&](int buf) {
@@ -172,28 +176,34 @@ __global__ __launch_bounds__(64 * NW) void k_attention(const AttnParams p) {
       s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh, qh[ks], s, 0, 0, 0);
     }
     // ---- online softmax (lane = query; registers = keys) ----
-    float tmax = -1e30f;
+    // the key bias (attention mask / keys past Tk) is only added where there is one: wave-uniform branch
+    if (p.bias != nullptr || (!more && (p.Tk & 31) != 0)) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int kl = (r & 3) + 8 * (r >> 2) + 4 * lh;
-      s[r] += bl[kl];
-      tmax = fmaxf(tmax, s[r]);
+      for (int g = 0; g < 4; ++g) {
+        const float4 bv = *reinterpret_cast<const float4*>(bl + 8 * g + 4 * lh);
+        s[4 * g] += bv.x; s[4 * g + 1] += bv.y; s[4 * g + 2] += bv.z; s[4 * g + 3] += bv.w;
+      }
     }
+    float tmax = s[0];
+#pragma unroll
+    for (int r = 1; r < 16; ++r) tmax = fmaxf(tmax, s[r]);
     tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
     const float m_new = fmaxf(m_run, tmax);
-    const float alpha = __expf(m_run - m_new);
+    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
     m_run = m_new;
     float psum = 0.f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      s[r] = __expf(s[r] - m_new);
+      s[r] = __builtin_amdgcn_exp2f(s[r] - m_new);
       psum += s[r];
     }
     l_run = l_run * alpha + psum;
+    if (__any(alpha != 1.0f)) {        // the running maximum moved for some query of this wave
 #pragma unroll
-    for (int nb = 0; nb < NB; ++nb)
+      for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) o[nb][r] *= alpha;
+        for (int r = 0; r < 16; ++r) o[nb][r] *= alpha;
+    }
     // ---- O^T += V^T P^T: P^T operand of k-block kb = this lane's score registers 8kb..8kb+7 ----
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb) {
