@@ -202,13 +202,28 @@ def main():
         n_launch, flops_fwd = eng.stats()
         g = agg["gemm"]
         peak = PEAK_TFLOPS[args.precision]
-        achieved = g[1] / (g[2] * 1e-3) / 1e12
+        # average GEMM launch duration: the schedule's 180 GEMM launches replayed back to back between ONE event pair on
+        # the launch stream (no per-launch event overhead; this is the figure rocprofv3's per-kernel average must match);
+        # the per-launch event pairs above (~+2.5 us each) give the per-family split and are reported beside it
+        gemm_us, gemm_n = eng.time_family("gemm", reps=10)
+        flops_gemm_fwd = g[1] / reps
+        achieved = flops_gemm_fwd / (gemm_us * 1e-6 * gemm_n) / 1e12
+        achieved_evpair = g[1] / (g[2] * 1e-3) / 1e12
         fwd_ms = 1e3 * dt / args.steps / S
+        # HBM-side bytes per GEMM launch: PMC counters cannot be read from inside the process, so this is the figure
+        # of the committed rocprofv3 --pmc passes over this same command (tools/pmc_traffic.py); null if absent
+        traffic, traffic_src = None, None
+        tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_gemm_hbm_traffic.json")
+        if os.path.exists(tpath) and args.precision == "bf16x3" and (B, T, L) == (8, 1024, 256):
+            with open(tpath) as f:
+                traffic = json.load(f)["gemm"]["hbm_bytes_per_launch"]
+            traffic_src = "profiles/r01_gemm_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, KiB, separate passes)"
         result["roofline"] = {
             "bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
-            "traffic": None,
+            "traffic": traffic, "traffic_source": traffic_src,
             "kernel": "k_gemm<*> (implicit-GEMM conv1d/linear, all tile instantiations)",
-            "flops_per_launch": g[1] / g[0], "avg_launch_us": 1e3 * g[2] / g[0], "launches_per_forward": g[0] // reps,
+            "flops_per_launch": g[1] / g[0], "avg_launch_us": gemm_us, "launches_per_forward": gemm_n,
+            "avg_launch_us_event_pair_per_launch": 1e3 * g[2] / g[0], "achieved_event_pair_per_launch": achieved_evpair,
             "per_kind_ms_per_forward": {k: v[2] / reps for k, v in agg.items()},
             "per_kind_launches": {k: v[0] // reps for k, v in agg.items()},
             "forward": {"launches": n_launch, "algorithmic_gflop": flops_model(B, T, L) / 1e9,

@@ -39,6 +39,8 @@ SIGNATURES = {
     "dv_unet_forward_timed": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                         C.c_void_p, C.c_int32]),
     "dv_unet_op_info": (C.c_int, [C.c_void_p, C.c_int32, C.c_char_p, C.POINTER(C.c_double), C.c_char_p]),
+    "dv_unet_time_family": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int32, C.c_void_p, C.POINTER(C.c_float),
+                                      C.POINTER(C.c_int32)]),
     "dv_unet_probe": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.c_int64, C.POINTER(C.c_int64)]),
     "dv_sampler_plan": (C.c_int, [C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                   C.POINTER(C.c_void_p)]),

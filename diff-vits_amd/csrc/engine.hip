@@ -964,6 +964,35 @@ extern "C" int dv_unet_forward_timed(dv_unet* u, const float* x, int32_t cx, con
   return DV_OK;
 }
 
+extern "C" int dv_unet_time_family(dv_unet* u, const char* kind, int32_t reps, void* stream, float* ms_total,
+                                   int32_t* launches) {
+  if (!u || !kind || !ms_total || !launches || reps < 1) return dv_fail(DV_ERR_INVALID, "dv_unet_time_family: bad argument");
+  if (!u->prepared || !u->cond_set || !u->io.x) return dv_fail(DV_ERR_STATE, "dv_unet_time_family needs a completed forward");
+  hipStream_t st = (hipStream_t)stream;
+  std::vector<int> idx;
+  for (int i = 0; i < (int)u->step_ops.size(); ++i)
+    if (strcmp(u->step_meta[i].kind, kind) == 0) idx.push_back(i);
+  if (idx.empty()) return dv_fail(DV_ERR_INVALID, "no launch of family '%s' in the schedule", kind);
+  hipEvent_t e0, e1;
+  HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
+  for (int i : idx) {               // untimed pass: code and arguments warm
+    hipError_t e = u->step_ops[i](st);
+    if (e != hipSuccess) return dv_fail(DV_ERR_HIP, "op %d failed: %s", i, hipGetErrorString(e));
+  }
+  HIPCHK(hipEventRecord(e0, st));
+  for (int r = 0; r < reps; ++r)
+    for (int i : idx) {
+      hipError_t e = u->step_ops[i](st);
+      if (e != hipSuccess) return dv_fail(DV_ERR_HIP, "op %d failed: %s", i, hipGetErrorString(e));
+    }
+  HIPCHK(hipEventRecord(e1, st));
+  HIPCHK(hipEventSynchronize(e1));
+  HIPCHK(hipEventElapsedTime(ms_total, e0, e1));
+  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+  *launches = (int32_t)idx.size() * reps;
+  return DV_OK;
+}
+
 extern "C" int dv_unet_op_info(dv_unet* u, int32_t index, char* kind16, double* flops, char* desc128) {
   if (!u || !u->prepared || index < 0 || index >= (int)u->step_meta.size()) return dv_fail(DV_ERR_INVALID, "dv_unet_op_info: bad index");
   if (kind16) { strncpy(kind16, u->step_meta[index].kind, 15); kind16[15] = 0; }

@@ -148,6 +148,14 @@ class UNetEngine:
             rows.append((kind.value.decode(), fl.value, float(ms[i]), desc.value.decode()))
         return rows
 
+    def time_family(self, kind, reps=5):
+        """Average launch duration (us) of one kernel family: its launches of the schedule replayed back to back
+        between one HIP event pair (after a completed forward).  Returns (us_per_launch, launches_per_forward)."""
+        ms, n = C.c_float(), C.c_int32()
+        _lib.check(_lib.lib().dv_unet_time_family(self._h, kind.encode(), reps, _lib.stream_ptr(), C.byref(ms),
+                                                  C.byref(n)), "dv_unet_time_family")
+        return 1e3 * ms.value / n.value, n.value // reps
+
     def probe(self, name):
         """Named intermediate [B, T, C] of the last forward (needs DVITS_KEEP_INTERMEDIATES=1)."""
         dims = (C.c_int64 * 3)()

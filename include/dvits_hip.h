@@ -110,6 +110,11 @@ int dv_unet_stats(dv_unet* u, int64_t* n_launch, double* flops);
 int dv_unet_forward_timed(dv_unet* u, const float* x, int32_t cx, const float* cond, const float* t, float* y,
                           void* stream, float* ms_per_op, int32_t capacity);
 int dv_unet_op_info(dv_unet* u, int32_t index, char* kind16, double* flops, char* desc128);
+/* Re-launches only the schedule's launches of one kernel family (e.g. "gemm"), in schedule order with their own
+ * arguments, `reps` times back to back between ONE HIP event pair on `stream` (after one untimed pass);
+ * *ms_total / *launches = that family's average launch duration without per-launch event overhead.  Needs a completed
+ * dv_unet_forward (the buffers then hold valid data; outputs are overwritten with the same values). */
+int dv_unet_time_family(dv_unet* u, const char* kind, int32_t reps, void* stream, float* ms_total, int32_t* launches);
 
 /* Debug/parity probe: copy a named intermediate activation (channels-last [B, T, C]) of the
  * last forward to the host.  Available only when dv_unet_prepare ran with the environment
