@@ -23,6 +23,11 @@ class UNetCfg(C.Structure):
                 ("norm_eps", C.c_float)]
 
 
+class PencCfg(C.Structure):
+    _fields_ = [("in_channels", C.c_int32), ("hidden_channels", C.c_int32), ("out_channels", C.c_int32),
+                ("n_layers", C.c_int32), ("num_heads", C.c_int32), ("ffn_kernel", C.c_int32)]
+
+
 MODEL_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_double, C.c_void_p, C.c_void_p)
 
 # every symbol include/dvits_hip.h declares: (restype, argtypes)
@@ -39,6 +44,12 @@ SIGNATURES = {
     "dv_unet_forward_timed": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                         C.c_void_p, C.c_int32]),
     "dv_unet_op_info": (C.c_int, [C.c_void_p, C.c_int32, C.c_char_p, C.POINTER(C.c_double), C.c_char_p]),
+    "dv_penc_create": (C.c_int, [C.POINTER(PencCfg), C.POINTER(C.c_void_p)]),
+    "dv_penc_destroy": (None, [C.c_void_p]),
+    "dv_penc_set_weight": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.POINTER(C.c_int64), C.c_int32]),
+    "dv_penc_prepare": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32]),
+    "dv_penc_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "dv_penc_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_double)]),
     "dv_unet_time_family": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int32, C.c_void_p, C.POINTER(C.c_float),
                                       C.POINTER(C.c_int32)]),
     "dv_unet_probe": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.c_int64, C.POINTER(C.c_int64)]),

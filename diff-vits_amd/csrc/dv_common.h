@@ -54,6 +54,9 @@ struct GemmParams {
   int ln_nblk;                  // = C/32 of the normalised rows
   const float* ln_u;            // consumer: u[n] = sum_k gamma[k]*W[n,k]  (packed column order)
   float ln_eps;
+  // prompt-encoder epilogue options (reference operations.py:687, 813, 820): ReLU, then a per-row keep mask
+  int relu;                     // 1: result = max(result, 0) after bias / residual
+  const float* rowmask;         // [M] multiplier of every output row (padding frames -> 0) or null
 };
 
 struct AttnParams {
@@ -94,6 +97,14 @@ struct GnApplyParams {
 hipError_t launch_gn_apply(const GnApplyParams& p, hipStream_t st);
 // LayerNorm rows (no affine: gamma/beta are folded into the consumer's weights) -> split planes
 hipError_t launch_ln_apply(const float* x, bf16_t* hi, bf16_t* lo, int M, int C, float eps, hipStream_t st);
+// LayerNorm rows WITH affine (+ optional per-row mask) -> fp32 [M, C] and/or split planes [M, C]
+hipError_t launch_ln_affine(const float* x, const float* gamma, const float* beta, const float* rowmask, float* out,
+                            bf16_t* hi, bf16_t* lo, int M, int C, float eps, hipStream_t st);
+// prompt-encoder input stage (reference model3.py:409-420, model.py:164-169): [B, C, L] channels-first ->
+// masked_fill(padding, 0) -> LayerNorm(C) with affine -> split planes [B*L, cpad] (zero padded);
+// also key_bias[b, t] = keep ? 0 : -1e30 for the attention kernels
+hipError_t launch_prompt_pre(const float* prompt, const float* keep, const float* gamma, const float* beta, bf16_t* hi,
+                             bf16_t* lo, float* key_bias, int B, int C, int L, int cpad, float eps, hipStream_t st);
 // GroupNorm statistics of the channel-concat [a0 | a1] -> part[B, nchunk, G, 2] (double sum, sumsq)
 hipError_t launch_gn_partial(const float* a0, int c0, const float* a1, int c1, double* part, int B, int T, int G,
                              int nchunk, hipStream_t st);

@@ -111,6 +111,7 @@ struct Probe { std::string name; float* p; int T, C; };
 
 struct dv_unet {
   dv_unet_cfg cfg{};
+  dv_penc_cfg pcfg{};                        // prompt-encoder handles (dv_penc wraps a dv_unet core)
   std::map<std::string, RawW> w;
   bool weights_dirty = true;
   // prepared state
@@ -862,6 +863,154 @@ struct Builder {
     if (!err.empty()) return dv_fail(DV_ERR_MISSING_WEIGHT, "%s", err.c_str());
     return DV_OK;
   }
+
+  // engine-made constant vector registered like a weight (per-source-channel scale for pack())
+  void const_vec(const std::string& name, int n, float value) {
+    if (dry || u->w.count(name)) return;
+    RawW r;
+    if (hipMalloc((void**)&r.p, (size_t)n * 4) != hipSuccess) { err = "hipMalloc(const) failed"; return; }
+    r.shape = {n}; r.numel = (size_t)n;
+    (void)launch_fill_f32(r.p, value, n, pack_stream);
+    u->w[name] = r;
+  }
+
+  // ---- PromptEncoder (reference model3.py:382-433): ConvLayer `pre` (k=1) -> n x EncSALayer
+  // (operations.py:784-821) -> ConvLayer `out_proj` (k=1) -> LayerNorm, the keep mask re-applied after every
+  // sub-layer.  Channels-last [B*L, C] throughout; the result [B, L, C_out] is exactly the encoder_hidden_states
+  // layout the denoiser takes (model3.py:912 transposes the reference's [B, C, L] back).
+  int build_penc() {
+    const dv_penc_cfg& c = u->pcfg;
+    const int H = c.hidden_channels, Cin = c.in_channels, Cout = c.out_channels, Ln = T, M = B * Ln, Bn = B;
+    const int cpad = rup(Cin, 32), KS9 = c.ffn_kernel;
+    std::vector<OpFn>& S = u->step_ops;
+    dv_unet* uu = u;
+    if (!dry && !u->zero_page) {
+      void* z = nullptr;
+      if (hipMalloc(&z, 256) != hipSuccess) return dv_fail(DV_ERR_HIP, "hipMalloc(zero page) failed");
+      (void)hipMemsetAsync(z, 0, 256, pack_stream);
+      u->owned.push_back(z);
+      u->zero_page = reinterpret_cast<bf16_t*>(z);
+    }
+    const int nblk = H / 32;
+    struct LnIn { Planes pl; float* stat = nullptr; };
+    auto ln_produce = [&](GemmParams& g, float* x32) {   // producer of a k=1 LayerNorm consumer
+      LnIn in;
+      if (!fuse_ln) { (void)x32; return in; }
+      in.pl = alloc_planes((size_t)M * H);
+      in.stat = alloc((size_t)M * nblk * 2);
+      g.out_hi = in.pl.hi; g.out_lo = in.pl.lo; g.rowstat_out = in.stat;
+      return in;
+    };
+    auto ln_consume = [&](GemmParams& g, LnIn& in, const float* x32, const PackedW* w) {
+      if (!fuse_ln) in.pl = ln_apply(S, x32, M, H);
+      else { g.ln_stat = in.stat; g.ln_nblk = nblk; g.ln_u = w->u; g.ln_eps = 1e-5f; }
+      g.seg[0] = seg(in.pl, H, Planes{}, 0, 1, 0);
+    };
+    auto ln_release = [&](LnIn& in) { release(in.pl); if (in.stat) release(in.stat); };
+
+    // keep mask of the call -> arena (the GEMM epilogues read it), key bias, masked-LayerNorm'd input planes
+    float* keep = alloc((size_t)M);
+    float* kbias = alloc((size_t)M);
+    emit(S, [=](hipStream_t st) { return launch_copy_f32(uu->io.mask, keep, (int64_t)Bn * Ln, st); });
+    Planes p0 = alloc_planes((size_t)M * cpad);
+    {
+      const float* g0 = W("pre.layer_norm.weight"); const float* b0 = W("pre.layer_norm.bias");
+      emit(S, [=](hipStream_t st) {
+        return launch_prompt_pre(uu->io.x, keep, g0, b0, p0.hi, p0.lo, kbias, Bn, Cin, Ln, cpad, 1e-5f, st);
+      });
+    }
+    const PackedW* w_pre = pack("pre", H, cpad, {{"pre.conv.weight", 0, Cin, 1, cpad, 0, 0, "", 0}},
+                                {{"pre.conv.bias", "", "", "", H, 0, 0, 0}});
+    if (!w_pre) return dv_fail(DV_ERR_MISSING_WEIGHT, "%s", err.c_str());
+    float* x = alloc((size_t)M * H);
+    LnIn lin;
+    {
+      GemmParams g = gp_base(Ln, M, H); g.seg[0] = seg(p0, cpad, Planes{}, 0, 1, 0);
+      g.out = x; g.rowmask = keep; lin = ln_produce(g, x); gemm(S, g, w_pre, Cin);
+    }
+    release(p0);
+    probe("pre", x, Ln, H);
+
+    const_vec("__const.ffn_scale", 4 * H, 1.0f / sqrtf((float)KS9));
+    for (int i = 0; i < c.n_layers; ++i) {
+      const std::string p = "layers." + std::to_string(i) + ".op.";
+      const PackedW* w_qkv = pack(p + "qkv", 3 * H, H, {{p + "self_attn.in_proj_weight", 0, H, 1, H, 0, 0, p + "layer_norm1.weight", 0}},
+                                  {{"", "", p + "self_attn.in_proj_weight", p + "layer_norm1.bias", 3 * H, H, 0, 0}});
+      const PackedW* w_o = pack(p + "out", H, H, {{p + "self_attn.out_proj.weight", 0, H, 1, H, 0, 0, "", 0}}, {});
+      std::vector<Piece> f1;
+      for (int j = 0; j < KS9; ++j) f1.push_back({p + "ffn.ffn_1." + std::to_string(j) + ".weight", 0, H, 1, H, H * j, 0, "", 0});
+      const PackedW* w_f1 = pack(p + "ffn1", 4 * H, KS9 * H, f1, {{p + "ffn.ffn_1.0.bias", "", "", "", 4 * H, 0, 0, 0}});
+      // relu(s * a) = s * relu(a), s = k^-1/2 > 0: the scale rides on ffn_2's input channels
+      const PackedW* w_f2 = pack(p + "ffn2", H, 4 * H, {{p + "ffn.ffn_2.weight", 0, 4 * H, 1, 4 * H, 0, 0, "__const.ffn_scale", 0}},
+                                 {{p + "ffn.ffn_2.bias", "", "", "", H, 0, 0, 0}});
+      if (!w_qkv || !w_o || !w_f1 || !w_f2) return dv_fail(DV_ERR_MISSING_WEIGHT, "%s", err.c_str());
+
+      // self-attention: LayerNorm1 finished in the qkv GEMM, padded keys masked by the key bias
+      float* qkv = alloc((size_t)M * 3 * H);
+      {
+        GemmParams g = gp_base(Ln, M, 3 * H);
+        g.out = qkv; ln_consume(g, lin, x, w_qkv); gemm(S, g, w_qkv, H);
+      }
+      ln_release(lin);
+      Planes ao = attention(S, qkv, 3 * H, qkv + H, qkv + 2 * H, 3 * H, kbias, Ln, Ln, H);
+      release(qkv);
+      float* x2 = alloc((size_t)M * H);
+      {
+        GemmParams g = gp_base(Ln, M, H); g.seg[0] = seg(ao, H, Planes{}, 0, 1, 0);
+        g.epi = EPI_RESIDUAL; g.res = x; g.out = x2; g.rowmask = keep; gemm(S, g, w_o, H);
+      }
+      release(ao); release(x);
+
+      // feed-forward: LayerNorm2 WITH affine (the k=9 zero padding pads the normalised tensor), then the nine
+      // shifted Linears as one contraction over two K-segments of the same planes: tap 0 at offset 0 (the
+      // reference multiplies the unpadded x there, operations.py:678) and taps 1..8 at offsets -3..+4
+      Planes n2 = alloc_planes((size_t)M * H);
+      {
+        const float* g2 = W(p + "layer_norm2.weight"); const float* b2 = W(p + "layer_norm2.bias");
+        const float* xin = x2;
+        cur_kind = "ln_apply";
+        emit(S, [=](hipStream_t st) { return launch_ln_affine(xin, g2, b2, nullptr, nullptr, n2.hi, n2.lo, Bn * Ln, H, 1e-5f, st); });
+      }
+      Planes hh = alloc_planes((size_t)M * 4 * H);
+      {
+        GemmParams g = gp_base(Ln, M, 4 * H);
+        g.seg[0] = seg(n2, H, Planes{}, 0, 1, 0);
+        if (KS9 > 1) { g.seg[1] = seg(n2, H, Planes{}, 0, KS9 - 1, (KS9 - 1) / 2 - 1); g.nseg = 2; }
+        g.relu = 1; g.out_hi = hh.hi; g.out_lo = hh.lo;
+        gemm(S, g, w_f1, KS9 * H);
+      }
+      release(n2);
+      float* x3 = alloc((size_t)M * H);
+      {
+        GemmParams g = gp_base(Ln, M, H); g.seg[0] = seg(hh, 4 * H, Planes{}, 0, 1, 0);
+        g.epi = EPI_RESIDUAL; g.res = x2; g.out = x3; g.rowmask = keep; lin = ln_produce(g, x3); gemm(S, g, w_f2, 4 * H);
+      }
+      release(hh); release(x2);
+      x = x3;
+      probe("layer" + std::to_string(i), x, Ln, H);
+    }
+
+    // out_proj ConvLayer (no masked_fill: model3.py:427), then the last LayerNorm with affine, both re-masked
+    const PackedW* w_op = pack("out_proj", Cout, H, {{"out_proj.conv.weight", 0, H, 1, H, 0, 0, "out_proj.layer_norm.weight", 0}},
+                               {{"out_proj.conv.bias", "", "out_proj.conv.weight", "out_proj.layer_norm.bias", Cout, H, 0, 0}});
+    if (!w_op) return dv_fail(DV_ERR_MISSING_WEIGHT, "%s", err.c_str());
+    float* z = alloc((size_t)M * Cout);
+    {
+      GemmParams g = gp_base(Ln, M, Cout);
+      g.out = z; g.rowmask = keep; ln_consume(g, lin, x, w_op); gemm(S, g, w_op, H);
+    }
+    ln_release(lin); release(x);
+    if (has("layer_norm.weight")) {
+      const float* gl = W("layer_norm.weight"); const float* bl = W("layer_norm.bias");
+      cur_kind = "ln_apply";
+      emit(S, [=](hipStream_t st) { return launch_ln_affine(z, gl, bl, keep, uu->io.y, nullptr, nullptr, Bn * Ln, Cout, 1e-5f, st); });
+    } else {
+      emit(S, [=](hipStream_t st) { return launch_copy_f32(z, uu->io.y, (int64_t)Bn * Ln * Cout, st); });
+    }
+    release(z);
+    if (!err.empty()) return dv_fail(DV_ERR_MISSING_WEIGHT, "%s", err.c_str());
+    return DV_OK;
+  }
 };
 
 extern "C" int dv_unet_prepare(dv_unet* u, int32_t B, int32_t T, int32_t L, int32_t precision, int32_t force_upsample_size) {
@@ -908,6 +1057,78 @@ extern "C" int dv_unet_prepare(dv_unet* u, int32_t B, int32_t T, int32_t L, int3
   return DV_OK;
 }
 
+// ----------------------------------------------------------------------------- C ABI: prompt encoder
+struct dv_penc { dv_unet core; };
+
+extern "C" int dv_penc_create(const dv_penc_cfg* cfg, dv_penc** out) {
+  if (!cfg || !out) return dv_fail(DV_ERR_INVALID, "dv_penc_create: null argument");
+  if (cfg->in_channels <= 0 || cfg->in_channels > 512) return dv_fail(DV_ERR_INVALID, "in_channels must be 1..512");
+  if (cfg->hidden_channels <= 0 || cfg->hidden_channels % 32 != 0 || cfg->hidden_channels > 512)
+    return dv_fail(DV_ERR_INVALID, "hidden_channels must be a positive multiple of 32, <= 512");
+  if (cfg->out_channels <= 0 || cfg->out_channels % 4 != 0 || cfg->out_channels > 2048)
+    return dv_fail(DV_ERR_INVALID, "out_channels must be a positive multiple of 4");
+  if (cfg->n_layers < 0 || cfg->n_layers > 64) return dv_fail(DV_ERR_INVALID, "n_layers out of range");
+  if (cfg->num_heads <= 0 || cfg->hidden_channels % cfg->num_heads != 0 || (cfg->hidden_channels / cfg->num_heads) % 4 != 0 ||
+      cfg->hidden_channels / cfg->num_heads > 64)
+    return dv_fail(DV_ERR_INVALID, "head dim must be a multiple of 4 and <= 64");
+  if (cfg->ffn_kernel < 1 || cfg->ffn_kernel % 2 != 1) return dv_fail(DV_ERR_INVALID, "ffn_kernel must be odd ('SAME' padding)");
+  dv_penc* p = new dv_penc();
+  p->core.pcfg = *cfg;
+  p->core.cfg.num_heads = cfg->num_heads;
+  *out = p;
+  return DV_OK;
+}
+
+extern "C" void dv_penc_destroy(dv_penc* p) {
+  if (!p) return;
+  (void)hipDeviceSynchronize();
+  unet_release_prepared(&p->core);
+  for (auto& kv : p->core.w)
+    if (kv.second.p) (void)hipFree(kv.second.p);
+  delete p;
+}
+
+extern "C" int dv_penc_set_weight(dv_penc* p, const char* name, const void* dev_ptr, const int64_t* shape, int32_t ndim) {
+  if (!p) return dv_fail(DV_ERR_INVALID, "dv_penc_set_weight: null handle");
+  return dv_unet_set_weight(&p->core, name, dev_ptr, shape, ndim);
+}
+
+extern "C" int dv_penc_prepare(dv_penc* p, int32_t B, int32_t L, int32_t precision) {
+  if (!p) return dv_fail(DV_ERR_INVALID, "dv_penc_prepare: null handle");
+  if (B <= 0 || L <= 0) return dv_fail(DV_ERR_INVALID, "dv_penc_prepare: B, L must be positive");
+  if (precision != DV_PREC_BF16X3 && precision != DV_PREC_BF16) return dv_fail(DV_ERR_INVALID, "unknown precision %d", precision);
+  dv_unet* u = &p->core;
+  HIPCHK(hipDeviceSynchronize());
+  HIPCHK(gemm_init());
+  unet_release_prepared(u);
+  u->B = B; u->T = L; u->L = L; u->precision = precision; u->force_up = 0;
+  const char* keep = getenv("DVITS_KEEP_INTERMEDIATES");
+  u->keep_intermediates = keep && keep[0] == '1';
+  size_t need = 0;
+  {
+    Builder b{};
+    b.u = u; b.dry = true; b.B = B; b.T = L; b.L = L; b.prec = precision;
+    b.arena.reuse = !u->keep_intermediates;
+    int rc = b.build_penc();
+    if (rc != DV_OK) return rc;
+    need = b.arena.high;
+  }
+  HIPCHK(hipMalloc((void**)&u->slab, need + 256));
+  u->slab_bytes = need;
+  {
+    Builder b{};
+    b.u = u; b.dry = false; b.B = B; b.T = L; b.L = L; b.prec = precision;
+    b.arena.reuse = !u->keep_intermediates;
+    int rc = b.build_penc();
+    if (rc != DV_OK) { unet_release_prepared(u); return rc; }
+  }
+  HIPCHK(hipDeviceSynchronize());
+  u->prepared = true;
+  u->weights_dirty = false;
+  u->generation++;
+  return DV_OK;
+}
+
 static int run_ops(const std::vector<OpFn>& ops, hipStream_t st, const char* what) {
   int i = 0;
   for (const OpFn& f : ops) {
@@ -915,6 +1136,21 @@ static int run_ops(const std::vector<OpFn>& ops, hipStream_t st, const char* wha
     if (e != hipSuccess) return dv_fail(DV_ERR_HIP, "%s: op %d failed to launch: %s", what, i, hipGetErrorString(e));
     ++i;
   }
+  return DV_OK;
+}
+
+extern "C" int dv_penc_forward(dv_penc* p, const float* prompt, const float* keep, float* out, void* stream) {
+  if (!p || !prompt || !keep || !out) return dv_fail(DV_ERR_INVALID, "dv_penc_forward: null argument");
+  dv_unet* u = &p->core;
+  if (!u->prepared) return dv_fail(DV_ERR_STATE, "dv_penc_forward before dv_penc_prepare");
+  u->io.x = prompt; u->io.mask = keep; u->io.y = out;
+  return run_ops(u->step_ops, (hipStream_t)stream, "prompt encoder");
+}
+
+extern "C" int dv_penc_stats(dv_penc* p, int64_t* n_launch, double* flops) {
+  if (!p || !p->core.prepared) return dv_fail(DV_ERR_STATE, "dv_penc_stats before prepare");
+  if (n_launch) *n_launch = (int64_t)p->core.step_ops.size();
+  if (flops) *flops = p->core.flops;
   return DV_OK;
 }
 

@@ -497,6 +497,7 @@ __global__ __launch_bounds__(64 * WM * WN * KS) void k_gemm(const GemmParams p) 
         }
       }
       const float2 st = p.ln_stat ? s_ln[rl] : make_float2(0.f, 1.f);
+      const float rmask = p.rowmask ? p.rowmask[mc] : 1.0f;
       float vv[16];
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
@@ -505,6 +506,8 @@ __global__ __launch_bounds__(64 * WM * WN * KS) void k_gemm(const GemmParams p) 
         if (p.ln_stat) v = st.y * (v - st.x * un[r]);
         v += bv[r];
         if (p.epi == EPI_RESIDUAL) v += rv[r];
+        if (p.relu) v = fmaxf(v, 0.f);
+        v *= rmask;
         vv[r] = (m_ok && n < p.N) ? v : 0.f;
       }
       if (p.epi == EPI_STORE_NCT) {

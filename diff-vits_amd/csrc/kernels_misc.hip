@@ -452,6 +452,119 @@ hipError_t launch_ln_apply(const float* x, bf16_t* hi, bf16_t* lo, int M, int C,
   return hipGetLastError();
 }
 
+// LayerNorm rows with affine (+ per-row keep mask) -> fp32 and/or split planes.  Prompt encoder: the input of the
+// k = 9 feed-forward (its zero padding must see gamma/beta applied, so they cannot be folded into the weights;
+// reference operations.py:816-817, 676-681) and the final LayerNorm (model3.py:428-430).  One wave per row.
+__global__ __launch_bounds__(256) void k_ln_affine(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                    const float* __restrict__ beta, const float* __restrict__ rowmask,
+                                                    float* __restrict__ out, bf16_t* __restrict__ hi,
+                                                    bf16_t* __restrict__ lo, int M, int C, float eps) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (row >= M) return;
+  const float* xr = x + (size_t)row * C;
+  float4 v[8];
+  const int n4 = C >> 2;
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int j = lane + i * 64;
+    v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (j < n4) {
+      v[i] = *reinterpret_cast<const float4*>(xr + j * 4);
+      s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+    }
+  }
+  const float mu = wave_sum(s) / (float)C;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int j = lane + i * 64;
+    if (j < n4) {
+      const float a = v[i].x - mu, b = v[i].y - mu, c = v[i].z - mu, d = v[i].w - mu;
+      q += (a * a + b * b) + (c * c + d * d);
+    }
+  }
+  const float rs = 1.0f / sqrtf(wave_sum(q) / (float)C + eps);
+  const float rm = rowmask ? rowmask[row] : 1.0f;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int j = lane + i * 64;
+    if (j < n4) {
+      const float4 g = *reinterpret_cast<const float4*>(gamma + j * 4);
+      const float4 b = *reinterpret_cast<const float4*>(beta + j * 4);
+      float4 y;
+      y.x = fmaf((v[i].x - mu) * rs, g.x, b.x) * rm; y.y = fmaf((v[i].y - mu) * rs, g.y, b.y) * rm;
+      y.z = fmaf((v[i].z - mu) * rs, g.z, b.z) * rm; y.w = fmaf((v[i].w - mu) * rs, g.w, b.w) * rm;
+      const size_t o = ((size_t)row * C >> 2) + j;
+      if (out) reinterpret_cast<float4*>(out)[o] = y;
+      if (hi) {
+        uint2 h, l;
+        split4(y, h, l);
+        reinterpret_cast<uint2*>(hi)[o] = h;
+        if (lo) reinterpret_cast<uint2*>(lo)[o] = l;
+      }
+    }
+  }
+}
+
+hipError_t launch_ln_affine(const float* x, const float* gamma, const float* beta, const float* rowmask, float* out,
+                            bf16_t* hi, bf16_t* lo, int M, int C, float eps, hipStream_t st) {
+  if (C % 4 != 0 || C > 2048 || !gamma || !beta) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(k_ln_affine, dim3((M + 3) / 4), dim3(256), 0, st, x, gamma, beta, rowmask, out, hi, lo, M, C, eps);
+  return hipGetLastError();
+}
+
+// Prompt-encoder input stage (reference model3.py:409-420 + model.py:164-169): one wave per frame (b, t) gathers
+// its C channels from the channels-first prompt, zeroes padding frames, LayerNorm(C) with affine, writes split
+// planes [B*L, cpad] (channels C..cpad-1 zero) for the k = 1 `pre` contraction, and the additive key bias of the
+// frame for the attention kernels (0 / -1e30: padded keys get exactly zero weight, operations.py:405-416).
+__global__ __launch_bounds__(256) void k_prompt_pre(const float* __restrict__ prompt, const float* __restrict__ keep,
+                                                     const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                     bf16_t* __restrict__ hi, bf16_t* __restrict__ lo,
+                                                     float* __restrict__ key_bias, int B, int C, int L, int cpad, float eps) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (row >= B * L) return;
+  const int b = row / L, t = row - b * L;
+  const float kp = keep[row];
+  float v[8];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int c = lane + i * 64;
+    v[i] = (c < C && kp != 0.f) ? prompt[((size_t)b * C + c) * L + t] : 0.f;
+    s += v[i];
+  }
+  const float mu = wave_sum(s) / (float)C;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int c = lane + i * 64;
+    if (c < C) q += (v[i] - mu) * (v[i] - mu);
+  }
+  const float rs = 1.0f / sqrtf(wave_sum(q) / (float)C + eps);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int c = lane + i * 64;
+    if (c < cpad) {
+      const float y = c < C ? fmaf((v[i] - mu) * rs, gamma[c], beta[c]) : 0.f;
+      const unsigned hb = pk_bf16(y, 0.f);
+      hi[(size_t)row * cpad + c] = (bf16_t)(hb & 0xffffu);
+      if (lo) lo[(size_t)row * cpad + c] = (bf16_t)(pk_bf16(y - __uint_as_float(hb << 16), 0.f) & 0xffffu);
+    }
+  }
+  if (lane == 0) key_bias[row] = kp != 0.f ? 0.f : -1e30f;
+}
+
+hipError_t launch_prompt_pre(const float* prompt, const float* keep, const float* gamma, const float* beta, bf16_t* hi,
+                             bf16_t* lo, float* key_bias, int B, int C, int L, int cpad, float eps, hipStream_t st) {
+  if (C > 512 || cpad > 512 || cpad < C) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(k_prompt_pre, dim3((B * L + 3) / 4), dim3(256), 0, st, prompt, keep, gamma, beta, hi, lo, key_bias, B, C,
+                     L, cpad, eps);
+  return hipGetLastError();
+}
+
 // ---------------------------------------------------------------------------------------
 // Small-M fp32 linear (the conditioning path: TimestepEmbedding MLP, the 22 batched
 // time_emb_proj GEMVs, the pooled-text projection; reference embeddings.py:186-201,

@@ -42,6 +42,7 @@ class UNetEngine:
         self._weight_sig = None
         self._prepared = None
         self.precision = None
+        self.cond_serial = 0            # bumped by every set_cond (callers that cache conditioning compare it)
 
     def __del__(self):
         try:
@@ -96,6 +97,7 @@ class UNetEngine:
         if bias is not None:
             bias = bias.detach().to(torch.float32).reshape(enc.shape[0], enc.shape[1]).contiguous()
         self._cond_keepalive = (enc, bias)
+        self.cond_serial += 1
         _lib.check(_lib.lib().dv_unet_set_cond(self._h, _lib.ptr(enc), _lib.ptr(bias), _lib.stream_ptr()),
                    "dv_unet_set_cond")
 
@@ -168,3 +170,78 @@ class UNetEngine:
     @property
     def handle(self):
         return self._h
+
+
+class PromptEncoderEngine:
+    """Native PromptEncoder (dv_penc_*, include/dvits_hip.h) for one mirror module (diff_vits_amd.model3.PromptEncoder)."""
+
+    def __init__(self, module):
+        self.module = module
+        c = _lib.PencCfg()
+        c.in_channels, c.hidden_channels, c.out_channels = module.in_channels, module.hidden_size, module.out_channels
+        c.n_layers, c.num_heads, c.ffn_kernel = module.num_layers, 8, 9
+        self.out_channels = c.out_channels
+        self._h = C.c_void_p()
+        _lib.check(_lib.lib().dv_penc_create(C.byref(c), C.byref(self._h)), "dv_penc_create")
+        self._weight_sig = None
+        self._prepared = None
+        self.precision = None
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None) and self._h.value:
+                _lib.lib().dv_penc_destroy(self._h)
+                self._h = C.c_void_p()
+        except Exception:
+            pass
+
+    def sync_weights(self, precision=None):
+        precision = precision or self.precision or default_precision()
+        if precision not in _PRECISIONS:
+            raise ValueError("precision must be one of %s" % sorted(_PRECISIONS))
+        sd = self.module.state_dict()
+        sig = tuple((k, v.data_ptr(), v._version, str(v.device)) for k, v in sd.items())
+        if sig != self._weight_sig:
+            L = _lib.lib()
+            for name, t in sd.items():
+                if name.startswith("g_proj."):
+                    continue                       # speaker projection: applied by the mirror before the call
+                if not t.is_cuda:
+                    raise RuntimeError("backend='hip' needs the module on a GPU (parameter %s is on %s)" % (name, t.device))
+                t32 = t.detach().to(torch.float32)
+                if name.endswith("conv.weight") and t32.dim() == 3:
+                    if t32.shape[0] != 1:
+                        raise ValueError("ConvTBC kernel_size %d is not used by PromptEncoder" % t32.shape[0])
+                    t32 = t32[0].t()               # [1, C_in, C_out] -> [C_out, C_in] (include/dvits_hip.h)
+                t32 = t32.contiguous()
+                shape = (C.c_int64 * t32.dim())(*t32.shape)
+                _lib.check(L.dv_penc_set_weight(self._h, name.encode(), _lib.ptr(t32), shape, t32.dim()),
+                           "dv_penc_set_weight(%s)" % name)
+            torch.cuda.synchronize()
+            self._weight_sig = sig
+            self._prepared = None
+        if precision != self.precision:
+            self.precision = precision
+            self._prepared = None
+
+    def forward(self, prompt, keep):
+        """prompt [B, C_in, L] float32 GPU, keep [B, L] float32 (1 = valid frame) -> [B, L, C_out] float32."""
+        if not prompt.is_cuda:
+            raise RuntimeError("backend='hip' needs GPU tensors; got prompt on %s" % prompt.device)
+        self.sync_weights()
+        B, _, L = prompt.shape
+        key = (B, L, self.precision)
+        if key != self._prepared:
+            _lib.check(_lib.lib().dv_penc_prepare(self._h, B, L, _PRECISIONS[self.precision]), "dv_penc_prepare")
+            self._prepared = key
+        x = prompt.detach().to(torch.float32).contiguous()
+        k = keep.detach().to(device=prompt.device, dtype=torch.float32).contiguous()
+        out = torch.empty((B, L, self.out_channels), device=prompt.device, dtype=torch.float32)
+        _lib.check(_lib.lib().dv_penc_forward(self._h, _lib.ptr(x), _lib.ptr(k), _lib.ptr(out), _lib.stream_ptr()),
+                   "dv_penc_forward")
+        return out
+
+    def stats(self):
+        n, f = C.c_int64(), C.c_double()
+        _lib.check(_lib.lib().dv_penc_stats(self._h, C.byref(n), C.byref(f)), "dv_penc_stats")
+        return n.value, f.value

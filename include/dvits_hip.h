@@ -58,8 +58,21 @@ typedef struct {
   float   norm_eps;               /* 1e-5 */
 } dv_unet_cfg;
 
+/* PromptEncoder constructor arguments (reference model3.py:382-406 as built by Diffusion_Encoder, model3.py:898:
+ * PromptEncoder(100, hidden, hidden, 4, 0.2); every layer is OPERATIONS_ENCODER[8] = EncSALayer(c, 8 heads,
+ * kernel_size 9, 'SAME'), operations.py:961-964). */
+typedef struct {
+  int32_t in_channels;            /* mel channels of the prompt, 100 */
+  int32_t hidden_channels;        /* 128 (config.json diffusion_encoder.hidden_channels) */
+  int32_t out_channels;           /* = hidden_channels at the reference call site */
+  int32_t n_layers;               /* 4 */
+  int32_t num_heads;              /* 8 */
+  int32_t ffn_kernel;             /* 9 */
+} dv_penc_cfg;
+
 typedef struct dv_unet dv_unet;
 typedef struct dv_plan dv_plan;
+typedef struct dv_penc dv_penc;
 
 const char* dv_last_error(void);
 /* Library/version probe: returns e.g. "dvits_hip 0.1 gfx950". */
@@ -160,6 +173,24 @@ int dv_sampler_run(dv_plan* p, dv_unet* u, float* x_inout, const float* cond, vo
  * tests: model(user, x_dev, t_input_host, out_dev) must enqueue out = f(x, t) on `stream`. */
 typedef int (*dv_model_fn)(void* user, const float* x, double t_input, float* out, void* stream);
 int dv_sampler_run_custom(dv_plan* p, dv_model_fn fn, void* user, float* x_inout, int64_t numel, void* stream);
+
+/* ---- prompt encoder: PromptEncoder.forward, reference model3.py:408-433 ------------------
+ * The reference recomputes it inside every denoiser call (Diffusion_Encoder.forward, model3.py:902-906) although it
+ * does not depend on the step; the host mirror calls this once per sampler run and feeds the result to
+ * dv_unet_set_cond. */
+int dv_penc_create(const dv_penc_cfg* cfg, dv_penc** out);
+void dv_penc_destroy(dv_penc* p);
+/* State-dict tensors under their reference names relative to the PromptEncoder ("pre.layer_norm.weight",
+ * "layers.0.op.self_attn.in_proj_weight" [3H,H], "layers.0.op.ffn.ffn_1.3.weight" [4H,H], "out_proj.conv.bias",
+ * "layer_norm.weight", ...), float32, copied.  The two ConvTBC weights (model.py:145-146, stored [1, C_in, C_out])
+ * are handed over as [C_out, C_in]: "pre.conv.weight", "out_proj.conv.weight". */
+int dv_penc_set_weight(dv_penc* p, const char* name, const void* dev_ptr, const int64_t* shape, int32_t ndim);
+int dv_penc_prepare(dv_penc* p, int32_t B, int32_t L, int32_t precision);
+/* prompt: [B, in_channels, L] float32 (the reference's src_tokens); keep: [B, L] float32, 1 = frame < length,
+ * 0 = padding (commons.sequence_mask, model3.py:416); out: [B, L, out_channels] float32 = the reference's return
+ * value transposed (model3.py:912 feeds prompt.transpose(1,2) to the UNet), padding frames zero. */
+int dv_penc_forward(dv_penc* p, const float* prompt, const float* keep, float* out, void* stream);
+int dv_penc_stats(dv_penc* p, int64_t* n_launch, double* flops);
 
 /* ---- single-operator entry points (parity tests of each kernel through the C ABI) ---- */
 

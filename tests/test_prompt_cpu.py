@@ -1,0 +1,91 @@
+"""CPU: the prompt encoder / Diffusion_Encoder row — oracle against the goldens captured from
+the stub-imported reference (tools/make_golden_prompt.py), mirror module layout, and the mirror's explicit torch
+backend against the same goldens."""
+import ast
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import rel_l2
+from diff_vits_amd import synth
+from diff_vits_amd.model3 import Diffusion_Encoder, PromptEncoder
+from oracle import prompt_ref, unet_ref
+
+CASES = ("cfg", "long")
+
+
+def prompt_case(gold, name):
+    g = gold("prompt_%s.npz" % name)
+    kw = ast.literal_eval(str(g["kwargs"]))
+    B, T, L = int(g["B"]), int(g["T"]), int(g["L"])
+    x = synth.normal(1234, "pe.x", (B, kw["in_channels"], T))
+    cond = synth.normal(1234, "pe.cond", (B, kw["hidden_channels"], T))
+    prompt = synth.normal(1234, "pe.prompt", (B, 100, L))
+    return g, kw, x, cond, prompt, g["lengths"], g["t"]
+
+
+def diffusion_state_dict(kw):
+    with torch.device("meta"):
+        shapes = {k: tuple(v.shape) for k, v in Diffusion_Encoder(backend="torch", **kw).state_dict().items()}
+    return synth.make_state_dict(shapes, seed=1234)
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_oracle_prompt_encoder_matches_reference(gold, name):
+    g, kw, x, cond, prompt, lengths, t = prompt_case(gold, name)
+    sd = {k[len("prompt_encoder."):]: torch.from_numpy(v) for k, v in diffusion_state_dict(kw).items()
+          if k.startswith("prompt_encoder.")}
+    probes = {}
+    with torch.no_grad():
+        enc = prompt_ref.prompt_encoder(sd, torch.from_numpy(prompt), torch.from_numpy(lengths), probes=probes)
+    assert rel_l2(enc.numpy(), g["enc"]) < 1e-6
+    for k, v in probes.items():
+        assert rel_l2(v.numpy(), g["probe_" + k]) < 1e-6
+    # padding frames are exactly zero, valid frames are not
+    for b, n in enumerate(lengths):
+        assert np.all(enc.numpy()[b, :, int(n):] == 0) and np.any(enc.numpy()[b, :, :int(n)] != 0)
+
+
+def test_oracle_diffusion_encoder_matches_reference(gold):
+    g, kw, x, cond, prompt, lengths, t = prompt_case(gold, "cfg")
+    sd = {k: torch.from_numpy(v) for k, v in diffusion_state_dict(kw).items()}
+    H = kw["hidden_channels"]
+    ucfg = unet_ref.default_config(kw["in_channels"] + H, kw["out_channels"], (128, 256, 384, 512), H, kw["n_heads"], 8, 2, 64)
+    with torch.no_grad():
+        y = prompt_ref.diffusion_encoder_forward(sd, ucfg, torch.from_numpy(x), torch.from_numpy(cond), torch.from_numpy(prompt),
+                                                 torch.from_numpy(lengths), torch.from_numpy(t))
+    assert rel_l2(y.numpy(), g["y"]) < 1e-6
+
+
+def test_mirror_layout_matches_reference(gold):
+    g = gold("prompt_cfg.npz")
+    with torch.device("meta"):
+        m = PromptEncoder(100, 128, 128, 4, 0.2, backend="torch")
+    sd = m.state_dict()
+    names = [str(n)[len("prompt_encoder."):] for n in g["names"]]
+    assert sorted(sd) == sorted(names)
+    for n, s in zip(names, g["shapes"]):
+        assert tuple(sd[n].shape) == ast.literal_eval(str(s)), n
+    assert sum(v.numel() for v in sd.values()) == int(g["n_params_prompt_encoder"]) == 2918344 - 0
+    with torch.device("meta"):
+        d = Diffusion_Encoder(in_channels=100, out_channels=100, hidden_channels=128, n_heads=8, p_dropout=0.2, backend="torch")
+    assert len([k for k in d.state_dict() if k.startswith("unet.")]) == 701
+    with pytest.raises(ValueError):
+        PromptEncoder(100, 128, 128, 4, backend="cuda")
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_mirror_torch_backend_matches_reference(gold, name):
+    g, kw, x, cond, prompt, lengths, t = prompt_case(gold, name)
+    m = Diffusion_Encoder(backend="torch", **kw).eval()
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in diffusion_state_dict(kw).items()})
+    with torch.no_grad():
+        enc = m.prompt_encoder(torch.from_numpy(prompt), torch.from_numpy(lengths))
+        assert rel_l2(enc.numpy(), g["enc"]) < 1e-6
+        if name == "cfg":
+            data = (torch.from_numpy(cond), torch.from_numpy(prompt), None, torch.from_numpy(lengths))
+            y = m(torch.from_numpy(x), data, torch.from_numpy(t))
+            assert rel_l2(y.numpy(), g["y"]) < 1e-6
+            y2 = m(torch.from_numpy(x), data, torch.from_numpy(t))       # cached conditioning: identical
+            assert torch.equal(y, y2)
