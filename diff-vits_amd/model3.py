@@ -208,6 +208,15 @@ class Diffusion_Encoder(nn.Module):
             self._unet_cond_serial = None
         return self._cond
 
+    def native_model(self, data):
+        """The sampler-side handle for a whole run: the reference wraps `lambda x, t: diff_model(x, data, t)` into
+        model_wrapper (model3.py:1173-1182); passing THIS object as `model` instead lets DPM_Solver / UniPC replay the
+        complete loop as one hipGraph (prompt encoder evaluated once, here).  Also a plain callable (x, t_input)."""
+        from .sampler._plan import NativeUNetModel
+        cond, prompt, cond_lengths, prompt_lengths = data
+        enc, mask = self._conditioning(prompt, prompt_lengths, torch.float32)
+        return NativeUNetModel(self.unet, cond, enc, mask)
+
     def forward(self, x, data, t):
         cond, prompt, cond_lengths, prompt_lengths = data
         enc, mask = self._conditioning(prompt, prompt_lengths, x.dtype)

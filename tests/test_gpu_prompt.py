@@ -70,3 +70,22 @@ def test_diffusion_encoder_hip_matches_reference(gold):
         dp2[:, :, :5] += 1.0
         y4 = m(dx, (dc, dp2, None, dl), dt)
         assert not torch.equal(m._cond[0], enc_before) and not torch.equal(y4, y)
+
+
+def test_diffusion_encoder_native_sampler_loop(gold):
+    """Whole DPM-Solver++ run through Diffusion_Encoder.native_model (one hipGraph) == the same solver stepping the
+    mirror's forward call by call (the reference's plumbing, model3.py:1173-1182)."""
+    from diff_vits_amd import synth
+    from diff_vits_amd.sampler import dpm_solver
+    g, kw, x, cond, prompt, lengths, t = prompt_case(gold, "cfg")
+    m = _model(kw)
+    dx, dc, dp = torch.from_numpy(x).cuda(), torch.from_numpy(cond).cuda(), torch.from_numpy(prompt).cuda()
+    dl = torch.from_numpy(lengths).cuda()
+    data = (dc, dp, None, dl)
+    ns = dpm_solver.NoiseScheduleVP("discrete", betas=torch.from_numpy(synth.make_betas()).cuda())
+    with torch.no_grad():
+        fn_native = dpm_solver.model_wrapper(m.native_model(data), ns, model_type="x_start")
+        a = dpm_solver.DPM_Solver(fn_native, ns, algorithm_type="dpmsolver++").sample(dx, steps=8, order=2, method="multistep")
+        fn_calls = dpm_solver.model_wrapper(lambda xx, tt: m(xx, data, tt), ns, model_type="x_start")
+        b = dpm_solver.DPM_Solver(fn_calls, ns, algorithm_type="dpmsolver++").sample(dx, steps=8, order=2, method="multistep")
+    assert torch.isfinite(a).all() and rel_l2(a.cpu().numpy(), b.cpu().numpy()) < 1e-5
