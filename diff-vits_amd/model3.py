@@ -237,3 +237,108 @@ class Diffusion_Encoder(nn.Module):
         tt = unet._timesteps(t, x).detach().to(device=x.device, dtype=torch.float32).contiguous()
         y = eng.eval(x.detach().to(torch.float32).contiguous(), cond.detach().to(torch.float32).contiguous(), tt)
         return y if x.dtype == torch.float32 else y.to(x.dtype)
+
+
+def linear_beta_schedule(timesteps):
+    """reference model3.py:935-942."""
+    scale = 1000 / timesteps
+    return torch.linspace(scale * 0.0001, scale * 0.02, timesteps, dtype=torch.float64)
+
+
+class NaturalSpeech2(nn.Module):
+    """Inference side of reference model3.NaturalSpeech2 (model3.py:955-1203): the diffusion model,
+    the schedule buffers of __init__ (:976-1018, same names/values, so a reference checkpoint's buffers load) and
+    `sample` for the 'unipc' and 'dpmsolver' methods.
+
+    The VITS prior is not part of this package: pass any module whose `.infer(text, text_lengths, spec, spec_lengths,
+    tone, language)` returns `(content [B, hidden, T], refer [B, 100, L])` as `vits=` (the reference's own `VITS`
+    instance works: it is pure PyTorch), or call `sample_from_prior` with those two tensors.  Differences from the
+    reference, all opt-in or fixes: `noise=` (explicit x_T; the reference draws torch.randn), batch > 1 for 'unipc'
+    (the reference's wrapper only broadcasts at B = 1), and a 'dpmsolver' branch that runs (the
+    reference's calls `vits.infer` with a tuple and cannot, quirk 7; here it uses the 'unipc' branch's plumbing with the
+    solver call of model3.py:1148-1158).  On the HIP backend the whole solver loop is one hipGraph replay."""
+
+    def __init__(self, cfg, vits=None, rvq_cross_entropy_loss_weight=0.1, diff_loss_weight=1.0, f0_loss_weight=1.0,
+                 duration_loss_weight=1.0, ddim_sampling_eta=0, min_snr_loss_weight=False, min_snr_gamma=5, backend=None):
+        super().__init__()
+        if vits is not None:
+            self.vits = vits
+        self.diff_model = Diffusion_Encoder(**cfg["diffusion_encoder"], backend=backend)
+        self.dim = self.diff_model.in_channels
+        betas = linear_beta_schedule(cfg["train"]["timesteps"])
+        alphas = 1. - betas
+        alphas_cumprod = torch.cumprod(alphas, dim=0)
+        alphas_cumprod_prev = F.pad(alphas_cumprod[:-1], (1, 0), value=1.)
+        self.num_timesteps = betas.shape[0]
+        self.sampling_timesteps = None
+        self.ddim_sampling_eta = ddim_sampling_eta
+
+        def register_buffer(name, val):
+            self.register_buffer(name, val.to(torch.float32))
+
+        register_buffer("betas", betas)
+        register_buffer("alphas_cumprod", alphas_cumprod)
+        register_buffer("alphas_cumprod_prev", alphas_cumprod_prev)
+        register_buffer("sqrt_alphas_cumprod", torch.sqrt(alphas_cumprod))
+        register_buffer("sqrt_one_minus_alphas_cumprod", torch.sqrt(1. - alphas_cumprod))
+        register_buffer("log_one_minus_alphas_cumprod", torch.log(1. - alphas_cumprod))
+        register_buffer("sqrt_recip_alphas_cumprod", torch.sqrt(1. / alphas_cumprod))
+        register_buffer("sqrt_recipm1_alphas_cumprod", torch.sqrt(1. / alphas_cumprod - 1))
+        posterior_variance = betas * (1. - alphas_cumprod_prev) / (1. - alphas_cumprod)
+        register_buffer("posterior_variance", posterior_variance)
+        register_buffer("posterior_log_variance_clipped", torch.log(posterior_variance.clamp(min=1e-20)))
+        register_buffer("posterior_mean_coef1", betas * torch.sqrt(alphas_cumprod_prev) / (1. - alphas_cumprod))
+        register_buffer("posterior_mean_coef2", (1. - alphas_cumprod_prev) * torch.sqrt(alphas) / (1. - alphas_cumprod))
+        snr = alphas_cumprod / (1 - alphas_cumprod)
+        if min_snr_loss_weight:
+            snr = snr.clamp(max=min_snr_gamma)
+        register_buffer("loss_weight", snr)
+
+    def sample_fun(self, x, t, data=None):
+        """reference model3.py:1113-1118: the x_start prediction handed to model_wrapper."""
+        return self.diff_model(x, data, t)
+
+    @torch.no_grad()
+    def sample_from_prior(self, content, refer, text_lengths, spec_lengths, vocos=None, sample_method="unipc", noise=None):
+        """(content, refer) -> (audio | None, mel): reference model3.py:1162-1203 after the `vits.infer` call."""
+        if sample_method not in ("unipc", "dpmsolver"):
+            raise ValueError("sample_method %r is not supported (this build: 'unipc', 'dpmsolver')" % (sample_method,))
+        shape = (content.shape[0], self.dim, content.shape[2])
+        audio = torch.randn(shape, device=refer.device) if noise is None else noise.to(refer.device)
+        if tuple(audio.shape) != shape:
+            raise ValueError("noise must have shape %s, got %s" % (shape, tuple(audio.shape)))
+        data = (content, refer, text_lengths, spec_lengths)
+        native = self.diff_model.backend == "hip" and audio.is_cuda
+        if sample_method == "unipc":
+            from .sampler.uni_pc import NoiseScheduleVP, UniPC, model_wrapper
+        else:
+            from .sampler.dpm_solver import DPM_Solver, NoiseScheduleVP, model_wrapper
+        noise_schedule = NoiseScheduleVP(schedule="discrete", betas=self.betas)
+        if native:
+            model_fn = model_wrapper(self.diff_model.native_model(data), noise_schedule, model_type="x_start")
+        else:
+            model_fn = model_wrapper(self.sample_fun, noise_schedule, model_type="x_start", model_kwargs={"data": data})
+        if sample_method == "unipc":
+            mel = UniPC(model_fn, noise_schedule, variant="bh2").sample(audio, steps=30, order=2, skip_type="time_uniform",
+                                                                        method="multistep")
+        else:
+            mel = DPM_Solver(model_fn, noise_schedule, algorithm_type="dpmsolver++").sample(
+                audio, steps=40, order=2, skip_type="time_uniform", method="multistep")
+        if vocos is None:
+            return None, mel
+        vocos.to(mel.device)
+        wav = vocos.decode(mel)
+        if wav.ndim == 3:
+            wav = wav.reshape(wav.shape[0], wav.shape[2])         # 'b 1 n -> b n'
+        return wav, mel
+
+    @torch.no_grad()
+    def sample(self, text, spec, text_lengths, spec_lengths, tone, language, vocos, sampling_timesteps=200,
+               sample_method="unipc", noise=None):
+        """reference model3.py:1119-1203 (same positional signature)."""
+        self.sampling_timesteps = sampling_timesteps
+        if not hasattr(self, "vits"):
+            raise RuntimeError("NaturalSpeech2.sample needs the VITS prior: construct with vits=<module with .infer(...)> "
+                               "or call sample_from_prior(content, refer, ...)")
+        content, refer = self.vits.infer(text, text_lengths, spec, spec_lengths, tone, language)
+        return self.sample_from_prior(content, refer, text_lengths, spec_lengths, vocos, sample_method, noise)

@@ -89,3 +89,57 @@ def test_mirror_torch_backend_matches_reference(gold, name):
             assert rel_l2(y.numpy(), g["y"]) < 1e-6
             y2 = m(torch.from_numpy(x), data, torch.from_numpy(t))       # cached conditioning: identical
             assert torch.equal(y, y2)
+
+
+# ---- NaturalSpeech2.sample orchestration ------------------------------------------------------
+def sample_case(gold):
+    from diff_vits_amd.model3 import NaturalSpeech2
+    g = gold("sample_unipc.npz")
+    dcfg = ast.literal_eval(str(g["diffusion_encoder"]))
+    cfg = {"diffusion_encoder": dcfg, "train": {"timesteps": int(g["timesteps"])}}
+    B, T, L = int(g["B"]), int(g["T"]), int(g["L"])
+    content = synth.normal(1234, "ns2.content", (B, dcfg["hidden_channels"], T))
+    refer = synth.normal(1234, "ns2.refer", (B, 100, L))
+    noise = synth.normal(1234, "ns2.noise", (B, dcfg["in_channels"], T))
+    return g, cfg, NaturalSpeech2, content, refer, noise
+
+
+class PassThroughVocoder:
+    def to(self, device):
+        return self
+
+    def decode(self, mel):
+        return mel.mean(dim=1, keepdim=True)
+
+
+def test_oracle_sample_orchestration_matches_reference(gold):
+    from oracle import sample_ref
+    g, cfg, _, content, refer, noise = sample_case(gold)
+    bufs = sample_ref.schedule_buffers(cfg["train"]["timesteps"])
+    for k, v in bufs.items():
+        assert np.array_equal(v.numpy(), g["buf_" + k]), k
+    sd = {k: torch.from_numpy(v) for k, v in diffusion_state_dict(cfg["diffusion_encoder"]).items()}
+    mel = sample_ref.sample_mel(sd, cfg["diffusion_encoder"], torch.from_numpy(content), torch.from_numpy(refer),
+                                torch.from_numpy(g["text_lengths"]), torch.from_numpy(g["spec_lengths"]),
+                                torch.from_numpy(noise), "unipc", cfg["train"]["timesteps"])
+    assert rel_l2(mel.numpy(), g["mel"]) < 1e-6
+
+
+def test_mirror_sample_torch_backend_matches_reference(gold):
+    g, cfg, NaturalSpeech2, content, refer, noise = sample_case(gold)
+
+    class Prior(torch.nn.Module):
+        def infer(self, text, text_lengths, spec, spec_lengths, tone, language):
+            return torch.from_numpy(content), spec
+    m = NaturalSpeech2(cfg, vits=Prior(), backend="torch").eval()
+    for k in ("betas", "alphas_cumprod", "sqrt_recipm1_alphas_cumprod", "posterior_mean_coef2"):
+        assert np.array_equal(getattr(m, k).numpy(), g["buf_" + k]), k
+    m.diff_model.load_state_dict({k: torch.from_numpy(v) for k, v in diffusion_state_dict(cfg["diffusion_encoder"]).items()})
+    audio, mel = m.sample(None, torch.from_numpy(refer), torch.from_numpy(g["text_lengths"]), torch.from_numpy(g["spec_lengths"]),
+                          None, None, PassThroughVocoder(), sample_method="unipc", noise=torch.from_numpy(noise))
+    assert rel_l2(mel.numpy(), g["mel"]) < 1e-5 and rel_l2(audio.numpy(), g["audio"]) < 1e-5
+    with pytest.raises(ValueError):
+        m.sample_from_prior(torch.from_numpy(content), torch.from_numpy(refer), None, torch.from_numpy(g["spec_lengths"]),
+                            sample_method="ddim")
+    with pytest.raises(RuntimeError):
+        NaturalSpeech2(cfg, backend="torch").sample(None, None, None, None, None, None, None)

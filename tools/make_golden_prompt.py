@@ -96,6 +96,55 @@ def main():
             names=np.array(sorted(k for k in shapes if k.startswith("prompt_encoder."))),
             shapes=np.array([repr(shapes[k]) for k in sorted(shapes) if k.startswith("prompt_encoder.")]),
             **{"probe_" + k: v.numpy() for k, v in probes.items()})
+    sample_golden(model3, args.ref)
+
+
+def sample_golden(model3, ref):
+    """NaturalSpeech2.sample (model3.py:1118-1203), 'unipc' branch, with the prior replaced by fixed synthetic
+    (content, refer), torch.randn by a fixed noise tensor and vocos by a pass-through: pins the orchestration row
+    (schedule buffers -> NoiseScheduleVP -> model_wrapper(sample_fun) -> UniPC bh2, 30 steps, order 2)."""
+    import json
+    from oracle import sample_ref
+    cfg = json.load(open(os.path.join(ref, "config.json")))
+    B, T, L = 1, 48, 30
+    m = model3.NaturalSpeech2(cfg).eval()
+    dshapes = {k: tuple(v.shape) for k, v in m.diff_model.state_dict().items()}
+    dsd = synth.make_state_dict(dshapes, seed=1234)
+    m.diff_model.load_state_dict({k: torch.from_numpy(v) for k, v in dsd.items()})
+    content = torch.from_numpy(synth.normal(1234, "ns2.content", (B, cfg["diffusion_encoder"]["hidden_channels"], T)))
+    refer = torch.from_numpy(synth.normal(1234, "ns2.refer", (B, 100, L)))
+    noise = torch.from_numpy(synth.normal(1234, "ns2.noise", (B, cfg["diffusion_encoder"]["in_channels"], T)))
+    text_lengths, spec_lengths = torch.tensor([17]), torch.tensor([L - 4])
+    m.vits.infer = lambda *a, **k: (content, refer)
+
+    class PassThroughVocoder:
+        def to(self, device):
+            return self
+
+        def decode(self, mel):
+            return mel.mean(dim=1, keepdim=True)
+
+    real_randn = torch.randn
+    torch.randn = lambda *a, **k: noise.clone() if tuple(a[0] if isinstance(a[0], (tuple, list)) else a) == tuple(noise.shape) \
+        else real_randn(*a, **k)
+    try:
+        audio, mel = m.sample(None, refer, text_lengths, spec_lengths, None, None, PassThroughVocoder(), sample_method="unipc")
+    finally:
+        torch.randn = real_randn
+    # oracle restatement of the same orchestration
+    tsd = {k: torch.from_numpy(v) for k, v in dsd.items()}
+    mel_or = sample_ref.sample_mel(tsd, cfg["diffusion_encoder"], content, refer, text_lengths, spec_lengths, noise,
+                                   sample_method="unipc", timesteps=cfg["train"]["timesteps"])
+    bufs_or = sample_ref.schedule_buffers(cfg["train"]["timesteps"])
+    bufs = {k: v.numpy() for k, v in m.state_dict().items() if k in bufs_or}
+    assert len(bufs) == len(bufs_or)
+    worst = max(rel(bufs_or[k].numpy(), bufs[k]) for k in bufs)
+    print("sample  unipc mel: oracle vs reference %.2e ; schedule buffers (%d) worst %.2e ; |mel| %.3f"
+          % (rel(mel_or.numpy(), mel.numpy()), len(bufs), worst, float(mel.abs().mean())))
+    np.savez_compressed(os.path.join(GOLD, "sample_unipc.npz"), B=B, T=T, L=L, text_lengths=text_lengths.numpy(),
+                        spec_lengths=spec_lengths.numpy(), mel=mel.numpy(), audio=audio.numpy(),
+                        diffusion_encoder=np.array(repr(cfg["diffusion_encoder"])), timesteps=cfg["train"]["timesteps"],
+                        **{"buf_" + k: v for k, v in bufs.items()})
 
 
 if __name__ == "__main__":
