@@ -759,7 +759,17 @@ struct Builder {
       emit(S, [=](hipStream_t st) { return launch_small_linear(tsin, C0, w1, b1, nullptr, h1, E, Bn, C0, E, 0, 1, st); });
       emit(S, [=](hipStream_t st) { return launch_small_linear(h1, E, w2, b2, aug_emb, emb, E, Bn, E, E, 0, 0, st); });
       float* tp = tproj; const int tt = tproj_total;
-      emit(S, [=](hipStream_t st) { return launch_small_linear(emb, E, Wt, bt, nullptr, tp, tt, Bn, E, tt, 1, 0, st); });
+      if (Bn <= 16) {   // lane-per-column kernel on the transposed table (built once, below the schedule's critical path)
+        float* WtT = nullptr;
+        if (!dry) {
+          if (hipMalloc((void**)&WtT, (size_t)tt * E * 4) != hipSuccess) return dv_fail(DV_ERR_HIP, "hipMalloc(time_emb_proj^T) failed");
+          u->owned.push_back(WtT);
+          (void)launch_transpose_f32(Wt, WtT, tt, E, pack_stream);
+        }
+        emit(S, [=](hipStream_t st) { return launch_small_linear_t(emb, E, WtT, bt, tp, tt, Bn, E, tt, 1, st); });
+      } else {
+        emit(S, [=](hipStream_t st) { return launch_small_linear(emb, E, Wt, bt, nullptr, tp, tt, Bn, E, tt, 1, 0, st); });
+      }
       release(tsin); release(h1);
       probe("emb", emb, 1, E);
     }

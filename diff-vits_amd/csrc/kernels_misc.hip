@@ -115,6 +115,20 @@ __global__ __launch_bounds__(256) void k_gn_apply(const GnApplyParams p, int row
   const int ctot = p.c0 + p.c1, G = p.groups, cg = ctot / G;
   const int g = blockIdx.y, b = blockIdx.z, tid = threadIdx.x;
   const int cbase = g * cg;
+  // the elements this thread normalises do not depend on the statistics: fetch the first two items now, so their
+  // (cold-L2) latency overlaps the slab reduction instead of following it
+  const int ncol4 = cg >> 2;
+  const int t0 = blockIdx.x * rows_per_block, t1r = min(p.T, t0 + rows_per_block);
+  const int total = (t1r - t0) * ncol4;
+  auto load_item = [&](int i) {
+    const int r = i / ncol4, c = cbase + (i - r * ncol4) * 4;
+    const size_t row = (size_t)b * p.T + t0 + r;
+    return *reinterpret_cast<const float4*>(c < p.c0 ? p.a0 + row * p.c0 + c : p.a1 + row * p.c1 + (c - p.c0));
+  };
+  constexpr int PF = 2;
+  float4 pv[PF];
+#pragma unroll
+  for (int k = 0; k < PF; ++k) pv[k] = tid + k * 256 < total ? load_item(tid + k * 256) : make_float4(0.f, 0.f, 0.f, 0.f);
   if (p.scale_in) {
     for (int c = tid; c < cg; c += 256) {
       s_scale[c] = p.scale_in[(size_t)b * ctot + cbase + c];
@@ -154,14 +168,10 @@ __global__ __launch_bounds__(256) void k_gn_apply(const GnApplyParams p, int row
     }
   }
   __syncthreads();
-  const int ncol4 = cg >> 2;
-  const int t0 = blockIdx.x * rows_per_block, t1r = min(p.T, t0 + rows_per_block);
-  const int total = (t1r - t0) * ncol4;
-  for (int i = tid; i < total; i += 256) {
+  for (int i = tid, k = 0; i < total; i += 256, ++k) {
     const int r = i / ncol4, j = i - r * ncol4, c = cbase + j * 4;
     const size_t row = (size_t)b * p.T + t0 + r;
-    const bool first = c < p.c0;
-    const float4 v = *reinterpret_cast<const float4*>(first ? p.a0 + row * p.c0 + c : p.a1 + row * p.c1 + (c - p.c0));
+    const float4 v = k == 0 ? pv[0] : (k == 1 ? pv[1] : load_item(i));
     const float4 sc = *reinterpret_cast<const float4*>(s_scale + j * 4);
     const float4 sh = *reinterpret_cast<const float4*>(s_shift + j * 4);
     float4 y;
@@ -612,6 +622,73 @@ __global__ __launch_bounds__(256) void k_small_linear(const float* __restrict__ 
       }
     }
   }
+}
+
+// Wide small-M fp32 linear on TRANSPOSED weights Wt [K, N] (the 22 batched time_emb_proj GEMVs: [B, 512] x [512, 14848]):
+// lane = output column, so the weight stream is read once, fully coalesced, and no cross-lane reduction is needed;
+// the (activated) input rows sit in LDS and are broadcast.  M <= 16.
+template <int MR>
+__global__ __launch_bounds__(256) void k_small_linear_t(const float* __restrict__ in, int ldin, const float* __restrict__ Wt,
+                                                         const float* __restrict__ bias, float* __restrict__ out, int ldo,
+                                                         int M, int K, int N, int silu_in) {
+  // workgroup = 64 output columns x 4 k-quarters (one wave each): 232 workgroups for N = 14848, 128 sequential
+  // k-steps per lane with 16 weight loads in flight; the four partial sums meet in LDS
+  extern __shared__ float s_in[];        // [K][MR] activated input, row index fastest; then [4][64][MR] partials
+  float* s_part = s_in + K * MR;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int i = tid; i < K * MR; i += 256) {
+    const int k = i / MR, m = i - k * MR;
+    float xv = m < M ? in[(size_t)m * ldin + k] : 0.f;
+    if (silu_in) xv = xv / (1.0f + __expf(-xv));
+    s_in[i] = xv;
+  }
+  __syncthreads();
+  const int n = blockIdx.x * 64 + lane;
+  const int nc = n < N ? n : N - 1;
+  float acc[MR];
+#pragma unroll
+  for (int m = 0; m < MR; ++m) acc[m] = 0.f;
+  const int kq = (K + 3) / 4, k0 = wave * kq, k1 = min(K, k0 + kq);
+  const float* w = Wt + nc;
+#pragma unroll 16
+  for (int k = k0; k < k1; ++k) {
+    const float wv = w[(size_t)k * N];
+#pragma unroll
+    for (int m = 0; m < MR; ++m) acc[m] = fmaf(s_in[k * MR + m], wv, acc[m]);
+  }
+#pragma unroll
+  for (int m = 0; m < MR; ++m) s_part[(wave * 64 + lane) * MR + m] = acc[m];
+  __syncthreads();
+  if (wave == 0 && n < N) {
+    const float bv = bias ? bias[n] : 0.f;
+#pragma unroll
+    for (int m = 0; m < MR; ++m) {
+      const float v = (s_part[lane * MR + m] + s_part[(64 + lane) * MR + m]) +
+                      (s_part[(128 + lane) * MR + m] + s_part[(192 + lane) * MR + m]);
+      if (m < M) out[(size_t)m * ldo + n] = v + bv;
+    }
+  }
+}
+
+hipError_t launch_small_linear_t(const float* in, int ldin, const float* Wt, const float* b, float* out, int ldo, int M,
+                                 int K, int N, int silu_in, hipStream_t st) {
+  if (M > 16 || ((size_t)K * 16 + 256 * 16) * sizeof(float) > 64 * 1024) return hipErrorInvalidValue;
+  const dim3 grid((N + 63) / 64);
+  if (M <= 8) hipLaunchKernelGGL(k_small_linear_t<8>, grid, dim3(256), ((size_t)K * 8 + 256 * 8) * 4, st, in, ldin, Wt, b, out, ldo, M, K, N, silu_in);
+  else hipLaunchKernelGGL(k_small_linear_t<16>, grid, dim3(256), ((size_t)K * 16 + 256 * 16) * 4, st, in, ldin, Wt, b, out, ldo, M, K, N, silu_in);
+  return hipGetLastError();
+}
+
+// dst[c, r] = src[r, c]  (one-off weight re-layout at prepare time)
+__global__ __launch_bounds__(256) void k_transpose_f32(const float* __restrict__ src, float* __restrict__ dst, int R, int Cc) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (int64_t)R * Cc) return;
+  const int r = (int)(i / Cc), c = (int)(i - (int64_t)r * Cc);
+  dst[(size_t)c * R + r] = src[i];
+}
+hipError_t launch_transpose_f32(const float* src, float* dst, int R, int Cc, hipStream_t st) {
+  hipLaunchKernelGGL(k_transpose_f32, dim3((unsigned)(((int64_t)R * Cc + 255) / 256)), dim3(256), 0, st, src, dst, R, Cc);
+  return hipGetLastError();
 }
 
 hipError_t launch_small_linear(const float* in, int ldin, const float* W, const float* b, const float* add,
