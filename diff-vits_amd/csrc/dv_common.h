@@ -72,6 +72,7 @@ struct AttnParams {
 // launchers (each enqueues on `st` and returns hipGetLastError())
 hipError_t launch_gemm(const GemmParams& p, int precision, hipStream_t st);
 hipError_t gemm_init();   // one-time kernel attribute setup (call outside stream capture)
+hipError_t attn_init();
 hipError_t launch_attention(const AttnParams& p, hipStream_t st);
 
 // misc kernels (kernels_misc.hip)

@@ -1035,6 +1035,7 @@ extern "C" int dv_unet_prepare(dv_unet* u, int32_t B, int32_t T, int32_t L, int3
   }
   HIPCHK(hipDeviceSynchronize());
   HIPCHK(gemm_init());
+  HIPCHK(attn_init());
   unet_release_prepared(u);
   u->B = B; u->T = T; u->L = L; u->precision = precision; u->force_up = force_upsample_size;
   const char* keep = getenv("DVITS_KEEP_INTERMEDIATES");
@@ -1110,6 +1111,7 @@ extern "C" int dv_penc_prepare(dv_penc* p, int32_t B, int32_t L, int32_t precisi
   dv_unet* u = &p->core;
   HIPCHK(hipDeviceSynchronize());
   HIPCHK(gemm_init());
+  HIPCHK(attn_init());
   unet_release_prepared(u);
   u->B = B; u->T = L; u->L = L; u->precision = precision; u->force_up = 0;
   const char* keep = getenv("DVITS_KEEP_INTERMEDIATES");
@@ -1295,6 +1297,7 @@ extern "C" int dv_op_conv1d(const float* x, const float* w, const float* bias, f
   if (!x || !w || !y || (k != 1 && k != 3) || (stride != 1 && stride != 2)) return dv_fail(DV_ERR_INVALID, "dv_op_conv1d: bad argument");
   hipStream_t st = (hipStream_t)stream;
   HIPCHK(gemm_init());
+  HIPCHK(attn_init());
   const bool x3 = precision == DV_PREC_BF16X3;
   const int cpad = rup(Cin, 32), Kp = k * cpad, Npad = rup(Cout, 128);
   OpScratch sc;
@@ -1328,6 +1331,7 @@ extern "C" int dv_op_linear(const float* x, const float* w, const float* bias, f
   if (!x || !w || !y || K % 32 != 0) return dv_fail(DV_ERR_INVALID, "dv_op_linear: K must be a multiple of 32");
   hipStream_t st = (hipStream_t)stream;
   HIPCHK(gemm_init());
+  HIPCHK(attn_init());
   const bool x3 = precision == DV_PREC_BF16X3;
   const int Npad = rup(N, 128);
   OpScratch sc;
@@ -1373,6 +1377,7 @@ extern "C" int dv_op_attention(const float* q, const float* k, const float* v, c
   a.q = q; a.k = k; a.v = v; a.bias = bias; a.o = o; a.o_hi = nullptr; a.o_lo = nullptr;
   a.ldq = a.ldk = a.ldv = a.ldo = H * d;
   a.B = B; a.H = H; a.Tq = Tq; a.Tk = Tk; a.d = d; a.scale = 1.0f / sqrtf((float)d); a.nsplit = 3;
+  HIPCHK(attn_init());
   hipError_t e = launch_attention(a, (hipStream_t)stream);
   if (e != hipSuccess) return dv_fail(DV_ERR_HIP, "attention launch failed: %s (d must be a multiple of 4, <= 64)", hipGetErrorString(e));
   return DV_OK;

@@ -14,8 +14,11 @@
 //                               V^T is stored in LDS with its key axis permuted (bits 2 and 3 of
 //                               the key index swapped) so that the matching 8 keys are one 16-byte
 //                               read; the per-query rescale and the final 1/l are per-lane scalars
-// K / V^T tiles of 32 keys are converted fp32 -> split bf16 once per workgroup and shared by its NW
-// waves (32*NW queries); two LDS buffers, global loads of tile t+1 in flight during tile t.
+// K / V tiles of 32 keys travel global -> LDS by LDS-DMA (global_load_lds, raw fp32, 4-stage ring, hand-counted
+// vmcnt): the producer kernel's output is never in this kernel's L2 (kernel boundary), so every tile is a ~2 us
+// fabric round trip and a short key loop is bound by how many tiles are in flight, not by bandwidth.  Each tile is
+// then converted fp32 -> split bf16 (K rows; V^T with the permuted key axis) once per workgroup, one tile ahead of
+// the MFMAs, and shared by its NW waves (32*NW queries).
 #include "dv_common.h"
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
@@ -30,6 +33,36 @@ __device__ __forceinline__ unsigned apk(float lo, float hi) {
 __device__ __forceinline__ float bf_lo(unsigned w) { return __uint_as_float(w << 16); }
 __device__ __forceinline__ float bf_hi(unsigned w) { return __uint_as_float(w & 0xffff0000u); }
 
+// LDS-DMA helpers (see kernels_gemm.hip): wave-uniform LDS base in M0, per-lane global source, not tracked by hipcc
+__device__ __forceinline__ void att_glds16(const void* gsrc, unsigned lds_dst) {
+  unsigned keep;
+  lds_dst = __builtin_amdgcn_readfirstlane(lds_dst);
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+__device__ __forceinline__ void att_glds4(const void* gsrc, unsigned lds_dst) {
+  unsigned keep;
+  lds_dst = __builtin_amdgcn_readfirstlane(lds_dst);
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void att_wait_vmcnt() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+template <int DP, int NW>
+struct AttnGeom {
+  static constexpr int KP = DP * 2 + 16, VP = 80, NB = (DP + 31) / 32;
+  static constexpr int K_PL = 32 * KP, V_PL = NB * 32 * VP;
+  static constexpr int NST = 4;                                  // raw tiles in flight
+  static constexpr int RAWK = 32 * DP * 4;                       // raw fp32 K (or V) tile bytes
+  static constexpr int RAW = (2 * RAWK + NW * 256 + 1023) / 1024 * 1024;   // + one 64-float bias slot per wave
+  static constexpr int buf_bytes(int npl) { return (K_PL + V_PL) * npl + 128; }
+  static constexpr int planes_bytes(int npl) { return (2 * buf_bytes(npl) + 1023) / 1024 * 1024; }
+  static constexpr int smem_bytes(int npl) { return planes_bytes(npl) + NST * RAW; }
+};
+
 template <int DP, int NW, int NSPLIT>
 __global__ __launch_bounds__(64 * NW) void k_attention(const AttnParams p) {
   constexpr bool SPLIT = NSPLIT == 3;
@@ -41,11 +74,18 @@ __global__ __launch_bounds__(64 * NW) void k_attention(const AttnParams p) {
   constexpr int K_PL = 32 * KP, V_PL = NB * 32 * VP;
   constexpr int BUF = (K_PL + V_PL) * NPL + 128;   // + 32 floats of key bias
   constexpr int NT = 64 * NW;
-  constexpr int TASKS = 4 * DP;                    // (key pair, 4-channel group) load tasks per tile
+  constexpr int TASKS = 4 * DP;                    // (key pair, 4-channel group) conversion tasks per tile
   constexpr int TPT = (TASKS + NT - 1) / NT;
-  __shared__ __attribute__((aligned(16))) char lds[2 * BUF];
+  using G = AttnGeom<DP, NW>;
+  constexpr int NST = G::NST, RAWK = G::RAWK, RAW = G::RAW;
+  constexpr int CPR = DP / 4;                      // 16-byte chunks per raw row
+  constexpr int KV_INSTR = 2 * 32 * CPR / 64;      // DMA wave-instructions per tile for K and V (= DP / 4)
+  constexpr int IPW = KV_INSTR / NW + 1;           // per wave per tile, + its bias slot
+  static_assert(KV_INSTR % NW == 0, "K/V DMA instructions must split evenly over the waves");
+  extern __shared__ __attribute__((aligned(1024))) char lds[];   // [2 x BUF planes | NST x RAW ring]
+  char* const raw0 = lds + G::planes_bytes(NPL);
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l31 = lane & 31, lh = lane >> 5;
   const int b = blockIdx.z, h = blockIdx.y;
   const int d = p.d;
@@ -84,29 +124,34 @@ __global__ __launch_bounds__(64 * NW) void k_attention(const AttnParams p) {
     for (int r = 0; r < 16; ++r) o[nb][r] = 0.f;
   float m_run = -1e30f, l_run = 0.f;
 
-  // ---- K / V tile staging: task = (key pair kp, channel group c4) ----
-  float4 rk0[TPT], rk1[TPT], rv0[TPT], rv1[TPT];
-  float rbias = 0.f;
-  auto load_tile = [&](int kt0) {
+  // ---- K / V tile staging ----
+  // DMA: instruction ii of a tile moves raw chunks [64 ii, 64 ii + 64) of the tile image [K: 32 x DP | V: 32 x DP]
+  // (row-major fp32, 16-byte chunks; chunks past d read a valid dummy and are zeroed at conversion)
+  const unsigned raw_base = (unsigned)(size_t)raw0;
+  auto issue_tile = [&](int t) {
+    const int kt0 = t * 32;
+    const unsigned st = raw_base + (unsigned)((t % NST) * RAW);
 #pragma unroll
-    for (int i = 0; i < TPT; ++i) {
-      const int task = tid + i * NT;
-      const int kp = task / (DP / 4), c4 = (task - kp * (DP / 4)) * 4;
-      const int k0 = min(kt0 + 2 * kp, p.Tk - 1), k1 = min(kt0 + 2 * kp + 1, p.Tk - 1);   // clamped: masked by the bias
-      const bool live = task < TASKS && c4 < d;
-      const int cc = live ? c4 : 0;
-      const size_t o0 = ((size_t)b * p.Tk + k0), o1 = ((size_t)b * p.Tk + k1);
-      rk0[i] = *reinterpret_cast<const float4*>(p.k + o0 * p.ldk + h * d + cc);
-      rk1[i] = *reinterpret_cast<const float4*>(p.k + o1 * p.ldk + h * d + cc);
-      rv0[i] = *reinterpret_cast<const float4*>(p.v + o0 * p.ldv + h * d + cc);
-      rv1[i] = *reinterpret_cast<const float4*>(p.v + o1 * p.ldv + h * d + cc);
+    for (int j = 0; j < KV_INSTR / NW; ++j) {
+      const int ii = wave + j * NW;
+      const int task = ii * 64 + lane;
+      const int which = task / (32 * CPR), rem = task - which * (32 * CPR);
+      const int row = rem / CPR, c4 = (rem - row * CPR) * 4;
+      const int key = min(kt0 + row, p.Tk - 1);                     // clamped: masked by the bias
+      const int cc = c4 < d ? c4 : 0;
+      const float* src = which ? p.v + ((size_t)b * p.Tk + key) * p.ldv + h * d + cc
+                               : p.k + ((size_t)b * p.Tk + key) * p.ldk + h * d + cc;
+      att_glds16(src, st + (unsigned)(ii * 1024));
     }
-    if (tid < 32) {
-      const int key = kt0 + tid;
-      rbias = (key < p.Tk) ? (p.bias ? p.bias[(size_t)b * p.Tk + key] * LOG2E : 0.f) : -1e30f;
+    {   // key bias of the tile (every wave fills its own slot so that all waves issue IPW instructions per tile)
+      const int key = min(kt0 + l31, p.Tk - 1);
+      const void* src = p.bias ? (const void*)(p.bias + (size_t)b * p.Tk + key) : (const void*)p.k;
+      att_glds4(src, st + (unsigned)(2 * RAWK + wave * 256));
     }
   };
-  auto store_tile = [&](int buf) {
+  // conversion of raw tile t -> split bf16 planes buffer `buf`: task = (key pair kp, 4-channel group c4)
+  auto convert_tile = [&](int t, int buf) {
+    const char* rs = raw0 + (t % NST) * RAW;
     char* base = lds + buf * BUF;
     char* k_hi = base;
     char* k_lo = base + K_PL;
@@ -118,7 +163,10 @@ __global__ __launch_bounds__(64 * NW) void k_attention(const AttnParams p) {
       const int task = tid + i * NT;
       if (task >= TASKS) continue;
       const int kp = task / (DP / 4), c4 = (task - kp * (DP / 4)) * 4;
-      float4 a = rk0[i], c = rk1[i], va = rv0[i], vc = rv1[i];
+      float4 a = *reinterpret_cast<const float4*>(rs + ((2 * kp) * DP + c4) * 4);
+      float4 c = *reinterpret_cast<const float4*>(rs + ((2 * kp + 1) * DP + c4) * 4);
+      float4 va = *reinterpret_cast<const float4*>(rs + RAWK + ((2 * kp) * DP + c4) * 4);
+      float4 vc = *reinterpret_cast<const float4*>(rs + RAWK + ((2 * kp + 1) * DP + c4) * 4);
       if (c4 >= d) { a = make_float4(0.f, 0.f, 0.f, 0.f); c = a; va = a; vc = a; }   // zero the padded channels
       // K rows 2kp, 2kp+1: 4 channels -> 8 bytes per plane
       uint2 h0, h1, l0, l1;
@@ -143,16 +191,34 @@ __global__ __launch_bounds__(64 * NW) void k_attention(const AttnParams p) {
         if (SPLIT) *reinterpret_cast<unsigned*>(v_lo + (c4 + e) * VP + slot * 2) = apk(ve0[e] - bf_lo(hw), ve1[e] - bf_hi(hw));
       }
     }
-    if (tid < 32) bl[tid] = rbias;
+    if (tid < 32) {
+      const int key = t * 32 + tid;
+      const float raw = reinterpret_cast<const float*>(rs + 2 * RAWK)[tid];     // wave 0's slot
+      bl[tid] = (key < p.Tk) ? (p.bias ? raw * LOG2E : 0.f) : -1e30f;
+    }
+  };
+  // this wave's DMA of the tiles issued after tile `t` may stay in flight; everything up to `t` has landed
+  auto wait_tile = [&](int t, int last_issued) {
+    const int pending = last_issued - t;
+    if (pending >= 3) att_wait_vmcnt<3 * IPW>();
+    else if (pending == 2) att_wait_vmcnt<2 * IPW>();
+    else if (pending == 1) att_wait_vmcnt<IPW>();
+    else att_wait_vmcnt<0>();
   };
 
   const int ntile = (p.Tk + 31) / 32;
-  load_tile(0);
-  store_tile(0);
+#pragma unroll
+  for (int t = 0; t < NST; ++t)
+    if (t < ntile) issue_tile(t);
+  wait_tile(0, min(ntile, NST) - 1);
   __syncthreads();
+  convert_tile(0, 0);
   for (int t = 0; t < ntile; ++t) {
     const bool more = t + 1 < ntile;
-    if (more) load_tile((t + 1) * 32);
+    if (more) wait_tile(t + 1, min(ntile - 1, t + NST - 1));
+    __syncthreads();          // planes[t&1] written, raw tile t+1 landed for every wave, tile t-1's MFMAs done
+    if (t + NST < ntile) issue_tile(t + NST);          // reuses the stage of raw tile t (converted before this barrier)
+    if (more) convert_tile(t + 1, (t + 1) & 1);
     const char* base = lds + (t & 1) * BUF;
     const char* k_hi = base;
     const char* k_lo = base + K_PL;
@@ -231,8 +297,6 @@ __global__ __launch_bounds__(64 * NW) void k_attention(const AttnParams p) {
         o[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, ph, o[nb], 0, 0, 0);
       }
     }
-    if (more) store_tile((t + 1) & 1);
-    __syncthreads();
   }
 
   const float l_tot = l_run + __shfl_xor(l_run, 32);
@@ -265,8 +329,32 @@ __global__ __launch_bounds__(64 * NW) void k_attention(const AttnParams p) {
 
 template <int DP, int NW>
 static void launch_att(const AttnParams& p, dim3 grid, hipStream_t st) {
-  if (p.nsplit == 3) hipLaunchKernelGGL((k_attention<DP, NW, 3>), grid, dim3(64 * NW), 0, st, p);
-  else hipLaunchKernelGGL((k_attention<DP, NW, 1>), grid, dim3(64 * NW), 0, st, p);
+  using G = AttnGeom<DP, NW>;
+  const int smem3 = G::smem_bytes(2), smem1 = G::smem_bytes(1);
+  if (p.nsplit == 3) hipLaunchKernelGGL((k_attention<DP, NW, 3>), grid, dim3(64 * NW), smem3, st, p);
+  else hipLaunchKernelGGL((k_attention<DP, NW, 1>), grid, dim3(64 * NW), smem1, st, p);
+}
+template <int DP, int NW>
+static hipError_t init_att() {
+  using G = AttnGeom<DP, NW>;
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_attention<DP, NW, 3>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, G::smem_bytes(2));
+  return e != hipSuccess ? e : hipFuncSetAttribute(reinterpret_cast<const void*>(k_attention<DP, NW, 1>),
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, G::smem_bytes(1));
+}
+// > 64 KiB of dynamic LDS needs the attribute; set once, outside any stream capture
+hipError_t attn_init() {
+  static bool done = false;
+  if (done) return hipSuccess;
+  hipError_t e = hipSuccess;
+#define ATT_INIT(DP)                                               \
+  if (e == hipSuccess) e = init_att<DP, 4>();                      \
+  if (e == hipSuccess) e = init_att<DP, 2>();                      \
+  if (e == hipSuccess) e = init_att<DP, 1>();
+  ATT_INIT(16) ATT_INIT(32) ATT_INIT(48) ATT_INIT(64)
+#undef ATT_INIT
+  done = e == hipSuccess;
+  return e;
 }
 
 hipError_t launch_attention(const AttnParams& p, hipStream_t st) {
