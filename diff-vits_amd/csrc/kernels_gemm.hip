@@ -19,96 +19,15 @@
 //               fp32 and/or split bf16 planes; optional per-(32-row block, channel) sum / sum of
 //               squares of the result (GroupNorm statistics for the consumer, no extra pass)
 #include "dv_common.h"
+#include "gemm_tile.h"
 
 #include <cstdio>
 #include <cstdlib>
 #include <type_traits>
 
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
-typedef __attribute__((ext_vector_type(16))) float f32x16;
-
-__device__ __forceinline__ unsigned cvt_pk_bf16(float lo, float hi) {
-  unsigned r;
-  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
-  return r;
-}
-__device__ __forceinline__ float gelu_erf(float v) { return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f)); }
-
-// LDS-DMA of 16 bytes per lane: LDS destination = wave-uniform `lds_dst` + lane*16 (M0 holds the
-// base), global source per lane.  Issued through asm so that hipcc neither counts it nor drains
-// it with vmcnt(0) at the next LDS read: the waits below are counted by hand.
-__device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst) {
-  unsigned keep;
-  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-               : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
-}
-#ifdef DV_GEMM_TRACE
-// development build only (make trace): per-workgroup s_memtime stamps of the kernel's phases
-__device__ unsigned long long g_gemm_trace[8192 * 16];
-#define DV_TRACE(i) do { if (threadIdx.x == 0 && blockIdx.x < 8192) g_gemm_trace[blockIdx.x * 16 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
-extern "C" int dv_debug_gemm_trace(unsigned long long* host, int n_wg) {
-  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_gemm_trace), (size_t)n_wg * 16 * sizeof(unsigned long long));
-}
-extern "C" int dv_debug_gemm_trace_clear() {
-  void* d = nullptr;
-  hipError_t e = hipGetSymbolAddress(&d, HIP_SYMBOL(g_gemm_trace));
-  return (int)(e != hipSuccess ? e : hipMemset(d, 0, sizeof(g_gemm_trace)));
-}
-#else
-#define DV_TRACE(i) do {} while (0)
-#endif
-__device__ __forceinline__ void glds4(const void* gsrc, unsigned lds_dst) {   // 4 bytes per lane
-  unsigned keep;
-  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
-               : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
-}
-template <int N>
-__device__ __forceinline__ void wait_vmcnt() {
-  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
-}
-
-// KS = 2 doubles the waves of a workgroup (two per SIMD): both groups stage every k-tile together and each
-// multiplies half of its 16-deep k-steps, so one wave's MFMAs overlap the other's address math and DMA issue;
-// the two partial accumulators are added through LDS before the epilogue.
 template <int BM, int BN, int BK, int WM, int WN, int NSPLIT, int KS>
 __global__ __launch_bounds__(64 * WM * WN * KS) void k_gemm(const GemmParams p) {
-  constexpr int FM = BM / (WM * 32), FN = BN / (WN * 32);
-  constexpr int NWQ = WM * WN;                       // waves per k-group (1, 2 or 4)
-  constexpr int NWV = NWQ * KS;                      // waves per workgroup
-  constexpr bool SPLIT = NSPLIT == 3;
-  constexpr int NPL = SPLIT ? 2 : 1;                 // planes per operand
-  constexpr int ROWB = BK * 2;                       // LDS row pitch (bytes), unpadded
-  constexpr int CPR = ROWB / 16;                     // 16-byte chunks per row: 4 (BK=32) or 8 (BK=64)
-  constexpr int RPI = 64 / CPR;                      // rows per wave-instruction
-  constexpr int A_PL = BM * ROWB, B_PL = BN * ROWB;  // bytes per plane tile
-  constexpr int STAGE = (A_PL + B_PL) * NPL;
-  constexpr int NSTAGE = (4 * STAGE <= 160 * 1024) ? 4 : 3;   // LDS ring depth: NSTAGE-1 tiles in flight
-  constexpr int A_IPW = BM / RPI / NWV, B_IPW = BN / RPI / NWV;   // DMA instructions per wave per plane
-  constexpr int LPT = (A_IPW + B_IPW) * NPL;         // DMA instructions per thread per k-tile
-  static_assert(BM % (RPI * NWV) == 0 && BN % (RPI * NWV) == 0, "tile rows must split over the waves");
   extern __shared__ __attribute__((aligned(1024))) char smem[];
-
-  DV_TRACE(0);
-#ifdef DV_GEMM_TRACE
-  if (threadIdx.x == 0 && blockIdx.x < 8192) {
-    unsigned xcc, hw;
-    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
-    g_gemm_trace[blockIdx.x * 16 + 6] = ((unsigned long long)xcc << 32) | hw;
-    g_gemm_trace[blockIdx.x * 16 + 7] = wall_clock64();
-  }
-#endif
-  // touch one field of every 64-byte line of the argument block up front: the scalar loads go out together and
-  // miss once in parallel, instead of one dependent miss per line as the prologue reaches each field
-  asm volatile("" ::"s"(p.seg[0].a0_hi), "s"(p.seg[1].a0_hi), "s"(p.seg[1].pad), "s"(p.T_in), "s"(p.w_hi), "s"(p.M),
-               "s"(p.res), "s"(p.out_hi), "s"(p.zero_page), "s"(p.ln_u));
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int kgrp = wave / NWQ, wq = wave % NWQ;
-  const int wm = wq / WN, wn = wq % WN;
-  const unsigned smem_base = (unsigned)(size_t)smem;   // LDS byte address of the ring
-
   // XCD-aware tile order: consecutive tile ids (same A rows, neighbouring N) share an L2.
   const int n_tiles_n = (p.N + BN - 1) / BN;
   const int nwg = gridDim.x;
@@ -117,451 +36,7 @@ __global__ __launch_bounds__(64 * WM * WN * KS) void k_gemm(const GemmParams p) 
     const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
     bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
   }
-  const int m0 = (bid / n_tiles_n) * BM;
-  const int n0 = (bid % n_tiles_n) * BN;
-#ifdef DV_GEMM_TRACE
-  if (m0 + n0 >= 0) DV_TRACE(8);    // first kernel-argument dependent value is available
-#endif
-
-  // ---- per-lane DMA geometry: lane -> (row within the instruction's RPI rows, LDS chunk slot) ----
-  const int l_row = lane / CPR, l_slot = lane % CPR;
-  auto swz = [](int row) { return CPR == 8 ? ((row >> 1) & 7) : ((row >> 2) & 3); };
-
-  int arow_b[A_IPW], arow_t[A_IPW], a_chunk[A_IPW];
-  unsigned arow_ok = 0;
-#pragma unroll
-  for (int q = 0; q < A_IPW; ++q) {
-    const int r = (q * NWV + wave) * RPI + l_row;     // row within the A tile
-    int m = m0 + r;
-    const bool ok = m < p.M;
-    arow_ok |= (ok ? 1u : 0u) << q;
-    m = ok ? m : 0;
-    arow_b[q] = m / p.T_out;
-    arow_t[q] = m - arow_b[q] * p.T_out;
-    a_chunk[q] = l_slot ^ swz(r);                     // source chunk that lands in this lane's slot
-  }
-  size_t b_off[B_IPW];
-#pragma unroll
-  for (int q = 0; q < B_IPW; ++q) {
-    const int r = (q * NWV + wave) * RPI + l_row;
-    b_off[q] = ((size_t)(n0 + r) * p.Kp + (l_slot ^ swz(r)) * 8) * 2;   // byte offset at kt = 0
-  }
-
-  // Source of the k-tile being issued, kept in wave-uniform registers and advanced incrementally: the segment
-  // descriptor (kernel-argument memory) is only re-read when a source tensor / tap is exhausted, never on the
-  // per-tile path (a scalar load there sits on every wave's critical path right after the barrier).
-  const int total_kt = p.seg[0].nkt + (p.nseg > 1 ? p.seg[1].nkt : 0);
-  int ld_seg = 0, ld_tap = 0, ld_half = 0;
-  const bf16_t* cur_hi; const bf16_t* cur_lo;
-  int cur_ld, cur_col, cur_toff;
-  auto enter = [&]() {
-    const GemmSeg& sg = p.seg[ld_seg];
-    cur_hi = ld_half ? sg.a1_hi : sg.a0_hi;
-    cur_lo = ld_half ? sg.a1_lo : sg.a0_lo;
-    cur_ld = ld_half ? sg.c1 : sg.c0;
-    cur_col = 0;
-    cur_toff = ld_tap - sg.pad;
-  };
-  enter();
-  DV_TRACE(9);     // row geometry done
-
-  // One k-tile's DMA = LPT wave-instructions per thread ("units"): A rows (hi, lo plane) then B rows (hi, lo).
-  // prep_a() forms the A source addresses of the tile being issued; issue_unit() sends one unit; advance()
-  // moves the source state to the next k-tile.  The main loop spreads the units between its MFMA groups.
-  const void* asrc[A_IPW * NPL];
-  auto prep_a = [&]() {
-#pragma unroll
-    for (int q = 0; q < A_IPW; ++q) {
-      const int ts = arow_t[q] * p.stride + cur_toff;
-      const bool ok = ((arow_ok >> q) & 1u) && ts >= 0 && ts < p.T_virt;
-      int st = ts;
-      st = p.up_mode == UP_X2 ? (ts >> 1) : st;
-      st = p.up_mode == UP_SIZE ? min((int)floorf((float)ts * p.up_scale), p.T_in - 1) : st;
-      const size_t e = ((size_t)arow_b[q] * p.T_in + st) * cur_ld + cur_col + a_chunk[q] * 8;
-      // conv zero padding / rows >= M read a 16-byte zero page instead
-      asrc[q * NPL] = ok ? (const void*)(cur_hi + e) : (const void*)p.zero_page;
-      if (SPLIT) asrc[q * NPL + 1] = ok ? (const void*)(cur_lo + e) : (const void*)p.zero_page;
-    }
-  };
-  auto issue_unit = [&](int kt, int u) {
-    const unsigned st_base = smem_base + (unsigned)((kt % NSTAGE) * STAGE);
-    if (u < A_IPW * NPL) {
-      const int q = u / NPL, pl = u % NPL;
-      glds16(asrc[u], st_base + (unsigned)(((q * NWV + wave) * RPI) * ROWB + pl * A_PL));
-    } else {
-      const int q = (u - A_IPW * NPL) / NPL, pl = (u - A_IPW * NPL) % NPL;
-      const size_t o = b_off[q] + (size_t)kt * (BK * 2);
-      glds16(reinterpret_cast<const char*>(pl ? p.w_lo : p.w_hi) + o,
-             st_base + (unsigned)(NPL * A_PL + ((q * NWV + wave) * RPI) * ROWB + pl * B_PL));
-    }
-  };
-  auto advance = [&]() {
-    cur_col += BK;
-    if (cur_col == cur_ld) {     // wave-uniform, once per (source tensor, tap)
-      const GemmSeg& sg = p.seg[ld_seg];
-      if (ld_half == 0 && sg.c1 > 0) ld_half = 1;
-      else {
-        ld_half = 0;
-        if (++ld_tap == sg.taps) { ld_tap = 0; ++ld_seg; }
-      }
-      if (ld_seg < p.nseg) enter();
-    }
-  };
-  auto issue = [&](int kt) {     // whole tile at once (prologue)
-    prep_a();
-#pragma unroll
-    for (int u = 0; u < LPT; ++u) issue_unit(kt, u);
-    advance();
-  };
-
-  f32x16 acc[FM][FN];
-#pragma unroll
-  for (int i = 0; i < FM; ++i)
-#pragma unroll
-    for (int j = 0; j < FN; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-  const int l31 = lane & 31, lh = lane >> 5;
-  // One k-tile of work for this wave: all operand fragments are read first, then the MFMAs go out in groups of
-  // FM*FN (one product term of one 16-deep k-step: consecutive MFMAs write different accumulators) and, when
-  // ISSUE, the DMA units of tile kt+NSTAGE-1 are spread between the groups: a wave blocked in the (slow, 64 B/clk
-  // per CU) vector-memory issue then has MFMAs in flight instead of serialising a DMA phase after an MFMA phase.
-  // Weights are the FIRST MFMA operand: the accumulator is the TRANSPOSED tile, lane = output row m,
-  // registers = 16 output columns in runs of 4 -> 16-byte epilogue loads / stores per lane.
-  constexpr int NKS = BK / 16 / KS;                  // 16-deep k-steps per wave per k-tile
-  constexpr int NTERM = SPLIT ? 3 : 1;
-  constexpr int NCH = NKS * NTERM;                   // MFMA groups per k-tile
-  auto step = [&](int kt, auto issue_tag) {
-    constexpr bool ISSUE = decltype(issue_tag)::value;
-    const char* base = smem + (kt % NSTAGE) * STAGE;
-    const char* a_hi = base;
-    const char* a_lo = base + A_PL;
-    const char* b_hi = base + NPL * A_PL;
-    const char* b_lo = b_hi + B_PL;
-    bf16x8 ah[NKS][FM], al[NKS][FM], bh[NKS][FN], bl[NKS][FN];
-#pragma unroll
-    for (int ks0 = 0; ks0 < NKS; ++ks0) {
-      const int chunk = (kgrp * NKS + ks0) * 2 + lh;
-#pragma unroll
-      for (int i = 0; i < FM; ++i) {
-        const int row = (wm * FM + i) * 32 + l31;
-        const int off = row * ROWB + ((chunk ^ swz(row)) << 4);
-        ah[ks0][i] = *reinterpret_cast<const bf16x8*>(a_hi + off);
-        if (SPLIT) al[ks0][i] = *reinterpret_cast<const bf16x8*>(a_lo + off);
-      }
-#pragma unroll
-      for (int j = 0; j < FN; ++j) {
-        const int row = (wn * FN + j) * 32 + l31;
-        const int off = row * ROWB + ((chunk ^ swz(row)) << 4);
-        bh[ks0][j] = *reinterpret_cast<const bf16x8*>(b_hi + off);
-        if (SPLIT) bl[ks0][j] = *reinterpret_cast<const bf16x8*>(b_lo + off);
-      }
-    }
-#pragma unroll
-    for (int c = 0; c < NCH; ++c) {
-      const int ks0 = c / NTERM, term = c % NTERM;
-#pragma unroll
-      for (int i = 0; i < FM; ++i)
-#pragma unroll
-        for (int j = 0; j < FN; ++j) {
-          if (SPLIT && term == 0)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh[ks0][j], al[ks0][i], acc[i][j], 0, 0, 0);
-          else if (SPLIT && term == 1)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bl[ks0][j], ah[ks0][i], acc[i][j], 0, 0, 0);
-          else
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh[ks0][j], ah[ks0][i], acc[i][j], 0, 0, 0);
-        }
-      if (ISSUE) {
-        __builtin_amdgcn_sched_barrier(0);
-        if (c == 0) prep_a();
-#pragma unroll
-        for (int u = c * LPT / NCH; u < (c + 1) * LPT / NCH; ++u) issue_unit(kt + NSTAGE - 1, u);
-        __builtin_amdgcn_sched_barrier(0);
-      }
-    }
-    if (ISSUE) advance();
-  };
-
-  // accumulator fragment (i, j), lane (l31, lh), register r = 4*g + e  holds
-  //   row m = m0 + (wm*FM+i)*32 + l31,  column n = n0 + (wn*FN+j)*32 + 8*g + 4*lh + e
-  // vector (16-byte) epilogue accesses need every row pitch and N to be a multiple of 4
-  const bool vec4 = ((p.N | p.ldo | (p.epi == EPI_RESIDUAL ? p.ldres : 0)) & 3) == 0;
-  auto load4 = [&](const float* base, size_t row_off, int nb, float* dst) {   // dst[0..3] = base[row_off + nb + e]
-    if (vec4) {
-      const float4 v = nb < p.N ? *reinterpret_cast<const float4*>(base + row_off + nb) : make_float4(0.f, 0.f, 0.f, 0.f);
-      dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w;
-    } else {
-#pragma unroll
-      for (int e = 0; e < 4; ++e) dst[e] = nb + e < p.N ? base[row_off + nb + e] : 0.f;
-    }
-  };
-
-  // residual operand of small tiles: fetched before the k-loop so its latency hides under it
-  constexpr bool PRE_RES = FM * FN <= 2;
-  float rpre[PRE_RES ? FM * FN * 16 : 1];
-  if (PRE_RES && p.epi == EPI_RESIDUAL) {
-#pragma unroll
-    for (int i = 0; i < FM; ++i) {
-      const size_t ro = (size_t)min(m0 + (wm * FM + i) * 32 + l31, p.M - 1) * p.ldres;
-#pragma unroll
-      for (int j = 0; j < FN; ++j)
-#pragma unroll
-        for (int g = 0; g < 4; ++g)
-          load4(p.res, ro, n0 + (wn * FN + j) * 32 + 8 * g + 4 * lh, &rpre[(j * FM + i) * 16 + 4 * g]);
-    }
-  }
-
-  // fused LayerNorm (consumer side): per-row mean / rstd of this tile's rows from the producer's partials
-  __shared__ float2 s_ln[BM];
-  if (p.ln_stat) {
-    for (int r = tid; r < BM; r += 64 * NWV) {
-      const int m = min(m0 + r, p.M - 1);
-      const float2* src = reinterpret_cast<const float2*>(p.ln_stat) + (size_t)m * p.ln_nblk;
-      float s1 = 0.f, s2 = 0.f;
-      for (int k = 0; k < p.ln_nblk; ++k) { const float2 v = src[k]; s1 += v.x; s2 += v.y; }
-      const float inv_c = 1.0f / (float)(p.ln_nblk * 32);
-      const float mean = s1 * inv_c;
-      const float var = fmaxf(s2 * inv_c - mean * mean, 0.f);
-      s_ln[r] = make_float2(mean, 1.0f / sqrtf(var + p.ln_eps));
-    }
-    __syncthreads();
-  }
-
-  // bias of this tile's columns -> LDS by DMA, oldest in the queue: landed before the first tile's wait returns
-  __shared__ __attribute__((aligned(16))) float s_bias[BN < 64 ? 64 : BN];
-  if (wave < (BN + 63) / 64) {
-    const int n = min(n0 + wave * 64 + lane, p.N - 1);
-    glds4(p.bias ? (const void*)(p.bias + n) : (const void*)p.zero_page, (unsigned)(size_t)s_bias + wave * 256);
-  }
-
-  // ---- main loop: wait(tile kt) -> barrier -> multiply tile kt with the DMA of tile kt+NSTAGE-1 interleaved ----
-  // NSTAGE-1 tiles are in flight; the counted vmcnt leaves the younger ones outstanding across the barrier
-  DV_TRACE(10);    // residual prefetch / LayerNorm rows / bias DMA issued
-#pragma unroll
-  for (int t = 0; t < NSTAGE - 1; ++t) {
-    if (t < total_kt) issue(t);
-#ifdef DV_GEMM_TRACE
-    if (t == 0) DV_TRACE(11);
-#endif
-  }
-  DV_TRACE(1);
-  // steady state: tile kt+NSTAGE-1 is issued while tile kt is multiplied; NSTAGE-2 younger tiles stay in flight
-  const int n_steady = total_kt - (NSTAGE - 1);
-  int kt = 0;
-  for (; kt < n_steady; ++kt) {
-    wait_vmcnt<(NSTAGE - 2) * LPT>();
-    __builtin_amdgcn_s_barrier();                    // tile kt visible; every wave is done with tile kt-1
-#ifdef DV_GEMM_TRACE
-    if (kt == 0) DV_TRACE(2);
-#endif
-    step(kt, std::true_type{});                      // DMA overwrites the stage tile kt-1 was read from
-  }
-  for (; kt < total_kt; ++kt) {                      // drain: nothing left to issue
-    const int younger = min(NSTAGE - 2, total_kt - 1 - kt);
-    if (younger >= 2) wait_vmcnt<2 * LPT>();
-    else if (younger == 1) wait_vmcnt<LPT>();
-    else wait_vmcnt<0>();
-    __builtin_amdgcn_s_barrier();
-#ifdef DV_GEMM_TRACE
-    if (kt == 0) DV_TRACE(2);
-#endif
-    step(kt, std::false_type{});
-  }
-
-  DV_TRACE(3);
-  if (KS == 2) {   // add the two k-groups' partial accumulators through LDS (lane-linear, conflict-free)
-    __builtin_amdgcn_s_barrier();                    // every wave is done reading the ring
-    float* red = reinterpret_cast<float*>(smem);
-    if (kgrp == 1) {
-#pragma unroll
-      for (int i = 0; i < FM; ++i)
-#pragma unroll
-        for (int j = 0; j < FN; ++j)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) red[((i * FN + j) * 16 + r) * (64 * NWQ) + wq * 64 + lane] = acc[i][j][r];
-    }
-    __syncthreads();
-    if (kgrp == 1) return;
-#pragma unroll
-    for (int i = 0; i < FM; ++i)
-#pragma unroll
-      for (int j = 0; j < FN; ++j)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[i][j][r] += red[((i * FN + j) * 16 + r) * (64 * NWQ) + wq * 64 + lane];
-  }
-
-  // ---- epilogue ----
-  DV_TRACE(4);
-  // store 4 consecutive columns of one row: fp32 and/or split bf16 planes
-  auto store4 = [&](size_t o, int nb, const float* v) {
-    if (vec4) {
-      if (nb >= p.N) return;
-      if (p.out) *reinterpret_cast<float4*>(p.out + o) = make_float4(v[0], v[1], v[2], v[3]);
-      if (p.out_hi) {
-        const unsigned h01 = cvt_pk_bf16(v[0], v[1]), h23 = cvt_pk_bf16(v[2], v[3]);
-        *reinterpret_cast<uint2*>(p.out_hi + o) = make_uint2(h01, h23);
-        if (p.out_lo) {
-          const unsigned l01 = cvt_pk_bf16(v[0] - __uint_as_float(h01 << 16), v[1] - __uint_as_float(h01 & 0xffff0000u));
-          const unsigned l23 = cvt_pk_bf16(v[2] - __uint_as_float(h23 << 16), v[3] - __uint_as_float(h23 & 0xffff0000u));
-          *reinterpret_cast<uint2*>(p.out_lo + o) = make_uint2(l01, l23);
-        }
-      }
-    } else {
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        if (nb + e >= p.N) continue;
-        if (p.out) p.out[o + e] = v[e];
-        if (p.out_hi) {
-          const unsigned hb = cvt_pk_bf16(v[e], 0.f);
-          p.out_hi[o + e] = (bf16_t)(hb & 0xffffu);
-          if (p.out_lo) p.out_lo[o + e] = (bf16_t)(cvt_pk_bf16(v[e] - __uint_as_float(hb << 16), 0.f) & 0xffffu);
-        }
-      }
-    }
-  };
-
-  if (p.epi == EPI_GEGLU) {
-    // packed column order: per 64-column block, [32 x a | 32 x gate]  (needs FN == 2 per wave)
-    if constexpr (FN == 2) {
-      const int blk = (n0 + wn * 64) >> 6;          // 64-column block index
-      const int nca = n0 + wn * 64 + 4 * lh;        // packed column of `a` for g = 0, e = 0
-      float ba[16], bg[16], ua[16], ug[16];
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int nb = nca + 8 * g;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const bool ok = nb + e < p.N;
-          ba[4 * g + e] = s_bias[wn * 64 + 8 * g + 4 * lh + e];
-          bg[4 * g + e] = s_bias[wn * 64 + 32 + 8 * g + 4 * lh + e];
-          ua[4 * g + e] = (p.ln_stat && ok) ? p.ln_u[nb + e] : 0.f;
-          ug[4 * g + e] = (p.ln_stat && ok) ? p.ln_u[nb + e + 32] : 0.f;
-        }
-      }
-#pragma unroll
-      for (int i = 0; i < FM; ++i) {
-        const int rl = (wm * FM + i) * 32 + l31;
-        const int m = m0 + rl;
-        if (m >= p.M) continue;
-        const float2 st = p.ln_stat ? s_ln[rl] : make_float2(0.f, 1.f);
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          float v[4];
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const int r = 4 * g + e;
-            float a = acc[i][0][r], gt = acc[i][1][r];
-            if (p.ln_stat) {
-              a = st.y * (a - st.x * ua[r]);
-              gt = st.y * (gt - st.x * ug[r]);
-            }
-            v[e] = (a + ba[r]) * gelu_erf(gt + bg[r]);
-          }
-          // output column of packed `a` column nb: 32 per 64-column block; nb < N  <=>  oc-run inside N/2
-          store4((size_t)m * p.ldo + blk * 32 + 8 * g + 4 * lh, nca + 8 * g, v);
-        }
-      }
-    }
-    DV_TRACE(5);
-    return;
-  }
-#pragma unroll
-  for (int j = 0; j < FN; ++j) {
-    const int nf = n0 + (wn * FN + j) * 32 + 4 * lh;   // column of g = 0, e = 0
-    float bv[16], un[16];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int n = nf + 8 * (r >> 2) + (r & 3);
-      bv[r] = s_bias[(wn * FN + j) * 32 + 4 * lh + 8 * (r >> 2) + (r & 3)];
-      un[r] = (p.ln_stat && n < p.N) ? p.ln_u[n] : 0.f;
-    }
-#pragma unroll
-    for (int i = 0; i < FM; ++i) {
-      const int mrow0 = m0 + (wm * FM + i) * 32;
-      const int rl = (wm * FM + i) * 32 + l31;
-      const int m = m0 + rl;
-      const bool m_ok = m < p.M;
-      const int mc = m_ok ? m : p.M - 1;
-      // residual operand: 4 x 16-byte loads issued back to back (clamped row), one wait
-      float rv[16];
-      if (p.epi == EPI_RESIDUAL) {
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          if (PRE_RES) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) rv[4 * g + e] = rpre[(j * FM + i) * 16 + 4 * g + e];
-          } else {
-            load4(p.res, (size_t)mc * p.ldres, nf + 8 * g, &rv[4 * g]);
-          }
-        }
-      }
-      const float2 st = p.ln_stat ? s_ln[rl] : make_float2(0.f, 1.f);
-      const float rmask = p.rowmask ? p.rowmask[mc] : 1.0f;
-      float vv[16];
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int n = nf + 8 * (r >> 2) + (r & 3);
-        float v = acc[i][j][r];
-        if (p.ln_stat) v = st.y * (v - st.x * un[r]);
-        v += bv[r];
-        if (p.epi == EPI_RESIDUAL) v += rv[r];
-        if (p.relu) v = fmaxf(v, 0.f);
-        v *= rmask;
-        vv[r] = (m_ok && n < p.N) ? v : 0.f;
-      }
-      if (p.epi == EPI_STORE_NCT) {
-        // [B, N, T_out]: the 32 lanes of a half-wave write 32 consecutive frames of one channel
-        if (m_ok) {
-          const int b = m / p.T_out, t = m - b * p.T_out;
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int n = nf + 8 * (r >> 2) + (r & 3);
-            if (n < p.N) p.out[((size_t)b * p.N + n) * p.T_out + t] = vv[r];
-          }
-        }
-      } else if (m_ok) {
-#pragma unroll
-        for (int g = 0; g < 4; ++g) store4((size_t)m * p.ldo + nf + 8 * g, nf + 8 * g, &vv[4 * g]);
-      }
-      if (p.rowstat_out) {   // row partials over this fragment's 32 columns (LayerNorm of the consumer)
-        const int nblk_total = (p.N + 31) >> 5;
-        const int cb = (n0 + (wn * FN + j) * 32) >> 5;
-        float a = 0.f, q = 0.f;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) { a += vv[r]; q += vv[r] * vv[r]; }
-        a += __shfl_xor(a, 32);
-        q += __shfl_xor(q, 32);
-        if (lh == 0 && m_ok && cb < nblk_total)
-          reinterpret_cast<float2*>(p.rowstat_out)[(size_t)m * nblk_total + cb] = make_float2(a, q);
-      }
-      if (p.stats) {
-        // column sums over this 32-row block: 16 values per lane summed across the 32 lanes of each half by a
-        // halving butterfly (8 + 4 + 2 + 1 exchanges, then one add with the neighbour lane)
-        float s1[16], s2[16];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) { s1[r] = vv[r]; s2[r] = vv[r] * vv[r]; }
-#pragma unroll
-        for (int w = 8; w >= 1; w >>= 1) {
-          const bool up = (l31 & (2 * w)) != 0;      // lane keeps the upper half of its 2w values
-#pragma unroll
-          for (int k = 0; k < w; ++k) {
-            const float k1 = up ? s1[k + w] : s1[k], x1 = up ? s1[k] : s1[k + w];
-            const float k2 = up ? s2[k + w] : s2[k], x2 = up ? s2[k] : s2[k + w];
-            s1[k] = k1 + __shfl_xor(x1, 2 * w);
-            s2[k] = k2 + __shfl_xor(x2, 2 * w);
-          }
-        }
-        s1[0] += __shfl_xor(s1[0], 1);
-        s2[0] += __shfl_xor(s2[0], 1);
-        const int r = (l31 >> 1) & 15;               // bit 4 -> r bit 3, ... bit 1 -> r bit 0
-        const int n = nf + 8 * (r >> 2) + (r & 3);
-        if ((l31 & 1) == 0 && n < p.N && mrow0 < p.M)
-          reinterpret_cast<float2*>(p.stats)[(size_t)(mrow0 >> 5) * p.N + n] = make_float2(s1[0], s2[0]);
-      }
-    }
-  }
-  DV_TRACE(5);
+  gemm_tile<BM, BN, BK, WM, WN, NSPLIT, KS, false>(p, (bid / n_tiles_n) * BM, (bid % n_tiles_n) * BN, smem);
 }
 
 template <int BM, int BN, int BK, int WM, int WN, int NSPLIT, int KS>
