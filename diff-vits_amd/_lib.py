@@ -52,6 +52,8 @@ SIGNATURES = {
     "dv_penc_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_double)]),
     "dv_unet_time_family": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int32, C.c_void_p, C.POINTER(C.c_float),
                                       C.POINTER(C.c_int32)]),
+    "dv_unet_persist_ticks": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.c_void_p, C.c_int32]),
+    "dv_unet_persist_status": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "dv_unet_probe": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.c_int64, C.POINTER(C.c_int64)]),
     "dv_sampler_plan": (C.c_int, [C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                   C.POINTER(C.c_void_p)]),

@@ -1,0 +1,303 @@
+// Flash-attention tile routine shared by the per-launch kernel (kernels_attn.hip) and the persistent per-XCD schedule
+// (persist.hip).  See kernels_attn.hip for the design notes.
+#pragma once
+#include "dv_common.h"
+#include "dv_device.h"
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ unsigned apk(float lo, float hi) {
+  unsigned r;
+  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+  return r;
+}
+__device__ __forceinline__ float bf_lo(unsigned w) { return __uint_as_float(w << 16); }
+__device__ __forceinline__ float bf_hi(unsigned w) { return __uint_as_float(w & 0xffff0000u); }
+
+template <int DP, int NW>
+struct AttnGeom {
+  static constexpr int KP = DP * 2 + 16, VP = 80, NB = (DP + 31) / 32;
+  static constexpr int K_PL = 32 * KP, V_PL = NB * 32 * VP;
+  static constexpr int NST = 4;                                  // raw tiles in flight
+  static constexpr int RAWK = 32 * DP * 4;                       // raw fp32 K (or V) tile bytes
+  static constexpr int KV_INSTR = 2 * 32 * (DP / 4) / 64;         // DMA wave-instructions per tile for K and V (= DP / 4)
+  static constexpr int KPW = (KV_INSTR + NW - 1) / NW;           // per wave (surplus slots land in a dummy area)
+  static constexpr int DUMMY = KPW * NW > KV_INSTR ? 1024 : 0;
+  static constexpr int RAW = (2 * RAWK + NW * 256 + DUMMY + 1023) / 1024 * 1024;   // + one 64-float bias slot per wave
+  static constexpr int buf_bytes(int npl) { return (K_PL + V_PL) * npl + 128; }
+  static constexpr int planes_bytes(int npl) { return (2 * buf_bytes(npl) + 1023) / 1024 * 1024; }
+  static constexpr int smem_bytes(int npl) { return planes_bytes(npl) + NST * RAW; }
+};
+
+// One (query block of 32*NW queries, head h, batch item b).  SC1: loads of q / k / v / bias bypass this CU's L1 (they
+// were written earlier in the SAME launch by other CUs: persist.hip).
+template <int DP, int NW, int NSPLIT, bool SC1>
+__device__ __forceinline__ void attn_tile(const AttnParams& p, const int qblk, const int h, const int b, char* lds) {
+  constexpr bool SPLIT = NSPLIT == 3;
+  constexpr int NPL = SPLIT ? 2 : 1;
+  constexpr int KS = DP / 16;                      // k-steps of K Q^T
+  constexpr int NB = (DP + 31) / 32;               // 32-wide output-channel blocks
+  constexpr int KP = DP * 2 + 16;                  // K row pitch (bytes): odd number of 16-byte slots
+  constexpr int VP = 80;                           // V^T row pitch: 32 keys * 2 B + 16
+  constexpr int K_PL = 32 * KP, V_PL = NB * 32 * VP;
+  constexpr int BUF = (K_PL + V_PL) * NPL + 128;   // + 32 floats of key bias
+  constexpr int NT = 64 * NW;
+  constexpr int TASKS = 4 * DP;                    // (key pair, 4-channel group) conversion tasks per tile
+  constexpr int TPT = (TASKS + NT - 1) / NT;
+  using G = AttnGeom<DP, NW>;
+  constexpr int NST = G::NST, RAWK = G::RAWK, RAW = G::RAW;
+  constexpr int CPR = DP / 4;                      // 16-byte chunks per raw row
+  constexpr int KV_INSTR = G::KV_INSTR, KPW = G::KPW;
+  constexpr int IPW = KPW + 1;                     // DMA instructions per wave per tile, + its bias slot
+  char* const raw0 = lds + G::planes_bytes(NPL);
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, lh = lane >> 5;
+  const int d = p.d;
+  const int qi = qblk * (32 * NW) + wave * 32 + l31;
+  const bool q_ok = qi < p.Tq;
+
+  // scores are kept in the log2 domain (q pre-scaled by d^-1/2 * log2 e, key bias by log2 e): the softmax
+  // exponentials are bare v_exp_f32
+  constexpr float LOG2E = 1.44269504088896340736f;
+  const float qscale = p.scale * LOG2E;
+  // ---- Q fragments (B operand of K Q^T): lane (query, lh) holds channels ks*16 + lh*8 .. +8 ----
+  bf16x8 qh[KS], ql[KS];
+  {
+    const float* qp = p.q + ((size_t)b * p.Tq + (q_ok ? qi : 0)) * p.ldq + h * d;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const int c = ks * 16 + lh * 8;
+      float4 a = make_float4(0.f, 0.f, 0.f, 0.f), c2 = a;
+      if (q_ok && c < d) a = ld_mut4<SC1>(qp + c);
+      if (q_ok && c + 4 < d) c2 = ld_mut4<SC1>(qp + c + 4);
+      a.x *= qscale; a.y *= qscale; a.z *= qscale; a.w *= qscale;
+      c2.x *= qscale; c2.y *= qscale; c2.z *= qscale; c2.w *= qscale;
+      u32x4 hw, lw;
+      hw.x = apk(a.x, a.y); hw.y = apk(a.z, a.w); hw.z = apk(c2.x, c2.y); hw.w = apk(c2.z, c2.w);
+      lw.x = apk(a.x - bf_lo(hw.x), a.y - bf_hi(hw.x)); lw.y = apk(a.z - bf_lo(hw.y), a.w - bf_hi(hw.y));
+      lw.z = apk(c2.x - bf_lo(hw.z), c2.y - bf_hi(hw.z)); lw.w = apk(c2.z - bf_lo(hw.w), c2.w - bf_hi(hw.w));
+      qh[ks] = __builtin_bit_cast(bf16x8, hw);
+      ql[ks] = __builtin_bit_cast(bf16x8, lw);
+    }
+  }
+
+  f32x16 o[NB];
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[nb][r] = 0.f;
+  float m_run = -1e30f, l_run = 0.f;
+
+  // ---- K / V tile staging ----
+  // DMA: instruction ii of a tile moves raw chunks [64 ii, 64 ii + 64) of the tile image [K: 32 x DP | V: 32 x DP]
+  // (row-major fp32, 16-byte chunks; chunks past d read a valid dummy and are zeroed at conversion)
+  const unsigned raw_base = (unsigned)(size_t)raw0;
+  auto issue_tile = [&](int t) {
+    const int kt0 = t * 32;
+    const unsigned st = raw_base + (unsigned)((t % NST) * RAW);
+#pragma unroll
+    for (int j = 0; j < KPW; ++j) {
+      const int ii = wave + j * NW;
+      if (ii >= KV_INSTR) {      // surplus slot of this wave: keeps every wave at KPW instructions per tile
+        if (SC1) glds16_sc1(p.k, st + (unsigned)(2 * RAWK + NW * 256));
+        else glds16(p.k, st + (unsigned)(2 * RAWK + NW * 256));
+        continue;
+      }
+      const int task = ii * 64 + lane;
+      const int which = task / (32 * CPR), rem = task - which * (32 * CPR);
+      const int row = rem / CPR, c4 = (rem - row * CPR) * 4;
+      const int key = min(kt0 + row, p.Tk - 1);                     // clamped: masked by the bias
+      const int cc = c4 < d ? c4 : 0;
+      const float* src = which ? p.v + ((size_t)b * p.Tk + key) * p.ldv + h * d + cc
+                               : p.k + ((size_t)b * p.Tk + key) * p.ldk + h * d + cc;
+      if (SC1) glds16_sc1(src, st + (unsigned)(ii * 1024));
+      else glds16(src, st + (unsigned)(ii * 1024));
+    }
+    {   // key bias of the tile (every wave fills its own slot so that all waves issue IPW instructions per tile)
+      const int key = min(kt0 + l31, p.Tk - 1);
+      const void* src = p.bias ? (const void*)(p.bias + (size_t)b * p.Tk + key) : (const void*)p.k;
+      if (SC1) glds4_sc1(src, st + (unsigned)(2 * RAWK + wave * 256));
+      else glds4(src, st + (unsigned)(2 * RAWK + wave * 256));
+    }
+  };
+  // conversion of raw tile t -> split bf16 planes buffer `buf`: task = (key pair kp, 4-channel group c4)
+  auto convert_tile = [&](int t, int buf) {
+    const char* rs = raw0 + (t % NST) * RAW;
+    char* base = lds + buf * BUF;
+    char* k_hi = base;
+    char* k_lo = base + K_PL;
+    char* v_hi = base + NPL * K_PL;
+    char* v_lo = v_hi + V_PL;
+    float* bl = reinterpret_cast<float*>(base + (K_PL + V_PL) * NPL);
+#pragma unroll
+    for (int i = 0; i < TPT; ++i) {
+      const int task = tid + i * NT;
+      if (task >= TASKS) continue;
+      const int kp = task / (DP / 4), c4 = (task - kp * (DP / 4)) * 4;
+      float4 a = *reinterpret_cast<const float4*>(rs + ((2 * kp) * DP + c4) * 4);
+      float4 c = *reinterpret_cast<const float4*>(rs + ((2 * kp + 1) * DP + c4) * 4);
+      float4 va = *reinterpret_cast<const float4*>(rs + RAWK + ((2 * kp) * DP + c4) * 4);
+      float4 vc = *reinterpret_cast<const float4*>(rs + RAWK + ((2 * kp + 1) * DP + c4) * 4);
+      if (c4 >= d) { a = make_float4(0.f, 0.f, 0.f, 0.f); c = a; va = a; vc = a; }   // zero the padded channels
+      // K rows 2kp, 2kp+1: 4 channels -> 8 bytes per plane
+      uint2 h0, h1, l0, l1;
+      h0.x = apk(a.x, a.y); h0.y = apk(a.z, a.w);
+      h1.x = apk(c.x, c.y); h1.y = apk(c.z, c.w);
+      *reinterpret_cast<uint2*>(k_hi + (2 * kp) * KP + c4 * 2) = h0;
+      *reinterpret_cast<uint2*>(k_hi + (2 * kp + 1) * KP + c4 * 2) = h1;
+      if (SPLIT) {
+        l0.x = apk(a.x - bf_lo(h0.x), a.y - bf_hi(h0.x)); l0.y = apk(a.z - bf_lo(h0.y), a.w - bf_hi(h0.y));
+        l1.x = apk(c.x - bf_lo(h1.x), c.y - bf_hi(h1.x)); l1.y = apk(c.z - bf_lo(h1.y), c.w - bf_hi(h1.y));
+        *reinterpret_cast<uint2*>(k_lo + (2 * kp) * KP + c4 * 2) = l0;
+        *reinterpret_cast<uint2*>(k_lo + (2 * kp + 1) * KP + c4 * 2) = l1;
+      }
+      // V^T: channel rows, key slot = key index with bits 2 and 3 swapped; keys 2kp, 2kp+1 are adjacent slots
+      const int j = 2 * kp;
+      const int slot = (j & 0x13) | ((j & 4) << 1) | ((j & 8) >> 1);
+      const float ve0[4] = {va.x, va.y, va.z, va.w}, ve1[4] = {vc.x, vc.y, vc.z, vc.w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const unsigned hw = apk(ve0[e], ve1[e]);
+        *reinterpret_cast<unsigned*>(v_hi + (c4 + e) * VP + slot * 2) = hw;
+        if (SPLIT) *reinterpret_cast<unsigned*>(v_lo + (c4 + e) * VP + slot * 2) = apk(ve0[e] - bf_lo(hw), ve1[e] - bf_hi(hw));
+      }
+    }
+    if (tid < 32) {
+      const int key = t * 32 + tid;
+      const float raw = reinterpret_cast<const float*>(rs + 2 * RAWK)[tid];     // wave 0's slot
+      bl[tid] = (key < p.Tk) ? (p.bias ? raw * LOG2E : 0.f) : -1e30f;
+    }
+  };
+  // this wave's DMA of the tiles issued after tile `t` may stay in flight; everything up to `t` has landed
+  auto wait_tile = [&](int t, int last_issued) {
+    const int pending = last_issued - t;
+    if (pending >= 3) wait_vmcnt<3 * IPW>();
+    else if (pending == 2) wait_vmcnt<2 * IPW>();
+    else if (pending == 1) wait_vmcnt<IPW>();
+    else wait_vmcnt<0>();
+  };
+
+  const int ntile = (p.Tk + 31) / 32;
+#pragma unroll
+  for (int t = 0; t < NST; ++t)
+    if (t < ntile) issue_tile(t);
+  wait_tile(0, min(ntile, NST) - 1);
+  __syncthreads();
+  convert_tile(0, 0);
+  for (int t = 0; t < ntile; ++t) {
+    const bool more = t + 1 < ntile;
+    if (more) wait_tile(t + 1, min(ntile - 1, t + NST - 1));
+    __syncthreads();          // planes[t&1] written, raw tile t+1 landed for every wave, tile t-1's MFMAs done
+    if (t + NST < ntile) issue_tile(t + NST);          // reuses the stage of raw tile t (converted before this barrier)
+    if (more) convert_tile(t + 1, (t + 1) & 1);
+    const char* base = lds + (t & 1) * BUF;
+    const char* k_hi = base;
+    const char* k_lo = base + K_PL;
+    const char* v_hi = base + NPL * K_PL;
+    const char* v_lo = v_hi + V_PL;
+    const float* bl = reinterpret_cast<const float*>(base + (K_PL + V_PL) * NPL);
+
+    // ---- S^T = K Q^T ----
+    f32x16 s;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s[r] = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const int off = l31 * KP + (ks * 2 + lh) * 16;
+      const bf16x8 kh = *reinterpret_cast<const bf16x8*>(k_hi + off);
+      if (SPLIT) {
+        const bf16x8 kl = *reinterpret_cast<const bf16x8*>(k_lo + off);
+        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kl, qh[ks], s, 0, 0, 0);
+        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh, ql[ks], s, 0, 0, 0);
+      }
+      s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh, qh[ks], s, 0, 0, 0);
+    }
+    // ---- online softmax (lane = query; registers = keys) ----
+    // the key bias (attention mask / keys past Tk) is only added where there is one: wave-uniform branch
+    if (p.bias != nullptr || (!more && (p.Tk & 31) != 0)) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const float4 bv = *reinterpret_cast<const float4*>(bl + 8 * g + 4 * lh);
+        s[4 * g] += bv.x; s[4 * g + 1] += bv.y; s[4 * g + 2] += bv.z; s[4 * g + 3] += bv.w;
+      }
+    }
+    float tmax = s[0];
+#pragma unroll
+    for (int r = 1; r < 16; ++r) tmax = fmaxf(tmax, s[r]);
+    tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
+    const float m_new = fmaxf(m_run, tmax);
+    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+    m_run = m_new;
+    float psum = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      s[r] = __builtin_amdgcn_exp2f(s[r] - m_new);
+      psum += s[r];
+    }
+    l_run = l_run * alpha + psum;
+    if (__any(alpha != 1.0f)) {        // the running maximum moved for some query of this wave
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[nb][r] *= alpha;
+    }
+    // ---- O^T += V^T P^T: P^T operand of k-block kb = this lane's score registers 8kb..8kb+7 ----
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+      u32x4 hw, lw;
+      hw.x = apk(s[kb * 8 + 0], s[kb * 8 + 1]); hw.y = apk(s[kb * 8 + 2], s[kb * 8 + 3]);
+      hw.z = apk(s[kb * 8 + 4], s[kb * 8 + 5]); hw.w = apk(s[kb * 8 + 6], s[kb * 8 + 7]);
+      const bf16x8 ph = __builtin_bit_cast(bf16x8, hw);
+      bf16x8 pl;
+      if (SPLIT) {
+        lw.x = apk(s[kb * 8 + 0] - bf_lo(hw.x), s[kb * 8 + 1] - bf_hi(hw.x));
+        lw.y = apk(s[kb * 8 + 2] - bf_lo(hw.y), s[kb * 8 + 3] - bf_hi(hw.y));
+        lw.z = apk(s[kb * 8 + 4] - bf_lo(hw.z), s[kb * 8 + 5] - bf_hi(hw.z));
+        lw.w = apk(s[kb * 8 + 6] - bf_lo(hw.w), s[kb * 8 + 7] - bf_hi(hw.w));
+        pl = __builtin_bit_cast(bf16x8, lw);
+      }
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) {
+        const int off = (nb * 32 + l31) * VP + (kb * 2 + lh) * 16;
+        const bf16x8 vh = *reinterpret_cast<const bf16x8*>(v_hi + off);
+        if (SPLIT) {
+          const bf16x8 vl = *reinterpret_cast<const bf16x8*>(v_lo + off);
+          o[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vl, ph, o[nb], 0, 0, 0);
+          o[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, pl, o[nb], 0, 0, 0);
+        }
+        o[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, ph, o[nb], 0, 0, 0);
+      }
+    }
+  }
+
+  const float l_tot = l_run + __shfl_xor(l_run, 32);
+  const float inv = 1.0f / l_tot;
+  if (q_ok) {
+    const size_t obase = ((size_t)b * p.Tq + qi) * p.ldo + h * d;
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int dv = nb * 32 + 8 * g + 4 * lh;
+        if (dv < d) {
+          const float4 v = make_float4(o[nb][4 * g] * inv, o[nb][4 * g + 1] * inv, o[nb][4 * g + 2] * inv,
+                                       o[nb][4 * g + 3] * inv);
+          if (p.o) *reinterpret_cast<float4*>(p.o + obase + dv) = v;
+          if (p.o_hi) {   // split bf16 planes for the to_out GEMM: hi = rne(v), lo = rne(v - hi)
+            uint2 hh, ll;
+            hh.x = apk(v.x, v.y); hh.y = apk(v.z, v.w);
+            *reinterpret_cast<uint2*>(p.o_hi + obase + dv) = hh;
+            if (p.o_lo) {
+              ll.x = apk(v.x - bf_lo(hh.x), v.y - bf_hi(hh.x));
+              ll.y = apk(v.z - bf_lo(hh.y), v.w - bf_hi(hh.y));
+              *reinterpret_cast<uint2*>(p.o_lo + obase + dv) = ll;
+            }
+          }
+        }
+      }
+  }
+}
+

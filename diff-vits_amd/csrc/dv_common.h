@@ -69,6 +69,18 @@ struct AttnParams {
   int nsplit;                   // 3: split-bf16 (hi*hi + lo*hi + hi*lo), 1: single bf16 product
 };
 
+// ---------------------------------------------------------------------------------------
+// Persistent per-XCD schedule (persist.hip): operation table in device memory, executed by one launch.
+// ---------------------------------------------------------------------------------------
+enum { POP_GEMM = 0, POP_ATTN = 1, POP_GN = 2, POP_SPLIT = 3 };
+struct PersistSync {
+  unsigned arrive[8][32];       // per-XCD arrival counter (one cache line each)
+  unsigned rank[8][32];         // per-XCD workgroup numbering
+  unsigned error;               // 1: barrier timed out, 2: unbalanced dispatch
+  unsigned pad_;
+  unsigned long long ticks[1024];   // s_memtime of XCD 0 / workgroup 0 after each operation (profiling aid)
+};
+
 // launchers (each enqueues on `st` and returns hipGetLastError())
 hipError_t launch_gemm(const GemmParams& p, int precision, hipStream_t st);
 hipError_t gemm_init();   // one-time kernel attribute setup (call outside stream capture)
@@ -96,6 +108,19 @@ struct GnApplyParams {
   int B, T;
 };
 hipError_t launch_gn_apply(const GnApplyParams& p, hipStream_t st);
+
+struct PersistOp {
+  int type;                     // POP_*
+  int cfg;                      // GEMM: tile configuration 0..2 (persist.hip); attention: padded head dim 16/32/48/64
+  int gn_rpb, gn_chunks;        // GroupNorm apply: frames per task, tasks per (item, group)
+  int64_t n4_per_item;          // split: float4 elements per batch item
+  const float* sp_in; bf16_t* sp_hi; bf16_t* sp_lo;
+  GemmParams g;
+  AttnParams a;
+  GnApplyParams gn;
+};
+hipError_t persist_init();      // attribute / co-residency check (call outside stream capture)
+hipError_t launch_persist(const PersistOp* ops_dev, int n_ops, PersistSync* sync, int B, hipStream_t st);
 // LayerNorm rows (no affine: gamma/beta are folded into the consumer's weights) -> split planes
 hipError_t launch_ln_apply(const float* x, bf16_t* hi, bf16_t* lo, int M, int C, float eps, hipStream_t st);
 // LayerNorm rows WITH affine (+ optional per-row mask) -> fp32 [M, C] and/or split planes [M, C]

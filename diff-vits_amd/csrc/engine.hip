@@ -49,8 +49,30 @@ struct Arena {
   std::map<size_t, size_t> live_;   // off -> size
   size_t top = 0, high = 0;
   bool reuse = true;
+  // exact: a released block is only handed to a later request of exactly the same byte count, and blocks are never
+  // split or merged.  Every tensor is utterance-major ([B][...] contiguous), so two tensors of equal size give each
+  // utterance the same byte range: an address then belongs to ONE utterance for the whole schedule, which is what lets
+  // the persistent per-XCD launch keep utterance b in XCD b's (non-coherent) L2 without ever sharing a line.
+  bool exact = false;
+  std::map<size_t, std::vector<size_t>> classes_;   // exact mode: true byte count -> free offsets
+  std::map<size_t, size_t> true_size_;              // exact mode: off -> requested byte count
   size_t alloc(size_t bytes) {
+    const size_t want = bytes;
     bytes = (bytes + 255) / 256 * 256;
+    if (reuse && exact) {
+      auto it = classes_.find(want);
+      if (it != classes_.end() && !it->second.empty()) {
+        size_t off = it->second.back();
+        it->second.pop_back();
+        live_[off] = bytes; true_size_[off] = want;
+        return off;
+      }
+      size_t off = top;
+      top += bytes;
+      if (top > high) high = top;
+      live_[off] = bytes; true_size_[off] = want;
+      return off;
+    }
     if (reuse) {
       int best = -1;
       for (int i = 0; i < (int)free_.size(); ++i)
@@ -75,6 +97,7 @@ struct Arena {
     size_t size = it->second;
     live_.erase(it);
     if (!reuse) return;
+    if (exact) { classes_[true_size_[off]].push_back(off); return; }
     // insert sorted by offset and coalesce
     size_t i = 0;
     while (i < free_.size() && free_[i].off < off) ++i;
@@ -125,6 +148,12 @@ struct dv_unet {
   struct OpMeta { const char* kind; double flops; std::string desc; };
   std::vector<OpMeta> step_meta;          // parallel to step_ops (profiling / roofline report)
   std::vector<Probe> probes;
+  // persistent per-XCD schedule (persist.hip): descriptors of the step ops that can run inside it
+  std::vector<PersistOp> pops;
+  std::vector<int> step_pop;              // parallel to step_ops: index into pops, or -1
+  PersistOp* pops_dev = nullptr; PersistSync* psync = nullptr;
+  int p_begin = 0, p_end = 0;             // step_ops[p_begin, p_end) run as one persistent launch when persist_on
+  bool persist_on = false;
   double flops = 0;
   bool keep_intermediates = false;
   // per-call I/O (read by the ops when they are enqueued)
@@ -141,6 +170,7 @@ static void unet_release_prepared(dv_unet* u) {
   if (u->slab) (void)hipFree(u->slab);
   u->slab = nullptr; u->slab_bytes = 0;
   u->step_ops.clear(); u->cond_ops.clear(); u->probes.clear(); u->step_meta.clear();
+  u->pops.clear(); u->step_pop.clear(); u->pops_dev = nullptr; u->psync = nullptr; u->persist_on = false; u->p_begin = u->p_end = 0;
   u->prepared = false; u->cond_set = false; u->flops = 0;
 }
 
@@ -229,11 +259,32 @@ struct Builder {
   const char* cur_kind = "misc";
   double cur_flops = 0;
   std::string cur_desc;
-  void emit(std::vector<OpFn>& ops, OpFn f) {
+  void emit(std::vector<OpFn>& ops, OpFn f, const PersistOp* pop = nullptr) {
     if (dry) return;
     ops.push_back(std::move(f));
-    if (&ops == &u->step_ops) u->step_meta.push_back({cur_kind, cur_flops, cur_desc});
+    if (&ops == &u->step_ops) {
+      u->step_meta.push_back({cur_kind, cur_flops, cur_desc});
+      if (pop) { u->step_pop.push_back((int)u->pops.size()); u->pops.push_back(*pop); }
+      else u->step_pop.push_back(-1);
+    }
     cur_kind = "misc"; cur_flops = 0; cur_desc.clear();
+  }
+  // descriptor of a GEMM for the persistent schedule, or false if its shape is outside what persist.hip instantiates
+  bool persist_gemm(const GemmParams& gin, PersistOp& po) {
+    if (prec != DV_PREC_BF16X3 || gin.epi == EPI_STORE_NCT || !gin.w_lo) return false;
+    bool k64 = true;
+    for (int s2 = 0; s2 < gin.nseg; ++s2) k64 = k64 && gin.seg[s2].c0 % 64 == 0 && gin.seg[s2].c1 % 64 == 0;
+    int cfg, bm, bk;
+    if (gin.epi == EPI_GEGLU) { if (!k64) return false; cfg = 1; bm = 128; bk = 64; }
+    else {
+      const bool big = gin.T_out % 128 == 0 && (gin.T_out / 128) * ((gin.N + 127) / 128) >= 24;
+      if (big || !k64) { cfg = 0; bm = 128; bk = 32; } else { cfg = 2; bm = 64; bk = 64; }
+    }
+    if (gin.T_out % bm != 0 || gin.M != B * gin.T_out) return false;
+    po = PersistOp{};
+    po.type = POP_GEMM; po.cfg = cfg; po.g = gin;
+    for (int s2 = 0; s2 < gin.nseg; ++s2) po.g.seg[s2].nkt = gin.seg[s2].taps * (gin.seg[s2].c0 + gin.seg[s2].c1) / bk;
+    return true;
   }
   void probe(const std::string& name, const float* p, int T_, int C_) {
     if (!dry && u->keep_intermediates) u->probes.push_back(Probe{name, const_cast<float*>(p), T_, C_});
@@ -332,7 +383,9 @@ struct Builder {
       cur_desc = buf;
     }
     u->flops += dry ? 0.0 : cur_flops;
-    emit(ops, [g, p](hipStream_t st) { return launch_gemm(g, p, st); });
+    PersistOp po;
+    const bool pok = !dry && persist_gemm(g, po);
+    emit(ops, [g, p](hipStream_t st) { return launch_gemm(g, p, st); }, pok ? &po : nullptr);
   }
 
   static GemmSeg seg(Planes a0, int c0, Planes a1, int c1, int taps, int pad) {
@@ -380,7 +433,14 @@ struct Builder {
       snprintf(buf, sizeof(buf), "T=%d C=%d%s%s", Tn, C, fast ? " slab" : " table", raw_out ? " +raw" : "");
       cur_desc = buf;
     }
-    emit(ops, [gp](hipStream_t st) { return launch_gn_apply(gp, st); });
+    PersistOp po{};
+    if (fast) {
+      po.type = POP_GN; po.gn = gp;
+      po.gn_chunks = std::max(1, std::min(Tn / 4, 64 / G));
+      po.gn_rpb = (Tn + po.gn_chunks - 1) / po.gn_chunks;
+      po.gn_chunks = (Tn + po.gn_rpb - 1) / po.gn_rpb;
+    }
+    emit(ops, [gp](hipStream_t st) { return launch_gn_apply(gp, st); }, fast ? &po : nullptr);
     if (sc) { release(sc); release(sh); }
     return out;
   }
@@ -395,7 +455,9 @@ struct Builder {
   Planes split(std::vector<OpFn>& ops, const float* x, size_t n) {
     Planes out = alloc_planes(n);
     cur_kind = "split";
-    emit(ops, [=](hipStream_t st) { return launch_split(x, out.hi, out.lo, (int64_t)n, st); });
+    PersistOp po{};
+    po.type = POP_SPLIT; po.sp_in = x; po.sp_hi = out.hi; po.sp_lo = out.lo; po.n4_per_item = (int64_t)(n / 4 / (size_t)B);
+    emit(ops, [=](hipStream_t st) { return launch_split(x, out.hi, out.lo, (int64_t)n, st); }, (n % (4 * (size_t)B) == 0) ? &po : nullptr);
     return out;
   }
 
@@ -478,7 +540,9 @@ struct Builder {
       cur_desc = buf;
     }
     if (!dry) u->flops += cur_flops;
-    emit(ops, [a](hipStream_t st) { return launch_attention(a, st); });
+    PersistOp po{};
+    po.type = POP_ATTN; po.cfg = (a.d + 15) / 16 * 16; po.a = a;
+    emit(ops, [a](hipStream_t st) { return launch_attention(a, st); }, (prec == DV_PREC_BF16X3 && a.d % 4 == 0 && a.d <= 64) ? &po : nullptr);
     return o;
   }
 
@@ -1041,12 +1105,14 @@ extern "C" int dv_unet_prepare(dv_unet* u, int32_t B, int32_t T, int32_t L, int3
   const char* keep = getenv("DVITS_KEEP_INTERMEDIATES");
   u->keep_intermediates = keep && keep[0] == '1';
 
+  const bool persist_env = [] { const char* e = getenv("DVITS_PERSIST"); return e && e[0] == '1'; }();
   // pass 1: measure the arena
   size_t need = 0;
   {
     Builder b{};
     b.u = u; b.dry = true; b.B = B; b.T = T; b.L = L; b.prec = precision;
     b.arena.reuse = !u->keep_intermediates;
+    b.arena.exact = persist_env;
     int rc = b.build();
     if (rc != DV_OK) return rc;
     need = b.arena.high;
@@ -1058,8 +1124,34 @@ extern "C" int dv_unet_prepare(dv_unet* u, int32_t B, int32_t T, int32_t L, int3
     Builder b{};
     b.u = u; b.dry = false; b.B = B; b.T = T; b.L = L; b.prec = precision;
     b.arena.reuse = !u->keep_intermediates;
+    b.arena.exact = persist_env;
     int rc = b.build();
     if (rc != DV_OK) { unet_release_prepared(u); return rc; }
+  }
+  // Persistent per-XCD schedule (DVITS_PERSIST=1): the longest run of consecutive step operations that persist.hip
+  // can execute (normally conv_in .. the final GroupNorm; input packing, the conditioning GEMVs and conv_out, whose
+  // I/O pointers change per call, stay ordinary launches around it).
+  {
+    const char* pe = getenv("DVITS_PERSIST");
+    const int n = (int)u->step_ops.size();
+    int best0 = 0, best1 = 0;
+    for (int i = 0; i < n;) {
+      if (u->step_pop[i] < 0) { ++i; continue; }
+      int j = i;
+      while (j < n && u->step_pop[j] >= 0) ++j;
+      if (j - i > best1 - best0) { best0 = i; best1 = j; }
+      i = j;
+    }
+    if (pe && pe[0] == '1' && best1 - best0 >= 8 && persist_init() == hipSuccess) {
+      const int np = best1 - best0;
+      HIPCHK(hipMalloc((void**)&u->pops_dev, (size_t)np * sizeof(PersistOp)));
+      u->owned.push_back(u->pops_dev);
+      HIPCHK(hipMemcpy(u->pops_dev, u->pops.data() + u->step_pop[best0], (size_t)np * sizeof(PersistOp), hipMemcpyHostToDevice));
+      HIPCHK(hipMalloc((void**)&u->psync, sizeof(PersistSync)));
+      u->owned.push_back(u->psync);
+      HIPCHK(hipMemset(u->psync, 0, sizeof(PersistSync)));
+      u->p_begin = best0; u->p_end = best1; u->persist_on = true;
+    }
   }
   HIPCHK(hipDeviceSynchronize());
   u->prepared = true;
@@ -1182,7 +1274,46 @@ int dv_unet_enqueue(dv_unet* u, const float* x, int cx, const float* cond, const
   if (cx <= 0 || cx > u->cfg.in_channels || (cx < u->cfg.in_channels && !cond))
     return dv_fail(DV_ERR_INVALID, "forward: cx=%d inconsistent with in_channels=%d / cond", cx, u->cfg.in_channels);
   u->io.x = x; u->io.cx = cx; u->io.cond = cond; u->io.t = t; u->io.y = y;
-  return run_ops(u->step_ops, st, "forward");
+  if (!u->persist_on) return run_ops(u->step_ops, st, "forward");
+  for (int i = 0; i < u->p_begin; ++i) {
+    hipError_t e = u->step_ops[i](st);
+    if (e != hipSuccess) return dv_fail(DV_ERR_HIP, "forward: op %d failed to launch: %s", i, hipGetErrorString(e));
+  }
+  {
+    hipError_t e = launch_persist(u->pops_dev, u->p_end - u->p_begin, u->psync, u->B, st);
+    if (e != hipSuccess) return dv_fail(DV_ERR_HIP, "forward: persistent launch failed: %s", hipGetErrorString(e));
+  }
+  for (int i = u->p_end; i < (int)u->step_ops.size(); ++i) {
+    hipError_t e = u->step_ops[i](st);
+    if (e != hipSuccess) return dv_fail(DV_ERR_HIP, "forward: op %d failed to launch: %s", i, hipGetErrorString(e));
+  }
+  return DV_OK;
+}
+
+extern "C" int dv_unet_persist_ticks(dv_unet* u, int32_t* first_op, uint64_t* ticks, int32_t capacity) {
+  if (!u || !u->prepared || !u->persist_on || !ticks) return dv_fail(DV_ERR_STATE, "dv_unet_persist_ticks: persistent schedule is off");
+  PersistSync h;
+  HIPCHK(hipDeviceSynchronize());
+  HIPCHK(hipMemcpy(&h, u->psync, sizeof(h), hipMemcpyDeviceToHost));
+  const int n = std::min(capacity, std::min(1024, u->p_end - u->p_begin + 1));
+  for (int i = 0; i < n; ++i) ticks[i] = h.ticks[i];
+  if (first_op) *first_op = u->p_begin;
+  return n;
+}
+
+extern "C" int dv_unet_persist_status(dv_unet* u, int32_t* n_ops, int32_t* error_flag) {
+  if (!u || !u->prepared) return dv_fail(DV_ERR_STATE, "dv_unet_persist_status before prepare");
+  if (n_ops) *n_ops = u->persist_on ? u->p_end - u->p_begin : 0;
+  if (error_flag) {
+    *error_flag = 0;
+    if (u->persist_on) {
+      PersistSync h;
+      HIPCHK(hipDeviceSynchronize());
+      HIPCHK(hipMemcpy(&h, u->psync, sizeof(h), hipMemcpyDeviceToHost));
+      *error_flag = (int32_t)h.error;
+    }
+  }
+  return DV_OK;
 }
 
 extern "C" int dv_unet_forward(dv_unet* u, const float* x, int32_t cx, const float* cond, const float* t, float* y, void* stream) {

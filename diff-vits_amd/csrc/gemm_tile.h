@@ -2,28 +2,12 @@
 // (persist.hip).  See kernels_gemm.hip for the design notes.
 #pragma once
 #include "dv_common.h"
+#include "dv_device.h"
 
 #include <type_traits>
 
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
-typedef __attribute__((ext_vector_type(16))) float f32x16;
-
-__device__ __forceinline__ unsigned cvt_pk_bf16(float lo, float hi) {
-  unsigned r;
-  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
-  return r;
-}
-__device__ __forceinline__ float gelu_erf(float v) { return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f)); }
-
-// LDS-DMA of 16 bytes per lane: LDS destination = wave-uniform `lds_dst` + lane*16 (M0 holds the
-// base), global source per lane.  Issued through asm so that hipcc neither counts it nor drains
-// it with vmcnt(0) at the next LDS read: the waits below are counted by hand.
-__device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst) {
-  unsigned keep;
-  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-               : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
-}
-#ifdef DV_GEMM_TRACE
+#if defined(DV_GEMM_TRACE) && defined(DV_GEMM_TRACE_OWNER)
+#define DV_GEMM_TRACING 1
 // development build only (make trace): per-workgroup s_memtime stamps of the kernel's phases
 __device__ unsigned long long g_gemm_trace[8192 * 16];
 #define DV_TRACE(i) do { if (threadIdx.x == 0 && blockIdx.x < 8192) g_gemm_trace[blockIdx.x * 16 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
@@ -38,45 +22,16 @@ extern "C" int dv_debug_gemm_trace_clear() {
 #else
 #define DV_TRACE(i) do {} while (0)
 #endif
-__device__ __forceinline__ void glds16_sc1(const void* gsrc, unsigned lds_dst) {   // L1-bypassing variant
-  unsigned keep;
-  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off sc1\n\ts_mov_b32 m0, %0"
-               : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+__device__ __forceinline__ unsigned cvt_pk_bf16(float lo, float hi) {
+  unsigned r;
+  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+  return r;
 }
-// plain-value loads of mutable data: default policy, or `sc1` (L2-served) inside a persistent launch
-template <bool SC1>
-__device__ __forceinline__ float4 ld_mut4(const float* p) {
-  if (!SC1) return *reinterpret_cast<const float4*>(p);
-  float4 v;
-  asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(v) : "v"(p) : "memory");
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  return v;
-}
-template <bool SC1>
-__device__ __forceinline__ float2 ld_mut2(const float2* p) {
-  if (!SC1) return *p;
-  float2 v;
-  asm volatile("global_load_dwordx2 %0, %1, off sc1" : "=v"(v) : "v"(p) : "memory");
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  return v;
-}
-template <bool SC1>
-__device__ __forceinline__ float ld_mut1(const float* p) {
-  if (!SC1) return *p;
-  float v;
-  asm volatile("global_load_dword %0, %1, off sc1" : "=v"(v) : "v"(p) : "memory");
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  return v;
-}
-__device__ __forceinline__ void glds4(const void* gsrc, unsigned lds_dst) {   // 4 bytes per lane
-  unsigned keep;
-  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
-               : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
-}
-template <int N>
-__device__ __forceinline__ void wait_vmcnt() {
-  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
-}
+__device__ __forceinline__ float gelu_erf(float v) { return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f)); }
 
 // KS = 2 doubles the waves of a workgroup (two per SIMD): both groups stage every k-tile together and each
 // multiplies half of its 16-deep k-steps, so one wave's MFMAs overlap the other's address math and DMA issue;
@@ -101,7 +56,7 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int m0, con
   constexpr int LPT = (A_IPW + B_IPW) * NPL;         // DMA instructions per thread per k-tile
   static_assert(BM % (RPI * NWV) == 0 && BN % (RPI * NWV) == 0, "tile rows must split over the waves");
   DV_TRACE(0);
-#ifdef DV_GEMM_TRACE
+#ifdef DV_GEMM_TRACING
   if (threadIdx.x == 0 && blockIdx.x < 8192) {
     unsigned xcc, hw;
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
@@ -121,7 +76,7 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int m0, con
   const int wm = wq / WN, wn = wq % WN;
   const unsigned smem_base = (unsigned)(size_t)smem;   // LDS byte address of the ring
 
-#ifdef DV_GEMM_TRACE
+#ifdef DV_GEMM_TRACING
   if (m0 + n0 >= 0) DV_TRACE(8);    // first kernel-argument dependent value is available
 #endif
 
@@ -358,7 +313,7 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int m0, con
 #pragma unroll
   for (int t = 0; t < NSTAGE - 1; ++t) {
     if (t < total_kt) issue(t);
-#ifdef DV_GEMM_TRACE
+#ifdef DV_GEMM_TRACING
     if (t == 0) DV_TRACE(11);
 #endif
   }
@@ -369,7 +324,7 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int m0, con
   for (; kt < n_steady; ++kt) {
     wait_vmcnt<(NSTAGE - 2) * LPT>();
     __builtin_amdgcn_s_barrier();                    // tile kt visible; every wave is done with tile kt-1
-#ifdef DV_GEMM_TRACE
+#ifdef DV_GEMM_TRACING
     if (kt == 0) DV_TRACE(2);
 #endif
     step(kt, std::true_type{});                      // DMA overwrites the stage tile kt-1 was read from
@@ -380,7 +335,7 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int m0, con
     else if (younger == 1) wait_vmcnt<LPT>();
     else wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();
-#ifdef DV_GEMM_TRACE
+#ifdef DV_GEMM_TRACING
     if (kt == 0) DV_TRACE(2);
 #endif
     step(kt, std::false_type{});

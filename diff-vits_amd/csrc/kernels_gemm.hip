@@ -19,6 +19,7 @@
 //               fp32 and/or split bf16 planes; optional per-(32-row block, channel) sum / sum of
 //               squares of the result (GroupNorm statistics for the consumer, no extra pass)
 #include "dv_common.h"
+#define DV_GEMM_TRACE_OWNER   // the trace build's stamp buffer lives in this translation unit
 #include "gemm_tile.h"
 
 #include <cstdio>

@@ -3,22 +3,7 @@
 // and the sampler's fused linear-combination update.  All are wave64 kernels with 16-byte
 // accesses where the layout allows.
 #include "dv_common.h"
-
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-  return v;
-}
-__device__ __forceinline__ double wave_sum_d(double v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-  return v;
-}
-__device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
-  return v;
-}
+#include "misc_body.h"
 
 // ---------------------------------------------------------------------------------------
 // (B, C, T) channels-first inputs x | cond  ->  (B*T, cpad) channels-last, zero padded.
@@ -27,24 +12,6 @@ __device__ __forceinline__ float wave_max(float v) {
 // engine is channels-last.  32x32 LDS-transposed tiles: reads coalesced along T, writes
 // along C.
 // ---------------------------------------------------------------------------------------
-__device__ __forceinline__ unsigned pk_bf16(float lo, float hi) {
-  unsigned r;
-  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
-  return r;
-}
-// 4 floats -> 4 bf16 hi (uint2) + 4 bf16 lo (uint2), hi = rne(x), lo = rne(x - hi)
-__device__ __forceinline__ void split4(const float4 v, uint2& hi, uint2& lo) {
-  hi.x = pk_bf16(v.x, v.y);
-  hi.y = pk_bf16(v.z, v.w);
-  lo.x = pk_bf16(v.x - __uint_as_float(hi.x << 16), v.y - __uint_as_float(hi.x & 0xffff0000u));
-  lo.y = pk_bf16(v.z - __uint_as_float(hi.y << 16), v.w - __uint_as_float(hi.y & 0xffff0000u));
-}
-__device__ __forceinline__ void split1(float v, bf16_t& hi, bf16_t& lo) {
-  const unsigned h = pk_bf16(v, 0.f);
-  hi = (bf16_t)(h & 0xffffu);
-  lo = (bf16_t)(pk_bf16(v - __uint_as_float(h << 16), 0.f) & 0xffffu);
-}
-
 __global__ __launch_bounds__(256) void k_pack_input(const float* __restrict__ x, int cx,
                                                      const float* __restrict__ cond, int cc,
                                                      bf16_t* __restrict__ out_hi, bf16_t* __restrict__ out_lo,
@@ -84,12 +51,7 @@ hipError_t launch_pack_input(const float* x, int cx, const float* cond, int cc, 
 }
 
 __global__ void k_split(const float* __restrict__ in, bf16_t* __restrict__ hi, bf16_t* __restrict__ lo, int64_t n4) {
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
-    uint2 h, l;
-    split4(reinterpret_cast<const float4*>(in)[i], h, l);
-    reinterpret_cast<uint2*>(hi)[i] = h;
-    if (lo) reinterpret_cast<uint2*>(lo)[i] = l;
-  }
+  split_body<false>(in, hi, lo, 0, n4, (int64_t)blockIdx.x * blockDim.x + threadIdx.x, (int64_t)gridDim.x * blockDim.x);
 }
 hipError_t launch_split(const float* in, bf16_t* hi, bf16_t* lo, int64_t n, hipStream_t st) {
   if (n % 4 != 0) return hipErrorInvalidValue;
@@ -108,89 +70,7 @@ hipError_t launch_split(const float* in, bf16_t* hi, bf16_t* lo, int64_t n, hipS
 // y = act(x*scale + shift) -> hi/lo planes, 16-byte loads, 8-byte stores.
 // ---------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_gn_apply(const GnApplyParams p, int rows_per_block) {
-  // grid = (frame chunks, groups, batch): a workgroup normalises `rows_per_block` frames of ONE group
-  // (cg channels) of one batch item, so it only reduces that group's slice of the statistics slab
-  __shared__ float s_scale[512], s_shift[512];
-  __shared__ double s_red[8];
-  const int ctot = p.c0 + p.c1, G = p.groups, cg = ctot / G;
-  const int g = blockIdx.y, b = blockIdx.z, tid = threadIdx.x;
-  const int cbase = g * cg;
-  // the elements this thread normalises do not depend on the statistics: fetch the first two items now, so their
-  // (cold-L2) latency overlaps the slab reduction instead of following it
-  const int ncol4 = cg >> 2;
-  const int t0 = blockIdx.x * rows_per_block, t1r = min(p.T, t0 + rows_per_block);
-  const int total = (t1r - t0) * ncol4;
-  auto load_item = [&](int i) {
-    const int r = i / ncol4, c = cbase + (i - r * ncol4) * 4;
-    const size_t row = (size_t)b * p.T + t0 + r;
-    return *reinterpret_cast<const float4*>(c < p.c0 ? p.a0 + row * p.c0 + c : p.a1 + row * p.c1 + (c - p.c0));
-  };
-  constexpr int PF = 2;
-  float4 pv[PF];
-#pragma unroll
-  for (int k = 0; k < PF; ++k) pv[k] = tid + k * 256 < total ? load_item(tid + k * 256) : make_float4(0.f, 0.f, 0.f, 0.f);
-  if (p.scale_in) {
-    for (int c = tid; c < cg; c += 256) {
-      s_scale[c] = p.scale_in[(size_t)b * ctot + cbase + c];
-      s_shift[c] = p.shift_in[(size_t)b * ctot + cbase + c];
-    }
-  } else {
-    const int RB = p.T >> 5;             // 32-row blocks per batch item (T % 32 == 0)
-    double s1 = 0, s2 = 0;
-    for (int item = tid; item < cg * RB; item += 256) {
-      const int rb = item / cg, c = cbase + (item - rb * cg);
-      const bool first = c < p.c0;
-      const float2* slab = reinterpret_cast<const float2*>(first ? p.slab0 : p.slab1);
-      const int ld = first ? p.c0 : p.c1, cc = first ? c : c - p.c0;
-      const float2 v = slab[(size_t)(b * RB + rb) * ld + cc];
-      s1 += v.x;
-      s2 += v.y;
-    }
-    s1 = wave_sum_d(s1);
-    s2 = wave_sum_d(s2);
-    if ((tid & 63) == 0) { s_red[(tid >> 6) * 2] = s1; s_red[(tid >> 6) * 2 + 1] = s2; }
-    __syncthreads();
-    const double t1 = (s_red[0] + s_red[2]) + (s_red[4] + s_red[6]);
-    const double t2 = (s_red[1] + s_red[3]) + (s_red[5] + s_red[7]);
-    const double n = (double)cg * (double)p.T;
-    const double mean = t1 / n;
-    double var = t2 / n - mean * mean;
-    var = var > 0 ? var : 0;
-    const float rstd = (float)(1.0 / sqrt(var + (double)p.eps));
-    for (int c = tid; c < cg; c += 256) {
-      const int cc = cbase + c;
-      const float a = rstd * p.gamma[cc];
-      const float sh = p.beta[cc] - (float)mean * a;
-      const float ts = p.tscale ? 1.0f + p.tscale[(size_t)b * p.ld_t + cc] : 1.0f;
-      const float tb = p.tshift ? p.tshift[(size_t)b * p.ld_t + cc] : 0.0f;
-      s_scale[c] = a * ts;
-      s_shift[c] = fmaf(sh, ts, tb);
-    }
-  }
-  __syncthreads();
-  for (int i = tid, k = 0; i < total; i += 256, ++k) {
-    const int r = i / ncol4, j = i - r * ncol4, c = cbase + j * 4;
-    const size_t row = (size_t)b * p.T + t0 + r;
-    const float4 v = k == 0 ? pv[0] : (k == 1 ? pv[1] : load_item(i));
-    const float4 sc = *reinterpret_cast<const float4*>(s_scale + j * 4);
-    const float4 sh = *reinterpret_cast<const float4*>(s_shift + j * 4);
-    float4 y;
-    y.x = fmaf(v.x, sc.x, sh.x); y.y = fmaf(v.y, sc.y, sh.y); y.z = fmaf(v.z, sc.z, sh.z); y.w = fmaf(v.w, sc.w, sh.w);
-    if (p.silu) {
-      y.x = y.x / (1.0f + __expf(-y.x)); y.y = y.y / (1.0f + __expf(-y.y));
-      y.z = y.z / (1.0f + __expf(-y.z)); y.w = y.w / (1.0f + __expf(-y.w));
-    }
-    uint2 h, l;
-    split4(y, h, l);
-    const size_t o = (row * ctot + c) >> 2;
-    reinterpret_cast<uint2*>(p.out_hi)[o] = h;
-    if (p.out_lo) reinterpret_cast<uint2*>(p.out_lo)[o] = l;
-    if (p.raw_hi) {
-      split4(v, h, l);
-      reinterpret_cast<uint2*>(p.raw_hi)[o] = h;
-      if (p.raw_lo) reinterpret_cast<uint2*>(p.raw_lo)[o] = l;
-    }
-  }
+  gn_apply_body<256, false>(p, rows_per_block, blockIdx.x, blockIdx.y, blockIdx.z);
 }
 
 hipError_t launch_gn_apply(const GnApplyParams& p, hipStream_t st) {

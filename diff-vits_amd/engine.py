@@ -150,6 +150,12 @@ class UNetEngine:
             rows.append((kind.value.decode(), fl.value, float(ms[i]), desc.value.decode()))
         return rows
 
+    def persist_status(self):
+        """(operations inside the persistent launch, error flag) - see dv_unet_persist_status."""
+        n, err = C.c_int32(), C.c_int32()
+        _lib.check(_lib.lib().dv_unet_persist_status(self._h, C.byref(n), C.byref(err)), "dv_unet_persist_status")
+        return n.value, err.value
+
     def time_family(self, kind, reps=5):
         """Average launch duration (us) of one kernel family: its launches of the schedule replayed back to back
         between one HIP event pair (after a completed forward).  Returns (us_per_launch, launches_per_forward)."""

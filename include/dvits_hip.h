@@ -129,6 +129,16 @@ int dv_unet_op_info(dv_unet* u, int32_t index, char* kind16, double* flops, char
  * dv_unet_forward (the buffers then hold valid data; outputs are overwritten with the same values). */
 int dv_unet_time_family(dv_unet* u, const char* kind, int32_t reps, void* stream, float* ms_total, int32_t* launches);
 
+/* Persistent per-XCD schedule (environment DVITS_PERSIST=1 at prepare time; csrc/persist.hip): *n_ops = number of
+ * schedule operations that run inside the one persistent launch (0 = off / not applicable to this shape);
+ * *error_flag = 0 ok, 1 = an in-launch barrier timed out, 2 = the workgroups were not spread evenly over the XCDs
+ * (synchronises the device). */
+int dv_unet_persist_status(dv_unet* u, int32_t* n_ops, int32_t* error_flag);
+/* Profiling aid: s_memtime stamps taken by one workgroup of XCD 0 after every operation of the last persistent launch;
+ * returns the number of stamps written (operations + 1) or a negative error; *first_op = schedule index of the first
+ * operation inside the launch (pairs with dv_unet_op_info). */
+int dv_unet_persist_ticks(dv_unet* u, int32_t* first_op, uint64_t* ticks, int32_t capacity);
+
 /* Debug/parity probe: copy a named intermediate activation (channels-last [B, T, C]) of the
  * last forward to the host.  Available only when dv_unet_prepare ran with the environment
  * variable DVITS_KEEP_INTERMEDIATES=1 (buffers are then never reused).  dims[3] = {B, T, C};

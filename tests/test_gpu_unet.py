@@ -310,3 +310,39 @@ def test_unet_unfused_layernorm_mode(gold):
     assert rel_l2(y.cpu().numpy(), gold("unet_oddT.npz")["y"]) < 2e-4
     m2, *_ = _build("oddT")
     assert m2.hip_engine().prepare(2, 100, 50) and m2.hip_engine().stats()[0] == n_launch - 48
+
+
+def test_persistent_per_xcd_schedule_matches_per_launch():
+    """DVITS_PERSIST=1 (csrc/persist.hip): the body of a forward as ONE launch with XCD-local barriers, utterance b on
+    XCD b % 8.  Same kernels' tile routines (L1-bypassing loads), different tile menu: agreement with the per-launch
+    schedule to float32 rounding, for a full batch and for one that leaves XCDs idle; barrier error flag clear."""
+    from diff_vits_amd import synth
+    from diff_vits_amd.unet1d.unet_1d_condition import UNet1DConditionModel
+    kw = UNET_CASES["cfg1"][0]
+    with torch.device("meta"):
+        shapes = {k: tuple(v.shape) for k, v in UNet1DConditionModel(**kw).state_dict().items()}
+    sd = {k: torch.from_numpy(v) for k, v in synth.make_state_dict(shapes, seed=1234).items()}
+    for B, T, L in ((8, 512, 48), (3, 512, 40)):
+        x = torch.from_numpy(synth.normal(7, "x", (B, 80, T))).cuda()
+        cond = torch.from_numpy(synth.normal(7, "c", (B, 128, T))).cuda()
+        enc = torch.from_numpy(synth.normal(7, "e", (B, L, 128))).cuda()
+        t = torch.full((B,), 321.5, device="cuda")
+        outs = []
+        for persist in ("0", "1"):
+            os.environ["DVITS_PERSIST"] = persist
+            try:
+                m = UNet1DConditionModel(**kw).eval()
+                m.load_state_dict(sd)
+                eng = m.cuda().hip_engine()
+                eng.sync_weights()
+                eng.prepare(B, T, L)
+                eng.set_cond(enc, None)
+                y1 = eng.eval(x, cond, t).clone()
+                y2 = eng.eval(x, cond, t).clone()          # second call: same buffers, same schedule
+                n_ops, err = eng.persist_status()
+            finally:
+                os.environ.pop("DVITS_PERSIST", None)
+            assert torch.equal(y1, y2)
+            assert err == 0 and (n_ops > 100) == (persist == "1")
+            outs.append(y1.cpu().numpy())
+        assert rel_l2(outs[1], outs[0]) < 5e-5

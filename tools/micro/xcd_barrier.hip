@@ -20,11 +20,23 @@ __device__ __forceinline__ u32x4 load16_sc1(const void* p) {   // L1-bypassing l
   return v;
 }
 
+// LDS-DMA read of 16 bytes per lane with a cache-policy modifier, then back from LDS
+template <int POL>
+__device__ __forceinline__ u32x4 load16_dma(const void* p, char* lds_slot) {
+  const unsigned dst = __builtin_amdgcn_readfirstlane((unsigned)(size_t)lds_slot);
+  if (POL == 0) asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off\n\ts_waitcnt vmcnt(0)" ::"v"(p), "s"(dst) : "memory");
+  if (POL == 1) asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off sc1\n\ts_waitcnt vmcnt(0)" ::"v"(p), "s"(dst) : "memory");
+  if (POL == 2) asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off nt\n\ts_waitcnt vmcnt(0)" ::"v"(p), "s"(dst) : "memory");
+  if (POL == 3) asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off sc0 sc1\n\ts_waitcnt vmcnt(0)" ::"v"(p), "s"(dst) : "memory");
+  return *reinterpret_cast<const u32x4*>(lds_slot + (threadIdx.x & 63) * 16);
+}
+
 // SCOPE 0: workgroup-scope atomics (execute in the XCD's L2), 1: agent-scope atomics.  LOADS 0: plain, 1: sc1.
 template <int SCOPE, int LOADS>
 __global__ __launch_bounds__(256) void k_phases(Sync* s, u32x4* data, int chunk16, int phases, unsigned long long* ticks,
                                                  unsigned* bad) {
   __shared__ unsigned s_rank, s_xcc, s_n;
+  __shared__ __attribute__((aligned(1024))) char s_dma[4][1024];
   if (threadIdx.x == 0) {
     unsigned xcc;
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
@@ -58,7 +70,10 @@ __global__ __launch_bounds__(256) void k_phases(Sync* s, u32x4* data, int chunk1
     }
     __syncthreads();
     for (int i = threadIdx.x; i < chunk16; i += 256) {
-      const u32x4 v = LOADS ? load16_sc1(theirs + i) : theirs[i];
+      u32x4 v;
+      if (LOADS == 0) v = theirs[i];
+      else if (LOADS == 1) v = load16_sc1(theirs + i);
+      else v = load16_dma<LOADS - 2>(theirs + i, s_dma[threadIdx.x >> 6]);
       mism += (v.x != (unsigned)ph);
     }
     __syncthreads();      // (a second barrier would be needed before overwriting `mine`: the reader of MY chunk may
@@ -92,11 +107,13 @@ int run(const char* name, int chunk_bytes, int phases) {
 }
 
 int main() {
-  for (int chunk : {256, 16384}) {
-    if (run<0, 0>("workgroup-scope atomics (L2), plain loads", chunk, 20)) return 1;
-    if (run<0, 1>("workgroup-scope atomics (L2), sc1 loads", chunk, 20)) return 1;
-    if (run<1, 0>("agent-scope atomics, plain loads", chunk, 20)) return 1;
-    if (run<1, 1>("agent-scope atomics, sc1 loads", chunk, 20)) return 1;
+  for (int chunk : {16384, 65536}) {
+    if (run<1, 0>("agent-scope atomics, plain loads", chunk, 50)) return 1;
+    if (run<1, 1>("agent-scope atomics, sc1 loads", chunk, 50)) return 1;
+    if (run<1, 2>("agent-scope atomics, LDS-DMA default policy", chunk, 50)) return 1;
+    if (run<1, 3>("agent-scope atomics, LDS-DMA sc1", chunk, 50)) return 1;
+    if (run<1, 4>("agent-scope atomics, LDS-DMA nt", chunk, 50)) return 1;
+    if (run<1, 5>("agent-scope atomics, LDS-DMA sc0 sc1", chunk, 50)) return 1;
   }
   return 0;
 }
