@@ -47,9 +47,10 @@ def run(B, T, L, persist, reps=20):
     return y.cpu().numpy(), n_ops, err, ms
 
 
-for B, T, L in ((8, 1024, 256), (8, 512, 64), (3, 512, 40)):
-    a, n0, e0, ms0 = run(B, T, L, False)
-    b, n1, e1, ms1 = run(B, T, L, True)
-    rel = float(np.linalg.norm(a.astype(np.float64) - b) / np.linalg.norm(a.astype(np.float64)))
-    print("B=%d T=%d L=%d: per-launch %.3f ms | persistent %.3f ms (%d ops in one launch, error flag %d) | rel-L2 %.2e finite %s"
-          % (B, T, L, ms0, ms1, n1, e1, rel, bool(np.isfinite(b).all())))
+if __name__ == "__main__":
+    for B, T, L in ((8, 1024, 256), (8, 512, 64), (3, 512, 40)):
+        a, n0, e0, ms0 = run(B, T, L, False)
+        b, n1, e1, ms1 = run(B, T, L, True)
+        rel = float(np.linalg.norm(a.astype(np.float64) - b) / np.linalg.norm(a.astype(np.float64)))
+        print("B=%d T=%d L=%d: per-launch %.3f ms | persistent %.3f ms (%d ops in one launch, error flag %d) | rel-L2 %.2e finite %s"
+              % (B, T, L, ms0, ms1, n1, e1, rel, bool(np.isfinite(b).all())))
