@@ -51,7 +51,11 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int m0, con
   constexpr int RPI = 64 / CPR;                      // rows per wave-instruction
   constexpr int A_PL = BM * ROWB, B_PL = BN * ROWB;  // bytes per plane tile
   constexpr int STAGE = (A_PL + B_PL) * NPL;
-  constexpr int NSTAGE = (4 * STAGE <= 160 * 1024) ? 4 : 3;   // LDS ring depth: NSTAGE-1 tiles in flight
+#ifndef DV_NSTAGE_64
+#define DV_NSTAGE_64 4
+#endif
+  // LDS ring depth: NSTAGE-1 tiles in flight (DV_NSTAGE_64: experiment knob for the 64x64 tiles' occupancy)
+  constexpr int NSTAGE = (BM == 64 && BN == 64 && !SC1) ? DV_NSTAGE_64 : ((4 * STAGE <= 160 * 1024) ? 4 : 3);
   constexpr int A_IPW = BM / RPI / NWV, B_IPW = BN / RPI / NWV;   // DMA instructions per wave per plane
   constexpr int LPT = (A_IPW + B_IPW) * NPL;         // DMA instructions per thread per k-tile
   static_assert(BM % (RPI * NWV) == 0 && BN % (RPI * NWV) == 0, "tile rows must split over the waves");

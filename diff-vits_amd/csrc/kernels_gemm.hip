@@ -43,7 +43,7 @@ __global__ __launch_bounds__(64 * WM * WN * KS) void k_gemm(const GemmParams p) 
 template <int BM, int BN, int BK, int WM, int WN, int NSPLIT, int KS>
 struct GemmCfg {
   static constexpr int STAGE_B = (BM + BN) * BK * 2 * (NSPLIT == 3 ? 2 : 1);
-  static constexpr int SMEM = ((4 * STAGE_B <= 160 * 1024) ? 4 : 3) * STAGE_B;
+  static constexpr int SMEM = ((BM == 64 && BN == 64) ? DV_NSTAGE_64 : ((4 * STAGE_B <= 160 * 1024) ? 4 : 3)) * STAGE_B;
   // > 64 KiB of dynamic LDS needs the attribute; set once, outside any stream capture
   static hipError_t init() {
     return hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm<BM, BN, BK, WM, WN, NSPLIT, KS>),
