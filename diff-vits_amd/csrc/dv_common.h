@@ -47,7 +47,7 @@ struct GemmParams {
   float* stats;                 // [ceil(M/32), N, 2] per 32-row block column (sum, sumsq) or null
   const bf16_t* zero_page;      // >= 16 bytes of zeros (source of padded / out-of-range rows)
   // LayerNorm fused across two GEMMs (reference attention.py:157,176,189): the PRODUCER of x writes per-row
-  // partial (sum, sumsq) over each 32-column block of its output; the CONSUMER multiplies the raw x by the
+  // partial (sum, squared deviations from the block mean) over each 32-column block of its output; the CONSUMER multiplies the raw x by the
   // gamma-folded weights and finishes y = rstd*(acc - mean*u[n]) + bias'[n] in its epilogue.
   float* rowstat_out;           // producer: [M, N/32, 2] or null
   const float* ln_stat;         // consumer: the A operand's [M, ln_nblk, 2] row partials, or null (no LayerNorm)

@@ -294,12 +294,19 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int m0, con
     for (int r = tid; r < BM; r += 64 * NWV) {
       const int m = min(m0 + r, p.M - 1);
       const float2* src = reinterpret_cast<const float2*>(p.ln_stat) + (size_t)m * p.ln_nblk;
-      float s1 = 0.f, s2 = 0.f;
-      for (int k = 0; k < p.ln_nblk; ++k) { const float2 v = ld_mut2<SC1>(src + k); s1 += v.x; s2 += v.y; }
+      // partials per 32-column block: (sum, sum of squared deviations from the block's own mean); combined with the
+      // parallel-variance formula, so no E[x^2] - mean^2 cancellation for rows whose mean is large against their spread
+      float s1 = 0.f;
+      for (int k = 0; k < p.ln_nblk; ++k) s1 += ld_mut2<SC1>(src + k).x;
       const float inv_c = 1.0f / (float)(p.ln_nblk * 32);
       const float mean = s1 * inv_c;
-      const float var = fmaxf(s2 * inv_c - mean * mean, 0.f);
-      s_ln[r] = make_float2(mean, 1.0f / sqrtf(var + p.ln_eps));
+      float m2 = 0.f;
+      for (int k = 0; k < p.ln_nblk; ++k) {
+        const float2 v = ld_mut2<SC1>(src + k);
+        const float dm = v.x * (1.0f / 32.0f) - mean;
+        m2 += v.y + 32.0f * dm * dm;
+      }
+      s_ln[r] = make_float2(mean, 1.0f / sqrtf(m2 * inv_c + p.ln_eps));
     }
     __syncthreads();
   }
@@ -502,8 +509,11 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int m0, con
         const int cb = (n0 + (wn * FN + j) * 32) >> 5;
         float a = 0.f, q = 0.f;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { a += vv[r]; q += vv[r] * vv[r]; }
+        for (int r = 0; r < 16; ++r) a += vv[r];
         a += __shfl_xor(a, 32);
+        const float mb = a * (1.0f / 32.0f);           // block mean; q = squared deviations from it
+#pragma unroll
+        for (int r = 0; r < 16; ++r) q += (vv[r] - mb) * (vv[r] - mb);
         q += __shfl_xor(q, 32);
         if (lh == 0 && m_ok && cb < nblk_total)
           reinterpret_cast<float2*>(p.rowstat_out)[(size_t)m * nblk_total + cb] = make_float2(a, q);
