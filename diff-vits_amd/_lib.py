@@ -57,6 +57,8 @@ SIGNATURES = {
     "dv_unet_probe": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.c_int64, C.POINTER(C.c_int64)]),
     "dv_sampler_plan": (C.c_int, [C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                   C.POINTER(C.c_void_p)]),
+    "dv_sampler_plan_ex": (C.c_int, [C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                                     C.c_double, C.c_double, C.c_int32, C.POINTER(C.c_void_p)]),
     "dv_plan_destroy": (None, [C.c_void_p]),
     "dv_plan_info": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.c_void_p, C.c_void_p]),
     "dv_plan_coefs": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.c_void_p]),

@@ -127,6 +127,8 @@ bool solve_small(int n, double A[3][3], double b[3], double x[3]) {
 
 struct dv_plan {
   int solver = 0, steps = 0, order = 0, skip = 0, lof = 1;
+  double t_start = -1.0, t_end = -1.0;   // <= 0: the defaults T and 1/N
+  int denoise_to_zero = 0;
   Schedule ns;
   std::vector<double> timesteps;      // steps + 1
   std::vector<double> t_input;        // per EVAL
@@ -145,7 +147,8 @@ struct dv_plan {
 static int build_plan(dv_plan* p) {
   const Schedule& ns = p->ns;
   const int N = p->steps, order = p->order;
-  const double t_0 = 1.0 / ns.total_N, t_T = 1.0;
+  // dpm_solver.py:1157-1158 / uni_pc.py:596-597: t_0 = 1/N unless t_end is given, t_T = T unless t_start is given
+  const double t_0 = p->t_end > 0 ? p->t_end : 1.0 / ns.total_N, t_T = p->t_start > 0 ? p->t_start : 1.0;
   // ---- time grid (get_time_steps, dpm_solver.py:453-480), float32 as the reference stores it
   p->timesteps.resize(N + 1);
   auto linspace32 = [&](float a, float b, std::vector<double>& out) {
@@ -320,17 +323,28 @@ static int build_plan(dv_plan* p) {
       if (rc != DV_OK) return rc;
     }
   }
+  if (p->denoise_to_zero) {   // dpm_solver.py:1234-1240, uni_pc.py:660-666: x <- data prediction at t_0 (one more evaluation)
+    add_eval(0, t_0, 0);
+    add_comb(0, 0.0, {{0, 1.0}});
+  }
   return DV_OK;
 }
 
 extern "C" int dv_sampler_plan(int32_t solver, const float* betas, int32_t n_betas, int32_t steps, int32_t order,
                                int32_t skip_type, int32_t lower_order_final, dv_plan** out) {
+  return dv_sampler_plan_ex(solver, betas, n_betas, steps, order, skip_type, lower_order_final, -1.0, -1.0, 0, out);
+}
+
+extern "C" int dv_sampler_plan_ex(int32_t solver, const float* betas, int32_t n_betas, int32_t steps, int32_t order,
+                                  int32_t skip_type, int32_t lower_order_final, double t_start, double t_end,
+                                  int32_t denoise_to_zero, dv_plan** out) {
   if (!betas || !out || n_betas < 2) return dv_fail(DV_ERR_INVALID, "dv_sampler_plan: bad argument");
   if (solver < DV_SOLVER_DPMPP || solver > DV_SOLVER_UNIPC_BH2) return dv_fail(DV_ERR_INVALID, "unknown solver %d", solver);
   if (order < 1 || order > 3) return dv_fail(DV_ERR_INVALID, "Solver order must be 1 or 2 or 3, got %d", order);
   if (steps < order) return dv_fail(DV_ERR_INVALID, "steps (%d) must be >= order (%d)", steps, order);
   dv_plan* p = new dv_plan();
   p->solver = solver; p->steps = steps; p->order = order; p->skip = skip_type; p->lof = lower_order_final;
+  p->t_start = t_start; p->t_end = t_end; p->denoise_to_zero = denoise_to_zero ? 1 : 0;
   p->ns.init(betas, n_betas, solver == DV_SOLVER_DPMPP);
   int rc = build_plan(p);
   if (rc != DV_OK) { delete p; return rc; }

@@ -120,16 +120,23 @@ def wrap_model(model, noise_schedule, model_type="noise", model_kwargs={}, guida
 class Plan:
     """Compiled multistep loop: events + fp64-derived coefficient rows."""
 
-    def __init__(self, solver, betas, steps, order, skip_type, lower_order_final):
+    def __init__(self, solver, betas, steps, order, skip_type, lower_order_final, t_start=None, t_end=None,
+                 denoise_to_zero=False):
         L = _lib()
+        for name, v in (("t_start", t_start), ("t_end", t_end)):
+            # reference dpm_solver.py:1159 / uni_pc.py:598
+            assert v is None or v > 0, ("Time range needs to be greater than 0. For discrete-time DPMs, it needs to be in "
+                                        "[1 / N, 1], where N is the length of betas array")
         if skip_type not in L.SKIP:
             raise ValueError("Unsupported skip_type {}, need to be 'logSNR' or 'time_uniform' or 'time_quadratic'"
                              .format(skip_type))
         betas = np.ascontiguousarray(betas, dtype=np.float32)
         self._h = C.c_void_p()
-        L.check(L.lib().dv_sampler_plan(solver, betas.ctypes.data_as(C.c_void_p), len(betas), steps, order,
-                                        L.SKIP[skip_type], int(bool(lower_order_final)), C.byref(self._h)),
-                "dv_sampler_plan")
+        L.check(L.lib().dv_sampler_plan_ex(solver, betas.ctypes.data_as(C.c_void_p), len(betas), steps, order,
+                                           L.SKIP[skip_type], int(bool(lower_order_final)),
+                                           -1.0 if t_start is None else float(t_start), -1.0 if t_end is None else float(t_end),
+                                           int(bool(denoise_to_zero)), C.byref(self._h)),
+                "dv_sampler_plan_ex")
         nfe = C.c_int32()
         L.check(L.lib().dv_plan_info(self._h, C.byref(nfe), None, None), "dv_plan_info")
         self.nfe = nfe.value
@@ -159,13 +166,19 @@ class Plan:
     def handle(self):
         return self._h
 
-    def run_python(self, x, data_model):
-        """Execute the loop with torch ops; `data_model(x, eval_idx)` returns the x0 prediction."""
+    def run_python(self, x, data_model, intermediates=None):
+        """Execute the loop with torch ops; `data_model(x, eval_idx)` returns the x0 prediction.  `intermediates`
+        (a list) receives what the reference's return_intermediate collects: the start point, x after every step
+        and, with denoise_to_zero, the final data prediction (dpm_solver.py:1179-1240)."""
         hist = [None] * self.n_slots
         xp = None
+        first = True
         for typ, src, eidx, dst, coef, s0, s1, s2, s3 in self.events.tolist():
             if typ == 0:
                 hist[dst] = data_model(x if src == 0 else xp, eidx)
+                if first and intermediates is not None:
+                    intermediates.append(x)
+                first = False
             else:
                 c = self.coefs[coef]
                 out = float(c[0]) * x
@@ -174,6 +187,8 @@ class Plan:
                         out = out + float(c[1 + k]) * hist[s]
                 if dst == 0:
                     x = out
+                    if intermediates is not None:
+                        intermediates.append(x)
                 else:
                     xp = out
         return x
@@ -212,16 +227,18 @@ class NativeUNetModel:
         return self._xbuf.clone()
 
 
-def sample_with_plan(plan, model_fn, noise_schedule, x):
+def sample_with_plan(plan, model_fn, noise_schedule, x, intermediates=None):
     """Run a compiled loop for a solver-level `model_fn` (noise prediction, as returned by
-    model_wrapper or supplied by the user)."""
+    model_wrapper or supplied by the user).  With `intermediates` (a list to fill) the loop runs step by step from
+    Python (same kernels per evaluation) instead of as one graph replay."""
     info = getattr(model_fn, "_dv", None)
     ns = noise_schedule
     B = x.shape[0]
     with torch.no_grad():
         if info is not None and info["model_type"] == "x_start":
             raw = info["model"]
-            if isinstance(raw, NativeUNetModel) and x.is_cuda and raw.unet.backend == "hip" and not info["model_kwargs"]:
+            if (isinstance(raw, NativeUNetModel) and x.is_cuda and raw.unet.backend == "hip" and not info["model_kwargs"]
+                    and intermediates is None):
                 return raw.run_plan(plan, x)
             kwargs = info["model_kwargs"]
 
@@ -239,7 +256,7 @@ def sample_with_plan(plan, model_fn, noise_schedule, x):
                 a = float(ns.marginal_alpha(torch.tensor([eval_t[eidx]], dtype=torch.float64))[0])
                 s = float(ns.marginal_std(torch.tensor([eval_t[eidx]], dtype=torch.float64))[0])
                 return (xx - s * noise) / a
-        return plan.run_python(x, data_model)
+        return plan.run_python(x, data_model, intermediates)
 
 
 def _eval_times(plan):

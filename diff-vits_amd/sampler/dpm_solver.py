@@ -43,24 +43,28 @@ class DPM_Solver:
         plan = self._plan(N, min(2, N), skip_type, True)
         return torch.as_tensor(plan.timesteps, dtype=torch.float32, device=device)
 
-    def _plan(self, steps, order, skip_type, lower_order_final):
-        key = (steps, order, skip_type, bool(lower_order_final))
+    def _plan(self, steps, order, skip_type, lower_order_final, t_start=None, t_end=None, denoise_to_zero=False):
+        key = (steps, order, skip_type, bool(lower_order_final), t_start, t_end, bool(denoise_to_zero))
         if key not in self._plans:
             self._plans[key] = Plan(_SOLVER_DPMPP, self.noise_schedule._betas, steps, order, skip_type,
-                                    lower_order_final)
+                                    lower_order_final, t_start, t_end, denoise_to_zero)
         return self._plans[key]
 
     def sample(self, x, steps=20, t_start=None, t_end=None, order=2, skip_type="time_uniform", method="multistep",
                lower_order_final=True, denoise_to_zero=False, solver_type="dpmsolver", atol=0.0078, rtol=0.05,
                return_intermediate=False):
-        """x_T -> x_0 (reference dpm_solver.py:1047-1245).  NFE == steps."""
+        """x at t_start (default T) -> x at t_end (default 1/N), reference dpm_solver.py:1047-1245.  NFE == steps
+        (+1 with denoise_to_zero).  return_intermediate=True returns (x, [start point, x after every step, ...])."""
         if method != "multistep":
             raise ValueError("Got wrong method {} (this build implements method='multistep')".format(method))
         if order not in (1, 2, 3):
             raise ValueError("Solver order must be 1 or 2 or 3, got {}".format(order))
-        if solver_type != "dpmsolver" or denoise_to_zero or return_intermediate or t_start is not None or t_end is not None:
-            raise ValueError("solver_type='taylor', denoise_to_zero, return_intermediate and custom t_start/t_end "
-                             "are not supported on this path")
+        if solver_type != "dpmsolver":
+            raise ValueError("solver_type='taylor' is not supported on this path")
         assert steps >= order
-        plan = self._plan(steps, order, skip_type, lower_order_final)
-        return sample_with_plan(plan, self.model_fn, self.noise_schedule, x)
+        plan = self._plan(steps, order, skip_type, lower_order_final, t_start, t_end, denoise_to_zero)
+        if not return_intermediate:
+            return sample_with_plan(plan, self.model_fn, self.noise_schedule, x)
+        inter = []
+        out = sample_with_plan(plan, self.model_fn, self.noise_schedule, x, inter)
+        return out, inter

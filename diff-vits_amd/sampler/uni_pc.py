@@ -38,22 +38,25 @@ class UniPC:
         self.predict_x0 = True
         self._plans = {}
 
-    def _plan(self, steps, order, skip_type, lower_order_final):
-        key = (steps, order, skip_type, bool(lower_order_final))
+    def _plan(self, steps, order, skip_type, lower_order_final, t_start=None, t_end=None, denoise_to_zero=False):
+        key = (steps, order, skip_type, bool(lower_order_final), t_start, t_end, bool(denoise_to_zero))
         if key not in self._plans:
             self._plans[key] = Plan(_SOLVERS[self.variant], self.noise_schedule._betas, steps, order, skip_type,
-                                    lower_order_final)
+                                    lower_order_final, t_start, t_end, denoise_to_zero)
         return self._plans[key]
 
     def sample(self, x, steps=20, t_start=None, t_end=None, order=2, skip_type="time_uniform", method="multistep",
                lower_order_final=True, denoise_to_zero=False, atol=0.0078, rtol=0.05, return_intermediate=False):
-        """x_T -> x_0 (reference uni_pc.py:590-672).  NFE == steps."""
+        """x at t_start (default T) -> x at t_end (default 1/N), reference uni_pc.py:590-672.  NFE == steps (+1 with
+        denoise_to_zero).  return_intermediate=True returns (x, [start point, x after every step, ...])."""
         if method != "multistep":
             raise ValueError("Got wrong method {}".format(method))
         if order not in (1, 2, 3):
             raise ValueError("UniPC order must be 1, 2 or 3 in this build, got {}".format(order))
-        if denoise_to_zero or return_intermediate or t_start is not None or t_end is not None:
-            raise ValueError("denoise_to_zero, return_intermediate and custom t_start/t_end are not supported")
         assert steps >= order
-        plan = self._plan(steps, order, skip_type, lower_order_final)
-        return sample_with_plan(plan, self.model_fn, self.noise_schedule, x)
+        plan = self._plan(steps, order, skip_type, lower_order_final, t_start, t_end, denoise_to_zero)
+        if not return_intermediate:
+            return sample_with_plan(plan, self.model_fn, self.noise_schedule, x)
+        inter = []
+        out = sample_with_plan(plan, self.model_fn, self.noise_schedule, x, inter)
+        return out, inter

@@ -158,6 +158,12 @@ typedef enum { DV_SKIP_TIME_UNIFORM = 0, DV_SKIP_TIME_QUADRATIC = 1, DV_SKIP_LOG
  * betas: HOST float32[n_betas] (the reference's `self.betas`, model3.py:990). */
 int dv_sampler_plan(int32_t solver, const float* betas, int32_t n_betas, int32_t steps, int32_t order,
                     int32_t skip_type, int32_t lower_order_final, dv_plan** out);
+/* The same with the remaining multistep options of DPM_Solver.sample / UniPC.sample (dpm_solver.py:1047-1050,
+ * uni_pc.py:590-591): integrate from t_start (<= 0: T = 1) down to t_end (<= 0: 1/N); denoise_to_zero appends the
+ * data prediction at t_end as one more model evaluation (dpm_solver.py:1234-1240). */
+int dv_sampler_plan_ex(int32_t solver, const float* betas, int32_t n_betas, int32_t steps, int32_t order,
+                       int32_t skip_type, int32_t lower_order_final, double t_start, double t_end,
+                       int32_t denoise_to_zero, dv_plan** out);
 void dv_plan_destroy(dv_plan* p);
 
 /* Introspection for tests: number of model evaluations, and the plan's tables.

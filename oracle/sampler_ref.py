@@ -130,13 +130,16 @@ def _dpmpp_update(ns, x, m_list, t_list, t, order):
 
 
 def dpm_solver_pp_sample(model, betas, x, steps=20, order=2, skip_type="time_uniform",
-                         lower_order_final=True, return_intermediate=False):
+                         lower_order_final=True, return_intermediate=False, t_start=None, t_end=None,
+                         denoise_to_zero=False):
     """DPM_Solver(model_fn, ns, 'dpmsolver++').sample(x, steps, order, skip_type,
     method='multistep'), dpm_solver.py:1047-1245 (multistep branch :1171-1213).
     `model(x, t_input)` is the raw x0-prediction network."""
     ns = Schedule(betas, clip=True)
     fn = wrap_x_start_model(model, ns)
-    t_0, t_T = 1.0 / ns.total_N, ns.T
+    # dpm_solver.py:1157-1158: t_0 = 1/N unless t_end is given, t_T = T unless t_start is given
+    t_0 = 1.0 / ns.total_N if t_end is None else t_end
+    t_T = ns.T if t_start is None else t_start
     assert steps >= order
     ts = time_steps(ns, skip_type, t_T, t_0, steps)
     inter = []
@@ -157,6 +160,9 @@ def dpm_solver_pp_sample(model, betas, x, steps=20, order=2, skip_type="time_uni
         m_list = m_list[1:] + [None]
         if step < steps:
             m_list[-1] = fn(x, t)
+    if denoise_to_zero:            # dpm_solver.py:1234-1240: x0 prediction at t_0 (one more evaluation)
+        x = fn(x, torch.ones((1,)) * t_0)
+        inter.append(x)
     return (x, inter) if return_intermediate else x
 
 
@@ -210,12 +216,13 @@ def _unipc_bh_update(ns, fn, x, m_list, t_list, t, order, variant, use_corrector
 
 
 def unipc_sample(model, betas, x, steps=20, order=2, skip_type="time_uniform", variant="bh2",
-                 lower_order_final=True, return_intermediate=False):
+                 lower_order_final=True, return_intermediate=False, t_start=None, t_end=None, denoise_to_zero=False):
     """UniPC(model_fn, ns, variant=...).sample(x, steps, order, skip_type, 'multistep'),
     uni_pc.py:590-672."""
     ns = Schedule(betas, clip=False)
     fn = wrap_x_start_model(model, ns)
-    t_0, t_T = 1.0 / ns.total_N, ns.T
+    t_0 = 1.0 / ns.total_N if t_end is None else t_end        # uni_pc.py:596-597
+    t_T = ns.T if t_start is None else t_start
     assert steps >= order
     ts = time_steps(ns, skip_type, t_T, t_0, steps)
     inter = []
@@ -236,6 +243,9 @@ def unipc_sample(model, betas, x, steps=20, order=2, skip_type="time_uniform", v
         m_list = m_list[1:] + [None]
         if step < steps:
             m_list[-1] = m_x
+    if denoise_to_zero:            # uni_pc.py:660-666
+        x = fn(x, torch.ones((1,)) * t_0)
+        inter.append(x)
     return (x, inter) if return_intermediate else x
 
 

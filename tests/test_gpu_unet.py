@@ -380,3 +380,26 @@ def test_unet_large_mean_activations_within_budget():
     err = rel_l2(y, ref)
     print("large-mean activations: rel-L2 %.2e" % err)
     assert err < 1e-3
+
+
+def test_native_sampler_options_graph_equals_stepwise():
+    """t_start / t_end / denoise_to_zero inside the hipGraph loop == the same plan stepped from Python
+    (return_intermediate=True forces the step-by-step path); UniPC likewise."""
+    from diff_vits_amd import synth
+    from diff_vits_amd.sampler import dpm_solver, uni_pc
+    m, kw, sd, sample, t, enc, mask = _build("cfg1")
+    x, cond, enc_np, mask_np = synth.make_inputs(1, 80, 256, 128, seed=77)
+    x, cond = torch.from_numpy(x).cuda(), torch.from_numpy(cond).cuda()
+    enc_t, mask_t = torch.from_numpy(enc_np).cuda(), torch.from_numpy(mask_np).cuda()
+    betas = torch.from_numpy(synth.make_betas())
+    for mod, make in ((dpm_solver, lambda fn, ns: dpm_solver.DPM_Solver(fn, ns, algorithm_type="dpmsolver++")),
+                      (uni_pc, lambda fn, ns: uni_pc.UniPC(fn, ns, variant="bh2"))):
+        ns = mod.NoiseScheduleVP("discrete", betas=betas)
+        native = mod.NativeUNetModel(m, cond, enc_t, mask_t)
+        fn = mod.model_wrapper(native, ns, model_type="x_start")
+        opts = dict(steps=6, order=2, skip_type="time_uniform", t_start=0.7, t_end=0.1, denoise_to_zero=True)
+        with torch.no_grad():
+            a = make(fn, ns).sample(x.clone(), **opts)
+            b, inter = make(fn, ns).sample(x.clone(), return_intermediate=True, **opts)
+        assert len(inter) == 6 + 2 and torch.isfinite(a).all()
+        assert rel_l2(a.cpu().numpy(), b.cpu().numpy()) < 1e-5

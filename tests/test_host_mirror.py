@@ -148,3 +148,62 @@ def test_solver_error_behaviour():
         dpm_solver.NoiseScheduleVP("linear")
     with pytest.raises(AssertionError):
         dpm_solver.model_wrapper(lambda xx, t: xx, ns, model_type="bogus")
+
+
+# ---- remaining multistep options of DPM_Solver.sample / UniPC.sample (t_start / t_end, denoise_to_zero,
+#      return_intermediate) against the reference's outputs (tools/make_golden_sampler_opts.py) -------------------------
+OPTION_CASES = {
+    "dpm_window": ("dpm", dict(steps=12, order=2, skip_type="time_uniform", t_start=0.8, t_end=0.05)),
+    "dpm_dtz_logsnr": ("dpm", dict(steps=8, order=3, skip_type="logSNR", denoise_to_zero=True)),
+    "dpm_inter_quad": ("dpm", dict(steps=10, order=2, skip_type="time_quadratic", return_intermediate=True)),
+    "dpm_all": ("dpm", dict(steps=9, order=2, skip_type="time_uniform", t_start=0.95, t_end=0.01, denoise_to_zero=True,
+                            return_intermediate=True)),
+    "unipc_window_dtz": ("unipc", dict(steps=10, order=2, skip_type="time_uniform", t_start=0.9, t_end=0.02, denoise_to_zero=True,
+                                        return_intermediate=True)),
+    "unipc_o3_logsnr": ("unipc", dict(steps=7, order=3, skip_type="logSNR", t_end=0.004)),
+}
+
+
+@pytest.mark.parametrize("key", sorted(OPTION_CASES))
+def test_sampler_options_match_reference(gold, key):
+    g = gold("sampler_options.npz")
+    solver, kw = OPTION_CASES[key]
+    B = 2 if solver == "dpm" else 1
+    x = torch.from_numpy(synth.normal(1234, "opts." + key, (B, 5, 24)))
+    betas = torch.from_numpy(synth.make_betas())
+    mod = dpm_solver if solver == "dpm" else uni_pc
+    ns = mod.NoiseScheduleVP("discrete", betas=betas)
+    fn = mod.model_wrapper(lambda xx, t, **k: sampler_ref.standin_model(xx, t), ns, model_type="x_start")
+    if solver == "dpm":
+        r = mod.DPM_Solver(fn, ns, algorithm_type="dpmsolver++").sample(x.clone(), method="multistep", **kw)
+    else:
+        r = mod.UniPC(fn, ns, variant="bh2").sample(x.clone(), method="multistep", **kw)
+    if kw.get("return_intermediate"):
+        out, inter = r
+        ref_inter = g[key + "_inter"]
+        assert len(inter) == len(ref_inter)
+        for a, b in zip(inter, ref_inter):
+            assert rel_l2(a.numpy(), b) < 2e-5
+    else:
+        out = r
+    assert rel_l2(out.numpy(), g[key + "_x"]) < 2e-5
+    # oracle on the same case
+    okw = dict(kw)
+    args = (okw.pop("steps"), okw.pop("order"), okw.pop("skip_type"))
+    okw.pop("return_intermediate", None)
+    if solver == "dpm":
+        o = sampler_ref.dpm_solver_pp_sample(sampler_ref.standin_model, betas, x.clone(), *args, **okw)
+    else:
+        o = sampler_ref.unipc_sample(sampler_ref.standin_model, betas, x.clone(), *args, "bh2", **okw)
+    assert rel_l2(o.numpy(), g[key + "_x"]) < 1e-6
+
+
+def test_sampler_option_errors_like_reference():
+    betas = torch.from_numpy(synth.make_betas())
+    ns = dpm_solver.NoiseScheduleVP("discrete", betas=betas)
+    fn = dpm_solver.model_wrapper(lambda xx, t, **k: xx, ns, model_type="x_start")
+    x = torch.zeros(1, 2, 4)
+    with pytest.raises(AssertionError):
+        dpm_solver.DPM_Solver(fn, ns, algorithm_type="dpmsolver++").sample(x, steps=4, t_end=0.0)
+    with pytest.raises(ValueError):
+        dpm_solver.DPM_Solver(fn, ns, algorithm_type="dpmsolver++").sample(x, steps=4, method="adaptive")
