@@ -175,6 +175,8 @@ hipError_t launch_pack_weight(const PackSpec& s, bf16_t* hi, bf16_t* lo, int Kp,
 // bias'[n] = bias[n] + sum_c W[n,c]*beta[c]   (LayerNorm beta fold), rows permuted like geglu packing
 hipError_t launch_fold_bias(const float* W, const float* bias, const float* beta, float* out, int N, int C,
                             int n_off, int geglu, hipStream_t st);
+// out[N, K] = A[N, C] * Bm[C, K] in fp64 accumulation (weight products at prepare time)
+hipError_t launch_matmul_f32(const float* A, const float* Bm, float* out, int N, int Cc, int K, hipStream_t st);
 hipError_t launch_copy_f32(const float* src, float* dst, int64_t n, hipStream_t st);
 hipError_t launch_fill_f32(float* dst, float v, int64_t n, hipStream_t st);
 // sampler update: out = c[0]*x + c[1]*m0 + c[2]*m1 + c[3]*m2 + c[4]*m3 (coefficient row of 8 floats on device)

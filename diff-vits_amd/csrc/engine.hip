@@ -236,6 +236,7 @@ struct Builder {
   std::string err;
   hipStream_t pack_stream = nullptr;
   bool fuse_ln = [] { const char* e = getenv("DVITS_FUSE_LN"); return !(e && e[0] == '0'); }();   // default on
+  bool merge_ff = [] { const char* e = getenv("DVITS_MERGE_FF"); return !(e && e[0] == '0'); }();  // default on
 
   // ---- weights
   const RawW* raw(const std::string& name) {
@@ -567,9 +568,10 @@ struct Builder {
                                {{tb + "attn2.to_out.0.bias", "", "", "", C, 0, 0, 0}});
     const PackedW* w_gg = pack(tb + "geglu", 8 * C, C, {{tb + "ff.net.0.proj.weight", 0, C, 1, C, 0, 0, tb + "norm3.weight", 1}},
                                {{tb + "ff.net.0.proj.bias", "", tb + "ff.net.0.proj.weight", tb + "norm3.bias", 8 * C, C, 0, 1}});
-    const PackedW* w_ff = pack(tb + "ffout", C, 4 * C, {{tb + "ff.net.2.weight", 0, 4 * C, 1, 4 * C, 0, 0, "", 0}},
+    const bool merged_ffproj = merge_ff && fuse_ln && !u->keep_intermediates;
+    const PackedW* w_ff = merged_ffproj ? w_gg : pack(tb + "ffout", C, 4 * C, {{tb + "ff.net.2.weight", 0, 4 * C, 1, 4 * C, 0, 0, "", 0}},
                                {{tb + "ff.net.2.bias", "", "", "", C, 0, 0, 0}});
-    const PackedW* w_out = pack(p + "proj_out", C, C, {{p + "proj_out.weight", 1, C, 1, C, 0, 0, "", 0}},
+    const PackedW* w_out = merged_ffproj ? w_gg : pack(p + "proj_out", C, C, {{p + "proj_out.weight", 1, C, 1, C, 0, 0, "", 0}},
                                 {{p + "proj_out.bias", "", "", "", C, 0, 0, 0}});
     if (!w_in || !w_qkv || !w_o1 || !w_q2 || !w_o2 || !w_gg || !w_ff || !w_out) return Act{};
     (void)D;
@@ -650,6 +652,37 @@ struct Builder {
     {
       GemmParams g = gp_base(Tn, M, 8 * C);
       g.epi = EPI_GEGLU; g.out_hi = gg.hi; g.out_lo = gg.lo; g.ldo = 4 * C; ln_consume(g, l3, h3, w_gg); gemm(ops, g, w_gg, C);
+    }
+    // ff.net.2 and proj_out are two k=1 contractions with only the residual add between them:
+    //   proj_out(h3 + gg W2^T + b2) + x = h3 Wo^T + gg (Wo W2)^T + (Wo b2 + bo) + x
+    // -> ONE contraction over two K-segments [raw planes of h3 | GEGLU product] (16 launches fewer per forward).
+    // Needs the raw h3 planes of the fused-LayerNorm schedule; the per-layer probe build keeps the two-step form.
+    if (merged_ffproj) {
+      const std::string mw = tb + "__ffproj.weight", mb = tb + "__ffproj.bias";
+      if (!dry) {
+        const float* Wo = W(p + "proj_out.weight"); const float* W2 = W(tb + "ff.net.2.weight");
+        const float* bo = W(p + "proj_out.bias"); const float* b2 = W(tb + "ff.net.2.bias");
+        float* dw = derived(mw, {C, 4 * C});
+        float* db = derived(mb, {C});
+        if (!Wo || !W2 || !bo || !b2 || !dw || !db) return Act{};
+        (void)launch_matmul_f32(Wo, W2, dw, C, C, 4 * C, pack_stream);
+        (void)launch_fold_bias(Wo, bo, b2, db, C, C, 0, 0, pack_stream);
+      }
+      const PackedW* w_m = pack(p + "ffproj", C, 5 * C, {{p + "proj_out.weight", 1, C, 1, C, 0, 0, "", 0}, {mw, 0, 4 * C, 1, 4 * C, C, 0, "", 0}},
+                                {{mb, "", "", "", C, 0, 0, 0}});
+      if (!w_m) return Act{};
+      Act out{};
+      out.p = alloc((size_t)M * C); out.C = C; out.T = Tn; out.stat = alloc_stat(Tn, C);
+      {
+        GemmParams g = gp_base(Tn, M, C);
+        g.seg[0] = seg(l3.pl, C, Planes{}, 0, 1, 0);
+        g.seg[1] = seg(gg, 4 * C, Planes{}, 0, 1, 0); g.nseg = 2;
+        g.epi = EPI_RESIDUAL; g.res = x.p; g.out = out.p; g.stats = out.stat; gemm(ops, g, w_m, 5 * C);
+      }
+      ln_release(l3);
+      release(gg); release(h3);
+      probe(p.substr(0, p.size() - 1), out.p, Tn, C);
+      return out;
     }
     ln_release(l3);
     Planes h4 = alloc_planes((size_t)M * C);
@@ -936,6 +969,22 @@ struct Builder {
     }
     if (!err.empty()) return dv_fail(DV_ERR_MISSING_WEIGHT, "%s", err.c_str());
     return DV_OK;
+  }
+
+  // engine-made weight (a product of two state-dict tensors), registered under `name` like a state-dict entry and
+  // recomputed at every prepare: returns the device buffer to fill, or null in the dry pass / on failure
+  float* derived(const std::string& name, const std::vector<int64_t>& shape) {
+    if (dry) return nullptr;
+    size_t n = 1;
+    for (auto v : shape) n *= (size_t)v;
+    RawW& r = u->w[name];
+    if (r.numel != n) {
+      if (r.p) (void)hipFree(r.p);
+      r.p = nullptr;
+      if (hipMalloc((void**)&r.p, n * 4) != hipSuccess) { err = "hipMalloc(derived weight) failed"; return nullptr; }
+    }
+    r.shape = shape; r.numel = n;
+    return r.p;
   }
 
   // engine-made constant vector registered like a weight (per-source-channel scale for pack())

@@ -734,6 +734,20 @@ hipError_t launch_fold_bias(const float* W, const float* bias, const float* beta
   return hipGetLastError();
 }
 
+// out[n, k] = sum_c A[n, c] * Bm[c, k]   (fp64 accumulate; one-off weight products at prepare time)
+__global__ __launch_bounds__(256) void k_matmul_f32(const float* __restrict__ A, const float* __restrict__ Bm,
+                                                     float* __restrict__ out, int N, int Cc, int K) {
+  const int k = blockIdx.x * 256 + threadIdx.x, n = blockIdx.y;
+  if (k >= K || n >= N) return;
+  double s = 0;
+  for (int c = 0; c < Cc; ++c) s += (double)A[(size_t)n * Cc + c] * (double)Bm[(size_t)c * K + k];
+  out[(size_t)n * K + k] = (float)s;
+}
+hipError_t launch_matmul_f32(const float* A, const float* Bm, float* out, int N, int Cc, int K, hipStream_t st) {
+  hipLaunchKernelGGL(k_matmul_f32, dim3((K + 255) / 256, N), dim3(256), 0, st, A, Bm, out, N, Cc, K);
+  return hipGetLastError();
+}
+
 // ---------------------------------------------------------------------------------------
 __global__ void k_copy_f32(const float* __restrict__ src, float* __restrict__ dst, int64_t n) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)

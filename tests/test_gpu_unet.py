@@ -309,7 +309,8 @@ def test_unet_unfused_layernorm_mode(gold):
         os.environ.pop("DVITS_FUSE_LN", None)
     assert rel_l2(y.cpu().numpy(), gold("unet_oddT.npz")["y"]) < 2e-4
     m2, *_ = _build("oddT")
-    assert m2.hip_engine().prepare(2, 100, 50) and m2.hip_engine().stats()[0] == n_launch - 48
+    # default schedule: 48 LayerNorm launches and (merged ff.net.2 + proj_out) 16 GEMM launches fewer
+    assert m2.hip_engine().prepare(2, 100, 50) and m2.hip_engine().stats()[0] == n_launch - 64
 
 
 def test_persistent_per_xcd_schedule_matches_per_launch():
@@ -403,3 +404,25 @@ def test_native_sampler_options_graph_equals_stepwise():
             b, inter = make(fn, ns).sample(x.clone(), return_intermediate=True, **opts)
         assert len(inter) == 6 + 2 and torch.isfinite(a).all()
         assert rel_l2(a.cpu().numpy(), b.cpu().numpy()) < 1e-5
+
+
+def test_merged_ff_proj_out_matches_two_step(gold):
+    """Default schedule: ff.net.2 and proj_out of every transformer block as ONE contraction over [h3 | GEGLU product]
+    with the pre-multiplied weight Wo W2 (16 launches fewer).  DVITS_MERGE_FF=0 keeps the reference's two steps; both
+    meet the golden vector, and they agree with each other to rounding."""
+    m, kw, sd, sample, t, enc, mask = _build("oddT")
+    args = (torch.from_numpy(sample).cuda(), torch.from_numpy(t).cuda(), torch.from_numpy(enc).cuda())
+    with torch.no_grad():
+        y = m(*args, encoder_attention_mask=torch.from_numpy(mask).cuda()).sample
+    n_merged = m.hip_engine().stats()[0]
+    os.environ["DVITS_MERGE_FF"] = "0"
+    try:
+        m2, *_ = _build("oddT")
+        with torch.no_grad():
+            y2 = m2(*args, encoder_attention_mask=torch.from_numpy(mask).cuda()).sample
+        n_two = m2.hip_engine().stats()[0]
+    finally:
+        os.environ.pop("DVITS_MERGE_FF", None)
+    g = gold("unet_oddT.npz")["y"]
+    assert rel_l2(y.cpu().numpy(), g) < 2e-4 and rel_l2(y2.cpu().numpy(), g) < 2e-4
+    assert rel_l2(y.cpu().numpy(), y2.cpu().numpy()) < 5e-5 and n_two == n_merged + 16
