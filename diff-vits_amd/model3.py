@@ -342,3 +342,110 @@ class NaturalSpeech2(nn.Module):
                                "or call sample_from_prior(content, refer, ...)")
         content, refer = self.vits.infer(text, text_lengths, spec, spec_lengths, tone, language)
         return self.sample_from_prior(content, refer, text_lengths, spec_lengths, vocos, sample_method, noise)
+
+
+# ---- SURVEY.md §8f rank 3 (inference side of the VITS prior, from the text encoder's outputs onward) ------------------
+def _conv1x1(conv, x, native):
+    """k = 1 Conv1d on [B, C, T]: the implicit-GEMM kernel through the C ABI (dv_op_conv1d) on the HIP backend."""
+    if not native:
+        return conv(x)
+    from . import _lib
+    x32 = x.detach().to(torch.float32).contiguous()
+    w = conv.weight.detach().to(torch.float32).contiguous()
+    b = conv.bias.detach().to(torch.float32).contiguous()
+    out = torch.empty((x32.shape[0], w.shape[0], x32.shape[2]), device=x.device, dtype=torch.float32)
+    _lib.check(_lib.lib().dv_op_conv1d(_lib.ptr(x32), _lib.ptr(w), _lib.ptr(b), _lib.ptr(out), x32.shape[0], x32.shape[1],
+                                       x32.shape[2], w.shape[0], 1, 1, 0, _lib.PREC_BF16X3, _lib.stream_ptr()), "dv_op_conv1d")
+    return out.to(x.dtype)
+
+
+def generate_path(duration, mask):
+    """reference commons.py:128-143.  duration [b, 1, t_x], mask [b, 1, t_y, t_x] -> monotonic alignment [b, 1, t_y, t_x]."""
+    b, _, t_y, t_x = mask.shape
+    cum = torch.cumsum(duration, -1).view(b * t_x)
+    path = sequence_mask(cum, t_y).to(mask.dtype).view(b, t_x, t_y)
+    path = path - F.pad(path, (0, 0, 1, 0, 0, 0))[:, :-1]
+    return path.unsqueeze(1).transpose(2, 3) * mask
+
+
+class DurationPredictor_unet(nn.Module):
+    """reference model3.py:275-321: 1x1 convs around the UNet at the duration-predictor configuration
+    (block_out_channels = (h/4, h/4, h/2, h/2), out_channels 1), integer timestep 1, float [B, 1, L] prompt mask."""
+
+    def __init__(self, in_channels, hidden_channels, prompt_channels, kernel_size, p_dropout, out_channels=1, n_heads=8,
+                 backend=None):
+        super().__init__()
+        self.n_heads, self.p_dropout = n_heads, p_dropout
+        self.pre = nn.Conv1d(in_channels, hidden_channels, kernel_size=1)
+        self.enc = UNet1DConditionModel(
+            in_channels=in_channels, out_channels=out_channels,
+            block_out_channels=(hidden_channels // 4, hidden_channels // 4, hidden_channels // 2, hidden_channels // 2),
+            norm_num_groups=8, cross_attention_dim=hidden_channels, attention_head_dim=n_heads, addition_embed_type="text",
+            resnet_time_scale_shift="scale_shift", backend=backend)
+        self.prompt_proj = nn.Conv1d(prompt_channels, hidden_channels, 1)
+        self.backend = self.enc.backend
+
+    def forward(self, x, x_lengths, prompt, prompt_lengths):
+        native = self.backend == "hip" and x.is_cuda
+        x, prompt = x.detach(), prompt.detach()
+        prompt = _conv1x1(self.prompt_proj, prompt, native)
+        x_mask = torch.unsqueeze(sequence_mask(x_lengths, x.size(2)), 1).to(x.dtype)
+        prompt_mask = torch.unsqueeze(sequence_mask(prompt_lengths, prompt.size(2)), 1).to(x.dtype)
+        x = _conv1x1(self.pre, x, native) * x_mask
+        prompt = prompt * prompt_mask
+        x = self.enc(x, 1, prompt.transpose(1, 2), encoder_attention_mask=prompt_mask).sample
+        return x * x_mask
+
+
+class VITS(nn.Module):
+    """Inference side of the reference's prior (model3.py:646-860): `infer` = reference encoder (TextTimeEmbedding, one
+    head) -> text encoder -> DurationPredictor_unet -> monotonic alignment -> prior sample -> 6-layer `o_proj`
+    PromptEncoder with speaker conditioning.  Parameter names of `ref_enc.*`, `dp.*`, `o_proj.*` are the reference's.
+
+    The text encoder (`enc_p`: attentions.Encoder with relative-position attention) is not part of this package: pass
+    any module with the reference signature `enc_p(x, x_lengths, tone, language, g) -> (x, m_p, logs_p, x_mask)` (the
+    reference's own `TextEncoder` instance works), or call `infer_from_encoder` with those four tensors.  The duration
+    predictor's UNet and `o_proj` run on the HIP engine (backend='hip'); the once-per-utterance glue (reference encoder,
+    alignment path, gathers) is a handful of torch ops on the same device.  `noise=` fixes the prior noise (the reference
+    draws torch.randn_like)."""
+
+    def __init__(self, n_vocab=None, spec_channels=None, inter_channels=128, hidden_channels=256, gin_channels=256, enc_p=None,
+                 backend=None, **unused):
+        super().__init__()
+        from .unet1d.embeddings import TextTimeEmbedding
+        self.inter_channels, self.hidden_channels, self.gin_channels = inter_channels, hidden_channels, gin_channels
+        if enc_p is not None:
+            self.enc_p = enc_p
+        self.dp = DurationPredictor_unet(hidden_channels, 256, 100, 3, 0.5, backend=backend)
+        self.ref_enc = TextTimeEmbedding(100, gin_channels, 1)
+        self.o_proj = PromptEncoder(inter_channels, hidden_channels, inter_channels, 6, 0.2, gin_channels=gin_channels,
+                                    backend=backend)
+
+    @torch.no_grad()
+    def infer_from_encoder(self, x, m_p, logs_p, x_mask, x_lengths, y, y_lengths, g=None, noise_scale=0.667, length_scale=1,
+                           noise=None):
+        """reference model3.py:839-860 (after the `enc_p` call).  Returns (z [B, inter, T'], y, y_lengths')."""
+        if g is None:
+            g = self.ref_enc(y.transpose(1, 2)).unsqueeze(-1)
+        logw = self.dp(x, x_lengths, y, y_lengths)
+        w = torch.exp(logw) * x_mask * length_scale
+        w_ceil = torch.ceil(w)
+        y_len = torch.clamp_min(torch.sum(w_ceil, [1, 2]), 1).long()
+        y_mask = torch.unsqueeze(sequence_mask(y_len, None), 1).to(x_mask.dtype)
+        attn = generate_path(w_ceil, torch.unsqueeze(x_mask, 2) * torch.unsqueeze(y_mask, -1))
+        m_p = torch.matmul(attn.squeeze(1), m_p.transpose(1, 2)).transpose(1, 2)
+        logs_p = torch.matmul(attn.squeeze(1), logs_p.transpose(1, 2)).transpose(1, 2)
+        eps = torch.randn_like(m_p) if noise is None else noise.to(m_p)
+        z_p = m_p + eps * torch.exp(logs_p) * noise_scale
+        return self.o_proj(z_p, y_len, g), y, y_len
+
+    @torch.no_grad()
+    def infer(self, x, x_lengths, y, y_lengths, tone, language, noise_scale=0.667, length_scale=1, noise_scale_w=0.8,
+              max_len=None, sdp_ratio=0, noise=None):
+        """reference model3.py:817-860 (same positional signature); returns (z, y)."""
+        if not hasattr(self, "enc_p"):
+            raise RuntimeError("VITS.infer needs the text encoder: construct with enc_p=<module> or call infer_from_encoder")
+        g = self.ref_enc(y.transpose(1, 2)).unsqueeze(-1)
+        x, m_p, logs_p, x_mask = self.enc_p(x, x_lengths, tone, language, g)
+        z, y, _ = self.infer_from_encoder(x, m_p, logs_p, x_mask, x_lengths, y, y_lengths, g, noise_scale, length_scale, noise)
+        return z, y

@@ -124,3 +124,23 @@ def test_sample_dpmsolver_hip_matches_oracle(gold):
                                 torch.from_numpy(g["text_lengths"]), torch.from_numpy(g["spec_lengths"]),
                                 torch.from_numpy(noise), "dpmsolver", cfg["train"]["timesteps"])
     assert rel_l2(mel.cpu().numpy(), ref.numpy()) < 5e-4
+
+
+# ---- the VITS prior from the text encoder's outputs onward, HIP backend ---------------
+def test_prior_hip_matches_reference(gold):
+    """Duration predictor (UNet engine at the (64,64,128,128) configuration + native 1x1 convs), alignment and the 6-layer
+    speaker-conditioned o_proj prompt encoder (dv_penc_*) against the reference's vits.infer output."""
+    from test_prompt_cpu import prior_case
+    from diff_vits_amd import synth
+    from diff_vits_amd.model3 import VITS
+    g, sd, y = prior_case(gold)
+    m = VITS(backend="hip").eval()
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    m = m.cuda()
+    noise = torch.from_numpy(synth.normal(1234, "prior.noise", tuple(g["z"].shape))).cuda()
+    dev = lambda a: torch.from_numpy(a).cuda()       # noqa: E731
+    z, _, ylen = m.infer_from_encoder(dev(g["enc_x"]), dev(g["enc_m_p"]), dev(g["enc_logs_p"]), dev(g["enc_x_mask"]),
+                                      dev(g["x_lengths"]), dev(y), dev(g["y_lengths"]), noise=noise)
+    assert np.array_equal(ylen.cpu().numpy(), g["y_len_out"])
+    assert rel_l2(z.cpu().numpy(), g["z"]) < 2e-4
+    assert m.o_proj.hip_engine().stats()[0] == 2 + 1 + 6 * 6 + 2

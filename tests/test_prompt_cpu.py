@@ -143,3 +143,57 @@ def test_mirror_sample_torch_backend_matches_reference(gold):
                             sample_method="ddim")
     with pytest.raises(RuntimeError):
         NaturalSpeech2(cfg, backend="torch").sample(None, None, None, None, None, None, None)
+
+
+# ---- the VITS prior from the text encoder's outputs onward ------------------------------
+def prior_case(gold):
+    g = gold("prior_infer.npz")
+    names = [str(n) for n in g["names"]]
+    shapes = {n: ast.literal_eval(str(s)) for n, s in zip(names, g["shapes"])}
+    sd = synth.make_state_dict(shapes, seed=1234)
+    L = int(g["L"])
+    y = synth.normal(1234, "prior.refer", (2, 100, L))
+    return g, sd, y
+
+
+def test_oracle_prior_matches_reference(gold):
+    from oracle import prior_ref
+    g, sd, y = prior_case(gold)
+    tsd = {k: torch.from_numpy(v) for k, v in sd.items()}
+    with torch.no_grad():
+        z, _, ylen, logw = prior_ref.infer_from_encoder(
+            tsd, torch.from_numpy(g["enc_x"]), torch.from_numpy(g["enc_m_p"]), torch.from_numpy(g["enc_logs_p"]),
+            torch.from_numpy(g["enc_x_mask"]), torch.from_numpy(g["x_lengths"]), torch.from_numpy(y),
+            torch.from_numpy(g["y_lengths"]), lambda shp: torch.from_numpy(synth.normal(1234, "prior.noise", shp)))
+    assert np.array_equal(ylen.numpy(), g["y_len_out"]) and rel_l2(z.numpy(), g["z"]) < 1e-6
+    # the integer durations of this fixture are not within rounding of a boundary (the GPU test relies on it)
+    w = np.exp(g["logw"]) * g["enc_x_mask"]
+    assert np.abs(w - np.round(w))[g["enc_x_mask"] > 0].min() > 1e-3
+
+
+def test_mirror_prior_torch_backend_matches_reference(gold):
+    from diff_vits_amd.model3 import VITS, generate_path
+    g, sd, y = prior_case(gold)
+    m = VITS(backend="torch").eval()
+    own = m.state_dict()
+    assert sorted(own) == sorted(sd) and all(tuple(own[k].shape) == tuple(sd[k].shape) for k in sd)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    noise = torch.from_numpy(synth.normal(1234, "prior.noise", tuple(g["z"].shape)))
+    z, yy, ylen = m.infer_from_encoder(torch.from_numpy(g["enc_x"]), torch.from_numpy(g["enc_m_p"]), torch.from_numpy(g["enc_logs_p"]),
+                                       torch.from_numpy(g["enc_x_mask"]), torch.from_numpy(g["x_lengths"]), torch.from_numpy(y),
+                                       torch.from_numpy(g["y_lengths"]), noise=noise)
+    assert np.array_equal(ylen.numpy(), g["y_len_out"]) and rel_l2(z.numpy(), g["z"]) < 1e-5
+
+    class Enc(torch.nn.Module):          # any module with the reference's enc_p signature plugs in
+        def forward(self, x, x_lengths, tone, language, g_):
+            return (torch.from_numpy(gold("prior_infer.npz")["enc_x"]), torch.from_numpy(gold("prior_infer.npz")["enc_m_p"]),
+                    torch.from_numpy(gold("prior_infer.npz")["enc_logs_p"]), torch.from_numpy(gold("prior_infer.npz")["enc_x_mask"]))
+    m.enc_p = Enc()
+    z2, _ = m.infer(None, torch.from_numpy(g["x_lengths"]), torch.from_numpy(y), torch.from_numpy(g["y_lengths"]), None, None, noise=noise)
+    assert torch.equal(z2, z)
+    with pytest.raises(RuntimeError):
+        VITS(backend="torch").infer(None, None, torch.from_numpy(y), None, None, None)
+    # alignment path: each output frame belongs to exactly one token, in order
+    d = torch.tensor([[[2.0, 0.0, 3.0]]])
+    p = generate_path(d, torch.ones(1, 1, 5, 3))
+    assert p.sum().item() == 5 and p[0, 0, :, 0].tolist() == [1, 1, 0, 0, 0] and p[0, 0, :, 2].tolist() == [0, 0, 1, 1, 1]

@@ -97,6 +97,7 @@ def main():
             shapes=np.array([repr(shapes[k]) for k in sorted(shapes) if k.startswith("prompt_encoder.")]),
             **{"probe_" + k: v.numpy() for k, v in probes.items()})
     sample_golden(model3, args.ref)
+    prior_golden(model3, args.ref)
 
 
 def sample_golden(model3, ref):
@@ -145,6 +146,56 @@ def sample_golden(model3, ref):
                         spec_lengths=spec_lengths.numpy(), mel=mel.numpy(), audio=audio.numpy(),
                         diffusion_encoder=np.array(repr(cfg["diffusion_encoder"])), timesteps=cfg["train"]["timesteps"],
                         **{"buf_" + k: v for k, v in bufs.items()})
+
+
+def prior_golden(model3, ref):
+    """VITS.infer (model3.py:817-860) with synthetic weights in ref_enc / dp / o_proj, the reference's own randomly
+    initialised text encoder (its outputs are captured and stored: the tests start from them), torch.randn_like
+    replaced by the seeded generator."""
+    import json
+    from oracle import prior_ref
+    cfg = json.load(open(os.path.join(ref, "config.json")))
+    torch.manual_seed(0)
+    m = model3.NaturalSpeech2(cfg).eval()
+    v = m.vits
+    shapes = {k: tuple(t.shape) for k, t in v.state_dict().items() if k.split(".")[0] in ("ref_enc", "dp", "o_proj")}
+    sd = synth.make_state_dict(shapes, seed=1234)
+    missing = v.load_state_dict({k: torch.from_numpy(t) for k, t in sd.items()}, strict=False)
+    assert not [k for k in missing.unexpected_keys]
+    B, Tx, L = 2, 11, 36
+    n_sym = v.enc_p.emb.weight.shape[0]
+    text = torch.from_numpy((synth.uniform(1234, "prior.text", (B, Tx)) * 0.5 + 0.5) * (n_sym - 1)).long()
+    tone = torch.zeros((B, Tx), dtype=torch.long)
+    lang = torch.zeros((B, Tx), dtype=torch.long)
+    x_lengths = torch.tensor([Tx, Tx - 3])
+    y = torch.from_numpy(synth.normal(1234, "prior.refer", (B, 100, L)))
+    y_lengths = torch.tensor([L, L - 9])
+    captured = {}
+    enc_forward = v.enc_p.forward
+
+    def enc_hook(*a, **k):
+        out = enc_forward(*a, **k)
+        captured["enc"] = [t.clone() for t in out]
+        return out
+    v.enc_p.forward = enc_hook
+    real = torch.randn_like
+    torch.randn_like = lambda t, **k: torch.from_numpy(synth.normal(1234, "prior.noise", tuple(t.shape))).to(t.dtype)
+    try:
+        z, yy = v.infer(text, x_lengths, y, y_lengths, tone, lang)
+    finally:
+        torch.randn_like = real
+        v.enc_p.forward = enc_forward
+    x, m_p, logs_p, x_mask = captured["enc"]
+    tsd = {k: torch.from_numpy(t) for k, t in sd.items()}
+    zo, _, ylen_o, logw_o = prior_ref.infer_from_encoder(
+        tsd, x, m_p, logs_p, x_mask, x_lengths, y, y_lengths,
+        lambda shp: torch.from_numpy(synth.normal(1234, "prior.noise", shp)))
+    print("prior  z: oracle vs reference %.2e ; frames %s ; |z| %.3f" % (rel(zo.numpy(), z.numpy()), list(ylen_o.numpy()), float(z.abs().mean())))
+    np.savez_compressed(os.path.join(GOLD, "prior_infer.npz"), enc_x=x.numpy(), enc_m_p=m_p.numpy(), enc_logs_p=logs_p.numpy(),
+                        enc_x_mask=x_mask.numpy(), x_lengths=x_lengths.numpy(), y_lengths=y_lengths.numpy(), L=L,
+                        z=z.numpy(), y_len_out=ylen_o.numpy(), logw=logw_o.numpy(),
+                        names=np.array(sorted(shapes)), shapes=np.array([repr(shapes[k]) for k in sorted(shapes)]),
+                        vits_cfg=np.array(repr({k: cfg["vits"][k] for k in ("inter_channels", "hidden_channels")})))
 
 
 if __name__ == "__main__":
