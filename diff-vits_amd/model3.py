@@ -397,25 +397,156 @@ class DurationPredictor_unet(nn.Module):
         return x * x_mask
 
 
+class ChannelLayerNorm(nn.Module):
+    """reference attentions.LayerNorm (attentions.py:12-24): LayerNorm over the channel axis of [B, C, T]; parameters
+    `gamma` / `beta`."""
+
+    def __init__(self, channels, eps=1e-5):
+        super().__init__()
+        self.channels, self.eps = channels, eps
+        self.gamma = nn.Parameter(torch.ones(channels))
+        self.beta = nn.Parameter(torch.zeros(channels))
+
+    def forward(self, x):
+        return F.layer_norm(x.transpose(1, -1), (self.channels,), self.gamma, self.beta, self.eps).transpose(1, -1)
+
+
+class RelativeMultiHeadAttention(nn.Module):
+    """reference attentions.MultiHeadAttention (attentions.py:142-300) as the text encoder uses it: self-attention with
+    windowed relative-position key / value embeddings shared by the heads.  The relative terms are written as band
+    gathers (offset j - i within +-window) rather than the reference's pad-and-reshape skewing."""
+
+    def __init__(self, channels, out_channels, n_heads, p_dropout=0.0, window_size=4):
+        super().__init__()
+        assert channels % n_heads == 0
+        self.n_heads, self.window_size, self.k_channels = n_heads, window_size, channels // n_heads
+        self.conv_q = nn.Conv1d(channels, channels, 1)
+        self.conv_k = nn.Conv1d(channels, channels, 1)
+        self.conv_v = nn.Conv1d(channels, channels, 1)
+        self.conv_o = nn.Conv1d(channels, out_channels, 1)
+        std = self.k_channels ** -0.5
+        self.emb_rel_k = nn.Parameter(torch.randn(1, window_size * 2 + 1, self.k_channels) * std)
+        self.emb_rel_v = nn.Parameter(torch.randn(1, window_size * 2 + 1, self.k_channels) * std)
+
+    def forward(self, x, c, attn_mask=None):
+        b, ch, t = x.shape
+        h, d, w = self.n_heads, self.k_channels, self.window_size
+        q = self.conv_q(x).view(b, h, d, t).transpose(2, 3) / math.sqrt(d)
+        k = self.conv_k(c).view(b, h, d, t).transpose(2, 3)
+        v = self.conv_v(c).view(b, h, d, t).transpose(2, 3)
+        i = torch.arange(t, device=x.device).unsqueeze(1)
+        j = torch.arange(t, device=x.device).unsqueeze(0)
+        off = j - i + w
+        band = (off >= 0) & (off <= 2 * w)
+        scores = torch.matmul(q, k.transpose(-2, -1))
+        q_rel = torch.matmul(q, self.emb_rel_k[0].t())
+        scores = scores + q_rel.gather(-1, off.clamp(0, 2 * w).expand(b, h, t, t)) * band
+        if attn_mask is not None:
+            scores = scores.masked_fill(attn_mask == 0, -1e4)
+        p_attn = F.softmax(scores, dim=-1)
+        out = torch.matmul(p_attn, v)
+        jj = i + torch.arange(2 * w + 1, device=x.device).unsqueeze(0) - w
+        valid = (jj >= 0) & (jj < t)
+        rel_w = p_attn.gather(-1, jj.clamp(0, t - 1).expand(b, h, t, 2 * w + 1)) * valid
+        out = out + torch.matmul(rel_w, self.emb_rel_v[0])
+        return self.conv_o(out.transpose(2, 3).contiguous().view(b, ch, t))
+
+
+class FFN(nn.Module):
+    """reference attentions.FFN (attentions.py:322-380): two 'same'-padded convs with ReLU, masked."""
+
+    def __init__(self, in_channels, out_channels, filter_channels, kernel_size, p_dropout=0.0):
+        super().__init__()
+        self.kernel_size = kernel_size
+        self.conv_1 = nn.Conv1d(in_channels, filter_channels, kernel_size)
+        self.conv_2 = nn.Conv1d(filter_channels, out_channels, kernel_size)
+
+    def forward(self, x, x_mask):
+        pad = ((self.kernel_size - 1) // 2, self.kernel_size // 2)
+        x = torch.relu(self.conv_1(F.pad(x * x_mask, pad)))
+        return self.conv_2(F.pad(x * x_mask, pad)) * x_mask
+
+
+class Encoder(nn.Module):
+    """reference attentions.Encoder (attentions.py:37-88)."""
+
+    def __init__(self, hidden_channels, filter_channels, n_heads, n_layers, kernel_size=1, p_dropout=0.0, window_size=4,
+                 gin_channels=0, cond_layer_idx=2):
+        super().__init__()
+        self.n_layers = n_layers
+        self.cond_layer_idx = n_layers
+        if gin_channels != 0:
+            self.spk_emb_linear = nn.Linear(gin_channels, hidden_channels)
+            self.cond_layer_idx = cond_layer_idx
+            assert self.cond_layer_idx < n_layers, "cond_layer_idx should be less than n_layers"
+        self.attn_layers = nn.ModuleList([RelativeMultiHeadAttention(hidden_channels, hidden_channels, n_heads, p_dropout, window_size)
+                                          for _ in range(n_layers)])
+        self.norm_layers_1 = nn.ModuleList([ChannelLayerNorm(hidden_channels) for _ in range(n_layers)])
+        self.ffn_layers = nn.ModuleList([FFN(hidden_channels, hidden_channels, filter_channels, kernel_size, p_dropout)
+                                         for _ in range(n_layers)])
+        self.norm_layers_2 = nn.ModuleList([ChannelLayerNorm(hidden_channels) for _ in range(n_layers)])
+
+    def forward(self, x, x_mask, g=None):
+        attn_mask = x_mask.unsqueeze(2) * x_mask.unsqueeze(-1)
+        x = x * x_mask
+        for i in range(self.n_layers):
+            if i == self.cond_layer_idx and g is not None:
+                x = (x + self.spk_emb_linear(g.transpose(1, 2)).transpose(1, 2)) * x_mask
+            x = self.norm_layers_1[i](x + self.attn_layers[i](x, x, attn_mask))
+            x = self.norm_layers_2[i](x + self.ffn_layers[i](x, x_mask))
+        return x * x_mask
+
+
+class TextEncoder(nn.Module):
+    """reference model3.TextEncoder (model3.py:322-381).  The vocabulary sizes come from the reference's `text`
+    package there (len(symbols), num_tones, num_languages = 108 / 11 / 3 in this checkout); here they are arguments.
+    Once per utterance over <= a few hundred tokens: plain torch ops on the caller's device."""
+
+    def __init__(self, n_vocab, out_channels, hidden_channels, filter_channels, n_heads, n_layers, kernel_size, p_dropout,
+                 gin_channels=0, n_tones=11, n_languages=3):
+        super().__init__()
+        self.out_channels, self.hidden_channels = out_channels, hidden_channels
+        self.emb = nn.Embedding(n_vocab, hidden_channels)
+        self.tone_emb = nn.Embedding(n_tones, hidden_channels)
+        self.language_emb = nn.Embedding(n_languages, hidden_channels)
+        for e in (self.emb, self.tone_emb, self.language_emb):
+            nn.init.normal_(e.weight, 0.0, hidden_channels ** -0.5)
+        self.encoder = Encoder(hidden_channels, filter_channels, n_heads, n_layers, kernel_size, p_dropout, gin_channels=gin_channels)
+        self.proj = nn.Conv1d(hidden_channels, out_channels * 2, 1)
+
+    def forward(self, x, x_lengths, tone, language, g=None):
+        x = (self.emb(x) + self.tone_emb(tone) + self.language_emb(language)) * math.sqrt(self.hidden_channels)
+        x = torch.transpose(x, 1, -1)
+        x_mask = torch.unsqueeze(sequence_mask(x_lengths, x.size(2)), 1).to(x.dtype)
+        x = self.encoder(x * x_mask, x_mask, g=g)
+        stats = self.proj(x) * x_mask
+        m, logs = torch.split(stats, self.out_channels, dim=1)
+        return x, m, logs, x_mask
+
+
 class VITS(nn.Module):
     """Inference side of the reference's prior (model3.py:646-860): `infer` = reference encoder (TextTimeEmbedding, one
     head) -> text encoder -> DurationPredictor_unet -> monotonic alignment -> prior sample -> 6-layer `o_proj`
     PromptEncoder with speaker conditioning.  Parameter names of `ref_enc.*`, `dp.*`, `o_proj.*` are the reference's.
 
-    The text encoder (`enc_p`: attentions.Encoder with relative-position attention) is not part of this package: pass
-    any module with the reference signature `enc_p(x, x_lengths, tone, language, g) -> (x, m_p, logs_p, x_mask)` (the
-    reference's own `TextEncoder` instance works), or call `infer_from_encoder` with those four tensors.  The duration
+    With `n_vocab` given the text encoder `enc_p` (TextEncoder over the relative-position Encoder, reference parameter
+    names) is built too; otherwise pass any module with the reference signature
+    `enc_p(x, x_lengths, tone, language, g) -> (x, m_p, logs_p, x_mask)`, or call `infer_from_encoder`.  The duration
     predictor's UNet and `o_proj` run on the HIP engine (backend='hip'); the once-per-utterance glue (reference encoder,
     alignment path, gathers) is a handful of torch ops on the same device.  `noise=` fixes the prior noise (the reference
     draws torch.randn_like)."""
 
-    def __init__(self, n_vocab=None, spec_channels=None, inter_channels=128, hidden_channels=256, gin_channels=256, enc_p=None,
+    def __init__(self, n_vocab=None, spec_channels=None, inter_channels=128, hidden_channels=256, filter_channels=256,
+                 n_heads=2, n_layers=6, kernel_size=3, p_dropout=0.1, gin_channels=256, enc_p=None, n_tones=11, n_languages=3,
                  backend=None, **unused):
         super().__init__()
         from .unet1d.embeddings import TextTimeEmbedding
         self.inter_channels, self.hidden_channels, self.gin_channels = inter_channels, hidden_channels, gin_channels
         if enc_p is not None:
             self.enc_p = enc_p
+        elif n_vocab is not None:
+            self.enc_p = TextEncoder(n_vocab, inter_channels, hidden_channels, filter_channels, n_heads, n_layers, kernel_size,
+                                     p_dropout, gin_channels, n_tones, n_languages)
         self.dp = DurationPredictor_unet(hidden_channels, 256, 100, 3, 0.5, backend=backend)
         self.ref_enc = TextTimeEmbedding(100, gin_channels, 1)
         self.o_proj = PromptEncoder(inter_channels, hidden_channels, inter_channels, 6, 0.2, gin_channels=gin_channels,

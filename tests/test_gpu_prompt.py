@@ -128,15 +128,13 @@ def test_sample_dpmsolver_hip_matches_oracle(gold):
 
 # ---- the VITS prior from the text encoder's outputs onward, HIP backend ---------------
 def test_prior_hip_matches_reference(gold):
-    """Duration predictor (UNet engine at the (64,64,128,128) configuration + native 1x1 convs), alignment and the 6-layer
-    speaker-conditioned o_proj prompt encoder (dv_penc_*) against the reference's vits.infer output."""
-    from test_prompt_cpu import prior_case
+    """VITS.infer from text ids: text encoder (torch ops), duration predictor (UNet engine at the (64,64,128,128)
+    configuration + native 1x1 convs), alignment and the 6-layer speaker-conditioned o_proj prompt encoder (dv_penc_*)
+    against the reference's vits.infer output."""
+    from test_prompt_cpu import prior_case, vits_mirror
     from diff_vits_amd import synth
-    from diff_vits_amd.model3 import VITS
     g, sd, y = prior_case(gold)
-    m = VITS(backend="hip").eval()
-    m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
-    m = m.cuda()
+    m = vits_mirror(g, sd, "hip").cuda()
     noise = torch.from_numpy(synth.normal(1234, "prior.noise", tuple(g["z"].shape))).cuda()
     dev = lambda a: torch.from_numpy(a).cuda()       # noqa: E731
     z, _, ylen = m.infer_from_encoder(dev(g["enc_x"]), dev(g["enc_m_p"]), dev(g["enc_logs_p"]), dev(g["enc_x_mask"]),
@@ -144,3 +142,5 @@ def test_prior_hip_matches_reference(gold):
     assert np.array_equal(ylen.cpu().numpy(), g["y_len_out"])
     assert rel_l2(z.cpu().numpy(), g["z"]) < 2e-4
     assert m.o_proj.hip_engine().stats()[0] == 2 + 1 + 6 * 6 + 2
+    z2, _ = m.infer(dev(g["text"]), dev(g["x_lengths"]), dev(y), dev(g["y_lengths"]), dev(g["tone"]), dev(g["language"]), noise=noise)
+    assert rel_l2(z2.cpu().numpy(), g["z"]) < 2e-4

@@ -171,13 +171,36 @@ def test_oracle_prior_matches_reference(gold):
     assert np.abs(w - np.round(w))[g["enc_x_mask"] > 0].min() > 1e-3
 
 
+def vits_mirror(g, sd, backend):
+    from diff_vits_amd.model3 import VITS
+    kw = ast.literal_eval(str(g["vits_kwargs"]))
+    m = VITS(int(g["n_vocab"]), 513, n_tones=int(g["n_tones"]), n_languages=int(g["n_languages"]), backend=backend, **kw).eval()
+    own = m.state_dict()
+    assert sorted(own) == sorted(sd) and all(tuple(own[k].shape) == tuple(sd[k].shape) for k in sd)   # 949 reference names
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    return m
+
+
+def test_oracle_text_encoder_matches_reference(gold):
+    from oracle import prior_ref, text_enc_ref
+    g, sd, y = prior_case(gold)
+    tsd = {k: torch.from_numpy(v) for k, v in sd.items()}
+    with torch.no_grad():
+        gg = prior_ref.ref_enc(tsd, torch.from_numpy(y)).unsqueeze(-1)
+        x, m_p, logs_p, x_mask = text_enc_ref.text_encoder(tsd, torch.from_numpy(g["text"]), torch.from_numpy(g["x_lengths"]),
+                                                           torch.from_numpy(g["tone"]), torch.from_numpy(g["language"]), gg)
+    for a, k in ((x, "enc_x"), (m_p, "enc_m_p"), (logs_p, "enc_logs_p"), (x_mask, "enc_x_mask")):
+        assert rel_l2(a.numpy(), g[k]) < 1e-6, k
+
+
 def test_mirror_prior_torch_backend_matches_reference(gold):
     from diff_vits_amd.model3 import VITS, generate_path
     g, sd, y = prior_case(gold)
-    m = VITS(backend="torch").eval()
-    own = m.state_dict()
-    assert sorted(own) == sorted(sd) and all(tuple(own[k].shape) == tuple(sd[k].shape) for k in sd)
-    m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    m = vits_mirror(g, sd, "torch")
+    noise_full = torch.from_numpy(synth.normal(1234, "prior.noise", tuple(g["z"].shape)))
+    zf, _ = m.infer(torch.from_numpy(g["text"]), torch.from_numpy(g["x_lengths"]), torch.from_numpy(y), torch.from_numpy(g["y_lengths"]),
+                    torch.from_numpy(g["tone"]), torch.from_numpy(g["language"]), noise=noise_full)
+    assert rel_l2(zf.numpy(), g["z"]) < 1e-5               # whole VITS.infer, text ids -> z
     noise = torch.from_numpy(synth.normal(1234, "prior.noise", tuple(g["z"].shape)))
     z, yy, ylen = m.infer_from_encoder(torch.from_numpy(g["enc_x"]), torch.from_numpy(g["enc_m_p"]), torch.from_numpy(g["enc_logs_p"]),
                                        torch.from_numpy(g["enc_x_mask"]), torch.from_numpy(g["x_lengths"]), torch.from_numpy(y),

@@ -158,15 +158,15 @@ def prior_golden(model3, ref):
     torch.manual_seed(0)
     m = model3.NaturalSpeech2(cfg).eval()
     v = m.vits
-    shapes = {k: tuple(t.shape) for k, t in v.state_dict().items() if k.split(".")[0] in ("ref_enc", "dp", "o_proj")}
+    shapes = {k: tuple(t.shape) for k, t in v.state_dict().items() if k.split(".")[0] in ("ref_enc", "dp", "o_proj", "enc_p")}
     sd = synth.make_state_dict(shapes, seed=1234)
     missing = v.load_state_dict({k: torch.from_numpy(t) for k, t in sd.items()}, strict=False)
     assert not [k for k in missing.unexpected_keys]
     B, Tx, L = 2, 11, 36
     n_sym = v.enc_p.emb.weight.shape[0]
     text = torch.from_numpy((synth.uniform(1234, "prior.text", (B, Tx)) * 0.5 + 0.5) * (n_sym - 1)).long()
-    tone = torch.zeros((B, Tx), dtype=torch.long)
-    lang = torch.zeros((B, Tx), dtype=torch.long)
+    tone = torch.from_numpy((synth.uniform(1234, "prior.tone", (B, Tx)) * 0.5 + 0.5) * (v.enc_p.tone_emb.weight.shape[0] - 1)).long()
+    lang = torch.from_numpy((synth.uniform(1234, "prior.lang", (B, Tx)) * 0.5 + 0.5) * (v.enc_p.language_emb.weight.shape[0] - 1)).long()
     x_lengths = torch.tensor([Tx, Tx - 3])
     y = torch.from_numpy(synth.normal(1234, "prior.refer", (B, 100, L)))
     y_lengths = torch.tensor([L, L - 9])
@@ -187,13 +187,21 @@ def prior_golden(model3, ref):
         v.enc_p.forward = enc_forward
     x, m_p, logs_p, x_mask = captured["enc"]
     tsd = {k: torch.from_numpy(t) for k, t in sd.items()}
+    from oracle import text_enc_ref
+    g_ref = prior_ref.ref_enc(tsd, y).unsqueeze(-1)
+    eo = text_enc_ref.text_encoder(tsd, text, x_lengths, tone, lang, g_ref, cfg["vits"]["n_heads"], cfg["vits"]["n_layers"],
+                                   cfg["vits"]["kernel_size"])
+    print("prior  text encoder: oracle vs reference x %.2e  m %.2e  logs %.2e" % (
+        rel(eo[0].numpy(), x.numpy()), rel(eo[1].numpy(), m_p.numpy()), rel(eo[2].numpy(), logs_p.numpy())))
     zo, _, ylen_o, logw_o = prior_ref.infer_from_encoder(
         tsd, x, m_p, logs_p, x_mask, x_lengths, y, y_lengths,
         lambda shp: torch.from_numpy(synth.normal(1234, "prior.noise", shp)))
     print("prior  z: oracle vs reference %.2e ; frames %s ; |z| %.3f" % (rel(zo.numpy(), z.numpy()), list(ylen_o.numpy()), float(z.abs().mean())))
     np.savez_compressed(os.path.join(GOLD, "prior_infer.npz"), enc_x=x.numpy(), enc_m_p=m_p.numpy(), enc_logs_p=logs_p.numpy(),
                         enc_x_mask=x_mask.numpy(), x_lengths=x_lengths.numpy(), y_lengths=y_lengths.numpy(), L=L,
-                        z=z.numpy(), y_len_out=ylen_o.numpy(), logw=logw_o.numpy(),
+                        z=z.numpy(), y_len_out=ylen_o.numpy(), logw=logw_o.numpy(), text=text.numpy(), tone=tone.numpy(),
+                        language=lang.numpy(), n_vocab=n_sym, n_tones=v.enc_p.tone_emb.weight.shape[0],
+                        n_languages=v.enc_p.language_emb.weight.shape[0], vits_kwargs=np.array(repr(cfg["vits"])),
                         names=np.array(sorted(shapes)), shapes=np.array([repr(shapes[k]) for k in sorted(shapes)]),
                         vits_cfg=np.array(repr({k: cfg["vits"][k] for k in ("inter_channels", "hidden_channels")})))
 
