@@ -334,13 +334,17 @@ class NaturalSpeech2(nn.Module):
 
     @torch.no_grad()
     def sample(self, text, spec, text_lengths, spec_lengths, tone, language, vocos, sampling_timesteps=200,
-               sample_method="unipc", noise=None):
-        """reference model3.py:1119-1203 (same positional signature)."""
+               sample_method="unipc", noise=None, prior_noise=None):
+        """reference model3.py:1119-1203 (same positional signature).  `noise` = x_T, `prior_noise` = the prior's
+        normal draw (forwarded as `noise=` to this package's VITS.infer); both default to fresh torch.randn draws."""
         self.sampling_timesteps = sampling_timesteps
         if not hasattr(self, "vits"):
             raise RuntimeError("NaturalSpeech2.sample needs the VITS prior: construct with vits=<module with .infer(...)> "
                                "or call sample_from_prior(content, refer, ...)")
-        content, refer = self.vits.infer(text, text_lengths, spec, spec_lengths, tone, language)
+        if prior_noise is None:
+            content, refer = self.vits.infer(text, text_lengths, spec, spec_lengths, tone, language)
+        else:
+            content, refer = self.vits.infer(text, text_lengths, spec, spec_lengths, tone, language, noise=prior_noise)
         return self.sample_from_prior(content, refer, text_lengths, spec_lengths, vocos, sample_method, noise)
 
 

@@ -144,3 +144,14 @@ def test_prior_hip_matches_reference(gold):
     assert m.o_proj.hip_engine().stats()[0] == 2 + 1 + 6 * 6 + 2
     z2, _ = m.infer(dev(g["text"]), dev(g["x_lengths"]), dev(y), dev(g["y_lengths"]), dev(g["tone"]), dev(g["language"]), noise=noise)
     assert rel_l2(z2.cpu().numpy(), g["z"]) < 2e-4
+
+
+def test_full_chain_ids_to_mel_hip(gold):
+    """The same call on the HIP backend (duration-predictor UNet, o_proj and prompt encoders, 30-step UniPC loop as one
+    hipGraph): mel within 5e-4 of the reference's (budget 1e-3), same frame count."""
+    from test_prompt_cpu import PassThroughVocoder, full_chain
+    ns2, gf, args, x_T, pn = full_chain(gold, "hip")
+    ns2 = ns2.cuda()
+    audio, mel = ns2.sample(*[torch.from_numpy(a).cuda() for a in args], PassThroughVocoder(), sample_method="unipc",
+                            noise=torch.from_numpy(x_T).cuda(), prior_noise=torch.from_numpy(pn).cuda())
+    assert mel.shape == gf["mel"].shape and rel_l2(mel.cpu().numpy(), gf["mel"]) < 5e-4

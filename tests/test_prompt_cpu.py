@@ -220,3 +220,29 @@ def test_mirror_prior_torch_backend_matches_reference(gold):
     d = torch.tensor([[[2.0, 0.0, 3.0]]])
     p = generate_path(d, torch.ones(1, 1, 5, 3))
     assert p.sum().item() == 5 and p[0, 0, :, 0].tolist() == [1, 1, 0, 0, 0] and p[0, 0, :, 2].tolist() == [0, 0, 1, 1, 1]
+
+
+def full_chain(gold, backend):
+    """NaturalSpeech2(cfg, vits=VITS(...)) with every weight synthetic (the fixtures' seeds), as tts_infer.py builds it."""
+    from diff_vits_amd.model3 import NaturalSpeech2
+    g, sd, y = prior_case(gold)
+    gf = gold("sample_full.npz")
+    dcfg = ast.literal_eval(str(gf["diffusion_encoder"]))
+    ns2 = NaturalSpeech2({"diffusion_encoder": dcfg, "train": {"timesteps": int(gf["timesteps"])}}, vits=vits_mirror(g, sd, backend),
+                         backend=backend).eval()
+    ns2.diff_model.load_state_dict({k: torch.from_numpy(v) for k, v in diffusion_state_dict(dcfg).items()})
+    T = gf["mel"].shape[2]
+    x_T = synth.normal(1234, "full.x_T", (1, dcfg["in_channels"], T))
+    pn = synth.normal(1234, "full.prior_noise", (1, 128, T))
+    args = (g["text"][:1], y[:1], g["x_lengths"][:1], g["y_lengths"][:1], g["tone"][:1], g["language"][:1])
+    return ns2, gf, args, x_T, pn
+
+
+def test_full_chain_ids_to_mel_torch_backend(gold):
+    """tts_infer.py's model.sample(phoneme, refer, phoneme_length, refer_length, tone, language, vocos) on the mirrors:
+    text encoder -> durations -> alignment -> o_proj -> prompt encoder -> 30-step UniPC over the UNet, against the
+    reference's own sample() run here on the same synthetic weights and noise."""
+    ns2, gf, args, x_T, pn = full_chain(gold, "torch")
+    audio, mel = ns2.sample(*[torch.from_numpy(a) for a in args], PassThroughVocoder(), sample_method="unipc",
+                            noise=torch.from_numpy(x_T), prior_noise=torch.from_numpy(pn))
+    assert mel.shape == gf["mel"].shape and rel_l2(mel.numpy(), gf["mel"]) < 2e-5 and rel_l2(audio.numpy(), gf["audio"]) < 2e-5

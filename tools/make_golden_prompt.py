@@ -197,6 +197,27 @@ def prior_golden(model3, ref):
         tsd, x, m_p, logs_p, x_mask, x_lengths, y, y_lengths,
         lambda shp: torch.from_numpy(synth.normal(1234, "prior.noise", shp)))
     print("prior  z: oracle vs reference %.2e ; frames %s ; |z| %.3f" % (rel(zo.numpy(), z.numpy()), list(ylen_o.numpy()), float(z.abs().mean())))
+    # ---- the whole tts_infer.py call, phoneme ids -> mel: NaturalSpeech2.sample('unipc') with the real vits.infer (B = 1:
+    #      the reference's UniPC wrapper only broadcasts there), every weight synthetic, all noise from the seeded generator
+    dshapes = {k: tuple(t.shape) for k, t in m.diff_model.state_dict().items()}
+    m.diff_model.load_state_dict({k: torch.from_numpy(t) for k, t in synth.make_state_dict(dshapes, seed=1234).items()})
+
+    class PassThroughVocoder:
+        def to(self, device):
+            return self
+
+        def decode(self, mel):
+            return mel.mean(dim=1, keepdim=True)
+    real_like, real_randn = torch.randn_like, torch.randn
+    torch.randn_like = lambda t, **k: torch.from_numpy(synth.normal(1234, "full.prior_noise", tuple(t.shape))).to(t.dtype)
+    torch.randn = lambda *a, **k: torch.from_numpy(synth.normal(1234, "full.x_T", tuple(a[0]) if isinstance(a[0], (tuple, list)) else tuple(a)))
+    try:
+        audio_f, mel_f = m.sample(text[:1], y[:1], x_lengths[:1], y_lengths[:1], tone[:1], lang[:1], PassThroughVocoder(), sample_method="unipc")
+    finally:
+        torch.randn_like, torch.randn = real_like, real_randn
+    print("full   ids -> mel: frames %d ; |mel| %.3f" % (mel_f.shape[2], float(mel_f.abs().mean())))
+    np.savez_compressed(os.path.join(GOLD, "sample_full.npz"), mel=mel_f.numpy(), audio=audio_f.numpy(),
+                        diffusion_encoder=np.array(repr(cfg["diffusion_encoder"])), timesteps=cfg["train"]["timesteps"])
     np.savez_compressed(os.path.join(GOLD, "prior_infer.npz"), enc_x=x.numpy(), enc_m_p=m_p.numpy(), enc_logs_p=logs_p.numpy(),
                         enc_x_mask=x_mask.numpy(), x_lengths=x_lengths.numpy(), y_lengths=y_lengths.numpy(), L=L,
                         z=z.numpy(), y_len_out=ylen_o.numpy(), logw=logw_o.numpy(), text=text.numpy(), tone=tone.numpy(),
