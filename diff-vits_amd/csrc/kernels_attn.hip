@@ -22,6 +22,8 @@
 #include "dv_common.h"
 #include "attn_tile.h"
 
+#include <cstdlib>
+
 template <int DP, int NW, int NSPLIT>
 __global__ __launch_bounds__(64 * NW) void k_attention(const AttnParams p) {
   extern __shared__ __attribute__((aligned(1024))) char lds[];   // [2 x BUF planes | NST x RAW ring]
@@ -49,6 +51,7 @@ hipError_t attn_init() {
   if (done) return hipSuccess;
   hipError_t e = hipSuccess;
 #define ATT_INIT(DP)                                               \
+  if (e == hipSuccess) e = init_att<DP, 8>();                      \
   if (e == hipSuccess) e = init_att<DP, 4>();                      \
   if (e == hipSuccess) e = init_att<DP, 2>();                      \
   if (e == hipSuccess) e = init_att<DP, 1>();
@@ -60,13 +63,17 @@ hipError_t attn_init() {
 
 hipError_t launch_attention(const AttnParams& p, hipStream_t st) {
   if (p.d % 4 != 0 || p.d > 64 || p.d <= 0 || (p.nsplit != 1 && p.nsplit != 3)) return hipErrorInvalidValue;
-  // queries per workgroup: enough workgroups to cover the 256 CUs even at the short levels
+  // queries per workgroup: the K / V tiles are converted once per workgroup, so more waves per workgroup (256 queries
+  // at 8) amortise that best - measured faster than spreading over more, smaller workgroups at every level of the
+  // denoiser, down to 32 workgroups (DVITS_ATTN_NW8 = wave-count threshold for 8 waves, default 256)
   const long waves = (long)p.B * p.H * ((p.Tq + 31) / 32);
-  const int nw = waves >= 2048 ? 4 : (waves >= 512 ? 2 : 1);
+  static const int nw8_min = [] { const char* e = getenv("DVITS_ATTN_NW8"); return e ? atoi(e) : 256; }();
+  const int nw = waves >= nw8_min ? 8 : (waves >= 64 ? 4 : (waves >= 16 ? 2 : 1));
   dim3 grid((p.Tq + 32 * nw - 1) / (32 * nw), p.H, p.B);
   const int dp = (p.d + 15) / 16 * 16;
 #define ATT(DP)                                         \
-  if (nw == 4) launch_att<DP, 4>(p, grid, st);          \
+  if (nw == 8) launch_att<DP, 8>(p, grid, st);          \
+  else if (nw == 4) launch_att<DP, 4>(p, grid, st);     \
   else if (nw == 2) launch_att<DP, 2>(p, grid, st);     \
   else launch_att<DP, 1>(p, grid, st);
   if (dp == 16) { ATT(16) } else if (dp == 32) { ATT(32) } else if (dp == 48) { ATT(48) } else { ATT(64) }
