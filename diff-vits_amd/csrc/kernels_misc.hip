@@ -5,6 +5,8 @@
 #include "dv_common.h"
 #include "misc_body.h"
 
+#include <cstdlib>
+
 // ---------------------------------------------------------------------------------------
 // (B, C, T) channels-first inputs x | cond  ->  (B*T, cpad) channels-last, zero padded.
 // The boundary tensors of UNet1DConditionModel.forward are channels-first
@@ -79,8 +81,9 @@ hipError_t launch_gn_apply(const GnApplyParams& p, hipStream_t st) {
   const int cg = ctot / p.groups;
   if (cg % 4 != 0 || p.c0 % 4 != 0 || cg > 512 || p.groups > 64) return hipErrorInvalidValue;
   if (!p.scale_in && (p.T % 32 != 0 || !p.slab0 || (p.c1 && !p.slab1))) return hipErrorInvalidValue;
-  // ~1024 workgroups: (frame chunks) x groups x batch
-  int chunks = 1024 / (p.groups * p.B);
+  // ~1024 workgroups: (frame chunks) x groups x batch  (DVITS_GN_WGS: experiment knob)
+  static const int target = [] { const char* e = getenv("DVITS_GN_WGS"); return e ? atoi(e) : 1024; }();
+  int chunks = target / (p.groups * p.B);
   chunks = chunks < 1 ? 1 : chunks;
   int rpb = (p.T + chunks - 1) / chunks;
   rpb = rpb < 4 ? 4 : rpb;
