@@ -126,7 +126,9 @@ struct PackedW {
   int Kp = 0, N = 0, N_pad = 0;
 };
 
-struct Act { float* p = nullptr; int C = 0, T = 0; float* stat = nullptr; };   // channels-last fp32 [B*T, C] (+ GN stat slab)
+struct Act {   // channels-last fp32 [B*T, C] (+ GN stat slab) (+ split planes when the consumer is a resampling conv)
+  float* p = nullptr; int C = 0, T = 0; float* stat = nullptr; bf16_t* pl_hi = nullptr; bf16_t* pl_lo = nullptr;
+};
 
 typedef std::function<hipError_t(hipStream_t)> OpFn;
 
@@ -476,7 +478,7 @@ struct Builder {
 
   // ResnetBlock2D (reference resnet.py:591-641): apply(norm1) -> conv1 -> apply(norm2, temb) -> conv2 (+1x1
   // shortcut as a second K-segment | + identity residual)
-  Act resnet(std::vector<OpFn>& ops, const std::string& p, Act x0, Act x1, int cout) {
+  Act resnet(std::vector<OpFn>& ops, const std::string& p, Act x0, Act x1, int cout, bool want_planes = false) {
     const int cin = x0.C + x1.C, Tn = x0.T, M = B * Tn;
     const float eps = u->cfg.norm_eps;
     const bool shortcut = has(p + "conv_shortcut.weight");
@@ -513,6 +515,10 @@ struct Builder {
       if (shortcut) { g.seg[1] = seg(raw, cin, Planes{}, 0, 1, 0); g.nseg = 2; }
       else { g.epi = EPI_RESIDUAL; g.res = x0.p; g.ldres = cout; }
       g.out = out.p; g.stats = out.stat;
+      if (want_planes) {   // the next op is a resampling conv: hand it split planes instead of a k_split launch
+        Planes pl = alloc_planes((size_t)M * cout);
+        out.pl_hi = pl.hi; out.pl_lo = pl.lo; g.out_hi = pl.hi; g.out_lo = pl.lo;
+      }
       gemm(ops, g, w2, K2);
     }
     release(n2);
@@ -548,7 +554,7 @@ struct Builder {
   }
 
   // Transformer2DModel + BasicTransformerBlock (reference transformer_1d.py:191-326, attention.py:130-203)
-  Act transformer(std::vector<OpFn>& ops, const std::string& p, Act x) {
+  Act transformer(std::vector<OpFn>& ops, const std::string& p, Act x, bool want_planes = false) {
     const int C = x.C, Tn = x.T, M = B * Tn, D = u->cfg.cross_attention_dim;
     const std::string tb = p + "transformer_blocks.0.";
     const PackedW* w_in = pack(p + "proj_in", C, C, {{p + "proj_in.weight", 1, C, 1, C, 0, 0, "", 0}},
@@ -677,7 +683,12 @@ struct Builder {
         GemmParams g = gp_base(Tn, M, C);
         g.seg[0] = seg(l3.pl, C, Planes{}, 0, 1, 0);
         g.seg[1] = seg(gg, 4 * C, Planes{}, 0, 1, 0); g.nseg = 2;
-        g.epi = EPI_RESIDUAL; g.res = x.p; g.out = out.p; g.stats = out.stat; gemm(ops, g, w_m, 5 * C);
+        g.epi = EPI_RESIDUAL; g.res = x.p; g.out = out.p; g.stats = out.stat;
+        if (want_planes) {
+          Planes pl = alloc_planes((size_t)M * C);
+          out.pl_hi = pl.hi; out.pl_lo = pl.lo; g.out_hi = pl.hi; g.out_lo = pl.lo;
+        }
+        gemm(ops, g, w_m, 5 * C);
       }
       ln_release(l3);
       release(gg); release(h3);
@@ -698,7 +709,12 @@ struct Builder {
     out.p = alloc((size_t)M * C); out.C = C; out.T = Tn; out.stat = alloc_stat(Tn, C);
     {
       GemmParams g = gp_base(Tn, M, C); g.seg[0] = seg(h4, C, Planes{}, 0, 1, 0);
-      g.epi = EPI_RESIDUAL; g.res = x.p; g.out = out.p; g.stats = out.stat; gemm(ops, g, w_out, C);
+      g.epi = EPI_RESIDUAL; g.res = x.p; g.out = out.p; g.stats = out.stat;
+      if (want_planes) {
+        Planes pl = alloc_planes((size_t)M * C);
+        out.pl_hi = pl.hi; out.pl_lo = pl.lo; g.out_hi = pl.hi; g.out_lo = pl.lo;
+      }
+      gemm(ops, g, w_out, C);
     }
     release(h4);
     probe(p.substr(0, p.size() - 1), out.p, Tn, C);
@@ -712,7 +728,9 @@ struct Builder {
     const PackedW* w = pack(p + "conv", C, 3 * C, {{p + "conv.weight", 1, C, 3, C, 0, 0, "", 0}},
                             {{p + "conv.bias", "", "", "", C, 0, 0, 0}});
     if (!w) return Act{};
-    Planes xs = split(ops, x.p, (size_t)B * x.T * C);
+    Planes xs;
+    if (x.pl_hi) { xs.hi = x.pl_hi; xs.lo = x.pl_lo; }
+    else xs = split(ops, x.p, (size_t)B * x.T * C);
     GemmParams g = gp_base(x.T, 0, C);
     g.seg[0] = seg(xs, C, Planes{}, 0, 3, 1);
     g.T_in = x.T;
@@ -894,10 +912,11 @@ struct Builder {
       const std::string bp = "down_blocks." + std::to_string(i) + ".";
       const bool attn = i < n - 1;
       for (int j = 0; j < lpb; ++j) {
-        Act r = resnet(S, bp + "resnets." + std::to_string(j) + ".", h, Act{}, c.block_out_channels[i]);
+        const bool feeds_resampler = i < n - 1 && j == lpb - 1;     // its output is the downsampler's input
+        Act r = resnet(S, bp + "resnets." + std::to_string(j) + ".", h, Act{}, c.block_out_channels[i], feeds_resampler && !attn);
         if (!r.p) return dv_fail(DV_ERR_MISSING_WEIGHT, "%s", err.c_str());
         if (attn) {
-          Act a = transformer(S, bp + "attentions." + std::to_string(j) + ".", r);
+          Act a = transformer(S, bp + "attentions." + std::to_string(j) + ".", r, feeds_resampler);
           if (!a.p) return dv_fail(DV_ERR_MISSING_WEIGHT, "%s", err.c_str());
           release_act(r);
           r = a;
@@ -928,12 +947,13 @@ struct Builder {
       for (int j = 0; j < lpb + 1; ++j) {
         Act sk = skips.back();
         skips.pop_back();
-        Act r = resnet(S, bp + "resnets." + std::to_string(j) + ".", h, sk, cout);
+        const bool feeds_resampler = !last && j == lpb;              // its output is the upsampler's input
+        Act r = resnet(S, bp + "resnets." + std::to_string(j) + ".", h, sk, cout, feeds_resampler && !attn);
         if (!r.p) return dv_fail(DV_ERR_MISSING_WEIGHT, "%s", err.c_str());
         release_act(h);
         release_act(sk);
         if (attn) {
-          Act a = transformer(S, bp + "attentions." + std::to_string(j) + ".", r);
+          Act a = transformer(S, bp + "attentions." + std::to_string(j) + ".", r, feeds_resampler);
           if (!a.p) return dv_fail(DV_ERR_MISSING_WEIGHT, "%s", err.c_str());
           release_act(r);
           r = a;
