@@ -31,7 +31,20 @@ __device__ __forceinline__ unsigned cvt_pk_bf16(float lo, float hi) {
   asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
   return r;
 }
-__device__ __forceinline__ float gelu_erf(float v) { return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f)); }
+// GELU with the exact-erf definition (reference unet1d/activations / F.gelu default), erf by Abramowitz-Stegun 7.1.26
+// (|error| <= 1.5e-7): branch-free, one v_exp_f32 and one v_rcp_f32, ~20 issue slots instead of erff()'s two divergent
+// polynomial branches.  1 + erf is formed without cancellation on the negative side: measured max |error| of the GELU
+// 4.2e-7 over [-12, 12] (tools check in DESIGN.md), two orders below the split-bf16 product error.
+__device__ __forceinline__ float gelu_erf(float v) {
+  const float z = fabsf(v) * 0.70710678118654752440f;
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
+  float p = fmaf(1.061405429f, t, -1.453152027f);
+  p = fmaf(p, t, 1.421413741f);
+  p = fmaf(p, t, -0.284496736f);
+  p = fmaf(p, t, 0.254829592f);
+  const float y = p * t * __builtin_amdgcn_exp2f(-1.44269504088896340736f * z * z);   // = 1 - erf(z)
+  return 0.5f * v * (v < 0.f ? y : 2.0f - y);
+}
 
 // KS = 2 doubles the waves of a workgroup (two per SIMD): both groups stage every k-tile together and each
 // multiplies half of its 16-deep k-steps, so one wave's MFMAs overlap the other's address math and DMA issue;
@@ -353,26 +366,37 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int m0, con
   }
 
   DV_TRACE(3);
-  if (KS == 2) {   // add the two k-groups' partial accumulators through LDS (lane-linear, conflict-free)
+  // KS == 2: add the two k-groups' partial accumulators through LDS (lane-linear, conflict-free).  With an even
+  // number of row fragments each k-group keeps the sums of ITS fragments (i % 2 == kgrp) and both run the epilogue on
+  // their half, so all eight waves share the (store- and GELU-bound) epilogue; otherwise group 1 hands everything over.
+  constexpr bool SPLIT_EPI = KS == 2 && FM % 2 == 0;
+  if (KS == 2) {
     __builtin_amdgcn_s_barrier();                    // every wave is done reading the ring
     float* red = reinterpret_cast<float*>(smem);
-    if (kgrp == 1) {
 #pragma unroll
-      for (int i = 0; i < FM; ++i)
+    for (int i = 0; i < FM; ++i) {
+      const bool mine = SPLIT_EPI ? ((i & 1) == kgrp) : (kgrp == 0);
+      if (!mine) {
 #pragma unroll
         for (int j = 0; j < FN; ++j)
 #pragma unroll
           for (int r = 0; r < 16; ++r) red[((i * FN + j) * 16 + r) * (64 * NWQ) + wq * 64 + lane] = acc[i][j][r];
+      }
     }
     __syncthreads();
-    if (kgrp == 1) return;
+    if (!SPLIT_EPI && kgrp == 1) return;
 #pragma unroll
-    for (int i = 0; i < FM; ++i)
+    for (int i = 0; i < FM; ++i) {
+      const bool mine = SPLIT_EPI ? ((i & 1) == kgrp) : true;
+      if (mine) {
 #pragma unroll
-      for (int j = 0; j < FN; ++j)
+        for (int j = 0; j < FN; ++j)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[i][j][r] += red[((i * FN + j) * 16 + r) * (64 * NWQ) + wq * 64 + lane];
+          for (int r = 0; r < 16; ++r) acc[i][j][r] += red[((i * FN + j) * 16 + r) * (64 * NWQ) + wq * 64 + lane];
+      }
+    }
   }
+  auto my_frag_row = [&](int i) { return !SPLIT_EPI || ((i & 1) == kgrp); };
 
   // ---- epilogue ----
   DV_TRACE(4);
@@ -424,6 +448,7 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int m0, con
       }
 #pragma unroll
       for (int i = 0; i < FM; ++i) {
+        if (!my_frag_row(i)) continue;
         const int rl = (wm * FM + i) * 32 + l31;
         const int m = m0 + rl;
         if (m >= p.M) continue;
@@ -461,6 +486,7 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int m0, con
     }
 #pragma unroll
     for (int i = 0; i < FM; ++i) {
+      if (!my_frag_row(i)) continue;
       const int mrow0 = m0 + (wm * FM + i) * 32;
       const int rl = (wm * FM + i) * 32 + l31;
       const int m = m0 + rl;
