@@ -97,6 +97,8 @@ template <int BK> struct Tiles {
       if (cnt(64, 64) >= min_wg) return T2G::launch(p, x3, st);
       return T4G::launch(p, x3, st);
     }
+    static const int t1_min = [] { const char* e = getenv("DVITS_GEMM_T1"); return e ? atoi(e) : (1 << 30); }();   // experiment knob
+    if (BK == 64 && cnt(128, 64) >= t1_min) return T1::launch(p, x3, st);
     if (cnt(64, 64) >= min_wg) return ksplit ? T2::launch(p, x3, st) : T2S::launch(p, x3, st);
     if (cnt(64, 32) >= min_wg) return T3::launch(p, x3, st);
     return T4::launch(p, x3, st);
