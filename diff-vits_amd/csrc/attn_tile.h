@@ -27,7 +27,7 @@ struct AttnGeom {
   static constexpr int DUMMY = KPW * NW > KV_INSTR ? 1024 : 0;
   static constexpr int RAW = (2 * RAWK + NW * 256 + DUMMY + 1023) / 1024 * 1024;   // + one 64-float bias slot per wave
   static constexpr int buf_bytes(int npl) { return (K_PL + V_PL) * npl + 128; }
-  static constexpr int planes_bytes(int npl) { return (2 * buf_bytes(npl) + 1023) / 1024 * 1024; }
+  static constexpr int planes_bytes(int npl) { return (4 * buf_bytes(npl) + 1023) / 1024 * 1024; }   // 2 sub-tiles x double buffer
   static constexpr int smem_bytes(int npl) { return planes_bytes(npl) + NST * RAW; }
 };
 
@@ -180,64 +180,78 @@ __device__ __forceinline__ void attn_tile(const AttnParams& p, const int qblk, c
     else wait_vmcnt<0>();
   };
 
-  const int ntile = (p.Tk + 31) / 32;
+  // Two 32-key sub-tiles per iteration: one barrier, two independent S^T MFMA chains, one softmax pass over 32 scores per
+  // lane.  Sub-tile t lives in raw stage t % NST and, converted, in planes buffer 2 * (iteration & 1) + (t & 1).  A
+  // trailing odd sub-tile is processed as fully masked (its keys clamp to Tk - 1, its bias is -1e30).
+  const int nsub = (p.Tk + 31) / 32, nit = (nsub + 1) / 2, nsub2 = 2 * nit;
 #pragma unroll
   for (int t = 0; t < NST; ++t)
-    if (t < ntile) issue_tile(t);
-  wait_tile(0, min(ntile, NST) - 1);
+    if (t < nsub2) issue_tile(t);
+  wait_tile(1, min(nsub2, NST) - 1);
   __syncthreads();
   convert_tile(0, 0);
-  for (int t = 0; t < ntile; ++t) {
-    const bool more = t + 1 < ntile;
-    if (more) wait_tile(t + 1, min(ntile - 1, t + NST - 1));
-    __syncthreads();          // planes[t&1] written, raw tile t+1 landed for every wave, tile t-1's MFMAs done
-    if (t + NST < ntile) issue_tile(t + NST);          // reuses the stage of raw tile t (converted before this barrier)
-    if (more) convert_tile(t + 1, (t + 1) & 1);
-    const char* base = lds + (t & 1) * BUF;
-    const char* k_hi = base;
-    const char* k_lo = base + K_PL;
-    const char* v_hi = base + NPL * K_PL;
-    const char* v_lo = v_hi + V_PL;
-    const float* bl = reinterpret_cast<const float*>(base + (K_PL + V_PL) * NPL);
+  convert_tile(1, 1);
+  for (int it = 0; it < nit; ++it) {
+    const bool more = it + 1 < nit;
+    if (more) wait_vmcnt<0>();   // sub-tiles 2it+2, 2it+3 (issued one iteration ago) have landed for this wave
+    __syncthreads();            // planes of this iteration written, next raw sub-tiles landed, previous MFMAs done
+    if (2 * it + NST < nsub2) { issue_tile(2 * it + NST); issue_tile(2 * it + NST + 1); }   // stages of sub-tiles 2it, 2it+1
+    if (more) { convert_tile(2 * it + 2, 2 * ((it + 1) & 1)); convert_tile(2 * it + 3, 2 * ((it + 1) & 1) + 1); }
+    const char* base0 = lds + (2 * (it & 1)) * BUF;
 
-    // ---- S^T = K Q^T ----
-    f32x16 s;
+    // ---- S^T = K Q^T for both sub-tiles (independent accumulators: the MFMA chains interleave) ----
+    f32x16 s[2];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) s[r] = 0.f;
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s[u][r] = 0.f;
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
       const int off = l31 * KP + (ks * 2 + lh) * 16;
-      const bf16x8 kh = *reinterpret_cast<const bf16x8*>(k_hi + off);
-      if (SPLIT) {
-        const bf16x8 kl = *reinterpret_cast<const bf16x8*>(k_lo + off);
-        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kl, qh[ks], s, 0, 0, 0);
-        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh, ql[ks], s, 0, 0, 0);
+      bf16x8 kh[2], kl[2];
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        kh[u] = *reinterpret_cast<const bf16x8*>(base0 + u * BUF + off);
+        if (SPLIT) kl[u] = *reinterpret_cast<const bf16x8*>(base0 + u * BUF + K_PL + off);
       }
-      s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh, qh[ks], s, 0, 0, 0);
+      if (SPLIT) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) s[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kl[u], qh[ks], s[u], 0, 0, 0);
+#pragma unroll
+        for (int u = 0; u < 2; ++u) s[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh[u], ql[ks], s[u], 0, 0, 0);
+      }
+#pragma unroll
+      for (int u = 0; u < 2; ++u) s[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh[u], qh[ks], s[u], 0, 0, 0);
     }
     // ---- online softmax (lane = query; registers = keys) ----
     // the key bias (attention mask / keys past Tk) is only added where there is one: wave-uniform branch
-    if (p.bias != nullptr || (!more && (p.Tk & 31) != 0)) {
+    if (p.bias != nullptr || (!more && (p.Tk & 63) != 0)) {
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const float4 bv = *reinterpret_cast<const float4*>(bl + 8 * g + 4 * lh);
-        s[4 * g] += bv.x; s[4 * g + 1] += bv.y; s[4 * g + 2] += bv.z; s[4 * g + 3] += bv.w;
+      for (int u = 0; u < 2; ++u) {
+        const float* bl = reinterpret_cast<const float*>(base0 + u * BUF + (K_PL + V_PL) * NPL);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const float4 bv = *reinterpret_cast<const float4*>(bl + 8 * g + 4 * lh);
+          s[u][4 * g] += bv.x; s[u][4 * g + 1] += bv.y; s[u][4 * g + 2] += bv.z; s[u][4 * g + 3] += bv.w;
+        }
       }
     }
-    float tmax = s[0];
+    float tmax = fmaxf(s[0][0], s[1][0]);
 #pragma unroll
-    for (int r = 1; r < 16; ++r) tmax = fmaxf(tmax, s[r]);
+    for (int r = 1; r < 16; ++r) tmax = fmaxf(tmax, fmaxf(s[0][r], s[1][r]));
     tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
     const float m_new = fmaxf(m_run, tmax);
     const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
     m_run = m_new;
-    float psum = 0.f;
+    float psum0 = 0.f, psum1 = 0.f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      s[r] = __builtin_amdgcn_exp2f(s[r] - m_new);
-      psum += s[r];
+      s[0][r] = __builtin_amdgcn_exp2f(s[0][r] - m_new);
+      s[1][r] = __builtin_amdgcn_exp2f(s[1][r] - m_new);
+      psum0 += s[0][r];
+      psum1 += s[1][r];
     }
-    l_run = l_run * alpha + psum;
+    l_run = l_run * alpha + (psum0 + psum1);
     if (__any(alpha != 1.0f)) {        // the running maximum moved for some query of this wave
 #pragma unroll
       for (int nb = 0; nb < NB; ++nb)
@@ -246,29 +260,34 @@ __device__ __forceinline__ void attn_tile(const AttnParams& p, const int qblk, c
     }
     // ---- O^T += V^T P^T: P^T operand of k-block kb = this lane's score registers 8kb..8kb+7 ----
 #pragma unroll
-    for (int kb = 0; kb < 2; ++kb) {
-      u32x4 hw, lw;
-      hw.x = apk(s[kb * 8 + 0], s[kb * 8 + 1]); hw.y = apk(s[kb * 8 + 2], s[kb * 8 + 3]);
-      hw.z = apk(s[kb * 8 + 4], s[kb * 8 + 5]); hw.w = apk(s[kb * 8 + 6], s[kb * 8 + 7]);
-      const bf16x8 ph = __builtin_bit_cast(bf16x8, hw);
-      bf16x8 pl;
-      if (SPLIT) {
-        lw.x = apk(s[kb * 8 + 0] - bf_lo(hw.x), s[kb * 8 + 1] - bf_hi(hw.x));
-        lw.y = apk(s[kb * 8 + 2] - bf_lo(hw.y), s[kb * 8 + 3] - bf_hi(hw.y));
-        lw.z = apk(s[kb * 8 + 4] - bf_lo(hw.z), s[kb * 8 + 5] - bf_hi(hw.z));
-        lw.w = apk(s[kb * 8 + 6] - bf_lo(hw.w), s[kb * 8 + 7] - bf_hi(hw.w));
-        pl = __builtin_bit_cast(bf16x8, lw);
-      }
+    for (int u = 0; u < 2; ++u) {
+      const char* v_hi = base0 + u * BUF + NPL * K_PL;
+      const char* v_lo = v_hi + V_PL;
 #pragma unroll
-      for (int nb = 0; nb < NB; ++nb) {
-        const int off = (nb * 32 + l31) * VP + (kb * 2 + lh) * 16;
-        const bf16x8 vh = *reinterpret_cast<const bf16x8*>(v_hi + off);
+      for (int kb = 0; kb < 2; ++kb) {
+        u32x4 hw, lw;
+        hw.x = apk(s[u][kb * 8 + 0], s[u][kb * 8 + 1]); hw.y = apk(s[u][kb * 8 + 2], s[u][kb * 8 + 3]);
+        hw.z = apk(s[u][kb * 8 + 4], s[u][kb * 8 + 5]); hw.w = apk(s[u][kb * 8 + 6], s[u][kb * 8 + 7]);
+        const bf16x8 ph = __builtin_bit_cast(bf16x8, hw);
+        bf16x8 pl;
         if (SPLIT) {
-          const bf16x8 vl = *reinterpret_cast<const bf16x8*>(v_lo + off);
-          o[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vl, ph, o[nb], 0, 0, 0);
-          o[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, pl, o[nb], 0, 0, 0);
+          lw.x = apk(s[u][kb * 8 + 0] - bf_lo(hw.x), s[u][kb * 8 + 1] - bf_hi(hw.x));
+          lw.y = apk(s[u][kb * 8 + 2] - bf_lo(hw.y), s[u][kb * 8 + 3] - bf_hi(hw.y));
+          lw.z = apk(s[u][kb * 8 + 4] - bf_lo(hw.z), s[u][kb * 8 + 5] - bf_hi(hw.z));
+          lw.w = apk(s[u][kb * 8 + 6] - bf_lo(hw.w), s[u][kb * 8 + 7] - bf_hi(hw.w));
+          pl = __builtin_bit_cast(bf16x8, lw);
         }
-        o[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, ph, o[nb], 0, 0, 0);
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+          const int off = (nb * 32 + l31) * VP + (kb * 2 + lh) * 16;
+          const bf16x8 vh = *reinterpret_cast<const bf16x8*>(v_hi + off);
+          if (SPLIT) {
+            const bf16x8 vl = *reinterpret_cast<const bf16x8*>(v_lo + off);
+            o[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vl, ph, o[nb], 0, 0, 0);
+            o[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, pl, o[nb], 0, 0, 0);
+          }
+          o[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, ph, o[nb], 0, 0, 0);
+        }
       }
     }
   }
