@@ -87,6 +87,9 @@ def test_group_stats(B, T, C, G):
 @pytest.mark.parametrize("B,H,Tq,Tk,d,masked", [
     (2, 8, 40, 40, 4, False), (2, 8, 100, 50, 16, True), (1, 8, 1024, 1024, 16, False), (2, 8, 512, 256, 32, True),
     (2, 8, 256, 256, 48, False), (2, 8, 128, 256, 64, True), (2, 8, 37, 60, 8, True), (1, 8, 64, 33, 12, False),
+    # odd numbers of 32-key sub-tiles (the trailing one is processed fully masked), with 1..8 waves per workgroup
+    (1, 8, 96, 70, 16, True), (2, 8, 33, 129, 32, False), (1, 8, 300, 97, 48, True), (2, 8, 512, 80, 16, True),
+    (2, 8, 512, 161, 64, False),
 ])
 def test_attention(B, H, Tq, Tk, d, masked):
     L = _lib()
