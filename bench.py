@@ -222,10 +222,10 @@ def main():
             "bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
             "traffic": traffic, "traffic_source": traffic_src,
             "kernel": "k_gemm<*> (implicit-GEMM conv1d/linear, all tile instantiations)",
-            "flops_per_launch": g[1] / g[0], "avg_launch_us": gemm_us, "launches_per_forward": gemm_n,
-            "avg_launch_us_event_pair_per_launch": 1e3 * g[2] / g[0], "achieved_event_pair_per_launch": achieved_evpair,
+            "flops_per_launch": flops_gemm_fwd / gemm_n, "avg_launch_us": gemm_us, "launches_per_forward": gemm_n,
+            "avg_op_us_event_pair_per_operation": 1e3 * g[2] / g[0], "achieved_event_pair_per_launch": achieved_evpair,
             "per_kind_ms_per_forward": {k: v[2] / reps for k, v in agg.items()},
-            "per_kind_launches": {k: v[0] // reps for k, v in agg.items()},
+            "per_kind_operations": {k: v[0] // reps for k, v in agg.items()},   # a split-K GEMM pair is one operation
             "forward": {"launches": n_launch, "algorithmic_gflop": flops_model(B, T, L) / 1e9,
                         "engine_counted_gflop": flops_fwd / 1e9, "ms_in_graph": fwd_ms,
                         "tflops": flops_model(B, T, L) / (fwd_ms * 1e-3) / 1e12,

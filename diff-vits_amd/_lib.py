@@ -43,6 +43,7 @@ SIGNATURES = {
     "dv_unet_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_double)]),
     "dv_unet_forward_timed": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                         C.c_void_p, C.c_int32]),
+    "dv_unet_op_count": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32)]),
     "dv_unet_op_info": (C.c_int, [C.c_void_p, C.c_int32, C.c_char_p, C.POINTER(C.c_double), C.c_char_p]),
     "dv_penc_create": (C.c_int, [C.POINTER(PencCfg), C.POINTER(C.c_void_p)]),
     "dv_penc_destroy": (None, [C.c_void_p]),

@@ -57,7 +57,18 @@ struct GemmParams {
   // prompt-encoder epilogue options (reference operations.py:687, 813, 820): ReLU, then a per-row keep mask
   int relu;                     // 1: result = max(result, 0) after bias / residual
   const float* rowmask;         // [M] multiplier of every output row (padding frames -> 0) or null
+  // split-K over two launches (long K, too few tiles to occupy the chip): scratch for the k-slices' raw accumulators
+  // (>= gemm_splitk_bytes(M, N, sk_split)), or null.  The caller sets sk_buf / sk_split from gemm_splitk_plan() and
+  // leaves sk_mode 0; launch_gemm runs the pair with its ordinary tile choice.
+  float* sk_buf;
+  int sk_split;
+  int sk_mode;                  // internal: 0 single launch, 1 k-slice pass (dump), 2 epilogue pass
 };
+// number of k-slices launch_gemm should run this GEMM in (0: single launch); env DVITS_SPLITK tunes / disables
+int gemm_splitk_plan(int M, int N, int K, int epi);
+inline size_t gemm_splitk_bytes(int M, int N, int split) {
+  return (size_t)split * ((M + 127) / 128 * 128) * ((N + 127) / 128 * 128) * sizeof(float);
+}
 
 struct AttnParams {
   const float* q; const float* k; const float* v; const float* bias;

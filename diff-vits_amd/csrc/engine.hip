@@ -147,7 +147,7 @@ struct dv_unet {
   char* slab = nullptr; size_t slab_bytes = 0;
   bf16_t* zero_page = nullptr;               // 256 zero bytes: source of padded rows for the LDS-DMA
   std::vector<OpFn> step_ops, cond_ops;
-  struct OpMeta { const char* kind; double flops; std::string desc; };
+  struct OpMeta { const char* kind; double flops; std::string desc; int launches; };
   std::vector<OpMeta> step_meta;          // parallel to step_ops (profiling / roofline report)
   std::vector<Probe> probes;
   // persistent per-XCD schedule (persist.hip): descriptors of the step ops that can run inside it
@@ -260,17 +260,18 @@ struct Builder {
     arena.release(off);
   }
   const char* cur_kind = "misc";
+  int cur_launches = 1;                   // kernel launches of the operation being emitted (split-K pair: 2)
   double cur_flops = 0;
   std::string cur_desc;
   void emit(std::vector<OpFn>& ops, OpFn f, const PersistOp* pop = nullptr) {
     if (dry) return;
     ops.push_back(std::move(f));
     if (&ops == &u->step_ops) {
-      u->step_meta.push_back({cur_kind, cur_flops, cur_desc});
+      u->step_meta.push_back({cur_kind, cur_flops, cur_desc, cur_launches});
       if (pop) { u->step_pop.push_back((int)u->pops.size()); u->pops.push_back(*pop); }
       else u->step_pop.push_back(-1);
     }
-    cur_kind = "misc"; cur_flops = 0; cur_desc.clear();
+    cur_kind = "misc"; cur_flops = 0; cur_desc.clear(); cur_launches = 1;
   }
   // descriptor of a GEMM for the persistent schedule, or false if its shape is outside what persist.hip instantiates
   bool persist_gemm(const GemmParams& gin, PersistOp& po) {
@@ -386,9 +387,16 @@ struct Builder {
       cur_desc = buf;
     }
     u->flops += dry ? 0.0 : cur_flops;
+    // long K on few tiles: offer scratch for a two-launch split-K (kernels_gemm.hip decides with the same predicate)
+    int k_pad = 0;
+    for (int s2 = 0; s2 < g.nseg; ++s2) k_pad += g.seg[s2].taps * (g.seg[s2].c0 + g.seg[s2].c1);
+    g.sk_split = arena.exact ? 0 : gemm_splitk_plan(g.M, g.N, k_pad, g.epi);
+    if (g.sk_split >= 2) g.sk_buf = alloc(gemm_splitk_bytes(g.M, g.N, g.sk_split) / sizeof(float));
+    if (g.sk_split >= 2) { cur_desc += " splitk=" + std::to_string(g.sk_split); cur_launches = 2; }
     PersistOp po;
     const bool pok = !dry && persist_gemm(g, po);
     emit(ops, [g, p](hipStream_t st) { return launch_gemm(g, p, st); }, pok ? &po : nullptr);
+    if (g.sk_buf) release((const void*)g.sk_buf);
   }
 
   static GemmSeg seg(Planes a0, int c0, Planes a1, int c1, int taps, int pad) {
@@ -1418,8 +1426,9 @@ extern "C" int dv_unet_time_family(dv_unet* u, const char* kind, int32_t reps, v
   if (!u->prepared || !u->cond_set || !u->io.x) return dv_fail(DV_ERR_STATE, "dv_unet_time_family needs a completed forward");
   hipStream_t st = (hipStream_t)stream;
   std::vector<int> idx;
+  int per_rep = 0;
   for (int i = 0; i < (int)u->step_ops.size(); ++i)
-    if (strcmp(u->step_meta[i].kind, kind) == 0) idx.push_back(i);
+    if (strcmp(u->step_meta[i].kind, kind) == 0) { idx.push_back(i); per_rep += u->step_meta[i].launches; }
   if (idx.empty()) return dv_fail(DV_ERR_INVALID, "no launch of family '%s' in the schedule", kind);
   hipEvent_t e0, e1;
   HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
@@ -1437,7 +1446,7 @@ extern "C" int dv_unet_time_family(dv_unet* u, const char* kind, int32_t reps, v
   HIPCHK(hipEventSynchronize(e1));
   HIPCHK(hipEventElapsedTime(ms_total, e0, e1));
   (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
-  *launches = (int32_t)idx.size() * reps;
+  *launches = (int32_t)per_rep * reps;
   return DV_OK;
 }
 
@@ -1449,9 +1458,18 @@ extern "C" int dv_unet_op_info(dv_unet* u, int32_t index, char* kind16, double* 
   return DV_OK;
 }
 
+extern "C" int dv_unet_op_count(dv_unet* u, int32_t* n_ops) {
+  if (!u || !u->prepared || !n_ops) return dv_fail(DV_ERR_STATE, "dv_unet_op_count before prepare");
+  *n_ops = (int32_t)u->step_ops.size();
+  return DV_OK;
+}
+
 extern "C" int dv_unet_stats(dv_unet* u, int64_t* n_launch, double* flops) {
   if (!u || !u->prepared) return dv_fail(DV_ERR_STATE, "dv_unet_stats before prepare");
-  if (n_launch) *n_launch = (int64_t)u->step_ops.size();
+  if (n_launch) {
+    *n_launch = 0;
+    for (const auto& m : u->step_meta) *n_launch += m.launches;
+  }
   if (flops) *flops = u->flops;
   return DV_OK;
 }

@@ -52,8 +52,12 @@ __device__ __forceinline__ float gelu_erf(float v) {
 // SC1: every load of MUTABLE data (A planes, residual, LayerNorm partials) bypasses this CU's L1 (`sc1`: served by the
 // XCD's L2).  Needed when producer and consumer run inside ONE launch on different CUs (persist.hip); weights and
 // biases are never written on the GPU and keep the default policy.
+// Split-K over two launches (p.sk_mode; long-K GEMMs with too few tiles to occupy 256 CUs): mode 1 runs slice ksel of
+// p.sk_split equal k-tile ranges and dumps the raw accumulators lane-linearly (coalesced 16-byte stores) to p.sk_buf;
+// mode 2 (same tile shape) starts from the sum of the slices, skips the k-loop and runs the ordinary epilogue.
+// Measured: worth ~25 % on the K >= 1536 GEMMs of the 128-frame level, ~1 % of a forward.
 template <int BM, int BN, int BK, int WM, int WN, int NSPLIT, int KS, bool SC1>
-__device__ __forceinline__ void gemm_tile(const GemmParams& p, const int m0, const int n0, char* smem) {
+__device__ __forceinline__ void gemm_tile(const GemmParams& p, const int m0, const int n0, char* smem, const int ksel = 0) {
   constexpr int FM = BM / (WM * 32), FN = BN / (WN * 32);
   constexpr int NWQ = WM * WN;                       // waves per k-group (1, 2 or 4)
   constexpr int NWV = NWQ * KS;                      // waves per workgroup
@@ -125,6 +129,9 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int m0, con
   // descriptor (kernel-argument memory) is only re-read when a source tensor / tap is exhausted, never on the
   // per-tile path (a scalar load there sits on every wave's critical path right after the barrier).
   const int total_kt = p.seg[0].nkt + (p.nseg > 1 ? p.seg[1].nkt : 0);
+  int kt0 = 0, nk = total_kt;                        // this launch's k-tiles: [kt0, kt0 + nk)
+  if (p.sk_mode == 1) { kt0 = ksel * total_kt / p.sk_split; nk = (ksel + 1) * total_kt / p.sk_split - kt0; }
+  if (p.sk_mode == 2) nk = 0;
   int ld_seg = 0, ld_tap = 0, ld_half = 0;
   const bf16_t* cur_hi; const bf16_t* cur_lo;
   int cur_ld, cur_col, cur_toff;
@@ -188,6 +195,11 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int m0, con
     for (int u = 0; u < LPT; ++u) issue_unit(kt, u);
     advance();
   };
+  if (kt0 > 0) {                                     // second k-half: move the source state to its first tile
+    for (int t = 0; t < kt0; ++t) advance();
+#pragma unroll
+    for (int q = 0; q < B_IPW; ++q) b_off[q] += (size_t)kt0 * (BK * 2);
+  }
 
   f32x16 acc[FM][FN];
 #pragma unroll
@@ -196,8 +208,29 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int m0, con
     for (int j = 0; j < FN; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
+  constexpr bool SPLIT_EPI = KS == 2 && FM % 2 == 0;
   const int l31 = lane & 31, lh = lane >> 5;
+  // split-K dump: [slice][tile][fragment][4 column groups][64 * NWQ lanes] float4
+  const size_t sk_tile = ((size_t)(m0 / BM) * ((p.N + BN - 1) / BN) + n0 / BN) * (FM * FN * 4) * (64 * NWQ);
+  const size_t sk_slice = (size_t)((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN) * (FM * FN * 4) * (64 * NWQ);
+  if (p.sk_mode == 2) {                              // accumulators = sum of the k-slices' dumps
+    const float4* s0 = reinterpret_cast<const float4*>(p.sk_buf) + sk_tile + wq * 64 + lane;
+    for (int sl = 0; sl < p.sk_split; ++sl, s0 += sk_slice) {
+#pragma unroll
+      for (int i = 0; i < FM; ++i) {
+        if (SPLIT_EPI ? ((i & 1) == kgrp) : (kgrp == 0)) {
+#pragma unroll
+          for (int j = 0; j < FN; ++j)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+              const float4 a = s0[(size_t)((i * FN + j) * 4 + g) * (64 * NWQ)];
+              acc[i][j][4 * g] += a.x; acc[i][j][4 * g + 1] += a.y; acc[i][j][4 * g + 2] += a.z; acc[i][j][4 * g + 3] += a.w;
+            }
+        }
+      }
+    }
+  }
+
   // One k-tile of work for this wave: all operand fragments are read first, then the MFMAs go out in groups of
   // FM*FN (one product term of one 16-deep k-step: consecutive MFMAs write different accumulators) and, when
   // ISSUE, the DMA units of tile kt+NSTAGE-1 are spread between the groups: a wave blocked in the (slow, 64 B/clk
@@ -292,7 +325,7 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int m0, con
   // residual operand of small tiles: fetched before the k-loop so its latency hides under it
   constexpr bool PRE_RES = FM * FN <= 2;
   float rpre[PRE_RES ? FM * FN * 16 : 1];
-  if (PRE_RES && p.epi == EPI_RESIDUAL) {
+  if (PRE_RES && p.epi == EPI_RESIDUAL && p.sk_mode != 1) {
 #pragma unroll
     for (int i = 0; i < FM; ++i) {
       const size_t ro = (size_t)min(m0 + (wm * FM + i) * 32 + l31, p.M - 1) * p.ldres;
@@ -303,7 +336,7 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int m0, con
 
   // fused LayerNorm (consumer side): per-row mean / rstd of this tile's rows from the producer's partials
   __shared__ float2 s_ln[BM];
-  if (p.ln_stat) {
+  if (p.ln_stat && p.sk_mode != 1) {
     for (int r = tid; r < BM; r += 64 * NWV) {
       const int m = min(m0 + r, p.M - 1);
       const float2* src = reinterpret_cast<const float2*>(p.ln_stat) + (size_t)m * p.ln_nblk;
@@ -336,14 +369,14 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int m0, con
   DV_TRACE(10);    // residual prefetch / LayerNorm rows / bias DMA issued
 #pragma unroll
   for (int t = 0; t < NSTAGE - 1; ++t) {
-    if (t < total_kt) issue(t);
+    if (t < nk) issue(t);
 #ifdef DV_GEMM_TRACING
     if (t == 0) DV_TRACE(11);
 #endif
   }
   DV_TRACE(1);
   // steady state: tile kt+NSTAGE-1 is issued while tile kt is multiplied; NSTAGE-2 younger tiles stay in flight
-  const int n_steady = total_kt - (NSTAGE - 1);
+  const int n_steady = nk - (NSTAGE - 1);
   int kt = 0;
   for (; kt < n_steady; ++kt) {
     wait_vmcnt<(NSTAGE - 2) * LPT>();
@@ -353,8 +386,8 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int m0, con
 #endif
     step(kt, std::true_type{});                      // DMA overwrites the stage tile kt-1 was read from
   }
-  for (; kt < total_kt; ++kt) {                      // drain: nothing left to issue
-    const int younger = min(NSTAGE - 2, total_kt - 1 - kt);
+  for (; kt < nk; ++kt) {                            // drain: nothing left to issue
+    const int younger = min(NSTAGE - 2, nk - 1 - kt);
     if (younger >= 2) wait_vmcnt<2 * LPT>();
     else if (younger == 1) wait_vmcnt<LPT>();
     else wait_vmcnt<0>();
@@ -365,11 +398,11 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int m0, con
     step(kt, std::false_type{});
   }
 
+  if (nk == 0) { wait_vmcnt<0>(); __syncthreads(); }   // epilogue-only launch: the bias DMA has landed
   DV_TRACE(3);
   // KS == 2: add the two k-groups' partial accumulators through LDS (lane-linear, conflict-free).  With an even
   // number of row fragments each k-group keeps the sums of ITS fragments (i % 2 == kgrp) and both run the epilogue on
   // their half, so all eight waves share the (store- and GELU-bound) epilogue; otherwise group 1 hands everything over.
-  constexpr bool SPLIT_EPI = KS == 2 && FM % 2 == 0;
   if (KS == 2) {
     __builtin_amdgcn_s_barrier();                    // every wave is done reading the ring
     float* red = reinterpret_cast<float*>(smem);
@@ -397,6 +430,20 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int m0, con
     }
   }
   auto my_frag_row = [&](int i) { return !SPLIT_EPI || ((i & 1) == kgrp); };
+  if (p.sk_mode == 1) {                              // first pass of a split-K pair: dump this k-slice and leave
+    float4* d0 = reinterpret_cast<float4*>(p.sk_buf) + (size_t)ksel * sk_slice + sk_tile + wq * 64 + lane;
+#pragma unroll
+    for (int i = 0; i < FM; ++i) {
+      if (!my_frag_row(i)) continue;
+#pragma unroll
+      for (int j = 0; j < FN; ++j)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+          d0[(size_t)((i * FN + j) * 4 + g) * (64 * NWQ)] =
+              make_float4(acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]);
+    }
+    return;
+  }
 
   // ---- epilogue ----
   DV_TRACE(4);

@@ -37,7 +37,13 @@ __global__ __launch_bounds__(64 * WM * WN * KS) void k_gemm(const GemmParams p) 
     const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
     bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
   }
-  gemm_tile<BM, BN, BK, WM, WN, NSPLIT, KS, false>(p, (bid / n_tiles_n) * BM, (bid % n_tiles_n) * BN, smem);
+  int ksel = 0;
+  if (p.sk_mode == 1) {                                // XCD-contiguous ids share a k-slice: an L2 holds one slice of A and W
+    const int tiles = nwg / p.sk_split;
+    ksel = bid / tiles;
+    bid -= ksel * tiles;
+  }
+  gemm_tile<BM, BN, BK, WM, WN, NSPLIT, KS, false>(p, (bid / n_tiles_n) * BM, (bid % n_tiles_n) * BN, smem, ksel);
 }
 
 template <int BM, int BN, int BK, int WM, int WN, int NSPLIT, int KS>
@@ -50,7 +56,7 @@ struct GemmCfg {
                                hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
   }
   static hipError_t launch(const GemmParams& p, hipStream_t st) {
-    const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
+    const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN) * (p.sk_mode == 1 ? p.sk_split : 1);
     hipLaunchKernelGGL((k_gemm<BM, BN, BK, WM, WN, NSPLIT, KS>), dim3(tiles), dim3(64 * WM * WN * KS), SMEM, st, p);
     return hipGetLastError();
   }
@@ -124,14 +130,41 @@ static const GemmTune& gemm_tune() {
   return t;
 }
 
+// Split-K pair (env DVITS_SPLITK="max_tiles,min_k,split", "0" disables): a GEMM with at most max_tiles 64x64 tiles
+// and K >= min_k runs as two launches - `split` k-slices per tile on split x the workgroups (raw accumulators dumped),
+// then an epilogue-only pass that sums the slices.  Only pays when the single launch leaves CUs idle for a long k-loop:
+// the 128-frame level (128 tiles) with K >= 1536 gains ~25 %; at 192 tiles the 1.5 rounds of workgroups lose.
+// A 128x128-tile variant with 4-8 slices was measured slower everywhere (the dump and the second epilogue are both
+// store-bound: ~10 us + ~9 us per GEMM regardless of K).
+struct SplitKTune { int max_tiles = 160, min_k = 1536, split = 2; };
+static SplitKTune splitk_tune() {   // read when an engine is prepared, not per launch
+  SplitKTune v;
+  if (const char* e = getenv("DVITS_SPLITK")) { v.max_tiles = 0; sscanf(e, "%d,%d,%d", &v.max_tiles, &v.min_k, &v.split); }
+  return v;
+}
+int gemm_splitk_plan(int M, int N, int K, int epi) {
+  const SplitKTune t = splitk_tune();
+  const int tiles = ((M + 63) / 64) * ((N + 63) / 64);
+  if (tiles > t.max_tiles || K < t.min_k || t.split < 2 || (epi != EPI_STORE && epi != EPI_RESIDUAL)) return 0;
+  return t.split;
+}
+
 hipError_t launch_gemm(const GemmParams& pin, int precision, hipStream_t st) {
   GemmParams p = pin;
+  const bool x3 = precision == 0;
+  if (!p.zero_page || (x3 && !p.w_lo)) return hipErrorInvalidValue;
+  if (p.sk_buf && p.sk_split >= 2 && p.sk_mode == 0) {
+    p.sk_mode = 1;
+    hipError_t e = launch_gemm(p, precision, st);
+    if (e != hipSuccess) return e;
+    p.sk_mode = 2;
+    return launch_gemm(p, precision, st);
+  }
+  if (!p.sk_buf || p.sk_split < 2) { p.sk_buf = nullptr; p.sk_split = 0; p.sk_mode = 0; }
   const GemmTune& tune = gemm_tune();
   const int big_tiles = ((p.M + 127) / 128) * ((p.N + 127) / 128);
-  const bool x3 = precision == 0;
   bool k64 = tune.bk64 != 0;
   for (int s = 0; s < p.nseg; ++s) k64 = k64 && p.seg[s].c0 % 64 == 0 && p.seg[s].c1 % 64 == 0;
-  if (!p.zero_page || (x3 && !p.w_lo)) return hipErrorInvalidValue;
   const bool big = big_tiles >= tune.big;
   const int bk = (!big && k64) ? 64 : 32;
   for (int s = 0; s < p.nseg; ++s) {

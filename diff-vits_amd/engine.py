@@ -135,8 +135,10 @@ class UNetEngine:
         return n.value, f.value
 
     def profile_forward(self, x, cond, t):
-        """One eager forward with HIP events around every launch -> list of (kind, flops, ms, desc)."""
-        n, _ = self.stats()
+        """One eager forward with HIP events around every operation -> list of (kind, flops, ms, desc)."""
+        n_ops = C.c_int32()
+        _lib.check(_lib.lib().dv_unet_op_count(self._h, C.byref(n_ops)), "dv_unet_op_count")
+        n = n_ops.value
         ms = (C.c_float * n)()
         out = torch.empty((x.shape[0], self.out_channels, x.shape[2]), device=x.device, dtype=torch.float32)
         _lib.check(_lib.lib().dv_unet_forward_timed(self._h, _lib.ptr(x), x.shape[1], _lib.ptr(cond), _lib.ptr(t),

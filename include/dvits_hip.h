@@ -115,10 +115,14 @@ int dv_unet_forward(dv_unet* u, const float* x, int32_t cx, const float* cond, c
 /* Number of kernel launches one forward enqueues, and algorithmic FLOPs (2*MAC of all
  * contractions) of one forward at the prepared shape — for the roofline report. */
 int dv_unet_stats(dv_unet* u, int64_t* n_launch, double* flops);
+/* Number of schedule OPERATIONS of one forward (the index range of dv_unet_op_info / dv_unet_forward_timed).  An
+ * operation is one kernel launch, except a split-K GEMM pair (k-slice pass + epilogue pass), which is one operation
+ * of two launches. */
+int dv_unet_op_count(dv_unet* u, int32_t* n_ops);
 
 /* Measurement aid for bench.py: one forward with a HIP event pair around every launch of the
- * schedule (eager, not graph-replayed); ms_per_op[i] = elapsed ms of launch i.
- * dv_unet_op_info gives launch i's kernel family ("gemm", "attn", "gn_partial", "gn_finalize",
+ * schedule (eager, not graph-replayed); ms_per_op[i] = elapsed ms of operation i (capacity >= dv_unet_op_count).
+ * dv_unet_op_info gives operation i's kernel family ("gemm", "attn", "gn_partial", "gn_finalize",
  * "ln_stats", "misc"), its algorithmic FLOPs (0 for non-contractions) and a shape description. */
 int dv_unet_forward_timed(dv_unet* u, const float* x, int32_t cx, const float* cond, const float* t, float* y,
                           void* stream, float* ms_per_op, int32_t capacity);

@@ -349,6 +349,42 @@ def test_persistent_per_xcd_schedule_matches_per_launch():
         assert rel_l2(outs[1], outs[0]) < 5e-5
 
 
+def test_split_k_pair_matches_single_launch():
+    """Long-K GEMMs with few tiles run as a two-launch split-K pair (kernels_gemm.hip, DVITS_SPLITK).  Same engine with
+    the split disabled, on a ragged batch (rows beyond M in the last tile) and with three slices: agreement to float32
+    rounding, and the split schedule has one extra launch per split GEMM."""
+    from diff_vits_amd import synth
+    from diff_vits_amd.unet1d.unet_1d_condition import UNet1DConditionModel
+    kw = UNET_CASES["cfg1"][0]
+    with torch.device("meta"):
+        shapes = {k: tuple(v.shape) for k, v in UNet1DConditionModel(**kw).state_dict().items()}
+    sd = {k: torch.from_numpy(v) for k, v in synth.make_state_dict(shapes, seed=99).items()}
+    B, T, L = 3, 200, 33
+    x = torch.from_numpy(synth.normal(8, "x", (B, 80, T))).cuda()
+    cond = torch.from_numpy(synth.normal(8, "c", (B, 128, T))).cuda()
+    enc = torch.from_numpy(synth.normal(8, "e", (B, L, 128))).cuda()
+    t = torch.full((B,), 77.0, device="cuda")
+    outs, launches = [], []
+    for knob in ("0", None, "4096,768,3"):
+        if knob is None:
+            os.environ.pop("DVITS_SPLITK", None)
+        else:
+            os.environ["DVITS_SPLITK"] = knob
+        try:
+            m = UNet1DConditionModel(**kw).eval()
+            m.load_state_dict(sd)
+            eng = m.cuda().hip_engine()
+            eng.sync_weights()
+            eng.prepare(B, T, L)
+            eng.set_cond(enc, None)
+            outs.append(eng.eval(x, cond, t).clone().cpu().numpy())
+            launches.append(eng.stats()[0])
+        finally:
+            os.environ.pop("DVITS_SPLITK", None)
+    assert launches[0] < launches[1] < launches[2]
+    assert rel_l2(outs[1], outs[0]) < 2e-5 and rel_l2(outs[2], outs[0]) < 2e-5
+
+
 def test_unet_large_mean_activations_within_budget():
     """Robustness of the statistics paths (GroupNorm slabs reduced in fp64, fused-LayerNorm block partials combined with
     the parallel-variance formula): every bias of the network scaled x25, so normalised tensors have |mean| >> spread.
