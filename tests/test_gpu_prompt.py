@@ -155,3 +155,23 @@ def test_full_chain_ids_to_mel_hip(gold):
     audio, mel = ns2.sample(*[torch.from_numpy(a).cuda() for a in args], PassThroughVocoder(), sample_method="unipc",
                             noise=torch.from_numpy(x_T).cuda(), prior_noise=torch.from_numpy(pn).cuda())
     assert mel.shape == gf["mel"].shape and rel_l2(mel.cpu().numpy(), gf["mel"]) < 5e-4
+
+
+def test_checkpoint_to_mel_through_tts_infer_glue_hip(gold, tmp_path):
+    """diff_vits_amd.tts_infer: `load_model` on a reference-format checkpoint ({'step', 'model'}, reference names, one
+    training-only entry) -> `.to('cuda')` -> `synthesize` (HIP backend by default): mel within 5e-4 of the reference's
+    own sample() output (budget 1e-3)."""
+    from diff_vits_amd import synth, tts_infer
+    from test_prompt_cpu import PassThroughVocoder
+    from test_tts_infer import reference_checkpoint
+    path, cfg, g, gf, y = reference_checkpoint(gold, tmp_path)
+    model = tts_infer.load_model(path, "cuda", cfg)
+    T = gf["mel"].shape[2]
+    x_T = torch.from_numpy(synth.normal(1234, "full.x_T", (1, cfg["diffusion_encoder"]["in_channels"], T))).cuda()
+    pn = torch.from_numpy(synth.normal(1234, "full.prior_noise", (1, 128, T))).cuda()
+    batch = (torch.from_numpy(g["text"][:1]), torch.from_numpy(g["tone"][:1]), torch.from_numpy(g["language"][:1]),
+             torch.from_numpy(y[:1]), g["x_lengths"][:1].tolist())
+    audio, mel = tts_infer.synthesize(model, cfg, PassThroughVocoder(), [batch], None, "cuda", prompt_length="frames",
+                                      sample_method="unipc", noise=x_T, prior_noise=pn)
+    assert model.diff_model.backend == "hip" and mel.is_cuda and not audio.is_cuda
+    assert mel.shape == gf["mel"].shape and rel_l2(mel.cpu().numpy(), gf["mel"]) < 5e-4
