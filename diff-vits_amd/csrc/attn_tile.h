@@ -7,12 +7,12 @@
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+#ifndef DV_ATTN_KVSPLIT_MAX
+#define DV_ATTN_KVSPLIT_MAX 16
+#endif
 
-__device__ __forceinline__ unsigned apk(float lo, float hi) {
-  unsigned r;
-  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
-  return r;
-}
+__device__ __forceinline__ unsigned apk(float lo, float hi) { return dv_cvt_pk_bf16(lo, hi); }
 __device__ __forceinline__ float bf_lo(unsigned w) { return __uint_as_float(w << 16); }
 __device__ __forceinline__ float bf_hi(unsigned w) { return __uint_as_float(w & 0xffff0000u); }
 
@@ -31,6 +31,23 @@ struct AttnGeom {
   static constexpr int smem_bytes(int npl) { return planes_bytes(npl) + NST * RAW; }
 };
 
+#if defined(DV_GEMM_TRACE) && defined(DV_ATTN_TRACE_OWNER)
+// development build only (make trace): per-workgroup s_memtime stamps of the attention kernel's phases
+__device__ unsigned long long g_attn_trace[4096 * 16];
+#define DV_ATRACE(i) do { const unsigned w_ = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z); \
+    if (threadIdx.x == 0 && w_ < 4096) g_attn_trace[w_ * 16 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+extern "C" int dv_debug_attn_trace(unsigned long long* host, int n_wg) {
+  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_attn_trace), (size_t)n_wg * 16 * sizeof(unsigned long long));
+}
+extern "C" int dv_debug_attn_trace_clear() {
+  void* d = nullptr;
+  hipError_t e = hipGetSymbolAddress(&d, HIP_SYMBOL(g_attn_trace));
+  return (int)(e != hipSuccess ? e : hipMemset(d, 0, sizeof(g_attn_trace)));
+}
+#else
+#define DV_ATRACE(i) do {} while (0)
+#endif
+
 // One (query block of 32*NW queries, head h, batch item b).  SC1: loads of q / k / v / bias bypass this CU's L1 (they
 // were written earlier in the SAME launch by other CUs: persist.hip).
 template <int DP, int NW, int NSPLIT, bool SC1>
@@ -45,7 +62,7 @@ __device__ __forceinline__ void attn_tile(const AttnParams& p, const int qblk, c
   constexpr int BUF = (K_PL + V_PL) * NPL + 128;   // + 32 floats of key bias
   constexpr int NT = 64 * NW;
   constexpr int TASKS = 4 * DP;                    // (key pair, 4-channel group) conversion tasks per tile
-  constexpr int TPT = (TASKS + NT - 1) / NT;
+  constexpr bool KVSPLIT = DP <= DV_ATTN_KVSPLIT_MAX;   // conversion task granularity (see convert_pair)
   using G = AttnGeom<DP, NW>;
   constexpr int NST = G::NST, RAWK = G::RAWK, RAW = G::RAW;
   constexpr int CPR = DP / 4;                      // 16-byte chunks per raw row
@@ -53,6 +70,7 @@ __device__ __forceinline__ void attn_tile(const AttnParams& p, const int qblk, c
   constexpr int IPW = KPW + 1;                     // DMA instructions per wave per tile, + its bias slot
   char* const raw0 = lds + G::planes_bytes(NPL);
 
+  DV_ATRACE(0);
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l31 = lane & 31, lh = lane >> 5;
   const int d = p.d;
@@ -123,52 +141,75 @@ __device__ __forceinline__ void attn_tile(const AttnParams& p, const int qblk, c
       else glds4(src, st + (unsigned)(2 * RAWK + wave * 256));
     }
   };
-  // conversion of raw tile t -> split bf16 planes buffer `buf`: task = (key pair kp, 4-channel group c4)
-  auto convert_tile = [&](int t, int buf) {
-    const char* rs = raw0 + (t % NST) * RAW;
-    char* base = lds + buf * BUF;
-    char* k_hi = base;
-    char* k_lo = base + K_PL;
-    char* v_hi = base + NPL * K_PL;
-    char* v_lo = v_hi + V_PL;
-    float* bl = reinterpret_cast<float*>(base + (K_PL + V_PL) * NPL);
+  // conversion of the raw sub-tile pair (t0, t0 + 1) -> split bf16 planes buffers (buf0, buf0 + 1).  The key loop is
+  // bound by vector-ALU work (softmax + operand splitting, two waves per SIMD), and the waves meet at one barrier per
+  // iteration: the conversion is therefore cut into small tasks = (sub-tile, K or V, key pair kp, 4-channel group c4)
+  // of 8 elements, spread over as many waves as there are (4 * TASKS = 16 DP tasks per pair: 256 .. 1024), instead of
+  // 16-element tasks that kept only DP / 16 waves busy while the others waited.  TASKS is a multiple of 64, so the
+  // K / V choice is wave-uniform.  Measured: the 8-element tasks pay at d = 16 only (more, narrower LDS writes cost
+  // more than the better balance gains at d >= 48); wider heads keep K and V of a (kp, c4) in one 16-element task,
+  // still spread over both sub-tiles.
+  auto convert_pair = [&](int t0, int buf0) {
+    constexpr int NPART = KVSPLIT ? 2 : 1;              // K and V of a (kp, c4) as two tasks, or as one
+    constexpr int TASKS2 = 2 * NPART * TASKS;
+    // only the first wave of each SIMD converts (waves w and w + 4 share a SIMD): its partner starts the MFMAs at
+    // once, which de-phases the pair - one in the vector ALU while the other is in the matrix pipe
+    constexpr int CT = 64 * (NW < 4 ? NW : 4);
+    constexpr int TPT2 = (TASKS2 + CT - 1) / CT;
 #pragma unroll
-    for (int i = 0; i < TPT; ++i) {
-      const int task = tid + i * NT;
-      if (task >= TASKS) continue;
-      const int kp = task / (DP / 4), c4 = (task - kp * (DP / 4)) * 4;
+    for (int i = 0; i < TPT2; ++i) {
+      const int task = tid + i * CT;
+      if (tid >= CT || task >= TASKS2) continue;
+      const int tl = task / (NPART * TASKS), r1 = task - tl * (NPART * TASKS);
+      const int which = KVSPLIT ? __builtin_amdgcn_readfirstlane(r1 / TASKS) : 0, r2 = r1 - which * TASKS;
+      const int kp = r2 / (DP / 4), c4 = (r2 - kp * (DP / 4)) * 4;
+      const char* rs = raw0 + ((t0 + tl) % NST) * RAW + which * RAWK;
+      char* base = lds + (buf0 + tl) * BUF;
       float4 a = *reinterpret_cast<const float4*>(rs + ((2 * kp) * DP + c4) * 4);
       float4 c = *reinterpret_cast<const float4*>(rs + ((2 * kp + 1) * DP + c4) * 4);
-      float4 va = *reinterpret_cast<const float4*>(rs + RAWK + ((2 * kp) * DP + c4) * 4);
-      float4 vc = *reinterpret_cast<const float4*>(rs + RAWK + ((2 * kp + 1) * DP + c4) * 4);
-      if (c4 >= d) { a = make_float4(0.f, 0.f, 0.f, 0.f); c = a; va = a; vc = a; }   // zero the padded channels
-      // K rows 2kp, 2kp+1: 4 channels -> 8 bytes per plane
-      uint2 h0, h1, l0, l1;
-      h0.x = apk(a.x, a.y); h0.y = apk(a.z, a.w);
-      h1.x = apk(c.x, c.y); h1.y = apk(c.z, c.w);
-      *reinterpret_cast<uint2*>(k_hi + (2 * kp) * KP + c4 * 2) = h0;
-      *reinterpret_cast<uint2*>(k_hi + (2 * kp + 1) * KP + c4 * 2) = h1;
-      if (SPLIT) {
-        l0.x = apk(a.x - bf_lo(h0.x), a.y - bf_hi(h0.x)); l0.y = apk(a.z - bf_lo(h0.y), a.w - bf_hi(h0.y));
-        l1.x = apk(c.x - bf_lo(h1.x), c.y - bf_hi(h1.x)); l1.y = apk(c.z - bf_lo(h1.y), c.w - bf_hi(h1.y));
-        *reinterpret_cast<uint2*>(k_lo + (2 * kp) * KP + c4 * 2) = l0;
-        *reinterpret_cast<uint2*>(k_lo + (2 * kp + 1) * KP + c4 * 2) = l1;
+      if (c4 >= d) { a = make_float4(0.f, 0.f, 0.f, 0.f); c = a; }   // zero the padded channels
+      if (which == 0) {
+        // K rows 2kp, 2kp+1: 4 channels -> 8 bytes per plane
+        char* k_hi = base;
+        char* k_lo = base + K_PL;
+        uint2 h0, h1, l0, l1;
+        h0.x = apk(a.x, a.y); h0.y = apk(a.z, a.w);
+        h1.x = apk(c.x, c.y); h1.y = apk(c.z, c.w);
+        *reinterpret_cast<uint2*>(k_hi + (2 * kp) * KP + c4 * 2) = h0;
+        *reinterpret_cast<uint2*>(k_hi + (2 * kp + 1) * KP + c4 * 2) = h1;
+        if (SPLIT) {
+          l0.x = apk(a.x - bf_lo(h0.x), a.y - bf_hi(h0.x)); l0.y = apk(a.z - bf_lo(h0.y), a.w - bf_hi(h0.y));
+          l1.x = apk(c.x - bf_lo(h1.x), c.y - bf_hi(h1.x)); l1.y = apk(c.z - bf_lo(h1.y), c.w - bf_hi(h1.y));
+          *reinterpret_cast<uint2*>(k_lo + (2 * kp) * KP + c4 * 2) = l0;
+          *reinterpret_cast<uint2*>(k_lo + (2 * kp + 1) * KP + c4 * 2) = l1;
+        }
       }
-      // V^T: channel rows, key slot = key index with bits 2 and 3 swapped; keys 2kp, 2kp+1 are adjacent slots
-      const int j = 2 * kp;
-      const int slot = (j & 0x13) | ((j & 4) << 1) | ((j & 8) >> 1);
-      const float ve0[4] = {va.x, va.y, va.z, va.w}, ve1[4] = {vc.x, vc.y, vc.z, vc.w};
+      if (!KVSPLIT) {
+        a = *reinterpret_cast<const float4*>(rs + RAWK + ((2 * kp) * DP + c4) * 4);
+        c = *reinterpret_cast<const float4*>(rs + RAWK + ((2 * kp + 1) * DP + c4) * 4);
+        if (c4 >= d) { a = make_float4(0.f, 0.f, 0.f, 0.f); c = a; }
+      }
+      if (!KVSPLIT || which == 1) {
+        // V^T: channel rows, key slot = key index with bits 2 and 3 swapped; keys 2kp, 2kp+1 are adjacent slots
+        char* v_hi = base + NPL * K_PL;
+        char* v_lo = v_hi + V_PL;
+        const int j = 2 * kp;
+        const int slot = (j & 0x13) | ((j & 4) << 1) | ((j & 8) >> 1);
+        const float ve0[4] = {a.x, a.y, a.z, a.w}, ve1[4] = {c.x, c.y, c.z, c.w};
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const unsigned hw = apk(ve0[e], ve1[e]);
-        *reinterpret_cast<unsigned*>(v_hi + (c4 + e) * VP + slot * 2) = hw;
-        if (SPLIT) *reinterpret_cast<unsigned*>(v_lo + (c4 + e) * VP + slot * 2) = apk(ve0[e] - bf_lo(hw), ve1[e] - bf_hi(hw));
+        for (int e = 0; e < 4; ++e) {
+          const unsigned hw = apk(ve0[e], ve1[e]);
+          *reinterpret_cast<unsigned*>(v_hi + (c4 + e) * VP + slot * 2) = hw;
+          if (SPLIT) *reinterpret_cast<unsigned*>(v_lo + (c4 + e) * VP + slot * 2) = apk(ve0[e] - bf_lo(hw), ve1[e] - bf_hi(hw));
+        }
       }
     }
-    if (tid < 32) {
-      const int key = t * 32 + tid;
-      const float raw = reinterpret_cast<const float*>(rs + 2 * RAWK)[tid];     // wave 0's slot
-      bl[tid] = (key < p.Tk) ? (p.bias ? raw * LOG2E : 0.f) : -1e30f;
+    if (wave == NW - 1) {        // key bias of both sub-tiles (the last wave has the fewest conversion tasks)
+      const int tl = lane >> 5, t = t0 + tl;
+      const int key = t * 32 + l31;
+      const float raw = reinterpret_cast<const float*>(raw0 + (t % NST) * RAW + 2 * RAWK)[l31];     // wave 0's slot
+      float* bl = reinterpret_cast<float*>(lds + (buf0 + tl) * BUF + (K_PL + V_PL) * NPL);
+      bl[l31] = (key < p.Tk) ? (p.bias ? raw * LOG2E : 0.f) : -1e30f;
     }
   };
   // this wave's DMA of the tiles issued after tile `t` may stay in flight; everything up to `t` has landed
@@ -184,19 +225,25 @@ __device__ __forceinline__ void attn_tile(const AttnParams& p, const int qblk, c
   // lane.  Sub-tile t lives in raw stage t % NST and, converted, in planes buffer 2 * (iteration & 1) + (t & 1).  A
   // trailing odd sub-tile is processed as fully masked (its keys clamp to Tk - 1, its bias is -1e30).
   const int nsub = (p.Tk + 31) / 32, nit = (nsub + 1) / 2, nsub2 = 2 * nit;
+  DV_ATRACE(1);                  // Q fragments loaded and split
 #pragma unroll
   for (int t = 0; t < NST; ++t)
     if (t < nsub2) issue_tile(t);
+  DV_ATRACE(2);                  // ring filled
   wait_tile(1, min(nsub2, NST) - 1);
   __syncthreads();
-  convert_tile(0, 0);
-  convert_tile(1, 1);
+  DV_ATRACE(3);                  // first two sub-tiles landed
+  convert_pair(0, 0);
+  DV_ATRACE(4);                  // and converted
   for (int it = 0; it < nit; ++it) {
+#ifdef DV_GEMM_TRACE
+    if (it == 1) DV_ATRACE(5);   // first iteration done
+#endif
     const bool more = it + 1 < nit;
     if (more) wait_vmcnt<0>();   // sub-tiles 2it+2, 2it+3 (issued one iteration ago) have landed for this wave
     __syncthreads();            // planes of this iteration written, next raw sub-tiles landed, previous MFMAs done
     if (2 * it + NST < nsub2) { issue_tile(2 * it + NST); issue_tile(2 * it + NST + 1); }   // stages of sub-tiles 2it, 2it+1
-    if (more) { convert_tile(2 * it + 2, 2 * ((it + 1) & 1)); convert_tile(2 * it + 3, 2 * ((it + 1) & 1) + 1); }
+    if (more) convert_pair(2 * it + 2, 2 * ((it + 1) & 1));
     const char* base0 = lds + (2 * (it & 1)) * BUF;
 
     // ---- S^T = K Q^T for both sub-tiles (independent accumulators: the MFMA chains interleave) ----
@@ -236,22 +283,27 @@ __device__ __forceinline__ void attn_tile(const AttnParams& p, const int qblk, c
         }
       }
     }
-    float tmax = fmaxf(s[0][0], s[1][0]);
+    // vector-ALU economy (this loop is VALU-bound): three-input max, packed fp32 subtract / add
+    float tmax = m_run;
 #pragma unroll
-    for (int r = 1; r < 16; ++r) tmax = fmaxf(tmax, fmaxf(s[0][r], s[1][r]));
-    tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
-    const float m_new = fmaxf(m_run, tmax);
+    for (int r = 0; r < 16; ++r) tmax = __builtin_fmaxf(__builtin_fmaxf(tmax, s[0][r]), s[1][r]);   // v_max3_f32
+    const float m_new = fmaxf(tmax, __shfl_xor(tmax, 32));
     const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
     m_run = m_new;
-    float psum0 = 0.f, psum1 = 0.f;
+    const f32x2 mneg = {-m_new, -m_new};
+    f32x2 psum = {0.f, 0.f};
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      s[0][r] = __builtin_amdgcn_exp2f(s[0][r] - m_new);
-      s[1][r] = __builtin_amdgcn_exp2f(s[1][r] - m_new);
-      psum0 += s[0][r];
-      psum1 += s[1][r];
-    }
-    l_run = l_run * alpha + (psum0 + psum1);
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int r = 0; r < 16; r += 2) {
+        f32x2 v = {s[u][r], s[u][r + 1]};
+        v += mneg;                                            // v_pk_add_f32
+        v.x = __builtin_amdgcn_exp2f(v.x);
+        v.y = __builtin_amdgcn_exp2f(v.y);
+        psum += v;
+        s[u][r] = v.x; s[u][r + 1] = v.y;
+      }
+    l_run = l_run * alpha + (psum.x + psum.y);
     if (__any(alpha != 1.0f)) {        // the running maximum moved for some query of this wave
 #pragma unroll
       for (int nb = 0; nb < NB; ++nb)
@@ -271,10 +323,15 @@ __device__ __forceinline__ void attn_tile(const AttnParams& p, const int qblk, c
         const bf16x8 ph = __builtin_bit_cast(bf16x8, hw);
         bf16x8 pl;
         if (SPLIT) {
-          lw.x = apk(s[u][kb * 8 + 0] - bf_lo(hw.x), s[u][kb * 8 + 1] - bf_hi(hw.x));
-          lw.y = apk(s[u][kb * 8 + 2] - bf_lo(hw.y), s[u][kb * 8 + 3] - bf_hi(hw.y));
-          lw.z = apk(s[u][kb * 8 + 4] - bf_lo(hw.z), s[u][kb * 8 + 5] - bf_hi(hw.z));
-          lw.w = apk(s[u][kb * 8 + 6] - bf_lo(hw.w), s[u][kb * 8 + 7] - bf_hi(hw.w));
+          auto lo_pair = [&](unsigned h2, float x0, float x1) {   // residual of two scores: one packed subtract
+            const f32x2 x = {x0, x1}, hf = {bf_lo(h2), bf_hi(h2)};
+            const f32x2 dlt = x - hf;
+            return apk(dlt.x, dlt.y);
+          };
+          lw.x = lo_pair(hw.x, s[u][kb * 8 + 0], s[u][kb * 8 + 1]);
+          lw.y = lo_pair(hw.y, s[u][kb * 8 + 2], s[u][kb * 8 + 3]);
+          lw.z = lo_pair(hw.z, s[u][kb * 8 + 4], s[u][kb * 8 + 5]);
+          lw.w = lo_pair(hw.w, s[u][kb * 8 + 6], s[u][kb * 8 + 7]);
           pl = __builtin_bit_cast(bf16x8, lw);
         }
 #pragma unroll
@@ -292,6 +349,7 @@ __device__ __forceinline__ void attn_tile(const AttnParams& p, const int qblk, c
     }
   }
 
+  DV_ATRACE(6);                  // key loop done
   const float l_tot = l_run + __shfl_xor(l_run, 32);
   const float inv = 1.0f / l_tot;
   if (q_ok) {
@@ -318,5 +376,6 @@ __device__ __forceinline__ void attn_tile(const AttnParams& p, const int qblk, c
         }
       }
   }
+  DV_ATRACE(7);
 }
 

@@ -56,3 +56,12 @@ __device__ __forceinline__ void wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
+// Two floats -> packed bf16 pair (round to nearest even): one v_cvt_pk_bf16_f32.  Written as a vector conversion, NOT
+// inline assembly: the compiler's hazard recogniser does not look inside asm blocks, and a conversion scheduled right
+// behind the transcendental-unit instruction (v_exp_f32) that produces its operand read a stale register.
+typedef float dv_f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 dv_bf16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned dv_cvt_pk_bf16(float lo, float hi) {
+  const dv_f32x2 v = {lo, hi};
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, dv_bf16x2));
+}

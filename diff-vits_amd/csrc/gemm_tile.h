@@ -26,11 +26,7 @@ extern "C" int dv_debug_gemm_trace_clear() {
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 
-__device__ __forceinline__ unsigned cvt_pk_bf16(float lo, float hi) {
-  unsigned r;
-  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
-  return r;
-}
+__device__ __forceinline__ unsigned cvt_pk_bf16(float lo, float hi) { return dv_cvt_pk_bf16(lo, hi); }
 // GELU with the exact-erf definition (reference unet1d/activations / F.gelu default), erf by Abramowitz-Stegun 7.1.26
 // (|error| <= 1.5e-7): branch-free, one v_exp_f32 and one v_rcp_f32, ~20 issue slots instead of erff()'s two divergent
 // polynomial branches.  1 + erf is formed without cancellation on the negative side: measured max |error| of the GELU

@@ -20,6 +20,7 @@
 // then converted fp32 -> split bf16 (K rows; V^T with the permuted key axis) once per workgroup, one tile ahead of
 // the MFMAs, and shared by its NW waves (32*NW queries).
 #include "dv_common.h"
+#define DV_ATTN_TRACE_OWNER   // the trace build's stamp buffer lives in this translation unit
 #include "attn_tile.h"
 
 #include <cstdlib>

@@ -20,11 +20,7 @@ __device__ __forceinline__ float wave_max(float v) {
   return v;
 }
 
-__device__ __forceinline__ unsigned pk_bf16(float lo, float hi) {
-  unsigned r;
-  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
-  return r;
-}
+__device__ __forceinline__ unsigned pk_bf16(float lo, float hi) { return dv_cvt_pk_bf16(lo, hi); }
 // 4 floats -> 4 bf16 hi (uint2) + 4 bf16 lo (uint2), hi = rne(x), lo = rne(x - hi)
 __device__ __forceinline__ void split4(const float4 v, uint2& hi, uint2& lo) {
   hi.x = pk_bf16(v.x, v.y);
