@@ -23,9 +23,8 @@ struct AttnGeom {
   static constexpr int NST = 4;                                  // raw tiles in flight
   static constexpr int RAWK = 32 * DP * 4;                       // raw fp32 K (or V) tile bytes
   static constexpr int KV_INSTR = 2 * 32 * (DP / 4) / 64;         // DMA wave-instructions per tile for K and V (= DP / 4)
-  static constexpr int KPW = (KV_INSTR + NW - 1) / NW;           // per wave (surplus slots land in a dummy area)
-  static constexpr int DUMMY = KPW * NW > KV_INSTR ? 1024 : 0;
-  static constexpr int RAW = (2 * RAWK + NW * 256 + DUMMY + 1023) / 1024 * 1024;   // + one 64-float bias slot per wave
+  static constexpr int KPW = (KV_INSTR + NW - 1) / NW;           // per wave (at most)
+  static constexpr int RAW = (2 * RAWK + 256 + 1023) / 1024 * 1024;   // + the tile's key bias (32 floats, by wave 0)
   static constexpr int buf_bytes(int npl) { return (K_PL + V_PL) * npl + 128; }
   static constexpr int planes_bytes(int npl) { return (4 * buf_bytes(npl) + 1023) / 1024 * 1024; }   // 2 sub-tiles x double buffer
   static constexpr int smem_bytes(int npl) { return planes_bytes(npl) + NST * RAW; }
@@ -67,7 +66,6 @@ __device__ __forceinline__ void attn_tile(const AttnParams& p, const int qblk, c
   constexpr int NST = G::NST, RAWK = G::RAWK, RAW = G::RAW;
   constexpr int CPR = DP / 4;                      // 16-byte chunks per raw row
   constexpr int KV_INSTR = G::KV_INSTR, KPW = G::KPW;
-  constexpr int IPW = KPW + 1;                     // DMA instructions per wave per tile, + its bias slot
   char* const raw0 = lds + G::planes_bytes(NPL);
 
   DV_ATRACE(0);
@@ -82,8 +80,9 @@ __device__ __forceinline__ void attn_tile(const AttnParams& p, const int qblk, c
   constexpr float LOG2E = 1.44269504088896340736f;
   const float qscale = p.scale * LOG2E;
   // ---- Q fragments (B operand of K Q^T): lane (query, lh) holds channels ks*16 + lh*8 .. +8 ----
+  // (loaded AFTER the K / V ring has been filled: the two cold-miss round trips overlap)
   bf16x8 qh[KS], ql[KS];
-  {
+  auto load_q = [&]() {
     const float* qp = p.q + ((size_t)b * p.Tq + (q_ok ? qi : 0)) * p.ldq + h * d;
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
@@ -100,7 +99,7 @@ __device__ __forceinline__ void attn_tile(const AttnParams& p, const int qblk, c
       qh[ks] = __builtin_bit_cast(bf16x8, hw);
       ql[ks] = __builtin_bit_cast(bf16x8, lw);
     }
-  }
+  };
 
   f32x16 o[NB];
 #pragma unroll
@@ -113,32 +112,45 @@ __device__ __forceinline__ void attn_tile(const AttnParams& p, const int qblk, c
   // DMA: instruction ii of a tile moves raw chunks [64 ii, 64 ii + 64) of the tile image [K: 32 x DP | V: 32 x DP]
   // (row-major fp32, 16-byte chunks; chunks past d read a valid dummy and are zeroed at conversion)
   const unsigned raw_base = (unsigned)(size_t)raw0;
+  // per-lane source geometry of this wave's DMA instructions, computed once (the key loop is vector-ALU bound: per
+  // tile only the key clamp and one 64-bit multiply-add per instruction remain).  Kept in registers when a wave has
+  // few instructions per tile (the wide workgroups of the large shapes), recomputed per tile otherwise.
+  constexpr bool GEO_REGS = KPW <= 4;
+  const float* dma_src[GEO_REGS ? KPW : 1];
+  int dma_row[GEO_REGS ? KPW : 1], dma_ld[GEO_REGS ? KPW : 1];
+  auto dma_geo = [&](int j, const float*& base, int& row, int& ld) {
+    const int task = (wave + j * NW) * 64 + lane;
+    const int which = task / (32 * CPR), rem = task - which * (32 * CPR);
+    row = rem / CPR;
+    const int c4 = (rem - row * CPR) * 4;
+    const int cc = c4 < d ? c4 : 0;
+    ld = which ? p.ldv : p.ldk;
+    base = (which ? p.v + (size_t)b * p.Tk * p.ldv : p.k + (size_t)b * p.Tk * p.ldk) + h * d + cc;
+  };
+  if (GEO_REGS) {
+#pragma unroll
+    for (int j = 0; j < KPW; ++j) dma_geo(j, dma_src[j], dma_row[j], dma_ld[j]);
+  }
+  const float* const bias_b = p.bias ? p.bias + (size_t)b * p.Tk : nullptr;
   auto issue_tile = [&](int t) {
     const int kt0 = t * 32;
     const unsigned st = raw_base + (unsigned)((t % NST) * RAW);
 #pragma unroll
     for (int j = 0; j < KPW; ++j) {
       const int ii = wave + j * NW;
-      if (ii >= KV_INSTR) {      // surplus slot of this wave: keeps every wave at KPW instructions per tile
-        if (SC1) glds16_sc1(p.k, st + (unsigned)(2 * RAWK + NW * 256));
-        else glds16(p.k, st + (unsigned)(2 * RAWK + NW * 256));
-        continue;
-      }
-      const int task = ii * 64 + lane;
-      const int which = task / (32 * CPR), rem = task - which * (32 * CPR);
-      const int row = rem / CPR, c4 = (rem - row * CPR) * 4;
-      const int key = min(kt0 + row, p.Tk - 1);                     // clamped: masked by the bias
-      const int cc = c4 < d ? c4 : 0;
-      const float* src = which ? p.v + ((size_t)b * p.Tk + key) * p.ldv + h * d + cc
-                               : p.k + ((size_t)b * p.Tk + key) * p.ldk + h * d + cc;
+      if (ii >= KV_INSTR) continue;      // every wait below is vmcnt(0): the waves need not issue equal counts
+      const float* base; int row, ld;
+      if (GEO_REGS) { base = dma_src[j]; row = dma_row[j]; ld = dma_ld[j]; }
+      else dma_geo(j, base, row, ld);
+      const float* src = base + (size_t)min(kt0 + row, p.Tk - 1) * ld;   // key clamped: masked by the bias
       if (SC1) glds16_sc1(src, st + (unsigned)(ii * 1024));
       else glds16(src, st + (unsigned)(ii * 1024));
     }
-    {   // key bias of the tile (every wave fills its own slot so that all waves issue IPW instructions per tile)
+    if (wave == 0) {   // key bias of the tile
       const int key = min(kt0 + l31, p.Tk - 1);
-      const void* src = p.bias ? (const void*)(p.bias + (size_t)b * p.Tk + key) : (const void*)p.k;
-      if (SC1) glds4_sc1(src, st + (unsigned)(2 * RAWK + wave * 256));
-      else glds4(src, st + (unsigned)(2 * RAWK + wave * 256));
+      const void* src = bias_b ? (const void*)(bias_b + key) : (const void*)p.k;
+      if (SC1) glds4_sc1(src, st + (unsigned)(2 * RAWK));
+      else glds4(src, st + (unsigned)(2 * RAWK));
     }
   };
   // conversion of the raw sub-tile pair (t0, t0 + 1) -> split bf16 planes buffers (buf0, buf0 + 1).  The key loop is
@@ -207,30 +219,23 @@ __device__ __forceinline__ void attn_tile(const AttnParams& p, const int qblk, c
     if (wave == NW - 1) {        // key bias of both sub-tiles (the last wave has the fewest conversion tasks)
       const int tl = lane >> 5, t = t0 + tl;
       const int key = t * 32 + l31;
-      const float raw = reinterpret_cast<const float*>(raw0 + (t % NST) * RAW + 2 * RAWK)[l31];     // wave 0's slot
+      const float raw = reinterpret_cast<const float*>(raw0 + (t % NST) * RAW + 2 * RAWK)[l31];
       float* bl = reinterpret_cast<float*>(lds + (buf0 + tl) * BUF + (K_PL + V_PL) * NPL);
       bl[l31] = (key < p.Tk) ? (p.bias ? raw * LOG2E : 0.f) : -1e30f;
     }
-  };
-  // this wave's DMA of the tiles issued after tile `t` may stay in flight; everything up to `t` has landed
-  auto wait_tile = [&](int t, int last_issued) {
-    const int pending = last_issued - t;
-    if (pending >= 3) wait_vmcnt<3 * IPW>();
-    else if (pending == 2) wait_vmcnt<2 * IPW>();
-    else if (pending == 1) wait_vmcnt<IPW>();
-    else wait_vmcnt<0>();
   };
 
   // Two 32-key sub-tiles per iteration: one barrier, two independent S^T MFMA chains, one softmax pass over 32 scores per
   // lane.  Sub-tile t lives in raw stage t % NST and, converted, in planes buffer 2 * (iteration & 1) + (t & 1).  A
   // trailing odd sub-tile is processed as fully masked (its keys clamp to Tk - 1, its bias is -1e30).
   const int nsub = (p.Tk + 31) / 32, nit = (nsub + 1) / 2, nsub2 = 2 * nit;
-  DV_ATRACE(1);                  // Q fragments loaded and split
+  DV_ATRACE(1);
 #pragma unroll
   for (int t = 0; t < NST; ++t)
     if (t < nsub2) issue_tile(t);
   DV_ATRACE(2);                  // ring filled
-  wait_tile(1, min(nsub2, NST) - 1);
+  load_q();                      // behind the DMAs in the memory queue: when it has returned, so have they
+  wait_vmcnt<0>();
   __syncthreads();
   DV_ATRACE(3);                  // first two sub-tiles landed
   convert_pair(0, 0);

@@ -24,7 +24,7 @@ if len(sys.argv) > 1:
     shapes = [tuple(int(v) for v in a.split("x")) for a in sys.argv[1:]]
 NWG = 4096
 buf = np.zeros((NWG, 16), dtype=np.uint64)
-names = ["Q load + split", "fill ring", "first tiles land", "convert 2 tiles", "first iteration", "rest of key loop",
+names = ["geometry", "fill ring", "Q + first tiles land", "convert 2 tiles", "first iteration", "rest of key loop",
          "normalise + store", "whole workgroup"]
 for B, H, Tq, Tk, d in shapes:
     q = torch.randn(B, Tq, H * d, device="cuda")
