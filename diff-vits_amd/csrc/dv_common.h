@@ -63,7 +63,12 @@ struct GemmParams {
   float* sk_buf;
   int sk_split;
   int sk_mode;                  // internal: 0 single launch, 1 k-slice pass (dump), 2 epilogue pass
+  int force_tile;               // 0: launch_gemm's shape heuristic; else a GT_* tile of the menu (set by the prepare-time tuner)
 };
+// tile menu ids (kernels_gemm.hip); GT_BK64 is or-ed in when the tile runs 64-deep k-tiles
+enum { GT_AUTO = 0, GT_T0 = 1, GT_T1 = 2, GT_T2 = 3, GT_T2S = 4, GT_T2G = 5, GT_T3 = 6, GT_T4 = 7, GT_T4G = 8, GT_BK64 = 0x100 };
+// candidate tiles (force_tile values) that can run this GEMM; returns the count written to out[cap]
+int gemm_candidates(const GemmParams& p, int* out, int cap);
 // number of k-slices launch_gemm should run this GEMM in (0: single launch); env DVITS_SPLITK tunes / disables
 int gemm_splitk_plan(int M, int N, int K, int epi);
 inline size_t gemm_splitk_bytes(int M, int N, int split) {

@@ -147,7 +147,14 @@ struct dv_unet {
   char* slab = nullptr; size_t slab_bytes = 0;
   bf16_t* zero_page = nullptr;               // 256 zero bytes: source of padded rows for the LDS-DMA
   std::vector<OpFn> step_ops, cond_ops;
-  struct OpMeta { const char* kind; double flops; std::string desc; int launches; };
+  // GEMM launch parameters live here (stable addresses): the prepare-time tuner rewrites their tile choice in place
+  std::vector<std::unique_ptr<GemmParams>> gemm_store;
+  int tuned_gemms = 0, tuned_changed = 0;
+  struct OpMeta {
+  const char* kind; double flops; std::string desc;
+  const GemmParams* gp;         // the operation's GEMM parameters (tile / split-K chosen at prepare time), or null
+  int launches() const { return gp && gp->sk_buf && gp->sk_split >= 2 ? 2 : 1; }
+};
   std::vector<OpMeta> step_meta;          // parallel to step_ops (profiling / roofline report)
   std::vector<Probe> probes;
   // persistent per-XCD schedule (persist.hip): descriptors of the step ops that can run inside it
@@ -171,7 +178,7 @@ static void unet_release_prepared(dv_unet* u) {
   u->packed.clear();
   if (u->slab) (void)hipFree(u->slab);
   u->slab = nullptr; u->slab_bytes = 0;
-  u->step_ops.clear(); u->cond_ops.clear(); u->probes.clear(); u->step_meta.clear();
+  u->step_ops.clear(); u->cond_ops.clear(); u->probes.clear(); u->step_meta.clear(); u->gemm_store.clear();
   u->pops.clear(); u->step_pop.clear(); u->pops_dev = nullptr; u->psync = nullptr; u->persist_on = false; u->p_begin = u->p_end = 0;
   u->prepared = false; u->cond_set = false; u->flops = 0;
 }
@@ -230,6 +237,75 @@ extern "C" int dv_unet_set_weight(dv_unet* u, const char* name, const void* dev_
 }
 
 // ----------------------------------------------------------------------------- plan builder
+static bool autotune_on() {
+  const char* e = getenv("DVITS_GEMM_AUTOTUNE");       // opt-in: "1", or "2" to also report how many GEMMs moved
+  return e && (e[0] == '1' || e[0] == '2');
+}
+
+// Prepare-time tile tuner.  The denoiser's GEMMs sit where per-workgroup fixed cost, rounds of workgroups and k-loop
+// efficiency trade against each other shape by shape, so every GEMM of the schedule is timed on its real
+// operands with each tile of the menu that can run it (and, where scratch was offered, with and without the split-K
+// pair), behind an L2 flush as in the real sequence (its inputs were written by the previous kernel and the L2 does
+// not survive a kernel boundary), and keeps the fastest.  ~0.1 s per prepare.  Off by default (DVITS_GEMM_AUTOTUNE=1):
+// measured at the bench shape it moves 17-18 of 180 GEMMs off the heuristic's tile for +0.5 % end to end, and it makes
+// the schedule (hence the float32 rounding of the result) depend on timing noise.
+static int autotune_gemms(dv_unet* u, int precision) {
+  u->tuned_gemms = u->tuned_changed = 0;
+  if (!autotune_on() || u->gemm_store.empty()) return DV_OK;
+  HIPCHK(hipDeviceSynchronize());                      // weight packing (pack stream) has finished
+  hipStream_t st = nullptr;
+  hipEvent_t e0, e1;
+  HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
+  const size_t flush_bytes = 48u << 20;
+  void* flush = nullptr;
+  HIPCHK(hipMalloc(&flush, flush_bytes));
+  auto time_one = [&](const GemmParams& t, float& best) -> bool {
+    if (launch_gemm(t, precision, st) != hipSuccess) { (void)hipGetLastError(); return false; }   // also warms the code
+    best = 1e30f;
+    for (int r = 0; r < 3; ++r) {
+      if (hipMemsetAsync(flush, r, flush_bytes, st) != hipSuccess) return false;
+      if (hipEventRecord(e0, st) != hipSuccess) return false;
+      if (launch_gemm(t, precision, st) != hipSuccess) return false;
+      if (hipEventRecord(e1, st) != hipSuccess || hipEventSynchronize(e1) != hipSuccess) return false;
+      float ms = 0;
+      if (hipEventElapsedTime(&ms, e0, e1) != hipSuccess) return false;
+      best = ms < best ? ms : best;
+    }
+    return true;
+  };
+  for (auto& up : u->gemm_store) {
+    GemmParams* gp = up.get();
+    if (!gp->out && !gp->out_hi) continue;             // output pointer patched per call (conv_out): heuristic
+    int cands[12];
+    const int n = gemm_candidates(*gp, cands, 12);
+    float best = 1e30f;
+    int best_tile = gp->force_tile, best_split = gp->sk_split;
+    const int heur_split = gp->sk_split;
+    {   // the heuristic's own choice is the incumbent: a candidate must beat it by 3 % to replace it
+      float ms;
+      if (time_one(*gp, ms)) best = ms * 0.97f;
+    }
+    for (int c = 0; c < n; ++c)
+      for (int sp = 0; sp < (gp->sk_buf ? 2 : 1); ++sp) {
+        GemmParams t = *gp;
+        t.force_tile = cands[c];
+        t.sk_split = sp ? (heur_split > 2 ? heur_split : 2) : 0;
+        float ms;
+        if (time_one(t, ms) && ms < best) { best = ms; best_tile = cands[c]; best_split = t.sk_split; }
+      }
+    if (best_tile != gp->force_tile || best_split != heur_split) u->tuned_changed++;
+    gp->force_tile = best_tile;
+    gp->sk_split = best_split;
+    u->tuned_gemms++;
+  }
+  if (const char* e = getenv("DVITS_GEMM_AUTOTUNE"))
+    if (e[0] == '2') fprintf(stderr, "[dvits] GEMM tuner: %d of %d GEMMs moved off the heuristic tile\n", u->tuned_changed, u->tuned_gemms);
+  (void)hipFree(flush);
+  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+  HIPCHK(hipDeviceSynchronize());
+  return DV_OK;
+}
+
 struct Builder {
   dv_unet* u;
   Arena arena;
@@ -260,18 +336,18 @@ struct Builder {
     arena.release(off);
   }
   const char* cur_kind = "misc";
-  int cur_launches = 1;                   // kernel launches of the operation being emitted (split-K pair: 2)
+  const GemmParams* cur_gp = nullptr;     // GEMM parameters of the operation being emitted
   double cur_flops = 0;
   std::string cur_desc;
   void emit(std::vector<OpFn>& ops, OpFn f, const PersistOp* pop = nullptr) {
     if (dry) return;
     ops.push_back(std::move(f));
     if (&ops == &u->step_ops) {
-      u->step_meta.push_back({cur_kind, cur_flops, cur_desc, cur_launches});
+      u->step_meta.push_back({cur_kind, cur_flops, cur_desc, cur_gp});
       if (pop) { u->step_pop.push_back((int)u->pops.size()); u->pops.push_back(*pop); }
       else u->step_pop.push_back(-1);
     }
-    cur_kind = "misc"; cur_flops = 0; cur_desc.clear(); cur_launches = 1;
+    cur_kind = "misc"; cur_flops = 0; cur_desc.clear(); cur_gp = nullptr;
   }
   // descriptor of a GEMM for the persistent schedule, or false if its shape is outside what persist.hip instantiates
   bool persist_gemm(const GemmParams& gin, PersistOp& po) {
@@ -391,11 +467,19 @@ struct Builder {
     int k_pad = 0;
     for (int s2 = 0; s2 < g.nseg; ++s2) k_pad += g.seg[s2].taps * (g.seg[s2].c0 + g.seg[s2].c1);
     g.sk_split = arena.exact ? 0 : gemm_splitk_plan(g.M, g.N, k_pad, g.epi);
-    if (g.sk_split >= 2) g.sk_buf = alloc(gemm_splitk_bytes(g.M, g.N, g.sk_split) / sizeof(float));
-    if (g.sk_split >= 2) { cur_desc += " splitk=" + std::to_string(g.sk_split); cur_launches = 2; }
+    // with the tuner on, scratch is also offered to GEMMs the heuristic would not split (the tuner times both ways)
+    const bool offer = !arena.exact && autotune_on() && gemm_splitk_plan(64, 64, 1 << 20, EPI_STORE) != 0 && k_pad >= 768 && (g.epi == EPI_STORE || g.epi == EPI_RESIDUAL) &&
+                       ((g.M + 63) / 64) * ((g.N + 63) / 64) <= 256;
+    if (g.sk_split >= 2 || offer) g.sk_buf = alloc(gemm_splitk_bytes(g.M, g.N, g.sk_split > 2 ? g.sk_split : 2) / sizeof(float));
     PersistOp po;
     const bool pok = !dry && persist_gemm(g, po);
-    emit(ops, [g, p](hipStream_t st) { return launch_gemm(g, p, st); }, pok ? &po : nullptr);
+    if (dry) emit(ops, OpFn{}, nullptr);
+    else {
+      u->gemm_store.emplace_back(new GemmParams(g));
+      const GemmParams* gp = u->gemm_store.back().get();
+      cur_gp = gp;
+      emit(ops, [gp, p](hipStream_t st) { return launch_gemm(*gp, p, st); }, pok ? &po : nullptr);
+    }
     if (g.sk_buf) release((const void*)g.sk_buf);
   }
 
@@ -1205,6 +1289,10 @@ extern "C" int dv_unet_prepare(dv_unet* u, int32_t B, int32_t T, int32_t L, int3
     int rc = b.build();
     if (rc != DV_OK) { unet_release_prepared(u); return rc; }
   }
+  if (!persist_env) {
+    int rc = autotune_gemms(u, precision);
+    if (rc != DV_OK) { unet_release_prepared(u); return rc; }
+  }
   // Persistent per-XCD schedule (DVITS_PERSIST=1): the longest run of consecutive step operations that persist.hip
   // can execute (normally conv_in .. the final GroupNorm; input packing, the conditioning GEMVs and conv_out, whose
   // I/O pointers change per call, stay ordinary launches around it).
@@ -1428,7 +1516,7 @@ extern "C" int dv_unet_time_family(dv_unet* u, const char* kind, int32_t reps, v
   std::vector<int> idx;
   int per_rep = 0;
   for (int i = 0; i < (int)u->step_ops.size(); ++i)
-    if (strcmp(u->step_meta[i].kind, kind) == 0) { idx.push_back(i); per_rep += u->step_meta[i].launches; }
+    if (strcmp(u->step_meta[i].kind, kind) == 0) { idx.push_back(i); per_rep += u->step_meta[i].launches(); }
   if (idx.empty()) return dv_fail(DV_ERR_INVALID, "no launch of family '%s' in the schedule", kind);
   hipEvent_t e0, e1;
   HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
@@ -1453,7 +1541,16 @@ extern "C" int dv_unet_time_family(dv_unet* u, const char* kind, int32_t reps, v
 extern "C" int dv_unet_op_info(dv_unet* u, int32_t index, char* kind16, double* flops, char* desc128) {
   if (!u || !u->prepared || index < 0 || index >= (int)u->step_meta.size()) return dv_fail(DV_ERR_INVALID, "dv_unet_op_info: bad index");
   if (kind16) { strncpy(kind16, u->step_meta[index].kind, 15); kind16[15] = 0; }
-  if (desc128) { strncpy(desc128, u->step_meta[index].desc.c_str(), 127); desc128[127] = 0; }
+  if (desc128) {
+    std::string d = u->step_meta[index].desc;
+    if (const GemmParams* gp = u->step_meta[index].gp) {
+      static const char* names[] = {"auto", "128x128", "128x64", "64x64k2", "64x64", "64x64g", "64x32", "32x32", "32x64g"};
+      const int ft = gp->force_tile & 0xff;
+      d += std::string(" tile=") + (ft < 9 ? names[ft] : "?") + ((gp->force_tile & GT_BK64) ? "x64" : "");
+      if (gp->sk_buf && gp->sk_split >= 2) d += " splitk=" + std::to_string(gp->sk_split);
+    }
+    strncpy(desc128, d.c_str(), 127); desc128[127] = 0;
+  }
   if (flops) *flops = u->step_meta[index].flops;
   return DV_OK;
 }
@@ -1468,7 +1565,7 @@ extern "C" int dv_unet_stats(dv_unet* u, int64_t* n_launch, double* flops) {
   if (!u || !u->prepared) return dv_fail(DV_ERR_STATE, "dv_unet_stats before prepare");
   if (n_launch) {
     *n_launch = 0;
-    for (const auto& m : u->step_meta) *n_launch += m.launches;
+    for (const auto& m : u->step_meta) *n_launch += m.launches();
   }
   if (flops) *flops = u->flops;
   return DV_OK;

@@ -109,6 +109,19 @@ template <int BK> struct Tiles {
     if (cnt(64, 32) >= min_wg) return T3::launch(p, x3, st);
     return T4::launch(p, x3, st);
   }
+  static hipError_t launch_forced(const GemmParams& p, bool x3, int tile, hipStream_t st) {
+    switch (tile) {
+      case GT_T0: return T0::launch(p, x3, st);
+      case GT_T1: return T1::launch(p, x3, st);
+      case GT_T2: return T2::launch(p, x3, st);
+      case GT_T2S: return T2S::launch(p, x3, st);
+      case GT_T2G: return T2G::launch(p, x3, st);
+      case GT_T3: return T3::launch(p, x3, st);
+      case GT_T4: return T4::launch(p, x3, st);
+      case GT_T4G: return T4G::launch(p, x3, st);
+      default: return hipErrorInvalidValue;
+    }
+  }
 };
 
 hipError_t gemm_init() {
@@ -120,7 +133,7 @@ hipError_t gemm_init() {
 // minimum workgroups wanted from the smaller tiles, and whether 64-deep k-tiles are used when the channel
 // counts allow.  The denoiser's GEMMs are small (M = B*T_l <= 8192, N = 128..4096): filling 256 CUs with
 // >= 1-2 workgroups each matters more than tile efficiency.
-struct GemmTune { int big = 384, min_wg = 128, bk64 = 1, ksplit = 1; };
+struct GemmTune { int big = 144, min_wg = 128, bk64 = 1, ksplit = 1; };
 static const GemmTune& gemm_tune() {
   static GemmTune t = [] {
     GemmTune v;
@@ -149,6 +162,29 @@ int gemm_splitk_plan(int M, int N, int K, int epi) {
   return t.split;
 }
 
+// Tiles that can run this GEMM, for the prepare-time tuner (engine.hip): it times each on the real operands.
+// GEGLU needs a 64-column block inside one wave (FN == 2 tiles); 64-deep k-tiles need channel counts % 64 == 0.
+int gemm_candidates(const GemmParams& p, int* out, int cap) {
+  bool k64 = true;
+  for (int s = 0; s < p.nseg; ++s) k64 = k64 && p.seg[s].c0 % 64 == 0 && p.seg[s].c1 % 64 == 0;
+  auto cnt = [&](int bm, int bn) { return ((p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn); };
+  int n = 0;
+  auto add = [&](int id) { if (n < cap) out[n++] = id; };
+  if (cnt(128, 128) >= 24) add(GT_T0);
+  if (p.epi == EPI_GEGLU) {
+    if (cnt(128, 64) >= 32) add(k64 ? (GT_T1 | GT_BK64) : GT_T1);
+    add(k64 ? (GT_T2G | GT_BK64) : GT_T2G);
+    if (cnt(64, 64) < 64) add(k64 ? (GT_T4G | GT_BK64) : GT_T4G);
+    return n;
+  }
+  if (k64 && cnt(128, 64) >= 64) add(GT_T1 | GT_BK64);
+  if (k64) { add(GT_T2 | GT_BK64); add(GT_T2S | GT_BK64); }
+  else add(GT_T2);
+  if (cnt(64, 64) < 256) add(k64 ? (GT_T3 | GT_BK64) : GT_T3);
+  if (cnt(64, 64) < 64) add(k64 ? (GT_T4 | GT_BK64) : GT_T4);
+  return n;
+}
+
 hipError_t launch_gemm(const GemmParams& pin, int precision, hipStream_t st) {
   GemmParams p = pin;
   const bool x3 = precision == 0;
@@ -165,12 +201,15 @@ hipError_t launch_gemm(const GemmParams& pin, int precision, hipStream_t st) {
   const int big_tiles = ((p.M + 127) / 128) * ((p.N + 127) / 128);
   bool k64 = tune.bk64 != 0;
   for (int s = 0; s < p.nseg; ++s) k64 = k64 && p.seg[s].c0 % 64 == 0 && p.seg[s].c1 % 64 == 0;
-  const bool big = big_tiles >= tune.big;
-  const int bk = (!big && k64) ? 64 : 32;
+  const int ft = p.force_tile & 0xff;
+  if (ft != GT_AUTO && (p.force_tile & GT_BK64) && !k64) return hipErrorInvalidValue;
+  const bool big = ft != GT_AUTO ? ft == GT_T0 : big_tiles >= tune.big;
+  const int bk = ft != GT_AUTO ? ((p.force_tile & GT_BK64) ? 64 : 32) : ((!big && k64) ? 64 : 32);
   for (int s = 0; s < p.nseg; ++s) {
     if (p.seg[s].c0 % 32 != 0 || p.seg[s].c1 % 32 != 0) return hipErrorInvalidValue;
     p.seg[s].nkt = p.seg[s].taps * (p.seg[s].c0 + p.seg[s].c1) / bk;
   }
+  if (ft != GT_AUTO) return bk == 64 ? Tiles<64>::launch_forced(p, x3, ft, st) : Tiles<32>::launch_forced(p, x3, ft, st);
   if (big) return tune.ksplit ? Tiles<32>::T0::launch(p, x3, st) : Tiles<32>::T0S::launch(p, x3, st);
   if (bk == 64) return Tiles<64>::launch(p, x3, tune.min_wg, tune.ksplit != 0, st);
   return Tiles<32>::launch(p, x3, tune.min_wg > 0 ? tune.min_wg : 1, false, st);

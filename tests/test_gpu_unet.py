@@ -365,6 +365,7 @@ def test_split_k_pair_matches_single_launch():
     enc = torch.from_numpy(synth.normal(8, "e", (B, L, 128))).cuda()
     t = torch.full((B,), 77.0, device="cuda")
     outs, launches = [], []
+    os.environ["DVITS_GEMM_AUTOTUNE"] = "0"          # the shape heuristic decides (the tuner would time both ways)
     for knob in ("0", None, "4096,768,3"):
         if knob is None:
             os.environ.pop("DVITS_SPLITK", None)
@@ -381,8 +382,44 @@ def test_split_k_pair_matches_single_launch():
             launches.append(eng.stats()[0])
         finally:
             os.environ.pop("DVITS_SPLITK", None)
+    os.environ.pop("DVITS_GEMM_AUTOTUNE", None)
     assert launches[0] < launches[1] < launches[2]
     assert rel_l2(outs[1], outs[0]) < 2e-5 and rel_l2(outs[2], outs[0]) < 2e-5
+
+
+def test_gemm_tile_tuner_keeps_results():
+    """Prepare-time tile tuner (engine.hip autotune_gemms): every GEMM timed with each tile of the menu that can run it.
+    Tiles differ in summation order only: the tuned schedule agrees with the heuristic one to float32 rounding, and
+    the per-operation report names the tile."""
+    from diff_vits_amd import synth
+    from diff_vits_amd.unet1d.unet_1d_condition import UNet1DConditionModel
+    kw = UNET_CASES["cfg1"][0]
+    with torch.device("meta"):
+        shapes = {k: tuple(v.shape) for k, v in UNet1DConditionModel(**kw).state_dict().items()}
+    sd = {k: torch.from_numpy(v) for k, v in synth.make_state_dict(shapes, seed=5).items()}
+    B, T, L = 2, 384, 40
+    x = torch.from_numpy(synth.normal(9, "x", (B, 80, T))).cuda()
+    cond = torch.from_numpy(synth.normal(9, "c", (B, 128, T))).cuda()
+    enc = torch.from_numpy(synth.normal(9, "e", (B, L, 128))).cuda()
+    t = torch.full((B,), 500.0, device="cuda")
+    outs = []
+    for knob in ("0", "1"):
+        os.environ["DVITS_GEMM_AUTOTUNE"] = knob
+        try:
+            m = UNet1DConditionModel(**kw).eval()
+            m.load_state_dict(sd)
+            eng = m.cuda().hip_engine()
+            eng.sync_weights()
+            eng.prepare(B, T, L)
+            eng.set_cond(enc, None)
+            outs.append(eng.eval(x, cond, t).clone().cpu().numpy())
+            descs = [d for k, _, _, d in eng.profile_forward(x, cond, t) if k == "gemm"]
+        finally:
+            os.environ.pop("DVITS_GEMM_AUTOTUNE", None)
+        assert all(" tile=" in d for d in descs if "conv_out" not in d)
+        if knob == "0":                                    # heuristic everywhere; the tuner keeps "auto" where it is not beaten
+            assert all("tile=auto" in d for d in descs if "conv_out" not in d)
+    assert rel_l2(outs[1], outs[0]) < 2e-5
 
 
 def test_unet_large_mean_activations_within_budget():
