@@ -64,12 +64,14 @@ hipError_t attn_init() {
 
 hipError_t launch_attention(const AttnParams& p, hipStream_t st) {
   if (p.d % 4 != 0 || p.d > 64 || p.d <= 0 || (p.nsplit != 1 && p.nsplit != 3)) return hipErrorInvalidValue;
-  // queries per workgroup: the K / V tiles are converted once per workgroup, so more waves per workgroup (256 queries
-  // at 8) amortise that best - measured faster than spreading over more, smaller workgroups at every level of the
-  // denoiser, down to 32 workgroups (DVITS_ATTN_NW8 = wave-count threshold for 8 waves, default 256)
+  // queries per workgroup: the K / V tiles are converted once per workgroup, so more waves per workgroup amortise
+  // that, fewer spread the launch over more CUs.  Measured at the bench shape (after the conversion was made cheap):
+  // 8 waves (256 queries) for the 1024-frame level, 4 waves below it (DVITS_ATTN_NW8 / DVITS_ATTN_NW4 = wave-count
+  // thresholds for 8 / 4 waves per workgroup)
   const long waves = (long)p.B * p.H * ((p.Tq + 31) / 32);
-  static const int nw8_min = [] { const char* e = getenv("DVITS_ATTN_NW8"); return e ? atoi(e) : 256; }();
-  const int nw = waves >= nw8_min ? 8 : (waves >= 64 ? 4 : (waves >= 16 ? 2 : 1));
+  static const int nw8_min = [] { const char* e = getenv("DVITS_ATTN_NW8"); return e ? atoi(e) : 1100; }();
+  static const int nw4_min = [] { const char* e = getenv("DVITS_ATTN_NW4"); return e ? atoi(e) : 64; }();
+  const int nw = waves >= nw8_min ? 8 : (waves >= nw4_min ? 4 : (waves >= 16 ? 2 : 1));
   dim3 grid((p.Tq + 32 * nw - 1) / (32 * nw), p.H, p.B);
   const int dp = (p.d + 15) / 16 * 16;
 #define ATT(DP)                                         \
