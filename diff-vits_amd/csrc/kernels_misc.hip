@@ -511,15 +511,16 @@ __global__ __launch_bounds__(256) void k_small_linear(const float* __restrict__ 
 // lane = output column, so the weight stream is read once, fully coalesced, and no cross-lane reduction is needed;
 // the (activated) input rows sit in LDS and are broadcast.  M <= 16.
 template <int MR>
-__global__ __launch_bounds__(256) void k_small_linear_t(const float* __restrict__ in, int ldin, const float* __restrict__ Wt,
+__global__ __launch_bounds__(512) void k_small_linear_t(const float* __restrict__ in, int ldin, const float* __restrict__ Wt,
                                                          const float* __restrict__ bias, float* __restrict__ out, int ldo,
                                                          int M, int K, int N, int silu_in) {
-  // workgroup = 64 output columns x 4 k-quarters (one wave each): 232 workgroups for N = 14848, 128 sequential
-  // k-steps per lane with 16 weight loads in flight; the four partial sums meet in LDS
-  extern __shared__ float s_in[];        // [K][MR] activated input, row index fastest; then [4][64][MR] partials
+  // workgroup = 64 output columns x 8 k-eighths (one wave each): 232 workgroups for N = 14848, 64 sequential
+  // k-steps per lane with 16 weight loads in flight (the 30 MB table is streamed every step: bytes in flight per CU
+  // are what sets the rate - four waves per workgroup reached 1.5 TB/s); the eight partial sums meet in LDS
+  extern __shared__ float s_in[];        // [K][MR] activated input, row index fastest; then [8][64][MR] partials
   float* s_part = s_in + K * MR;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  for (int i = tid; i < K * MR; i += 256) {
+  for (int i = tid; i < K * MR; i += 512) {
     const int k = i / MR, m = i - k * MR;
     float xv = m < M ? in[(size_t)m * ldin + k] : 0.f;
     if (silu_in) xv = xv / (1.0f + __expf(-xv));
@@ -531,7 +532,7 @@ __global__ __launch_bounds__(256) void k_small_linear_t(const float* __restrict_
   float acc[MR];
 #pragma unroll
   for (int m = 0; m < MR; ++m) acc[m] = 0.f;
-  const int kq = (K + 3) / 4, k0 = wave * kq, k1 = min(K, k0 + kq);
+  const int kq = (K + 7) / 8, k0 = wave * kq, k1 = min(K, k0 + kq);
   const float* w = Wt + nc;
 #pragma unroll 16
   for (int k = k0; k < k1; ++k) {
@@ -546,8 +547,9 @@ __global__ __launch_bounds__(256) void k_small_linear_t(const float* __restrict_
     const float bv = bias ? bias[n] : 0.f;
 #pragma unroll
     for (int m = 0; m < MR; ++m) {
-      const float v = (s_part[lane * MR + m] + s_part[(64 + lane) * MR + m]) +
-                      (s_part[(128 + lane) * MR + m] + s_part[(192 + lane) * MR + m]);
+      float v = 0.f;
+#pragma unroll
+      for (int w = 0; w < 8; ++w) v += s_part[(w * 64 + lane) * MR + m];
       if (m < M) out[(size_t)m * ldo + n] = v + bv;
     }
   }
@@ -555,10 +557,10 @@ __global__ __launch_bounds__(256) void k_small_linear_t(const float* __restrict_
 
 hipError_t launch_small_linear_t(const float* in, int ldin, const float* Wt, const float* b, float* out, int ldo, int M,
                                  int K, int N, int silu_in, hipStream_t st) {
-  if (M > 16 || ((size_t)K * 16 + 256 * 16) * sizeof(float) > 64 * 1024) return hipErrorInvalidValue;
+  if (M > 16 || ((size_t)K * 16 + 512 * 16) * sizeof(float) > 64 * 1024) return hipErrorInvalidValue;
   const dim3 grid((N + 63) / 64);
-  if (M <= 8) hipLaunchKernelGGL(k_small_linear_t<8>, grid, dim3(256), ((size_t)K * 8 + 256 * 8) * 4, st, in, ldin, Wt, b, out, ldo, M, K, N, silu_in);
-  else hipLaunchKernelGGL(k_small_linear_t<16>, grid, dim3(256), ((size_t)K * 16 + 256 * 16) * 4, st, in, ldin, Wt, b, out, ldo, M, K, N, silu_in);
+  if (M <= 8) hipLaunchKernelGGL(k_small_linear_t<8>, grid, dim3(512), ((size_t)K * 8 + 512 * 8) * 4, st, in, ldin, Wt, b, out, ldo, M, K, N, silu_in);
+  else hipLaunchKernelGGL(k_small_linear_t<16>, grid, dim3(512), ((size_t)K * 16 + 512 * 16) * 4, st, in, ldin, Wt, b, out, ldo, M, K, N, silu_in);
   return hipGetLastError();
 }
 
