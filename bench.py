@@ -231,7 +231,7 @@ def main():
                         "tflops": flops_model(B, T, L) / (fwd_ms * 1e-3) / 1e12,
                         "frac_of_peak": flops_model(B, T, L) / (fwd_ms * 1e-3) / 1e12 / peak},
         }
-    if not args.no_cpu_baseline:
+    if not args.no_cpu_baseline and world == 1:        # reported at N = 1 only (rank 0's host cores, bounded sample)
         result["cpu_baseline"] = cpu_baseline(sd, B, T, L, S)
         result["speedup_vs_cpu_baseline"] = frames_per_s / result["cpu_baseline"]["value"] / world
     print(json.dumps(result))
