@@ -62,7 +62,8 @@ struct GemmParams {
   // leaves sk_mode 0; launch_gemm runs the pair with its ordinary tile choice.
   float* sk_buf;
   int sk_split;
-  int sk_mode;                  // internal: 0 single launch, 1 k-slice pass (dump), 2 epilogue pass
+  int sk_mode;                  // internal: 0 single launch, 1 k-slice pass (dump), 2 epilogue pass, 3 fused pair
+  unsigned* sk_ticket;          // per-tile arrival counters (zero between launches) for the fused pair, or null: two launches
   int force_tile;               // 0: launch_gemm's shape heuristic; else a GT_* tile of the menu (set by the prepare-time tuner)
 };
 // tile menu ids (kernels_gemm.hip); GT_BK64 is or-ed in when the tile runs 64-deep k-tiles

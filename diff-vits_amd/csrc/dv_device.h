@@ -16,6 +16,19 @@ __device__ __forceinline__ void glds16_sc1(const void* gsrc, unsigned lds_dst) {
   asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off sc1\n\ts_mov_b32 m0, %0"
                : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
 }
+// Hand-over of data between workgroups of ONE launch (split-K finish): the producer writes through (`sc0 sc1`: the
+// line does not stay dirty in its XCD's L2), the consumer - after it has seen the producer's agent-scope atomic -
+// loads past its L1 at system scope.  (tools/micro/xcd_barrier.hip: plain loads return stale L1 lines.)
+typedef float dv_f32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void st_handover16(float4* p, float4 v) {
+  const dv_f32x4 r = {v.x, v.y, v.z, v.w};
+  asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" :: "v"(p), "v"(r) : "memory");
+}
+__device__ __forceinline__ float4 ld_handover16(const float4* p) {   // caller waits (vmcnt) before using the value
+  float4 v;
+  asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1" : "=v"(v) : "v"(p) : "memory");
+  return v;
+}
 // plain-value loads of mutable data: default policy, or `sc1` (L2-served) inside a persistent launch
 template <bool SC1>
 __device__ __forceinline__ float4 ld_mut4(const float* p) {

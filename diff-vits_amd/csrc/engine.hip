@@ -146,6 +146,7 @@ struct dv_unet {
   std::map<std::string, PackedW> packed;
   char* slab = nullptr; size_t slab_bytes = 0;
   bf16_t* zero_page = nullptr;               // 256 zero bytes: source of padded rows for the LDS-DMA
+  unsigned* sk_tickets = nullptr;            // per-tile arrival counters of the fused split-K pairs (zero between launches)
   std::vector<OpFn> step_ops, cond_ops;
   // GEMM launch parameters live here (stable addresses): the prepare-time tuner rewrites their tile choice in place
   std::vector<std::unique_ptr<GemmParams>> gemm_store;
@@ -153,7 +154,7 @@ struct dv_unet {
   struct OpMeta {
   const char* kind; double flops; std::string desc;
   const GemmParams* gp;         // the operation's GEMM parameters (tile / split-K chosen at prepare time), or null
-  int launches() const { return gp && gp->sk_buf && gp->sk_split >= 2 ? 2 : 1; }
+  int launches() const { return gp && gp->sk_buf && gp->sk_split >= 2 && !(gp->sk_ticket && gp->sk_split == 2) ? 2 : 1; }
 };
   std::vector<OpMeta> step_meta;          // parallel to step_ops (profiling / roofline report)
   std::vector<Probe> probes;
@@ -175,6 +176,7 @@ static void unet_release_prepared(dv_unet* u) {
   for (void* p : u->owned) (void)hipFree(p);
   u->owned.clear();
   u->zero_page = nullptr;
+  u->sk_tickets = nullptr;
   u->packed.clear();
   if (u->slab) (void)hipFree(u->slab);
   u->slab = nullptr; u->slab_bytes = 0;
@@ -470,7 +472,11 @@ struct Builder {
     // with the tuner on, scratch is also offered to GEMMs the heuristic would not split (the tuner times both ways)
     const bool offer = !arena.exact && autotune_on() && gemm_splitk_plan(64, 64, 1 << 20, EPI_STORE) != 0 && k_pad >= 768 && (g.epi == EPI_STORE || g.epi == EPI_RESIDUAL) &&
                        ((g.M + 63) / 64) * ((g.N + 63) / 64) <= 256;
-    if (g.sk_split >= 2 || offer) g.sk_buf = alloc(gemm_splitk_bytes(g.M, g.N, g.sk_split > 2 ? g.sk_split : 2) / sizeof(float));
+    if (g.sk_split >= 2 || offer) {
+      g.sk_buf = alloc(gemm_splitk_bytes(g.M, g.N, g.sk_split > 2 ? g.sk_split : 2) / sizeof(float));
+      // null: two launches (DVITS_SPLITK_FUSED=0); the counters are indexed by tile id of any tile shape >= 32x32
+      g.sk_ticket = ((g.M + 31) / 32) * ((g.N + 31) / 32) <= 4096 ? u->sk_tickets : nullptr;
+    }
     PersistOp po;
     const bool pok = !dry && persist_gemm(g, po);
     if (dry) emit(ops, OpFn{}, nullptr);
@@ -884,6 +890,14 @@ struct Builder {
         (void)hipMemsetAsync(z, 0, 256, pack_stream);
         u->owned.push_back(z);
         u->zero_page = reinterpret_cast<bf16_t*>(z);
+      }
+      const char* fe = getenv("DVITS_SPLITK_FUSED");
+      if (!u->sk_tickets && !(fe && fe[0] == '0')) {
+        void* z = nullptr;
+        if (hipMalloc(&z, 4096 * sizeof(unsigned)) != hipSuccess) return dv_fail(DV_ERR_HIP, "hipMalloc(split-K tickets) failed");
+        (void)hipMemsetAsync(z, 0, 4096 * sizeof(unsigned), pack_stream);
+        u->owned.push_back(z);
+        u->sk_tickets = reinterpret_cast<unsigned*>(z);
       }
     }
 
@@ -1547,7 +1561,7 @@ extern "C" int dv_unet_op_info(dv_unet* u, int32_t index, char* kind16, double* 
       static const char* names[] = {"auto", "128x128", "128x64", "64x64k2", "64x64", "64x64g", "64x32", "32x32", "32x64g"};
       const int ft = gp->force_tile & 0xff;
       d += std::string(" tile=") + (ft < 9 ? names[ft] : "?") + ((gp->force_tile & GT_BK64) ? "x64" : "");
-      if (gp->sk_buf && gp->sk_split >= 2) d += " splitk=" + std::to_string(gp->sk_split);
+      if (gp->sk_buf && gp->sk_split >= 2) d += " splitk=" + std::to_string(gp->sk_split) + (gp->sk_ticket && gp->sk_split == 2 ? "f" : "");
     }
     strncpy(desc128, d.c_str(), 127); desc128[127] = 0;
   }

@@ -51,6 +51,9 @@ __device__ __forceinline__ float gelu_erf(float v) {
 // Split-K over two launches (p.sk_mode; long-K GEMMs with too few tiles to occupy 256 CUs): mode 1 runs slice ksel of
 // p.sk_split equal k-tile ranges and dumps the raw accumulators lane-linearly (coalesced 16-byte stores) to p.sk_buf;
 // mode 2 (same tile shape) starts from the sum of the slices, skips the k-loop and runs the ordinary epilogue.
+// Mode 3 (p.sk_ticket given, two slices) does both in ONE launch: each workgroup dumps its half with write-through
+// stores and takes a ticket from the tile's agent-scope counter; the first to arrive leaves, the second adds the
+// partner's dump (system-scope loads, after the atomic) and runs the epilogue.  No workgroup ever waits for another.
 // Measured: worth ~25 % on the K >= 1536 GEMMs of the 128-frame level, ~1 % of a forward.
 template <int BM, int BN, int BK, int WM, int WN, int NSPLIT, int KS, bool SC1>
 __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int m0, const int n0, char* smem, const int ksel = 0) {
@@ -126,7 +129,7 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int m0, con
   // per-tile path (a scalar load there sits on every wave's critical path right after the barrier).
   const int total_kt = p.seg[0].nkt + (p.nseg > 1 ? p.seg[1].nkt : 0);
   int kt0 = 0, nk = total_kt;                        // this launch's k-tiles: [kt0, kt0 + nk)
-  if (p.sk_mode == 1) { kt0 = ksel * total_kt / p.sk_split; nk = (ksel + 1) * total_kt / p.sk_split - kt0; }
+  if (p.sk_mode == 1 || p.sk_mode == 3) { kt0 = ksel * total_kt / p.sk_split; nk = (ksel + 1) * total_kt / p.sk_split - kt0; }
   if (p.sk_mode == 2) nk = 0;
   int ld_seg = 0, ld_tap = 0, ld_half = 0;
   const bf16_t* cur_hi; const bf16_t* cur_lo;
@@ -321,7 +324,7 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int m0, con
   // residual operand of small tiles: fetched before the k-loop so its latency hides under it
   constexpr bool PRE_RES = FM * FN <= 2;
   float rpre[PRE_RES ? FM * FN * 16 : 1];
-  if (PRE_RES && p.epi == EPI_RESIDUAL && p.sk_mode != 1) {
+  if (PRE_RES && p.epi == EPI_RESIDUAL && p.sk_mode != 1) {   // (mode 3: half of the workgroups prefetch in vain)
 #pragma unroll
     for (int i = 0; i < FM; ++i) {
       const size_t ro = (size_t)min(m0 + (wm * FM + i) * 32 + l31, p.M - 1) * p.ldres;
@@ -426,6 +429,43 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int m0, con
     }
   }
   auto my_frag_row = [&](int i) { return !SPLIT_EPI || ((i & 1) == kgrp); };
+  if (p.sk_mode == 3) {                              // fused split-K pair: hand over, or finish
+    float4* d0 = reinterpret_cast<float4*>(p.sk_buf) + (size_t)ksel * sk_slice + sk_tile + wq * 64 + lane;
+#pragma unroll
+    for (int i = 0; i < FM; ++i) {
+      if (!my_frag_row(i)) continue;
+#pragma unroll
+      for (int j = 0; j < FN; ++j)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+          st_handover16(d0 + (size_t)((i * FN + j) * 4 + g) * (64 * NWQ),
+                        make_float4(acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]));
+    }
+    wait_vmcnt<0>();                                 // this thread's dump has been written through
+    __shared__ unsigned s_arrival;
+    __syncthreads();                                 // (the waves of a k-group that handed everything over have left)
+    unsigned* const ticket = p.sk_ticket + (m0 / BM) * ((p.N + BN - 1) / BN) + n0 / BN;
+    if (tid == 0) s_arrival = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    if (s_arrival == 0) return;                      // the partner finishes this tile
+    if (tid == 0) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
+    const float4* s0 = reinterpret_cast<const float4*>(p.sk_buf) + (size_t)(ksel ^ 1) * sk_slice + sk_tile + wq * 64 + lane;
+#pragma unroll
+    for (int i = 0; i < FM; ++i) {
+      if (!my_frag_row(i)) continue;
+#pragma unroll
+      for (int j = 0; j < FN; ++j) {
+        float4 v[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) v[g] = ld_handover16(s0 + (size_t)((i * FN + j) * 4 + g) * (64 * NWQ));
+        wait_vmcnt<0>();
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          acc[i][j][4 * g] += v[g].x; acc[i][j][4 * g + 1] += v[g].y; acc[i][j][4 * g + 2] += v[g].z; acc[i][j][4 * g + 3] += v[g].w;
+        }
+      }
+    }
+  }
   if (p.sk_mode == 1) {                              // first pass of a split-K pair: dump this k-slice and leave
     float4* d0 = reinterpret_cast<float4*>(p.sk_buf) + (size_t)ksel * sk_slice + sk_tile + wq * 64 + lane;
 #pragma unroll

@@ -38,7 +38,7 @@ __global__ __launch_bounds__(64 * WM * WN * KS) void k_gemm(const GemmParams p) 
     bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
   }
   int ksel = 0;
-  if (p.sk_mode == 1) {                                // XCD-contiguous ids share a k-slice: an L2 holds one slice of A and W
+  if (p.sk_mode == 1 || p.sk_mode == 3) {              // XCD-contiguous ids share a k-slice: an L2 holds one slice of A and W
     const int tiles = nwg / p.sk_split;
     ksel = bid / tiles;
     bid -= ksel * tiles;
@@ -56,7 +56,7 @@ struct GemmCfg {
                                hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
   }
   static hipError_t launch(const GemmParams& p, hipStream_t st) {
-    const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN) * (p.sk_mode == 1 ? p.sk_split : 1);
+    const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN) * (p.sk_mode == 1 || p.sk_mode == 3 ? p.sk_split : 1);
     hipLaunchKernelGGL((k_gemm<BM, BN, BK, WM, WN, NSPLIT, KS>), dim3(tiles), dim3(64 * WM * WN * KS), SMEM, st, p);
     return hipGetLastError();
   }
@@ -189,6 +189,10 @@ hipError_t launch_gemm(const GemmParams& pin, int precision, hipStream_t st) {
   GemmParams p = pin;
   const bool x3 = precision == 0;
   if (!p.zero_page || (x3 && !p.w_lo)) return hipErrorInvalidValue;
+  if (p.sk_buf && p.sk_split == 2 && p.sk_ticket && p.sk_mode == 0) {
+    p.sk_mode = 3;                                     // both k-halves and the epilogue in one launch
+    return launch_gemm(p, precision, st);
+  }
   if (p.sk_buf && p.sk_split >= 2 && p.sk_mode == 0) {
     p.sk_mode = 1;
     hipError_t e = launch_gemm(p, precision, st);
@@ -196,7 +200,7 @@ hipError_t launch_gemm(const GemmParams& pin, int precision, hipStream_t st) {
     p.sk_mode = 2;
     return launch_gemm(p, precision, st);
   }
-  if (!p.sk_buf || p.sk_split < 2) { p.sk_buf = nullptr; p.sk_split = 0; p.sk_mode = 0; }
+  if (!p.sk_buf || p.sk_split < 2) { p.sk_buf = nullptr; p.sk_split = 0; p.sk_mode = 0; p.sk_ticket = nullptr; }
   const GemmTune& tune = gemm_tune();
   const int big_tiles = ((p.M + 127) / 128) * ((p.N + 127) / 128);
   bool k64 = tune.bk64 != 0;

@@ -350,9 +350,12 @@ def test_persistent_per_xcd_schedule_matches_per_launch():
 
 
 def test_split_k_pair_matches_single_launch():
-    """Long-K GEMMs with few tiles run as a two-launch split-K pair (kernels_gemm.hip, DVITS_SPLITK).  Same engine with
-    the split disabled, on a ragged batch (rows beyond M in the last tile) and with three slices: agreement to float32
-    rounding, and the split schedule has one extra launch per split GEMM."""
+    """Long-K GEMMs with few tiles run with K split over two workgroups per tile (kernels_gemm.hip, DVITS_SPLITK): by
+    default as ONE launch (the second workgroup to arrive at the tile's ticket adds the partner's dump and runs the
+    epilogue), with DVITS_SPLITK_FUSED=0 as a two-launch pair (k-slice pass + epilogue-only pass), also with three
+    slices.  Same engine with the split disabled, on a ragged batch (rows beyond M in the last tile): agreement to
+    float32 rounding; launch counts tell the schedules apart; the fused pair is bit-identical to the two-launch pair
+    (same two partial sums, one addition) and stable over repeated calls (the tickets reset themselves)."""
     from diff_vits_amd import synth
     from diff_vits_amd.unet1d.unet_1d_condition import UNet1DConditionModel
     kw = UNET_CASES["cfg1"][0]
@@ -366,7 +369,8 @@ def test_split_k_pair_matches_single_launch():
     t = torch.full((B,), 77.0, device="cuda")
     outs, launches = [], []
     os.environ["DVITS_GEMM_AUTOTUNE"] = "0"          # the shape heuristic decides (the tuner would time both ways)
-    for knob in ("0", None, "4096,768,3"):
+    for knob, fused in (("0", "0"), (None, "0"), ("4096,768,3", "0"), (None, "1")):
+        os.environ["DVITS_SPLITK_FUSED"] = fused
         if knob is None:
             os.environ.pop("DVITS_SPLITK", None)
         else:
@@ -378,13 +382,18 @@ def test_split_k_pair_matches_single_launch():
             eng.sync_weights()
             eng.prepare(B, T, L)
             eng.set_cond(enc, None)
-            outs.append(eng.eval(x, cond, t).clone().cpu().numpy())
+            y = eng.eval(x, cond, t).clone()
+            for _ in range(3):
+                assert torch.equal(eng.eval(x, cond, t), y)
+            outs.append(y.cpu().numpy())
             launches.append(eng.stats()[0])
         finally:
             os.environ.pop("DVITS_SPLITK", None)
+            os.environ.pop("DVITS_SPLITK_FUSED", None)
     os.environ.pop("DVITS_GEMM_AUTOTUNE", None)
-    assert launches[0] < launches[1] < launches[2]
+    assert launches[0] < launches[1] < launches[2] and launches[3] == launches[0]
     assert rel_l2(outs[1], outs[0]) < 2e-5 and rel_l2(outs[2], outs[0]) < 2e-5
+    assert np.array_equal(outs[3], outs[1])
 
 
 def test_gemm_tile_tuner_keeps_results():
