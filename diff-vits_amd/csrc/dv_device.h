@@ -19,15 +19,22 @@ __device__ __forceinline__ void glds16_sc1(const void* gsrc, unsigned lds_dst) {
 // Hand-over of data between workgroups of ONE launch (split-K finish): the producer writes through (`sc0 sc1`: the
 // line does not stay dirty in its XCD's L2), the consumer - after it has seen the producer's agent-scope atomic -
 // loads past its L1 at system scope.  (tools/micro/xcd_barrier.hip: plain loads return stale L1 lines.)
-typedef float dv_f32x4 __attribute__((ext_vector_type(4)));
+// Written as relaxed system-scope atomics on 64-bit halves (the compiler emits global_store/load_dwordx2 sc0 sc1 and
+// tracks the loads' completion itself; an asm load whose result is consumed after a separate asm wait is not safe -
+// the compiler may copy the destination registers before the wait).
 __device__ __forceinline__ void st_handover16(float4* p, float4 v) {
-  const dv_f32x4 r = {v.x, v.y, v.z, v.w};
-  asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" :: "v"(p), "v"(r) : "memory");
+  unsigned long long* q = reinterpret_cast<unsigned long long*>(p);
+  const unsigned long long lo = (unsigned long long)__float_as_uint(v.x) | ((unsigned long long)__float_as_uint(v.y) << 32);
+  const unsigned long long hi = (unsigned long long)__float_as_uint(v.z) | ((unsigned long long)__float_as_uint(v.w) << 32);
+  __hip_atomic_store(q, lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  __hip_atomic_store(q + 1, hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
-__device__ __forceinline__ float4 ld_handover16(const float4* p) {   // caller waits (vmcnt) before using the value
-  float4 v;
-  asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1" : "=v"(v) : "v"(p) : "memory");
-  return v;
+__device__ __forceinline__ float4 ld_handover16(const float4* p) {
+  const unsigned long long* q = reinterpret_cast<const unsigned long long*>(p);
+  const unsigned long long lo = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  const unsigned long long hi = __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  return make_float4(__uint_as_float((unsigned)lo), __uint_as_float((unsigned)(lo >> 32)),
+                     __uint_as_float((unsigned)hi), __uint_as_float((unsigned)(hi >> 32)));
 }
 // plain-value loads of mutable data: default policy, or `sc1` (L2-served) inside a persistent launch
 template <bool SC1>
