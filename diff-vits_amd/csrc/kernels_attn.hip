@@ -14,11 +14,13 @@
 //                               V^T is stored in LDS with its key axis permuted (bits 2 and 3 of
 //                               the key index swapped) so that the matching 8 keys are one 16-byte
 //                               read; the per-query rescale and the final 1/l are per-lane scalars
-// K / V tiles of 32 keys travel global -> LDS by LDS-DMA (global_load_lds, raw fp32, 4-stage ring, hand-counted
-// vmcnt): the producer kernel's output is never in this kernel's L2 (kernel boundary), so every tile is a ~2 us
-// fabric round trip and a short key loop is bound by how many tiles are in flight, not by bandwidth.  Each tile is
-// then converted fp32 -> split bf16 (K rows; V^T with the permuted key axis) once per workgroup, one tile ahead of
-// the MFMAs, and shared by its NW waves (32*NW queries).
+// K / V tiles of 32 keys travel global -> LDS by LDS-DMA (global_load_lds, raw fp32, 4-stage ring; a wave only
+// issues the instructions that carry data, every wait is vmcnt(0)): the producer kernel's output is never in this
+// kernel's L2 (kernel boundary), so every tile is a ~2 us fabric round trip and a short key loop is bound by how many
+// tiles are in flight, not by bandwidth.  Two 32-key sub-tiles are processed per iteration (one barrier).  Each pair is
+// converted fp32 -> split bf16 (K rows; V^T with the permuted key axis) once per workgroup, one iteration ahead of
+// the MFMAs, by ONE wave of each SIMD pair, and shared by the NW waves (32*NW queries).  The key loop is bound by
+// vector-ALU work (softmax, P -> hi + lo, the conversion), not by MFMA: see DESIGN.md and tools/attn_trace.py.
 #include "dv_common.h"
 #define DV_ATTN_TRACE_OWNER   // the trace build's stamp buffer lives in this translation unit
 #include "attn_tile.h"
