@@ -248,6 +248,50 @@ def test_config2_full_size_per_sample_independence():
             assert rel_l2(full[b:b + 1].cpu().numpy(), one.cpu().numpy()) < 1e-5, b
 
 
+def test_config2_full_size_forward_vs_oracle():
+    """BASELINE config 2 at full size (B=8, C=80, T=1024, L=256, ragged prompt mask, eight different timesteps): one
+    forward on the HIP path - the schedule bench.py times, with its split-K pairs and tile choices - against the
+    oracle's fp32 forward on the host (a few seconds on the GPU box).  Tolerance 2e-4 relative L2 (budget 1e-3)."""
+    from diff_vits_amd import synth
+    from oracle import unet_ref
+    m, kw, sd = _bench_model()
+    x, cond, enc, mask = synth.make_inputs(8, 80, 1024, 256, seed=11, ragged_mask=True)
+    t = np.array([999.0, 949.05, 800.5, 640.25, 333.0, 120.75, 40.0, 0.0], dtype=np.float32)
+    with torch.no_grad():
+        y = m(torch.cat([torch.from_numpy(x), torch.from_numpy(cond)], 1).cuda(), torch.from_numpy(t).cuda(),
+              torch.from_numpy(enc).cuda(), encoder_attention_mask=torch.from_numpy(mask).cuda()).sample
+        ref = unet_ref.unet_forward({k: torch.from_numpy(v) for k, v in sd.items()}, oracle_cfg(kw),
+                                    torch.cat([torch.from_numpy(x), torch.from_numpy(cond)], 1), torch.from_numpy(t),
+                                    torch.from_numpy(enc), torch.from_numpy(mask))
+    err = rel_l2(y.cpu().numpy(), ref.numpy())
+    assert err < 2e-4, err
+
+
+def test_config2_full_size_sampler_steps_vs_oracle():
+    """BASELINE config 2 at full size: a 3-step DPM-Solver++ 2M run (order 2, time_uniform, multistep: first-order step,
+    second-order step, lower-order final step; the whole loop one hipGraph, replayed twice) against the oracle's
+    sampler over the oracle's denoiser on the host.  Tolerance 5e-4 relative L2 on the final mel (budget 1e-3)."""
+    from diff_vits_amd import synth
+    from diff_vits_amd.sampler import dpm_solver
+    from oracle import sampler_ref, unet_ref
+    m, kw, sd = _bench_model()
+    x, cond, enc, mask = synth.make_inputs(8, 80, 1024, 256, seed=1234, ragged_mask=True)
+    betas = torch.from_numpy(synth.make_betas())
+    ns = dpm_solver.NoiseScheduleVP("discrete", betas=betas)
+    native = dpm_solver.NativeUNetModel(m, torch.from_numpy(cond).cuda(), torch.from_numpy(enc).cuda(),
+                                        torch.from_numpy(mask).cuda())
+    solver = dpm_solver.DPM_Solver(dpm_solver.model_wrapper(native, ns, model_type="x_start"), ns, algorithm_type="dpmsolver++")
+    with torch.no_grad():
+        out1 = solver.sample(torch.from_numpy(x).cuda(), steps=3, order=2, skip_type="time_uniform", method="multistep")
+        out2 = solver.sample(torch.from_numpy(x).cuda(), steps=3, order=2, skip_type="time_uniform", method="multistep")
+        model = unet_ref.diffusion_model_fn({k: torch.from_numpy(v) for k, v in sd.items()}, oracle_cfg(kw),
+                                            torch.from_numpy(cond), torch.from_numpy(enc), torch.from_numpy(mask))
+        ref = sampler_ref.dpm_solver_pp_sample(model, betas, torch.from_numpy(x), 3, 2)
+    assert torch.equal(out1, out2)
+    err = rel_l2(out1.cpu().numpy(), ref.numpy())
+    assert err < 5e-4, err
+
+
 def test_config4_longform_unipc_T2048():
     """BASELINE config 4: UniPC bh2, 20 steps, B=1, C=80, T=2048, L=256.  (a) one forward at T=2048
     against the oracle; (b) the hipGraph-replayed native loop equals the same compiled plan driven from
