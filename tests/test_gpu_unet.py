@@ -509,6 +509,39 @@ def test_unet_large_mean_activations_within_budget():
     assert err < 1e-3
 
 
+def test_unet_mask_edge_cases():
+    """Prompt-mask edge cases of the reference (the mask bias is -10000, finite): an utterance whose
+    prompt is FULLY masked (softmax over equally biased keys = plain attention over all of them), one with a single
+    valid key, a float additive-bias mask [B, 1, L] (the duration predictor's call form), a length-1 prompt, and an
+    int64 timestep tensor - each against the oracle."""
+    from diff_vits_amd import synth
+    from diff_vits_amd.unet1d.unet_1d_condition import UNet1DConditionModel
+    from oracle import unet_ref
+    kw = UNET_CASES["tiny"][0]
+    with torch.device("meta"):
+        shapes = {k: tuple(v.shape) for k, v in UNet1DConditionModel(**kw).state_dict().items()}
+    tsd = {k: torch.from_numpy(v) for k, v in synth.make_state_dict(shapes, seed=99).items()}
+    m = UNet1DConditionModel(backend="hip", **kw).eval()
+    m.load_state_dict(tsd)
+    m = m.cuda()
+    B, T = 3, 96
+    for L, kind in ((20, "bool"), (20, "bias"), (1, "bool")):
+        x = torch.from_numpy(synth.normal(6, "x%d" % L, (B, kw["in_channels"], T)))
+        enc = torch.from_numpy(synth.normal(6, "e%d" % L, (B, L, kw["cross_attention_dim"])))
+        t = torch.tensor([999, 500, 0], dtype=torch.int64) if kind == "bias" else torch.tensor([700.25, 33.0, 0.5])
+        keep = torch.ones((B, L), dtype=torch.bool)
+        if L > 1:
+            keep[0, :] = False                     # fully masked prompt
+            keep[1, 1:] = False                    # a single valid key
+        mask = keep if kind == "bool" else ((1.0 - keep.float()) * -10000.0).unsqueeze(1)
+        with torch.no_grad():
+            ref = unet_ref.unet_forward(tsd, oracle_cfg(kw), x, t, enc, mask).numpy()
+            y = m(x.cuda(), t.cuda(), enc.cuda(), encoder_attention_mask=mask.cuda()).sample.cpu().numpy()
+        assert np.isfinite(y).all()
+        err = rel_l2(y, ref)
+        assert err < 2e-4, (L, kind, err)
+
+
 def test_native_sampler_options_graph_equals_stepwise():
     """t_start / t_end / denoise_to_zero inside the hipGraph loop == the same plan stepped from Python
     (return_intermediate=True forces the step-by-step path); UniPC likewise."""
