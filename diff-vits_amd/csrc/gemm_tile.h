@@ -362,6 +362,13 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int m0, con
     const int n = min(n0 + wave * 64 + lane, p.N - 1);
     glds4(p.bias ? (const void*)(p.bias + n) : (const void*)p.zero_page, (unsigned)(size_t)s_bias + wave * 256);
   }
+  // LayerNorm consumer: u[n] of this tile's columns the same way (a global load at the head of the epilogue would be a
+  // dependent L2 round trip on every workgroup's critical path)
+  __shared__ __attribute__((aligned(16))) float s_u[BN < 64 ? 64 : BN];
+  if (p.ln_stat && wave < (BN + 63) / 64) {
+    const int n = min(n0 + wave * 64 + lane, p.N - 1);
+    glds4((const void*)(p.ln_u + n), (unsigned)(size_t)s_u + wave * 256);
+  }
 
   // ---- main loop: wait(tile kt) -> barrier -> multiply tile kt with the DMA of tile kt+NSTAGE-1 interleaved ----
   // NSTAGE-1 tiles are in flight; the counted vmcnt leaves the younger ones outstanding across the barrier
@@ -525,8 +532,8 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int m0, con
           const bool ok = nb + e < p.N;
           ba[4 * g + e] = s_bias[wn * 64 + 8 * g + 4 * lh + e];
           bg[4 * g + e] = s_bias[wn * 64 + 32 + 8 * g + 4 * lh + e];
-          ua[4 * g + e] = (p.ln_stat && ok) ? p.ln_u[nb + e] : 0.f;
-          ug[4 * g + e] = (p.ln_stat && ok) ? p.ln_u[nb + e + 32] : 0.f;
+          ua[4 * g + e] = (p.ln_stat && ok) ? s_u[wn * 64 + 8 * g + 4 * lh + e] : 0.f;
+          ug[4 * g + e] = (p.ln_stat && ok) ? s_u[wn * 64 + 32 + 8 * g + 4 * lh + e] : 0.f;
         }
       }
 #pragma unroll
@@ -565,7 +572,7 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int m0, con
     for (int r = 0; r < 16; ++r) {
       const int n = nf + 8 * (r >> 2) + (r & 3);
       bv[r] = s_bias[(wn * FN + j) * 32 + 4 * lh + 8 * (r >> 2) + (r & 3)];
-      un[r] = (p.ln_stat && n < p.N) ? p.ln_u[n] : 0.f;
+      un[r] = (p.ln_stat && n < p.N) ? s_u[(wn * FN + j) * 32 + 4 * lh + 8 * (r >> 2) + (r & 3)] : 0.f;
     }
 #pragma unroll
     for (int i = 0; i < FM; ++i) {
