@@ -69,8 +69,8 @@ def cpu_baseline(sd, B, T, L, solver_steps, sample_steps=4):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3, help="timed sampler runs")
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10, help="timed sampler runs")
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=8, help="utterances per GPU")
     ap.add_argument("--frames", type=int, default=1024)
     ap.add_argument("--prompt", type=int, default=256)
