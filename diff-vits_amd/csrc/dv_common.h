@@ -163,8 +163,8 @@ hipError_t launch_small_linear(const float* in, int ldin, const float* W, const 
                                float* out, int ldo, int M, int K, int N, int silu_in, int silu_out,
                                hipStream_t st);
 // the same on transposed weights Wt [K, N] (lane = output column; wide N, M <= 16), and the one-off transpose
-hipError_t launch_small_linear_t(const float* in, int ldin, const float* Wt, const float* b, float* out, int ldo, int M,
-                                 int K, int N, int silu_in, hipStream_t st);
+hipError_t launch_small_linear_t(const float* in, int ldin, const float* Wt, const float* b, const float* add, float* out,
+                                 int ldo, int M, int K, int N, int silu_in, int silu_out, hipStream_t st);
 hipError_t launch_transpose_f32(const float* src, float* dst, int R, int Cc, hipStream_t st);
 hipError_t launch_timestep_sincos(const float* t, float* out, int B, int dim, hipStream_t st);
 hipError_t launch_layernorm_rows(const float* x, const float* g, const float* b, float* out, int M, int C,

@@ -977,8 +977,21 @@ struct Builder {
       emit(S, [=](hipStream_t st) { return launch_timestep_sincos(uu->io.t, tsin, Bn, C0, st); });
       const float* w1 = W("time_embedding.linear_1.weight"); const float* b1 = W("time_embedding.linear_1.bias");
       const float* w2 = W("time_embedding.linear_2.weight"); const float* b2 = W("time_embedding.linear_2.bias");
-      emit(S, [=](hipStream_t st) { return launch_small_linear(tsin, C0, w1, b1, nullptr, h1, E, Bn, C0, E, 0, 1, st); });
-      emit(S, [=](hipStream_t st) { return launch_small_linear(h1, E, w2, b2, aug_emb, emb, E, Bn, E, E, 0, 0, st); });
+      if (Bn <= 16) {   // lane-per-column kernel on transposed weights (built once): a quarter of the row-per-wave kernel's time
+        float* w1T = nullptr; float* w2T = nullptr;
+        if (!dry) {
+          if (hipMalloc((void**)&w1T, (size_t)E * C0 * 4) != hipSuccess || hipMalloc((void**)&w2T, (size_t)E * E * 4) != hipSuccess)
+            return dv_fail(DV_ERR_HIP, "hipMalloc(time_embedding^T) failed");
+          u->owned.push_back(w1T); u->owned.push_back(w2T);
+          (void)launch_transpose_f32(w1, w1T, E, C0, pack_stream);
+          (void)launch_transpose_f32(w2, w2T, E, E, pack_stream);
+        }
+        emit(S, [=](hipStream_t st) { return launch_small_linear_t(tsin, C0, w1T, b1, nullptr, h1, E, Bn, C0, E, 0, 1, st); });
+        emit(S, [=](hipStream_t st) { return launch_small_linear_t(h1, E, w2T, b2, aug_emb, emb, E, Bn, E, E, 0, 0, st); });
+      } else {
+        emit(S, [=](hipStream_t st) { return launch_small_linear(tsin, C0, w1, b1, nullptr, h1, E, Bn, C0, E, 0, 1, st); });
+        emit(S, [=](hipStream_t st) { return launch_small_linear(h1, E, w2, b2, aug_emb, emb, E, Bn, E, E, 0, 0, st); });
+      }
       float* tp = tproj; const int tt = tproj_total;
       if (Bn <= 16) {   // lane-per-column kernel on the transposed table (built once, below the schedule's critical path)
         float* WtT = nullptr;
@@ -987,7 +1000,7 @@ struct Builder {
           u->owned.push_back(WtT);
           (void)launch_transpose_f32(Wt, WtT, tt, E, pack_stream);
         }
-        emit(S, [=](hipStream_t st) { return launch_small_linear_t(emb, E, WtT, bt, tp, tt, Bn, E, tt, 1, st); });
+        emit(S, [=](hipStream_t st) { return launch_small_linear_t(emb, E, WtT, bt, nullptr, tp, tt, Bn, E, tt, 1, 0, st); });
       } else {
         emit(S, [=](hipStream_t st) { return launch_small_linear(emb, E, Wt, bt, nullptr, tp, tt, Bn, E, tt, 1, 0, st); });
       }

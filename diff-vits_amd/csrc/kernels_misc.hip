@@ -512,8 +512,9 @@ __global__ __launch_bounds__(256) void k_small_linear(const float* __restrict__ 
 // the (activated) input rows sit in LDS and are broadcast.  M <= 16.
 template <int MR>
 __global__ __launch_bounds__(512) void k_small_linear_t(const float* __restrict__ in, int ldin, const float* __restrict__ Wt,
-                                                         const float* __restrict__ bias, float* __restrict__ out, int ldo,
-                                                         int M, int K, int N, int silu_in) {
+                                                         const float* __restrict__ bias, const float* __restrict__ add,
+                                                         float* __restrict__ out, int ldo, int M, int K, int N, int silu_in,
+                                                         int silu_out) {
   // workgroup = 64 output columns x 8 k-eighths (one wave each): 232 workgroups for N = 14848, 64 sequential
   // k-steps per lane with 16 weight loads in flight (the 30 MB table is streamed every step: bytes in flight per CU
   // are what sets the rate - four waves per workgroup reached 1.5 TB/s); the eight partial sums meet in LDS
@@ -550,17 +551,22 @@ __global__ __launch_bounds__(512) void k_small_linear_t(const float* __restrict_
       float v = 0.f;
 #pragma unroll
       for (int w = 0; w < 8; ++w) v += s_part[(w * 64 + lane) * MR + m];
-      if (m < M) out[(size_t)m * ldo + n] = v + bv;
+      if (m < M) {
+        v += bv;
+        if (silu_out) v = v / (1.0f + __expf(-v));
+        if (add) v += add[(size_t)m * ldo + n];
+        out[(size_t)m * ldo + n] = v;
+      }
     }
   }
 }
 
-hipError_t launch_small_linear_t(const float* in, int ldin, const float* Wt, const float* b, float* out, int ldo, int M,
-                                 int K, int N, int silu_in, hipStream_t st) {
+hipError_t launch_small_linear_t(const float* in, int ldin, const float* Wt, const float* b, const float* add, float* out,
+                                 int ldo, int M, int K, int N, int silu_in, int silu_out, hipStream_t st) {
   if (M > 16 || ((size_t)K * 16 + 512 * 16) * sizeof(float) > 64 * 1024) return hipErrorInvalidValue;
   const dim3 grid((N + 63) / 64);
-  if (M <= 8) hipLaunchKernelGGL(k_small_linear_t<8>, grid, dim3(512), ((size_t)K * 8 + 512 * 8) * 4, st, in, ldin, Wt, b, out, ldo, M, K, N, silu_in);
-  else hipLaunchKernelGGL(k_small_linear_t<16>, grid, dim3(512), ((size_t)K * 16 + 512 * 16) * 4, st, in, ldin, Wt, b, out, ldo, M, K, N, silu_in);
+  if (M <= 8) hipLaunchKernelGGL(k_small_linear_t<8>, grid, dim3(512), ((size_t)K * 8 + 512 * 8) * 4, st, in, ldin, Wt, b, add, out, ldo, M, K, N, silu_in, silu_out);
+  else hipLaunchKernelGGL(k_small_linear_t<16>, grid, dim3(512), ((size_t)K * 16 + 512 * 16) * 4, st, in, ldin, Wt, b, add, out, ldo, M, K, N, silu_in, silu_out);
   return hipGetLastError();
 }
 
