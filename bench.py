@@ -10,11 +10,46 @@ batch per GPU.  One JSON line is printed by rank 0 (contract in the task descrip
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+
+
+def spawn_ranks(n):
+    """`python bench.py --gpus N` without a launcher: start N rank processes of this script (one per GPU, RCCL
+    rendezvous on 127.0.0.1) and exit with the worst of their codes.  Runs before torch / the HIP library are imported,
+    so the parent never touches a GPU; the children are fresh processes, not re-execs of an initialised one."""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), DVITS_BENCH_SPAWNED="1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    for p in procs:
+        rc = max(rc, abs(p.wait()))
+    sys.exit(rc)
+
+
+def _early_gpus():
+    for i, a in enumerate(sys.argv):
+        if a == "--gpus" and i + 1 < len(sys.argv):
+            return int(sys.argv[i + 1])
+        if a.startswith("--gpus="):
+            return int(a.split("=", 1)[1])
+    return 1
+
+
+if __name__ == "__main__" and "WORLD_SIZE" not in os.environ and _early_gpus() > 1:
+    spawn_ranks(_early_gpus())
 
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
@@ -46,24 +81,52 @@ def build_model(device, precision):
     return m, sd
 
 
-def cpu_baseline(sd, B, T, L, solver_steps, sample_steps=4):
-    """Oracle (CPU restatement of the reference, oracle/) on the host cores: `sample_steps` of the
-    `solver_steps` DPM-Solver++ steps at the bench shape, scaled linearly (NFE == steps)."""
+def cpu_baseline(sd, B, T, L, solver_steps, sample_steps=2):
+    """Oracle (CPU restatement of the reference, oracle/) on the host cores (SURVEY.md §8d "CPU reference timing").
+    The thread count is swept over {8, 16, 32, 64, all} capped by this process's CPU affinity (128 threads on a
+    128-core host measured 3.6x SLOWER than 8 in round 1: oversubscription); per count one warm-up forward and the
+    median of 3 forwards at the bench shape.  The best count then runs `sample_steps` solver steps (median of 3) and
+    that time is scaled to `solver_steps` (NFE == steps for the multistep solver)."""
+    import statistics
     from oracle import sampler_ref, unet_ref
     cfg = unet_ref.default_config()
     x, cond, enc, mask = map(torch.from_numpy, synth.make_inputs(B, 80, T, L, seed=1234))
     betas = torch.from_numpy(synth.make_betas())
     model = unet_ref.diffusion_model_fn(sd, cfg, cond, enc, mask)
+    avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    counts = sorted({min(c, avail) for c in (8, 16, 32, 64, avail)})
+    t_in = torch.full((B,), 500.0)
+    t_all0 = time.perf_counter()
+    sweep = {}
     with torch.no_grad():
-        model(x, torch.full((B,), 500.0))                       # warm-up (allocator, oneDNN primitives)
-        t0 = time.perf_counter()
-        sampler_ref.dpm_solver_pp_sample(model, betas, x, sample_steps, 2)
-        dt = time.perf_counter() - t0
+        for c in counts:
+            torch.set_num_threads(c)
+            model(x, t_in)                                          # warm-up (thread pool, allocator, oneDNN primitives)
+            ts = []
+            for _ in range(3):
+                t0 = time.perf_counter()
+                model(x, t_in)
+                ts.append(time.perf_counter() - t0)
+            sweep[c] = statistics.median(ts)
+            if time.perf_counter() - t_all0 > 45.0:                 # bounded: stop sweeping, keep what was measured
+                break
+        best = min(sweep, key=sweep.get)
+        torch.set_num_threads(best)
+        runs = []
+        for _ in range(3):
+            t0 = time.perf_counter()
+            sampler_ref.dpm_solver_pp_sample(model, betas, x, sample_steps, 2)
+            runs.append(time.perf_counter() - t0)
+            if time.perf_counter() - t_all0 > 90.0:
+                break
+    dt = statistics.median(runs)
     full = dt * solver_steps / sample_steps
-    return {"value": B * T / full, "unit": "mel-frames/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": "%d of %d DPM-Solver++ steps at B=%d,T=%d,L=%d on torch-CPU fp32 (%.1f s), scaled x%.1f"
-                      % (sample_steps, solver_steps, B, T, L, dt, solver_steps / sample_steps),
-            "seconds_sampled": dt}
+    return {"value": B * T / full, "unit": "mel-frames/s", "cores": best, "kind": "port",
+            "sample": "median of %d runs of %d of the %d DPM-Solver++ steps at B=%d,T=%d,L=%d on torch-CPU fp32 with %d "
+                      "threads (best of the sweep; %d CPUs in the affinity mask), scaled x%.1f"
+                      % (len(runs), sample_steps, solver_steps, B, T, L, best, avail, solver_steps / sample_steps),
+            "seconds_sampled": time.perf_counter() - t_all0,
+            "thread_sweep_forward_s": {str(k): round(v, 4) for k, v in sweep.items()}}
 
 
 def main():
@@ -85,8 +148,11 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
-        raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (args.gpus, world))
+    if world != args.gpus:
+        raise SystemExit("--gpus %d does not match WORLD_SIZE %d (run `python bench.py --gpus N`, which starts the N "
+                         "ranks itself, or torchrun --nproc-per-node N bench.py --gpus N)" % (args.gpus, world))
+    if torch.cuda.device_count() < world:
+        raise SystemExit("--gpus %d: only %d GPU(s) visible" % (world, torch.cuda.device_count()))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
@@ -180,7 +246,8 @@ def main():
         "data": "synthetic",
         "config": {"workload": "B=%d/GPU, C=80, T=%d, L=%d, %d-step DPM-Solver++(2M) multistep, UNet1DConditionModel "
                                "(128,256,384,512), seeded random-init weights" % (B, T, L, S),
-                   "global_batch": G, "concurrent_sub_batches_per_gpu": NS, "parallelism": "dp%d (batch-sharded, RCCL broadcast of conditioning + all-gather of mels)" % world},
+                   "global_batch": G, "concurrent_sub_batches_per_gpu": NS,
+                   "rccl_world_size": torch.distributed.get_world_size() if world > 1 else 1, "parallelism": "dp%d (batch-sharded, RCCL broadcast of conditioning + all-gather of mels)" % world},
     }
 
     # ---- roofline of the dominant kernel family (implicit GEMM), timed live with HIP events ----

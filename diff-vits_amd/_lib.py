@@ -12,7 +12,7 @@ LIB_PATH = os.path.join(_HERE, "libdvits_hip.so")
 CSRC = os.path.join(_HERE, "csrc")
 
 PREC_BF16X3, PREC_BF16 = 0, 1
-SOLVER_DPMPP, SOLVER_UNIPC_BH1, SOLVER_UNIPC_BH2 = 0, 1, 2
+SOLVER_DPMPP, SOLVER_UNIPC_BH1, SOLVER_UNIPC_BH2, SOLVER_UNIPC_VARY = 0, 1, 2, 3
 SKIP = {"time_uniform": 0, "time_quadratic": 1, "logSNR": 2}
 
 

@@ -6,8 +6,8 @@
 // the host in fp64 into a list of events
 //     EVAL : m[slot] = model(x or x_pred, t_input)
 //     COMB : x or x_pred = c0*x + sum_k c_k * m[slot_k]
-// (DPM-Solver++ orders 1-3: dpm_solver.py:547-580, 796-831, 854-889; UniPC bh1/bh2 orders 1-3:
-// uni_pc.py:471-588; loops dpm_solver.py:1171-1213 and uni_pc.py:606-658), and executed as
+// (DPM-Solver++ orders 1-3: dpm_solver.py:547-580, 796-831, 854-889; UniPC bh1/bh2/vary_coeff, orders 1-8:
+// uni_pc.py:368-588; loops dpm_solver.py:1171-1213 and uni_pc.py:606-658), and executed as
 // steps x (UNet schedule + one fused lincomb kernel), captured into a hipGraph.
 //
 // Deviation from the reference, documented in DESIGN.md: the x0 -> noise -> x0 round trip of
@@ -95,15 +95,16 @@ struct Schedule {
 
 struct Event {
   int type;          // 0 EVAL, 1 COMB
-  int src;           // EVAL: 0 = x, 1 = x_pred
+  int src;           // EVAL: input, COMB: base of the c0 term; 0 = x, 1 = x_pred
   int eval_idx;      // EVAL: index into t_input
   int dst;           // EVAL: history slot;  COMB: 0 = x, 1 = x_pred
   int coef;          // COMB: row of the coefficient table
   int slots[4];      // COMB: history slots of the m terms (-1 = unused)
 };
 
-// solve A x = b (n <= 3), Gaussian elimination with partial pivoting
-bool solve_small(int n, double A[3][3], double b[3], double x[3]) {
+// solve A x = b (n <= MAXO), Gaussian elimination with partial pivoting (torch.linalg.solve / inv of the reference)
+constexpr int MAXO = 8;               // highest multistep order compiled (history slots: order + 1)
+bool solve_small(int n, double A[MAXO][MAXO], double b[MAXO], double x[MAXO]) {
   for (int c = 0; c < n; ++c) {
     int piv = c;
     for (int r = c + 1; r < n; ++r) if (fabs(A[r][c]) > fabs(A[piv][c])) piv = r;
@@ -119,6 +120,16 @@ bool solve_small(int n, double A[3][3], double b[3], double x[3]) {
     double s = b[r];
     for (int k = r + 1; k < n; ++k) s -= A[r][k] * x[k];
     x[r] = s / A[r][r];
+  }
+  return true;
+}
+// inverse of an n x n matrix (columns = solutions for the unit vectors)
+bool invert_small(int n, const double A[MAXO][MAXO], double inv[MAXO][MAXO]) {
+  for (int c = 0; c < n; ++c) {
+    double M[MAXO][MAXO], e[MAXO], col[MAXO];
+    for (int i = 0; i < n; ++i) { for (int j = 0; j < n; ++j) M[i][j] = A[i][j]; e[i] = i == c ? 1.0 : 0.0; }
+    if (!solve_small(n, M, e, col)) return false;
+    for (int i = 0; i < n; ++i) inv[i][c] = col[i];
   }
   return true;
 }
@@ -179,15 +190,23 @@ static int build_plan(dv_plan* p) {
     p->t_input.push_back(t_in(t));
     p->ev.push_back(e);
   };
+  // COMB: dst = c0 * x + sum_k c_k * m[slot_k].  The update kernel takes four m terms: longer sums (orders >= 4) are
+  // chained through x_pred (dst' = 1 * x_pred + next four terms) - x_pred is free whenever the chain is needed: a
+  // predictor writes it anyway, and the corrector's EVAL has consumed it by the time the corrector sum is formed.
   auto add_comb = [&](int dst, double c0, const std::vector<std::pair<int, double>>& terms) {
-    Event e{}; e.type = 1; e.dst = dst; e.coef = (int)p->coefs.size();
-    std::array<float, 8> row{};
-    row[0] = (float)c0;
-    for (int k = 0; k < 4; ++k) e.slots[k] = -1;
-    int k = 0;
-    for (auto& t : terms) { e.slots[k] = t.first; row[1 + k] = (float)t.second; ++k; }
-    p->coefs.push_back(row);
-    p->ev.push_back(e);
+    const int n = (int)terms.size();
+    int done = 0, src = 0;
+    do {
+      const int take = std::min(4, n - done), last = done + take >= n;
+      Event e{}; e.type = 1; e.src = src; e.dst = last ? dst : 1; e.coef = (int)p->coefs.size();
+      std::array<float, 8> row{};
+      row[0] = done == 0 ? (float)c0 : 1.0f;
+      for (int k = 0; k < 4; ++k) e.slots[k] = -1;
+      for (int k = 0; k < take; ++k) { e.slots[k] = terms[done + k].first; row[1 + k] = (float)terms[done + k].second; }
+      p->coefs.push_back(row);
+      p->ev.push_back(e);
+      done += take; src = 1;
+    } while (done < n);
   };
   const std::vector<double>& ts = p->timesteps;
   std::vector<int> hist;            // history slots, newest first
@@ -251,61 +270,98 @@ static int build_plan(dv_plan* p) {
       }
     }
   } else {
-    // ---------------- UniPC multistep, B(h) variants, x0-prediction ----------------
-    const bool bh1 = p->solver == DV_SOLVER_UNIPC_BH1;
+    // ---------------- UniPC multistep, x0-prediction: B(h) variants (uni_pc.py:471-588) and 'vary_coeff'
+    // (multistep_uni_pc_vary_update, uni_pc.py:368-469); any order <= MAXO (the reference solves the order x order
+    // systems with torch.linalg.solve / inv, :545-560, :410-420) ----------------
+    const bool bh1 = p->solver == DV_SOLVER_UNIPC_BH1, vary = p->solver == DV_SOLVER_UNIPC_VARY;
     auto do_step = [&](double t, int ord, bool corr) -> int {
       const double t0 = htime[0];
       const double lam0 = ns.lambda(t0), lam_t = ns.lambda(t);
       const double h = lam_t - lam0, hh = -h;
       const double a = ns.alpha(t), c0 = ns.sigma(t) / ns.sigma(t0);
       const double h_phi_1 = expm1(hh);
-      const double B_h = bh1 ? hh : expm1(hh);
-      double rks[3];
+      double rks[MAXO];
       for (int i = 1; i < ord; ++i) rks[i - 1] = (ns.lambda(htime[i]) - lam0) / h;
       rks[ord - 1] = 1.0;
-      double R[3][3], b[3];
-      {
-        double h_phi_k = h_phi_1 / hh - 1.0, fact = 1.0;
-        for (int i = 1; i <= ord; ++i) {
-          for (int j = 0; j < ord; ++j) R[i - 1][j] = pow(rks[j], i - 1);
-          b[i - 1] = h_phi_k * fact / B_h;
-          fact *= (i + 1);
-          h_phi_k = h_phi_k / hh - 1.0 / fact;
+      // Both variants reduce to  x_t = c0 x - a h_phi_1 m0 - a * sum_j w_j D1_j  (- a * w_t (m_t - m0) in the
+      // corrector), D1_j = (m_j - m0) / rk_j for the older evaluations j = 1 .. ord-1: wp[] / wc[] are the weights.
+      double wp[MAXO] = {0}, wc[MAXO] = {0}, wt = 0.0;
+      if (!vary) {
+        const double B_h = bh1 ? hh : expm1(hh);
+        double R[MAXO][MAXO], b[MAXO];
+        {
+          double h_phi_k = h_phi_1 / hh - 1.0, fact = 1.0;
+          for (int i = 1; i <= ord; ++i) {
+            for (int j = 0; j < ord; ++j) R[i - 1][j] = pow(rks[j], i - 1);
+            b[i - 1] = h_phi_k * fact / B_h;
+            fact *= (i + 1);
+            h_phi_k = h_phi_k / hh - 1.0 / fact;
+          }
         }
-      }
-      double rho_p[3] = {0, 0, 0}, rho_c[3] = {0, 0, 0};
-      if (ord == 2) rho_p[0] = 0.5;
-      else if (ord == 3) {
-        double A2[3][3], b2[3];
-        for (int i = 0; i < 2; ++i) { for (int j = 0; j < 2; ++j) A2[i][j] = R[i][j]; b2[i] = b[i]; }
-        if (!solve_small(2, A2, b2, rho_p)) return dv_fail(DV_ERR_INVALID, "UniPC predictor system is singular");
-      }
-      if (corr) {
-        if (ord == 1) rho_c[0] = 0.5;
-        else {
-          double A3[3][3], b3[3];
-          for (int i = 0; i < ord; ++i) { for (int j = 0; j < ord; ++j) A3[i][j] = R[i][j]; b3[i] = b[i]; }
-          if (!solve_small(ord, A3, b3, rho_c)) return dv_fail(DV_ERR_INVALID, "UniPC corrector system is singular");
+        double rho_p[MAXO] = {0}, rho_c[MAXO] = {0};
+        if (ord == 2) rho_p[0] = 0.5;                       // the reference's simplified order-2 predictor
+        else if (ord >= 3) {
+          double A2[MAXO][MAXO], b2[MAXO];
+          for (int i = 0; i < ord - 1; ++i) { for (int j = 0; j < ord - 1; ++j) A2[i][j] = R[i][j]; b2[i] = b[i]; }
+          if (!solve_small(ord - 1, A2, b2, rho_p)) return dv_fail(DV_ERR_INVALID, "UniPC predictor system is singular");
+        }
+        if (corr) {
+          if (ord == 1) rho_c[0] = 0.5;                     // simplified order-1 corrector
+          else {
+            double A3[MAXO][MAXO], b3[MAXO];
+            for (int i = 0; i < ord; ++i) { for (int j = 0; j < ord; ++j) A3[i][j] = R[i][j]; b3[i] = b[i]; }
+            if (!solve_small(ord, A3, b3, rho_c)) return dv_fail(DV_ERR_INVALID, "UniPC corrector system is singular");
+          }
+        }
+        for (int j = 0; j < ord - 1; ++j) { wp[j] = B_h * rho_p[j]; wc[j] = B_h * rho_c[j]; }
+        wt = B_h * rho_c[ord - 1];
+      } else {
+        const int K = ord;
+        double Cm[MAXO][MAXO];                              // C[i][k] = rks[i]^k / (k+1)!   (uni_pc.py:399-405)
+        for (int i = 0; i < K; ++i) {
+          double col = 1.0;
+          for (int k = 1; k <= K; ++k) { Cm[i][k - 1] = col; col = col * rks[i] / (k + 1); }
+        }
+        double h_phi_ks[MAXO + 2];                          // uni_pc.py:419-426
+        {
+          double h_phi_k = h_phi_1, fact = 1.0;
+          for (int k = 1; k <= K + 1; ++k) { h_phi_ks[k - 1] = h_phi_k; h_phi_k = h_phi_k / hh - 1.0 / fact; fact *= (k + 1); }
+        }
+        if (K > 1) {
+          double Ap[MAXO][MAXO];
+          if (!invert_small(K - 1, Cm, Ap)) return dv_fail(DV_ERR_INVALID, "UniPC vary_coeff predictor matrix is singular");
+          for (int k = 0; k < K - 1; ++k)
+            for (int j = 0; j < K - 1; ++j) wp[j] += h_phi_ks[k + 1] * Ap[k][j];
+        }
+        if (corr) {
+          double Ac[MAXO][MAXO];
+          if (!invert_small(K, Cm, Ac)) return dv_fail(DV_ERR_INVALID, "UniPC vary_coeff corrector matrix is singular");
+          for (int k = 0; k < K - 1; ++k)
+            for (int j = 0; j < K - 1; ++j) wc[j] += h_phi_ks[k + 1] * Ac[k][j];
+          // the reference indexes A_c with the residual loop's LAST k (uni_pc.py:444-447: `k` leaks out of the loop;
+          // 0 when the loop body never ran) - reproduced as written
+          const int kq = K >= 2 ? K - 2 : 0;
+          wt = h_phi_ks[K] * Ac[kq][K - 1];
         }
       }
       // predictor
       {
         std::vector<std::pair<int, double>> terms;
         double cm0 = -a * h_phi_1;
-        for (int k = 1; k < ord; ++k) cm0 += a * B_h * rho_p[k - 1] / rks[k - 1];
+        for (int k = 1; k < ord; ++k) cm0 += a * wp[k - 1] / rks[k - 1];
         terms.push_back({hist[0], cm0});
-        for (int k = 1; k < ord; ++k) terms.push_back({hist[k], -a * B_h * rho_p[k - 1] / rks[k - 1]});
+        for (int k = 1; k < ord; ++k) terms.push_back({hist[k], -a * wp[k - 1] / rks[k - 1]});
         add_comb(corr ? 1 : 0, c0, terms);
       }
       if (corr) {
         const int s = free_slot();
         add_eval(1, t, s);
         std::vector<std::pair<int, double>> terms;
-        double cm0 = -a * h_phi_1 + a * B_h * rho_c[ord - 1];
-        for (int k = 1; k < ord; ++k) cm0 += a * B_h * rho_c[k - 1] / rks[k - 1];
+        double cm0 = -a * h_phi_1 + a * wt;
+        for (int k = 1; k < ord; ++k) cm0 += a * wc[k - 1] / rks[k - 1];
         terms.push_back({hist[0], cm0});
-        for (int k = 1; k < ord; ++k) terms.push_back({hist[k], -a * B_h * rho_c[k - 1] / rks[k - 1]});
-        terms.push_back({s, -a * B_h * rho_c[ord - 1]});
+        for (int k = 1; k < ord; ++k) terms.push_back({hist[k], -a * wc[k - 1] / rks[k - 1]});
+        terms.push_back({s, -a * wt});
         add_comb(0, c0, terms);
         push_hist(s, t);
       }
@@ -339,8 +395,9 @@ extern "C" int dv_sampler_plan_ex(int32_t solver, const float* betas, int32_t n_
                                   int32_t skip_type, int32_t lower_order_final, double t_start, double t_end,
                                   int32_t denoise_to_zero, dv_plan** out) {
   if (!betas || !out || n_betas < 2) return dv_fail(DV_ERR_INVALID, "dv_sampler_plan: bad argument");
-  if (solver < DV_SOLVER_DPMPP || solver > DV_SOLVER_UNIPC_BH2) return dv_fail(DV_ERR_INVALID, "unknown solver %d", solver);
-  if (order < 1 || order > 3) return dv_fail(DV_ERR_INVALID, "Solver order must be 1 or 2 or 3, got %d", order);
+  if (solver < DV_SOLVER_DPMPP || solver > DV_SOLVER_UNIPC_VARY) return dv_fail(DV_ERR_INVALID, "unknown solver %d", solver);
+  if (solver == DV_SOLVER_DPMPP && (order < 1 || order > 3)) return dv_fail(DV_ERR_INVALID, "Solver order must be 1 or 2 or 3, got %d", order);
+  if (order < 1 || order > MAXO) return dv_fail(DV_ERR_INVALID, "UniPC order must be 1..%d, got %d", MAXO, order);
   if (steps < order) return dv_fail(DV_ERR_INVALID, "steps (%d) must be >= order (%d)", steps, order);
   dv_plan* p = new dv_plan();
   p->solver = solver; p->steps = steps; p->order = order; p->skip = skip_type; p->lof = lower_order_final;
@@ -394,7 +451,7 @@ extern "C" int dv_plan_events(const dv_plan* p, int32_t* n_events, int32_t* ev9,
     for (size_t i = 0; i < p->ev.size(); ++i) {
       const Event& e = p->ev[i];
       int32_t* r = ev9 + i * 9;
-      r[0] = e.type; r[1] = e.src; r[2] = e.eval_idx; r[3] = e.dst; r[4] = e.coef;
+      r[0] = e.type; r[1] = e.src; r[2] = e.type == 0 ? e.eval_idx : -1; r[3] = e.dst; r[4] = e.coef;
       for (int k = 0; k < 4; ++k) r[5 + k] = e.type == 1 ? e.slots[k] : -1;
     }
   }
@@ -444,7 +501,7 @@ static int run_events(dv_plan* p, float* x, int64_t numel, EvalFn eval, hipStrea
     } else {
       const float* ms[4];
       for (int k = 0; k < 4; ++k) ms[k] = e.slots[k] >= 0 ? p->m[e.slots[k]] : nullptr;
-      hipError_t he = launch_lincomb(e.dst == 0 ? x : p->xp, x, ms[0], ms[1], ms[2], ms[3], p->d_coefs + (size_t)e.coef * 8,
+      hipError_t he = launch_lincomb(e.dst == 0 ? x : p->xp, e.src == 0 ? x : p->xp, ms[0], ms[1], ms[2], ms[3], p->d_coefs + (size_t)e.coef * 8,
                                      numel, st);
       if (he != hipSuccess) return dv_fail(DV_ERR_HIP, "lincomb launch failed: %s", hipGetErrorString(he));
     }

@@ -197,14 +197,19 @@ class Diffusion_Encoder(nn.Module):
         self._unet_cond_serial = None
 
     def _conditioning(self, prompt, prompt_lengths, dtype):
-        """Step-invariant part of model3.py:904-906, 911: encoder output (re-masked), bool mask; cached while the same
-        (prompt, prompt_lengths) tensors and weights are passed."""
-        key = (prompt.data_ptr(), prompt._version, tuple(prompt.shape), prompt_lengths.data_ptr(), prompt_lengths._version,
-               tuple((p.data_ptr(), p._version) for p in self.prompt_encoder.parameters()))
-        if key != self._cond_key:
+        """Step-invariant part of model3.py:904-906, 911: encoder output (re-masked), bool mask; cached while the SAME
+        (prompt, prompt_lengths) tensor objects, unmodified, and the same weights are passed.  The cache entry holds the
+        two tensors themselves: a key made of data_ptr()/_version alone can be met by a NEW prompt allocated at the freed
+        address of the old one (the caching allocator recycles blocks), which then got the previous speaker's states."""
+        wkey = tuple((p.data_ptr(), p._version) for p in self.prompt_encoder.parameters())
+        key = self._cond_key
+        hit = (key is not None and key[0] is prompt and key[1] == prompt._version and key[2] is prompt_lengths
+               and key[3] == prompt_lengths._version and key[4] == wkey and key[5] == dtype)
+        if not hit:
             mask = sequence_mask(prompt_lengths, prompt.size(2))
             enc = self.prompt_encoder.encode_channels_last(prompt, prompt_lengths) * mask.unsqueeze(-1).to(dtype)
-            self._cond, self._cond_key = (enc, mask.to(torch.bool)), key
+            self._cond = (enc, mask.to(torch.bool))
+            self._cond_key = (prompt, prompt._version, prompt_lengths, prompt_lengths._version, wkey, dtype)
             self._unet_cond_serial = None
         return self._cond
 

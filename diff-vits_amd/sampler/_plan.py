@@ -181,7 +181,7 @@ class Plan:
                 first = False
             else:
                 c = self.coefs[coef]
-                out = float(c[0]) * x
+                out = float(c[0]) * (x if src == 0 else xp)      # src 1: continuation of a sum chained through x_pred
                 for k, s in enumerate((s0, s1, s2, s3)):
                     if s >= 0:
                         out = out + float(c[1 + k]) * hist[s]

@@ -39,8 +39,8 @@ class DPM_Solver:
         self._plans = {}
 
     def get_time_steps(self, skip_type, t_T, t_0, N, device):
-        """Time grid of the loop (reference dpm_solver.py:453-480) for the default range."""
-        plan = self._plan(N, min(2, N), skip_type, True)
+        """Time grid of the loop from t_T down to t_0 (reference dpm_solver.py:453-480)."""
+        plan = self._plan(N, min(2, N), skip_type, True, float(t_T), float(t_0))
         return torch.as_tensor(plan.timesteps, dtype=torch.float32, device=device)
 
     def _plan(self, steps, order, skip_type, lower_order_final, t_start=None, t_end=None, denoise_to_zero=False):

@@ -1,8 +1,8 @@
 """UniPC mirror of the reference `sampler/uni_pc.py` (public symbols `NoiseScheduleVP`,
 `model_wrapper`, `UniPC`; reference model3.py:1162 imports exactly these).
 
-Same execution model as `dpm_solver.py` in this package: the multistep B(h) predictor-corrector
-loop (reference uni_pc.py:471-588, 590-672) is compiled on the host into linear-combination
+Same execution model as `dpm_solver.py` in this package: the multistep predictor-corrector loop - variants
+'bh1' / 'bh2' (reference uni_pc.py:471-588) and 'vary_coeff' (:368-469), orders 1..8, loop :590-672 - is compiled on the host into linear-combination
 coefficients and replayed natively or around a Python callable.  Unlike the reference's
 'x_start' wrapper (uni_pc.py:189-191, which only broadcasts correctly at B == 1) the batch
 broadcast here is the intended per-sample one; at B == 1 both coincide.
@@ -11,7 +11,8 @@ from ._plan import NativeUNetModel, NoiseScheduleBase, Plan, sample_with_plan, w
 
 __all__ = ["NoiseScheduleVP", "model_wrapper", "UniPC", "NativeUNetModel"]
 
-_SOLVERS = {"bh1": 1, "bh2": 2}
+_SOLVERS = {"bh1": 1, "bh2": 2, "vary_coeff": 3}
+MAX_ORDER = 8
 
 
 class NoiseScheduleVP(NoiseScheduleBase):
@@ -31,7 +32,7 @@ class UniPC:
         if correcting_x0_fn is not None or correcting_xt_fn is not None:
             raise ValueError("correcting_x0_fn / correcting_xt_fn are not supported on this path")
         if variant not in _SOLVERS:
-            raise NotImplementedError("variant %r (supported: 'bh1', 'bh2')" % (variant,))
+            raise NotImplementedError("variant %r (supported: 'bh1', 'bh2', 'vary_coeff')" % (variant,))
         self.model_fn = model_fn
         self.noise_schedule = noise_schedule
         self.variant = variant
@@ -51,8 +52,8 @@ class UniPC:
         denoise_to_zero).  return_intermediate=True returns (x, [start point, x after every step, ...])."""
         if method != "multistep":
             raise ValueError("Got wrong method {}".format(method))
-        if order not in (1, 2, 3):
-            raise ValueError("UniPC order must be 1, 2 or 3 in this build, got {}".format(order))
+        if not (isinstance(order, int) and 1 <= order <= MAX_ORDER):
+            raise ValueError("UniPC order must be an integer in 1..{} in this build, got {}".format(MAX_ORDER, order))
         assert steps >= order
         plan = self._plan(steps, order, skip_type, lower_order_final, t_start, t_end, denoise_to_zero)
         if not return_intermediate:

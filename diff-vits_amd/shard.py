@@ -33,14 +33,28 @@ def broadcast_conditioning(enc, mask, src=0, group=None):
     return enc, mask
 
 
-def gather_outputs(local, group=None):
-    """All-gather equal-sized shards [B, C, T] into the global [world*B, C, T] (rank order)."""
+def gather_outputs(local, group=None, global_batch=None):
+    """All-gather the ranks' shards [B_r, C, T] into the global [G, C, T] (rank order).  With `global_batch` the shard
+    sizes are those of `shard_range` (they may differ by one when G % world != 0): every rank pads its shard to the
+    largest, one `all_gather_into_tensor` moves them (RCCL has no ragged all-gather), and the padding rows are dropped."""
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
         return local
     world = dist.get_world_size(group)
-    out = torch.empty((world * local.shape[0],) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
-    dist.all_gather_into_tensor(out, local.contiguous(), group=group)
-    return out
+    local = local.contiguous()
+    if global_batch is None or global_batch % world == 0:
+        out = torch.empty((world * local.shape[0],) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+        dist.all_gather_into_tensor(out, local, group=group)
+        return out
+    sizes = [b - a for a, b in (shard_range(global_batch, world, r) for r in range(world))]
+    if local.shape[0] != sizes[dist.get_rank(group)]:
+        raise ValueError("gather_outputs: local shard has %d rows, shard_range gives %d"
+                         % (local.shape[0], sizes[dist.get_rank(group)]))
+    big = max(sizes)
+    padded = local.new_zeros((big,) + tuple(local.shape[1:]))
+    padded[:local.shape[0]] = local
+    out = torch.empty((world * big,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    dist.all_gather_into_tensor(out, padded, group=group)
+    return torch.cat([out[r * big:r * big + sizes[r]] for r in range(world)], dim=0)
 
 
 def sharded_sample(run_local, x_shard, cond_shard, enc_global, mask_global, group=None):
@@ -52,4 +66,4 @@ def sharded_sample(run_local, x_shard, cond_shard, enc_global, mask_global, grou
     lo, hi = shard_range(enc_global.shape[0], world, rank)
     mel = run_local(x_shard, cond_shard, enc_global[lo:hi].contiguous(),
                     None if mask_global is None else mask_global[lo:hi].contiguous())
-    return gather_outputs(mel, group)
+    return gather_outputs(mel, group, global_batch=enc_global.shape[0])

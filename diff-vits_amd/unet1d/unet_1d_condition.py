@@ -199,6 +199,16 @@ class UNet1DConditionModel(nn.Module):
         self.backend = backend or os.environ.get("DVITS_BACKEND", "hip")
         if self.backend not in ("hip", "torch"):
             raise ValueError("backend must be 'hip' or 'torch', got %r" % (self.backend,))
+        if self.backend == "hip":
+            # the native timestep-embedding kernel (csrc/kernels_misc.hip k_timestep_sincos) is the diffusion
+            # configuration's: [cos | sin], no frequency shift, E = 4 * block_out_channels[0].  The torch mirror honours
+            # other values; the HIP backend must refuse them rather than compute something else silently.
+            hip_only = [("flip_sin_to_cos", flip_sin_to_cos, True), ("freq_shift", freq_shift, 0),
+                        ("time_embedding_dim", time_embedding_dim, None)]
+            bad = ["%s=%r" % (k, v) for k, v, want in hip_only if v != want and not (k == "time_embedding_dim" and v == chans[0] * 4)]
+            if bad:
+                raise ValueError("UNet1DConditionModel backend='hip' does not implement " + "; ".join(bad)
+                                 + " (construct with backend='torch' for these)")
         self._engine = None
 
     # ------------------------------------------------------------------ engine plumbing
@@ -258,7 +268,7 @@ class UNet1DConditionModel(nn.Module):
         if self.backend == "hip":
             if self.training and torch.is_grad_enabled():
                 raise RuntimeError("backend='hip' is inference-only; construct with backend='torch' to train")
-            out = self.hip_engine().forward(sample, timesteps, encoder_hidden_states, bias)
+            out = self.hip_engine().forward(sample, timesteps, encoder_hidden_states, bias, mask_src=encoder_attention_mask)
         else:
             out = self._forward_torch(sample, timesteps, encoder_hidden_states, bias)
         if not return_dict:

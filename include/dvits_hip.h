@@ -153,7 +153,10 @@ int dv_unet_probe(dv_unet* u, const char* name, float* host_out, int64_t capacit
 
 /* ---- sampler: DPM-Solver++ / UniPC multistep loops --------------------------------- */
 
-typedef enum { DV_SOLVER_DPMPP = 0, DV_SOLVER_UNIPC_BH1 = 1, DV_SOLVER_UNIPC_BH2 = 2 } dv_solver;
+/* DV_SOLVER_UNIPC_VARY: variant='vary_coeff' (multistep_uni_pc_vary_update, uni_pc.py:368-469).  DPM-Solver++ takes
+ * orders 1-3 (the reference's three closed forms); the UniPC variants any order 1..8 (the reference solves the
+ * order x order systems numerically, uni_pc.py:545-560 / :410-420). */
+typedef enum { DV_SOLVER_DPMPP = 0, DV_SOLVER_UNIPC_BH1 = 1, DV_SOLVER_UNIPC_BH2 = 2, DV_SOLVER_UNIPC_VARY = 3 } dv_solver;
 typedef enum { DV_SKIP_TIME_UNIFORM = 0, DV_SKIP_TIME_QUADRATIC = 1, DV_SKIP_LOGSNR = 2 } dv_skip;
 
 /* Host fp64 precompute of every schedule scalar of the loop
@@ -177,9 +180,10 @@ int dv_plan_info(const dv_plan* p, int32_t* nfe, double* t_input, double* timest
 
 /* The compiled loop, for host-side execution with an arbitrary Python callable and for tests:
  * coefficient rows (8 floats each: c0 for x, c1..c4 for the history terms) and events
- * (9 int32 each: type 0=EVAL/1=COMB, src 0=x/1=x_pred, eval_idx, dst (EVAL: history slot;
- * COMB: 0=x/1=x_pred), coef row, slot0..slot3 (-1 = unused)).  *n_slots = number of
- * history buffers the loop needs. */
+ * (9 int32 each: type 0=EVAL/1=COMB, src 0=x/1=x_pred (EVAL: the network input; COMB: the
+ * tensor the c0 term multiplies - sums of more than four history terms are chained through
+ * x_pred), eval_idx (EVAL; -1 for COMB), dst (EVAL: history slot; COMB: 0=x/1=x_pred), coef row,
+ * slot0..slot3 (-1 = unused)).  *n_slots = number of history buffers the loop needs. */
 int dv_plan_coefs(const dv_plan* p, int32_t* n_rows, float* rows8);
 int dv_plan_events(const dv_plan* p, int32_t* n_events, int32_t* ev9, int32_t* n_slots);
 

@@ -215,6 +215,66 @@ def _unipc_bh_update(ns, fn, x, m_list, t_list, t, order, variant, use_corrector
     return x_t, m_t
 
 
+def _unipc_vary_update(ns, fn, x, m_list, t_list, t, order, use_corrector):
+    """multistep_uni_pc_vary_update with predict_x0=True, uni_pc.py:368-469 (variant='vary_coeff'): residual weights
+    from the inverse of C[i, k] = rks[i]^k / (k+1)! instead of the B(h) systems.  The corrector's last term indexes
+    A_c with the loop variable `k` left over from the residual loop (:444-447), reproduced as written."""
+    t = t.reshape(-1)
+    t0 = t_list[-1]
+    lam0, lam_t = ns.lam(t0), ns.lam(t)
+    m0 = m_list[-1]
+    sig0, sig_t = ns.sigma(t0), ns.sigma(t)
+    alpha_t = torch.exp(ns.log_alpha(t))
+    h = lam_t - lam0
+    rks, D1s = [], []
+    for i in range(1, order):
+        rk = (ns.lam(t_list[-(i + 1)]) - lam0) / h
+        rks.append(rk)
+        D1s.append((m_list[-(i + 1)] - m0) / rk)
+    rks.append(1.0)
+    rks = torch.tensor([float(r) for r in rks])
+    K = len(rks)
+    cols, col = [], torch.ones_like(rks)
+    for k in range(1, K + 1):
+        cols.append(col)
+        col = col * rks / (k + 1)
+    Cm = torch.stack(cols, dim=1)
+    A_p = torch.linalg.inv(Cm[:-1, :-1]) if D1s else None
+    if D1s:
+        D1s = torch.stack(D1s, dim=1)
+    A_c = torch.linalg.inv(Cm) if use_corrector else None
+    hh = -h
+    h_phi_1 = torch.expm1(hh)
+    h_phi_ks, fact, h_phi_k = [], 1, h_phi_1
+    for k in range(1, K + 2):
+        h_phi_ks.append(h_phi_k)
+        h_phi_k = h_phi_k / hh - 1 / fact
+        fact *= (k + 1)
+    x_t_ = sig_t / sig0 * x - alpha_t * h_phi_1 * m0
+    x_t = x_t_
+    if len(D1s) > 0:
+        for k in range(K - 1):
+            x_t = x_t - alpha_t * h_phi_ks[k + 1] * torch.einsum("bkct,k->bct", D1s, A_p[k])
+    m_t = None
+    if use_corrector:
+        m_t = fn(x_t, t)
+        D1_t = m_t - m0
+        x_t = x_t_
+        k = 0
+        for k in range(K - 1):
+            x_t = x_t - alpha_t * h_phi_ks[k + 1] * torch.einsum("bkct,k->bct", D1s, A_c[k][:-1])
+        x_t = x_t - alpha_t * h_phi_ks[K] * (D1_t * A_c[k][-1])
+    return x_t, m_t
+
+
+def _unipc_update(ns, fn, x, m_list, t_list, t, order, variant, use_corrector):
+    """multistep_uni_pc_update dispatch, uni_pc.py:357-366."""
+    if "bh" in variant:
+        return _unipc_bh_update(ns, fn, x, m_list, t_list, t, order, variant, use_corrector)
+    assert variant == "vary_coeff"
+    return _unipc_vary_update(ns, fn, x, m_list, t_list, t, order, use_corrector)
+
+
 def unipc_sample(model, betas, x, steps=20, order=2, skip_type="time_uniform", variant="bh2",
                  lower_order_final=True, return_intermediate=False, t_start=None, t_end=None, denoise_to_zero=False):
     """UniPC(model_fn, ns, variant=...).sample(x, steps, order, skip_type, 'multistep'),
@@ -230,14 +290,14 @@ def unipc_sample(model, betas, x, steps=20, order=2, skip_type="time_uniform", v
     t_list, m_list = [t], [fn(x, t)]
     for step in range(1, order):
         t = ts[step]
-        x, m_x = _unipc_bh_update(ns, fn, x, m_list, t_list, t, step, variant, True)
+        x, m_x = _unipc_update(ns, fn, x, m_list, t_list, t, step, variant, True)
         inter.append(x)
         t_list.append(t)
         m_list.append(m_x)
     for step in range(order, steps + 1):
         t = ts[step]
         step_order = min(order, steps + 1 - step) if lower_order_final else order
-        x, m_x = _unipc_bh_update(ns, fn, x, m_list, t_list, t, step_order, variant, step != steps)
+        x, m_x = _unipc_update(ns, fn, x, m_list, t_list, t, step_order, variant, step != steps)
         inter.append(x)
         t_list = t_list[1:] + [t]
         m_list = m_list[1:] + [None]

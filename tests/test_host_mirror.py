@@ -42,6 +42,19 @@ def test_ctor_rejects_unsupported_like_reference():
         UNet1DConditionModel(**{**kw, "mid_block_type": "UNetMidBlock2DSimpleCrossAttn"})
 
 
+def test_hip_backend_rejects_timestep_embedding_variants_the_kernel_does_not_implement():
+    """flip_sin_to_cos / freq_shift / time_embedding_dim are honoured by the torch mirror (reference embeddings.py:24-64)
+    but hard-wired in the HIP timestep kernel: backend='hip' must refuse them instead of differing silently."""
+    kw = dict(UNET_CASES["tiny"][0])
+    for extra in ({"flip_sin_to_cos": False}, {"freq_shift": 1}, {"time_embedding_dim": 96}):
+        with torch.device("meta"):
+            with pytest.raises(ValueError):
+                UNet1DConditionModel(backend="hip", **{**kw, **extra})
+            UNet1DConditionModel(backend="torch", **{**kw, **extra})      # the mirror builds it
+    with torch.device("meta"):
+        UNet1DConditionModel(backend="hip", **{**kw, "time_embedding_dim": 4 * kw["block_out_channels"][0]})
+
+
 def test_hip_backend_fails_loudly_without_gpu_tensors():
     kw, sd, sample, t, enc, mask = unet_case("tiny")
     m = UNet1DConditionModel(**kw).eval()          # default backend = hip

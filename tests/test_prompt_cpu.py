@@ -91,6 +91,33 @@ def test_mirror_torch_backend_matches_reference(gold, name):
             assert torch.equal(y, y2)
 
 
+def test_conditioning_cache_survives_address_reuse(gold):
+    """Regression (round-1 advisor finding): the step-invariant conditioning is cached per (prompt, lengths) pair.  A key
+    of data_ptr()/_version alone is met by a NEW same-shape prompt allocated at the freed address of the previous one
+    (the allocator recycles blocks), which then silently got the previous speaker's encoder states.  The cache entry
+    now owns the tensors: freed-and-reallocated prompts always re-encode; in-place edits (version bump) too."""
+    g, kw, x, cond, prompt, lengths, t = prompt_case(gold, "cfg")
+    m = Diffusion_Encoder(backend="torch", **kw).eval()
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in diffusion_state_dict(kw).items()})
+    ln = torch.from_numpy(lengths)
+    with torch.no_grad():
+        for i in range(6):
+            spec = torch.from_numpy(prompt).clone() * float(i + 1)       # same shape, often the same address
+            enc, _ = m._conditioning(spec, ln, torch.float32)
+            want = m.prompt_encoder.encode_channels_last(spec, ln) * sequence_mask_like(ln, spec.size(2))
+            assert torch.equal(enc, want), i
+            del spec
+        spec = torch.from_numpy(prompt).clone()
+        e1 = m._conditioning(spec, ln, torch.float32)[0]
+        assert m._conditioning(spec, ln, torch.float32)[0] is e1        # hit: same objects, unmodified
+        spec.mul_(2.0)                                                  # in-place edit -> new version -> re-encode
+        assert not torch.equal(m._conditioning(spec, ln, torch.float32)[0], e1)
+
+
+def sequence_mask_like(lengths, L):
+    return (torch.arange(L)[None, :] < lengths[:, None]).unsqueeze(-1).to(torch.float32)
+
+
 # ---- SURVEY 8f rank 2: NaturalSpeech2.sample orchestration ------------------------------------------------------
 def sample_case(gold):
     from diff_vits_amd.model3 import NaturalSpeech2

@@ -71,8 +71,9 @@ def _worker(rank, world, port, G, out_path):
 
 
 @pytest.mark.slow
-def test_two_rank_sharded_run_equals_single_process(tmp_path):
-    G, world = 4, 2
+@pytest.mark.parametrize("G", [4, 3])      # 3: ragged shards (2 + 1), padded all-gather
+def test_two_rank_sharded_run_equals_single_process(tmp_path, G):
+    world = 2
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]

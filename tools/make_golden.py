@@ -165,7 +165,10 @@ def make_samplers(ref_dpm, ref_unipc, ref_unet_cls):
         xo = sampler_ref.dpm_solver_pp_sample(sampler_ref.standin_model, betas, xB.clone(), steps, order, skip)
         print("[dpm++  s=%-2d o=%d %-14s] oracle-vs-ref %.2e  NFE %d" % (steps, order, skip, rel(xo, xr), len(calls)))
     uni_cases = [(10, 2, "bh2"), (20, 2, "bh2"), (30, 2, "bh2"), (20, 2, "bh1"), (20, 3, "bh2"), (5, 2, "bh2"),
-                 (20, 1, "bh2")]
+                 (20, 1, "bh2"),
+                 # round 2: the general-order linear solves (uni_pc.py:545-560) and variant='vary_coeff' (:368-469)
+                 (20, 4, "bh2"), (12, 5, "bh1"), (20, 6, "bh2"), (20, 1, "vary_coeff"), (20, 2, "vary_coeff"),
+                 (20, 3, "vary_coeff"), (12, 4, "vary_coeff"), (6, 3, "vary_coeff")]
     for steps, order, variant in uni_cases:
         calls.clear()
         fn = ref_unipc.model_wrapper(standin, ns_u, model_type="x_start")
