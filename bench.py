@@ -94,22 +94,29 @@ def cpu_baseline(sd, B, T, L, solver_steps, sample_steps=2):
     betas = torch.from_numpy(synth.make_betas())
     model = unet_ref.diffusion_model_fn(sd, cfg, cond, enc, mask)
     avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    counts = sorted({min(c, avail) for c in (8, 16, 32, 64, avail)})
+    # ascending; "all" only on hosts with <= 64 CPUs (one forward on 256 threads of a 256-CPU box took 134 s in round 2:
+    # oversubscribed intra-op pools), and the sweep stops as soon as a count is clearly past the optimum
+    counts = sorted({min(c, avail) for c in (8, 16, 32, 64)} | ({avail} if avail <= 64 else set()))
     t_in = torch.full((B,), 500.0)
     t_all0 = time.perf_counter()
     sweep = {}
     with torch.no_grad():
         for c in counts:
             torch.set_num_threads(c)
+            t0 = time.perf_counter()
             model(x, t_in)                                          # warm-up (thread pool, allocator, oneDNN primitives)
+            warm = time.perf_counter() - t0
+            if sweep and warm > 4.0 * min(sweep.values()):          # far past the optimum: do not spend the budget here
+                sweep[c] = warm
+                break
             ts = []
             for _ in range(3):
                 t0 = time.perf_counter()
                 model(x, t_in)
                 ts.append(time.perf_counter() - t0)
             sweep[c] = statistics.median(ts)
-            if time.perf_counter() - t_all0 > 45.0:                 # bounded: stop sweeping, keep what was measured
-                break
+            if sweep[c] > 1.3 * min(sweep.values()) or time.perf_counter() - t_all0 > 30.0:
+                break                                               # past the optimum / bounded
         best = min(sweep, key=sweep.get)
         torch.set_num_threads(best)
         runs = []

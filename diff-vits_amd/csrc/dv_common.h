@@ -24,6 +24,25 @@ struct GemmSeg {
   int nkt;             // k-tiles of this segment = taps * (c0+c1) / BK   (set by the launcher)
 };
 
+// A operand produced inside the GEMM ("AF" tiles, gemm_tile.h): instead of split planes written by a separate
+// GroupNorm-apply launch, the conv reads the producer's fp32 rows itself, applies GroupNorm (+ temb scale/shift) (+ SiLU)
+// and the hi/lo split on its producer waves, and the taps of a k=3 conv read shifted windows of ONE LDS slab
+// (reference resnet.py:591-641: norm1 -> SiLU -> conv1, norm2 (+temb) -> SiLU -> conv2; transformer_1d.py:264-268:
+// norm -> proj_in; unet_1d_condition.py:1027-1031: conv_norm_out -> SiLU -> conv_out).
+struct AfSrc {
+  const float* x;        // fp32 channels-last [B*T, C]
+  const float* stat16;   // [B*T/32][C/16][2]: (sum, sum of squares) per 32-frame x 16-channel block, written by x's producer
+  int C, pad_;
+};
+struct AfParams {
+  AfSrc src[2][2];       // [segment][half of the channel concat]; segment 1 (1x1 shortcut) is always read raw
+  int mode0;             // segment 0: 1 = normalise, 2 = normalise + SiLU  (segment 1: raw split)
+  int groups;
+  const float* gamma; const float* beta;                     // GroupNorm affine over segment 0's concat channels
+  const float* tscale; const float* tshift; int ld_t;        // temb scale / shift rows [B, ld_t], or null
+  float eps;
+};
+
 struct GemmParams {
   GemmSeg seg[2];
   int nseg;
@@ -45,6 +64,7 @@ struct GemmParams {
   bf16_t* out_lo;
   int ldo;
   float* stats;                 // [ceil(M/32), N, 2] per 32-row block column (sum, sumsq) or null
+  float* stats16;               // [M/32, N/16, 2] per (32-row, 16-column) block (sum, sumsq) or null (N % 16 == 0)
   const bf16_t* zero_page;      // >= 16 bytes of zeros (source of padded / out-of-range rows)
   // LayerNorm fused across two GEMMs (reference attention.py:157,176,189): the PRODUCER of x writes per-row
   // partial (sum, squared deviations from the block mean) over each 32-column block of its output; the CONSUMER multiplies the raw x by the
@@ -65,9 +85,14 @@ struct GemmParams {
   int sk_mode;                  // internal: 0 single launch, 1 k-slice pass (dump), 2 epilogue pass, 3 fused pair
   unsigned* sk_ticket;          // per-tile arrival counters (zero between launches) for the fused pair, or null: two launches
   int force_tile;               // 0: launch_gemm's shape heuristic; else a GT_* tile of the menu (set by the prepare-time tuner)
+  int af;                       // 1: A operand produced in-kernel from afp (plane pointers of seg[] unused); T_out % 32 == 0
+  AfParams afp;
 };
 // tile menu ids (kernels_gemm.hip); GT_BK64 is or-ed in when the tile runs 64-deep k-tiles
-enum { GT_AUTO = 0, GT_T0 = 1, GT_T1 = 2, GT_T2 = 3, GT_T2S = 4, GT_T2G = 5, GT_T3 = 6, GT_T4 = 7, GT_T4G = 8, GT_BK64 = 0x100 };
+enum { GT_AUTO = 0, GT_T0 = 1, GT_T1 = 2, GT_T2 = 3, GT_T2S = 4, GT_T2G = 5, GT_T3 = 6, GT_T4 = 7, GT_T4G = 8, GT_AF64 = 9, GT_AF32 = 10,
+       GT_BK64 = 0x100 };
+// true if launch_gemm can run this GEMM (p.af = 1) on the tiles that produce the A operand in-kernel
+bool gemm_af_supported(const GemmParams& p);
 // candidate tiles (force_tile values) that can run this GEMM; returns the count written to out[cap]
 int gemm_candidates(const GemmParams& p, int* out, int cap);
 // number of k-slices launch_gemm should run this GEMM in (0: single launch); env DVITS_SPLITK tunes / disables
@@ -158,6 +183,8 @@ hipError_t launch_gn_finalize(const double* part, int nchunk, const float* gamma
                               float* mean_out, float* rstd_out, int B, int T, int C, int G, float eps,
                               hipStream_t st);
 hipError_t launch_ln_stats(const float* x, float* mean, float* rstd, int M, int C, float eps, hipStream_t st);
+// fp32 [M, C] -> per (32-row, 16-column) block (sum, M2 about the block mean) [M/32, C/16, 2]
+hipError_t launch_stat16(const float* x, float* stat16, int M, int C, hipStream_t st);
 // out[m,n] = act_out( sum_k act_in(in[m,k]) * W[n,k] + b[n] ) + add[m,n];  fp32, small M
 hipError_t launch_small_linear(const float* in, int ldin, const float* W, const float* b, const float* add,
                                float* out, int ldo, int M, int K, int N, int silu_in, int silu_out,

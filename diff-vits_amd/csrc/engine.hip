@@ -126,8 +126,11 @@ struct PackedW {
   int Kp = 0, N = 0, N_pad = 0;
 };
 
-struct Act {   // channels-last fp32 [B*T, C] (+ GN stat slab) (+ split planes when the consumer is a resampling conv)
-  float* p = nullptr; int C = 0, T = 0; float* stat = nullptr; bf16_t* pl_hi = nullptr; bf16_t* pl_lo = nullptr;
+struct Act {   // channels-last fp32 [B*T, C] (+ GN statistics) (+ split planes when the consumer is a resampling conv)
+  float* p = nullptr; int C = 0, T = 0;
+  float* stat = nullptr;      // per-column slab [B*T/32, C, 2] (consumer: k_gn_apply), or
+  float* stat16 = nullptr;    // per 32x16-block statistics [B*T/32, C/16, 2] (consumer: a conv that normalises its own operand)
+  bf16_t* pl_hi = nullptr; bf16_t* pl_lo = nullptr;
 };
 
 typedef std::function<hipError_t(hipStream_t)> OpFn;
@@ -353,7 +356,7 @@ struct Builder {
   }
   // descriptor of a GEMM for the persistent schedule, or false if its shape is outside what persist.hip instantiates
   bool persist_gemm(const GemmParams& gin, PersistOp& po) {
-    if (prec != DV_PREC_BF16X3 || gin.epi == EPI_STORE_NCT || !gin.w_lo) return false;
+    if (prec != DV_PREC_BF16X3 || gin.epi == EPI_STORE_NCT || !gin.w_lo || gin.af) return false;
     bool k64 = true;
     for (int s2 = 0; s2 < gin.nseg; ++s2) k64 = k64 && gin.seg[s2].c0 % 64 == 0 && gin.seg[s2].c1 % 64 == 0;
     int cfg, bm, bk;
@@ -448,8 +451,52 @@ struct Builder {
     return pl;
   }
   void release(const Planes& pl) { if (pl.hi) release((const void*)pl.hi); if (pl.lo) release((const void*)pl.lo); }
-  // per-32-row-block column sums of a GEMM output (GroupNorm statistics for its consumer)
-  float* alloc_stat(int Tn, int C) { return (Tn % 32 == 0) ? alloc((size_t)(B * Tn / 32) * C * 2) : nullptr; }
+  // GroupNorm statistics of a GEMM output for its consumer, written by the GEMM's epilogue.  With the fused schedule
+  // (default; DVITS_FUSE_GN=0 restores the k_gn_apply launches) the consumer conv normalises its own operand from
+  // per-(32-frame, 16-channel)-block statistics; otherwise k_gn_apply reduces a per-column slab.
+  bool fuse_gn = [] { const char* e = getenv("DVITS_FUSE_GN"); return !(e && e[0] == '0'); }();
+  // a tensor carries 32x16-block statistics iff every GroupNorm over it (alone or concatenated with another such
+  // tensor) has whole 16-channel blocks per group and 64-channel chunks: then every consumer can take the fused path
+  bool af_tensor(int Tn, int C) const {
+    const int G = u->cfg.norm_num_groups;
+    return fuse_gn && !arena.exact && Tn % 32 == 0 && C % 64 == 0 && C % G == 0 && (C / G) % 16 == 0;
+  }
+  void alloc_stat(Act& a) {
+    if (a.T % 32 != 0) return;
+    if (af_tensor(a.T, a.C)) a.stat16 = alloc((size_t)(B * a.T / 32) * (a.C / 16) * 2);
+    else a.stat = alloc((size_t)(B * a.T / 32) * a.C * 2);
+  }
+  void stat_out(GemmParams& g, const Act& a) { g.stats = a.stat; g.stats16 = a.stat16; }
+  // Fill the in-kernel GroupNorm of [a0 | a1] (+ temb scale/shift) (+ SiLU) as segment 0's operand of `g` (k taps), and
+  // optionally the raw [r0 | r1] as segment 1 (1x1 shortcut).  False if the shapes are outside what the AF tiles take.
+  bool af_setup(GemmParams& g, Act a0, Act a1, int taps, const std::string& pre, float eps, const float* tscale,
+                const float* tshift, int ld_t, bool silu, const Act* r0 = nullptr, const Act* r1 = nullptr) {
+    if (!a0.stat16 || (a1.C > 0 && !a1.stat16)) return false;
+    g.af = 1;
+    g.seg[0] = GemmSeg{}; g.seg[0].c0 = a0.C; g.seg[0].c1 = a1.C; g.seg[0].taps = taps; g.seg[0].pad = (taps - 1) / 2;
+    g.afp = AfParams{};
+    g.afp.src[0][0] = AfSrc{a0.p, a0.stat16, a0.C, 0};
+    g.afp.src[0][1] = AfSrc{a1.p, a1.stat16, a1.C, 0};
+    g.afp.mode0 = silu ? 2 : 1; g.afp.groups = u->cfg.norm_num_groups;
+    g.afp.gamma = W(pre + ".weight"); g.afp.beta = W(pre + ".bias"); g.afp.eps = eps;
+    g.afp.tscale = tscale; g.afp.tshift = tshift; g.afp.ld_t = ld_t;
+    g.nseg = 1;
+    if (r0) {
+      g.seg[1] = GemmSeg{}; g.seg[1].c0 = r0->C; g.seg[1].c1 = r1 ? r1->C : 0; g.seg[1].taps = 1; g.seg[1].pad = 0;
+      g.afp.src[1][0] = AfSrc{r0->p, nullptr, r0->C, 0};
+      if (r1 && r1->C > 0) g.afp.src[1][1] = AfSrc{r1->p, nullptr, r1->C, 0};
+      g.nseg = 2;
+    }
+    if (dry) {   // weights are not resolved in the dry pass: check with placeholders
+      GemmParams t = g; t.B = B;
+      t.afp.gamma = t.afp.beta = reinterpret_cast<const float*>(0x1000);
+      if (!gemm_af_supported(t)) { g.af = 0; return false; }
+      return true;
+    }
+    GemmParams t = g; t.B = B;
+    if (!gemm_af_supported(t)) { g.af = 0; return false; }
+    return true;
+  }
 
   void gemm(std::vector<OpFn>& ops, GemmParams g, const PackedW* pw, int k_real) {
     g.w_hi = pw->hi; g.w_lo = pw->lo; g.Kp = pw->Kp; g.N_pad = pw->N_pad;
@@ -460,8 +507,8 @@ struct Builder {
     cur_kind = "gemm"; cur_flops = 2.0 * (double)g.M * (double)g.N * (double)k_real;
     {
       char buf[128];
-      snprintf(buf, sizeof(buf), "M=%d N=%d K=%d taps=%d nseg=%d epi=%d stride=%d up=%d%s", g.M, g.N, k_real, g.seg[0].taps,
-               g.nseg, g.epi, g.stride, g.up_mode, g.stats ? " +stats" : "");
+      snprintf(buf, sizeof(buf), "M=%d N=%d K=%d taps=%d nseg=%d epi=%d stride=%d up=%d%s%s", g.M, g.N, k_real, g.seg[0].taps,
+               g.nseg, g.epi, g.stride, g.up_mode, (g.stats || g.stats16) ? " +stats" : "", g.af ? " +gn" : "");
       cur_desc = buf;
     }
     u->flops += dry ? 0.0 : cur_flops;
@@ -580,25 +627,37 @@ struct Builder {
     const int cin = x0.C + x1.C, Tn = x0.T, M = B * Tn;
     const float eps = u->cfg.norm_eps;
     const bool shortcut = has(p + "conv_shortcut.weight");
-    Planes raw;
-    Planes n1 = norm_apply(ops, x0, x1, p + "norm1", eps, nullptr, nullptr, 0, true, shortcut ? &raw : nullptr);
     const PackedW* w1 = pack(p + "conv1", cout, 3 * cin, {{p + "conv1.weight", 1, cin, 3, cin, 0, 0, "", 0}},
                              {{p + "conv1.bias", "", "", "", cout, 0, 0, 0}});
     if (!w1) return Act{};
     Act h{};
-    h.p = alloc((size_t)M * cout); h.C = cout; h.T = Tn; h.stat = alloc_stat(Tn, cout);
+    h.p = alloc((size_t)M * cout); h.C = cout; h.T = Tn; alloc_stat(h);
+    Planes raw;
+    bool raw_made = false;
+    // both convs of a block take the fused path or neither (conv2's folded shortcut reads the raw fp32 input)
+    bool fused = false;
     {
-      GemmParams g = gp_base(Tn, M, cout);
-      g.seg[0] = seg(n1, cin, Planes{}, 0, 3, 1);
-      g.out = h.p; g.stats = h.stat;
-      gemm(ops, g, w1, 3 * cin);
+      GemmParams t1 = gp_base(Tn, M, cout), t2 = gp_base(Tn, M, cout);
+      fused = af_setup(t1, x0, x1, 3, p + "norm1", eps, nullptr, nullptr, 0, true) &&
+              af_setup(t2, h, Act{}, 3, p + "norm2", eps, nullptr, nullptr, 0, true, shortcut ? &x0 : nullptr, shortcut ? &x1 : nullptr);
     }
-    release(n1);
+    {
+      // fused: conv1 normalises [x0 | x1] itself (GroupNorm + SiLU on its producer waves); else k_gn_apply -> planes
+      GemmParams g = gp_base(Tn, M, cout);
+      g.out = h.p; stat_out(g, h);
+      if (fused && af_setup(g, x0, x1, 3, p + "norm1", eps, nullptr, nullptr, 0, true)) gemm(ops, g, w1, 3 * cin);
+      else {
+        g.af = 0;
+        Planes n1 = norm_apply(ops, x0, x1, p + "norm1", eps, nullptr, nullptr, 0, true, shortcut ? &raw : nullptr);
+        raw_made = shortcut;
+        g.seg[0] = seg(n1, cin, Planes{}, 0, 3, 1);
+        gemm(ops, g, w1, 3 * cin);
+        release(n1);
+      }
+    }
     probe(p + "conv1", h.p, Tn, cout);
 
     const int toff = tproj_off[p];
-    Planes n2 = norm_apply(ops, h, Act{}, p + "norm2", eps, tproj + toff, tproj + toff + cout, tproj_total, true, nullptr);
-    release(h.p); if (h.stat) release(h.stat);
     const int K2 = 3 * cout + (shortcut ? cin : 0);
     std::vector<Piece> pcs = {{p + "conv2.weight", 1, cout, 3, cout, 0, 0, "", 0}};
     std::vector<BiasPiece> bps = {{p + "conv2.bias", shortcut ? p + "conv_shortcut.bias" : "", "", "", cout, 0, 0, 0}};
@@ -606,21 +665,32 @@ struct Builder {
     const PackedW* w2 = pack(p + "conv2", cout, K2, pcs, bps);
     if (!w2) return Act{};
     Act out{};
-    out.p = alloc((size_t)M * cout); out.C = cout; out.T = Tn; out.stat = alloc_stat(Tn, cout);
+    out.p = alloc((size_t)M * cout); out.C = cout; out.T = Tn; alloc_stat(out);
     {
       GemmParams g = gp_base(Tn, M, cout);
-      g.seg[0] = seg(n2, cout, Planes{}, 0, 3, 1);
-      if (shortcut) { g.seg[1] = seg(raw, cin, Planes{}, 0, 1, 0); g.nseg = 2; }
-      else { g.epi = EPI_RESIDUAL; g.res = x0.p; g.ldres = cout; }
-      g.out = out.p; g.stats = out.stat;
+      if (!shortcut) { g.epi = EPI_RESIDUAL; g.res = x0.p; g.ldres = cout; }
+      g.out = out.p; stat_out(g, out);
       if (want_planes) {   // the next op is a resampling conv: hand it split planes instead of a k_split launch
         Planes pl = alloc_planes((size_t)M * cout);
         out.pl_hi = pl.hi; out.pl_lo = pl.lo; g.out_hi = pl.hi; g.out_lo = pl.lo;
       }
-      gemm(ops, g, w2, K2);
+      // fused: conv2 normalises h (GroupNorm + temb scale/shift + SiLU) and splits the raw [x0 | x1] of the folded
+      // 1x1 shortcut itself; it needs the raw fp32 input, so both convs of a block are fused or neither
+      if (fused && af_setup(g, h, Act{}, 3, p + "norm2", eps, tproj + toff, tproj + toff + cout, tproj_total, true,
+                            shortcut ? &x0 : nullptr, shortcut ? &x1 : nullptr))
+        gemm(ops, g, w2, K2);
+      else {
+        g.af = 0;
+        Planes n2 = norm_apply(ops, h, Act{}, p + "norm2", eps, tproj + toff, tproj + toff + cout, tproj_total, true, nullptr);
+        g.seg[0] = seg(n2, cout, Planes{}, 0, 3, 1);
+        g.nseg = 1;
+        if (shortcut) { g.seg[1] = seg(raw, cin, Planes{}, 0, 1, 0); g.nseg = 2; }
+        gemm(ops, g, w2, K2);
+        release(n2);
+      }
     }
-    release(n2);
-    if (shortcut) release(raw);
+    release_act(h);
+    if (raw_made) release(raw);
     probe(p.substr(0, p.size() - 1), out.p, Tn, cout);
     return out;
   }
@@ -701,15 +771,20 @@ struct Builder {
     };
     auto ln_release = [&](LnIn& in) { release(in.pl); if (in.stat) release(in.stat); };
 
-    // GN(eps 1e-6) -> 1x1 proj_in
-    Planes gn = norm_apply(ops, x, Act{}, p + "norm", 1e-6f, nullptr, nullptr, 0, false, nullptr);
+    // GN(eps 1e-6) -> 1x1 proj_in (fused: proj_in normalises x itself)
     float* h = alloc((size_t)M * C);
     LnIn l1;
     {
-      GemmParams g = gp_base(Tn, M, C); g.seg[0] = seg(gn, C, Planes{}, 0, 1, 0);
-      g.out = h; l1 = ln_produce(g); gemm(ops, g, w_in, C);
+      GemmParams g = gp_base(Tn, M, C);
+      g.out = h; l1 = ln_produce(g);
+      if (af_setup(g, x, Act{}, 1, p + "norm", 1e-6f, nullptr, nullptr, 0, false)) gemm(ops, g, w_in, C);
+      else {
+        Planes gn = norm_apply(ops, x, Act{}, p + "norm", 1e-6f, nullptr, nullptr, 0, false, nullptr);
+        g.seg[0] = seg(gn, C, Planes{}, 0, 1, 0);
+        gemm(ops, g, w_in, C);
+        release(gn);
+      }
     }
-    release(gn);
     probe(p + "proj_in", h, Tn, C);
 
     // self-attention
@@ -776,12 +851,12 @@ struct Builder {
                                 {{mb, "", "", "", C, 0, 0, 0}});
       if (!w_m) return Act{};
       Act out{};
-      out.p = alloc((size_t)M * C); out.C = C; out.T = Tn; out.stat = alloc_stat(Tn, C);
+      out.p = alloc((size_t)M * C); out.C = C; out.T = Tn; alloc_stat(out);
       {
         GemmParams g = gp_base(Tn, M, C);
         g.seg[0] = seg(l3.pl, C, Planes{}, 0, 1, 0);
         g.seg[1] = seg(gg, 4 * C, Planes{}, 0, 1, 0); g.nseg = 2;
-        g.epi = EPI_RESIDUAL; g.res = x.p; g.out = out.p; g.stats = out.stat;
+        g.epi = EPI_RESIDUAL; g.res = x.p; g.out = out.p; stat_out(g, out);
         if (want_planes) {
           Planes pl = alloc_planes((size_t)M * C);
           out.pl_hi = pl.hi; out.pl_lo = pl.lo; g.out_hi = pl.hi; g.out_lo = pl.lo;
@@ -804,10 +879,10 @@ struct Builder {
     if (h4f) probe(tb + "ff", h4f, Tn, C);
 
     Act out{};
-    out.p = alloc((size_t)M * C); out.C = C; out.T = Tn; out.stat = alloc_stat(Tn, C);
+    out.p = alloc((size_t)M * C); out.C = C; out.T = Tn; alloc_stat(out);
     {
       GemmParams g = gp_base(Tn, M, C); g.seg[0] = seg(h4, C, Planes{}, 0, 1, 0);
-      g.epi = EPI_RESIDUAL; g.res = x.p; g.out = out.p; g.stats = out.stat;
+      g.epi = EPI_RESIDUAL; g.res = x.p; g.out = out.p; stat_out(g, out);
       if (want_planes) {
         Planes pl = alloc_planes((size_t)M * C);
         out.pl_hi = pl.hi; out.pl_lo = pl.lo; g.out_hi = pl.hi; g.out_lo = pl.lo;
@@ -839,15 +914,15 @@ struct Builder {
       else g.up_mode = UP_X2;
     }
     Act out{};
-    out.p = alloc((size_t)B * g.T_out * C); out.C = C; out.T = g.T_out; out.stat = alloc_stat(g.T_out, C);
-    g.M = B * g.T_out; g.out = out.p; g.stats = out.stat;
+    out.p = alloc((size_t)B * g.T_out * C); out.C = C; out.T = g.T_out; alloc_stat(out);
+    g.M = B * g.T_out; g.out = out.p; stat_out(g, out);
     gemm(ops, g, w, 3 * C);
     release(xs);
     probe(p.substr(0, p.size() - 1), out.p, g.T_out, C);
     return out;
   }
 
-  void release_act(const Act& a) { if (a.p) release(a.p); if (a.stat) release(a.stat); }
+  void release_act(const Act& a) { if (a.p) release(a.p); if (a.stat) release(a.stat); if (a.stat16) release(a.stat16); }
 
   // ---- whole network
   int build() {
@@ -1016,11 +1091,11 @@ struct Builder {
                               {{"conv_in.bias", "", "", "", C0, 0, 0, 0}});
     if (!wci) return dv_fail(DV_ERR_MISSING_WEIGHT, "%s", err.c_str());
     Act h{};
-    h.p = alloc((size_t)B * T * C0); h.C = C0; h.T = T; h.stat = alloc_stat(T, C0);
+    h.p = alloc((size_t)B * T * C0); h.C = C0; h.T = T; alloc_stat(h);
     {
       GemmParams g = gp_base(T, B * T, C0);
       g.seg[0] = seg(xin, cpad, Planes{}, 0, 3, 1);
-      g.out = h.p; g.stats = h.stat;
+      g.out = h.p; stat_out(g, h);
       gemm(S, g, wci, 3 * cin);
     }
     release(xin);
@@ -1088,14 +1163,16 @@ struct Builder {
     }
     // conv_norm_out -> SiLU -> conv_out, written channels-first straight into y
     {
-      Planes nf = norm_apply(S, h, Act{}, "conv_norm_out", c.norm_eps, nullptr, nullptr, 0, true, nullptr);
-      release_act(h);
       const int co = c.out_channels;
       const PackedW* wo = pack("conv_out", co, 3 * C0, {{"conv_out.weight", 1, C0, 3, C0, 0, 0, "", 0}},
                                {{"conv_out.bias", "", "", "", co, 0, 0, 0}});
       if (!wo) return dv_fail(DV_ERR_MISSING_WEIGHT, "%s", err.c_str());
       GemmParams g = gp_base(T, B * T, co);
-      g.seg[0] = seg(nf, C0, Planes{}, 0, 3, 1);
+      Planes nf;
+      if (!af_setup(g, h, Act{}, 3, "conv_norm_out", c.norm_eps, nullptr, nullptr, 0, true)) {
+        nf = norm_apply(S, h, Act{}, "conv_norm_out", c.norm_eps, nullptr, nullptr, 0, true, nullptr);
+        g.seg[0] = seg(nf, C0, Planes{}, 0, 3, 1);
+      }
       g.epi = EPI_STORE_NCT; g.ldo = co;
       g.w_hi = wo->hi; g.w_lo = wo->lo; g.Kp = wo->Kp; g.N_pad = wo->N_pad; g.bias = wo->bias; g.B = B;
       g.zero_page = u->zero_page;
@@ -1104,7 +1181,8 @@ struct Builder {
       cur_desc = "conv_out (NCT store)";
       if (!dry) u->flops += cur_flops;
       emit(S, [g, pr, uu](hipStream_t st) { GemmParams gg = g; gg.out = uu->io.y; return launch_gemm(gg, pr, st); });
-      release(nf);
+      if (nf.hi) release(nf);
+      release_act(h);
     }
     if (!err.empty()) return dv_fail(DV_ERR_MISSING_WEIGHT, "%s", err.c_str());
     return DV_OK;
@@ -1664,6 +1742,43 @@ extern "C" int dv_op_conv1d(const float* x, const float* w, const float* bias, f
   g.w_hi = hi; g.w_lo = lo; g.Kp = Kp; g.N_pad = Npad; g.bias = bias;
   g.M = B * g.T_out; g.N = Cout; g.epi = EPI_STORE_NCT; g.out = y; g.ldo = Cout; g.zero_page = zp;
   HIPCHK(launch_gemm(g, precision, st));
+  HIPCHK(hipStreamSynchronize(st));
+  return DV_OK;
+}
+
+extern "C" int dv_op_gn_conv1d(const float* x_cl, const float* gamma, const float* beta, const float* tscale, const float* tshift,
+                               const float* w, const float* bias, float* y, int32_t B, int32_t Cin, int32_t T, int32_t Cout,
+                               int32_t k, int32_t groups, float eps, int32_t silu, int32_t precision, void* stream) {
+  if (!x_cl || !gamma || !beta || !w || !y || (k != 1 && k != 3)) return dv_fail(DV_ERR_INVALID, "dv_op_gn_conv1d: bad argument");
+  if (T % 32 != 0 || Cin % 64 != 0 || groups <= 0 || Cin % groups != 0 || (Cin / groups) % 16 != 0 || Cin > 1024)
+    return dv_fail(DV_ERR_INVALID, "dv_op_gn_conv1d: needs T %% 32 == 0, Cin %% 64 == 0 (<= 1024), whole 16-channel blocks per group");
+  hipStream_t st = (hipStream_t)stream;
+  HIPCHK(gemm_init());
+  const bool x3 = precision == DV_PREC_BF16X3;
+  const int Kp = k * Cin, Npad = rup(Cout, 128);
+  OpScratch sc;
+  float* st16 = sc.get<float>((size_t)(B * T / 32) * (Cin / 16) * 2 * sizeof(float), st, false);
+  bf16_t* hi = sc.get<bf16_t>((size_t)Npad * Kp * 2, st, true);
+  bf16_t* lo = x3 ? sc.get<bf16_t>((size_t)Npad * Kp * 2, st, true) : nullptr;
+  bf16_t* zp = sc.get<bf16_t>(256, st, true);
+  if (!st16 || !hi || !zp || (x3 && !lo)) return dv_fail(DV_ERR_HIP, "dv_op_gn_conv1d: hipMalloc failed");
+  HIPCHK(launch_stat16(x_cl, st16, B * T, Cin, st));
+  PackSpec s{};
+  s.src = w; s.N = Cout; s.kind = 1; s.C = Cin; s.taps = k; s.c_pad = Cin; s.k_off = 0; s.n_off = 0;
+  HIPCHK(launch_pack_weight(s, hi, lo, Kp, st));
+  GemmParams g{};
+  g.seg[0].c0 = Cin; g.seg[0].taps = k; g.seg[0].pad = (k - 1) / 2;
+  g.nseg = 1; g.B = B; g.T_in = g.T_out = g.T_virt = T; g.stride = 1; g.up_mode = UP_NONE;
+  g.w_hi = hi; g.w_lo = lo; g.Kp = Kp; g.N_pad = Npad; g.bias = bias;
+  g.M = B * T; g.N = Cout; g.epi = EPI_STORE_NCT; g.out = y; g.ldo = Cout; g.zero_page = zp;
+  g.af = 1;
+  g.afp.src[0][0] = AfSrc{x_cl, st16, Cin, 0};
+  g.afp.mode0 = silu ? 2 : 1; g.afp.groups = groups; g.afp.gamma = gamma; g.afp.beta = beta; g.afp.eps = eps;
+  g.afp.tscale = tscale; g.afp.tshift = tshift; g.afp.ld_t = Cin;
+  if (const char* e = getenv("DVITS_AF_DEBUG")) g.af |= atoi(e) << 1;     // trace build only (gemm_tile.h)
+  if (const char* e = getenv("DVITS_AF_TILE")) g.force_tile = atoi(e) == 32 ? GT_AF32 : (atoi(e) == 64 ? GT_AF64 : 0);
+  hipError_t le = launch_gemm(g, precision, st);
+  if (le != hipSuccess) return dv_fail(DV_ERR_HIP, "dv_op_gn_conv1d: launch failed: %s", hipGetErrorString(le));
   HIPCHK(hipStreamSynchronize(st));
   return DV_OK;
 }

@@ -11,8 +11,13 @@
 // development build only (make trace): per-workgroup s_memtime stamps of the kernel's phases
 __device__ unsigned long long g_gemm_trace[8192 * 16];
 #define DV_TRACE(i) do { if (threadIdx.x == 0 && blockIdx.x < 8192) g_gemm_trace[blockIdx.x * 16 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#define DV_TRACE_P(i, first) do { if ((int)threadIdx.x == (first) && blockIdx.x < 8192) g_gemm_trace[blockIdx.x * 16 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
 extern "C" int dv_debug_gemm_trace(unsigned long long* host, int n_wg) {
   return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_gemm_trace), (size_t)n_wg * 16 * sizeof(unsigned long long));
+}
+__device__ unsigned long long g_wave_trace[8192 * 16];
+extern "C" int dv_debug_wave_trace(unsigned long long* host, int n_wg) {
+  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_wave_trace), (size_t)n_wg * 16 * sizeof(unsigned long long));
 }
 extern "C" int dv_debug_gemm_trace_clear() {
   void* d = nullptr;
@@ -21,10 +26,12 @@ extern "C" int dv_debug_gemm_trace_clear() {
 }
 #else
 #define DV_TRACE(i) do {} while (0)
+#define DV_TRACE_P(i, first) do {} while (0)
 #endif
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ unsigned cvt_pk_bf16(float lo, float hi) { return dv_cvt_pk_bf16(lo, hi); }
 // GELU with the exact-erf definition (reference unet1d/activations / F.gelu default), erf by Abramowitz-Stegun 7.1.26
@@ -55,26 +62,37 @@ __device__ __forceinline__ float gelu_erf(float v) {
 // stores and takes a ticket from the tile's agent-scope counter; the first to arrive leaves, the second adds the
 // partner's dump (system-scope loads, after the atomic) and runs the epilogue.  No workgroup ever waits for another.
 // Measured: worth ~25 % on the K >= 1536 GEMMs of the 128-frame level, ~1 % of a forward.
-template <int BM, int BN, int BK, int WM, int WN, int NSPLIT, int KS, bool SC1>
+// AF ("A fused"): the A operand is not DMA'd from split planes but PRODUCED in the workgroup: NWQ extra producer waves
+// load the fp32 rows of a 64-channel chunk (BM + 2 frames: the k = 3 halo), apply GroupNorm (+ temb scale/shift) (+ SiLU)
+// and the hi/lo split, and write one LDS slab per chunk (double-buffered); the MFMA waves read the taps as shifted row
+// windows of that slab, so a k = 3 conv reads its input ONCE (fp32) instead of three times (planes), and the separate
+// GroupNorm-apply launch disappears.  Producer waves use ordinary loads (their own vmcnt), the MFMA waves keep the
+// hand-counted LDS-DMA ring for the weights; both meet at the one s_barrier per k-tile.  The k-tile order is
+// chunk-major (segment -> concat half -> 64-channel chunk -> tap); tiles never span utterances (T_out % BM == 0).
+template <int BM, int BN, int BK, int WM, int WN, int NSPLIT, int KS, bool SC1, bool AF = false>
 __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int m0, const int n0, char* smem, const int ksel = 0) {
   constexpr int FM = BM / (WM * 32), FN = BN / (WN * 32);
   constexpr int NWQ = WM * WN;                       // waves per k-group (1, 2 or 4)
-  constexpr int NWV = NWQ * KS;                      // waves per workgroup
+  constexpr int NWV = NWQ * KS;                      // MFMA waves per workgroup (AF: + NWP producer waves)
+  constexpr int NWP = AF ? 2 * NWQ : 0;              // producer waves: two per SIMD at NWQ = 4 (a lone wave issues ~1 instruction / 4 cycles)
+  static_assert(!AF || (BK == 64 && !SC1), "AF tiles: 64-deep k-tiles, per-launch kernel");
   constexpr bool SPLIT = NSPLIT == 3;
   constexpr int NPL = SPLIT ? 2 : 1;                 // planes per operand
   constexpr int ROWB = BK * 2;                       // LDS row pitch (bytes), unpadded
   constexpr int CPR = ROWB / 16;                     // 16-byte chunks per row: 4 (BK=32) or 8 (BK=64)
   constexpr int RPI = 64 / CPR;                      // rows per wave-instruction
-  constexpr int A_PL = BM * ROWB, B_PL = BN * ROWB;  // bytes per plane tile
+  constexpr int A_PL = AF ? 0 : BM * ROWB, B_PL = BN * ROWB;  // bytes per plane tile in the ring (AF: weights only)
   constexpr int STAGE = (A_PL + B_PL) * NPL;
+  constexpr int SLAB_PL = (BM + 2) * ROWB, SLAB = SLAB_PL * NPL;   // AF: one chunk's normalised rows incl. halo
 #ifndef DV_NSTAGE_64
 #define DV_NSTAGE_64 4
 #endif
   // LDS ring depth: NSTAGE-1 tiles in flight (DV_NSTAGE_64: experiment knob for the 64x64 tiles' occupancy)
-  constexpr int NSTAGE = (BM == 64 && BN == 64 && !SC1) ? DV_NSTAGE_64 : ((4 * STAGE <= 160 * 1024) ? 4 : 3);
-  constexpr int A_IPW = BM / RPI / NWV, B_IPW = BN / RPI / NWV;   // DMA instructions per wave per plane
+  constexpr int NSTAGE = AF ? 4 : ((BM == 64 && BN == 64 && !SC1) ? DV_NSTAGE_64 : ((4 * STAGE <= 160 * 1024) ? 4 : 3));
+  constexpr int A_IPW = AF ? 0 : BM / RPI / NWV, B_IPW = BN / RPI / NWV;   // DMA instructions per wave per plane
+  constexpr int A_IPW1 = A_IPW ? A_IPW : 1;          // (array extents)
   constexpr int LPT = (A_IPW + B_IPW) * NPL;         // DMA instructions per thread per k-tile
-  static_assert(BM % (RPI * NWV) == 0 && BN % (RPI * NWV) == 0, "tile rows must split over the waves");
+  static_assert((AF || BM % (RPI * NWV) == 0) && BN % (RPI * NWV) == 0, "tile rows must split over the waves");
   DV_TRACE(0);
 #ifdef DV_GEMM_TRACING
   if (threadIdx.x == 0 && blockIdx.x < 8192) {
@@ -104,7 +122,7 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int m0, con
   const int l_row = lane / CPR, l_slot = lane % CPR;
   auto swz = [](int row) { return CPR == 8 ? ((row >> 1) & 7) : ((row >> 2) & 3); };
 
-  int arow_b[A_IPW], arow_t[A_IPW], a_chunk[A_IPW];
+  int arow_b[A_IPW1], arow_t[A_IPW1], a_chunk[A_IPW1];
   unsigned arow_ok = 0;
 #pragma unroll
   for (int q = 0; q < A_IPW; ++q) {
@@ -131,6 +149,36 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int m0, con
   int kt0 = 0, nk = total_kt;                        // this launch's k-tiles: [kt0, kt0 + nk)
   if (p.sk_mode == 1 || p.sk_mode == 3) { kt0 = ksel * total_kt / p.sk_split; nk = (ksel + 1) * total_kt / p.sk_split - kt0; }
   if (p.sk_mode == 2) nk = 0;
+  // ---- AF: position in the chunk-major k-tile order, wave-uniform.  koff() = packed-K element offset of the tile ----
+  struct AfIt { int seg, half, col, tap, taps, c0, c1, kbase, pad; };
+  auto af_enter = [&](AfIt& s) {
+    const GemmSeg& sg = p.seg[s.seg < p.nseg ? s.seg : 0];
+    s.taps = sg.taps; s.c0 = sg.c0; s.c1 = sg.c1; s.pad = sg.pad;
+    s.kbase = s.seg == 0 ? 0 : p.seg[0].taps * (p.seg[0].c0 + p.seg[0].c1);
+  };
+  auto af_next = [&](AfIt& s) {
+    if (++s.tap == s.taps) {
+      s.tap = 0; s.col += 64;
+      if (s.col == (s.half ? s.c1 : s.c0)) {
+        s.col = 0;
+        if (s.half == 0 && s.c1 > 0) s.half = 1;
+        else { s.half = 0; ++s.seg; af_enter(s); }
+      }
+    }
+  };
+  auto af_koff = [&](const AfIt& s) { return s.kbase + s.tap * (s.c0 + s.c1) + (s.half ? s.c0 : 0) + s.col; };
+  AfIt af0{};                                        // first tile of this workgroup's k-range
+  if (AF) {
+    af_enter(af0);
+    if (p.sk_mode == 3) {                            // the split point moves to the next chunk boundary (a slab is per chunk)
+      int cut = total_kt / p.sk_split;
+      AfIt s = af0;
+      for (int t = 0; t < cut; ++t) af_next(s);
+      while (s.tap != 0 && cut < total_kt) { af_next(s); ++cut; }
+      if (ksel == 0) { kt0 = 0; nk = cut; }
+      else { kt0 = cut; nk = total_kt - cut; af0 = s; }
+    }
+  }
   int ld_seg = 0, ld_tap = 0, ld_half = 0;
   const bf16_t* cur_hi; const bf16_t* cur_lo;
   int cur_ld, cur_col, cur_toff;
@@ -148,7 +196,8 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int m0, con
   // One k-tile's DMA = LPT wave-instructions per thread ("units"): A rows (hi, lo plane) then B rows (hi, lo).
   // prep_a() forms the A source addresses of the tile being issued; issue_unit() sends one unit; advance()
   // moves the source state to the next k-tile.  The main loop spreads the units between its MFMA groups.
-  const void* asrc[A_IPW * NPL];
+  const void* asrc[A_IPW1 * NPL];
+  int af_issue_koff = 0;                             // AF: packed-K offset of the tile being issued
   auto prep_a = [&]() {
 #pragma unroll
     for (int q = 0; q < A_IPW; ++q) {
@@ -171,7 +220,7 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int m0, con
       else glds16(asrc[u], st_base + (unsigned)(((q * NWV + wave) * RPI) * ROWB + pl * A_PL));
     } else {
       const int q = (u - A_IPW * NPL) / NPL, pl = (u - A_IPW * NPL) % NPL;
-      const size_t o = b_off[q] + (size_t)kt * (BK * 2);
+      const size_t o = b_off[q] + (AF ? (size_t)af_issue_koff * 2 : (size_t)kt * (BK * 2));
       glds16(reinterpret_cast<const char*>(pl ? p.w_lo : p.w_hi) + o,
              st_base + (unsigned)(NPL * A_PL + ((q * NWV + wave) * RPI) * ROWB + pl * B_PL));
     }
@@ -188,13 +237,16 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int m0, con
       if (ld_seg < p.nseg) enter();
     }
   };
+  AfIt af_is = af0;              // AF: tile being issued (runs NSTAGE-1 tiles ahead of the one being multiplied)
   auto issue = [&](int kt) {     // whole tile at once (prologue)
-    prep_a();
+    if (AF) af_issue_koff = af_koff(af_is);
+    else prep_a();
 #pragma unroll
     for (int u = 0; u < LPT; ++u) issue_unit(kt, u);
-    advance();
+    if (AF) af_next(af_is);
+    else advance();
   };
-  if (kt0 > 0) {                                     // second k-half: move the source state to its first tile
+  if (!AF && kt0 > 0) {                              // second k-half: move the source state to its first tile
     for (int t = 0; t < kt0; ++t) advance();
 #pragma unroll
     for (int q = 0; q < B_IPW; ++q) b_off[q] += (size_t)kt0 * (BK * 2);
@@ -207,6 +259,17 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int m0, con
     for (int j = 0; j < FN; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  // AF tiles run ONE MFMA wave per SIMD with a single 32x32 fragment: twelve MFMAs per k-tile chained on one accumulator
+  // expose the MFMA result latency (measured: ~1800 cycles per k-tile).  Each 16-deep k-step gets its own accumulator
+  // (four independent chains, summed once before the epilogue).
+  constexpr int NACC = (AF && FM * FN == 1) ? (BK / 16 / KS) : 1;
+  f32x16 accq[NACC > 1 ? NACC - 1 : 1];
+  if (NACC > 1) {
+#pragma unroll
+    for (int a = 0; a < NACC - 1; ++a)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) accq[a][r] = 0.f;
+  }
   constexpr bool SPLIT_EPI = KS == 2 && FM % 2 == 0;
   const int l31 = lane & 31, lh = lane >> 5;
   // split-K dump: [slice][tile][fragment][4 column groups][64 * NWQ lanes] float4
@@ -239,20 +302,24 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int m0, con
   constexpr int NKS = BK / 16 / KS;                  // 16-deep k-steps per wave per k-tile
   constexpr int NTERM = SPLIT ? 3 : 1;
   constexpr int NCH = NKS * NTERM;                   // MFMA groups per k-tile
+  AfIt af_cs = af0;              // AF: tile being multiplied
+  int af_par = 0;                // AF: slab (chunk parity) it reads
   auto step = [&](int kt, auto issue_tag) {
     constexpr bool ISSUE = decltype(issue_tag)::value;
     const char* base = smem + (kt % NSTAGE) * STAGE;
-    const char* a_hi = base;
-    const char* a_lo = base + A_PL;
+    const char* a_hi = AF ? smem + NSTAGE * STAGE + af_par * SLAB : base;
+    const char* a_lo = AF ? a_hi + SLAB_PL : base + A_PL;
     const char* b_hi = base + NPL * A_PL;
     const char* b_lo = b_hi + B_PL;
+    // AF: slab row 0 is frame t0 - 1; tap j of a conv padded by `pad` reads row + j + 1 - pad
+    const int af_rowoff = AF ? af_cs.tap + 1 - af_cs.pad : 0;
     bf16x8 ah[NKS][FM], al[NKS][FM], bh[NKS][FN], bl[NKS][FN];
 #pragma unroll
     for (int ks0 = 0; ks0 < NKS; ++ks0) {
       const int chunk = (kgrp * NKS + ks0) * 2 + lh;
 #pragma unroll
       for (int i = 0; i < FM; ++i) {
-        const int row = (wm * FM + i) * 32 + l31;
+        const int row = (wm * FM + i) * 32 + l31 + af_rowoff;
         const int off = row * ROWB + ((chunk ^ swz(row)) << 4);
         ah[ks0][i] = *reinterpret_cast<const bf16x8*>(a_hi + off);
         if (SPLIT) al[ks0][i] = *reinterpret_cast<const bf16x8*>(a_lo + off);
@@ -267,27 +334,30 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int m0, con
     }
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
-      const int ks0 = c / NTERM, term = c % NTERM;
+      // (independent accumulators per k-step: consecutive MFMAs alternate chains)
+      const int ks0 = NACC > 1 ? c % NKS : c / NTERM, term = NACC > 1 ? c / NKS : c % NTERM;
 #pragma unroll
       for (int i = 0; i < FM; ++i)
 #pragma unroll
         for (int j = 0; j < FN; ++j) {
+          f32x16& ac = (NACC > 1 && ks0 > 0) ? accq[ks0 - 1] : acc[i][j];
           if (SPLIT && term == 0)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh[ks0][j], al[ks0][i], acc[i][j], 0, 0, 0);
+            ac = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh[ks0][j], al[ks0][i], ac, 0, 0, 0);
           else if (SPLIT && term == 1)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bl[ks0][j], ah[ks0][i], acc[i][j], 0, 0, 0);
+            ac = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bl[ks0][j], ah[ks0][i], ac, 0, 0, 0);
           else
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh[ks0][j], ah[ks0][i], acc[i][j], 0, 0, 0);
+            ac = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh[ks0][j], ah[ks0][i], ac, 0, 0, 0);
         }
       if (ISSUE) {
         __builtin_amdgcn_sched_barrier(0);
-        if (c == 0) prep_a();
+        if (c == 0) { if (AF) af_issue_koff = af_koff(af_is); else prep_a(); }
 #pragma unroll
         for (int u = c * LPT / NCH; u < (c + 1) * LPT / NCH; ++u) issue_unit(kt + NSTAGE - 1, u);
         __builtin_amdgcn_sched_barrier(0);
       }
     }
-    if (ISSUE) advance();
+    if (ISSUE) { if (AF) af_next(af_is); else advance(); }
+    if (AF) { af_next(af_cs); if (af_cs.tap == 0) af_par ^= 1; }
   };
 
   // accumulator fragment (i, j), lane (l31, lh), register r = 4*g + e  holds
@@ -324,7 +394,7 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int m0, con
   // residual operand of small tiles: fetched before the k-loop so its latency hides under it
   constexpr bool PRE_RES = FM * FN <= 2;
   float rpre[PRE_RES ? FM * FN * 16 : 1];
-  if (PRE_RES && p.epi == EPI_RESIDUAL && p.sk_mode != 1) {   // (mode 3: half of the workgroups prefetch in vain)
+  if (PRE_RES && p.epi == EPI_RESIDUAL && p.sk_mode != 1 && !(AF && kgrp >= KS)) {   // (mode 3: half of the workgroups prefetch in vain)
 #pragma unroll
     for (int i = 0; i < FM; ++i) {
       const size_t ro = (size_t)min(m0 + (wm * FM + i) * 32 + l31, p.M - 1) * p.ldres;
@@ -370,6 +440,232 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int m0, con
     glds4((const void*)(p.ln_u + n), (unsigned)(size_t)s_u + wave * 256);
   }
 
+  // ---- AF: the producer waves' whole life (table, slabs, one barrier per k-tile), then they leave ----
+  if constexpr (AF) {
+    __shared__ __attribute__((aligned(16))) float s_gscale[1024], s_gshift[1024];
+    if (kgrp >= KS) {                                // waves past the KS k-groups of MFMA waves
+      constexpr int NP = 64 * NWP;                   // producer threads
+      const int ptid = tid - 64 * NWV, pw = wave - NWV;
+#ifndef DV_AF_PRODUCER_PRIO
+#define DV_AF_PRODUCER_PRIO 3
+#endif
+      // the producer shares its SIMD with two MFMA waves and is the youngest wave there: without priority it gets the
+      // leftover issue slots and arrives last at every k-tile barrier
+      __builtin_amdgcn_s_setprio(DV_AF_PRODUCER_PRIO);
+      const int T = p.T_out, b_item = m0 / T, t0 = m0 - b_item * T;
+      // tasks of a chunk = (slab row, 4-channel group): rounds 0 and 1 cover the BM tile rows (BM * 16 = 2 NP tasks),
+      // round 2 the two halo rows (32 tasks, first producer wave).  A thread keeps its 4-channel group over all rounds
+      // (NP % 16 == 0), so the chunk's scale / shift for those channels are read from the table once per chunk.
+      static_assert(BM * 16 == 2 * NP, "two task rounds cover the tile rows");
+      float4 rv[3];
+      bool rok[3];
+      const int c4 = ptid & 15;
+      auto task_row = [&](int j) { return j < 2 ? ((j * NP + ptid) >> 4) + 1 : (ptid < 16 ? 0 : BM + 1); };
+      // Loads are UNCONDITIONAL (clamped row; zeroed at conversion): a per-element "load or zero" select makes hipcc
+      // branch around each load and wait for it.  The halo tasks exist in the first producer wave only (wave-uniform).
+      auto load_round = [&](const AfIt& c, int j) {
+        if (j == 2 && (pw != 0 || c.taps != 3)) { rok[2] = false; return; }
+        const AfSrc& a = p.afp.src[c.seg][c.half];
+        const int t = t0 - 1 + task_row(j);
+        rok[j] = t >= 0 && t < T && (j < 2 || ptid < 32);
+        rv[j] = *reinterpret_cast<const float4*>(a.x + ((size_t)b_item * T + min(max(t, 0), T - 1)) * a.C + c.col + c4 * 4);
+      };
+      float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
+      int cv_mode = 0;
+      auto conv_begin = [&](const AfIt& c) {         // per-chunk: mode and this thread's table entries
+        cv_mode = c.seg == 0 ? p.afp.mode0 : 0;
+        if (cv_mode) {
+          const int tab = (c.half ? c.c0 : 0) + c.col + c4 * 4;
+          sc = *reinterpret_cast<const float4*>(s_gscale + tab);
+          sh = *reinterpret_cast<const float4*>(s_gshift + tab);
+        }
+      };
+      auto convert_round = [&](int par, int j) {
+        if (j == 2 && (pw != 0 || ptid >= 32)) return;
+        char* sl = smem + NSTAGE * STAGE + par * SLAB;
+        const int srow = task_row(j);
+        float v[4] = {rv[j].x, rv[j].y, rv[j].z, rv[j].w};
+        if (cv_mode) {
+          const float scv[4] = {sc.x, sc.y, sc.z, sc.w}, shv[4] = {sh.x, sh.y, sh.z, sh.w};
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            v[e] = fmaf(v[e], scv[e], shv[e]);
+            if (cv_mode == 2) v[e] = v[e] * __builtin_amdgcn_rcpf(1.0f + __expf(-v[e]));   // SiLU
+          }
+        }
+        // conv zero padding pads the NORMALISED tensor: frames outside the utterance are zeros, not norm(0)
+        if (!rok[j]) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = 0.f;
+        }
+        uint2 hw, lw;
+        hw.x = cvt_pk_bf16(v[0], v[1]); hw.y = cvt_pk_bf16(v[2], v[3]);
+        lw.x = cvt_pk_bf16(v[0] - __uint_as_float(hw.x << 16), v[1] - __uint_as_float(hw.x & 0xffff0000u));
+        lw.y = cvt_pk_bf16(v[2] - __uint_as_float(hw.y << 16), v[3] - __uint_as_float(hw.y & 0xffff0000u));
+        const int off = srow * ROWB + (((c4 >> 1) ^ swz(srow)) << 4) + (c4 & 1) * 8;
+        *reinterpret_cast<uint2*>(sl + off) = hw;
+        if (SPLIT) *reinterpret_cast<uint2*>(sl + SLAB_PL + off) = lw;
+      };
+      AfIt nx = af0;                                 // chunk whose raw rows are in registers (next to be converted)
+      int left = nk;                                 // tiles of the range from nx's chunk on
+      auto chunk_after = [&](AfIt c) { c.tap = c.taps - 1; af_next(c); return c; };
+#pragma unroll
+      for (int j = 0; j < 3; ++j) load_round(nx, j); // first chunk's rows: in flight under the table build
+      DV_TRACE_P(12, 64 * NWV);
+      // GroupNorm table of segment 0 (this utterance): scale[c] = rstd*gamma*(1+ts), shift[c] = (beta - mean*rstd*gamma)*(1+ts) + tb.
+      // Latency is what matters here (every workgroup waits for its first slab): the per-channel parameters are
+      // fetched first (they do not depend on the statistics), every producer wave reduces ALL groups itself (64 / G
+      // lanes per group, entries of a group strided over them, one pass in fp64: no cross-wave step), and the channel
+      // owner picks its group's (mean, rstd) from the lane that holds them.
+      if (p.afp.mode0) {
+        const int G = p.afp.groups, c0s = p.seg[0].c0, ctot = c0s + p.seg[0].c1, cg = ctot / G, nvb = cg >> 4, RB = T >> 5;
+        constexpr int CPT = 1024 / NP;               // channels per producer thread (ctot <= 1024)
+        float pg[CPT], pb[CPT], pts[CPT], ptb[CPT];
+#pragma unroll
+        for (int k = 0; k < CPT; ++k) {
+          const int cc = min(ptid + k * NP, ctot - 1);
+          pg[k] = p.afp.gamma[cc];
+          pb[k] = p.afp.beta[cc];
+          pts[k] = p.afp.tscale ? p.afp.tscale[(size_t)b_item * p.afp.ld_t + cc] : 0.0f;
+          ptb[k] = p.afp.tshift ? p.afp.tshift[(size_t)b_item * p.afp.ld_t + cc] : 0.0f;
+        }
+        // block entries (sum, M2 about the block mean) of this utterance: fetched by all producer threads at once (one
+        // round trip: at most a few independent loads each) into the last ring stage - the weight prologue fills stages
+        // 0 .. NSTAGE-2, the last one is first written after the first k-tile barrier - then every producer wave
+        // reduces all groups from there (n_ent <= STAGE / 8, checked by the launcher)
+        const int nblk = ctot >> 4, n_ent = RB * nblk;
+        float2* s_ent = reinterpret_cast<float2*>(smem + (NSTAGE - 1) * STAGE);
+        for (int e0 = 0; e0 < n_ent; e0 += 4 * NP) {
+          float2 ev[4];
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const int e = min(e0 + k * NP + ptid, n_ent - 1);
+            const int rb = e / nblk, vb = e - rb * nblk;
+            const int half = vb * 16 >= c0s;
+            const AfSrc& a = p.afp.src[0][half];
+            const int vbl = half ? vb - (c0s >> 4) : vb;
+            ev[k] = reinterpret_cast<const float2*>(a.stat16)[(size_t)(b_item * RB + rb) * (a.C >> 4) + vbl];
+          }
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const int e = e0 + k * NP + ptid;
+            if (e < n_ent) s_ent[e] = ev[k];
+          }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                // (#T0) entries staged (the MFMA waves join it before their loop)
+        const int lpg = 64 / G;                      // lanes per group (G a power of two <= 64)
+        const int g = lane / lpg, sub = lane - g * lpg;
+        // M2_b + sum_b^2 / 512 = the block's sum of squares; accumulated in fp64 (the single fp64 subtraction below is harmless)
+        double s1 = 0, q = 0;
+        for (int i0 = sub; i0 < RB * nvb; i0 += 4 * lpg) {
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const int i = i0 + k * lpg;
+            const int rb = i / nvb;
+            const float2 v = s_ent[min(rb * nblk + g * nvb + (i - rb * nvb), n_ent - 1)];
+            if (i < RB * nvb) {
+              s1 += (double)v.x;
+              q += (double)v.y + (double)v.x * (double)v.x * (1.0 / 512.0);
+            }
+          }
+        }
+        for (int o = lpg >> 1; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o); q += __shfl_xor(q, o); }
+        const double n = (double)cg * (double)T;
+        const double mean_d = s1 / n;
+        double var = q / n - mean_d * mean_d;
+        var = var > 0 ? var : 0;
+        const float mean = (float)mean_d, rstd = 1.0f / sqrtf((float)var + p.afp.eps);
+#pragma unroll
+        for (int k = 0; k < CPT; ++k) {
+          const int cc = ptid + k * NP;
+          const int src_lane = min(cc, ctot - 1) / cg * lpg;
+          const float gm = __shfl(mean, src_lane), gr = __shfl(rstd, src_lane);
+          if (cc < ctot) {
+            const float a = gr * pg[k];
+            const float ts = 1.0f + pts[k];
+            s_gscale[cc] = a * ts;
+            s_gshift[cc] = fmaf(pb[k] - gm * a, ts, ptb[k]);
+          }
+        }
+      }
+      else __builtin_amdgcn_s_barrier();             // (#T0) nothing to stage
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      DV_TRACE_P(13, 64 * NWV);
+      __builtin_amdgcn_s_barrier();                  // (#T) table complete (the MFMA waves join it before their loop)
+      DV_TRACE_P(14, 64 * NWV);
+      // chunk 0 -> slab 0, and the rows of chunk 1 into the registers
+      conv_begin(nx);
+      {
+        const AfIt n1 = chunk_after(nx);
+        const bool more = left - nx.taps > 0;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) { convert_round(0, j); if (more) load_round(n1, j); }
+        left -= nx.taps;
+        nx = n1;
+      }
+      DV_TRACE_P(15, 64 * NWV);
+      // Steady state: while the MFMA waves multiply chunk c (slab par), chunk c+1 (in registers) is converted into the
+      // other slab and the rows of chunk c+2 are fetched - one task round per k-tile of a three-tap chunk (the work of
+      // a chunk is spread over its tiles: a producer wave must not be the last at the barrier), all rounds at once in
+      // a one-tap chunk.
+      AfIt cs = af0;                                 // tile the MFMA waves multiply at loop index kt
+      AfIt n2 = nx;                                  // chunk after nx (valid while `more2`)
+      bool more1 = false, more2 = false;
+      int par = 0;
+#ifdef DV_GEMM_TRACING
+      unsigned long long tr_pbar = 0, tr_pwork = 0;
+#endif
+      for (int kt = 0; kt < nk; ++kt) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's slab writes have landed
+#ifdef DV_GEMM_TRACING
+        const unsigned long long trp0 = __builtin_amdgcn_s_memtime();
+#endif
+        __builtin_amdgcn_s_barrier();
+#ifdef DV_GEMM_TRACING
+        tr_pbar += __builtin_amdgcn_s_memtime() - trp0;
+        if (kt == nk - 1 && (int)threadIdx.x == 64 * NWV && blockIdx.x < 8192) g_gemm_trace[blockIdx.x * 16 + 11] = tr_pbar;
+#endif
+        if (cs.tap == 0) {                           // a chunk starts: its slab is read now, the other one is free
+          more1 = left > 0;                          // nx exists
+          more2 = left - nx.taps > 0;                // and so does the chunk after it
+          if (more1) { conv_begin(nx); n2 = chunk_after(nx); }
+        }
+#ifdef DV_GEMM_TRACING
+        // development knobs (trace build): p.af bit 1 = producers skip the slab work in the k-loop, bit 2 = skip only the loads
+        if (p.af & 2) more1 = false;
+        if (p.af & 4) more2 = false;
+#endif
+#ifdef DV_GEMM_TRACING
+        const unsigned long long trq0 = __builtin_amdgcn_s_memtime();
+#endif
+        if (more1) {
+          if (cs.taps == 1) {
+#pragma unroll
+            for (int j = 0; j < 3; ++j) { convert_round(par ^ 1, j); if (more2) load_round(n2, j); }
+          } else {
+            const int j = cs.tap;
+            if (j == 0) { convert_round(par ^ 1, 0); if (more2) load_round(n2, 0); }
+            else if (j == 1) { convert_round(par ^ 1, 1); if (more2) load_round(n2, 1); }
+            else { convert_round(par ^ 1, 2); if (more2) load_round(n2, 2); }
+          }
+        }
+#ifdef DV_GEMM_TRACING
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        tr_pwork += __builtin_amdgcn_s_memtime() - trq0;
+        if (kt == nk - 1 && (int)threadIdx.x == 64 * NWV + 64 && blockIdx.x < 8192) g_gemm_trace[blockIdx.x * 16 + 12] = tr_pwork;
+        if (kt == nk - 1 && lane == 0 && blockIdx.x < 8192) g_wave_trace[blockIdx.x * 16 + wave] = tr_pwork;
+#endif
+        af_next(cs);
+        if (cs.tap == 0) {                           // chunk finished
+          par ^= 1;
+          if (more1) { left -= nx.taps; nx = n2; }
+        }
+      }
+      return;
+    }
+  }
+
   // ---- main loop: wait(tile kt) -> barrier -> multiply tile kt with the DMA of tile kt+NSTAGE-1 interleaved ----
   // NSTAGE-1 tiles are in flight; the counted vmcnt leaves the younger ones outstanding across the barrier
   DV_TRACE(10);    // residual prefetch / LayerNorm rows / bias DMA issued
@@ -381,17 +677,37 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int m0, con
 #endif
   }
   DV_TRACE(1);
+  if (AF) { __builtin_amdgcn_s_barrier(); __builtin_amdgcn_s_barrier(); }   // (#T0, #T) pair with the producer waves' table barriers
   // steady state: tile kt+NSTAGE-1 is issued while tile kt is multiplied; NSTAGE-2 younger tiles stay in flight
   const int n_steady = nk - (NSTAGE - 1);
   int kt = 0;
+#ifdef DV_GEMM_TRACING
+  unsigned long long tr_vm = 0, tr_bar = 0, tr_step = 0;
+#endif
   for (; kt < n_steady; ++kt) {
+#ifdef DV_GEMM_TRACING
+    const unsigned long long tr0 = __builtin_amdgcn_s_memtime();
+#endif
     wait_vmcnt<(NSTAGE - 2) * LPT>();
+#ifdef DV_GEMM_TRACING
+    const unsigned long long tr1 = __builtin_amdgcn_s_memtime();
+#endif
     __builtin_amdgcn_s_barrier();                    // tile kt visible; every wave is done with tile kt-1
 #ifdef DV_GEMM_TRACING
+    const unsigned long long tr2 = __builtin_amdgcn_s_memtime();
     if (kt == 0) DV_TRACE(2);
 #endif
     step(kt, std::true_type{});                      // DMA overwrites the stage tile kt-1 was read from
+#ifdef DV_GEMM_TRACING
+    tr_vm += tr1 - tr0; tr_bar += tr2 - tr1; tr_step += __builtin_amdgcn_s_memtime() - tr2;
+#endif
   }
+#ifdef DV_GEMM_TRACING
+  if (AF && lane == 0 && blockIdx.x < 8192) g_wave_trace[blockIdx.x * 16 + wave] = tr_vm + tr_step;
+  if (AF && threadIdx.x == 0 && blockIdx.x < 8192) {   // AF: the prologue-split slots carry the steady loop's wait sums
+    g_gemm_trace[blockIdx.x * 16 + 8] = tr_vm; g_gemm_trace[blockIdx.x * 16 + 9] = tr_bar; g_gemm_trace[blockIdx.x * 16 + 10] = tr_step;
+  }
+#endif
   for (; kt < nk; ++kt) {                            // drain: nothing left to issue
     const int younger = min(NSTAGE - 2, nk - 1 - kt);
     if (younger >= 2) wait_vmcnt<2 * LPT>();
@@ -404,6 +720,12 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int m0, con
     step(kt, std::false_type{});
   }
 
+  if (NACC > 1) {
+#pragma unroll
+    for (int a = 0; a < NACC - 1; ++a)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[0][0][r] += accq[a][r];
+  }
   if (nk == 0) { wait_vmcnt<0>(); __syncthreads(); }   // epilogue-only launch: the bias DMA has landed
   DV_TRACE(3);
   // KS == 2: add the two k-groups' partial accumulators through LDS (lane-linear, conflict-free).  With an even
@@ -657,6 +979,26 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int m0, con
         const int n = nf + 8 * (r >> 2) + (r & 3);
         if ((l31 & 1) == 0 && n < p.N && mrow0 < p.M)
           reinterpret_cast<float2*>(p.stats)[(size_t)(mrow0 >> 5) * p.N + n] = make_float2(s1[0], s2[0]);
+      }
+      if (p.stats16) {
+        // per (32-row, 16-column) block: (sum, squared deviations from the block's OWN mean) - no E[x^2] - mean^2
+        // cancellation when |mean| >> spread; the consumer combines blocks with the parallel-variance formula in fp64.
+        // Registers 0-7 / 8-15 are the fragment's first / second 16 columns (column = 8g + 4lh + e, r = 4g + e);
+        // every lane holds columns of both halves, so both sums run over all 64 lanes.
+        float a1[2] = {0.f, 0.f}, a2[2] = {0.f, 0.f};
+#pragma unroll
+        for (int r = 0; r < 16; ++r) a1[r >> 3] += vv[r];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { a1[0] += __shfl_xor(a1[0], o); a1[1] += __shfl_xor(a1[1], o); }
+        const float mb[2] = {a1[0] * (1.0f / 512.0f), a1[1] * (1.0f / 512.0f)};
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { const float dv = vv[r] - mb[r >> 3]; a2[r >> 3] = fmaf(dv, dv, a2[r >> 3]); }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { a2[0] += __shfl_xor(a2[0], o); a2[1] += __shfl_xor(a2[1], o); }
+        const int cb0 = (n0 + (wn * FN + j) * 32) >> 4;
+        if (lane < 2 && mrow0 < p.M && (cb0 + lane) * 16 < p.N)
+          reinterpret_cast<float2*>(p.stats16)[(size_t)(mrow0 >> 5) * (p.N >> 4) + cb0 + lane] =
+              make_float2(lane ? a1[1] : a1[0], lane ? a2[1] : a2[0]);
       }
     }
   }

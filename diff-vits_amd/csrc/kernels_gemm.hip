@@ -26,8 +26,8 @@
 #include <cstdlib>
 #include <type_traits>
 
-template <int BM, int BN, int BK, int WM, int WN, int NSPLIT, int KS>
-__global__ __launch_bounds__(64 * WM * WN * KS) void k_gemm(const GemmParams p) {
+template <int BM, int BN, int BK, int WM, int WN, int NSPLIT, int KS, bool AF = false>
+__global__ __launch_bounds__(64 * WM * WN * (KS + (AF ? 2 : 0))) void k_gemm(const GemmParams p) {
   extern __shared__ __attribute__((aligned(1024))) char smem[];
   // XCD-aware tile order: consecutive tile ids (same A rows, neighbouring N) share an L2.
   const int n_tiles_n = (p.N + BN - 1) / BN;
@@ -43,7 +43,7 @@ __global__ __launch_bounds__(64 * WM * WN * KS) void k_gemm(const GemmParams p) 
     ksel = bid / tiles;
     bid -= ksel * tiles;
   }
-  gemm_tile<BM, BN, BK, WM, WN, NSPLIT, KS, false>(p, (bid / n_tiles_n) * BM, (bid % n_tiles_n) * BN, smem, ksel);
+  gemm_tile<BM, BN, BK, WM, WN, NSPLIT, KS, false, AF>(p, (bid / n_tiles_n) * BM, (bid % n_tiles_n) * BN, smem, ksel);
 }
 
 template <int BM, int BN, int BK, int WM, int WN, int NSPLIT, int KS>
@@ -61,6 +61,37 @@ struct GemmCfg {
     return hipGetLastError();
   }
 };
+
+// AF tiles (A operand produced in-kernel, gemm_tile.h): WM*WN MFMA waves + as many producer waves, 64-deep k-tiles,
+// ring of 4 weight stages + two slabs of BM + 2 normalised rows
+template <int BM, int BN, int WM, int WN, int KS, int NSPLIT>
+struct GemmCfgAF {
+  static constexpr int NPL = NSPLIT == 3 ? 2 : 1;
+  static constexpr int SMEM = 4 * BN * 128 * NPL + 2 * (BM + 2) * 128 * NPL;
+  static hipError_t init() {
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm<BM, BN, 64, WM, WN, NSPLIT, KS, true>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
+  }
+  static hipError_t launch(const GemmParams& p, hipStream_t st) {
+    const int tiles = (p.M / BM) * ((p.N + BN - 1) / BN) * (p.sk_mode == 3 ? p.sk_split : 1);
+    hipLaunchKernelGGL((k_gemm<BM, BN, 64, WM, WN, NSPLIT, KS, true>), dim3(tiles), dim3(64 * WM * WN * (KS + 2)), SMEM, st, p);
+    return hipGetLastError();
+  }
+};
+template <int BM, int BN, int WM, int WN, int KS>
+struct GemmTileAF {
+  static hipError_t init() {
+    hipError_t e = GemmCfgAF<BM, BN, WM, WN, KS, 3>::init();
+    return e != hipSuccess ? e : GemmCfgAF<BM, BN, WM, WN, KS, 1>::init();
+  }
+  static hipError_t launch(const GemmParams& p, bool x3, hipStream_t st) {
+    return x3 ? GemmCfgAF<BM, BN, WM, WN, KS, 3>::launch(p, st) : GemmCfgAF<BM, BN, WM, WN, KS, 1>::launch(p, st);
+  }
+};
+// 64x64: two k-groups of four MFMA waves (two per SIMD: one's LDS reads overlap the other's MFMAs) + eight producer waves
+// (1024 threads, <= 128 VGPRs); 32x64 (T_out % 64 != 0): two k-groups of two MFMA waves + four producer waves
+using AF64 = GemmTileAF<64, 64, 2, 2, 2>;
+using AF32 = GemmTileAF<32, 64, 1, 2, 2>;
 
 template <int BM, int BN, int BK, int WM, int WN, int KS = 1>
 struct GemmTile {
@@ -126,7 +157,29 @@ template <int BK> struct Tiles {
 
 hipError_t gemm_init() {
   hipError_t e = Tiles<32>::init();
-  return e != hipSuccess ? e : Tiles<64>::init();
+  if (e != hipSuccess) return e;
+  if ((e = Tiles<64>::init()) != hipSuccess) return e;
+  if ((e = AF64::init()) != hipSuccess) return e;
+  return AF32::init();
+}
+
+// Can this GEMM run on the AF tiles?  (the engine asks before it plans a fused GroupNorm -> conv)
+bool gemm_af_supported(const GemmParams& p) {
+  if (p.stride != 1 || p.up_mode != UP_NONE || p.T_in != p.T_out || p.T_out % 32 != 0 || p.M != p.B * p.T_out) return false;
+  if (p.ln_stat || p.epi == EPI_GEGLU) return false;
+  for (int s = 0; s < p.nseg; ++s) {
+    const GemmSeg& sg = p.seg[s];
+    if (sg.c0 % 64 != 0 || sg.c1 % 64 != 0 || sg.c0 <= 0 || (sg.taps != 1 && sg.taps != 3) || sg.pad != (sg.taps - 1) / 2) return false;
+    if (!p.afp.src[s][0].x || p.afp.src[s][0].C != sg.c0 || (sg.c1 > 0 && (!p.afp.src[s][1].x || p.afp.src[s][1].C != sg.c1))) return false;
+  }
+  if (p.nseg > 1 && p.seg[1].taps != 1) return false;
+  if (p.afp.mode0) {
+    const int ctot = p.seg[0].c0 + p.seg[0].c1, G = p.afp.groups;
+    if (G <= 0 || G > 64 || (G & (G - 1)) != 0 || ctot > 1024 || ctot % G != 0 || (ctot / G) % 16 != 0 || !p.afp.gamma || !p.afp.beta) return false;
+    if (!p.afp.src[0][0].stat16 || (p.seg[0].c1 > 0 && !p.afp.src[0][1].stat16)) return false;
+    if ((p.T_out / 32) * (ctot / 16) > 1024) return false;      // block entries of one utterance are staged in a ring stage (8 KiB in bf16 mode)
+  }
+  return true;
 }
 
 // Tunables (env DVITS_GEMM_CFG="big,min_wg,bk64"): workgroup-count threshold for the 128x128x32 tile,
@@ -189,6 +242,18 @@ hipError_t launch_gemm(const GemmParams& pin, int precision, hipStream_t st) {
   GemmParams p = pin;
   const bool x3 = precision == 0;
   if (!p.zero_page || (x3 && !p.w_lo)) return hipErrorInvalidValue;
+  if (p.af) {
+    if (!gemm_af_supported(p)) return hipErrorInvalidValue;
+    // split-K: only the one-launch pair (ticket hand-over); the k-range is cut at a chunk boundary inside the kernel
+    if (p.sk_buf && p.sk_split == 2 && p.sk_ticket) p.sk_mode = 3;
+    else { p.sk_buf = nullptr; p.sk_split = 0; p.sk_mode = 0; p.sk_ticket = nullptr; }
+    for (int s = 0; s < p.nseg; ++s) p.seg[s].nkt = p.seg[s].taps * (p.seg[s].c0 + p.seg[s].c1) / 64;
+    const int ft = p.force_tile & 0xff;
+    const bool t64 = p.T_out % 64 == 0;
+    if (ft == GT_AF64 && !t64) return hipErrorInvalidValue;
+    const bool use64 = ft == GT_AF64 || (ft != GT_AF32 && t64);
+    return use64 ? AF64::launch(p, x3, st) : AF32::launch(p, x3, st);
+  }
   if (p.sk_buf && p.sk_split == 2 && p.sk_ticket && p.sk_mode == 0) {
     p.sk_mode = 3;                                     // both k-halves and the epilogue in one launch
     return launch_gemm(p, precision, st);

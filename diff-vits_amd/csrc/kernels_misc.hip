@@ -823,3 +823,32 @@ hipError_t launch_lincomb(float* out, const float* x, const float* m0, const flo
   if (n4 * 4 < n) hipLaunchKernelGGL(k_lincomb_tail, dim3(1), dim3(4), 0, st, out, x, m0, m1, m2, m3, coef, n4 * 4, n);
   return hipGetLastError();
 }
+
+
+// ---- 32x16-block statistics of a channels-last fp32 tensor [M, C] -> stat16 [M/32, C/16, 2] = (sum, squared deviations
+// from the block's own mean): what a GEMM epilogue writes beside its output for the consumer conv that normalises its own
+// operand (gemm_tile.h, AF tiles).  Standalone form for tensors that did not come out of such an epilogue.
+__global__ __launch_bounds__(64) void k_stat16(const float* __restrict__ x, float* __restrict__ stat16, int M, int C) {
+  const int rb = blockIdx.x, cb = blockIdx.y, lane = threadIdx.x;
+  const int row = rb * 32 + (lane >> 1), col = cb * 16 + (lane & 1) * 8;
+  float v[8];
+  const bool ok = row < M;
+  const float4 a = ok ? *reinterpret_cast<const float4*>(x + (size_t)row * C + col) : make_float4(0.f, 0.f, 0.f, 0.f);
+  const float4 b = ok ? *reinterpret_cast<const float4*>(x + (size_t)row * C + col + 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+  v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+  float s1 = 0.f;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) s1 += v[e];
+  s1 = wave_sum(s1);
+  const float mb = s1 * (1.0f / 512.0f);
+  float s2 = 0.f;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { const float d = v[e] - mb; s2 = fmaf(d, d, s2); }
+  s2 = wave_sum(s2);
+  if (lane == 0) reinterpret_cast<float2*>(stat16)[(size_t)rb * (C >> 4) + cb] = make_float2(s1, s2);
+}
+hipError_t launch_stat16(const float* x, float* stat16, int M, int C, hipStream_t st) {
+  if (M % 32 != 0 || C % 16 != 0) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(k_stat16, dim3(M / 32, C / 16), dim3(64), 0, st, x, stat16, M, C);
+  return hipGetLastError();
+}

@@ -22,24 +22,46 @@ lib.dv_debug_gemm_trace.argtypes = [C.c_void_p, C.c_int]
 
 shapes = [(8192, 128, 128), (4096, 256, 2048), (1024, 3072, 512), (2048, 384, 3072), (2048, 1536, 384),
           (4096, 256, 256), (2048, 384, 384)]
-if len(sys.argv) > 1:
-    shapes = [tuple(int(v) for v in a.split("x")) for a in sys.argv[1:]]
+# "af:BxTxCinxCoutxk" traces the fused GroupNorm -> conv tiles (dv_op_gn_conv1d) instead of a plain linear
+af_shapes = [tuple(int(v) for v in a[3:].split("x")) for a in sys.argv[1:] if a.startswith("af:")]
+plain = [a for a in sys.argv[1:] if not a.startswith("af:")]
+if plain:
+    shapes = [tuple(int(v) for v in a.split("x")) for a in plain]
+elif af_shapes:
+    shapes = []
 NWG = 8192
 buf = np.zeros((NWG, 16), dtype=np.uint64)
-for M, K, N in shapes:
-    x = torch.randn(M, K, device="cuda")
-    w = torch.randn(N, K, device="cuda") / K ** 0.5
-    b = torch.randn(N, device="cuda")
-    y = torch.empty(M, N, device="cuda")
+for spec in shapes + [("af",) + a for a in af_shapes]:
+    if spec[0] == "af":
+        _, Bn, Tn, Ci, Co, kk = spec
+        M, K, N = Bn * Tn, Ci * kk, Co
+        x = torch.randn(M, Ci, device="cuda")
+        w = torch.randn(Co, Ci, kk, device="cuda") / K ** 0.5
+        b = torch.randn(N, device="cuda")
+        gam, bet = torch.ones(Ci, device="cuda"), torch.zeros(Ci, device="cuda")
+        y = torch.empty(Bn, Co, Tn, device="cuda")
+
+        def run():
+            L.check(lib.dv_op_gn_conv1d(L.ptr(x), L.ptr(gam), L.ptr(bet), None, None, L.ptr(w), L.ptr(b), L.ptr(y), Bn, Ci, Tn,
+                                        Co, kk, 8, 1e-5, 1, 0, None))
+    else:
+        M, K, N = spec
+        x = torch.randn(M, K, device="cuda")
+        w = torch.randn(N, K, device="cuda") / K ** 0.5
+        b = torch.randn(N, device="cuda")
+        y = torch.empty(M, N, device="cuda")
+
+        def run():
+            L.check(lib.dv_op_linear(L.ptr(x), L.ptr(w), L.ptr(b), L.ptr(y), M, K, N, 0, None))
     for _ in range(3):
-        L.check(lib.dv_op_linear(L.ptr(x), L.ptr(w), L.ptr(b), L.ptr(y), M, K, N, 0, None))
+        run()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     buf[:] = 0
     assert lib.dv_debug_gemm_trace_clear() == 0
-    # the split kernel of dv_op_linear runs first; the trace only sees the GEMM
+    # the split / statistics / packing kernels of the op run first; the trace only sees the GEMM
     e0.record()
-    L.check(lib.dv_op_linear(L.ptr(x), L.ptr(w), L.ptr(b), L.ptr(y), M, K, N, 0, None))
+    run()
     e1.record()
     torch.cuda.synchronize()
     assert lib.dv_debug_gemm_trace(buf.ctypes.data_as(C.c_void_p), NWG) == 0
@@ -48,8 +70,22 @@ for M, K, N in shapes:
     n = int(live.sum())
     t = t[live]
     pro = np.stack([t[:, 8] - t[:, 0], t[:, 9] - t[:, 8], t[:, 10] - t[:, 9], t[:, 11] - t[:, 10], t[:, 1] - t[:, 11]], 1)
-    print("   prologue split (median cyc): kernarg-ready %d | row geometry %d | bias/residual/LN setup %d | issue tile 0 %d | "
-          "issue tiles 1.. %d" % tuple(np.median(pro, 0)))
+    if spec[0] != "af":
+        print("   prologue split (median cyc): kernarg-ready %d | row geometry %d | bias/residual/LN setup %d | issue tile 0 %d | "
+              "issue tiles 1.. %d" % tuple(np.median(pro, 0)))
+    if spec[0] == "af":
+        wb = np.zeros((NWG, 16), dtype=np.uint64)
+        lib.dv_debug_wave_trace.restype = C.c_int
+        lib.dv_debug_wave_trace.argtypes = [C.c_void_p, C.c_int]
+        assert lib.dv_debug_wave_trace(wb.ctypes.data_as(C.c_void_p), NWG) == 0
+        print("   per-wave busy cycles between barriers, summed over the loop (median over workgroups; waves 0-7 multiply, 8-15 produce): %s"
+              % np.median(wb.astype(np.int64)[live], 0).astype(int).tolist())
+        print("   steady k-loop sums (median cyc): MFMA wave 0 waits for its DMA %d | waits at the barrier %d | multiplies %d ;  "
+              "producer wave 0 waits at the barrier %d ; producer wave 1 works (incl. landing of its slab writes) %d"
+              % tuple(np.median(t[:, 8:13], 0)))
+        pp = np.stack([t[:, 12] - t[:, 0], t[:, 13] - t[:, 12], t[:, 14] - t[:, 13], t[:, 15] - t[:, 14], t[:, 2] - t[:, 15]], 1)
+        print("   producer wave (median cyc): start -> first rows requested %d | statistics + table %d | wait at table barrier %d | "
+              "chunk 0 converted, chunk 1 requested %d | -> first k-tile barrier released %d" % tuple(np.median(pp, 0)))
     ph = np.stack([t[:, 1] - t[:, 0], t[:, 2] - t[:, 1], t[:, 3] - t[:, 2], t[:, 4] - t[:, 3], t[:, 5] - t[:, 4],
                    t[:, 5] - t[:, 0]], 1)
     wall = t[:, 7]
