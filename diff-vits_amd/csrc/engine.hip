@@ -451,10 +451,13 @@ struct Builder {
     return pl;
   }
   void release(const Planes& pl) { if (pl.hi) release((const void*)pl.hi); if (pl.lo) release((const void*)pl.lo); }
-  // GroupNorm statistics of a GEMM output for its consumer, written by the GEMM's epilogue.  With the fused schedule
-  // (default; DVITS_FUSE_GN=0 restores the k_gn_apply launches) the consumer conv normalises its own operand from
-  // per-(32-frame, 16-channel)-block statistics; otherwise k_gn_apply reduces a per-column slab.
-  bool fuse_gn = [] { const char* e = getenv("DVITS_FUSE_GN"); return !(e && e[0] == '0'); }();
+  // GroupNorm statistics of a GEMM output for its consumer, written by the GEMM's epilogue: k_gn_apply reduces a
+  // per-column slab (default).  DVITS_FUSE_GN=1: the consumer conv normalises its own operand from per-(32-frame,
+  // 16-channel)-block statistics (AF tiles, gemm_tile.h) and the k_gn_apply launches disappear.  Built, parity-green and
+  // OFF by default: measured slower - an N-tiled conv repeats the elementwise GroupNorm + SiLU +
+  // hi/lo split of its rows in every 64-column tile (2-8x), and that conversion costs more vector-ALU time per element
+  // than the tile's MFMAs.
+  bool fuse_gn = [] { const char* e = getenv("DVITS_FUSE_GN"); return e && e[0] == '1'; }();
   // a tensor carries 32x16-block statistics iff every GroupNorm over it (alone or concatenated with another such
   // tensor) has whole 16-channel blocks per group and 64-channel chunks: then every consumer can take the fused path
   bool af_tensor(int Tn, int C) const {

@@ -15,10 +15,6 @@ __device__ unsigned long long g_gemm_trace[8192 * 16];
 extern "C" int dv_debug_gemm_trace(unsigned long long* host, int n_wg) {
   return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_gemm_trace), (size_t)n_wg * 16 * sizeof(unsigned long long));
 }
-__device__ unsigned long long g_wave_trace[8192 * 16];
-extern "C" int dv_debug_wave_trace(unsigned long long* host, int n_wg) {
-  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_wave_trace), (size_t)n_wg * 16 * sizeof(unsigned long long));
-}
 extern "C" int dv_debug_gemm_trace_clear() {
   void* d = nullptr;
   hipError_t e = hipGetSymbolAddress(&d, HIP_SYMBOL(g_gemm_trace));
@@ -62,19 +58,20 @@ __device__ __forceinline__ float gelu_erf(float v) {
 // stores and takes a ticket from the tile's agent-scope counter; the first to arrive leaves, the second adds the
 // partner's dump (system-scope loads, after the atomic) and runs the epilogue.  No workgroup ever waits for another.
 // Measured: worth ~25 % on the K >= 1536 GEMMs of the 128-frame level, ~1 % of a forward.
-// AF ("A fused"): the A operand is not DMA'd from split planes but PRODUCED in the workgroup: NWQ extra producer waves
-// load the fp32 rows of a 64-channel chunk (BM + 2 frames: the k = 3 halo), apply GroupNorm (+ temb scale/shift) (+ SiLU)
-// and the hi/lo split, and write one LDS slab per chunk (double-buffered); the MFMA waves read the taps as shifted row
-// windows of that slab, so a k = 3 conv reads its input ONCE (fp32) instead of three times (planes), and the separate
-// GroupNorm-apply launch disappears.  Producer waves use ordinary loads (their own vmcnt), the MFMA waves keep the
-// hand-counted LDS-DMA ring for the weights; both meet at the one s_barrier per k-tile.  The k-tile order is
-// chunk-major (segment -> concat half -> 64-channel chunk -> tap); tiles never span utterances (T_out % BM == 0).
+// AF ("A fused"): the A operand is not DMA'd from split planes written by a GroupNorm-apply launch but PRODUCED in the
+// workgroup from the producer's fp32 rows: GroupNorm (+ temb scale/shift) (+ SiLU) and the hi/lo split happen once per
+// PHASE - up to AF_CH 64-channel chunks of BM + 2 frames (the k = 3 halo) converted by ALL waves into an LDS slab that
+// stays resident while the k-loop multiplies its (chunk, tap) tiles, streaming only the weights through the DMA ring.
+// The taps of a k = 3 conv read shifted row windows of the slab, so the conv reads its input once (fp32) instead of three
+// times (planes).  [A first version with dedicated producer waves converting one chunk ahead of the MFMA waves was
+// correct but measured ~1800 cycles per k-tile against 960 for the plain kernel: sixteen waves meeting at every k-tile
+// barrier with the VALU pipe of each SIMD shared between them - DESIGN.md.]  The k-tile order is chunk-major (segment ->
+// concat half -> 64-channel chunk -> tap); tiles never span utterances (T_out % BM == 0).
 template <int BM, int BN, int BK, int WM, int WN, int NSPLIT, int KS, bool SC1, bool AF = false>
 __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int m0, const int n0, char* smem, const int ksel = 0) {
   constexpr int FM = BM / (WM * 32), FN = BN / (WN * 32);
   constexpr int NWQ = WM * WN;                       // waves per k-group (1, 2 or 4)
-  constexpr int NWV = NWQ * KS;                      // MFMA waves per workgroup (AF: + NWP producer waves)
-  constexpr int NWP = AF ? 2 * NWQ : 0;              // producer waves: two per SIMD at NWQ = 4 (a lone wave issues ~1 instruction / 4 cycles)
+  constexpr int NWV = NWQ * KS;                      // waves per workgroup
   static_assert(!AF || (BK == 64 && !SC1), "AF tiles: 64-deep k-tiles, per-launch kernel");
   constexpr bool SPLIT = NSPLIT == 3;
   constexpr int NPL = SPLIT ? 2 : 1;                 // planes per operand
@@ -83,12 +80,14 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int m0, con
   constexpr int RPI = 64 / CPR;                      // rows per wave-instruction
   constexpr int A_PL = AF ? 0 : BM * ROWB, B_PL = BN * ROWB;  // bytes per plane tile in the ring (AF: weights only)
   constexpr int STAGE = (A_PL + B_PL) * NPL;
-  constexpr int SLAB_PL = (BM + 2) * ROWB, SLAB = SLAB_PL * NPL;   // AF: one chunk's normalised rows incl. halo
+  constexpr int AF_CH = BM == 64 ? 5 : 11;           // AF: chunks per phase (slab = AF_CH x (BM+2) rows x 128 B per plane)
+  constexpr int CH_PL = (BM + 2) * ROWB;             // AF: one chunk of one plane
+  constexpr int SLAB_PL = AF_CH * CH_PL, SLAB = SLAB_PL * NPL;
 #ifndef DV_NSTAGE_64
 #define DV_NSTAGE_64 4
 #endif
   // LDS ring depth: NSTAGE-1 tiles in flight (DV_NSTAGE_64: experiment knob for the 64x64 tiles' occupancy)
-  constexpr int NSTAGE = AF ? 4 : ((BM == 64 && BN == 64 && !SC1) ? DV_NSTAGE_64 : ((4 * STAGE <= 160 * 1024) ? 4 : 3));
+  constexpr int NSTAGE = AF ? 3 : ((BM == 64 && BN == 64 && !SC1) ? DV_NSTAGE_64 : ((4 * STAGE <= 160 * 1024) ? 4 : 3));
   constexpr int A_IPW = AF ? 0 : BM / RPI / NWV, B_IPW = BN / RPI / NWV;   // DMA instructions per wave per plane
   constexpr int A_IPW1 = A_IPW ? A_IPW : 1;          // (array extents)
   constexpr int LPT = (A_IPW + B_IPW) * NPL;         // DMA instructions per thread per k-tile
@@ -303,11 +302,11 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int m0, con
   constexpr int NTERM = SPLIT ? 3 : 1;
   constexpr int NCH = NKS * NTERM;                   // MFMA groups per k-tile
   AfIt af_cs = af0;              // AF: tile being multiplied
-  int af_par = 0;                // AF: slab (chunk parity) it reads
+  int af_ci = 0;                 // AF: its chunk's index inside the resident phase
   auto step = [&](int kt, auto issue_tag) {
     constexpr bool ISSUE = decltype(issue_tag)::value;
     const char* base = smem + (kt % NSTAGE) * STAGE;
-    const char* a_hi = AF ? smem + NSTAGE * STAGE + af_par * SLAB : base;
+    const char* a_hi = AF ? smem + NSTAGE * STAGE + af_ci * CH_PL : base;
     const char* a_lo = AF ? a_hi + SLAB_PL : base + A_PL;
     const char* b_hi = base + NPL * A_PL;
     const char* b_lo = b_hi + B_PL;
@@ -357,7 +356,7 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int m0, con
       }
     }
     if (ISSUE) { if (AF) af_next(af_is); else advance(); }
-    if (AF) { af_next(af_cs); if (af_cs.tap == 0) af_par ^= 1; }
+    if (AF) { af_next(af_cs); if (af_cs.tap == 0) ++af_ci; }
   };
 
   // accumulator fragment (i, j), lane (l31, lh), register r = 4*g + e  holds
@@ -394,7 +393,7 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int m0, con
   // residual operand of small tiles: fetched before the k-loop so its latency hides under it
   constexpr bool PRE_RES = FM * FN <= 2;
   float rpre[PRE_RES ? FM * FN * 16 : 1];
-  if (PRE_RES && p.epi == EPI_RESIDUAL && p.sk_mode != 1 && !(AF && kgrp >= KS)) {   // (mode 3: half of the workgroups prefetch in vain)
+  if (PRE_RES && p.epi == EPI_RESIDUAL && p.sk_mode != 1) {   // (mode 3: half of the workgroups prefetch in vain)
 #pragma unroll
     for (int i = 0; i < FM; ++i) {
       const size_t ro = (size_t)min(m0 + (wm * FM + i) * 32 + l31, p.M - 1) * p.ldres;
@@ -440,63 +439,122 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int m0, con
     glds4((const void*)(p.ln_u + n), (unsigned)(size_t)s_u + wave * 256);
   }
 
-  // ---- AF: the producer waves' whole life (table, slabs, one barrier per k-tile), then they leave ----
-  if constexpr (AF) {
-    __shared__ __attribute__((aligned(16))) float s_gscale[1024], s_gshift[1024];
-    if (kgrp >= KS) {                                // waves past the KS k-groups of MFMA waves
-      constexpr int NP = 64 * NWP;                   // producer threads
-      const int ptid = tid - 64 * NWV, pw = wave - NWV;
-#ifndef DV_AF_PRODUCER_PRIO
-#define DV_AF_PRODUCER_PRIO 3
-#endif
-      // the producer shares its SIMD with two MFMA waves and is the youngest wave there: without priority it gets the
-      // leftover issue slots and arrives last at every k-tile barrier
-      __builtin_amdgcn_s_setprio(DV_AF_PRODUCER_PRIO);
-      const int T = p.T_out, b_item = m0 / T, t0 = m0 - b_item * T;
-      // tasks of a chunk = (slab row, 4-channel group): rounds 0 and 1 cover the BM tile rows (BM * 16 = 2 NP tasks),
-      // round 2 the two halo rows (32 tasks, first producer wave).  A thread keeps its 4-channel group over all rounds
-      // (NP % 16 == 0), so the chunk's scale / shift for those channels are read from the table once per chunk.
-      static_assert(BM * 16 == 2 * NP, "two task rounds cover the tile rows");
-      float4 rv[3];
-      bool rok[3];
-      const int c4 = ptid & 15;
-      auto task_row = [&](int j) { return j < 2 ? ((j * NP + ptid) >> 4) + 1 : (ptid < 16 ? 0 : BM + 1); };
-      // Loads are UNCONDITIONAL (clamped row; zeroed at conversion): a per-element "load or zero" select makes hipcc
-      // branch around each load and wait for it.  The halo tasks exist in the first producer wave only (wave-uniform).
-      auto load_round = [&](const AfIt& c, int j) {
-        if (j == 2 && (pw != 0 || c.taps != 3)) { rok[2] = false; return; }
-        const AfSrc& a = p.afp.src[c.seg][c.half];
-        const int t = t0 - 1 + task_row(j);
-        rok[j] = t >= 0 && t < T && (j < 2 || ptid < 32);
-        rv[j] = *reinterpret_cast<const float4*>(a.x + ((size_t)b_item * T + min(max(t, 0), T - 1)) * a.C + c.col + c4 * 4);
-      };
+  // ---- AF: GroupNorm table of this utterance, and the phase converter (all waves) ----
+  constexpr int NT_ALL = 64 * NWV;
+  __shared__ __attribute__((aligned(16))) float s_gscale[AF ? 1024 : 4], s_gshift[AF ? 1024 : 4];
+  const int af_T = p.T_out, af_b = AF ? m0 / p.T_out : 0, af_t0 = AF ? m0 - af_b * p.T_out : 0;
+  auto af_table = [&]() {
+    // scale[c] = rstd*gamma*(1+ts), shift[c] = (beta - mean*rstd*gamma)*(1+ts) + tb over segment 0's concat channels.
+    // Latency matters (the first multiply waits for it): the per-channel parameters are fetched first (independent of
+    // the statistics); the utterance's block entries (sum, M2 about the block mean) are fetched by all threads at once
+    // into the last ring stage (the weight prologue fills stages 0 .. NSTAGE-2 only); every wave then reduces ALL groups
+    // from there (64 / G lanes per group, one pass in fp64) and the channel owner picks its group's (mean, rstd).
+    const int G = p.afp.groups, c0s = p.seg[0].c0, ctot = c0s + p.seg[0].c1, cg = ctot / G, nvb = cg >> 4, RB = af_T >> 5;
+    constexpr int CPT = (1024 + NT_ALL - 1) / NT_ALL;
+    float pg[CPT], pb[CPT], pts[CPT], ptb[CPT];
+#pragma unroll
+    for (int k = 0; k < CPT; ++k) {
+      const int cc = min(tid + k * NT_ALL, ctot - 1);
+      pg[k] = p.afp.gamma[cc];
+      pb[k] = p.afp.beta[cc];
+      pts[k] = p.afp.tscale ? p.afp.tscale[(size_t)af_b * p.afp.ld_t + cc] : 0.0f;
+      ptb[k] = p.afp.tshift ? p.afp.tshift[(size_t)af_b * p.afp.ld_t + cc] : 0.0f;
+    }
+    const int nblk = ctot >> 4, n_ent = RB * nblk;
+    float2* s_ent = reinterpret_cast<float2*>(smem + (NSTAGE - 1) * STAGE);
+    for (int e0 = 0; e0 < n_ent; e0 += 2 * NT_ALL) {
+      float2 ev[2];
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        const int e = min(e0 + k * NT_ALL + tid, n_ent - 1);
+        const int rb = e / nblk, vb = e - rb * nblk;
+        const int half = vb * 16 >= c0s;
+        const AfSrc& a = p.afp.src[0][half];
+        const int vbl = half ? vb - (c0s >> 4) : vb;
+        ev[k] = reinterpret_cast<const float2*>(a.stat16)[(size_t)(af_b * RB + rb) * (a.C >> 4) + vbl];
+      }
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        const int e = e0 + k * NT_ALL + tid;
+        if (e < n_ent) s_ent[e] = ev[k];
+      }
+    }
+    __syncthreads();
+    const int lpg = 64 / G;                          // lanes per group (G a power of two <= 64)
+    const int g = lane / lpg, sub = lane - g * lpg;
+    // M2_b + sum_b^2 / 512 = the block's sum of squares; accumulated in fp64 (the one fp64 subtraction below is harmless)
+    double s1 = 0, q = 0;
+    for (int i0 = sub; i0 < RB * nvb; i0 += 4 * lpg) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int i = i0 + k * lpg;
+        const int rb = i / nvb;
+        const float2 v = s_ent[min(rb * nblk + g * nvb + (i - rb * nvb), n_ent - 1)];
+        if (i < RB * nvb) {
+          s1 += (double)v.x;
+          q += (double)v.y + (double)v.x * (double)v.x * (1.0 / 512.0);
+        }
+      }
+    }
+    for (int o = lpg >> 1; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o); q += __shfl_xor(q, o); }
+    const double n = (double)cg * (double)af_T;
+    const double mean_d = s1 / n;
+    double var = q / n - mean_d * mean_d;
+    var = var > 0 ? var : 0;
+    const float mean = (float)mean_d, rstd = 1.0f / sqrtf((float)var + p.afp.eps);
+#pragma unroll
+    for (int k = 0; k < CPT; ++k) {
+      const int cc = tid + k * NT_ALL;
+      const int src_lane = min(cc, ctot - 1) / cg * lpg;
+      const float gm = __shfl(mean, src_lane), gr = __shfl(rstd, src_lane);
+      if (cc < ctot) {
+        const float a = gr * pg[k];
+        const float ts = 1.0f + pts[k];
+        s_gscale[cc] = a * ts;
+        s_gshift[cc] = fmaf(pb[k] - gm * a, ts, ptb[k]);
+      }
+    }
+    __syncthreads();
+  };
+  // Convert the chunks [c, c + n) of the k-range (c at tap 0) into the slab: task = (slab row, 4-channel group); a
+  // thread keeps its 4-channel group (NT_ALL % 16 == 0).  Loads are unconditional (clamped row, zeroed afterwards): a
+  // per-element "load or zero" select makes hipcc branch around each load and wait for it.
+  auto af_convert = [&](AfIt c, int n) {
+    constexpr int TASKS = (BM + 2) * 16, RNDS = (TASKS + NT_ALL - 1) / NT_ALL;
+    const int c4 = tid & 15;
+    for (int ci = 0; ci < n; ++ci) {
+      const AfSrc& a = p.afp.src[c.seg][c.half];
+      const int mode = c.seg == 0 ? p.afp.mode0 : 0;
+      const float* base = a.x + (size_t)af_b * af_T * a.C + c.col + c4 * 4;
+      const int ldc = a.C;
+      float4 rv[RNDS];
+#pragma unroll
+      for (int j = 0; j < RNDS; ++j) {
+        const int srow = min((j * NT_ALL + tid) >> 4, BM + 1);
+        const int t = af_t0 - 1 + srow;
+        rv[j] = *reinterpret_cast<const float4*>(base + (size_t)min(max(t, 0), af_T - 1) * ldc);
+      }
       float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
-      int cv_mode = 0;
-      auto conv_begin = [&](const AfIt& c) {         // per-chunk: mode and this thread's table entries
-        cv_mode = c.seg == 0 ? p.afp.mode0 : 0;
-        if (cv_mode) {
-          const int tab = (c.half ? c.c0 : 0) + c.col + c4 * 4;
-          sc = *reinterpret_cast<const float4*>(s_gscale + tab);
-          sh = *reinterpret_cast<const float4*>(s_gshift + tab);
-        }
-      };
-      auto convert_round = [&](int par, int j) {
-        if (j == 2 && (pw != 0 || ptid >= 32)) return;
-        char* sl = smem + NSTAGE * STAGE + par * SLAB;
-        const int srow = task_row(j);
+      if (mode) {
+        const int tab = (c.half ? c.c0 : 0) + c.col + c4 * 4;
+        sc = *reinterpret_cast<const float4*>(s_gscale + tab);
+        sh = *reinterpret_cast<const float4*>(s_gshift + tab);
+      }
+      char* sl = smem + NSTAGE * STAGE + ci * CH_PL;
+#pragma unroll
+      for (int j = 0; j < RNDS; ++j) {
+        const int id = j * NT_ALL + tid;
+        if (id >= TASKS) continue;
+        const int srow = id >> 4;
+        const int t = af_t0 - 1 + srow;
         float v[4] = {rv[j].x, rv[j].y, rv[j].z, rv[j].w};
-        if (cv_mode) {
-          const float scv[4] = {sc.x, sc.y, sc.z, sc.w}, shv[4] = {sh.x, sh.y, sh.z, sh.w};
+        const float scv[4] = {sc.x, sc.y, sc.z, sc.w}, shv[4] = {sh.x, sh.y, sh.z, sh.w};
 #pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            v[e] = fmaf(v[e], scv[e], shv[e]);
-            if (cv_mode == 2) v[e] = v[e] * __builtin_amdgcn_rcpf(1.0f + __expf(-v[e]));   // SiLU
-          }
-        }
-        // conv zero padding pads the NORMALISED tensor: frames outside the utterance are zeros, not norm(0)
-        if (!rok[j]) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = 0.f;
+        for (int e = 0; e < 4; ++e) {
+          v[e] = fmaf(v[e], scv[e], shv[e]);
+          if (mode == 2) v[e] = v[e] * __builtin_amdgcn_rcpf(1.0f + __expf(-v[e]));   // SiLU
+          // conv zero padding pads the NORMALISED tensor: frames outside the utterance are zeros, not norm(0)
+          if (t < 0 || t >= af_T) v[e] = 0.f;
         }
         uint2 hw, lw;
         hw.x = cvt_pk_bf16(v[0], v[1]); hw.y = cvt_pk_bf16(v[2], v[3]);
@@ -505,166 +563,21 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int m0, con
         const int off = srow * ROWB + (((c4 >> 1) ^ swz(srow)) << 4) + (c4 & 1) * 8;
         *reinterpret_cast<uint2*>(sl + off) = hw;
         if (SPLIT) *reinterpret_cast<uint2*>(sl + SLAB_PL + off) = lw;
-      };
-      AfIt nx = af0;                                 // chunk whose raw rows are in registers (next to be converted)
-      int left = nk;                                 // tiles of the range from nx's chunk on
-      auto chunk_after = [&](AfIt c) { c.tap = c.taps - 1; af_next(c); return c; };
-#pragma unroll
-      for (int j = 0; j < 3; ++j) load_round(nx, j); // first chunk's rows: in flight under the table build
-      DV_TRACE_P(12, 64 * NWV);
-      // GroupNorm table of segment 0 (this utterance): scale[c] = rstd*gamma*(1+ts), shift[c] = (beta - mean*rstd*gamma)*(1+ts) + tb.
-      // Latency is what matters here (every workgroup waits for its first slab): the per-channel parameters are
-      // fetched first (they do not depend on the statistics), every producer wave reduces ALL groups itself (64 / G
-      // lanes per group, entries of a group strided over them, one pass in fp64: no cross-wave step), and the channel
-      // owner picks its group's (mean, rstd) from the lane that holds them.
-      if (p.afp.mode0) {
-        const int G = p.afp.groups, c0s = p.seg[0].c0, ctot = c0s + p.seg[0].c1, cg = ctot / G, nvb = cg >> 4, RB = T >> 5;
-        constexpr int CPT = 1024 / NP;               // channels per producer thread (ctot <= 1024)
-        float pg[CPT], pb[CPT], pts[CPT], ptb[CPT];
-#pragma unroll
-        for (int k = 0; k < CPT; ++k) {
-          const int cc = min(ptid + k * NP, ctot - 1);
-          pg[k] = p.afp.gamma[cc];
-          pb[k] = p.afp.beta[cc];
-          pts[k] = p.afp.tscale ? p.afp.tscale[(size_t)b_item * p.afp.ld_t + cc] : 0.0f;
-          ptb[k] = p.afp.tshift ? p.afp.tshift[(size_t)b_item * p.afp.ld_t + cc] : 0.0f;
-        }
-        // block entries (sum, M2 about the block mean) of this utterance: fetched by all producer threads at once (one
-        // round trip: at most a few independent loads each) into the last ring stage - the weight prologue fills stages
-        // 0 .. NSTAGE-2, the last one is first written after the first k-tile barrier - then every producer wave
-        // reduces all groups from there (n_ent <= STAGE / 8, checked by the launcher)
-        const int nblk = ctot >> 4, n_ent = RB * nblk;
-        float2* s_ent = reinterpret_cast<float2*>(smem + (NSTAGE - 1) * STAGE);
-        for (int e0 = 0; e0 < n_ent; e0 += 4 * NP) {
-          float2 ev[4];
-#pragma unroll
-          for (int k = 0; k < 4; ++k) {
-            const int e = min(e0 + k * NP + ptid, n_ent - 1);
-            const int rb = e / nblk, vb = e - rb * nblk;
-            const int half = vb * 16 >= c0s;
-            const AfSrc& a = p.afp.src[0][half];
-            const int vbl = half ? vb - (c0s >> 4) : vb;
-            ev[k] = reinterpret_cast<const float2*>(a.stat16)[(size_t)(b_item * RB + rb) * (a.C >> 4) + vbl];
-          }
-#pragma unroll
-          for (int k = 0; k < 4; ++k) {
-            const int e = e0 + k * NP + ptid;
-            if (e < n_ent) s_ent[e] = ev[k];
-          }
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();                // (#T0) entries staged (the MFMA waves join it before their loop)
-        const int lpg = 64 / G;                      // lanes per group (G a power of two <= 64)
-        const int g = lane / lpg, sub = lane - g * lpg;
-        // M2_b + sum_b^2 / 512 = the block's sum of squares; accumulated in fp64 (the single fp64 subtraction below is harmless)
-        double s1 = 0, q = 0;
-        for (int i0 = sub; i0 < RB * nvb; i0 += 4 * lpg) {
-#pragma unroll
-          for (int k = 0; k < 4; ++k) {
-            const int i = i0 + k * lpg;
-            const int rb = i / nvb;
-            const float2 v = s_ent[min(rb * nblk + g * nvb + (i - rb * nvb), n_ent - 1)];
-            if (i < RB * nvb) {
-              s1 += (double)v.x;
-              q += (double)v.y + (double)v.x * (double)v.x * (1.0 / 512.0);
-            }
-          }
-        }
-        for (int o = lpg >> 1; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o); q += __shfl_xor(q, o); }
-        const double n = (double)cg * (double)T;
-        const double mean_d = s1 / n;
-        double var = q / n - mean_d * mean_d;
-        var = var > 0 ? var : 0;
-        const float mean = (float)mean_d, rstd = 1.0f / sqrtf((float)var + p.afp.eps);
-#pragma unroll
-        for (int k = 0; k < CPT; ++k) {
-          const int cc = ptid + k * NP;
-          const int src_lane = min(cc, ctot - 1) / cg * lpg;
-          const float gm = __shfl(mean, src_lane), gr = __shfl(rstd, src_lane);
-          if (cc < ctot) {
-            const float a = gr * pg[k];
-            const float ts = 1.0f + pts[k];
-            s_gscale[cc] = a * ts;
-            s_gshift[cc] = fmaf(pb[k] - gm * a, ts, ptb[k]);
-          }
-        }
       }
-      else __builtin_amdgcn_s_barrier();             // (#T0) nothing to stage
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      DV_TRACE_P(13, 64 * NWV);
-      __builtin_amdgcn_s_barrier();                  // (#T) table complete (the MFMA waves join it before their loop)
-      DV_TRACE_P(14, 64 * NWV);
-      // chunk 0 -> slab 0, and the rows of chunk 1 into the registers
-      conv_begin(nx);
-      {
-        const AfIt n1 = chunk_after(nx);
-        const bool more = left - nx.taps > 0;
-#pragma unroll
-        for (int j = 0; j < 3; ++j) { convert_round(0, j); if (more) load_round(n1, j); }
-        left -= nx.taps;
-        nx = n1;
-      }
-      DV_TRACE_P(15, 64 * NWV);
-      // Steady state: while the MFMA waves multiply chunk c (slab par), chunk c+1 (in registers) is converted into the
-      // other slab and the rows of chunk c+2 are fetched - one task round per k-tile of a three-tap chunk (the work of
-      // a chunk is spread over its tiles: a producer wave must not be the last at the barrier), all rounds at once in
-      // a one-tap chunk.
-      AfIt cs = af0;                                 // tile the MFMA waves multiply at loop index kt
-      AfIt n2 = nx;                                  // chunk after nx (valid while `more2`)
-      bool more1 = false, more2 = false;
-      int par = 0;
-#ifdef DV_GEMM_TRACING
-      unsigned long long tr_pbar = 0, tr_pwork = 0;
-#endif
-      for (int kt = 0; kt < nk; ++kt) {
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's slab writes have landed
-#ifdef DV_GEMM_TRACING
-        const unsigned long long trp0 = __builtin_amdgcn_s_memtime();
-#endif
-        __builtin_amdgcn_s_barrier();
-#ifdef DV_GEMM_TRACING
-        tr_pbar += __builtin_amdgcn_s_memtime() - trp0;
-        if (kt == nk - 1 && (int)threadIdx.x == 64 * NWV && blockIdx.x < 8192) g_gemm_trace[blockIdx.x * 16 + 11] = tr_pbar;
-#endif
-        if (cs.tap == 0) {                           // a chunk starts: its slab is read now, the other one is free
-          more1 = left > 0;                          // nx exists
-          more2 = left - nx.taps > 0;                // and so does the chunk after it
-          if (more1) { conv_begin(nx); n2 = chunk_after(nx); }
-        }
-#ifdef DV_GEMM_TRACING
-        // development knobs (trace build): p.af bit 1 = producers skip the slab work in the k-loop, bit 2 = skip only the loads
-        if (p.af & 2) more1 = false;
-        if (p.af & 4) more2 = false;
-#endif
-#ifdef DV_GEMM_TRACING
-        const unsigned long long trq0 = __builtin_amdgcn_s_memtime();
-#endif
-        if (more1) {
-          if (cs.taps == 1) {
-#pragma unroll
-            for (int j = 0; j < 3; ++j) { convert_round(par ^ 1, j); if (more2) load_round(n2, j); }
-          } else {
-            const int j = cs.tap;
-            if (j == 0) { convert_round(par ^ 1, 0); if (more2) load_round(n2, 0); }
-            else if (j == 1) { convert_round(par ^ 1, 1); if (more2) load_round(n2, 1); }
-            else { convert_round(par ^ 1, 2); if (more2) load_round(n2, 2); }
-          }
-        }
-#ifdef DV_GEMM_TRACING
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        tr_pwork += __builtin_amdgcn_s_memtime() - trq0;
-        if (kt == nk - 1 && (int)threadIdx.x == 64 * NWV + 64 && blockIdx.x < 8192) g_gemm_trace[blockIdx.x * 16 + 12] = tr_pwork;
-        if (kt == nk - 1 && lane == 0 && blockIdx.x < 8192) g_wave_trace[blockIdx.x * 16 + wave] = tr_pwork;
-#endif
-        af_next(cs);
-        if (cs.tap == 0) {                           // chunk finished
-          par ^= 1;
-          if (more1) { left -= nx.taps; nx = n2; }
-        }
-      }
-      return;
+      c.tap = c.taps - 1;
+      af_next(c);
     }
-  }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // slab writes landed before this wave reaches the k-tile barrier
+  };
+  // chunks / tiles of the next phase starting at chunk state c with `left` tiles of the range remaining
+  auto af_phase = [&](AfIt c, int left, int& n_chunks, int& n_tiles) {
+    n_chunks = 0; n_tiles = 0;
+    while (n_chunks < AF_CH && n_tiles < left) {
+      n_tiles += c.taps; ++n_chunks;
+      c.tap = c.taps - 1;
+      af_next(c);
+    }
+  };
 
   // ---- main loop: wait(tile kt) -> barrier -> multiply tile kt with the DMA of tile kt+NSTAGE-1 interleaved ----
   // NSTAGE-1 tiles are in flight; the counted vmcnt leaves the younger ones outstanding across the barrier
@@ -677,7 +590,23 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int m0, con
 #endif
   }
   DV_TRACE(1);
-  if (AF) { __builtin_amdgcn_s_barrier(); __builtin_amdgcn_s_barrier(); }   // (#T0, #T) pair with the producer waves' table barriers
+  AfIt af_pc = af0;              // AF: first chunk of the phase being multiplied
+  int af_ph_tiles = 0, af_ph_chunks = 0, af_left = nk;
+  if (AF) {
+    if (p.afp.mode0) af_table();
+    af_phase(af_pc, af_left, af_ph_chunks, af_ph_tiles);
+    af_convert(af_pc, af_ph_chunks);                 // (visible after the first k-tile barrier)
+  }
+  // AF: a phase ends -> every wave has finished reading the slab (barrier), convert the next phase, go on
+  auto af_boundary = [&]() {
+    if (AF && af_ph_tiles == 0 && af_left > 0) {
+      __syncthreads();
+      for (int c = 0; c < af_ph_chunks; ++c) { af_pc.tap = af_pc.taps - 1; af_next(af_pc); }
+      af_phase(af_pc, af_left, af_ph_chunks, af_ph_tiles);
+      af_convert(af_pc, af_ph_chunks);
+      af_ci = 0;
+    }
+  };
   // steady state: tile kt+NSTAGE-1 is issued while tile kt is multiplied; NSTAGE-2 younger tiles stay in flight
   const int n_steady = nk - (NSTAGE - 1);
   int kt = 0;
@@ -685,6 +614,7 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int m0, con
   unsigned long long tr_vm = 0, tr_bar = 0, tr_step = 0;
 #endif
   for (; kt < n_steady; ++kt) {
+    af_boundary();
 #ifdef DV_GEMM_TRACING
     const unsigned long long tr0 = __builtin_amdgcn_s_memtime();
 #endif
@@ -698,17 +628,18 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int m0, con
     if (kt == 0) DV_TRACE(2);
 #endif
     step(kt, std::true_type{});                      // DMA overwrites the stage tile kt-1 was read from
+    --af_ph_tiles; --af_left;
 #ifdef DV_GEMM_TRACING
     tr_vm += tr1 - tr0; tr_bar += tr2 - tr1; tr_step += __builtin_amdgcn_s_memtime() - tr2;
 #endif
   }
 #ifdef DV_GEMM_TRACING
-  if (AF && lane == 0 && blockIdx.x < 8192) g_wave_trace[blockIdx.x * 16 + wave] = tr_vm + tr_step;
   if (AF && threadIdx.x == 0 && blockIdx.x < 8192) {   // AF: the prologue-split slots carry the steady loop's wait sums
     g_gemm_trace[blockIdx.x * 16 + 8] = tr_vm; g_gemm_trace[blockIdx.x * 16 + 9] = tr_bar; g_gemm_trace[blockIdx.x * 16 + 10] = tr_step;
   }
 #endif
   for (; kt < nk; ++kt) {                            // drain: nothing left to issue
+    af_boundary();
     const int younger = min(NSTAGE - 2, nk - 1 - kt);
     if (younger >= 2) wait_vmcnt<2 * LPT>();
     else if (younger == 1) wait_vmcnt<LPT>();
@@ -718,6 +649,7 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int m0, con
     if (kt == 0) DV_TRACE(2);
 #endif
     step(kt, std::false_type{});
+    --af_ph_tiles; --af_left;
   }
 
   if (NACC > 1) {

@@ -27,7 +27,7 @@
 #include <type_traits>
 
 template <int BM, int BN, int BK, int WM, int WN, int NSPLIT, int KS, bool AF = false>
-__global__ __launch_bounds__(64 * WM * WN * (KS + (AF ? 2 : 0))) void k_gemm(const GemmParams p) {
+__global__ __launch_bounds__(64 * WM * WN * KS) void k_gemm(const GemmParams p) {
   extern __shared__ __attribute__((aligned(1024))) char smem[];
   // XCD-aware tile order: consecutive tile ids (same A rows, neighbouring N) share an L2.
   const int n_tiles_n = (p.N + BN - 1) / BN;
@@ -62,19 +62,20 @@ struct GemmCfg {
   }
 };
 
-// AF tiles (A operand produced in-kernel, gemm_tile.h): WM*WN MFMA waves + as many producer waves, 64-deep k-tiles,
-// ring of 4 weight stages + two slabs of BM + 2 normalised rows
+// AF tiles (A operand produced in-kernel, gemm_tile.h): 64-deep k-tiles, ring of 3 weight stages + a resident slab of
+// AF_CH chunks x (BM + 2) normalised rows
 template <int BM, int BN, int WM, int WN, int KS, int NSPLIT>
 struct GemmCfgAF {
   static constexpr int NPL = NSPLIT == 3 ? 2 : 1;
-  static constexpr int SMEM = 4 * BN * 128 * NPL + 2 * (BM + 2) * 128 * NPL;
+  static constexpr int AF_CH = BM == 64 ? 5 : 11;
+  static constexpr int SMEM = 3 * BN * 128 * NPL + AF_CH * (BM + 2) * 128 * NPL;
   static hipError_t init() {
     return hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm<BM, BN, 64, WM, WN, NSPLIT, KS, true>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
   }
   static hipError_t launch(const GemmParams& p, hipStream_t st) {
     const int tiles = (p.M / BM) * ((p.N + BN - 1) / BN) * (p.sk_mode == 3 ? p.sk_split : 1);
-    hipLaunchKernelGGL((k_gemm<BM, BN, 64, WM, WN, NSPLIT, KS, true>), dim3(tiles), dim3(64 * WM * WN * (KS + 2)), SMEM, st, p);
+    hipLaunchKernelGGL((k_gemm<BM, BN, 64, WM, WN, NSPLIT, KS, true>), dim3(tiles), dim3(64 * WM * WN * KS), SMEM, st, p);
     return hipGetLastError();
   }
 };
@@ -88,8 +89,7 @@ struct GemmTileAF {
     return x3 ? GemmCfgAF<BM, BN, WM, WN, KS, 3>::launch(p, st) : GemmCfgAF<BM, BN, WM, WN, KS, 1>::launch(p, st);
   }
 };
-// 64x64: two k-groups of four MFMA waves (two per SIMD: one's LDS reads overlap the other's MFMAs) + eight producer waves
-// (1024 threads, <= 128 VGPRs); 32x64 (T_out % 64 != 0): two k-groups of two MFMA waves + four producer waves
+// 64x64: two k-groups of four waves (two per SIMD); 32x64: two k-groups of two waves
 using AF64 = GemmTileAF<64, 64, 2, 2, 2>;
 using AF32 = GemmTileAF<32, 64, 1, 2, 2>;
 
@@ -248,7 +248,8 @@ hipError_t launch_gemm(const GemmParams& pin, int precision, hipStream_t st) {
     if (p.sk_buf && p.sk_split == 2 && p.sk_ticket) p.sk_mode = 3;
     else { p.sk_buf = nullptr; p.sk_split = 0; p.sk_mode = 0; p.sk_ticket = nullptr; }
     for (int s = 0; s < p.nseg; ++s) p.seg[s].nkt = p.seg[s].taps * (p.seg[s].c0 + p.seg[s].c1) / 64;
-    const int ft = p.force_tile & 0xff;
+    static const int env_tile = [] { const char* e = getenv("DVITS_AF_TILE"); return e ? atoi(e) : 0; }();   // experiment knob: 32 / 64
+    const int ft = (p.force_tile & 0xff) ? (p.force_tile & 0xff) : (env_tile == 32 ? GT_AF32 : 0);
     const bool t64 = p.T_out % 64 == 0;
     if (ft == GT_AF64 && !t64) return hipErrorInvalidValue;
     const bool use64 = ft == GT_AF64 || (ft != GT_AF32 && t64);

@@ -74,18 +74,8 @@ for spec in shapes + [("af",) + a for a in af_shapes]:
         print("   prologue split (median cyc): kernarg-ready %d | row geometry %d | bias/residual/LN setup %d | issue tile 0 %d | "
               "issue tiles 1.. %d" % tuple(np.median(pro, 0)))
     if spec[0] == "af":
-        wb = np.zeros((NWG, 16), dtype=np.uint64)
-        lib.dv_debug_wave_trace.restype = C.c_int
-        lib.dv_debug_wave_trace.argtypes = [C.c_void_p, C.c_int]
-        assert lib.dv_debug_wave_trace(wb.ctypes.data_as(C.c_void_p), NWG) == 0
-        print("   per-wave busy cycles between barriers, summed over the loop (median over workgroups; waves 0-7 multiply, 8-15 produce): %s"
-              % np.median(wb.astype(np.int64)[live], 0).astype(int).tolist())
-        print("   steady k-loop sums (median cyc): MFMA wave 0 waits for its DMA %d | waits at the barrier %d | multiplies %d ;  "
-              "producer wave 0 waits at the barrier %d ; producer wave 1 works (incl. landing of its slab writes) %d"
-              % tuple(np.median(t[:, 8:13], 0)))
-        pp = np.stack([t[:, 12] - t[:, 0], t[:, 13] - t[:, 12], t[:, 14] - t[:, 13], t[:, 15] - t[:, 14], t[:, 2] - t[:, 15]], 1)
-        print("   producer wave (median cyc): start -> first rows requested %d | statistics + table %d | wait at table barrier %d | "
-              "chunk 0 converted, chunk 1 requested %d | -> first k-tile barrier released %d" % tuple(np.median(pp, 0)))
+        print("   steady k-loop sums (median cyc): wave 0 waits for its DMA %d | waits at the barrier %d | multiplies %d"
+              % tuple(np.median(t[:, 8:11], 0)))
     ph = np.stack([t[:, 1] - t[:, 0], t[:, 2] - t[:, 1], t[:, 3] - t[:, 2], t[:, 4] - t[:, 3], t[:, 5] - t[:, 4],
                    t[:, 5] - t[:, 0]], 1)
     wall = t[:, 7]
