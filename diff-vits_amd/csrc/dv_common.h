@@ -101,6 +101,38 @@ inline size_t gemm_splitk_bytes(int M, int N, int split) {
   return (size_t)split * ((M + 127) / 128 * 128) * ((N + 127) / 128 * 128) * sizeof(float);
 }
 
+// ---------------------------------------------------------------------------------------
+// Row-block chain (kernels_chain.hip): two dependent K = C contractions of a transformer block in ONE launch.  A
+// workgroup owns 32 frames and ALL their channels, so everything between the two GEMMs (bias, residual, LayerNorm) is
+// row-local and the intermediate never leaves LDS; only the weights stream (LDS-DMA ring).
+//   stage 1:  x1 = A W1^T + b1 (+ res)          -> out1 fp32 [M, C]; raw split planes of x1 + LayerNorm row partials in LDS
+//   stage 2:  y  = LN(x1) W2^T + b2 (LayerNorm gamma/beta folded into W2 / b2 / u2, finished in the epilogue)
+//             -> out2 fp32 [M, ldo2], N2 = passes * C columns
+// A of stage 1: split planes [M, C] written by the attention kernel (amode 0: attention -> to_out + residual -> LN ->
+// to_q of the next attention, reference attention.py:157-189), or GroupNorm of the fp32 block input, normalised once per
+// row-block (amode 1: norm -> proj_in -> LN -> to_q/to_k/to_v, transformer_1d.py:264-268 + attention.py:157-160).
+// ---------------------------------------------------------------------------------------
+struct ChainParams {
+  int M, C, T;                   // rows (= B * T, T % 32 == 0), channels (128, 256, 384 or 512)
+  int amode;
+  const bf16_t* a_hi; const bf16_t* a_lo;                       // amode 0: [M, C] planes
+  const float* x; const float* stat16;                          // amode 1: fp32 [M, C] and its 32x16-block statistics
+  const float* gamma; const float* beta; float gn_eps; int groups;
+  // weights FRAGMENT-MAJOR (launch_relayout_frag of the packed [rows][Kp = C] planes)
+  const bf16_t* w1_hi; const bf16_t* w1_lo; int Kp1; const float* b1;
+  const float* res;              // [M, C] fp32 or null
+  float* out1;                   // [M, C] fp32
+  const bf16_t* w2_hi; const bf16_t* w2_lo; int Kp2; const float* b2; const float* u2;
+  int passes;                    // N2 = passes * C
+  float* out2; int ldo2;
+  float ln_eps;
+};
+bool chain2_supported(const ChainParams& p, int precision);
+hipError_t chain_init();
+hipError_t launch_chain2(const ChainParams& p, int precision, hipStream_t st);
+// packed weight plane [rows][Kp] -> fragment-major (rows % 32 == 0, Kp % 16 == 0), same size
+hipError_t launch_relayout_frag(const bf16_t* src, bf16_t* dst, int rows, int Kp, hipStream_t st);
+
 struct AttnParams {
   const float* q; const float* k; const float* v; const float* bias;
   float* o;                     // fp32 output or null

@@ -122,6 +122,7 @@ struct RawW { float* p = nullptr; std::vector<int64_t> shape; size_t numel = 0; 
 
 struct PackedW {
   bf16_t* hi = nullptr; bf16_t* lo = nullptr; float* bias = nullptr;
+  bf16_t* fhi = nullptr; bf16_t* flo = nullptr;   // fragment-major copies for the row-block chains (made on demand)
   float* u = nullptr;           // sum_k gamma[k]*W[n,k] (fused-LayerNorm consumers), packed row order
   int Kp = 0, N = 0, N_pad = 0;
 };
@@ -464,12 +465,44 @@ struct Builder {
     const int G = u->cfg.norm_num_groups;
     return fuse_gn && !arena.exact && Tn % 32 == 0 && C % 64 == 0 && C % G == 0 && (C / G) % 16 == 0;
   }
-  void alloc_stat(Act& a) {
+  void alloc_stat(Act& a, bool want16 = false) {
     if (a.T % 32 != 0) return;
-    if (af_tensor(a.T, a.C)) a.stat16 = alloc((size_t)(B * a.T / 32) * (a.C / 16) * 2);
+    if (want16 || af_tensor(a.T, a.C)) a.stat16 = alloc((size_t)(B * a.T / 32) * (a.C / 16) * 2);
     else a.stat = alloc((size_t)(B * a.T / 32) * a.C * 2);
   }
   void stat_out(GemmParams& g, const Act& a) { g.stats = a.stat; g.stats16 = a.stat16; }
+  // Row-block chains of a transformer block (kernels_chain.hip; DVITS_CHAIN=0 restores one launch per GEMM):
+  // norm -> proj_in -> LN -> to_q/k/v, and attention -> to_out + residual -> LN -> to_q of the next attention
+  bool chain_on = [] { const char* e = getenv("DVITS_CHAIN"); return !(e && e[0] == '0'); }();
+  bool chain_ok(int Tn, int C) const {
+    const int G = u->cfg.norm_num_groups;
+    return chain_on && fuse_ln && !arena.exact && prec == DV_PREC_BF16X3 && (C == 128 || C == 256 || C == 384) && Tn % 32 == 0 &&
+           G > 0 && G <= 64 && (G & (G - 1)) == 0 && C % G == 0 && (C / G) % 16 == 0 && (Tn / 32) * (C / 16) <= (C / 128) * 2048;
+  }
+  // fragment-major copies of a packed weight (kernels_chain.hip k_relayout_frag), made once per prepare
+  bool frag(const PackedW* cw) {
+    if (dry) return true;
+    PackedW* w = const_cast<PackedW*>(cw);
+    if (w->fhi) return true;
+    const size_t elems = (size_t)w->N_pad * w->Kp;
+    if (!w->lo || hipMalloc((void**)&w->fhi, elems * 2) != hipSuccess || hipMalloc((void**)&w->flo, elems * 2) != hipSuccess) {
+      err = "hipMalloc(fragment-major weights) failed"; return false;
+    }
+    u->owned.push_back(w->fhi); u->owned.push_back(w->flo);
+    if (launch_relayout_frag(w->hi, w->fhi, w->N_pad, w->Kp, pack_stream) != hipSuccess ||
+        launch_relayout_frag(w->lo, w->flo, w->N_pad, w->Kp, pack_stream) != hipSuccess) { err = "relayout launch failed"; return false; }
+    return true;
+  }
+  void chain(std::vector<OpFn>& ops, const ChainParams& cp, const char* what) {
+    cur_kind = "chain";
+    cur_flops = 2.0 * (double)cp.M * cp.C * cp.C * (1 + cp.passes);
+    char buf[96];
+    snprintf(buf, sizeof(buf), "%s M=%d C=%d N2=%d", what, cp.M, cp.C, cp.passes * cp.C);
+    cur_desc = buf;
+    if (!dry) u->flops += cur_flops;
+    const int pr = prec;
+    emit(ops, [cp, pr](hipStream_t st) { return launch_chain2(cp, pr, st); });
+  }
   // Fill the in-kernel GroupNorm of [a0 | a1] (+ temb scale/shift) (+ SiLU) as segment 0's operand of `g` (k taps), and
   // optionally the raw [r0 | r1] as segment 1 (1x1 shortcut).  False if the shapes are outside what the AF tiles take.
   bool af_setup(GemmParams& g, Act a0, Act a1, int taps, const std::string& pre, float eps, const float* tscale,
@@ -626,7 +659,8 @@ struct Builder {
 
   // ResnetBlock2D (reference resnet.py:591-641): apply(norm1) -> conv1 -> apply(norm2, temb) -> conv2 (+1x1
   // shortcut as a second K-segment | + identity residual)
-  Act resnet(std::vector<OpFn>& ops, const std::string& p, Act x0, Act x1, int cout, bool want_planes = false) {
+  Act resnet(std::vector<OpFn>& ops, const std::string& p, Act x0, Act x1, int cout, bool want_planes = false,
+             bool stat16_out = false) {
     const int cin = x0.C + x1.C, Tn = x0.T, M = B * Tn;
     const float eps = u->cfg.norm_eps;
     const bool shortcut = has(p + "conv_shortcut.weight");
@@ -668,7 +702,7 @@ struct Builder {
     const PackedW* w2 = pack(p + "conv2", cout, K2, pcs, bps);
     if (!w2) return Act{};
     Act out{};
-    out.p = alloc((size_t)M * cout); out.C = cout; out.T = Tn; alloc_stat(out);
+    out.p = alloc((size_t)M * cout); out.C = cout; out.T = Tn; alloc_stat(out, stat16_out);   // (its consumer is a chain)
     {
       GemmParams g = gp_base(Tn, M, cout);
       if (!shortcut) { g.epi = EPI_RESIDUAL; g.res = x0.p; g.ldres = cout; }
@@ -774,6 +808,53 @@ struct Builder {
     };
     auto ln_release = [&](LnIn& in) { release(in.pl); if (in.stat) release(in.stat); };
 
+    const bool chained = chain_ok(Tn, C) && x.stat16 && !af_tensor(Tn, C);
+    float* h3 = nullptr;
+    LnIn l3;
+    if (chained && !(frag(w_in) && frag(w_qkv) && frag(w_o1) && frag(w_q2))) return Act{};
+    if (chained) {
+      // chain 1: GN(eps 1e-6) -> proj_in -> LN1 -> to_q | to_k | to_v   (3 launches -> 1)
+      float* h = alloc((size_t)M * C);
+      float* qkv = alloc((size_t)M * 3 * C);
+      {
+        ChainParams cp{};
+        cp.M = M; cp.C = C; cp.T = Tn; cp.amode = 1;
+        cp.x = x.p; cp.stat16 = x.stat16; cp.gamma = W(p + "norm.weight"); cp.beta = W(p + "norm.bias"); cp.gn_eps = 1e-6f;
+        cp.groups = u->cfg.norm_num_groups;
+        cp.w1_hi = w_in->fhi; cp.w1_lo = w_in->flo; cp.Kp1 = w_in->Kp; cp.b1 = w_in->bias; cp.res = nullptr; cp.out1 = h;
+        cp.w2_hi = w_qkv->fhi; cp.w2_lo = w_qkv->flo; cp.Kp2 = w_qkv->Kp; cp.b2 = w_qkv->bias; cp.u2 = w_qkv->u;
+        cp.passes = 3; cp.out2 = qkv; cp.ldo2 = 3 * C; cp.ln_eps = 1e-5f;
+        chain(ops, cp, "norm+proj_in+LN+qkv");
+      }
+      probe(p + "proj_in", h, Tn, C);
+      Planes ao = attention(ops, qkv, 3 * C, qkv + C, qkv + 2 * C, 3 * C, nullptr, Tn, Tn, C);
+      release(qkv);
+      // chain 2: to_out + residual -> LN2 -> to_q of the cross attention   (2 launches -> 1)
+      float* h2 = alloc((size_t)M * C);
+      float* q2 = alloc((size_t)M * C);
+      {
+        ChainParams cp{};
+        cp.M = M; cp.C = C; cp.T = Tn; cp.amode = 0;
+        cp.a_hi = ao.hi; cp.a_lo = ao.lo;
+        cp.w1_hi = w_o1->fhi; cp.w1_lo = w_o1->flo; cp.Kp1 = w_o1->Kp; cp.b1 = w_o1->bias; cp.res = h; cp.out1 = h2;
+        cp.w2_hi = w_q2->fhi; cp.w2_lo = w_q2->flo; cp.Kp2 = w_q2->Kp; cp.b2 = w_q2->bias; cp.u2 = w_q2->u;
+        cp.passes = 1; cp.out2 = q2; cp.ldo2 = C; cp.ln_eps = 1e-5f;
+        chain(ops, cp, "to_out+res+LN+to_q");
+      }
+      release(ao); release(h);
+      probe(tb + "attn1", h2, Tn, C);
+      float* kv = cross_kv[p];
+      ao = attention(ops, q2, C, kv, kv + C, 2 * C, mask_bias, Tn, L, C);
+      release(q2);
+      h3 = alloc((size_t)M * C);
+      {
+        GemmParams g = gp_base(Tn, M, C); g.seg[0] = seg(ao, C, Planes{}, 0, 1, 0);
+        g.epi = EPI_RESIDUAL; g.res = h2; g.out = h3; l3 = ln_produce(g);
+        gemm(ops, g, w_o2, C);
+      }
+      release(ao); release(h2);
+      probe(tb + "attn2", h3, Tn, C);
+    } else {
     // GN(eps 1e-6) -> 1x1 proj_in (fused: proj_in normalises x itself)
     float* h = alloc((size_t)M * C);
     LnIn l1;
@@ -819,8 +900,7 @@ struct Builder {
     float* kv = cross_kv[p];
     ao = attention(ops, q2, C, kv, kv + C, 2 * C, mask_bias, Tn, L, C);
     release(q2);
-    float* h3 = alloc((size_t)M * C);
-    LnIn l3;
+    h3 = alloc((size_t)M * C);
     {
       GemmParams g = gp_base(Tn, M, C); g.seg[0] = seg(ao, C, Planes{}, 0, 1, 0);
       g.epi = EPI_RESIDUAL; g.res = h2; g.out = h3; l3 = ln_produce(g);
@@ -828,6 +908,7 @@ struct Builder {
     }
     release(ao); release(h2);
     probe(tb + "attn2", h3, Tn, C);
+    }
 
     // GEGLU feed-forward: the GEGLU product and the FF output only feed GEMMs -> split planes only
     Planes gg = alloc_planes((size_t)M * 4 * C);
@@ -1110,7 +1191,8 @@ struct Builder {
       const bool attn = i < n - 1;
       for (int j = 0; j < lpb; ++j) {
         const bool feeds_resampler = i < n - 1 && j == lpb - 1;     // its output is the downsampler's input
-        Act r = resnet(S, bp + "resnets." + std::to_string(j) + ".", h, Act{}, c.block_out_channels[i], feeds_resampler && !attn);
+        Act r = resnet(S, bp + "resnets." + std::to_string(j) + ".", h, Act{}, c.block_out_channels[i], feeds_resampler && !attn,
+                       attn && chain_ok(h.T, c.block_out_channels[i]));
         if (!r.p) return dv_fail(DV_ERR_MISSING_WEIGHT, "%s", err.c_str());
         if (attn) {
           Act a = transformer(S, bp + "attentions." + std::to_string(j) + ".", r, feeds_resampler);
@@ -1128,7 +1210,7 @@ struct Builder {
       }
     }
     {
-      Act r0 = resnet(S, "mid_block.resnets.0.", h, Act{}, h.C);
+      Act r0 = resnet(S, "mid_block.resnets.0.", h, Act{}, h.C, false, chain_ok(h.T, h.C));
       if (!r0.p) return dv_fail(DV_ERR_MISSING_WEIGHT, "%s", err.c_str());
       Act a = transformer(S, "mid_block.attentions.0.", r0);
       if (!a.p) return dv_fail(DV_ERR_MISSING_WEIGHT, "%s", err.c_str());
@@ -1145,7 +1227,7 @@ struct Builder {
         Act sk = skips.back();
         skips.pop_back();
         const bool feeds_resampler = !last && j == lpb;              // its output is the upsampler's input
-        Act r = resnet(S, bp + "resnets." + std::to_string(j) + ".", h, sk, cout, feeds_resampler && !attn);
+        Act r = resnet(S, bp + "resnets." + std::to_string(j) + ".", h, sk, cout, feeds_resampler && !attn, attn && chain_ok(h.T, cout));
         if (!r.p) return dv_fail(DV_ERR_MISSING_WEIGHT, "%s", err.c_str());
         release_act(h);
         release_act(sk);
@@ -1369,6 +1451,7 @@ extern "C" int dv_unet_prepare(dv_unet* u, int32_t B, int32_t T, int32_t L, int3
   HIPCHK(hipDeviceSynchronize());
   HIPCHK(gemm_init());
   HIPCHK(attn_init());
+  HIPCHK(chain_init());
   unet_release_prepared(u);
   u->B = B; u->T = T; u->L = L; u->precision = precision; u->force_up = force_upsample_size;
   const char* keep = getenv("DVITS_KEEP_INTERMEDIATES");

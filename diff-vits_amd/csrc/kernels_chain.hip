@@ -1,0 +1,413 @@
+// Row-block chain kernel for gfx950 (MI355X): two dependent K = C contractions of a transformer block in one launch
+// (dv_common.h ChainParams).  The denoiser's K = C GEMMs (M = 8192..2048 rows, N = K = 128..384) take 12-15 us each as
+// separate launches although their MFMA work is ~1 us: argument fetch, cold first loads, a 2-6 tile k-loop and a
+// store-bound epilogue per launch, and every intermediate makes an HBM/L2 round trip.  Here a workgroup owns 32 rows and
+// ALL channels: the A operand is resident in LDS, the first GEMM's result goes back into the same LDS region as split
+// planes (+ LayerNorm row partials), the second GEMM reads it from there.
+//
+// Only the weights stream, and they never touch LDS: they are stored FRAGMENT-MAJOR (k_relayout_frag: the 64 lanes'
+// 16-byte MFMA operand pieces of one (32-row, 16-k) fragment are 1 KiB contiguous), every wave loads exactly the
+// fragments it multiplies - one fully coalesced global_load_dwordx4 per fragment plane, DEPTH fragments ahead in
+// registers - so the k-loop has no barrier at all and the eight waves of a workgroup drift freely.  [First version: the
+// weight tiles went through a three-stage LDS-DMA ring with one barrier per [128 x 64] tile: ~1900 cycles per 32 KiB tile,
+// bound by the DMA latency with only two tiles in flight beside the resident A operand - profiles/r02_ops_profile_chain_v1.txt.]
+//
+//   waves      : 8 = 4 column-fragment owners (fragments wn, wn + 4, ... of the N = C output columns) x 2 k-groups (each
+//                multiplies one half of K); accumulators of all its fragments stay live (NS = C / 128 per wave)
+//   order      : 16-deep k-step outer, fragment inner (the A fragment of a k-step is read from LDS once)
+//   after GEMM : k-group 1 hands its accumulators over through LDS, k-group 0 runs the epilogue; the next GEMM's first
+//                weight fragments are already in flight
+#include "dv_common.h"
+#include "dv_device.h"
+
+#include <cstdlib>
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+#ifdef DV_GEMM_TRACE
+// development build only (make trace): per-workgroup s_memtime stamps of the chain kernel's phases (tools/chain_trace.py)
+__device__ unsigned long long g_chain_trace[8192 * 16];
+#define DV_CTRACE(i) do { if (threadIdx.x == 0 && blockIdx.x < 8192) g_chain_trace[blockIdx.x * 16 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+extern "C" int dv_debug_chain_trace(unsigned long long* host, int n_wg) {
+  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_chain_trace), (size_t)n_wg * 16 * sizeof(unsigned long long));
+}
+#else
+#define DV_CTRACE(i) do {} while (0)
+#endif
+
+namespace {
+
+constexpr int BM = 32, NWV = 8, NT = 64 * NWV, NT_LAUNCH = NT + 64;   // + one L2-prefetch wave
+constexpr int CHUNK_PL = BM * 128;                 // one 64-channel chunk of the resident A operand, one plane
+constexpr int DEPTH = 6;                           // weight fragments (hi + lo: 8 VGPRs each) in flight per wave
+
+__device__ __forceinline__ int swz(int row) { return (row >> 1) & 7; }
+__device__ __forceinline__ unsigned pk(float lo, float hi) { return dv_cvt_pk_bf16(lo, hi); }
+
+template <int NS, int AMODE>
+__global__ __launch_bounds__(NT_LAUNCH) void k_chain2(const ChainParams p) {
+  extern __shared__ __attribute__((aligned(1024))) char smem[];
+  constexpr int CH = 2 * NS;                       // 64-channel chunks of the A operand
+  constexpr int A_PL = CH * CHUNK_PL;              // bytes per plane of the resident A operand
+  constexpr int C = 128 * NS;
+  char* const a_reg = smem;                        // [2 planes][CH][32 rows][128 B]
+  char* const red_reg = smem + 2 * A_PL;           // k-group hand-over (NS * 16 KiB); GroupNorm entries before stage 1
+  __shared__ float2 s_rowp[BM][16];                // LayerNorm row partials per 32-column block (sum, M2 about the block mean)
+  __shared__ float2 s_ln[BM];                      // per row (mean, rstd)
+  __shared__ __attribute__((aligned(16))) float s_gscale[AMODE ? C : 4], s_gshift[AMODE ? C : 4];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  // ---- ninth wave: L2 prefetch, then it leaves ----
+  // Every workgroup streams ALL weights, the workgroups of an XCD walk the same addresses at the same pace, and an L2 does
+  // not survive a kernel boundary: without help every fragment load of every wave waits for an HBM / fabric fill
+  // (measured 40-50 GB/s per CU).  The workgroups of an XCD (observed placement: block b on XCD b % 8 - a speed
+  // assumption only) each touch one slice of the weight planes at launch, one 128-byte line per lane through LDS-DMA into
+  // a scratch word (no VGPR destination, the wave's own vmcnt), so the L2 fills with thousands of requests in flight
+  // while the eight compute waves start on their first fragments.
+  if (wave == NWV) {
+    __shared__ __attribute__((aligned(256))) unsigned s_pf[64];
+    const int xw = blockIdx.x >> 3, nxw = (gridDim.x + 7) >> 3;
+    const int l1 = C * C / 64, l2 = p.passes * l1;                    // 128-byte lines per plane of stage 1 / stage 2
+    const int total = 2 * (l1 + l2), per = (total + nxw - 1) / nxw;
+    const int end = min(total, (xw + 1) * per);
+    for (int ln = xw * per + lane; ln < end; ln += 64) {
+      const char* src;
+      if (ln < l1) src = reinterpret_cast<const char*>(p.w1_hi) + (size_t)ln * 128;
+      else if (ln < 2 * l1) src = reinterpret_cast<const char*>(p.w1_lo) + (size_t)(ln - l1) * 128;
+      else if (ln < 2 * l1 + l2) src = reinterpret_cast<const char*>(p.w2_hi) + (size_t)(ln - 2 * l1) * 128;
+      else src = reinterpret_cast<const char*>(p.w2_lo) + (size_t)(ln - 2 * l1 - l2) * 128;
+      glds4(src, (unsigned)(size_t)s_pf);
+    }
+    if (p.res) {                                   // this workgroup's residual rows (read by the first epilogue)
+      const char* r0 = reinterpret_cast<const char*>(p.res + (size_t)blockIdx.x * BM * C);
+      for (int ln = lane; ln < BM * C / 32; ln += 64) glds4(r0 + (size_t)ln * 128, (unsigned)(size_t)s_pf);
+    }
+    // the epilogues' bias / LayerNorm-u vectors (their first touch would be a dependent cold miss inside the epilogue)
+    for (int ln = lane; ln < C / 32; ln += 64) glds4(reinterpret_cast<const char*>(p.b1) + (size_t)ln * 128, (unsigned)(size_t)s_pf);
+    for (int ln = lane; ln < p.passes * C / 32; ln += 64) {
+      glds4(reinterpret_cast<const char*>(p.b2) + (size_t)ln * 128, (unsigned)(size_t)s_pf);
+      glds4(reinterpret_cast<const char*>(p.u2) + (size_t)ln * 128, (unsigned)(size_t)s_pf);
+    }
+    return;
+  }
+  DV_CTRACE(0);
+  const int wn = wave & 3, kg = wave >> 2, l31 = lane & 31, lh = lane >> 5;
+  const int m0 = blockIdx.x * BM;
+  const unsigned a_base = (unsigned)(size_t)a_reg;
+  const int d_row = lane >> 3, d_slot = lane & 7;
+
+  // ---- one GEMM stage over the resident A: acc[ns] += W[frag0 + ns*4 + wn][k-half kg] x A^T ----
+  // unit u = (k-step u / NS of this wave's k-half, fragment u % NS); its two operand planes are one coalesced 16-byte
+  // load per lane each from the fragment-major weights
+  constexpr int KSTEPS = C / 16, KH = KSTEPS / 2, U = NS * KH;
+  struct BFrag { bf16x8 h, l; };
+  auto load_unit = [&](const bf16_t* wf_hi, const bf16_t* wf_lo, int frag0, int u) {
+    const int ks = kg * KH + u / NS, nf = frag0 + (u % NS) * 4 + wn;
+    const size_t e = ((size_t)(nf * KSTEPS + ks) * 64 + lane) * 8;
+    BFrag f;
+    f.h = *reinterpret_cast<const bf16x8*>(wf_hi + e);
+    f.l = *reinterpret_cast<const bf16x8*>(wf_lo + e);
+    return f;
+  };
+  auto stage_prologue = [&](const bf16_t* wf_hi, const bf16_t* wf_lo, int frag0, BFrag (&bq)[DEPTH]) {
+#pragma unroll
+    for (int j = 0; j < DEPTH; ++j)
+      if (j < U) bq[j] = load_unit(wf_hi, wf_lo, frag0, j);
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  auto stage_loop = [&](const bf16_t* wf_hi, const bf16_t* wf_lo, int frag0, BFrag (&bq)[DEPTH], f32x16 (&acc)[NS]) {
+    // A fragment of k-step ksl (this wave's k-half): read one k-step ahead of its MFMAs (LDS latency off the chain)
+    auto read_a = [&](int ksl, bf16x8& h, bf16x8& l) {
+      const int c16 = (kg * KH + ksl) * 2 + lh;                    // 16-byte chunk of the row: k-step * 2 + half
+      const int off = (c16 >> 3) * CHUNK_PL + l31 * 128 + (((c16 & 7) ^ swz(l31)) << 4);
+      h = *reinterpret_cast<const bf16x8*>(a_reg + off);
+      l = *reinterpret_cast<const bf16x8*>(a_reg + A_PL + off);
+    };
+    bf16x8 ah[2], al[2];
+    read_a(0, ah[0], al[0]);
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int ksl = u / NS, cur = ksl & 1;
+      if (u % NS == 0 && ksl + 1 < KH) read_a(ksl + 1, ah[cur ^ 1], al[cur ^ 1]);
+      const BFrag f = bq[u % DEPTH];
+      acc[u % NS] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.h, al[cur], acc[u % NS], 0, 0, 0);
+      acc[u % NS] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.l, ah[cur], acc[u % NS], 0, 0, 0);
+      acc[u % NS] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.h, ah[cur], acc[u % NS], 0, 0, 0);
+      // pinned: without the scheduling barriers hipcc sinks every prefetch down to its use (load -> vmcnt(0) -> MFMA)
+      __builtin_amdgcn_sched_barrier(0);
+      if (u + DEPTH < U) bq[u % DEPTH] = load_unit(wf_hi, wf_lo, frag0, u + DEPTH);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+  // k-group 1 hands its accumulators to k-group 0 through `buf` (NS * 16 KiB)
+  auto kgroup_reduce = [&](f32x16 (&acc)[NS], char* buf) {
+    float* red = reinterpret_cast<float*>(buf);
+    __syncthreads();                               // the buffer's previous readers are done; every wave has left its k-loop
+    if (kg == 1) {
+#pragma unroll
+      for (int ns = 0; ns < NS; ++ns)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) red[((ns * 4 + wn) * 16 + r) * 64 + lane] = acc[ns][r];
+    }
+    __syncthreads();
+    if (kg == 0) {
+#pragma unroll
+      for (int ns = 0; ns < NS; ++ns)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[ns][r] += red[((ns * 4 + wn) * 16 + r) * 64 + lane];
+    }
+  };
+
+  // ================= A operand of stage 1 =================
+  if (AMODE == 0) {
+    // split planes from global by LDS-DMA: instruction = (chunk, 8 rows) of one plane
+    for (int idx = wave; idx < CH * 4; idx += NWV) {
+      const int c = idx >> 2, r8 = idx & 3, row = r8 * 8 + d_row;
+      const size_t e = (size_t)(m0 + row) * C + c * 64 + ((d_slot ^ swz(row)) << 3);
+      const unsigned dst = a_base + (unsigned)(c * CHUNK_PL + r8 * 1024);
+      glds16(p.a_hi + e, dst);
+      glds16(p.a_lo + e, dst + A_PL);
+    }
+  }
+  BFrag bq[DEPTH];
+  stage_prologue(p.w1_hi, p.w1_lo, 0, bq);         // the first weight fragments fly under the A operand's arrival / conversion
+  if (AMODE == 1) {
+    // GroupNorm of the fp32 rows, once per row-block: table of this utterance, then convert
+    const int T = p.T, b_item = m0 / T;
+    {
+      const int G = p.groups, cg = C / G, nvb = cg >> 4, RB = T >> 5, nblk = C >> 4, n_ent = RB * nblk;
+      const int cc = min(tid, C - 1);
+      const float pg = p.gamma[cc], pb = p.beta[cc];
+      float2* s_ent = reinterpret_cast<float2*>(red_reg);                          // NS * 16 KiB: n_ent <= NS * 2048
+      for (int e0 = 0; e0 < n_ent; e0 += 2 * NT) {
+        float2 ev[2];
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+          const int e = min(e0 + k * NT + tid, n_ent - 1);
+          ev[k] = reinterpret_cast<const float2*>(p.stat16)[(size_t)b_item * n_ent + e];
+        }
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+          const int e = e0 + k * NT + tid;
+          if (e < n_ent) s_ent[e] = ev[k];
+        }
+      }
+      __syncthreads();
+      const int lpg = 64 / G, g = lane / lpg, sub = lane - g * lpg;
+      double s1 = 0, q = 0;
+      for (int i0 = sub; i0 < RB * nvb; i0 += 4 * lpg) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int i = i0 + k * lpg, rb = i / nvb;
+          const float2 v = s_ent[min(rb * nblk + g * nvb + (i - rb * nvb), n_ent - 1)];
+          if (i < RB * nvb) { s1 += (double)v.x; q += (double)v.y + (double)v.x * (double)v.x * (1.0 / 512.0); }
+        }
+      }
+      for (int o = lpg >> 1; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o); q += __shfl_xor(q, o); }
+      const double n = (double)cg * (double)T, mean_d = s1 / n;
+      double var = q / n - mean_d * mean_d;
+      var = var > 0 ? var : 0;
+      const float mean = (float)mean_d, rstd = 1.0f / sqrtf((float)var + p.gn_eps);
+      const int src_lane = cc / cg * lpg;
+      const float gm = __shfl(mean, src_lane), gr = __shfl(rstd, src_lane);
+      if (tid < C) { const float a = gr * pg; s_gscale[tid] = a; s_gshift[tid] = pb - gm * a; }
+      __syncthreads();
+    }
+    constexpr int TASKS = BM * (C / 4), RNDS = (TASKS + NT - 1) / NT;    // (row, 4-channel group); NT % (C/4) may be != 0
+    float4 rv[RNDS];
+#pragma unroll
+    for (int j = 0; j < RNDS; ++j) {
+      const int id = min(j * NT + tid, TASKS - 1), row = id / (C / 4), c4 = id - row * (C / 4);
+      rv[j] = *reinterpret_cast<const float4*>(p.x + (size_t)(m0 + row) * C + c4 * 4);
+    }
+#pragma unroll
+    for (int j = 0; j < RNDS; ++j) {
+      const int id = j * NT + tid;
+      if (id >= TASKS) continue;
+      const int row = id / (C / 4), c4 = id - row * (C / 4);
+      const float4 sc = *reinterpret_cast<const float4*>(s_gscale + c4 * 4);
+      const float4 sh = *reinterpret_cast<const float4*>(s_gshift + c4 * 4);
+      const float v0 = fmaf(rv[j].x, sc.x, sh.x), v1 = fmaf(rv[j].y, sc.y, sh.y), v2 = fmaf(rv[j].z, sc.z, sh.z),
+                  v3 = fmaf(rv[j].w, sc.w, sh.w);
+      uint2 hw, lw;
+      hw.x = pk(v0, v1); hw.y = pk(v2, v3);
+      lw.x = pk(v0 - __uint_as_float(hw.x << 16), v1 - __uint_as_float(hw.x & 0xffff0000u));
+      lw.y = pk(v2 - __uint_as_float(hw.y << 16), v3 - __uint_as_float(hw.y & 0xffff0000u));
+      const int c = c4 >> 4, s16 = (c4 & 15) >> 1;
+      const int off = c * CHUNK_PL + row * 128 + ((s16 ^ swz(row)) << 4) + (c4 & 1) * 8;
+      *reinterpret_cast<uint2*>(a_reg + off) = hw;
+      *reinterpret_cast<uint2*>(a_reg + A_PL + off) = lw;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  }
+
+  DV_CTRACE(1);
+  if (AMODE == 0) wait_vmcnt<0>();                  // this wave's A pieces have landed
+  __syncthreads();                                 // A operand complete
+  DV_CTRACE(2);
+
+  // ================= stage 1 =================
+  f32x16 acc[NS];
+#pragma unroll
+  for (int ns = 0; ns < NS; ++ns)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[ns][r] = 0.f;
+  stage_loop(p.w1_hi, p.w1_lo, 0, bq, acc);
+  DV_CTRACE(3);
+  stage_prologue(p.w2_hi, p.w2_lo, 0, bq);         // the second GEMM's first fragments fly during the hand-over and the epilogue
+  kgroup_reduce(acc, red_reg);                     // (its leading barrier: every wave is done reading the A operand)
+  DV_CTRACE(4);
+  // epilogue 1 (k-group 0): x1 = acc + b1 (+ res) -> out1 fp32, raw split planes into the A region, row partials
+  if (kg == 0) {
+    const int m = m0 + l31;
+#pragma unroll
+    for (int ns = 0; ns < NS; ++ns) {
+      const int nf = ns * 128 + wn * 32 + 4 * lh;           // column of g = 0, e = 0
+      float vv[16];
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const float4 bv = *reinterpret_cast<const float4*>(p.b1 + nf + 8 * g);
+        float4 rr = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (p.res) rr = *reinterpret_cast<const float4*>(p.res + (size_t)m * C + nf + 8 * g);
+        vv[4 * g] = acc[ns][4 * g] + bv.x + rr.x; vv[4 * g + 1] = acc[ns][4 * g + 1] + bv.y + rr.y;
+        vv[4 * g + 2] = acc[ns][4 * g + 2] + bv.z + rr.z; vv[4 * g + 3] = acc[ns][4 * g + 3] + bv.w + rr.w;
+      }
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int n = nf + 8 * g;
+        *reinterpret_cast<float4*>(p.out1 + (size_t)m * C + n) = make_float4(vv[4 * g], vv[4 * g + 1], vv[4 * g + 2], vv[4 * g + 3]);
+        uint2 hw, lw;
+        hw.x = pk(vv[4 * g], vv[4 * g + 1]); hw.y = pk(vv[4 * g + 2], vv[4 * g + 3]);
+        lw.x = pk(vv[4 * g] - __uint_as_float(hw.x << 16), vv[4 * g + 1] - __uint_as_float(hw.x & 0xffff0000u));
+        lw.y = pk(vv[4 * g + 2] - __uint_as_float(hw.y << 16), vv[4 * g + 3] - __uint_as_float(hw.y & 0xffff0000u));
+        const int c = n >> 6, s16 = (n & 63) >> 3;
+        const int off = c * CHUNK_PL + l31 * 128 + ((s16 ^ swz(l31)) << 4) + ((n & 7) >> 2) * 8;
+        *reinterpret_cast<uint2*>(a_reg + off) = hw;
+        *reinterpret_cast<uint2*>(a_reg + A_PL + off) = lw;
+      }
+      float a = 0.f, q = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) a += vv[r];
+      a += __shfl_xor(a, 32);
+      const float mb = a * (1.0f / 32.0f);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) q += (vv[r] - mb) * (vv[r] - mb);
+      q += __shfl_xor(q, 32);
+      if (lh == 0) s_rowp[l31][ns * 4 + wn] = make_float2(a, q);
+    }
+  }
+  __syncthreads();
+  if (tid < BM) {
+    float s1 = 0.f;
+    for (int k = 0; k < 4 * NS; ++k) s1 += s_rowp[tid][k].x;
+    const float inv_c = 1.0f / (float)C, mean = s1 * inv_c;
+    float m2 = 0.f;
+    for (int k = 0; k < 4 * NS; ++k) {
+      const float2 v = s_rowp[tid][k];
+      const float dm = v.x * (1.0f / 32.0f) - mean;
+      m2 += v.y + 32.0f * dm * dm;
+    }
+    s_ln[tid] = make_float2(mean, 1.0f / sqrtf(m2 * inv_c + p.ln_eps));
+  }
+  __syncthreads();                                 // planes of x1 and the row statistics are visible
+  DV_CTRACE(5);
+
+  // ================= stage 2: `passes` contractions of C output columns each =================
+  for (int ps = 0; ps < p.passes; ++ps) {
+#pragma unroll
+    for (int ns = 0; ns < NS; ++ns)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[ns][r] = 0.f;
+    stage_loop(p.w2_hi, p.w2_lo, ps * (C / 32), bq, acc);
+    if (ps == 0) DV_CTRACE(6);
+    if (ps + 1 < p.passes) stage_prologue(p.w2_hi, p.w2_lo, (ps + 1) * (C / 32), bq);
+    kgroup_reduce(acc, red_reg);
+    if (ps == 0) DV_CTRACE(7);
+    if (kg == 0) {
+      const int m = m0 + l31;
+      const float2 st = s_ln[l31];
+#pragma unroll
+      for (int ns = 0; ns < NS; ++ns) {
+        const int nf = ps * C + ns * 128 + wn * 32 + 4 * lh;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int n = nf + 8 * g;
+          const float4 bv = *reinterpret_cast<const float4*>(p.b2 + n);
+          const float4 uv = *reinterpret_cast<const float4*>(p.u2 + n);
+          float4 o;
+          o.x = st.y * (acc[ns][4 * g] - st.x * uv.x) + bv.x;
+          o.y = st.y * (acc[ns][4 * g + 1] - st.x * uv.y) + bv.y;
+          o.z = st.y * (acc[ns][4 * g + 2] - st.x * uv.z) + bv.z;
+          o.w = st.y * (acc[ns][4 * g + 3] - st.x * uv.w) + bv.w;
+          *reinterpret_cast<float4*>(p.out2 + (size_t)m * p.ldo2 + n) = o;
+        }
+      }
+    }
+    if (ps == 0) DV_CTRACE(8);
+  }
+  DV_CTRACE(9);
+}
+
+// packed weights [rows][Kp] (k contiguous) -> fragment-major: the 16-byte operand pieces of the 64 lanes of one
+// (32-row, 16-k) MFMA fragment contiguous (lane (l31, lh) holds W[f*32 + l31][ks*16 + lh*8 .. +8])
+__global__ __launch_bounds__(64) void k_relayout_frag(const bf16_t* __restrict__ src, bf16_t* __restrict__ dst, int Kp, int ksteps) {
+  const int nf = blockIdx.x, ks = blockIdx.y, lane = threadIdx.x;
+  const uint4 v = *reinterpret_cast<const uint4*>(src + (size_t)(nf * 32 + (lane & 31)) * Kp + ks * 16 + (lane >> 5) * 8);
+  *reinterpret_cast<uint4*>(dst + ((size_t)(nf * ksteps + ks) * 64 + lane) * 8) = v;
+}
+
+template <int NS, int AMODE>
+hipError_t init_one() {
+  const int smem = 2 * 2 * NS * CHUNK_PL + NS * 16384;
+  return hipFuncSetAttribute(reinterpret_cast<const void*>(k_chain2<NS, AMODE>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+}
+template <int NS, int AMODE>
+hipError_t launch_one(const ChainParams& p, hipStream_t st) {
+  const int smem = 2 * 2 * NS * CHUNK_PL + NS * 16384;
+  hipLaunchKernelGGL((k_chain2<NS, AMODE>), dim3(p.M / BM), dim3(NT_LAUNCH), smem, st, p);
+  return hipGetLastError();
+}
+
+}  // namespace
+
+hipError_t chain_init() {
+  hipError_t e;
+  if ((e = init_one<1, 0>()) != hipSuccess) return e;
+  if ((e = init_one<2, 0>()) != hipSuccess) return e;
+  if ((e = init_one<3, 0>()) != hipSuccess) return e;
+  if ((e = init_one<4, 0>()) != hipSuccess) return e;
+  if ((e = init_one<1, 1>()) != hipSuccess) return e;
+  if ((e = init_one<2, 1>()) != hipSuccess) return e;
+  if ((e = init_one<3, 1>()) != hipSuccess) return e;
+  return init_one<4, 1>();
+}
+
+hipError_t launch_relayout_frag(const bf16_t* src, bf16_t* dst, int rows, int Kp, hipStream_t st) {
+  if (rows % 32 != 0 || Kp % 16 != 0) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(k_relayout_frag, dim3(rows / 32, Kp / 16), dim3(64), 0, st, src, dst, Kp, Kp / 16);
+  return hipGetLastError();
+}
+
+bool chain2_supported(const ChainParams& p, int precision) {
+  if (precision != 0) return false;                                  // split-bf16 mode only
+  if (p.C != 128 && p.C != 256 && p.C != 384) return false;   // (512 is instantiated; measured slower than one launch per GEMM)
+  if (p.M % 32 != 0 || p.T % 32 != 0 || p.M % p.T != 0 || p.passes < 1) return false;
+  if (p.Kp1 != p.C || p.Kp2 != p.C) return false;
+  if (p.amode == 1) {
+    const int G = p.groups;
+    if (G <= 0 || G > 64 || (G & (G - 1)) != 0 || p.C % G != 0 || (p.C / G) % 16 != 0) return false;
+    if ((p.T / 32) * (p.C / 16) > (p.C / 128) * 2048) return false;  // block entries of one utterance are staged in the hand-over region
+  }
+  return true;
+}
+
+hipError_t launch_chain2(const ChainParams& p, int precision, hipStream_t st) {
+  if (!chain2_supported(p, precision)) return hipErrorInvalidValue;
+  if (!p.w1_hi || !p.w1_lo || !p.w2_hi || !p.w2_lo || !p.b1 || !p.b2 || !p.u2 || !p.out1 || !p.out2) return hipErrorInvalidValue;
+  if (p.amode == 0 ? (!p.a_hi || !p.a_lo) : (!p.x || !p.stat16 || !p.gamma || !p.beta)) return hipErrorInvalidValue;
+  const int ns = p.C / 128;
+  if (p.amode == 0)
+    return ns == 1 ? launch_one<1, 0>(p, st) : (ns == 2 ? launch_one<2, 0>(p, st) : (ns == 3 ? launch_one<3, 0>(p, st) : launch_one<4, 0>(p, st)));
+  return ns == 1 ? launch_one<1, 1>(p, st) : (ns == 2 ? launch_one<2, 1>(p, st) : (ns == 3 ? launch_one<3, 1>(p, st) : launch_one<4, 1>(p, st)));
+}
