@@ -136,6 +136,41 @@ def cpu_baseline(sd, B, T, L, solver_steps, sample_steps=2):
             "thread_sweep_forward_s": {str(k): round(v, 4) for k, v in sweep.items()}}
 
 
+def lifecycle_extras(dev, precision):
+    """Engine life-cycle costs around the timed region: weight packing + planning for a first shape,
+    re-planning for another shape (packed weights are kept), hipGraph capture of a 30-step UniPC loop, and the latency
+    of ONE utterance at a length that is not a multiple of anything (B=1, T=300, L=150: the reference's default call)."""
+    from diff_vits_amd.sampler import uni_pc
+    out = {}
+    m, _ = build_model(dev, precision)
+    eng = m.hip_engine()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter(); eng._prepared = None; eng.prepare(1, 256, 150); torch.cuda.synchronize()
+    out["replan_ms_weights_kept"] = 1e3 * (time.perf_counter() - t0)
+    with torch.device("meta"):
+        shapes = {k: tuple(v.shape) for k, v in UNet1DConditionModel(**UNET_KW).state_dict().items()}
+    m2 = UNet1DConditionModel(backend="hip", **UNET_KW).eval()
+    m2.load_state_dict({k: torch.from_numpy(v) for k, v in synth.make_state_dict(shapes, seed=1234).items()})
+    m2 = m2.to(dev)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter(); e2 = m2.hip_engine(precision); e2.prepare(1, 300, 150); torch.cuda.synchronize()
+    out["first_prepare_ms_incl_weight_upload_and_packing"] = 1e3 * (time.perf_counter() - t0)
+    x, cond, enc, mask = (torch.from_numpy(a).to(dev) for a in synth.make_inputs(1, 80, 300, 150, seed=77))
+    ns = uni_pc.NoiseScheduleVP("discrete", betas=torch.from_numpy(synth.make_betas()))
+    native = uni_pc.NativeUNetModel(m2, cond, enc, mask)
+    solver = uni_pc.UniPC(uni_pc.model_wrapper(native, ns, model_type="x_start"), ns, variant="bh2")
+    with torch.no_grad():
+        t0 = time.perf_counter(); solver.sample(x, steps=30, order=2); torch.cuda.synchronize()
+        out["first_run_ms_incl_graph_capture"] = 1e3 * (time.perf_counter() - t0)
+        ts = []
+        for _ in range(5):
+            t0 = time.perf_counter(); solver.sample(x, steps=30, order=2); torch.cuda.synchronize()
+            ts.append(1e3 * (time.perf_counter() - t0))
+    out["b1_T300_L150_unipc30_latency_ms"] = sorted(ts)[len(ts) // 2]
+    out["b1_T300_mel_frames_per_s"] = 300.0 / (out["b1_T300_L150_unipc30_latency_ms"] * 1e-3)
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -284,17 +319,23 @@ def main():
         achieved = flops_gemm_fwd / (gemm_us * 1e-6 * gemm_n) / 1e12
         achieved_evpair = g[1] / (g[2] * 1e-3) / 1e12
         fwd_ms = 1e3 * dt / args.steps / S
-        # HBM-side bytes per GEMM launch: PMC counters cannot be read from inside the process, so this is the figure
-        # of the committed rocprofv3 --pmc passes over this same command (tools/pmc_traffic.py); null if absent
-        traffic, traffic_src = None, None
-        tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_gemm_hbm_traffic.json")
+        # HBM-side bytes per launch, HBM GB/s and MFMA utilisation: PMC counters cannot be read from inside the process, so
+        # these are the figures of the committed rocprofv3 --pmc passes over this same command (tools/pmc_roofline.py)
+        traffic = traffic_src = hbm_gbps = mfma_util = None
+        pmc_families = None
+        tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r02_pmc_roofline.json")
         if os.path.exists(tpath) and args.precision == "bf16x3" and (B, T, L) == (8, 1024, 256):
             with open(tpath) as f:
-                traffic = json.load(f)["gemm"]["hbm_bytes_per_launch"]
-            traffic_src = "profiles/r01_gemm_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, KiB, separate passes)"
+                pj = json.load(f)
+            traffic, hbm_gbps, mfma_util = (pj["gemm"][k] for k in ("hbm_bytes_per_launch", "hbm_gbps", "mfma_util"))
+            pmc_families = {k: {kk: v[kk] for kk in ("launches", "avg_us_kernel_trace", "hbm_bytes_per_launch", "hbm_gbps", "mfma_util")}
+                            for k, v in pj.items() if isinstance(v, dict)}
+            traffic_src = ("profiles/r02_pmc_roofline.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, KiB; SQ_VALU_MFMA_BUSY_CYCLES / "
+                           "(1024 SIMDs x kernel duration x 2.4 GHz); separate passes, eager launches)")
         result["roofline"] = {
             "bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
-            "traffic": traffic, "traffic_source": traffic_src,
+            "traffic": traffic, "traffic_source": traffic_src, "hbm_gbps": hbm_gbps, "mfma_util": mfma_util,
+            "pmc_per_kernel_family": pmc_families,
             "kernel": "k_gemm<*> (implicit-GEMM conv1d/linear, all tile instantiations)",
             "flops_per_launch": flops_gemm_fwd / gemm_n, "avg_launch_us": gemm_us, "launches_per_forward": gemm_n,
             "avg_op_us_event_pair_per_operation": 1e3 * g[2] / g[0], "achieved_event_pair_per_launch": achieved_evpair,
@@ -305,6 +346,8 @@ def main():
                         "tflops": flops_model(B, T, L) / (fwd_ms * 1e-3) / 1e12,
                         "frac_of_peak": flops_model(B, T, L) / (fwd_ms * 1e-3) / 1e12 / peak},
         }
+    if not args.no_roofline and world == 1:
+        result["extra"] = lifecycle_extras(dev, args.precision)
     if not args.no_cpu_baseline and world == 1:        # reported at N = 1 only (rank 0's host cores, bounded sample)
         result["cpu_baseline"] = cpu_baseline(sd, B, T, L, S)
         result["speedup_vs_cpu_baseline"] = frames_per_s / result["cpu_baseline"]["value"] / world

@@ -146,7 +146,10 @@ struct dv_unet {
   // prepared state
   bool prepared = false, cond_set = false;
   int B = 0, T = 0, L = 0, precision = 0, force_up = 0;
-  std::vector<void*> owned;                  // hipMalloc'ed (packed weights, tables)
+  std::vector<void*> owned;                  // hipMalloc'ed per prepared shape (tables, tickets, scratch)
+  std::vector<void*> owned_w;                // hipMalloc'ed packed weights: kept across prepares while the weights and the
+                                             // precision stay the same (a new (B, T, L) only re-plans the schedule)
+  int packed_prec = -1;
   std::map<std::string, PackedW> packed;
   char* slab = nullptr; size_t slab_bytes = 0;
   bf16_t* zero_page = nullptr;               // 256 zero bytes: source of padded rows for the LDS-DMA
@@ -176,12 +179,18 @@ struct dv_unet {
   int64_t generation = 0;
 };
 
-static void unet_release_prepared(dv_unet* u) {
+static void unet_release_packed(dv_unet* u) {
+  for (void* p : u->owned_w) (void)hipFree(p);
+  u->owned_w.clear();
+  u->packed.clear();
+  u->packed_prec = -1;
+}
+static void unet_release_prepared(dv_unet* u, bool keep_packed = false) {
   for (void* p : u->owned) (void)hipFree(p);
   u->owned.clear();
   u->zero_page = nullptr;
   u->sk_tickets = nullptr;
-  u->packed.clear();
+  if (!keep_packed) unet_release_packed(u);
   if (u->slab) (void)hipFree(u->slab);
   u->slab = nullptr; u->slab_bytes = 0;
   u->step_ops.clear(); u->cond_ops.clear(); u->probes.clear(); u->step_meta.clear(); u->gemm_store.clear();
@@ -389,11 +398,11 @@ struct Builder {
     pw.N = N; pw.Kp = Kp; pw.N_pad = rup(N, 128);
     const size_t elems = (size_t)pw.N_pad * Kp;
     if (hipMalloc((void**)&pw.hi, elems * 2) != hipSuccess) { err = "hipMalloc(packed weights) failed"; return nullptr; }
-    u->owned.push_back(pw.hi);
+    u->owned_w.push_back(pw.hi);
     (void)hipMemsetAsync(pw.hi, 0, elems * 2, pack_stream);
     if (prec == DV_PREC_BF16X3) {
       if (hipMalloc((void**)&pw.lo, elems * 2) != hipSuccess) { err = "hipMalloc(packed weights) failed"; return nullptr; }
-      u->owned.push_back(pw.lo);
+      u->owned_w.push_back(pw.lo);
       (void)hipMemsetAsync(pw.lo, 0, elems * 2, pack_stream);
     }
     for (const Piece& pc : pieces) {
@@ -408,7 +417,7 @@ struct Builder {
       if (s.kscale) {   // LayerNorm-folded piece: u[n] = sum_c gamma[c] * W[n, c]
         if (!pw.u) {
           if (hipMalloc((void**)&pw.u, (size_t)pw.N_pad * 4) != hipSuccess) { err = "hipMalloc(u) failed"; return nullptr; }
-          u->owned.push_back(pw.u);
+          u->owned_w.push_back(pw.u);
           (void)hipMemsetAsync(pw.u, 0, (size_t)pw.N_pad * 4, pack_stream);
         }
         if (launch_fold_bias(r->p, nullptr, s.kscale, pw.u, s.N, s.C, pc.n_off, pc.geglu, pack_stream) != hipSuccess) {
@@ -418,7 +427,7 @@ struct Builder {
     }
     if (!biases.empty()) {
       if (hipMalloc((void**)&pw.bias, (size_t)pw.N_pad * 4) != hipSuccess) { err = "hipMalloc(bias) failed"; return nullptr; }
-      u->owned.push_back(pw.bias);
+      u->owned_w.push_back(pw.bias);
       (void)hipMemsetAsync(pw.bias, 0, (size_t)pw.N_pad * 4, pack_stream);
       for (const BiasPiece& bp : biases) {
         const float* b1 = bp.bias.empty() ? nullptr : W(bp.bias);
@@ -432,7 +441,7 @@ struct Builder {
           static const float one_one[8] = {1.f, 1.f, 0, 0, 0, 0, 0, 0};
           float* dcoef = nullptr;
           if (hipMalloc((void**)&dcoef, sizeof(one_one)) != hipSuccess) { err = "hipMalloc failed"; return nullptr; }
-          u->owned.push_back(dcoef);
+          u->owned_w.push_back(dcoef);
           (void)hipMemcpyAsync(dcoef, one_one, sizeof(one_one), hipMemcpyHostToDevice, pack_stream);
           (void)launch_lincomb(pw.bias + bp.n_off, pw.bias + bp.n_off, W(bp.bias2), nullptr, nullptr, nullptr, dcoef, bp.N,
                                pack_stream);
@@ -488,7 +497,7 @@ struct Builder {
     if (!w->lo || hipMalloc((void**)&w->fhi, elems * 2) != hipSuccess || hipMalloc((void**)&w->flo, elems * 2) != hipSuccess) {
       err = "hipMalloc(fragment-major weights) failed"; return false;
     }
-    u->owned.push_back(w->fhi); u->owned.push_back(w->flo);
+    u->owned_w.push_back(w->fhi); u->owned_w.push_back(w->flo);
     if (launch_relayout_frag(w->hi, w->fhi, w->N_pad, w->Kp, pack_stream) != hipSuccess ||
         launch_relayout_frag(w->lo, w->flo, w->N_pad, w->Kp, pack_stream) != hipSuccess) { err = "relayout launch failed"; return false; }
     return true;
@@ -922,7 +931,7 @@ struct Builder {
     // Needs the raw h3 planes of the fused-LayerNorm schedule; the per-layer probe build keeps the two-step form.
     if (merged_ffproj) {
       const std::string mw = tb + "__ffproj.weight", mb = tb + "__ffproj.bias";
-      if (!dry) {
+      if (!dry && !u->packed.count(p + "ffproj")) {   // (kept across prepares with the packed weights)
         const float* Wo = W(p + "proj_out.weight"); const float* W2 = W(tb + "ff.net.2.weight");
         const float* bo = W(p + "proj_out.bias"); const float* b2 = W(tb + "ff.net.2.bias");
         float* dw = derived(mw, {C, 4 * C});
@@ -1452,7 +1461,9 @@ extern "C" int dv_unet_prepare(dv_unet* u, int32_t B, int32_t T, int32_t L, int3
   HIPCHK(gemm_init());
   HIPCHK(attn_init());
   HIPCHK(chain_init());
-  unet_release_prepared(u);
+  // a new shape re-plans the schedule; the packed weights survive unless the weights or the precision changed
+  unet_release_prepared(u, !u->weights_dirty && u->packed_prec == precision);
+  u->packed_prec = precision;
   u->B = B; u->T = T; u->L = L; u->precision = precision; u->force_up = force_upsample_size;
   const char* keep = getenv("DVITS_KEEP_INTERMEDIATES");
   u->keep_intermediates = keep && keep[0] == '1';

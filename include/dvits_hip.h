@@ -18,7 +18,8 @@
  *     The caller owns inputs/outputs; the library owns packed weights and workspace.
  *   - `stream` is a hipStream_t passed as void* (NULL = the default stream).  Work is
  *     enqueued asynchronously on it; nothing here synchronises the device except
- *     dv_unet_prepare / dv_*_destroy / dv_sampler_graph_build.
+ *     dv_unet_prepare / dv_penc_prepare / dv_*_destroy, the single-operator dv_op_* entry points (they
+ *     return results) and the first dv_sampler_run of a plan (it captures the loop into a hipGraph).
  *   - handles are not thread-safe; distinct handles are independent.
  */
 #ifndef DVITS_HIP_H
