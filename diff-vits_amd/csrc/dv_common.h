@@ -124,9 +124,26 @@ struct ChainParams {
   float* out1;                   // [M, C] fp32
   const bf16_t* w2_hi; const bf16_t* w2_lo; int Kp2; const float* b2; const float* u2;
   int passes;                    // N2 = passes * C
-  float* out2; int ldo2;
+  float* out2; int ldo2;         // (null with the cross-attention tail: the query never leaves the workgroup)
   float ln_eps;
+  // Optional tail (xa_kf_hi != null; amode 0, passes 1, 8 heads): the cross attention of the block and its output
+  // projection run inside the same launch - wave h is head h for the workgroup's 32 queries (keys / values of the
+  // utterance's prompt, hoisted by set_cond into MFMA-fragment order: launch_kv_frag) - then
+  //   stage 3:  x3 = O W3^T + b3 + x1 -> out3 fp32, raw split planes out3_hi / out3_lo and LayerNorm row partials
+  //             rowstat3 [M, C/32, 2] for the GEGLU GEMM (reference attention.py:176-203)
+  const bf16_t* xa_kf_hi; const bf16_t* xa_kf_lo;   // [B][H][nT][d/16][64 lanes][8]   K fragments (32 keys x 16 channels)
+  const bf16_t* xa_vf_hi; const bf16_t* xa_vf_lo;   // [B][H][nT][2][NB][64 lanes][8]  V^T fragments (32 channels x 16 keys, keys permuted)
+  const float* xa_bias;          // [B][nT * 32] key bias in the log2 domain (mask bias * log2 e; -1e30 beyond L)
+  int xa_nT, xa_d;               // 32-key tiles, head dim (16, 32 or 48)
+  float xa_qscale;               // d^-1/2 * log2 e
+  const bf16_t* w3_hi; const bf16_t* w3_lo; const float* b3;
+  float* out3; bf16_t* out3_hi; bf16_t* out3_lo; float* rowstat3;
 };
+// cross-attention K/V of one block, fp32 [B*L, 2C] (k | v) -> MFMA-fragment-major split planes (ChainParams xa_*)
+hipError_t launch_kv_frag(const float* kv, bf16_t* kf_hi, bf16_t* kf_lo, bf16_t* vf_hi, bf16_t* vf_lo, int B, int L, int C, int H,
+                          hipStream_t st);
+// key bias of the fused cross attention: out[b][k] = k < L ? (mask_bias ? mask_bias[b][k] : 0) * log2 e : -1e30, k < nT * 32
+hipError_t launch_xbias(const float* mask_bias, float* out, int B, int L, int nT, hipStream_t st);
 bool chain2_supported(const ChainParams& p, int precision);
 hipError_t chain_init();
 hipError_t launch_chain2(const ChainParams& p, int precision, hipStream_t st);

@@ -744,6 +744,15 @@ struct Builder {
   // cross-attention K/V of every transformer block (filled by the cond schedule)
   std::map<std::string, float*> cross_kv;
   float* mask_bias = nullptr;    // [B, L]
+  // the same as MFMA fragments for the blocks whose cross attention runs inside the chain kernel (kernels_chain.hip)
+  struct XFrag { bf16_t* kf_hi = nullptr; bf16_t* kf_lo = nullptr; bf16_t* vf_hi = nullptr; bf16_t* vf_lo = nullptr; };
+  std::map<std::string, XFrag> cross_frag;
+  float* xbias = nullptr;        // [B, nT * 32] key bias in the log2 domain
+  bool xa_on = [] { const char* e = getenv("DVITS_CHAIN_XATTN"); return !(e && e[0] == '0'); }();
+  bool xa_ok(int Tn, int C) const {
+    const int H = u->cfg.num_heads;
+    return xa_on && chain_ok(Tn, C) && H == 8 && C % H == 0 && (C / H == 16 || C / H == 32);
+  }
 
   Planes attention(std::vector<OpFn>& ops, const float* q, int ldq, const float* k, const float* v, int ldkv, const float* bias,
                    int Tq, int Tk, int C) {
@@ -838,6 +847,36 @@ struct Builder {
       probe(p + "proj_in", h, Tn, C);
       Planes ao = attention(ops, qkv, 3 * C, qkv + C, qkv + 2 * C, 3 * C, nullptr, Tn, Tn, C);
       release(qkv);
+      if (xa_ok(Tn, C) && cross_frag.count(p)) {
+        // chain 2 with the cross attention inside: to_out + residual -> LN2 -> to_q -> cross attention (wave = head, K / V
+        // of the prompt as hoisted MFMA fragments) -> to_out + residual -> LN3 partials   (4 launches -> 1)
+        if (!frag(w_o2)) return Act{};
+        float* h2 = alloc((size_t)M * C);
+        h3 = alloc((size_t)M * C);
+        l3 = LnIn{};
+        l3.pl = alloc_planes((size_t)M * C);
+        l3.stat = alloc((size_t)M * nblk * 2);
+        {
+          const XFrag& xf = cross_frag[p];
+          ChainParams cp{};
+          cp.M = M; cp.C = C; cp.T = Tn; cp.amode = 0;
+          cp.a_hi = ao.hi; cp.a_lo = ao.lo;
+          cp.w1_hi = w_o1->fhi; cp.w1_lo = w_o1->flo; cp.Kp1 = w_o1->Kp; cp.b1 = w_o1->bias; cp.res = h; cp.out1 = h2;
+          cp.w2_hi = w_q2->fhi; cp.w2_lo = w_q2->flo; cp.Kp2 = w_q2->Kp; cp.b2 = w_q2->bias; cp.u2 = w_q2->u;
+          cp.passes = 1; cp.out2 = nullptr; cp.ldo2 = C; cp.ln_eps = 1e-5f;
+          cp.xa_kf_hi = xf.kf_hi; cp.xa_kf_lo = xf.kf_lo; cp.xa_vf_hi = xf.vf_hi; cp.xa_vf_lo = xf.vf_lo; cp.xa_bias = xbias;
+          cp.xa_nT = (L + 31) / 32; cp.xa_d = C / u->cfg.num_heads;
+          cp.xa_qscale = (1.0f / sqrtf((float)cp.xa_d)) * 1.44269504088896340736f;
+          cp.w3_hi = w_o2->fhi; cp.w3_lo = w_o2->flo; cp.b3 = w_o2->bias;
+          cp.out3 = h3; cp.out3_hi = l3.pl.hi; cp.out3_lo = l3.pl.lo; cp.rowstat3 = l3.stat;
+          chain(ops, cp, "to_out+res+LN+to_q+xattn+to_out+res");
+          if (!dry) { u->flops += 4.0 * B * u->cfg.num_heads * (double)Tn * L * cp.xa_d + 2.0 * (double)M * C * C; }
+        }
+        release(ao); release(h);
+        probe(tb + "attn1", h2, Tn, C);
+        release(h2);
+        probe(tb + "attn2", h3, Tn, C);
+      } else {
       // chain 2: to_out + residual -> LN2 -> to_q of the cross attention   (2 launches -> 1)
       float* h2 = alloc((size_t)M * C);
       float* q2 = alloc((size_t)M * C);
@@ -863,6 +902,7 @@ struct Builder {
       }
       release(ao); release(h2);
       probe(tb + "attn2", h3, Tn, C);
+      }
     } else {
     // GN(eps 1e-6) -> 1x1 proj_in (fused: proj_in normalises x itself)
     float* h = alloc((size_t)M * C);
@@ -1079,6 +1119,23 @@ struct Builder {
     for (int i = 1; i < n; ++i)
       for (int j = 0; j < lpb + 1; ++j) xformers.push_back({"up_blocks." + std::to_string(i) + ".attentions." + std::to_string(j) + ".", c.block_out_channels[n - 1 - i]});
     for (auto& x : xformers) cross_kv[x.first] = alloc((size_t)B * L * 2 * x.second);
+    {
+      const int H = c.num_heads, nT = (L + 31) / 32;
+      xbias = alloc((size_t)B * nT * 32);
+      int lvl_T = T;
+      std::map<int, int> T_of_C;   // frames at the level of each channel count (the transformer of C runs at T_l)
+      for (int i = 0; i < n; ++i) { T_of_C[c.block_out_channels[i]] = lvl_T; lvl_T = (lvl_T + 2 - 3) / 2 + 1; }
+      for (auto& x : xformers) {
+        const int C = x.second;
+        if (!xa_ok(T_of_C[C], C)) continue;
+        const int d = C / H, KSq = d / 16, NBv = (d + 31) / 32;
+        const size_t kel = (size_t)B * H * nT * KSq * 64 * 8, vel = (size_t)B * H * nT * 2 * NBv * 64 * 8;
+        XFrag xf;
+        xf.kf_hi = reinterpret_cast<bf16_t*>(alloc((kel + 1) / 2)); xf.kf_lo = reinterpret_cast<bf16_t*>(alloc((kel + 1) / 2));
+        xf.vf_hi = reinterpret_cast<bf16_t*>(alloc((vel + 1) / 2)); xf.vf_lo = reinterpret_cast<bf16_t*>(alloc((vel + 1) / 2));
+        cross_frag[x.first] = xf;
+      }
+    }
 
     // ---------- cond schedule ----------
     {
@@ -1131,6 +1188,16 @@ struct Builder {
         g.seg[0] = seg(encs, D, Planes{}, 0, 1, 0);
         g.out = cross_kv[x.first];
         gemm(K, g, w, D);
+        if (cross_frag.count(x.first)) {   // the same K / V as MFMA fragments for the in-chain cross attention
+          const XFrag xf = cross_frag[x.first];
+          const float* kvp2 = cross_kv[x.first];
+          const int H = c.num_heads;
+          emit(K, [=](hipStream_t st) { return launch_kv_frag(kvp2, xf.kf_hi, xf.kf_lo, xf.vf_hi, xf.vf_lo, Bn, Ln, C, H, st); });
+        }
+      }
+      {
+        float* xb = xbias; const float* mbp = mask_bias; const int nT = (L + 31) / 32;
+        emit(K, [=](hipStream_t st) { return launch_xbias(mbp, xb, Bn, Ln, nT, st); });
       }
       release(encs);
     }

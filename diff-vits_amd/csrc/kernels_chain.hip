@@ -45,8 +45,8 @@ constexpr int DEPTH = 6;                           // weight fragments (hi + lo:
 __device__ __forceinline__ int swz(int row) { return (row >> 1) & 7; }
 __device__ __forceinline__ unsigned pk(float lo, float hi) { return dv_cvt_pk_bf16(lo, hi); }
 
-template <int NS, int AMODE>
-__global__ __launch_bounds__(NT_LAUNCH) void k_chain2(const ChainParams p) {
+template <int NS, int AMODE, bool XA = false>
+__global__ __launch_bounds__(XA ? NT : NT_LAUNCH) void k_chain2(const ChainParams p) {
   extern __shared__ __attribute__((aligned(1024))) char smem[];
   constexpr int CH = 2 * NS;                       // 64-channel chunks of the A operand
   constexpr int A_PL = CH * CHUNK_PL;              // bytes per plane of the resident A operand
@@ -65,18 +65,21 @@ __global__ __launch_bounds__(NT_LAUNCH) void k_chain2(const ChainParams p) {
   // assumption only) each touch one slice of the weight planes at launch, one 128-byte line per lane through LDS-DMA into
   // a scratch word (no VGPR destination, the wave's own vmcnt), so the L2 fills with thousands of requests in flight
   // while the eight compute waves start on their first fragments.
-  if (wave == NWV) {
+  // (the cross-attention variant runs without it: a ninth wave caps the kernel at 168 VGPRs and it needs ~230)
+  if (!XA && wave == NWV) {
     __shared__ __attribute__((aligned(256))) unsigned s_pf[64];
     const int xw = blockIdx.x >> 3, nxw = (gridDim.x + 7) >> 3;
-    const int l1 = C * C / 64, l2 = p.passes * l1;                    // 128-byte lines per plane of stage 1 / stage 2
-    const int total = 2 * (l1 + l2), per = (total + nxw - 1) / nxw;
+    const int l1 = C * C / 64, l2 = p.passes * l1, l3 = XA ? l1 : 0;   // 128-byte lines per plane of stage 1 / 2 / 3
+    const int total = 2 * (l1 + l2 + l3), per = (total + nxw - 1) / nxw;
     const int end = min(total, (xw + 1) * per);
     for (int ln = xw * per + lane; ln < end; ln += 64) {
       const char* src;
       if (ln < l1) src = reinterpret_cast<const char*>(p.w1_hi) + (size_t)ln * 128;
       else if (ln < 2 * l1) src = reinterpret_cast<const char*>(p.w1_lo) + (size_t)(ln - l1) * 128;
       else if (ln < 2 * l1 + l2) src = reinterpret_cast<const char*>(p.w2_hi) + (size_t)(ln - 2 * l1) * 128;
-      else src = reinterpret_cast<const char*>(p.w2_lo) + (size_t)(ln - 2 * l1 - l2) * 128;
+      else if (ln < 2 * l1 + 2 * l2) src = reinterpret_cast<const char*>(p.w2_lo) + (size_t)(ln - 2 * l1 - l2) * 128;
+      else if (ln < 2 * l1 + 2 * l2 + l3) src = reinterpret_cast<const char*>(p.w3_hi) + (size_t)(ln - 2 * l1 - 2 * l2) * 128;
+      else src = reinterpret_cast<const char*>(p.w3_lo) + (size_t)(ln - 2 * l1 - 2 * l2 - l3) * 128;
       glds4(src, (unsigned)(size_t)s_pf);
     }
     if (p.res) {                                   // this workgroup's residual rows (read by the first epilogue)
@@ -340,13 +343,244 @@ __global__ __launch_bounds__(NT_LAUNCH) void k_chain2(const ChainParams p) {
           o.y = st.y * (acc[ns][4 * g + 1] - st.x * uv.y) + bv.y;
           o.z = st.y * (acc[ns][4 * g + 2] - st.x * uv.z) + bv.z;
           o.w = st.y * (acc[ns][4 * g + 3] - st.x * uv.w) + bv.w;
-          *reinterpret_cast<float4*>(p.out2 + (size_t)m * p.ldo2 + n) = o;
+          if (!XA) *reinterpret_cast<float4*>(p.out2 + (size_t)m * p.ldo2 + n) = o;
+          else {
+            // the query of the cross attention stays in the workgroup: pre-scaled (d^-1/2 log2 e) split planes in the A
+            // region (the planes of x1 are dead: every wave has left the stage-2 k-loop)
+            const float q0 = o.x * p.xa_qscale, q1 = o.y * p.xa_qscale, q2 = o.z * p.xa_qscale, q3 = o.w * p.xa_qscale;
+            uint2 hw, lw;
+            hw.x = pk(q0, q1); hw.y = pk(q2, q3);
+            lw.x = pk(q0 - __uint_as_float(hw.x << 16), q1 - __uint_as_float(hw.x & 0xffff0000u));
+            lw.y = pk(q2 - __uint_as_float(hw.y << 16), q3 - __uint_as_float(hw.y & 0xffff0000u));
+            const int c = n >> 6, s16 = (n & 63) >> 3;
+            const int off = c * CHUNK_PL + l31 * 128 + ((s16 ^ swz(l31)) << 4) + ((n & 7) >> 2) * 8;
+            *reinterpret_cast<uint2*>(a_reg + off) = hw;
+            *reinterpret_cast<uint2*>(a_reg + A_PL + off) = lw;
+          }
         }
       }
     }
     if (ps == 0) DV_CTRACE(8);
   }
+  if constexpr (XA) {
+    // ================= cross attention: wave h = head h, 32 queries, keys / values as MFMA fragments from global =================
+    // Same arithmetic as k_attention (attn_tile.h): S^T = K Q^T and O^T += V^T P^T with split-bf16 operands (3 products),
+    // scores in the log2 domain, online softmax lane-local (lane = query, registers = keys), P never leaves registers.
+    stage_prologue(p.w3_hi, p.w3_lo, 0, bq);        // the output projection's first weight fragments fly under the attention
+    __syncthreads();                               // query planes complete
+    constexpr int d = 16 * NS, KSq = NS, NBv = NS == 3 ? 2 : 1;     // 8 heads: d = C / 8
+    const int nT = p.xa_nT;
+    const int h = wave, b_item = m0 / p.T;
+    bf16x8 qh[KSq], ql[KSq];
+#pragma unroll
+    for (int ks = 0; ks < KSq; ++ks) {
+      const int c16 = ((h * d + ks * 16) >> 3) + lh;
+      const int off = (c16 >> 3) * CHUNK_PL + l31 * 128 + (((c16 & 7) ^ swz(l31)) << 4);
+      qh[ks] = *reinterpret_cast<const bf16x8*>(a_reg + off);
+      ql[ks] = *reinterpret_cast<const bf16x8*>(a_reg + A_PL + off);
+    }
+    f32x16 o[NBv];
+#pragma unroll
+    for (int nb = 0; nb < NBv; ++nb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[nb][r] = 0.f;
+    float m_run = -1e30f, l_run = 0.f;
+    const size_t bh = (size_t)b_item * NWV + h;
+    const bf16x8* kfh = reinterpret_cast<const bf16x8*>(p.xa_kf_hi) + bh * nT * KSq * 64 + lane;
+    const bf16x8* kfl = reinterpret_cast<const bf16x8*>(p.xa_kf_lo) + bh * nT * KSq * 64 + lane;
+    const bf16x8* vfh = reinterpret_cast<const bf16x8*>(p.xa_vf_hi) + bh * nT * 2 * NBv * 64 + lane;
+    const bf16x8* vfl = reinterpret_cast<const bf16x8*>(p.xa_vf_lo) + bh * nT * 2 * NBv * 64 + lane;
+    const float* bias = p.xa_bias + (size_t)b_item * nT * 32 + 4 * lh;
+    __syncthreads();                               // every wave holds its query fragments: the A region may be rewritten
+    // K / V fragments and the key bias of tile t + 1 are requested before tile t is multiplied (pinned like the weight
+    // prefetch: the loads have no consumer in the current iteration and would otherwise sink to their use)
+    struct KVT { bf16x8 kh[KSq], kl[KSq], vh[2][NBv], vl[2][NBv]; float4 bv[4]; };
+    auto load_kv = [&](int t) {
+      KVT f;
+      const int tc = min(t, nT - 1);
+#pragma unroll
+      for (int ks = 0; ks < KSq; ++ks) { f.kh[ks] = kfh[(size_t)(tc * KSq + ks) * 64]; f.kl[ks] = kfl[(size_t)(tc * KSq + ks) * 64]; }
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int nb = 0; nb < NBv; ++nb) {
+          f.vh[kb][nb] = vfh[(size_t)((tc * 2 + kb) * NBv + nb) * 64];
+          f.vl[kb][nb] = vfl[(size_t)((tc * 2 + kb) * NBv + nb) * 64];
+        }
+#pragma unroll
+      for (int g = 0; g < 4; ++g) f.bv[g] = *reinterpret_cast<const float4*>(bias + tc * 32 + 8 * g);
+      return f;
+    };
+    KVT cur = load_kv(0);
+    for (int t = 0; t < nT; ++t) {
+      __builtin_amdgcn_sched_barrier(0);
+      KVT nxt = load_kv(t + 1);
+      __builtin_amdgcn_sched_barrier(0);
+      f32x16 sc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sc[r] = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < KSq; ++ks) {
+        sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cur.kl[ks], qh[ks], sc, 0, 0, 0);
+        sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cur.kh[ks], ql[ks], sc, 0, 0, 0);
+        sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cur.kh[ks], qh[ks], sc, 0, 0, 0);
+      }
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        sc[4 * g] += cur.bv[g].x; sc[4 * g + 1] += cur.bv[g].y; sc[4 * g + 2] += cur.bv[g].z; sc[4 * g + 3] += cur.bv[g].w;
+      }
+      float tmax = m_run;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) tmax = fmaxf(tmax, sc[r]);
+      const float m_new = fmaxf(tmax, __shfl_xor(tmax, 32));
+      const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+      m_run = m_new;
+      float psum = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { sc[r] = __builtin_amdgcn_exp2f(sc[r] - m_new); psum += sc[r]; }
+      l_run = l_run * alpha + psum;
+      if (__any(alpha != 1.0f)) {
+#pragma unroll
+        for (int nb = 0; nb < NBv; ++nb)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) o[nb][r] *= alpha;
+      }
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb) {
+        typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+        u32x4 hw, lw;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float x0 = sc[kb * 8 + 2 * e], x1 = sc[kb * 8 + 2 * e + 1];
+          const unsigned h2 = pk(x0, x1);
+          hw[e] = h2;
+          lw[e] = pk(x0 - __uint_as_float(h2 << 16), x1 - __uint_as_float(h2 & 0xffff0000u));
+        }
+        const bf16x8 ph = __builtin_bit_cast(bf16x8, hw), pl = __builtin_bit_cast(bf16x8, lw);
+#pragma unroll
+        for (int nb = 0; nb < NBv; ++nb) {
+          o[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cur.vl[kb][nb], ph, o[nb], 0, 0, 0);
+          o[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cur.vh[kb][nb], pl, o[nb], 0, 0, 0);
+          o[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cur.vh[kb][nb], ph, o[nb], 0, 0, 0);
+        }
+      }
+      cur = nxt;
+    }
+    {
+      const float inv = 1.0f / (l_run + __shfl_xor(l_run, 32));
+      // O (lane = query row, registers = channels 8g + 4lh + e of block nb) -> split planes in the A region, columns of head h
+#pragma unroll
+      for (int nb = 0; nb < NBv; ++nb)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int dv = nb * 32 + 8 * g + 4 * lh;
+          if (dv < d) {
+            const float v0 = o[nb][4 * g] * inv, v1 = o[nb][4 * g + 1] * inv, v2 = o[nb][4 * g + 2] * inv, v3 = o[nb][4 * g + 3] * inv;
+            uint2 hw, lw;
+            hw.x = pk(v0, v1); hw.y = pk(v2, v3);
+            lw.x = pk(v0 - __uint_as_float(hw.x << 16), v1 - __uint_as_float(hw.x & 0xffff0000u));
+            lw.y = pk(v2 - __uint_as_float(hw.y << 16), v3 - __uint_as_float(hw.y & 0xffff0000u));
+            const int n = h * d + dv, c = n >> 6, s16 = (n & 63) >> 3;
+            const int off = c * CHUNK_PL + l31 * 128 + ((s16 ^ swz(l31)) << 4) + ((n & 7) >> 2) * 8;
+            *reinterpret_cast<uint2*>(a_reg + off) = hw;
+            *reinterpret_cast<uint2*>(a_reg + A_PL + off) = lw;
+          }
+        }
+    }
+    __syncthreads();                               // attention output complete = A operand of stage 3
+    // ================= stage 3: x3 = O W3^T + b3 + x1 -> fp32, raw planes and LayerNorm row partials in global =================
+#pragma unroll
+    for (int ns = 0; ns < NS; ++ns)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[ns][r] = 0.f;
+    stage_loop(p.w3_hi, p.w3_lo, 0, bq, acc);
+    kgroup_reduce(acc, red_reg);
+    if (kg == 0) {
+      const int m = m0 + l31;
+#pragma unroll
+      for (int ns = 0; ns < NS; ++ns) {
+        const int nf = ns * 128 + wn * 32 + 4 * lh;
+        float vv[16];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const float4 bv = *reinterpret_cast<const float4*>(p.b3 + nf + 8 * g);
+          const float4 rr = *reinterpret_cast<const float4*>(p.out1 + (size_t)m * C + nf + 8 * g);   // x1, written by this workgroup
+          vv[4 * g] = acc[ns][4 * g] + bv.x + rr.x; vv[4 * g + 1] = acc[ns][4 * g + 1] + bv.y + rr.y;
+          vv[4 * g + 2] = acc[ns][4 * g + 2] + bv.z + rr.z; vv[4 * g + 3] = acc[ns][4 * g + 3] + bv.w + rr.w;
+        }
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const size_t o4 = (size_t)m * C + nf + 8 * g;
+          *reinterpret_cast<float4*>(p.out3 + o4) = make_float4(vv[4 * g], vv[4 * g + 1], vv[4 * g + 2], vv[4 * g + 3]);
+          uint2 hw, lw;
+          hw.x = pk(vv[4 * g], vv[4 * g + 1]); hw.y = pk(vv[4 * g + 2], vv[4 * g + 3]);
+          lw.x = pk(vv[4 * g] - __uint_as_float(hw.x << 16), vv[4 * g + 1] - __uint_as_float(hw.x & 0xffff0000u));
+          lw.y = pk(vv[4 * g + 2] - __uint_as_float(hw.y << 16), vv[4 * g + 3] - __uint_as_float(hw.y & 0xffff0000u));
+          *reinterpret_cast<uint2*>(p.out3_hi + o4) = hw;
+          *reinterpret_cast<uint2*>(p.out3_lo + o4) = lw;
+        }
+        float a = 0.f, q = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) a += vv[r];
+        a += __shfl_xor(a, 32);
+        const float mb = a * (1.0f / 32.0f);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) q += (vv[r] - mb) * (vv[r] - mb);
+        q += __shfl_xor(q, 32);
+        if (lh == 0) reinterpret_cast<float2*>(p.rowstat3)[(size_t)m * (C / 32) + ns * 4 + wn] = make_float2(a, q);
+      }
+    }
+  }
   DV_CTRACE(9);
+}
+
+// cross-attention K / V of one block, fp32 rows [B*L, 2C] (k | v), head h = columns [h*d, h*d + d) -> split-bf16 MFMA
+// fragments: K fragment (tile t, k-step ks): lane (l31, lh) = K[key t*32 + l31][ks*16 + lh*8 .. +8];  V^T fragment (tile t,
+// k-block kb, channel block nb): lane (l31, lh) = V[key(j)][nb*32 + l31], j = 0..7, key(j) = t*32 + kb*16 + (j < 4 ? 4 lh + j :
+// 8 + 4 lh + j - 4) - the order in which a lane of the S^T accumulator holds its keys.  Keys >= L and channels >= d are zero.
+__global__ __launch_bounds__(64) void k_kv_frag(const float* __restrict__ kv, bf16_t* __restrict__ kf_hi, bf16_t* __restrict__ kf_lo,
+                                                bf16_t* __restrict__ vf_hi, bf16_t* __restrict__ vf_lo, int L, int C, int H, int nT) {
+  const int t = blockIdx.x, h = blockIdx.y, b = blockIdx.z, lane = threadIdx.x, l31 = lane & 31, lh = lane >> 5;
+  const int d = C / H, KSq = d >> 4, NBv = (d + 31) >> 5;
+  const size_t bh = (size_t)b * H + h;
+  auto split8 = [&](const float (&v)[8], bf16_t* hi, bf16_t* lo) {
+    uint4 hw, lw;
+    unsigned* hp = &hw.x; unsigned* lp = &lw.x;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const unsigned h2 = pk(v[2 * e], v[2 * e + 1]);
+      hp[e] = h2;
+      lp[e] = pk(v[2 * e] - __uint_as_float(h2 << 16), v[2 * e + 1] - __uint_as_float(h2 & 0xffff0000u));
+    }
+    *reinterpret_cast<uint4*>(hi) = hw;
+    *reinterpret_cast<uint4*>(lo) = lw;
+  };
+  for (int ks = 0; ks < KSq; ++ks) {
+    const int key = t * 32 + l31;
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = key < L ? kv[((size_t)b * L + key) * 2 * C + h * d + ks * 16 + lh * 8 + j] : 0.f;
+    const size_t e = ((bh * nT + t) * KSq + ks) * 64 + lane;
+    split8(v, kf_hi + e * 8, kf_lo + e * 8);
+  }
+  for (int kb = 0; kb < 2; ++kb)
+    for (int nb = 0; nb < NBv; ++nb) {
+      const int ch = nb * 32 + l31;
+      float v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int key = t * 32 + kb * 16 + (j < 4 ? 4 * lh + j : 8 + 4 * lh + j - 4);
+        v[j] = (key < L && ch < d) ? kv[((size_t)b * L + key) * 2 * C + C + h * d + ch] : 0.f;
+      }
+      const size_t e = (((bh * nT + t) * 2 + kb) * NBv + nb) * 64 + lane;
+      split8(v, vf_hi + e * 8, vf_lo + e * 8);
+    }
+}
+__global__ void k_xbias(const float* __restrict__ mb, float* __restrict__ out, int B, int L, int Lp) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * Lp) return;
+  const int b = i / Lp, k = i - b * Lp;
+  out[i] = k < L ? (mb ? mb[(size_t)b * L + k] * 1.44269504088896340736f : 0.f) : -1e30f;
 }
 
 // packed weights [rows][Kp] (k contiguous) -> fragment-major: the 16-byte operand pieces of the 64 lanes of one
@@ -357,15 +591,15 @@ __global__ __launch_bounds__(64) void k_relayout_frag(const bf16_t* __restrict__
   *reinterpret_cast<uint4*>(dst + ((size_t)(nf * ksteps + ks) * 64 + lane) * 8) = v;
 }
 
-template <int NS, int AMODE>
+template <int NS, int AMODE, bool XA = false>
 hipError_t init_one() {
   const int smem = 2 * 2 * NS * CHUNK_PL + NS * 16384;
-  return hipFuncSetAttribute(reinterpret_cast<const void*>(k_chain2<NS, AMODE>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+  return hipFuncSetAttribute(reinterpret_cast<const void*>(k_chain2<NS, AMODE, XA>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
 }
-template <int NS, int AMODE>
+template <int NS, int AMODE, bool XA = false>
 hipError_t launch_one(const ChainParams& p, hipStream_t st) {
   const int smem = 2 * 2 * NS * CHUNK_PL + NS * 16384;
-  hipLaunchKernelGGL((k_chain2<NS, AMODE>), dim3(p.M / BM), dim3(NT_LAUNCH), smem, st, p);
+  hipLaunchKernelGGL((k_chain2<NS, AMODE, XA>), dim3(p.M / BM), dim3(XA ? NT : NT_LAUNCH), smem, st, p);
   return hipGetLastError();
 }
 
@@ -380,7 +614,22 @@ hipError_t chain_init() {
   if ((e = init_one<1, 1>()) != hipSuccess) return e;
   if ((e = init_one<2, 1>()) != hipSuccess) return e;
   if ((e = init_one<3, 1>()) != hipSuccess) return e;
-  return init_one<4, 1>();
+  if ((e = init_one<4, 1>()) != hipSuccess) return e;
+  if ((e = init_one<1, 0, true>()) != hipSuccess) return e;
+  return init_one<2, 0, true>();   // (C = 384 with the attention inside needs > 256 VGPRs: it keeps the separate launches)
+}
+
+hipError_t launch_kv_frag(const float* kv, bf16_t* kf_hi, bf16_t* kf_lo, bf16_t* vf_hi, bf16_t* vf_lo, int B, int L, int C, int H,
+                          hipStream_t st) {
+  if (H <= 0 || C % H != 0 || (C / H) % 16 != 0 || C / H > 64) return hipErrorInvalidValue;
+  const int nT = (L + 31) / 32;
+  hipLaunchKernelGGL(k_kv_frag, dim3(nT, H, B), dim3(64), 0, st, kv, kf_hi, kf_lo, vf_hi, vf_lo, L, C, H, nT);
+  return hipGetLastError();
+}
+hipError_t launch_xbias(const float* mask_bias, float* out, int B, int L, int nT, hipStream_t st) {
+  const int n = B * nT * 32;
+  hipLaunchKernelGGL(k_xbias, dim3((n + 255) / 256), dim3(256), 0, st, mask_bias, out, B, L, nT * 32);
+  return hipGetLastError();
 }
 
 hipError_t launch_relayout_frag(const bf16_t* src, bf16_t* dst, int rows, int Kp, hipStream_t st) {
@@ -394,6 +643,14 @@ bool chain2_supported(const ChainParams& p, int precision) {
   if (p.C != 128 && p.C != 256 && p.C != 384) return false;   // (512 is instantiated; measured slower than one launch per GEMM)
   if (p.M % 32 != 0 || p.T % 32 != 0 || p.M % p.T != 0 || p.passes < 1) return false;
   if (p.Kp1 != p.C || p.Kp2 != p.C) return false;
+  if (p.xa_kf_hi) {                                                    // cross-attention tail: wave = head
+    if (p.amode != 0 || p.passes != 1 || p.C % 8 != 0) return false;
+    const int d = p.C / 8;
+    if (d != p.xa_d || (d != 16 && d != 32) || p.xa_nT < 1) return false;
+    if (!p.xa_kf_lo || !p.xa_vf_hi || !p.xa_vf_lo || !p.xa_bias || !p.w3_hi || !p.w3_lo || !p.b3 || !p.out3 || !p.out3_hi || !p.out3_lo ||
+        !p.rowstat3)
+      return false;
+  }
   if (p.amode == 1) {
     const int G = p.groups;
     if (G <= 0 || G > 64 || (G & (G - 1)) != 0 || p.C % G != 0 || (p.C / G) % 16 != 0) return false;
@@ -404,9 +661,10 @@ bool chain2_supported(const ChainParams& p, int precision) {
 
 hipError_t launch_chain2(const ChainParams& p, int precision, hipStream_t st) {
   if (!chain2_supported(p, precision)) return hipErrorInvalidValue;
-  if (!p.w1_hi || !p.w1_lo || !p.w2_hi || !p.w2_lo || !p.b1 || !p.b2 || !p.u2 || !p.out1 || !p.out2) return hipErrorInvalidValue;
+  if (!p.w1_hi || !p.w1_lo || !p.w2_hi || !p.w2_lo || !p.b1 || !p.b2 || !p.u2 || !p.out1 || (!p.out2 && !p.xa_kf_hi)) return hipErrorInvalidValue;
   if (p.amode == 0 ? (!p.a_hi || !p.a_lo) : (!p.x || !p.stat16 || !p.gamma || !p.beta)) return hipErrorInvalidValue;
   const int ns = p.C / 128;
+  if (p.xa_kf_hi) return ns == 1 ? launch_one<1, 0, true>(p, st) : launch_one<2, 0, true>(p, st);
   if (p.amode == 0)
     return ns == 1 ? launch_one<1, 0>(p, st) : (ns == 2 ? launch_one<2, 0>(p, st) : (ns == 3 ? launch_one<3, 0>(p, st) : launch_one<4, 0>(p, st)));
   return ns == 1 ? launch_one<1, 1>(p, st) : (ns == 2 ? launch_one<2, 1>(p, st) : (ns == 3 ? launch_one<3, 1>(p, st) : launch_one<4, 1>(p, st)));

@@ -511,6 +511,37 @@ def test_unet_unfused_layernorm_mode(gold):
     assert m2.hip_engine().prepare(2, 100, 50) and m2.hip_engine().stats()[0] == n_launch - 64
 
 
+def test_row_block_chains_match_one_launch_per_gemm():
+    """Default schedule: the K = C GEMM chains of a transformer block run as row-block chain kernels (kernels_chain.hip:
+    GroupNorm -> proj_in -> LN -> q|k|v in one launch; attention -> to_out + residual -> LN -> to_q [-> cross attention ->
+    to_out + residual -> LN partials] in one launch).  DVITS_CHAIN=0 / DVITS_CHAIN_XATTN=0 restore the per-GEMM launches:
+    same weights, same arithmetic (split-bf16 products, folded LayerNorm), different summation order only - agreement to
+    float32 rounding, launch counts tell the schedules apart, and all three meet the reference's golden output."""
+    from diff_vits_amd import synth
+    from diff_vits_amd.unet1d.unet_1d_condition import UNet1DConditionModel
+    kw, sd, sample, t, enc, mask = unet_case("cfg1")
+    outs, launches = [], []
+    for chain, xattn in (("0", "1"), ("1", "0"), ("1", "1")):
+        os.environ["DVITS_CHAIN"], os.environ["DVITS_CHAIN_XATTN"] = chain, xattn
+        try:
+            m = UNet1DConditionModel(backend="hip", **kw).eval()
+            m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+            m = m.cuda()
+            with torch.no_grad():
+                y = m(torch.from_numpy(sample).cuda(), torch.from_numpy(t).cuda(), torch.from_numpy(enc).cuda(),
+                      encoder_attention_mask=torch.from_numpy(mask).cuda()).sample
+            outs.append(y.cpu().numpy())
+            launches.append(m.hip_engine().stats()[0])
+        finally:
+            os.environ.pop("DVITS_CHAIN", None)
+            os.environ.pop("DVITS_CHAIN_XATTN", None)
+    assert launches[0] > launches[1] > launches[2], launches
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "unet_cfg1.npz"))["y"]
+    for y in outs:
+        assert rel_l2(y, g) < 2e-4
+    assert rel_l2(outs[1], outs[0]) < 5e-5 and rel_l2(outs[2], outs[0]) < 5e-5
+
+
 def test_persistent_per_xcd_schedule_matches_per_launch():
     """DVITS_PERSIST=1 (csrc/persist.hip): the body of a forward as ONE launch with XCD-local barriers, utterance b on
     XCD b % 8.  Same kernels' tile routines (L1-bypassing loads), different tile menu: agreement with the per-launch
@@ -660,7 +691,7 @@ def test_unet_large_mean_activations_within_budget():
                      encoder_attention_mask=torch.from_numpy(mask).cuda()).sample.cpu().numpy()
     err = rel_l2(y, ref)
     print("large-mean activations: rel-L2 %.2e" % err)
-    assert err < 1e-3
+    assert err < 2e-4          # measured 1.8e-6 on MI355X (round 2); the path's budget is 1e-3
 
 
 def test_unet_mask_edge_cases():
