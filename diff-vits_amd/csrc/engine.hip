@@ -475,7 +475,12 @@ struct Builder {
     return fuse_gn && !arena.exact && Tn % 32 == 0 && C % 64 == 0 && C % G == 0 && (C / G) % 16 == 0;
   }
   void alloc_stat(Act& a, bool want16 = false) {
-    if (a.T % 32 != 0) return;
+    // 32-row blocks of the flat [B*T] row space must not span utterances: T % 32 == 0, or ONE utterance (its last block is
+    // partial: rows beyond M contribute zeros) - the single-utterance case is the real inference call (B = 1, any T)
+    if (a.T % 32 != 0) {
+      if (B == 1) a.stat = alloc((size_t)((a.T + 31) / 32) * a.C * 2);
+      return;
+    }
     if (want16 || af_tensor(a.T, a.C)) a.stat16 = alloc((size_t)(B * a.T / 32) * (a.C / 16) * 2);
     else a.stat = alloc((size_t)(B * a.T / 32) * a.C * 2);
   }

@@ -78,7 +78,7 @@ __device__ __forceinline__ void gn_apply_body(const GnApplyParams& p, int rows_p
       s_shift[c] = ld_mut1<SC1>(p.shift_in + (size_t)b * ctot + cbase + c);
     }
   } else {
-    const int RB = p.T >> 5;             // 32-row blocks per batch item (T % 32 == 0)
+    const int RB = (p.T + 31) >> 5;      // 32-row blocks per batch item (T % 32 == 0, or B == 1 with a partial last block)
     double s1 = 0, s2 = 0;
     for (int item = tid; item < cg * RB; item += NT) {
       const int rb = item / cg, c = cbase + (item - rb * cg);

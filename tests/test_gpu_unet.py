@@ -139,6 +139,24 @@ def test_unet_vs_golden(name, gold):
     assert err < 2e-4, err
 
 
+def test_unet_single_utterance_odd_length(gold):
+    """The real inference call is ONE utterance of arbitrary length.  With B = 1 the 32-frame statistics blocks cannot span
+    utterances, so the one-launch GroupNorm path (statistics from the producer's epilogue slab, partial last block) is
+    used for any T instead of the three-launch general path.  Item 0 of the odd-T golden case (T = 100) alone: same
+    output as inside the batch (utterances are independent), fewer launches than the B = 2 schedule."""
+    m, kw, sd, sample, t, enc, mask = _build("oddT")
+    with torch.no_grad():
+        y1 = m(torch.from_numpy(sample[:1]).cuda(), torch.from_numpy(t[:1]).cuda(), torch.from_numpy(enc[:1]).cuda(),
+               encoder_attention_mask=torch.from_numpy(mask[:1]).cuda()).sample
+    n1 = m.hip_engine().stats()[0]
+    with torch.no_grad():
+        m(torch.from_numpy(sample).cuda(), torch.from_numpy(t).cuda(), torch.from_numpy(enc).cuda(),
+          encoder_attention_mask=torch.from_numpy(mask).cuda())
+    n2 = m.hip_engine().stats()[0]
+    assert rel_l2(y1.cpu().numpy(), gold("unet_oddT.npz")["y"][:1]) < 2e-4
+    assert n1 < n2 - 60, (n1, n2)        # 61 GroupNorms: one launch each instead of three
+
+
 def test_unet_bf16_fast_mode(gold):
     m, kw, sd, sample, t, enc, mask = _build("cfg1", "bf16")
     with torch.no_grad():
