@@ -191,6 +191,9 @@ hipError_t launch_split(const float* in, bf16_t* hi, bf16_t* lo, int64_t n, hipS
 struct GnApplyParams {
   const float* a0; const float* a1; int c0, c1;
   const float* slab0; const float* slab1;
+  // alternative statistics: per (32-frame, 16-channel) block (sum, M2 about the block mean), [B*T/32][c/16][2] per source
+  // (gemm_tile.h stats16): 16x fewer entries to reduce, no E[x^2] - mean^2 cancellation
+  const float* st16_0; const float* st16_1;
   const float* scale_in; const float* shift_in;
   const float* gamma; const float* beta; float eps; int groups;
   const float* tscale; const float* tshift; int ld_t;

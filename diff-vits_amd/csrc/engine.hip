@@ -481,8 +481,18 @@ struct Builder {
       if (B == 1) a.stat = alloc((size_t)((a.T + 31) / 32) * a.C * 2);
       return;
     }
-    if (want16 || af_tensor(a.T, a.C)) a.stat16 = alloc((size_t)(B * a.T / 32) * (a.C / 16) * 2);
+    if (want16 || af_tensor(a.T, a.C) || stat16_everywhere()) a.stat16 = alloc((size_t)(B * a.T / 32) * (a.C / 16) * 2);
     else a.stat = alloc((size_t)(B * a.T / 32) * a.C * 2);
+  }
+  // every level has whole 16-channel blocks per GroupNorm group: all tensors carry block statistics (16x fewer entries
+  // for k_gn_apply to reduce, cheaper producer epilogue); otherwise (tiny / duration-predictor configurations) per-column slabs
+  bool stat16_everywhere() const {
+    static const bool off = [] { const char* e = getenv("DVITS_STAT16"); return e && e[0] == '0'; }();
+    if (off || arena.exact) return false;
+    const int G = u->cfg.norm_num_groups;
+    for (int i = 0; i < u->cfg.n_levels; ++i)
+      if (u->cfg.block_out_channels[i] % G != 0 || (u->cfg.block_out_channels[i] / G) % 16 != 0) return false;
+    return true;
   }
   void stat_out(GemmParams& g, const Act& a) { g.stats = a.stat; g.stats16 = a.stat16; }
   // Row-block chains of a transformer block (kernels_chain.hip; DVITS_CHAIN=0 restores one launch per GEMM):
@@ -521,7 +531,7 @@ struct Builder {
   // optionally the raw [r0 | r1] as segment 1 (1x1 shortcut).  False if the shapes are outside what the AF tiles take.
   bool af_setup(GemmParams& g, Act a0, Act a1, int taps, const std::string& pre, float eps, const float* tscale,
                 const float* tshift, int ld_t, bool silu, const Act* r0 = nullptr, const Act* r1 = nullptr) {
-    if (!a0.stat16 || (a1.C > 0 && !a1.stat16)) return false;
+    if (!fuse_gn || !a0.stat16 || (a1.C > 0 && !a1.stat16)) return false;
     g.af = 1;
     g.seg[0] = GemmSeg{}; g.seg[0].c0 = a0.C; g.seg[0].c1 = a1.C; g.seg[0].taps = taps; g.seg[0].pad = (taps - 1) / 2;
     g.afp = AfParams{};
@@ -605,8 +615,10 @@ struct Builder {
     gp.tscale = tscale; gp.tshift = tshift; gp.ld_t = ld_t; gp.silu = silu ? 1 : 0;
     gp.B = B; gp.T = Tn;
     float* sc = nullptr; float* sh = nullptr;
-    const bool fast = a0.stat && (a1.C == 0 || a1.stat);
-    if (fast) { gp.slab0 = a0.stat; gp.slab1 = a1.stat; }
+    const bool fast16 = a0.stat16 && (a1.C == 0 || a1.stat16) && ((a0.C + a1.C) / G) % 16 == 0 && a0.C % 16 == 0;
+    const bool fast = fast16 || (a0.stat && (a1.C == 0 || a1.stat));
+    if (fast16) { gp.st16_0 = a0.stat16; gp.st16_1 = a1.stat16; }
+    else if (fast) { gp.slab0 = a0.stat; gp.slab1 = a1.stat; }
     else {
       const int nchunk = std::max(1, std::min(64, (Tn + 63) / 64));
       double* part = reinterpret_cast<double*>(alloc((size_t)B * nchunk * G * 2 * 2));
@@ -628,7 +640,7 @@ struct Builder {
     cur_kind = "gn_apply";
     {
       char buf[96];
-      snprintf(buf, sizeof(buf), "T=%d C=%d%s%s", Tn, C, fast ? " slab" : " table", raw_out ? " +raw" : "");
+      snprintf(buf, sizeof(buf), "T=%d C=%d%s%s", Tn, C, fast16 ? " blockstats" : (fast ? " slab" : " table"), raw_out ? " +raw" : "");
       cur_desc = buf;
     }
     PersistOp po{};
@@ -638,7 +650,7 @@ struct Builder {
       po.gn_rpb = (Tn + po.gn_chunks - 1) / po.gn_chunks;
       po.gn_chunks = (Tn + po.gn_rpb - 1) / po.gn_rpb;
     }
-    emit(ops, [gp](hipStream_t st) { return launch_gn_apply(gp, st); }, fast ? &po : nullptr);
+    emit(ops, [gp](hipStream_t st) { return launch_gn_apply(gp, st); }, (fast && !fast16) ? &po : nullptr);
     if (sc) { release(sc); release(sh); }
     return out;
   }

@@ -81,7 +81,9 @@ hipError_t launch_gn_apply(const GnApplyParams& p, hipStream_t st) {
   const int cg = ctot / p.groups;
   if (cg % 4 != 0 || p.c0 % 4 != 0 || cg > 512 || p.groups > 64) return hipErrorInvalidValue;
   // slab statistics: 32-row blocks must not span utterances (T % 32 == 0, or a single utterance whose last block is partial)
-  if (!p.scale_in && ((p.T % 32 != 0 && p.B != 1) || !p.slab0 || (p.c1 && !p.slab1))) return hipErrorInvalidValue;
+  if (!p.scale_in && p.st16_0) {
+    if (p.T % 32 != 0 || cg % 16 != 0 || p.c0 % 16 != 0 || (p.c1 && !p.st16_1) || cg > 512) return hipErrorInvalidValue;
+  } else if (!p.scale_in && ((p.T % 32 != 0 && p.B != 1) || !p.slab0 || (p.c1 && !p.slab1))) return hipErrorInvalidValue;
   // ~1024 workgroups: (frame chunks) x groups x batch  (DVITS_GN_WGS: experiment knob)
   static const int target = [] { const char* e = getenv("DVITS_GN_WGS"); return e ? atoi(e) : 1024; }();
   int chunks = target / (p.groups * p.B);

@@ -77,6 +77,49 @@ __device__ __forceinline__ void gn_apply_body(const GnApplyParams& p, int rows_p
       s_scale[c] = ld_mut1<SC1>(p.scale_in + (size_t)b * ctot + cbase + c);
       s_shift[c] = ld_mut1<SC1>(p.shift_in + (size_t)b * ctot + cbase + c);
     }
+  } else if (p.st16_0) {
+    // block statistics: the group's RB x (cg / 16) entries are reduced by the first wave in one pass (fp64), while every
+    // thread already holds the affine parameters of its channels (fetched before the statistics arrive)
+    const int RB = p.T >> 5, nvb = cg >> 4;
+    float pg[2], pb[2], pts[2], ptb[2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int cc = cbase + min(tid + k * NT, cg - 1);
+      pg[k] = p.gamma[cc];
+      pb[k] = p.beta[cc];
+      pts[k] = p.tscale ? 1.0f + ld_mut1<SC1>(p.tscale + (size_t)b * p.ld_t + cc) : 1.0f;
+      ptb[k] = p.tshift ? ld_mut1<SC1>(p.tshift + (size_t)b * p.ld_t + cc) : 0.0f;
+    }
+    if (tid < 64) {
+      double s1 = 0, q = 0;
+      for (int e = tid; e < RB * nvb; e += 64) {
+        const int rb = e / nvb, vb = g * nvb + (e - rb * nvb);
+        const bool first = vb * 16 < p.c0;
+        const float2* st = reinterpret_cast<const float2*>(first ? p.st16_0 : p.st16_1);
+        const int nb = (first ? p.c0 : p.c1) >> 4, vbl = first ? vb : vb - (p.c0 >> 4);
+        const float2 v = ld_mut2<SC1>(st + (size_t)(b * RB + rb) * nb + vbl);
+        s1 += (double)v.x;
+        q += (double)v.y + (double)v.x * (double)v.x * (1.0 / 512.0);      // = the block's sum of squares
+      }
+      s1 = wave_sum_d(s1);
+      q = wave_sum_d(q);
+      if (tid == 0) { s_red[0] = s1; s_red[1] = q; }
+    }
+    __syncthreads();
+    const double n = (double)cg * (double)p.T;
+    const double mean = s_red[0] / n;
+    double var = s_red[1] / n - mean * mean;
+    var = var > 0 ? var : 0;
+    const float rstd = (float)(1.0 / sqrt(var + (double)p.eps));
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int c = tid + k * NT;
+      if (c < cg) {
+        const float a = rstd * pg[k];
+        s_scale[c] = a * pts[k];
+        s_shift[c] = fmaf(pb[k] - (float)mean * a, pts[k], ptb[k]);
+      }
+    }
   } else {
     const int RB = (p.T + 31) >> 5;      // 32-row blocks per batch item (T % 32 == 0, or B == 1 with a partial last block)
     double s1 = 0, s2 = 0;
