@@ -43,6 +43,23 @@ struct AfParams {
   float eps;
 };
 
+// GroupNorm of the GEMM's OWN output finished in its epilogue (gemm_tile.h "GNX"): every workgroup publishes the
+// 32x16-block statistics of its tile in an exchange buffer (8-byte words, written through), polls the words of its
+// groups until all of the utterance's tiles have published (EMPTY = all ones; the first kernel of every forward resets
+// the buffer), reduces them (fp64, fixed order) and writes y = SiLU(GN(v) * (1 + tscale) + tshift) as split planes
+// straight from the accumulator registers: the consumer's k_gn_apply launch and the fp32 round trip of the
+// intermediate disappear.  No counters and no read-modify-write atomics: a launch inside a hipGraph cannot be told its
+// sequence number, and a counter round trip sits on every workgroup's critical path.  All waiting workgroups must be
+// resident at once: launch_gemm refuses grids larger than the device's CU count (gemm_gnx_plan()).
+struct GnxParams {
+  unsigned long long* xchg;      // null: off.  [M / 32][N / 16] (sum | M2 << 32) words of THIS op, EMPTY before the launch
+  unsigned* status;              // set to 1 if a wait timed out (results invalid; the host checks after the run)
+  const float* gamma; const float* beta;   // [N]
+  const float* tscale; const float* tshift; int ld_t;   // temb scale / shift rows [B, ld_t] or null
+  int groups; float eps; int silu;
+  bf16_t* y_hi; bf16_t* y_lo;    // normalised split planes [M, N]
+};
+
 struct GemmParams {
   GemmSeg seg[2];
   int nseg;
@@ -87,7 +104,11 @@ struct GemmParams {
   int force_tile;               // 0: launch_gemm's shape heuristic; else a GT_* tile of the menu (set by the prepare-time tuner)
   int af;                       // 1: A operand produced in-kernel from afp (plane pointers of seg[] unused); T_out % 32 == 0
   AfParams afp;
+  GnxParams gnx;                // GroupNorm of the output in the epilogue (needs stats16)
 };
+// exchange words a GNX GEMM needs (M / 32 * N / 16), or 0 if launch_gemm would refuse it (tile shape vs T_out / groups,
+// more workgroups than `n_cu` compute units, unsupported epilogue)
+int gemm_gnx_plan(const GemmParams& p, int n_cu);
 // tile menu ids (kernels_gemm.hip); GT_BK64 is or-ed in when the tile runs 64-deep k-tiles
 enum { GT_AUTO = 0, GT_T0 = 1, GT_T1 = 2, GT_T2 = 3, GT_T2S = 4, GT_T2G = 5, GT_T3 = 6, GT_T4 = 7, GT_T4G = 8, GT_AF64 = 9, GT_AF32 = 10,
        GT_BK64 = 0x100 };
@@ -245,7 +266,9 @@ hipError_t launch_small_linear(const float* in, int ldin, const float* W, const 
 hipError_t launch_small_linear_t(const float* in, int ldin, const float* Wt, const float* b, const float* add, float* out,
                                  int ldo, int M, int K, int N, int silu_in, int silu_out, hipStream_t st);
 hipError_t launch_transpose_f32(const float* src, float* dst, int R, int Cc, hipStream_t st);
-hipError_t launch_timestep_sincos(const float* t, float* out, int B, int dim, hipStream_t st);
+// (reset / reset_words: 8-byte words the kernel also sets to all ones - the GnxParams exchange buffers; even count)
+hipError_t launch_timestep_sincos(const float* t, float* out, int B, int dim, hipStream_t st, unsigned long long* reset = nullptr,
+                                  size_t reset_words = 0);
 hipError_t launch_layernorm_rows(const float* x, const float* g, const float* b, float* out, int M, int C,
                                  float eps, hipStream_t st);
 // attention pooling pieces (reference embeddings.py:499-546)

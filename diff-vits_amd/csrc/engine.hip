@@ -154,6 +154,14 @@ struct dv_unet {
   char* slab = nullptr; size_t slab_bytes = 0;
   bf16_t* zero_page = nullptr;               // 256 zero bytes: source of padded rows for the LDS-DMA
   unsigned* sk_tickets = nullptr;            // per-tile arrival counters of the fused split-K pairs (zero between launches)
+  // GroupNorm finished in the producer GEMM's epilogue (GnxParams): the ops' exchange words (one pool, reset to EMPTY by
+  // the first kernel of every forward) and the time-out flag, in host memory the device writes through (read without a
+  // synchronisation)
+  static constexpr size_t GNX_POOL = (size_t)1 << 19;   // 8-byte words (4 MiB)
+  unsigned long long* gnx_pool = nullptr;
+  size_t gnx_words = 0;                      // words in use by the prepared schedule
+  unsigned* gnx_status = nullptr;
+  int gnx_ops = 0;
   std::vector<OpFn> step_ops, cond_ops;
   // GEMM launch parameters live here (stable addresses): the prepare-time tuner rewrites their tile choice in place
   std::vector<std::unique_ptr<GemmParams>> gemm_store;
@@ -190,6 +198,7 @@ static void unet_release_prepared(dv_unet* u, bool keep_packed = false) {
   u->owned.clear();
   u->zero_page = nullptr;
   u->sk_tickets = nullptr;
+  u->gnx_pool = nullptr; u->gnx_words = 0; u->gnx_ops = 0;
   if (!keep_packed) unet_release_packed(u);
   if (u->slab) (void)hipFree(u->slab);
   u->slab = nullptr; u->slab_bytes = 0;
@@ -228,6 +237,7 @@ extern "C" void dv_unet_destroy(dv_unet* u) {
   if (!u) return;
   (void)hipDeviceSynchronize();
   unet_release_prepared(u);
+  if (u->gnx_status) (void)hipHostFree(u->gnx_status);
   for (auto& kv : u->w)
     if (kv.second.p) (void)hipFree(kv.second.p);
   delete u;
@@ -558,6 +568,42 @@ struct Builder {
     return true;
   }
 
+  // GroupNorm (+ temb scale/shift) (+ SiLU) of a GEMM's own output finished in ITS epilogue (gemm_tile.h GNX; DVITS_GNX=0
+  // restores the k_gn_apply launch): fills g.gnx and allocates the normalised planes; false if launch_gemm would refuse.
+  // Call after g's segments, epilogue and statistics slab are set.
+  bool gnx_on = [] { const char* e = getenv("DVITS_GNX"); return !(e && e[0] == '0'); }();
+  size_t gnx_used = 0;
+  int n_cu = [] { int d = 0, n = 0; if (hipGetDevice(&d) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, d) != hipSuccess) n = 0; return n; }();
+  bool gnx_setup(GemmParams& g, const std::string& pre, float eps, const float* tscale, const float* tshift, int ld_t, bool silu,
+                 Planes* y) {
+    if (!gnx_on || arena.exact || autotune_on() || !g.stats16 || n_cu <= 0) return false;
+    GemmParams t = g;
+    t.B = B;
+    t.gnx = GnxParams{};
+    t.gnx.groups = u->cfg.norm_num_groups;
+    int k_pad = 0;
+    for (int s2 = 0; s2 < t.nseg; ++s2) k_pad += t.seg[s2].taps * (t.seg[s2].c0 + t.seg[s2].c1);
+    t.sk_split = gemm_splitk_plan(t.M, t.N, k_pad, t.epi);
+    if (t.sk_split >= 2) {
+      const char* fe = getenv("DVITS_SPLITK_FUSED");
+      if ((fe && fe[0] == '0') || ((t.M + 31) / 32) * ((t.N + 31) / 32) > 4096) return false;   // (two launches: see gemm())
+      t.sk_buf = reinterpret_cast<float*>(0x1000); t.sk_ticket = reinterpret_cast<unsigned*>(0x1000);
+    }
+    const int nw = gemm_gnx_plan(t, n_cu);
+    if (nw <= 0 || gnx_used + (size_t)nw > dv_unet::GNX_POOL) return false;
+    g.gnx = t.gnx;
+    g.gnx.gamma = W(pre + ".weight"); g.gnx.beta = W(pre + ".bias"); g.gnx.eps = eps;
+    g.gnx.tscale = tscale; g.gnx.tshift = tshift; g.gnx.ld_t = ld_t; g.gnx.silu = silu ? 1 : 0;
+    g.gnx.xchg = dry ? reinterpret_cast<unsigned long long*>(0x1000) : u->gnx_pool + gnx_used;
+    g.gnx.status = dry ? reinterpret_cast<unsigned*>(0x1000) : u->gnx_status;
+    gnx_used += ((size_t)nw + 1) & ~(size_t)1;
+    if (!dry) u->gnx_words = gnx_used;
+    *y = alloc_planes((size_t)g.M * g.N);
+    g.gnx.y_hi = y->hi; g.gnx.y_lo = y->lo;
+    if (!dry) u->gnx_ops++;
+    return true;
+  }
+
   void gemm(std::vector<OpFn>& ops, GemmParams g, const PackedW* pw, int k_real) {
     g.w_hi = pw->hi; g.w_lo = pw->lo; g.Kp = pw->Kp; g.N_pad = pw->N_pad;
     if (!g.bias) g.bias = pw->bias;
@@ -567,8 +613,9 @@ struct Builder {
     cur_kind = "gemm"; cur_flops = 2.0 * (double)g.M * (double)g.N * (double)k_real;
     {
       char buf[128];
-      snprintf(buf, sizeof(buf), "M=%d N=%d K=%d taps=%d nseg=%d epi=%d stride=%d up=%d%s%s", g.M, g.N, k_real, g.seg[0].taps,
-               g.nseg, g.epi, g.stride, g.up_mode, (g.stats || g.stats16) ? " +stats" : "", g.af ? " +gn" : "");
+      snprintf(buf, sizeof(buf), "M=%d N=%d K=%d taps=%d nseg=%d epi=%d stride=%d up=%d%s%s%s", g.M, g.N, k_real, g.seg[0].taps,
+               g.nseg, g.epi, g.stride, g.up_mode, (g.stats || g.stats16) ? " +stats" : "", g.af ? " +gn" : "",
+               g.gnx.xchg ? " +gnx" : "");
       cur_desc = buf;
     }
     u->flops += dry ? 0.0 : cur_flops;
@@ -697,6 +744,9 @@ struct Builder {
     h.p = alloc((size_t)M * cout); h.C = cout; h.T = Tn; alloc_stat(h);
     Planes raw;
     bool raw_made = false;
+    const int toff = tproj_off[p];
+    Planes n2x;                   // norm2(h) planes written by conv1's own epilogue (gnx_setup), if it can
+    bool gnx1 = false;
     // both convs of a block take the fused path or neither (conv2's folded shortcut reads the raw fp32 input)
     bool fused = false;
     {
@@ -714,13 +764,14 @@ struct Builder {
         Planes n1 = norm_apply(ops, x0, x1, p + "norm1", eps, nullptr, nullptr, 0, true, shortcut ? &raw : nullptr);
         raw_made = shortcut;
         g.seg[0] = seg(n1, cin, Planes{}, 0, 3, 1);
+        gnx1 = gnx_setup(g, p + "norm2", eps, tproj + toff, tproj + toff + cout, tproj_total, true, &n2x);
+        if (gnx1 && !u->keep_intermediates) g.out = nullptr;   // h is only ever read through norm2
         gemm(ops, g, w1, 3 * cin);
         release(n1);
       }
     }
     probe(p + "conv1", h.p, Tn, cout);
 
-    const int toff = tproj_off[p];
     const int K2 = 3 * cout + (shortcut ? cin : 0);
     std::vector<Piece> pcs = {{p + "conv2.weight", 1, cout, 3, cout, 0, 0, "", 0}};
     std::vector<BiasPiece> bps = {{p + "conv2.bias", shortcut ? p + "conv_shortcut.bias" : "", "", "", cout, 0, 0, 0}};
@@ -744,7 +795,7 @@ struct Builder {
         gemm(ops, g, w2, K2);
       else {
         g.af = 0;
-        Planes n2 = norm_apply(ops, h, Act{}, p + "norm2", eps, tproj + toff, tproj + toff + cout, tproj_total, true, nullptr);
+        Planes n2 = gnx1 ? n2x : norm_apply(ops, h, Act{}, p + "norm2", eps, tproj + toff, tproj + toff + cout, tproj_total, true, nullptr);
         g.seg[0] = seg(n2, cout, Planes{}, 0, 3, 1);
         g.nseg = 1;
         if (shortcut) { g.seg[1] = seg(raw, cin, Planes{}, 0, 1, 0); g.nseg = 2; }
@@ -1116,6 +1167,17 @@ struct Builder {
         u->owned.push_back(z);
         u->zero_page = reinterpret_cast<bf16_t*>(z);
       }
+      if (!u->gnx_pool) {
+        void* z = nullptr;
+        if (hipMalloc(&z, dv_unet::GNX_POOL * 8) != hipSuccess) return dv_fail(DV_ERR_HIP, "hipMalloc(GroupNorm exchange words) failed");
+        (void)hipMemsetAsync(z, 0xff, dv_unet::GNX_POOL * 8, pack_stream);
+        u->owned.push_back(z);
+        u->gnx_pool = reinterpret_cast<unsigned long long*>(z);
+      }
+      if (!u->gnx_status) {
+        if (hipHostMalloc((void**)&u->gnx_status, 64, hipHostMallocMapped) != hipSuccess) return dv_fail(DV_ERR_HIP, "hipHostMalloc(status word) failed");
+        *u->gnx_status = 0;
+      }
       const char* fe = getenv("DVITS_SPLITK_FUSED");
       if (!u->sk_tickets && !(fe && fe[0] == '0')) {
         void* z = nullptr;
@@ -1226,7 +1288,8 @@ struct Builder {
     {
       float* tsin = alloc((size_t)B * C0);
       float* h1 = alloc((size_t)B * E);
-      emit(S, [=](hipStream_t st) { return launch_timestep_sincos(uu->io.t, tsin, Bn, C0, st); });
+      // (the forward's first kernel also resets the exchange words of the in-epilogue GroupNorms: GnxParams)
+      emit(S, [=](hipStream_t st) { return launch_timestep_sincos(uu->io.t, tsin, Bn, C0, st, uu->gnx_pool, uu->gnx_words); });
       const float* w1 = W("time_embedding.linear_1.weight"); const float* b1 = W("time_embedding.linear_1.bias");
       const float* w2 = W("time_embedding.linear_2.weight"); const float* b2 = W("time_embedding.linear_2.bias");
       if (Bn <= 16) {   // lane-per-column kernel on transposed weights (built once): a quarter of the row-per-wave kernel's time
@@ -1718,9 +1781,26 @@ extern "C" int dv_unet_set_cond(dv_unet* u, const float* enc, const float* mask_
   return rc;
 }
 
+// In-kernel hand-over health (GnxParams): *n_ops = GEMMs of the schedule that finish their consumer's GroupNorm in the
+// epilogue; *timed_out = 1 if any such launch since prepare gave up waiting (its results are invalid).  No device
+// synchronisation: the flag lives in host memory the kernels write through; complete after the stream has drained.
+extern "C" int dv_unet_handover_status(dv_unet* u, int32_t* n_ops, int32_t* timed_out) {
+  if (!u || !u->prepared) return dv_fail(DV_ERR_STATE, "dv_unet_handover_status before prepare");
+  if (n_ops) *n_ops = u->gnx_ops;
+  if (timed_out) *timed_out = u->gnx_status ? (int32_t)*(volatile unsigned*)u->gnx_status : 0;
+  return DV_OK;
+}
+int dv_unet_health(const dv_unet* u) {
+  if (u->gnx_status && *(volatile unsigned*)u->gnx_status)
+    return dv_fail(DV_ERR_HIP, "an earlier launch's in-kernel GroupNorm hand-over timed out (its results are invalid); "
+                               "DVITS_GNX=0 runs GroupNorm as separate launches");
+  return DV_OK;
+}
+
 // internal: enqueue one forward (used by dv_unet_forward and the sampler)
 int dv_unet_enqueue(dv_unet* u, const float* x, int cx, const float* cond, const float* t, float* y, hipStream_t st) {
   if (!u->prepared) return dv_fail(DV_ERR_STATE, "forward before dv_unet_prepare");
+  if (int hrc = dv_unet_health(u)) return hrc;
   if (!u->cond_set) return dv_fail(DV_ERR_STATE, "forward before dv_unet_set_cond");
   if (cx <= 0 || cx > u->cfg.in_channels || (cx < u->cfg.in_channels && !cond))
     return dv_fail(DV_ERR_INVALID, "forward: cx=%d inconsistent with in_channels=%d / cond", cx, u->cfg.in_channels);

@@ -744,6 +744,7 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int m0, con
 
   // ---- epilogue ----
   DV_TRACE(4);
+  const bool gnx = !SC1 && !AF && p.gnx.xchg != nullptr;
   // store 4 consecutive columns of one row: fp32 and/or split bf16 planes
   auto store4 = [&](size_t o, int nb, const float* v) {
     if (vec4) {
@@ -860,6 +861,10 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int m0, con
         v *= rmask;
         vv[r] = (m_ok && n < p.N) ? v : 0.f;
       }
+      if (gnx) {                                     // the values stay in registers for the normalising second pass
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = vv[r];
+      }
       if (p.epi == EPI_STORE_NCT) {
         // [B, N, T_out]: the 32 lanes of a half-wave write 32 consecutive frames of one channel
         if (m_ok) {
@@ -928,9 +933,115 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int m0, con
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) { a2[0] += __shfl_xor(a2[0], o); a2[1] += __shfl_xor(a2[1], o); }
         const int cb0 = (n0 + (wn * FN + j) * 32) >> 4;
-        if (lane < 2 && mrow0 < p.M && (cb0 + lane) * 16 < p.N)
-          reinterpret_cast<float2*>(p.stats16)[(size_t)(mrow0 >> 5) * (p.N >> 4) + cb0 + lane] =
-              make_float2(lane ? a1[1] : a1[0], lane ? a2[1] : a2[0]);
+        if (lane < 2 && mrow0 < p.M && (cb0 + lane) * 16 < p.N) {
+          float2* const dst = reinterpret_cast<float2*>(p.stats16) + (size_t)(mrow0 >> 5) * (p.N >> 4) + cb0 + lane;
+          const float2 val = make_float2(lane ? a1[1] : a1[0], lane ? a2[1] : a2[0]);
+          *dst = val;
+          if (gnx)     // for the other workgroups of this launch: one 8-byte word (sum, M2), written through
+            __hip_atomic_store(p.gnx.xchg + (size_t)(mrow0 >> 5) * (p.N >> 4) + cb0 + lane,
+                               (unsigned long long)__float_as_uint(val.x) | ((unsigned long long)__float_as_uint(val.y) << 32),
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+      }
+    }
+  }
+  if (gnx) {
+    // ---- GroupNorm of this GEMM's own output (GnxParams, dv_common.h) ----
+    const int cpg = p.N / p.gnx.groups, bq = m0 / p.T_out;
+    float pg = 0.f, pb = 0.f, pts = 1.f, ptb = 0.f;  // this thread's column: affine + temb scale / shift (independent of the statistics)
+    if (tid < BN) {
+      const int c = min(n0 + tid, p.N - 1);
+      pg = p.gnx.gamma[c]; pb = p.gnx.beta[c];
+      if (p.gnx.tscale) pts = 1.0f + p.gnx.tscale[(size_t)bq * p.gnx.ld_t + c];
+      if (p.gnx.tshift) ptb = p.gnx.tshift[(size_t)bq * p.gnx.ld_t + c];
+    }
+    // statistics of the groups this tile's columns belong to: one wave per group, fp64, fixed order (deterministic)
+    constexpr int NWA = (KS == 2 && !SPLIT_EPI) ? NWQ : NWV;   // waves still here
+    __shared__ float2 s_gst[BN / 16 + 1];
+    __shared__ __attribute__((aligned(16))) float s_gA[BN < 64 ? 64 : BN], s_gB[BN < 64 ? 64 : BN];
+    const int g_lo = n0 / cpg, g_hi = (min(n0 + BN, p.N) - 1) / cpg;
+    const int RB = p.T_out >> 5, nvb = cpg >> 4, ncb = p.N >> 4;
+    for (int g = g_lo + wave; g <= g_hi; g += NWA) {
+      // poll the group's entries until none is EMPTY (all ones: the forward's first kernel resets the exchange words;
+      // a published (sum, M2) is finite).  All tiles of the utterance are resident and arrive within the spread of the
+      // workgroups' k-loops; a lane re-reads only what it has not seen yet; bounded and flagged, never a hang
+      constexpr int EPL = 4;                         // entries per lane: up to 256 per group (gemm_gnx_plan checks)
+      unsigned long long w[EPL];
+#pragma unroll
+      for (int k = 0; k < EPL; ++k) w[k] = ~0ull;
+      const int ne = RB * nvb;
+      for (int spins = 0;; ++spins) {
+        bool ok = true;
+#pragma unroll
+        for (int k = 0; k < EPL; ++k) {
+          const int e = lane + 64 * k;
+          if (e < ne && w[k] == ~0ull) {
+            const int rb = e / nvb, vb = e - rb * nvb;
+            w[k] = __hip_atomic_load(p.gnx.xchg + (size_t)(bq * RB + rb) * ncb + g * nvb + vb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            ok = ok && w[k] != ~0ull;
+          }
+        }
+        if (__all(ok)) break;
+        if (spins > (1 << 18)) {
+          if (lane == 0) __hip_atomic_store(p.gnx.status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+          break;
+        }
+        __builtin_amdgcn_s_sleep(1);
+      }
+      double s1 = 0.0, q = 0.0;
+#pragma unroll
+      for (int k = 0; k < EPL; ++k) {
+        if (lane + 64 * k < ne) {
+          const double sx = (double)__uint_as_float((unsigned)w[k]), m2 = (double)__uint_as_float((unsigned)(w[k] >> 32));
+          s1 += sx;
+          q += m2 + sx * sx * (1.0 / 512.0);         // = the block's sum of squares
+        }
+      }
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o); q += __shfl_xor(q, o); }
+      if (lane == 0) {
+        const double n = (double)cpg * (double)p.T_out, mean = s1 / n;
+        double var = q / n - mean * mean;
+        var = var > 0 ? var : 0;
+        s_gst[g - g_lo] = make_float2((float)mean, (float)(1.0 / sqrt(var + (double)p.gnx.eps)));
+      }
+    }
+    __syncthreads();
+    if (tid < BN) {
+      const float2 st = s_gst[min(n0 + tid, p.N - 1) / cpg - g_lo];
+      const float a = st.y * pg;
+      s_gA[tid] = a * pts;
+      s_gB[tid] = fmaf(pb - st.x * a, pts, ptb);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < FN; ++j) {
+      const int cl = (wn * FN + j) * 32 + 4 * lh;    // tile-local column of g = 0, e = 0
+#pragma unroll
+      for (int i = 0; i < FM; ++i) {
+        if (!my_frag_row(i)) continue;
+        const int m = m0 + (wm * FM + i) * 32 + l31;
+        if (m >= p.M) continue;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          if (n0 + cl + 8 * g >= p.N) continue;
+          const float4 sa = *reinterpret_cast<const float4*>(s_gA + cl + 8 * g);
+          const float4 sb = *reinterpret_cast<const float4*>(s_gB + cl + 8 * g);
+          float y[4] = {fmaf(acc[i][j][4 * g], sa.x, sb.x), fmaf(acc[i][j][4 * g + 1], sa.y, sb.y),
+                        fmaf(acc[i][j][4 * g + 2], sa.z, sb.z), fmaf(acc[i][j][4 * g + 3], sa.w, sb.w)};
+          if (p.gnx.silu) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) y[e] = y[e] / (1.0f + __expf(-y[e]));
+          }
+          const size_t o = (size_t)m * p.N + n0 + cl + 8 * g;
+          const unsigned h01 = cvt_pk_bf16(y[0], y[1]), h23 = cvt_pk_bf16(y[2], y[3]);
+          *reinterpret_cast<uint2*>(p.gnx.y_hi + o) = make_uint2(h01, h23);
+          if (p.gnx.y_lo) {
+            const unsigned l01 = cvt_pk_bf16(y[0] - __uint_as_float(h01 << 16), y[1] - __uint_as_float(h01 & 0xffff0000u));
+            const unsigned l23 = cvt_pk_bf16(y[2] - __uint_as_float(h23 << 16), y[3] - __uint_as_float(h23 & 0xffff0000u));
+            *reinterpret_cast<uint2*>(p.gnx.y_lo + o) = make_uint2(l01, l23);
+          }
+        }
       }
     }
   }

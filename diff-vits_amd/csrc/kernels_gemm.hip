@@ -238,10 +238,48 @@ int gemm_candidates(const GemmParams& p, int* out, int cap) {
   return n;
 }
 
+// Tile (BM x BN) the shape heuristic of launch_gemm picks for a non-AF, non-GEGLU GEMM (kept in step with
+// Tiles<BK>::launch below; used to plan the in-epilogue GroupNorm: its tiles must not span utterances and must all be resident)
+static void gemm_pick_tile(const GemmParams& p, int& bm, int& bn) {
+  const GemmTune& tune = gemm_tune();
+  auto cnt = [&](int a, int b) { return ((p.M + a - 1) / a) * ((p.N + b - 1) / b); };
+  bool k64 = tune.bk64 != 0;
+  for (int s = 0; s < p.nseg; ++s) k64 = k64 && p.seg[s].c0 % 64 == 0 && p.seg[s].c1 % 64 == 0;
+  if (cnt(128, 128) >= tune.big) { bm = 128; bn = 128; return; }
+  const int min_wg = k64 ? tune.min_wg : (tune.min_wg > 0 ? tune.min_wg : 1);
+  static const int t1_min = [] { const char* e = getenv("DVITS_GEMM_T1"); return e ? atoi(e) : (1 << 30); }();
+  if (k64 && cnt(128, 64) >= t1_min) { bm = 128; bn = 64; return; }
+  if (cnt(64, 64) >= min_wg) { bm = 64; bn = 64; return; }
+  if (cnt(64, 32) >= min_wg) { bm = 64; bn = 32; return; }
+  bm = 32; bn = 32;
+}
+
+int gemm_gnx_plan(const GemmParams& p, int n_cu) {
+  if (p.af || p.force_tile != GT_AUTO || (p.epi != EPI_STORE && p.epi != EPI_RESIDUAL) || !p.stats16 || p.rowmask || p.relu) return 0;
+  if (p.M != p.B * p.T_out || p.gnx.groups <= 0 || p.N % p.gnx.groups != 0) return 0;
+  const int cpg = p.N / p.gnx.groups;
+  if (cpg % 16 != 0 || p.N % 16 != 0) return 0;
+  int bm, bn;
+  gemm_pick_tile(p, bm, bn);
+  if (p.T_out % bm != 0 || p.N % bn != 0) return 0;
+  if ((p.T_out / 32) * (cpg / 16) > 256) return 0;     // entries of one group: four per lane of the reducing wave
+  // every workgroup that waits must be resident: (finishing) tiles <= compute units; the first arrivers of a fused
+  // split-K pair leave without waiting, so only the tile count matters there too
+  const int tiles = (p.M / bm) * (p.N / bn);
+  const bool pair = p.sk_buf && p.sk_split == 2 && p.sk_ticket;
+  if (p.sk_buf && !pair) return 0;                   // two-launch split-K: not supported with the in-epilogue GroupNorm
+  if (pair ? tiles >= n_cu : tiles > n_cu) return 0;
+  return (p.M / 32) * (p.N / 16);
+}
+
 hipError_t launch_gemm(const GemmParams& pin, int precision, hipStream_t st) {
   GemmParams p = pin;
   const bool x3 = precision == 0;
   if (!p.zero_page || (x3 && !p.w_lo)) return hipErrorInvalidValue;
+  if (p.gnx.xchg && p.sk_mode == 0) {            // (checked once, before the split-K recursion)
+    static const int n_cu = [] { int d = 0, n = 0; (void)hipGetDevice(&d); (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, d); return n; }();
+    if (!p.gnx.status || !p.gnx.y_hi || !p.gnx.gamma || !p.gnx.beta || gemm_gnx_plan(p, n_cu) <= 0) return hipErrorInvalidValue;
+  }
   if (p.af) {
     if (!gemm_af_supported(p)) return hipErrorInvalidValue;
     // split-K: only the one-launch pair (ticket hand-over); the k-range is cut at a chunk boundary inside the kernel

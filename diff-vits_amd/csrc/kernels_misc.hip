@@ -600,8 +600,12 @@ hipError_t launch_small_linear(const float* in, int ldin, const float* W, const 
 
 // Sinusoidal timestep embedding [cos | sin] (reference embeddings.py:24-64 with
 // flip_sin_to_cos=True, freq_shift=0): same fp32 operation order as the reference.
-__global__ void k_timestep_sincos(const float* __restrict__ t, float* __restrict__ out, int B, int dim) {
+__global__ void k_timestep_sincos(const float* __restrict__ t, float* __restrict__ out, int B, int dim,
+                                  unsigned long long* __restrict__ reset, size_t reset_words) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  // first kernel of a forward: the exchange words of the in-epilogue GroupNorms (GnxParams) start EMPTY (all ones)
+  for (size_t k = (size_t)i * 2; k < reset_words; k += (size_t)gridDim.x * blockDim.x * 2)
+    *reinterpret_cast<ulonglong2*>(reset + k) = make_ulonglong2(~0ull, ~0ull);
   const int half = dim >> 1;
   if (i >= B * half) return;
   const int b = i / half, j = i - b * half;
@@ -612,9 +616,12 @@ __global__ void k_timestep_sincos(const float* __restrict__ t, float* __restrict
   out[(size_t)b * dim + half + j] = sinf(arg);
 }
 
-hipError_t launch_timestep_sincos(const float* t, float* out, int B, int dim, hipStream_t st) {
+hipError_t launch_timestep_sincos(const float* t, float* out, int B, int dim, hipStream_t st, unsigned long long* reset,
+                                  size_t reset_words) {
   const int n = B * (dim / 2);
-  hipLaunchKernelGGL(k_timestep_sincos, dim3((n + 255) / 256), dim3(256), 0, st, t, out, B, dim);
+  if (reset_words & 1) return hipErrorInvalidValue;
+  const size_t want = std::max<size_t>((n + 255) / 256, std::min<size_t>(256, (reset_words / 2 + 255) / 256));
+  hipLaunchKernelGGL(k_timestep_sincos, dim3((unsigned)want), dim3(256), 0, st, t, out, B, dim, reset, reset ? reset_words : 0);
   return hipGetLastError();
 }
 

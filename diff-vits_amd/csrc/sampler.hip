@@ -27,6 +27,7 @@ int dv_fail(int code, const char* fmt, ...);
 struct dv_unet;
 int dv_unet_enqueue(dv_unet* u, const float* x, int cx, const float* cond, const float* t, float* y, hipStream_t st);
 int dv_unet_dims(const dv_unet* u, int* B, int* T, int* cin, int* cout, int64_t* gen);
+int dv_unet_health(const dv_unet* u);
 
 #define HIPCHK(expr)                                                                                  \
   do {                                                                                                \
@@ -514,6 +515,7 @@ extern "C" int dv_sampler_run(dv_plan* p, dv_unet* u, float* x_inout, const floa
   int B, T, cin, cout; int64_t gen;
   if (!dv_unet_dims(u, &B, &T, &cin, &cout, &gen)) return dv_fail(DV_ERR_STATE, "dv_sampler_run: unet not prepared / cond not set");
   if (cin > cout && !cond) return dv_fail(DV_ERR_INVALID, "dv_sampler_run: cond is required (in_channels > out_channels)");
+  if (int hrc = dv_unet_health(u)) return hrc;
   const int64_t numel = (int64_t)B * cout * T;
   int rc = plan_buffers(p, numel, B);
   if (rc != DV_OK) return rc;

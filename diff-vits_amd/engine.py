@@ -179,6 +179,13 @@ class UNetEngine:
         _lib.check(_lib.lib().dv_unet_persist_status(self._h, C.byref(n), C.byref(err)), "dv_unet_persist_status")
         return n.value, err.value
 
+    def handover_status(self):
+        """(GEMMs that finish their consumer's GroupNorm in the epilogue, timed-out flag) - see dv_unet_handover_status.
+        Meaningful after the stream has drained; a set flag also fails every later forward / sampler run."""
+        n, bad = C.c_int32(), C.c_int32()
+        _lib.check(_lib.lib().dv_unet_handover_status(self._h, C.byref(n), C.byref(bad)), "dv_unet_handover_status")
+        return n.value, bad.value
+
     def time_family(self, kind, reps=5):
         """Average launch duration (us) of one kernel family: its launches of the schedule replayed back to back
         between one HIP event pair (after a completed forward).  Returns (us_per_launch, launches_per_forward)."""

@@ -139,6 +139,12 @@ int dv_unet_time_family(dv_unet* u, const char* kind, int32_t reps, void* stream
  * *error_flag = 0 ok, 1 = an in-launch barrier timed out, 2 = the workgroups were not spread evenly over the XCDs
  * (synchronises the device). */
 int dv_unet_persist_status(dv_unet* u, int32_t* n_ops, int32_t* error_flag);
+/* GroupNorm finished inside the producer GEMM (default; environment DVITS_GNX=0 at prepare time restores the separate
+ * k_gn_apply launches): the workgroups of such a GEMM exchange their tile statistics inside the launch and wait for one
+ * another (bounded).  *n_ops = schedule operations that do so; *timed_out = 1 if any of them ever gave up waiting - the
+ * results of that launch are invalid and every later dv_unet_forward / dv_sampler_run on this handle fails with
+ * DV_ERR_HIP.  Does not synchronise: meaningful once the stream has drained. */
+int dv_unet_handover_status(dv_unet* u, int32_t* n_ops, int32_t* timed_out);
 /* Profiling aid: s_memtime stamps taken by one workgroup of XCD 0 after every operation of the last persistent launch;
  * returns the number of stamps written (operations + 1) or a negative error; *first_op = schedule index of the first
  * operation inside the launch (pairs with dv_unet_op_info). */

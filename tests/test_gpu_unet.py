@@ -560,6 +560,38 @@ def test_row_block_chains_match_one_launch_per_gemm():
     assert rel_l2(outs[1], outs[0]) < 5e-5 and rel_l2(outs[2], outs[0]) < 5e-5
 
 
+def test_groupnorm_finished_in_producer_epilogue_matches_separate_launch():
+    """Default schedule: conv1 of every resnet block finishes norm2 (+ temb scale/shift + SiLU) in its own epilogue - the
+    workgroups exchange 32x16-block statistics inside the launch (gemm_tile.h GNX) - instead of a k_gn_apply launch.
+    DVITS_GNX=0 restores the separate launches: same statistics, same fp64 combination - agreement to float32 rounding;
+    fewer launches; repeatable bit for bit (arrival order does not enter the arithmetic); no hand-over ever timed out."""
+    from diff_vits_amd.unet1d.unet_1d_condition import UNet1DConditionModel
+    kw, sd, sample, t, enc, mask = unet_case("cfg1")
+    outs, launches = [], []
+    for gnx in ("0", "1"):
+        os.environ["DVITS_GNX"] = gnx
+        try:
+            m = UNet1DConditionModel(backend="hip", **kw).eval()
+            m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+            m = m.cuda()
+            args = (torch.from_numpy(sample).cuda(), torch.from_numpy(t).cuda(), torch.from_numpy(enc).cuda())
+            with torch.no_grad():
+                y = m(*args, encoder_attention_mask=torch.from_numpy(mask).cuda()).sample
+                y2 = m(*args, encoder_attention_mask=torch.from_numpy(mask).cuda()).sample
+            torch.cuda.synchronize()
+            assert torch.equal(y, y2)
+            n_ops, bad = m.hip_engine().handover_status()
+            assert bad == 0 and (n_ops > 0) == (gnx == "1"), (n_ops, bad)
+            outs.append(y.cpu().numpy())
+            launches.append(m.hip_engine().stats()[0])
+        finally:
+            os.environ.pop("DVITS_GNX", None)
+    assert launches[1] < launches[0], launches
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "unet_cfg1.npz"))["y"]
+    assert rel_l2(outs[0], g) < 2e-4 and rel_l2(outs[1], g) < 2e-4
+    assert rel_l2(outs[1], outs[0]) < 2e-5
+
+
 def test_persistent_per_xcd_schedule_matches_per_launch():
     """DVITS_PERSIST=1 (csrc/persist.hip): the body of a forward as ONE launch with XCD-local barriers, utterance b on
     XCD b % 8.  Same kernels' tile routines (L1-bypassing loads), different tile menu: agreement with the per-launch
