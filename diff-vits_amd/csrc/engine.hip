@@ -132,6 +132,9 @@ struct Act {   // channels-last fp32 [B*T, C] (+ GN statistics) (+ split planes 
   float* stat = nullptr;      // per-column slab [B*T/32, C, 2] (consumer: k_gn_apply), or
   float* stat16 = nullptr;    // per 32x16-block statistics [B*T/32, C/16, 2] (consumer: a conv that normalises its own operand)
   bf16_t* pl_hi = nullptr; bf16_t* pl_lo = nullptr;
+  // GroupNorm + SiLU of this tensor for ONE consumer (`n_pre` = its norm's weight prefix), written by the producer GEMM's
+  // own epilogue (GnxParams); the consumer releases them
+  bf16_t* n_hi = nullptr; bf16_t* n_lo = nullptr; std::string n_pre;
 };
 
 typedef std::function<hipError_t(hipStream_t)> OpFn;
@@ -604,6 +607,23 @@ struct Builder {
     return true;
   }
 
+  // The build loop announces the single GroupNorm consumer of the next producer's output (a resnet block's norm1, or
+  // conv_norm_out); the producer's last GEMM takes the offer if it can finish that GroupNorm itself.
+  struct NextNorm { std::string pre; bool raw = false; bool set = false; } next_norm;
+  void announce_norm(const std::string& pre, bool raw_planes) { next_norm.pre = pre; next_norm.raw = raw_planes; next_norm.set = true; }
+  void offer_next(GemmParams& g, Act& out) {
+    if (!next_norm.set) return;
+    const NextNorm nn = next_norm;
+    next_norm.set = false;
+    Planes y;
+    if (!gnx_setup(g, nn.pre, u->cfg.norm_eps, nullptr, nullptr, 0, true, &y)) return;
+    out.n_hi = y.hi; out.n_lo = y.lo; out.n_pre = nn.pre;
+    if (nn.raw && !g.out_hi) {   // the consumer's folded 1x1 shortcut reads the raw tensor as split planes
+      Planes pl = alloc_planes((size_t)g.M * g.N);
+      out.pl_hi = pl.hi; out.pl_lo = pl.lo; g.out_hi = pl.hi; g.out_lo = pl.lo;
+    }
+  }
+
   void gemm(std::vector<OpFn>& ops, GemmParams g, const PackedW* pw, int k_real) {
     g.w_hi = pw->hi; g.w_lo = pw->lo; g.Kp = pw->Kp; g.N_pad = pw->N_pad;
     if (!g.bias) g.bias = pw->bias;
@@ -761,7 +781,14 @@ struct Builder {
       if (fused && af_setup(g, x0, x1, 3, p + "norm1", eps, nullptr, nullptr, 0, true)) gemm(ops, g, w1, 3 * cin);
       else {
         g.af = 0;
-        Planes n1 = norm_apply(ops, x0, x1, p + "norm1", eps, nullptr, nullptr, 0, true, shortcut ? &raw : nullptr);
+        Planes n1;
+        if (x1.C == 0 && x0.n_hi && x0.n_pre == p + "norm1" && (!shortcut || x0.pl_hi)) {   // normalised by its producer
+          n1.hi = x0.n_hi; n1.lo = x0.n_lo;
+          if (shortcut) { raw.hi = x0.pl_hi; raw.lo = x0.pl_lo; }
+        } else {
+          if (x0.n_hi) { Planes stale; stale.hi = x0.n_hi; stale.lo = x0.n_lo; release(stale); }
+          n1 = norm_apply(ops, x0, x1, p + "norm1", eps, nullptr, nullptr, 0, true, shortcut ? &raw : nullptr);
+        }
         raw_made = shortcut;
         g.seg[0] = seg(n1, cin, Planes{}, 0, 3, 1);
         gnx1 = gnx_setup(g, p + "norm2", eps, tproj + toff, tproj + toff + cout, tproj_total, true, &n2x);
@@ -788,6 +815,7 @@ struct Builder {
         Planes pl = alloc_planes((size_t)M * cout);
         out.pl_hi = pl.hi; out.pl_lo = pl.lo; g.out_hi = pl.hi; g.out_lo = pl.lo;
       }
+      const bool offered = next_norm.set;
       // fused: conv2 normalises h (GroupNorm + temb scale/shift + SiLU) and splits the raw [x0 | x1] of the folded
       // 1x1 shortcut itself; it needs the raw fp32 input, so both convs of a block are fused or neither
       if (fused && af_setup(g, h, Act{}, 3, p + "norm2", eps, tproj + toff, tproj + toff + cout, tproj_total, true,
@@ -799,6 +827,7 @@ struct Builder {
         g.seg[0] = seg(n2, cout, Planes{}, 0, 3, 1);
         g.nseg = 1;
         if (shortcut) { g.seg[1] = seg(raw, cin, Planes{}, 0, 1, 0); g.nseg = 2; }
+        if (offered) offer_next(g, out);
         gemm(ops, g, w2, K2);
         release(n2);
       }
@@ -1062,6 +1091,7 @@ struct Builder {
           Planes pl = alloc_planes((size_t)M * C);
           out.pl_hi = pl.hi; out.pl_lo = pl.lo; g.out_hi = pl.hi; g.out_lo = pl.lo;
         }
+        offer_next(g, out);
         gemm(ops, g, w_m, 5 * C);
       }
       ln_release(l3);
@@ -1088,6 +1118,7 @@ struct Builder {
         Planes pl = alloc_planes((size_t)M * C);
         out.pl_hi = pl.hi; out.pl_lo = pl.lo; g.out_hi = pl.hi; g.out_lo = pl.lo;
       }
+      offer_next(g, out);
       gemm(ops, g, w_out, C);
     }
     release(h4);
@@ -1117,6 +1148,7 @@ struct Builder {
     Act out{};
     out.p = alloc((size_t)B * g.T_out * C); out.C = C; out.T = g.T_out; alloc_stat(out);
     g.M = B * g.T_out; g.out = out.p; stat_out(g, out);
+    offer_next(g, out);
     gemm(ops, g, w, 3 * C);
     release(xs);
     probe(p.substr(0, p.size() - 1), out.p, g.T_out, C);
@@ -1336,39 +1368,55 @@ struct Builder {
       GemmParams g = gp_base(T, B * T, C0);
       g.seg[0] = seg(xin, cpad, Planes{}, 0, 3, 1);
       g.out = h.p; stat_out(g, h);
+      announce_norm("down_blocks.0.resnets.0.norm1", has("down_blocks.0.resnets.0.conv_shortcut.weight"));
+      offer_next(g, h);
       gemm(S, g, wci, 3 * cin);
     }
     release(xin);
     probe("conv_in", h.p, T, C0);
 
-    std::vector<Act> skips{h};
+    // a tensor kept for the up path's concat: without the planes that belong to its immediate consumer
+    auto skip_of = [](Act a) { a.pl_hi = a.pl_lo = a.n_hi = a.n_lo = nullptr; a.n_pre.clear(); return a; };
+    // the resnet block that consumes a down-path tensor alone: its norm1 can be finished by the tensor's producer
+    auto announce_resnet = [&](const std::string& rp) { announce_norm(rp + "norm1", has(rp + "conv_shortcut.weight")); };
+    std::vector<Act> skips{skip_of(h)};
     for (int i = 0; i < n; ++i) {
       const std::string bp = "down_blocks." + std::to_string(i) + ".";
       const bool attn = i < n - 1;
       for (int j = 0; j < lpb; ++j) {
         const bool feeds_resampler = i < n - 1 && j == lpb - 1;     // its output is the downsampler's input
+        // consumer of this (resnet [+ transformer]) pair's output: the block's next resnet, the downsampler, or the mid block
+        const std::string next_rp = j + 1 < lpb ? bp + "resnets." + std::to_string(j + 1) + "." : (i == n - 1 ? std::string("mid_block.resnets.0.") : std::string());
+        if (!attn && !next_rp.empty()) announce_resnet(next_rp);
         Act r = resnet(S, bp + "resnets." + std::to_string(j) + ".", h, Act{}, c.block_out_channels[i], feeds_resampler && !attn,
                        attn && chain_ok(h.T, c.block_out_channels[i]));
+        next_norm.set = false;
         if (!r.p) return dv_fail(DV_ERR_MISSING_WEIGHT, "%s", err.c_str());
         if (attn) {
+          if (!next_rp.empty()) announce_resnet(next_rp);
           Act a = transformer(S, bp + "attentions." + std::to_string(j) + ".", r, feeds_resampler);
+          next_norm.set = false;
           if (!a.p) return dv_fail(DV_ERR_MISSING_WEIGHT, "%s", err.c_str());
           release_act(r);
           r = a;
         }
         h = r;
-        skips.push_back(h);
+        skips.push_back(skip_of(h));
       }
       if (i < n - 1) {
+        announce_resnet("down_blocks." + std::to_string(i + 1) + ".resnets.0.");
         h = resample(S, bp + "downsamplers.0.", h, true, 0);
+        next_norm.set = false;
         if (!h.p) return dv_fail(DV_ERR_MISSING_WEIGHT, "%s", err.c_str());
-        skips.push_back(h);
+        skips.push_back(skip_of(h));
       }
     }
     {
       Act r0 = resnet(S, "mid_block.resnets.0.", h, Act{}, h.C, false, chain_ok(h.T, h.C));
       if (!r0.p) return dv_fail(DV_ERR_MISSING_WEIGHT, "%s", err.c_str());
+      announce_resnet("mid_block.resnets.1.");
       Act a = transformer(S, "mid_block.attentions.0.", r0);
+      next_norm.set = false;
       if (!a.p) return dv_fail(DV_ERR_MISSING_WEIGHT, "%s", err.c_str());
       release_act(r0);
       h = resnet(S, "mid_block.resnets.1.", a, Act{}, a.C);
@@ -1383,12 +1431,17 @@ struct Builder {
         Act sk = skips.back();
         skips.pop_back();
         const bool feeds_resampler = !last && j == lpb;              // its output is the upsampler's input
+        const bool final_op = last && j == lpb;                      // its output goes to conv_norm_out alone
+        if (final_op && !attn) announce_norm("conv_norm_out", false);
         Act r = resnet(S, bp + "resnets." + std::to_string(j) + ".", h, sk, cout, feeds_resampler && !attn, attn && chain_ok(h.T, cout));
+        next_norm.set = false;
         if (!r.p) return dv_fail(DV_ERR_MISSING_WEIGHT, "%s", err.c_str());
         release_act(h);
         release_act(sk);
         if (attn) {
+          if (final_op) announce_norm("conv_norm_out", false);
           Act a = transformer(S, bp + "attentions." + std::to_string(j) + ".", r, feeds_resampler);
+          next_norm.set = false;
           if (!a.p) return dv_fail(DV_ERR_MISSING_WEIGHT, "%s", err.c_str());
           release_act(r);
           r = a;
@@ -1410,7 +1463,10 @@ struct Builder {
       if (!wo) return dv_fail(DV_ERR_MISSING_WEIGHT, "%s", err.c_str());
       GemmParams g = gp_base(T, B * T, co);
       Planes nf;
-      if (!af_setup(g, h, Act{}, 3, "conv_norm_out", c.norm_eps, nullptr, nullptr, 0, true)) {
+      if (h.n_hi && h.n_pre == "conv_norm_out") {   // normalised by its producer's epilogue
+        nf.hi = h.n_hi; nf.lo = h.n_lo;
+        g.seg[0] = seg(nf, C0, Planes{}, 0, 3, 1);
+      } else if (!af_setup(g, h, Act{}, 3, "conv_norm_out", c.norm_eps, nullptr, nullptr, 0, true)) {
         nf = norm_apply(S, h, Act{}, "conv_norm_out", c.norm_eps, nullptr, nullptr, 0, true, nullptr);
         g.seg[0] = seg(nf, C0, Planes{}, 0, 3, 1);
       }
