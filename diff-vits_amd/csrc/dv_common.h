@@ -159,6 +159,13 @@ struct ChainParams {
   float xa_qscale;               // d^-1/2 * log2 e
   const bf16_t* w3_hi; const bf16_t* w3_lo; const float* b3;
   float* out3; bf16_t* out3_hi; bf16_t* out3_lo; float* rowstat3;
+  // Optional (sa_kf_hi != null; amode 1, passes 3 = to_q | to_k | to_v): the self-attention's K and V leave the kernel as
+  // MFMA fragments of 32-key tiles (tile = this row block) for k_attention_frag - no fp32 K / V, no conversion there:
+  //   K  [M/32][C/16][64 lanes][8]: lane (l31, lh) = K[tile*32 + l31][grp*16 + lh*8 .. +8]
+  //   V^T[M/32][C/32][2 k-blocks][64 lanes][8]: lane (l31, lh) = V[tile*32 + key(kb, lh, j)][blk*32 + l31], j = 0..7,
+  //      key(kb, lh, j) = kb*16 + (j < 4 ? 4 lh + j : 8 + 4 lh + j - 4) - the order of a score accumulator's registers
+  // out2 then receives the query columns only (ldo2 >= C).
+  bf16_t* sa_kf_hi; bf16_t* sa_kf_lo; bf16_t* sa_vf_hi; bf16_t* sa_vf_lo;
 };
 // cross-attention K/V of one block, fp32 [B*L, 2C] (k | v) -> MFMA-fragment-major split planes (ChainParams xa_*)
 hipError_t launch_kv_frag(const float* kv, bf16_t* kf_hi, bf16_t* kf_lo, bf16_t* vf_hi, bf16_t* vf_lo, int B, int L, int C, int H,
@@ -180,6 +187,27 @@ struct AttnParams {
   float scale;
   int nsplit;                   // 3: split-bf16 (hi*hi + lo*hi + hi*lo), 1: single bf16 product
 };
+
+// Attention over K / V that arrive as MFMA fragments of 32-key tiles (k_attention_frag, kernels_attn.hip): written by
+// the q|k|v chain kernel's epilogue (ChainParams sa_*: self attention) or by launch_kv_frag (the prompt's keys / values,
+// hoisted out of the sampler loop: cross attention).  Blocks are 64 lanes x 8 bf16 = 1 KiB per plane:
+//   K block   (b, h, t, ks):      kf + (b*k_b + h*k_h + t*k_t + ks) * 512
+//   V^T block (b, h, t, kb, nb):  vf + (b*v_b + hv + t*v_t + kb*v_kb + nb*v_nb) * 512,  hv = h*v_h, channel rows from 0
+//                                 (self_layout: hv = (h*d / 32) * v_nb, rows from (h*d) % 32 - fragments span heads)
+struct AttnFragParams {
+  const float* q; int ldq;      // fp32 queries [B*Tq, ldq], head h = columns [h*d, h*d + d)
+  const bf16_t* kf_hi; const bf16_t* kf_lo; const bf16_t* vf_hi; const bf16_t* vf_lo;
+  int k_b, k_h, k_t;            // K block strides (blocks)
+  int v_b, v_h, v_t, v_kb, v_nb;
+  int self_layout;
+  const float* bias;            // [B, bias_ld] additive key bias in the LOG2 domain (-1e30 beyond Tk), or null (no mask)
+  int bias_ld;
+  float* o; bf16_t* o_hi; bf16_t* o_lo; int ldo;
+  int B, H, Tq, Tk, d;
+  float scale;
+  int nsplit;
+};
+hipError_t launch_attention_frag(const AttnFragParams& p, hipStream_t st);
 
 // ---------------------------------------------------------------------------------------
 // Persistent per-XCD schedule (persist.hip): operation table in device memory, executed by one launch.

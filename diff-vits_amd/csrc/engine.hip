@@ -873,6 +873,38 @@ struct Builder {
     return o;
   }
 
+  // Attention over K / V fragments (k_attention_frag): self attention (fragments written by the q|k|v chain) or cross
+  // attention (the prompt's hoisted fragments)
+  Planes attention_frag(std::vector<OpFn>& ops, AttnFragParams a, int Tq, int Tk, int C) {
+    Planes o = alloc_planes((size_t)B * Tq * C);
+    a.o = nullptr; a.o_hi = o.hi; a.o_lo = o.lo; a.ldo = C;
+    a.B = B; a.H = u->cfg.num_heads; a.Tq = Tq; a.Tk = Tk; a.d = C / u->cfg.num_heads;
+    a.scale = 1.0f / sqrtf((float)a.d);
+    a.nsplit = prec == DV_PREC_BF16X3 ? 3 : 1;
+    cur_kind = "attn"; cur_flops = 4.0 * B * a.H * (double)Tq * Tk * a.d;
+    {
+      char buf[96];
+      snprintf(buf, sizeof(buf), "Tq=%d Tk=%d d=%d H=%d frag", Tq, Tk, a.d, a.H);
+      cur_desc = buf;
+    }
+    if (!dry) u->flops += cur_flops;
+    emit(ops, [a](hipStream_t st) { return launch_attention_frag(a, st); });
+    return o;
+  }
+  bool attn_frag_on = [] { const char* e = getenv("DVITS_ATTN_FRAG"); return !(e && e[0] == '0'); }();
+  // cross attention of block `p` over the prompt's K / V as hoisted MFMA fragments (cross_frag, key bias xbias)
+  Planes cross_attention_frag(std::vector<OpFn>& ops, const std::string& p, const float* q2, int Tn, int C) {
+    const XFrag& xf = cross_frag[p];
+    const int H = u->cfg.num_heads, dh = C / H, nT = (L + 31) / 32, KSq = dh / 16, NBv = (dh + 31) / 32;
+    AttnFragParams a{};
+    a.q = q2; a.ldq = C;
+    a.kf_hi = xf.kf_hi; a.kf_lo = xf.kf_lo; a.vf_hi = xf.vf_hi; a.vf_lo = xf.vf_lo;
+    a.k_b = H * nT * KSq; a.k_h = nT * KSq; a.k_t = KSq;
+    a.v_b = H * nT * 2 * NBv; a.v_h = nT * 2 * NBv; a.v_t = 2 * NBv; a.v_kb = NBv; a.v_nb = 1; a.self_layout = 0;
+    a.bias = xbias; a.bias_ld = nT * 32;
+    return attention_frag(ops, a, Tn, L, C);
+  }
+
   // Transformer2DModel + BasicTransformerBlock (reference transformer_1d.py:191-326, attention.py:130-203)
   Act transformer(std::vector<OpFn>& ops, const std::string& p, Act x, bool want_planes = false) {
     const int C = x.C, Tn = x.T, M = B * Tn, D = u->cfg.cross_attention_dim;
@@ -930,7 +962,13 @@ struct Builder {
     if (chained) {
       // chain 1: GN(eps 1e-6) -> proj_in -> LN1 -> to_q | to_k | to_v   (3 launches -> 1)
       float* h = alloc((size_t)M * C);
-      float* qkv = alloc((size_t)M * 3 * C);
+      // K and V leave the chain as MFMA fragments of 32-key tiles (k_attention_frag multiplies them as they are):
+      // DVITS_ATTN_FRAG=0 restores fp32 q | k | v and the converting attention kernel
+      const int dh = C / u->cfg.num_heads;
+      const bool sa_frag = attn_frag_on && !arena.exact && C % u->cfg.num_heads == 0 && dh % 16 == 0 && dh <= 64;
+      float* qkv = alloc((size_t)M * (sa_frag ? 1 : 3) * C);
+      Planes kf, vf;
+      if (sa_frag) { kf = alloc_planes((size_t)M * C); vf = alloc_planes((size_t)M * C); }
       {
         ChainParams cp{};
         cp.M = M; cp.C = C; cp.T = Tn; cp.amode = 1;
@@ -938,11 +976,23 @@ struct Builder {
         cp.groups = u->cfg.norm_num_groups;
         cp.w1_hi = w_in->fhi; cp.w1_lo = w_in->flo; cp.Kp1 = w_in->Kp; cp.b1 = w_in->bias; cp.res = nullptr; cp.out1 = h;
         cp.w2_hi = w_qkv->fhi; cp.w2_lo = w_qkv->flo; cp.Kp2 = w_qkv->Kp; cp.b2 = w_qkv->bias; cp.u2 = w_qkv->u;
-        cp.passes = 3; cp.out2 = qkv; cp.ldo2 = 3 * C; cp.ln_eps = 1e-5f;
-        chain(ops, cp, "norm+proj_in+LN+qkv");
+        cp.passes = 3; cp.out2 = qkv; cp.ldo2 = sa_frag ? C : 3 * C; cp.ln_eps = 1e-5f;
+        if (sa_frag) { cp.sa_kf_hi = kf.hi; cp.sa_kf_lo = kf.lo; cp.sa_vf_hi = vf.hi; cp.sa_vf_lo = vf.lo; }
+        chain(ops, cp, sa_frag ? "norm+proj_in+LN+q|Kfrag|Vfrag" : "norm+proj_in+LN+qkv");
       }
       probe(p + "proj_in", h, Tn, C);
-      Planes ao = attention(ops, qkv, 3 * C, qkv + C, qkv + 2 * C, 3 * C, nullptr, Tn, Tn, C);
+      Planes ao;
+      if (sa_frag) {
+        AttnFragParams a{};
+        a.q = qkv; a.ldq = C;
+        a.kf_hi = kf.hi; a.kf_lo = kf.lo; a.vf_hi = vf.hi; a.vf_lo = vf.lo;
+        const int nT = Tn / 32;
+        a.k_b = nT * (C / 16); a.k_h = dh / 16; a.k_t = C / 16;
+        a.v_b = nT * (C / 32) * 2; a.v_h = 0; a.v_t = (C / 32) * 2; a.v_kb = 1; a.v_nb = 2; a.self_layout = 1;
+        a.bias = nullptr; a.bias_ld = 0;
+        ao = attention_frag(ops, a, Tn, Tn, C);
+        release(kf); release(vf);
+      } else ao = attention(ops, qkv, 3 * C, qkv + C, qkv + 2 * C, 3 * C, nullptr, Tn, Tn, C);
       release(qkv);
       if (xa_ok(Tn, C) && cross_frag.count(p)) {
         // chain 2 with the cross attention inside: to_out + residual -> LN2 -> to_q -> cross attention (wave = head, K / V
@@ -989,7 +1039,8 @@ struct Builder {
       release(ao); release(h);
       probe(tb + "attn1", h2, Tn, C);
       float* kv = cross_kv[p];
-      ao = attention(ops, q2, C, kv, kv + C, 2 * C, mask_bias, Tn, L, C);
+      if (attn_frag_on && !arena.exact && cross_frag.count(p)) ao = cross_attention_frag(ops, p, q2, Tn, C);
+      else ao = attention(ops, q2, C, kv, kv + C, 2 * C, mask_bias, Tn, L, C);
       release(q2);
       h3 = alloc((size_t)M * C);
       {
@@ -1044,7 +1095,8 @@ struct Builder {
     }
     ln_release(l2);
     float* kv = cross_kv[p];
-    ao = attention(ops, q2, C, kv, kv + C, 2 * C, mask_bias, Tn, L, C);
+    if (attn_frag_on && !arena.exact && cross_frag.count(p)) ao = cross_attention_frag(ops, p, q2, Tn, C);
+    else ao = attention(ops, q2, C, kv, kv + C, 2 * C, mask_bias, Tn, L, C);
     release(q2);
     h3 = alloc((size_t)M * C);
     {
@@ -1238,7 +1290,9 @@ struct Builder {
       for (int i = 0; i < n; ++i) { T_of_C[c.block_out_channels[i]] = lvl_T; lvl_T = (lvl_T + 2 - 3) / 2 + 1; }
       for (auto& x : xformers) {
         const int C = x.second;
-        if (!xa_ok(T_of_C[C], C)) continue;
+        // fragments feed the in-chain cross attention (xa_ok) or k_attention_frag (any block with 16-channel head groups)
+        const bool frag_attn = attn_frag_on && !arena.exact && prec == DV_PREC_BF16X3 && C % H == 0 && (C / H) % 16 == 0 && C / H <= 64;
+        if (!xa_ok(T_of_C[C], C) && !frag_attn) continue;
         const int d = C / H, KSq = d / 16, NBv = (d + 31) / 32;
         const size_t kel = (size_t)B * H * nT * KSq * 64 * 8, vel = (size_t)B * H * nT * 2 * NBv * 64 * 8;
         XFrag xf;

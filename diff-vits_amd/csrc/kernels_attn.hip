@@ -48,6 +48,7 @@ static hipError_t init_att() {
   return e != hipSuccess ? e : hipFuncSetAttribute(reinterpret_cast<const void*>(k_attention<DP, NW, 1>),
                                                    hipFuncAttributeMaxDynamicSharedMemorySize, G::smem_bytes(1));
 }
+static hipError_t attn_frag_init();
 // > 64 KiB of dynamic LDS needs the attribute; set once, outside any stream capture
 hipError_t attn_init() {
   static bool done = false;
@@ -60,8 +61,289 @@ hipError_t attn_init() {
   if (e == hipSuccess) e = init_att<DP, 1>();
   ATT_INIT(16) ATT_INIT(32) ATT_INIT(48) ATT_INIT(64)
 #undef ATT_INIT
+  if (e == hipSuccess) e = attn_frag_init();
   done = e == hipSuccess;
   return e;
+}
+
+// ---------------------------------------------------------------------------------------
+// k_attention_frag: the same attention over K / V that arrive as split-bf16 MFMA fragments (AttnFragParams).  The
+// fragment blocks of a 32-key tile are lane-linear, so they travel global -> LDS by LDS-DMA exactly as they are multiplied
+// (one ds_read_b128 per lane, conflict-free, no swizzle, no padding) and the whole fp32 -> planes conversion stage of
+// k_attention - its vector-ALU work, its LDS round trip, its pipeline stage - is gone.  Ring of three 64-key pairs,
+// counted waits (a wave knows how many DMA instructions of a pair are its own), one barrier per pair.
+// ---------------------------------------------------------------------------------------
+template <int DP, int NW, int NSPLIT>
+__global__ __launch_bounds__(64 * NW) void k_attention_frag(const AttnFragParams p) {
+  extern __shared__ __attribute__((aligned(1024))) char lds[];
+  constexpr bool SPLIT = NSPLIT == 3;
+  constexpr int NPL = SPLIT ? 2 : 1;
+  constexpr int KS = DP / 16, NB = (DP + 31) / 32;
+  constexpr int KBL = KS * NPL, VBL = 2 * NB * NPL;      // 1 KiB blocks per 32-key sub-tile
+  constexpr int SUB = (KBL + VBL) * 1024;
+  constexpr int PAIR = 2 * SUB + 256;                   // + the pair's key bias (64 floats)
+  constexpr int NSTG = 3;
+  constexpr int NI = 2 * (KBL + VBL);                   // DMA instructions per pair
+  constexpr int CPW = (NI + NW - 1) / NW;               // per wave (at most)
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, lh = lane >> 5;
+  const int qblk = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+  const int d = p.d;
+  const int qi = qblk * (32 * NW) + wave * 32 + l31;
+  const bool q_ok = qi < p.Tq;
+  constexpr float LOG2E = 1.44269504088896340736f;
+  const float qscale = p.scale * LOG2E;
+  const int row0 = p.self_layout ? (h * d) & 31 : 0;    // first channel row of this head inside its first V^T fragment
+  const int nsub = (p.Tk + 31) / 32, nit = (nsub + 1) / 2;
+
+  // ---- this wave's DMA instructions of a pair: ii = wave + j * NW -> (sub-tile u, block blk) ----
+  const unsigned lds_base = (unsigned)(size_t)lds;
+  const bf16_t* src[CPW]; int step[CPW], tsel[CPW]; unsigned dst[CPW];
+  int my_n = 0;
+#pragma unroll
+  for (int j = 0; j < CPW; ++j) {
+    const int ii = wave + j * NW;
+    src[j] = nullptr; step[j] = 0; tsel[j] = 0; dst[j] = 0;
+    if (ii >= NI) continue;
+    ++my_n;
+    const int u = ii / (KBL + VBL), blk = ii - u * (KBL + VBL);
+    tsel[j] = u;
+    dst[j] = (unsigned)(u * SUB + blk * 1024);
+    if (blk < KBL) {
+      const int pl = blk / KS, ks = blk - pl * KS;
+      src[j] = (pl ? p.kf_lo : p.kf_hi) + ((size_t)b * p.k_b + (size_t)h * p.k_h + ks) * 512 + lane * 8;
+      step[j] = p.k_t;
+    } else {
+      const int vb = blk - KBL, pl = vb / (2 * NB), r = vb - pl * (2 * NB), kb = r / NB, nb = r - kb * NB;
+      const size_t hv = p.self_layout ? (size_t)((h * d) >> 5) * p.v_nb : (size_t)h * p.v_h;
+      src[j] = (pl ? p.vf_lo : p.vf_hi) + ((size_t)b * p.v_b + hv + (size_t)kb * p.v_kb + (size_t)nb * p.v_nb) * 512 + lane * 8;
+      step[j] = p.v_t;
+    }
+  }
+  const bool bias_wave = p.bias != nullptr && wave == 0;
+  if (bias_wave) ++my_n;
+  auto issue_pair = [&](int pr) {
+    const unsigned st = lds_base + (unsigned)((pr % NSTG) * PAIR);
+#pragma unroll
+    for (int j = 0; j < CPW; ++j) {
+      if (wave + j * NW >= NI) continue;
+      const int t = min(2 * pr + tsel[j], nsub - 1);      // a trailing odd sub-tile re-reads the last one (masked below)
+      glds16(src[j] + (size_t)t * step[j] * 512, st + dst[j]);
+    }
+    if (bias_wave) glds4(p.bias + (size_t)b * p.bias_ld + min(pr * 64 + lane, p.bias_ld - 1), st + 2 * SUB);
+  };
+  auto wait_pair = [&]() {     // at most this wave's instructions of ONE pair still in flight
+    if (my_n >= CPW + 1) wait_vmcnt<CPW + 1>();
+    else if (my_n == CPW) wait_vmcnt<CPW>();
+    else wait_vmcnt<(CPW > 1 ? CPW - 1 : 0)>();
+  };
+
+  issue_pair(0);
+  if (nit > 1) issue_pair(1);
+  // ---- Q fragments (B operand of K Q^T), behind the DMAs in the memory queue ----
+  bf16x8 qh[KS], ql[KS];
+  {
+    const float* qp = p.q + ((size_t)b * p.Tq + (q_ok ? qi : 0)) * p.ldq + h * d;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const int c = ks * 16 + lh * 8;
+      float4 a = make_float4(0.f, 0.f, 0.f, 0.f), c2 = a;
+      if (q_ok && c < d) a = *reinterpret_cast<const float4*>(qp + c);
+      if (q_ok && c + 4 < d) c2 = *reinterpret_cast<const float4*>(qp + c + 4);
+      a.x *= qscale; a.y *= qscale; a.z *= qscale; a.w *= qscale;
+      c2.x *= qscale; c2.y *= qscale; c2.z *= qscale; c2.w *= qscale;
+      u32x4 hw, lw;
+      hw.x = apk(a.x, a.y); hw.y = apk(a.z, a.w); hw.z = apk(c2.x, c2.y); hw.w = apk(c2.z, c2.w);
+      lw.x = apk(a.x - bf_lo(hw.x), a.y - bf_hi(hw.x)); lw.y = apk(a.z - bf_lo(hw.y), a.w - bf_hi(hw.y));
+      lw.z = apk(c2.x - bf_lo(hw.z), c2.y - bf_hi(hw.z)); lw.w = apk(c2.z - bf_lo(hw.w), c2.w - bf_hi(hw.w));
+      qh[ks] = __builtin_bit_cast(bf16x8, hw);
+      ql[ks] = __builtin_bit_cast(bf16x8, lw);
+    }
+  }
+  f32x16 o[NB];
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[nb][r] = 0.f;
+  float m_run = -1e30f, l_run = 0.f;
+
+  for (int it = 0; it < nit; ++it) {
+    if (it + 1 < nit) wait_pair(); else wait_vmcnt<0>();   // this wave's part of pair `it` has landed
+    __syncthreads();                                       // everyone's has; everyone is done with pair it - 1
+    if (it + 2 < nit) issue_pair(it + 2);                  // into the stage of pair it - 1
+    const char* base0 = lds + (it % NSTG) * PAIR;
+    const bool last = it + 1 == nit;
+
+    f32x16 s[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s[u][r] = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      bf16x8 kh[2], kl[2];
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        kh[u] = *reinterpret_cast<const bf16x8*>(base0 + u * SUB + ks * 1024 + lane * 16);
+        if (SPLIT) kl[u] = *reinterpret_cast<const bf16x8*>(base0 + u * SUB + (KS + ks) * 1024 + lane * 16);
+      }
+      if (SPLIT) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) s[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kl[u], qh[ks], s[u], 0, 0, 0);
+#pragma unroll
+        for (int u = 0; u < 2; ++u) s[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh[u], ql[ks], s[u], 0, 0, 0);
+      }
+#pragma unroll
+      for (int u = 0; u < 2; ++u) s[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh[u], qh[ks], s[u], 0, 0, 0);
+    }
+    if (p.bias != nullptr) {                   // key bias (log2 domain; -1e30 beyond Tk)
+      const float* bl = reinterpret_cast<const float*>(base0 + 2 * SUB);
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const float4 bv = *reinterpret_cast<const float4*>(bl + u * 32 + 8 * g + 4 * lh);
+          s[u][4 * g] += bv.x; s[u][4 * g + 1] += bv.y; s[u][4 * g + 2] += bv.z; s[u][4 * g + 3] += bv.w;
+        }
+    }
+    if (last && (p.Tk & 63) != 0) {            // keys past Tk of the last pair (a trailing odd sub-tile re-reads the last one)
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int key = (2 * it + u) * 32 + 8 * (r >> 2) + 4 * lh + (r & 3);
+          if (key >= p.Tk) s[u][r] = -1e30f;
+        }
+    }
+    float tmax = m_run;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) tmax = __builtin_fmaxf(__builtin_fmaxf(tmax, s[0][r]), s[1][r]);
+    const float m_new = fmaxf(tmax, __shfl_xor(tmax, 32));
+    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+    m_run = m_new;
+    const f32x2 mneg = {-m_new, -m_new};
+    f32x2 psum = {0.f, 0.f};
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int r = 0; r < 16; r += 2) {
+        f32x2 v = {s[u][r], s[u][r + 1]};
+        v += mneg;
+        v.x = __builtin_amdgcn_exp2f(v.x);
+        v.y = __builtin_amdgcn_exp2f(v.y);
+        psum += v;
+        s[u][r] = v.x; s[u][r + 1] = v.y;
+      }
+    l_run = l_run * alpha + (psum.x + psum.y);
+    if (__any(alpha != 1.0f)) {
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[nb][r] *= alpha;
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const char* vbase = base0 + u * SUB + KBL * 1024;
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb) {
+        u32x4 hw, lw;
+        hw.x = apk(s[u][kb * 8 + 0], s[u][kb * 8 + 1]); hw.y = apk(s[u][kb * 8 + 2], s[u][kb * 8 + 3]);
+        hw.z = apk(s[u][kb * 8 + 4], s[u][kb * 8 + 5]); hw.w = apk(s[u][kb * 8 + 6], s[u][kb * 8 + 7]);
+        const bf16x8 ph = __builtin_bit_cast(bf16x8, hw);
+        bf16x8 pl;
+        if (SPLIT) {
+          auto lo_pair = [&](unsigned h2, float x0, float x1) {
+            const f32x2 x = {x0, x1}, hf = {bf_lo(h2), bf_hi(h2)};
+            const f32x2 dlt = x - hf;
+            return apk(dlt.x, dlt.y);
+          };
+          lw.x = lo_pair(hw.x, s[u][kb * 8 + 0], s[u][kb * 8 + 1]);
+          lw.y = lo_pair(hw.y, s[u][kb * 8 + 2], s[u][kb * 8 + 3]);
+          lw.z = lo_pair(hw.z, s[u][kb * 8 + 4], s[u][kb * 8 + 5]);
+          lw.w = lo_pair(hw.w, s[u][kb * 8 + 6], s[u][kb * 8 + 7]);
+          pl = __builtin_bit_cast(bf16x8, lw);
+        }
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+          const bf16x8 vh = *reinterpret_cast<const bf16x8*>(vbase + (kb * NB + nb) * 1024 + lane * 16);
+          if (SPLIT) {
+            const bf16x8 vl = *reinterpret_cast<const bf16x8*>(vbase + (2 * NB + kb * NB + nb) * 1024 + lane * 16);
+            o[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vl, ph, o[nb], 0, 0, 0);
+            o[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, pl, o[nb], 0, 0, 0);
+          }
+          o[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, ph, o[nb], 0, 0, 0);
+        }
+      }
+    }
+  }
+  const float inv = 1.0f / (l_run + __shfl_xor(l_run, 32));
+  if (q_ok) {
+    const size_t obase = ((size_t)b * p.Tq + qi) * p.ldo + h * d;
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int dv = nb * 32 + 8 * g + 4 * lh - row0;   // channel of the head held by registers 4g .. 4g+3
+        if (dv >= 0 && dv < d) {
+          const float4 v = make_float4(o[nb][4 * g] * inv, o[nb][4 * g + 1] * inv, o[nb][4 * g + 2] * inv, o[nb][4 * g + 3] * inv);
+          if (p.o) *reinterpret_cast<float4*>(p.o + obase + dv) = v;
+          if (p.o_hi) {
+            uint2 hh, ll;
+            hh.x = apk(v.x, v.y); hh.y = apk(v.z, v.w);
+            *reinterpret_cast<uint2*>(p.o_hi + obase + dv) = hh;
+            if (p.o_lo) {
+              ll.x = apk(v.x - bf_lo(hh.x), v.y - bf_hi(hh.x));
+              ll.y = apk(v.z - bf_lo(hh.y), v.w - bf_hi(hh.y));
+              *reinterpret_cast<uint2*>(p.o_lo + obase + dv) = ll;
+            }
+          }
+        }
+      }
+  }
+}
+
+template <int DP, int NW>
+static constexpr int frag_smem(int npl) { return 3 * (2 * (DP / 16 + 2 * ((DP + 31) / 32)) * npl * 1024 + 256); }
+template <int DP, int NW>
+static void launch_att_frag(const AttnFragParams& p, dim3 grid, hipStream_t st) {
+  const int smem3 = frag_smem<DP, NW>(2), smem1 = frag_smem<DP, NW>(1);
+  if (p.nsplit == 3) hipLaunchKernelGGL((k_attention_frag<DP, NW, 3>), grid, dim3(64 * NW), smem3, st, p);
+  else hipLaunchKernelGGL((k_attention_frag<DP, NW, 1>), grid, dim3(64 * NW), smem1, st, p);
+}
+template <int DP, int NW>
+static hipError_t init_att_frag() {
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_attention_frag<DP, NW, 3>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, frag_smem<DP, NW>(2));
+  return e != hipSuccess ? e : hipFuncSetAttribute(reinterpret_cast<const void*>(k_attention_frag<DP, NW, 1>),
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, frag_smem<DP, NW>(1));
+}
+static hipError_t attn_frag_init() {
+  hipError_t e = hipSuccess;
+#define ATTF_INIT(DP)                                                  \
+  if (e == hipSuccess) e = init_att_frag<DP, 8>();                     \
+  if (e == hipSuccess) e = init_att_frag<DP, 4>();                     \
+  if (e == hipSuccess) e = init_att_frag<DP, 2>();
+  ATTF_INIT(16) ATTF_INIT(32) ATTF_INIT(48) ATTF_INIT(64)
+#undef ATTF_INIT
+  return e;
+}
+
+hipError_t launch_attention_frag(const AttnFragParams& p, hipStream_t st) {
+  if (p.d % 16 != 0 || p.d > 64 || p.d <= 0 || (p.nsplit != 1 && p.nsplit != 3) || !p.q || !p.kf_hi || !p.vf_hi) return hipErrorInvalidValue;
+  if (p.nsplit == 3 && (!p.kf_lo || !p.vf_lo)) return hipErrorInvalidValue;
+  if (p.self_layout && (p.d & 15)) return hipErrorInvalidValue;
+  const long waves = (long)p.B * p.H * ((p.Tq + 31) / 32);
+  static const int nw8_min = [] { const char* e = getenv("DVITS_ATTNF_NW8"); return e ? atoi(e) : 1100; }();
+  static const int nw4_min = [] { const char* e = getenv("DVITS_ATTNF_NW4"); return e ? atoi(e) : 64; }();
+  const int nw = waves >= nw8_min ? 8 : (waves >= nw4_min ? 4 : 2);
+  dim3 grid((p.Tq + 32 * nw - 1) / (32 * nw), p.H, p.B);
+#define ATTF(DP)                                             \
+  if (nw == 8) launch_att_frag<DP, 8>(p, grid, st);          \
+  else if (nw == 4) launch_att_frag<DP, 4>(p, grid, st);     \
+  else launch_att_frag<DP, 2>(p, grid, st);
+  if (p.d == 16) { ATTF(16) } else if (p.d == 32) { ATTF(32) } else if (p.d == 48) { ATTF(48) } else { ATTF(64) }
+#undef ATTF
+  return hipGetLastError();
 }
 
 hipError_t launch_attention(const AttnParams& p, hipStream_t st) {

@@ -21,6 +21,7 @@
 #include "dv_device.h"
 
 #include <cstdlib>
+#include <type_traits>
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
@@ -45,8 +46,8 @@ constexpr int DEPTH = 6;                           // weight fragments (hi + lo:
 __device__ __forceinline__ int swz(int row) { return (row >> 1) & 7; }
 __device__ __forceinline__ unsigned pk(float lo, float hi) { return dv_cvt_pk_bf16(lo, hi); }
 
-template <int NS, int AMODE, bool XA = false>
-__global__ __launch_bounds__(XA ? NT : NT_LAUNCH) void k_chain2(const ChainParams p) {
+template <int NS, int AMODE, bool XA = false, bool SA = false>
+__global__ __launch_bounds__((XA || (SA && NS >= 3)) ? NT : NT_LAUNCH) void k_chain2(const ChainParams p) {
   extern __shared__ __attribute__((aligned(1024))) char smem[];
   constexpr int CH = 2 * NS;                       // 64-channel chunks of the A operand
   constexpr int A_PL = CH * CHUNK_PL;              // bytes per plane of the resident A operand
@@ -54,7 +55,7 @@ __global__ __launch_bounds__(XA ? NT : NT_LAUNCH) void k_chain2(const ChainParam
   char* const a_reg = smem;                        // [2 planes][CH][32 rows][128 B]
   char* const red_reg = smem + 2 * A_PL;           // k-group hand-over (NS * 16 KiB); GroupNorm entries before stage 1
   __shared__ float2 s_rowp[BM][16];                // LayerNorm row partials per 32-column block (sum, M2 about the block mean)
-  __shared__ float2 s_ln[BM];                      // per row (mean, rstd)
+  __shared__ __attribute__((aligned(16))) float2 s_ln[BM];   // per row (mean, rstd)
   __shared__ __attribute__((aligned(16))) float s_gscale[AMODE ? C : 4], s_gshift[AMODE ? C : 4];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -66,7 +67,8 @@ __global__ __launch_bounds__(XA ? NT : NT_LAUNCH) void k_chain2(const ChainParam
   // a scratch word (no VGPR destination, the wave's own vmcnt), so the L2 fills with thousands of requests in flight
   // while the eight compute waves start on their first fragments.
   // (the cross-attention variant runs without it: a ninth wave caps the kernel at 168 VGPRs and it needs ~230)
-  if (!XA && wave == NWV) {
+  // (so does the C = 384 fragment-output variant: at 168 VGPRs it spills ~600 bytes per lane)
+  if (!XA && !(SA && NS >= 3) && wave == NWV) {
     __shared__ __attribute__((aligned(256))) unsigned s_pf[64];
     const int xw = blockIdx.x >> 3, nxw = (gridDim.x + 7) >> 3;
     const int l1 = C * C / 64, l2 = p.passes * l1, l3 = XA ? l1 : 0;   // 128-byte lines per plane of stage 1 / 2 / 3
@@ -113,13 +115,16 @@ __global__ __launch_bounds__(XA ? NT : NT_LAUNCH) void k_chain2(const ChainParam
     f.l = *reinterpret_cast<const bf16x8*>(wf_lo + e);
     return f;
   };
-  auto stage_prologue = [&](const bf16_t* wf_hi, const bf16_t* wf_lo, int frag0, BFrag (&bq)[DEPTH]) {
+  auto stage_prologue = [&](const bf16_t* wf_hi, const bf16_t* wf_lo, int frag0, BFrag (&bq)[DEPTH]) __attribute__((always_inline)) {
 #pragma unroll
     for (int j = 0; j < DEPTH; ++j)
       if (j < U) bq[j] = load_unit(wf_hi, wf_lo, frag0, j);
     __builtin_amdgcn_sched_barrier(0);
   };
-  auto stage_loop = [&](const bf16_t* wf_hi, const bf16_t* wf_lo, int frag0, BFrag (&bq)[DEPTH], f32x16 (&acc)[NS]) {
+  // swap_tag: the activations are the FIRST MFMA operand - the accumulator is then the tile itself, lane = output column,
+  // registers = rows 8g + 4lh + e (used for V: that register image IS the V^T operand fragment of the attention kernel)
+  auto stage_loop = [&](const bf16_t* wf_hi, const bf16_t* wf_lo, int frag0, BFrag (&bq)[DEPTH], f32x16 (&acc)[NS], auto swap_tag) __attribute__((always_inline)) {
+    constexpr bool SWAP = decltype(swap_tag)::value;
     // A fragment of k-step ksl (this wave's k-half): read one k-step ahead of its MFMAs (LDS latency off the chain)
     auto read_a = [&](int ksl, bf16x8& h, bf16x8& l) {
       const int c16 = (kg * KH + ksl) * 2 + lh;                    // 16-byte chunk of the row: k-step * 2 + half
@@ -134,9 +139,15 @@ __global__ __launch_bounds__(XA ? NT : NT_LAUNCH) void k_chain2(const ChainParam
       const int ksl = u / NS, cur = ksl & 1;
       if (u % NS == 0 && ksl + 1 < KH) read_a(ksl + 1, ah[cur ^ 1], al[cur ^ 1]);
       const BFrag f = bq[u % DEPTH];
-      acc[u % NS] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.h, al[cur], acc[u % NS], 0, 0, 0);
-      acc[u % NS] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.l, ah[cur], acc[u % NS], 0, 0, 0);
-      acc[u % NS] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.h, ah[cur], acc[u % NS], 0, 0, 0);
+      if (SWAP) {
+        acc[u % NS] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[cur], f.h, acc[u % NS], 0, 0, 0);
+        acc[u % NS] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[cur], f.l, acc[u % NS], 0, 0, 0);
+        acc[u % NS] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[cur], f.h, acc[u % NS], 0, 0, 0);
+      } else {
+        acc[u % NS] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.h, al[cur], acc[u % NS], 0, 0, 0);
+        acc[u % NS] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.l, ah[cur], acc[u % NS], 0, 0, 0);
+        acc[u % NS] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.h, ah[cur], acc[u % NS], 0, 0, 0);
+      }
       // pinned: without the scheduling barriers hipcc sinks every prefetch down to its use (load -> vmcnt(0) -> MFMA)
       __builtin_amdgcn_sched_barrier(0);
       if (u + DEPTH < U) bq[u % DEPTH] = load_unit(wf_hi, wf_lo, frag0, u + DEPTH);
@@ -144,7 +155,7 @@ __global__ __launch_bounds__(XA ? NT : NT_LAUNCH) void k_chain2(const ChainParam
     }
   };
   // k-group 1 hands its accumulators to k-group 0 through `buf` (NS * 16 KiB)
-  auto kgroup_reduce = [&](f32x16 (&acc)[NS], char* buf) {
+  auto kgroup_reduce = [&](f32x16 (&acc)[NS], char* buf) __attribute__((always_inline)) {
     float* red = reinterpret_cast<float*>(buf);
     __syncthreads();                               // the buffer's previous readers are done; every wave has left its k-loop
     if (kg == 1) {
@@ -256,7 +267,7 @@ __global__ __launch_bounds__(XA ? NT : NT_LAUNCH) void k_chain2(const ChainParam
   for (int ns = 0; ns < NS; ++ns)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[ns][r] = 0.f;
-  stage_loop(p.w1_hi, p.w1_lo, 0, bq, acc);
+  stage_loop(p.w1_hi, p.w1_lo, 0, bq, acc, std::false_type{});
   DV_CTRACE(3);
   stage_prologue(p.w2_hi, p.w2_lo, 0, bq);         // the second GEMM's first fragments fly during the hand-over and the epilogue
   kgroup_reduce(acc, red_reg);                     // (its leading barrier: every wave is done reading the A operand)
@@ -317,17 +328,53 @@ __global__ __launch_bounds__(XA ? NT : NT_LAUNCH) void k_chain2(const ChainParam
   DV_CTRACE(5);
 
   // ================= stage 2: `passes` contractions of C output columns each =================
-  for (int ps = 0; ps < p.passes; ++ps) {
+  // SA (self-attention operands as MFMA fragments: sa_kf / sa_vf, passes = q | k | v): the three passes are separate code
+  // - pass 1 stores K as K fragments, pass 2 runs with swapped operands and stores its accumulator as V^T fragments
+  auto do_pass = [&](const int ps, const int npass, auto mode_tag) __attribute__((always_inline)) {
+    constexpr int MODE = decltype(mode_tag)::value;    // 0: fp32 (or the in-kernel query), 1: K fragments, 2: V^T fragments
+    constexpr bool sa = MODE != 0;
 #pragma unroll
     for (int ns = 0; ns < NS; ++ns)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[ns][r] = 0.f;
-    stage_loop(p.w2_hi, p.w2_lo, ps * (C / 32), bq, acc);
+    stage_loop(p.w2_hi, p.w2_lo, ps * (C / 32), bq, acc, std::integral_constant<bool, MODE == 2>{});
     if (ps == 0) DV_CTRACE(6);
-    if (ps + 1 < p.passes) stage_prologue(p.w2_hi, p.w2_lo, (ps + 1) * (C / 32), bq);
+    if (ps + 1 < npass) stage_prologue(p.w2_hi, p.w2_lo, (ps + 1) * (C / 32), bq);
     kgroup_reduce(acc, red_reg);
     if (ps == 0) DV_CTRACE(7);
-    if (kg == 0) {
+    if (MODE == 2) {
+      if (kg == 0) {
+        // V: lane = channel ns*128 + wn*32 + l31, registers = rows (keys) 8g + 4lh + e.  Registers 8kb .. 8kb+7 are the
+        // 8 keys a lane of the S^T accumulator holds for k-block kb: written as they are, they form the V^T fragment
+        // (channel block f = ns*4 + wn, k-block kb) of this 32-key tile
+#pragma unroll
+        for (int ns = 0; ns < NS; ++ns) {
+          const int n = 2 * C + ns * 128 + wn * 32 + l31;
+          const float bv = p.b2[n], uv = p.u2[n];
+#pragma unroll
+          for (int kb = 0; kb < 2; ++kb) {
+            uint4 hw, lw;
+            unsigned* hp = &hw.x; unsigned* lp = &lw.x;
+#pragma unroll
+            for (int gg = 0; gg < 2; ++gg) {
+              // rows 8g + 4lh + e, g = 2kb + gg: their (mean, rstd) are 32 contiguous bytes of s_ln
+              const int g = 2 * kb + gg;
+              const float4 s01 = *reinterpret_cast<const float4*>(&s_ln[8 * g + 4 * lh]);
+              const float4 s23 = *reinterpret_cast<const float4*>(&s_ln[8 * g + 4 * lh + 2]);
+              const float x0 = s01.y * (acc[ns][4 * g] - s01.x * uv) + bv, x1 = s01.w * (acc[ns][4 * g + 1] - s01.z * uv) + bv;
+              const float x2 = s23.y * (acc[ns][4 * g + 2] - s23.x * uv) + bv, x3 = s23.w * (acc[ns][4 * g + 3] - s23.z * uv) + bv;
+              const unsigned h01 = pk(x0, x1), h23 = pk(x2, x3);
+              hp[2 * gg] = h01; hp[2 * gg + 1] = h23;
+              lp[2 * gg] = pk(x0 - __uint_as_float(h01 << 16), x1 - __uint_as_float(h01 & 0xffff0000u));
+              lp[2 * gg + 1] = pk(x2 - __uint_as_float(h23 << 16), x3 - __uint_as_float(h23 & 0xffff0000u));
+            }
+            const size_t eo = ((((size_t)blockIdx.x * (C / 32) + ns * 4 + wn) * 2 + kb) * 64 + lane) * 8;
+            *reinterpret_cast<uint4*>(p.sa_vf_hi + eo) = hw;
+            *reinterpret_cast<uint4*>(p.sa_vf_lo + eo) = lw;
+          }
+        }
+      }
+    } else if (kg == 0) {
       const int m = m0 + l31;
       const float2 st = s_ln[l31];
 #pragma unroll
@@ -343,7 +390,18 @@ __global__ __launch_bounds__(XA ? NT : NT_LAUNCH) void k_chain2(const ChainParam
           o.y = st.y * (acc[ns][4 * g + 1] - st.x * uv.y) + bv.y;
           o.z = st.y * (acc[ns][4 * g + 2] - st.x * uv.z) + bv.z;
           o.w = st.y * (acc[ns][4 * g + 3] - st.x * uv.w) + bv.w;
-          if (!XA) *reinterpret_cast<float4*>(p.out2 + (size_t)m * p.ldo2 + n) = o;
+          if (MODE == 1) {
+            // K: 4 channels of key row l31 -> 8 bytes of the K fragment (tile = this row block, 16-channel group n / 16):
+            // its lane (g & 1, l31) holds channels (n & ~7) .. + 8, this lane's four at byte 8 lh
+            uint2 hw, lw;
+            hw.x = pk(o.x, o.y); hw.y = pk(o.z, o.w);
+            lw.x = pk(o.x - __uint_as_float(hw.x << 16), o.y - __uint_as_float(hw.x & 0xffff0000u));
+            lw.y = pk(o.z - __uint_as_float(hw.y << 16), o.w - __uint_as_float(hw.y & 0xffff0000u));
+            const int nk = n - C;
+            const size_t eo = (((size_t)blockIdx.x * (C / 16) + (nk >> 4)) * 64 + (g & 1) * 32 + l31) * 8 + lh * 4;
+            *reinterpret_cast<uint2*>(p.sa_kf_hi + eo) = hw;
+            *reinterpret_cast<uint2*>(p.sa_kf_lo + eo) = lw;
+          } else if (!XA) *reinterpret_cast<float4*>(p.out2 + (size_t)m * p.ldo2 + n) = o;
           else {
             // the query of the cross attention stays in the workgroup: pre-scaled (d^-1/2 log2 e) split planes in the A
             // region (the planes of x1 are dead: every wave has left the stage-2 k-loop)
@@ -361,6 +419,13 @@ __global__ __launch_bounds__(XA ? NT : NT_LAUNCH) void k_chain2(const ChainParam
       }
     }
     if (ps == 0) DV_CTRACE(8);
+  };
+  if constexpr (SA) {
+    do_pass(0, 3, std::integral_constant<int, 0>{});
+    do_pass(1, 3, std::integral_constant<int, 1>{});
+    do_pass(2, 3, std::integral_constant<int, 2>{});
+  } else {
+    for (int ps = 0; ps < p.passes; ++ps) do_pass(ps, p.passes, std::integral_constant<int, 0>{});
   }
   if constexpr (XA) {
     // ================= cross attention: wave h = head h, 32 queries, keys / values as MFMA fragments from global =================
@@ -493,7 +558,7 @@ __global__ __launch_bounds__(XA ? NT : NT_LAUNCH) void k_chain2(const ChainParam
     for (int ns = 0; ns < NS; ++ns)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[ns][r] = 0.f;
-    stage_loop(p.w3_hi, p.w3_lo, 0, bq, acc);
+    stage_loop(p.w3_hi, p.w3_lo, 0, bq, acc, std::false_type{});
     kgroup_reduce(acc, red_reg);
     if (kg == 0) {
       const int m = m0 + l31;
@@ -591,15 +656,15 @@ __global__ __launch_bounds__(64) void k_relayout_frag(const bf16_t* __restrict__
   *reinterpret_cast<uint4*>(dst + ((size_t)(nf * ksteps + ks) * 64 + lane) * 8) = v;
 }
 
-template <int NS, int AMODE, bool XA = false>
+template <int NS, int AMODE, bool XA = false, bool SA = false>
 hipError_t init_one() {
   const int smem = 2 * 2 * NS * CHUNK_PL + NS * 16384;
-  return hipFuncSetAttribute(reinterpret_cast<const void*>(k_chain2<NS, AMODE, XA>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+  return hipFuncSetAttribute(reinterpret_cast<const void*>(k_chain2<NS, AMODE, XA, SA>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
 }
-template <int NS, int AMODE, bool XA = false>
+template <int NS, int AMODE, bool XA = false, bool SA = false>
 hipError_t launch_one(const ChainParams& p, hipStream_t st) {
   const int smem = 2 * 2 * NS * CHUNK_PL + NS * 16384;
-  hipLaunchKernelGGL((k_chain2<NS, AMODE, XA>), dim3(p.M / BM), dim3(XA ? NT : NT_LAUNCH), smem, st, p);
+  hipLaunchKernelGGL((k_chain2<NS, AMODE, XA, SA>), dim3(p.M / BM), dim3((XA || (SA && NS >= 3)) ? NT : NT_LAUNCH), smem, st, p);
   return hipGetLastError();
 }
 
@@ -615,6 +680,9 @@ hipError_t chain_init() {
   if ((e = init_one<2, 1>()) != hipSuccess) return e;
   if ((e = init_one<3, 1>()) != hipSuccess) return e;
   if ((e = init_one<4, 1>()) != hipSuccess) return e;
+  if ((e = init_one<1, 1, false, true>()) != hipSuccess) return e;
+  if ((e = init_one<2, 1, false, true>()) != hipSuccess) return e;
+  if ((e = init_one<3, 1, false, true>()) != hipSuccess) return e;
   if ((e = init_one<1, 0, true>()) != hipSuccess) return e;
   return init_one<2, 0, true>();   // (C = 384 with the attention inside needs > 256 VGPRs: it keeps the separate launches)
 }
@@ -651,6 +719,9 @@ bool chain2_supported(const ChainParams& p, int precision) {
         !p.rowstat3)
       return false;
   }
+  if (p.sa_kf_hi) {                                                    // q | k | v with K / V as attention fragments
+    if (p.amode != 1 || p.passes != 3 || p.C > 384 || !p.sa_kf_lo || !p.sa_vf_hi || !p.sa_vf_lo) return false;
+  }
   if (p.amode == 1) {
     const int G = p.groups;
     if (G <= 0 || G > 64 || (G & (G - 1)) != 0 || p.C % G != 0 || (p.C / G) % 16 != 0) return false;
@@ -665,6 +736,7 @@ hipError_t launch_chain2(const ChainParams& p, int precision, hipStream_t st) {
   if (p.amode == 0 ? (!p.a_hi || !p.a_lo) : (!p.x || !p.stat16 || !p.gamma || !p.beta)) return hipErrorInvalidValue;
   const int ns = p.C / 128;
   if (p.xa_kf_hi) return ns == 1 ? launch_one<1, 0, true>(p, st) : launch_one<2, 0, true>(p, st);
+  if (p.sa_kf_hi) return ns == 1 ? launch_one<1, 1, false, true>(p, st) : (ns == 2 ? launch_one<2, 1, false, true>(p, st) : launch_one<3, 1, false, true>(p, st));
   if (p.amode == 0)
     return ns == 1 ? launch_one<1, 0>(p, st) : (ns == 2 ? launch_one<2, 0>(p, st) : (ns == 3 ? launch_one<3, 0>(p, st) : launch_one<4, 0>(p, st)));
   return ns == 1 ? launch_one<1, 1>(p, st) : (ns == 2 ? launch_one<2, 1>(p, st) : (ns == 3 ? launch_one<3, 1>(p, st) : launch_one<4, 1>(p, st)));

@@ -560,6 +560,31 @@ def test_row_block_chains_match_one_launch_per_gemm():
     assert rel_l2(outs[1], outs[0]) < 5e-5 and rel_l2(outs[2], outs[0]) < 5e-5
 
 
+def test_attention_on_mfma_ready_fragments_matches_converting_kernel():
+    """Default schedule: the q|k|v chain writes K and V as split-bf16 MFMA fragments of 32-key tiles (V through a
+    swapped-operand GEMM pass, so its accumulator is the V^T fragment) and k_attention_frag multiplies them as they
+    arrive.  DVITS_ATTN_FRAG=0 restores fp32 q|k|v + the converting kernel: the same products in the same order -
+    agreement to float32 rounding (the hi/lo split of K, V happens before instead of after the LDS staging)."""
+    from diff_vits_amd.unet1d.unet_1d_condition import UNet1DConditionModel
+    kw, sd, sample, t, enc, mask = unet_case("cfg1")
+    outs = []
+    for fr in ("0", "1"):
+        os.environ["DVITS_ATTN_FRAG"] = fr
+        try:
+            m = UNet1DConditionModel(backend="hip", **kw).eval()
+            m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+            m = m.cuda()
+            with torch.no_grad():
+                y = m(torch.from_numpy(sample).cuda(), torch.from_numpy(t).cuda(), torch.from_numpy(enc).cuda(),
+                      encoder_attention_mask=torch.from_numpy(mask).cuda()).sample
+            outs.append(y.cpu().numpy())
+        finally:
+            os.environ.pop("DVITS_ATTN_FRAG", None)
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "unet_cfg1.npz"))["y"]
+    assert rel_l2(outs[0], g) < 2e-4 and rel_l2(outs[1], g) < 2e-4
+    assert rel_l2(outs[1], outs[0]) < 2e-5
+
+
 def test_groupnorm_finished_in_producer_epilogue_matches_separate_launch():
     """Default schedule: conv1 of every resnet block finishes norm2 (+ temb scale/shift + SiLU) in its own epilogue - the
     workgroups exchange 32x16-block statistics inside the launch (gemm_tile.h GNX) - instead of a k_gn_apply launch.
