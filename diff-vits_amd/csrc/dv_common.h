@@ -105,6 +105,7 @@ struct GemmParams {
   int af;                       // 1: A operand produced in-kernel from afp (plane pointers of seg[] unused); T_out % 32 == 0
   AfParams afp;
   GnxParams gnx;                // GroupNorm of the output in the epilogue (needs stats16)
+  int xcd_n;                    // internal (launch_gemm): XCDs the columns are split over (0: row bands of the tile grid)
 };
 // exchange words a GNX GEMM needs (M / 32 * N / 16), or 0 if launch_gemm would refuse it (tile shape vs T_out / groups,
 // more workgroups than `n_cu` compute units, unsupported epilogue)

@@ -29,10 +29,22 @@
 template <int BM, int BN, int BK, int WM, int WN, int NSPLIT, int KS, bool AF = false>
 __global__ __launch_bounds__(64 * WM * WN * KS) void k_gemm(const GemmParams p) {
   extern __shared__ __attribute__((aligned(1024))) char smem[];
-  // XCD-aware tile order: consecutive tile ids (same A rows, neighbouring N) share an L2.
+  // XCD-aware tile order (workgroup b runs on XCD b % 8; each XCD has its own L2, which starts cold): an XCD's workgroups
+  // form a rectangle of the tile grid so that its L2 fetches (rows / xm) of A and (columns / xn) of W once.
   const int n_tiles_n = (p.N + BN - 1) / BN;
   const int nwg = gridDim.x;
   int bid = blockIdx.x;
+  if (p.xcd_n > 0) {
+    // launch_gemm checked: 8 | nwg; (k-slices) x xm x xn = 8; xm | row tiles, xn | column tiles
+    const int n_tiles_m = (p.M + BM - 1) / BM;
+    const int xs = (p.sk_mode == 1 || p.sk_mode == 3) ? p.sk_split : 1, xn = p.xcd_n, xm = 8 / (xs * xn);
+    const int x = bid & 7, i = bid >> 3;
+    const int ks_i = x / (xm * xn), r = x - ks_i * (xm * xn), xm_i = r / xn, xn_i = r - xm_i * xn;
+    const int tn = n_tiles_n / xn, tm = n_tiles_m / xm;
+    const int lm = i / tn, ln = i - lm * tn;
+    gemm_tile<BM, BN, BK, WM, WN, NSPLIT, KS, false, AF>(p, (xm_i * tm + lm) * BM, (xn_i * tn + ln) * BN, smem, ks_i);
+    return;
+  }
   {
     const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
     bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
@@ -247,6 +259,11 @@ static void gemm_pick_tile(const GemmParams& p, int& bm, int& bn) {
   for (int s = 0; s < p.nseg; ++s) k64 = k64 && p.seg[s].c0 % 64 == 0 && p.seg[s].c1 % 64 == 0;
   if (cnt(128, 128) >= tune.big) { bm = 128; bn = 128; return; }
   const int min_wg = k64 ? tune.min_wg : (tune.min_wg > 0 ? tune.min_wg : 1);
+  if (p.epi == EPI_GEGLU) {
+    if (cnt(128, 64) >= min_wg) { bm = 128; bn = 64; return; }
+    if (cnt(64, 64) >= min_wg) { bm = 64; bn = 64; return; }
+    bm = 32; bn = 64; return;
+  }
   static const int t1_min = [] { const char* e = getenv("DVITS_GEMM_T1"); return e ? atoi(e) : (1 << 30); }();
   if (k64 && cnt(128, 64) >= t1_min) { bm = 128; bn = 64; return; }
   if (cnt(64, 64) >= min_wg) { bm = 64; bn = 64; return; }
@@ -305,6 +322,27 @@ hipError_t launch_gemm(const GemmParams& pin, int precision, hipStream_t st) {
     return launch_gemm(p, precision, st);
   }
   if (!p.sk_buf || p.sk_split < 2) { p.sk_buf = nullptr; p.sk_split = 0; p.sk_mode = 0; p.sk_ticket = nullptr; }
+  // XCD rectangle (k_gemm): split the columns over xn of the 8 XCDs where that lowers what one L2 has to fetch -
+  // (N / xn) x K of W plus (M / xm) x channels of A.  DVITS_XCD_N=<1|2|4|8> forces xn where it divides, 0 = row bands.
+  p.xcd_n = 0;
+  if (p.force_tile == GT_AUTO && !p.af) {
+    static const int env_xn = [] { const char* e = getenv("DVITS_XCD_N"); return e ? atoi(e) : -1; }();
+    int bm, bn;
+    gemm_pick_tile(p, bm, bn);
+    const int tm = (p.M + bm - 1) / bm, tn = (p.N + bn - 1) / bn;
+    const int xs = (p.sk_mode == 1 || p.sk_mode == 3) ? p.sk_split : 1;
+    long chans = 0, ktot = 0;
+    for (int s2 = 0; s2 < p.nseg; ++s2) { chans += p.seg[s2].c0 + p.seg[s2].c1; ktot += (long)p.seg[s2].taps * (p.seg[s2].c0 + p.seg[s2].c1); }
+    double best = 0; int best_xn = 0;
+    for (int xn = 1; xn * xs <= 8; xn *= 2) {
+      const int xm = 8 / (xs * xn);
+      if ((tm * tn * xs) % 8 != 0 || tm % xm != 0 || tn % xn != 0 || (xs != 1 && xs != 2)) continue;
+      if (env_xn >= 0 && xn != env_xn) continue;
+      const double cost = (double)p.N / xn * ktot + (double)p.M / xm * chans;
+      if (best_xn == 0 || cost < best * 0.97) { best = cost; best_xn = xn; }
+    }
+    if (env_xn != 0) p.xcd_n = best_xn;
+  }
   const GemmTune& tune = gemm_tune();
   const int big_tiles = ((p.M + 127) / 128) * ((p.N + 127) / 128);
   bool k64 = tune.bk64 != 0;
