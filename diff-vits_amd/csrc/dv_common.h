@@ -187,6 +187,7 @@ struct AttnParams {
   int B, H, Tq, Tk, d;
   float scale;
   int nsplit;                   // 3: split-bf16 (hi*hi + lo*hi + hi*lo), 1: single bf16 product
+  int no_xcd_map;               // internal (launcher): 1 = plain block order (DVITS_ATTN_XCD=0, experiments)
 };
 
 // Attention over K / V that arrive as MFMA fragments of 32-key tiles (k_attention_frag, kernels_attn.hip): written by
@@ -207,6 +208,7 @@ struct AttnFragParams {
   int B, H, Tq, Tk, d;
   float scale;
   int nsplit;
+  int no_xcd_map;               // internal (launcher)
 };
 hipError_t launch_attention_frag(const AttnFragParams& p, hipStream_t st);
 

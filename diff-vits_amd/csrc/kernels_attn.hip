@@ -27,10 +27,30 @@
 
 #include <cstdlib>
 
+// 1-D grid -> (query block, head, batch item).  Workgroup id runs on XCD id % 8 and every XCD has its own (cold) L2: all
+// query blocks of one (batch item, head) are given to ONE XCD, so its K / V cross the fabric once instead of once per
+// query block (up to 4x at the bench shape).
+__device__ __forceinline__ void attn_block_of(int id, int nq, int H, int B, int& qblk, int& h, int& b, bool by_xcd = true) {
+  const int pairs = H * B;
+  int pair;
+  if (by_xcd && (pairs & 7) == 0) {
+    const int x = id & 7, i = id >> 3;
+    pair = (i / nq) * 8 + x;
+    qblk = i - (i / nq) * nq;
+  } else {
+    pair = id / nq;
+    qblk = id - pair * nq;
+  }
+  b = pair / H;
+  h = pair - b * H;
+}
+
 template <int DP, int NW, int NSPLIT>
 __global__ __launch_bounds__(64 * NW) void k_attention(const AttnParams p) {
   extern __shared__ __attribute__((aligned(1024))) char lds[];   // [2 x BUF planes | NST x RAW ring]
-  attn_tile<DP, NW, NSPLIT, false>(p, blockIdx.x, blockIdx.y, blockIdx.z, lds);
+  int qblk, h, b;
+  attn_block_of(blockIdx.x, (p.Tq + 32 * NW - 1) / (32 * NW), p.H, p.B, qblk, h, b, p.no_xcd_map == 0);
+  attn_tile<DP, NW, NSPLIT, false>(p, qblk, h, b, lds);
 }
 
 template <int DP, int NW>
@@ -87,7 +107,8 @@ __global__ __launch_bounds__(64 * NW) void k_attention_frag(const AttnFragParams
   constexpr int CPW = (NI + NW - 1) / NW;               // per wave (at most)
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l31 = lane & 31, lh = lane >> 5;
-  const int qblk = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+  int qblk, h, b;
+  attn_block_of(blockIdx.x, (p.Tq + 32 * NW - 1) / (32 * NW), p.H, p.B, qblk, h, b, p.no_xcd_map == 0);
   const int d = p.d;
   const int qi = qblk * (32 * NW) + wave * 32 + l31;
   const bool q_ok = qi < p.Tq;
@@ -328,7 +349,11 @@ static hipError_t attn_frag_init() {
   return e;
 }
 
-hipError_t launch_attention_frag(const AttnFragParams& p, hipStream_t st) {
+static int attn_no_xcd_map() { static const int v = [] { const char* e = getenv("DVITS_ATTN_XCD"); return (e && e[0] == '0') ? 1 : 0; }(); return v; }
+
+hipError_t launch_attention_frag(const AttnFragParams& pin, hipStream_t st) {
+  AttnFragParams p = pin;
+  p.no_xcd_map = attn_no_xcd_map();
   if (p.d % 16 != 0 || p.d > 64 || p.d <= 0 || (p.nsplit != 1 && p.nsplit != 3) || !p.q || !p.kf_hi || !p.vf_hi) return hipErrorInvalidValue;
   if (p.nsplit == 3 && (!p.kf_lo || !p.vf_lo)) return hipErrorInvalidValue;
   if (p.self_layout && (p.d & 15)) return hipErrorInvalidValue;
@@ -336,7 +361,7 @@ hipError_t launch_attention_frag(const AttnFragParams& p, hipStream_t st) {
   static const int nw8_min = [] { const char* e = getenv("DVITS_ATTNF_NW8"); return e ? atoi(e) : 1100; }();
   static const int nw4_min = [] { const char* e = getenv("DVITS_ATTNF_NW4"); return e ? atoi(e) : 64; }();
   const int nw = waves >= nw8_min ? 8 : (waves >= nw4_min ? 4 : 2);
-  dim3 grid((p.Tq + 32 * nw - 1) / (32 * nw), p.H, p.B);
+  dim3 grid(((p.Tq + 32 * nw - 1) / (32 * nw)) * p.H * p.B);
 #define ATTF(DP)                                             \
   if (nw == 8) launch_att_frag<DP, 8>(p, grid, st);          \
   else if (nw == 4) launch_att_frag<DP, 4>(p, grid, st);     \
@@ -346,7 +371,9 @@ hipError_t launch_attention_frag(const AttnFragParams& p, hipStream_t st) {
   return hipGetLastError();
 }
 
-hipError_t launch_attention(const AttnParams& p, hipStream_t st) {
+hipError_t launch_attention(const AttnParams& pin, hipStream_t st) {
+  AttnParams p = pin;
+  p.no_xcd_map = attn_no_xcd_map();
   if (p.d % 4 != 0 || p.d > 64 || p.d <= 0 || (p.nsplit != 1 && p.nsplit != 3)) return hipErrorInvalidValue;
   // queries per workgroup: the K / V tiles are converted once per workgroup, so more waves per workgroup amortise
   // that, fewer spread the launch over more CUs.  Measured at the bench shape (after the conversion was made cheap):
@@ -356,7 +383,7 @@ hipError_t launch_attention(const AttnParams& p, hipStream_t st) {
   static const int nw8_min = [] { const char* e = getenv("DVITS_ATTN_NW8"); return e ? atoi(e) : 1100; }();
   static const int nw4_min = [] { const char* e = getenv("DVITS_ATTN_NW4"); return e ? atoi(e) : 64; }();
   const int nw = waves >= nw8_min ? 8 : (waves >= nw4_min ? 4 : (waves >= 16 ? 2 : 1));
-  dim3 grid((p.Tq + 32 * nw - 1) / (32 * nw), p.H, p.B);
+  dim3 grid(((p.Tq + 32 * nw - 1) / (32 * nw)) * p.H * p.B);
   const int dp = (p.d + 15) / 16 * 16;
 #define ATT(DP)                                         \
   if (nw == 8) launch_att<DP, 8>(p, grid, st);          \
