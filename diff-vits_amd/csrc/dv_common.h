@@ -167,6 +167,9 @@ struct ChainParams {
   //      key(kb, lh, j) = kb*16 + (j < 4 ? 4 lh + j : 8 + 4 lh + j - 4) - the order of a score accumulator's registers
   // out2 then receives the query columns only (ldo2 >= C).
   bf16_t* sa_kf_hi; bf16_t* sa_kf_lo; bf16_t* sa_vf_hi; bf16_t* sa_vf_lo;
+  // amode 1: workgroups per row block (0 / 1: one).  2 or 3: the stage-2 passes are shared out between them, each
+  // repeating stage 1 - for launches with fewer row blocks than CUs (every workgroup streams the weights it multiplies)
+  int nsplit;
 };
 // cross-attention K/V of one block, fp32 [B*L, 2C] (k | v) -> MFMA-fragment-major split planes (ChainParams xa_*)
 hipError_t launch_kv_frag(const float* kv, bf16_t* kf_hi, bf16_t* kf_lo, bf16_t* vf_hi, bf16_t* vf_lo, int B, int L, int C, int H,

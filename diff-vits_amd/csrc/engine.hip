@@ -978,6 +978,11 @@ struct Builder {
         cp.w2_hi = w_qkv->fhi; cp.w2_lo = w_qkv->flo; cp.Kp2 = w_qkv->Kp; cp.b2 = w_qkv->bias; cp.u2 = w_qkv->u;
         cp.passes = 3; cp.out2 = qkv; cp.ldo2 = sa_frag ? C : 3 * C; cp.ln_eps = 1e-5f;
         if (sa_frag) { cp.sa_kf_hi = kf.hi; cp.sa_kf_lo = kf.lo; cp.sa_vf_hi = vf.hi; cp.sa_vf_lo = vf.lo; }
+        {   // few row blocks: share the three passes out (DVITS_CHAIN_SPLIT=0: one workgroup per row block)
+          static const bool off = [] { const char* e = getenv("DVITS_CHAIN_SPLIT"); return e && e[0] == '0'; }();
+          const int rbs = M / 32, cus = n_cu > 0 ? n_cu : 256;
+          cp.nsplit = off ? 1 : (rbs * 3 <= cus ? 3 : (rbs * 2 <= cus ? 2 : 1));
+        }
         chain(ops, cp, sa_frag ? "norm+proj_in+LN+q|Kfrag|Vfrag" : "norm+proj_in+LN+qkv");
       }
       probe(p + "proj_in", h, Tn, C);

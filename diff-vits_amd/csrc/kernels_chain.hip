@@ -85,7 +85,7 @@ __global__ __launch_bounds__((XA || (SA && NS >= 3)) ? NT : NT_LAUNCH) void k_ch
       glds4(src, (unsigned)(size_t)s_pf);
     }
     if (p.res) {                                   // this workgroup's residual rows (read by the first epilogue)
-      const char* r0 = reinterpret_cast<const char*>(p.res + (size_t)blockIdx.x * BM * C);
+      const char* r0 = reinterpret_cast<const char*>(p.res + (size_t)(blockIdx.x / (p.nsplit > 1 && AMODE == 1 && !XA ? p.nsplit : 1)) * BM * C);
       for (int ln = lane; ln < BM * C / 32; ln += 64) glds4(r0 + (size_t)ln * 128, (unsigned)(size_t)s_pf);
     }
     // the epilogues' bias / LayerNorm-u vectors (their first touch would be a dependent cold miss inside the epilogue)
@@ -98,7 +98,14 @@ __global__ __launch_bounds__((XA || (SA && NS >= 3)) ? NT : NT_LAUNCH) void k_ch
   }
   DV_CTRACE(0);
   const int wn = wave & 3, kg = wave >> 2, l31 = lane & 31, lh = lane >> 5;
-  const int m0 = blockIdx.x * BM;
+  // nsplit workgroups per row block (amode 1 with several stage-2 passes, few row blocks): each repeats stage 1 (cheap:
+  // the kernel is bound by the weight stream, not by MFMA) and runs its share of the passes - a third of the q | k | v
+  // weights per workgroup on three times the CUs.  Part 0 writes out1.
+  const int nsp = (AMODE == 1 && !XA && p.nsplit > 1) ? p.nsplit : 1;
+  const int rb = nsp == 1 ? (int)blockIdx.x : (int)blockIdx.x / nsp, part = (int)blockIdx.x - rb * nsp;
+  const int npass_all = SA ? 3 : p.passes;
+  const int ps_lo = (part * npass_all + nsp - 1) / nsp, ps_hi = ((part + 1) * npass_all + nsp - 1) / nsp;
+  const int m0 = rb * BM;
   const unsigned a_base = (unsigned)(size_t)a_reg;
   const int d_row = lane >> 3, d_slot = lane & 7;
 
@@ -269,7 +276,7 @@ __global__ __launch_bounds__((XA || (SA && NS >= 3)) ? NT : NT_LAUNCH) void k_ch
     for (int r = 0; r < 16; ++r) acc[ns][r] = 0.f;
   stage_loop(p.w1_hi, p.w1_lo, 0, bq, acc, std::false_type{});
   DV_CTRACE(3);
-  stage_prologue(p.w2_hi, p.w2_lo, 0, bq);         // the second GEMM's first fragments fly during the hand-over and the epilogue
+  stage_prologue(p.w2_hi, p.w2_lo, ps_lo * (C / 32), bq);   // the second GEMM's first fragments fly during the hand-over and the epilogue
   kgroup_reduce(acc, red_reg);                     // (its leading barrier: every wave is done reading the A operand)
   DV_CTRACE(4);
   // epilogue 1 (k-group 0): x1 = acc + b1 (+ res) -> out1 fp32, raw split planes into the A region, row partials
@@ -290,7 +297,7 @@ __global__ __launch_bounds__((XA || (SA && NS >= 3)) ? NT : NT_LAUNCH) void k_ch
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const int n = nf + 8 * g;
-        *reinterpret_cast<float4*>(p.out1 + (size_t)m * C + n) = make_float4(vv[4 * g], vv[4 * g + 1], vv[4 * g + 2], vv[4 * g + 3]);
+        if (part == 0) *reinterpret_cast<float4*>(p.out1 + (size_t)m * C + n) = make_float4(vv[4 * g], vv[4 * g + 1], vv[4 * g + 2], vv[4 * g + 3]);
         uint2 hw, lw;
         hw.x = pk(vv[4 * g], vv[4 * g + 1]); hw.y = pk(vv[4 * g + 2], vv[4 * g + 3]);
         lw.x = pk(vv[4 * g] - __uint_as_float(hw.x << 16), vv[4 * g + 1] - __uint_as_float(hw.x & 0xffff0000u));
@@ -368,7 +375,7 @@ __global__ __launch_bounds__((XA || (SA && NS >= 3)) ? NT : NT_LAUNCH) void k_ch
               lp[2 * gg] = pk(x0 - __uint_as_float(h01 << 16), x1 - __uint_as_float(h01 & 0xffff0000u));
               lp[2 * gg + 1] = pk(x2 - __uint_as_float(h23 << 16), x3 - __uint_as_float(h23 & 0xffff0000u));
             }
-            const size_t eo = ((((size_t)blockIdx.x * (C / 32) + ns * 4 + wn) * 2 + kb) * 64 + lane) * 8;
+            const size_t eo = ((((size_t)rb * (C / 32) + ns * 4 + wn) * 2 + kb) * 64 + lane) * 8;
             *reinterpret_cast<uint4*>(p.sa_vf_hi + eo) = hw;
             *reinterpret_cast<uint4*>(p.sa_vf_lo + eo) = lw;
           }
@@ -398,7 +405,7 @@ __global__ __launch_bounds__((XA || (SA && NS >= 3)) ? NT : NT_LAUNCH) void k_ch
             lw.x = pk(o.x - __uint_as_float(hw.x << 16), o.y - __uint_as_float(hw.x & 0xffff0000u));
             lw.y = pk(o.z - __uint_as_float(hw.y << 16), o.w - __uint_as_float(hw.y & 0xffff0000u));
             const int nk = n - C;
-            const size_t eo = (((size_t)blockIdx.x * (C / 16) + (nk >> 4)) * 64 + (g & 1) * 32 + l31) * 8 + lh * 4;
+            const size_t eo = (((size_t)rb * (C / 16) + (nk >> 4)) * 64 + (g & 1) * 32 + l31) * 8 + lh * 4;
             *reinterpret_cast<uint2*>(p.sa_kf_hi + eo) = hw;
             *reinterpret_cast<uint2*>(p.sa_kf_lo + eo) = lw;
           } else if (!XA) *reinterpret_cast<float4*>(p.out2 + (size_t)m * p.ldo2 + n) = o;
@@ -421,11 +428,11 @@ __global__ __launch_bounds__((XA || (SA && NS >= 3)) ? NT : NT_LAUNCH) void k_ch
     if (ps == 0) DV_CTRACE(8);
   };
   if constexpr (SA) {
-    do_pass(0, 3, std::integral_constant<int, 0>{});
-    do_pass(1, 3, std::integral_constant<int, 1>{});
-    do_pass(2, 3, std::integral_constant<int, 2>{});
+    if (ps_lo <= 0 && 0 < ps_hi) do_pass(0, ps_hi, std::integral_constant<int, 0>{});
+    if (ps_lo <= 1 && 1 < ps_hi) do_pass(1, ps_hi, std::integral_constant<int, 1>{});
+    if (ps_lo <= 2 && 2 < ps_hi) do_pass(2, ps_hi, std::integral_constant<int, 2>{});
   } else {
-    for (int ps = 0; ps < p.passes; ++ps) do_pass(ps, p.passes, std::integral_constant<int, 0>{});
+    for (int ps = ps_lo; ps < ps_hi; ++ps) do_pass(ps, ps_hi, std::integral_constant<int, 0>{});
   }
   if constexpr (XA) {
     // ================= cross attention: wave h = head h, 32 queries, keys / values as MFMA fragments from global =================
@@ -664,7 +671,7 @@ hipError_t init_one() {
 template <int NS, int AMODE, bool XA = false, bool SA = false>
 hipError_t launch_one(const ChainParams& p, hipStream_t st) {
   const int smem = 2 * 2 * NS * CHUNK_PL + NS * 16384;
-  hipLaunchKernelGGL((k_chain2<NS, AMODE, XA, SA>), dim3(p.M / BM), dim3((XA || (SA && NS >= 3)) ? NT : NT_LAUNCH), smem, st, p);
+  hipLaunchKernelGGL((k_chain2<NS, AMODE, XA, SA>), dim3((p.M / BM) * ((AMODE == 1 && !XA && p.nsplit > 1) ? p.nsplit : 1)), dim3((XA || (SA && NS >= 3)) ? NT : NT_LAUNCH), smem, st, p);
   return hipGetLastError();
 }
 
@@ -719,6 +726,7 @@ bool chain2_supported(const ChainParams& p, int precision) {
         !p.rowstat3)
       return false;
   }
+  if (p.nsplit < 0 || p.nsplit > 3 || (p.nsplit > 1 && (p.amode != 1 || p.nsplit > p.passes))) return false;
   if (p.sa_kf_hi) {                                                    // q | k | v with K / V as attention fragments
     if (p.amode != 1 || p.passes != 3 || p.C > 384 || !p.sa_kf_lo || !p.sa_vf_hi || !p.sa_vf_lo) return false;
   }
