@@ -171,6 +171,23 @@ struct ChainParams {
   // repeating stage 1 - for launches with fewer row blocks than CUs (every workgroup streams the weights it multiplies)
   int nsplit;
 };
+// Feed-forward tail of a transformer block as ONE row-block launch (k_chain_ff, C = 128): LayerNorm3 (finished from the
+// producer's row partials) -> GEGLU (8C columns, packed [32 a | 32 gate] blocks; the 4C product stays in LDS as split
+// planes) -> merged ff.net.2 + proj_out over [h3 | product] (K = 5C) + bias + block residual -> fp32 output + 32x16
+// GroupNorm block statistics (+ split planes).  Reference attention.py:189-203 + transformer_1d.py:300-326.
+struct ChainFFParams {
+  int M, C, T;                                    // rows (T % 32 == 0), C = 128
+  const bf16_t* a_hi; const bf16_t* a_lo;         // raw split planes of h3 [M, C]
+  const float* rowstat; float ln_eps;             // LayerNorm row partials of h3 [M, C/32, 2]
+  const bf16_t* wg_hi; const bf16_t* wg_lo; const float* bg; const float* ug;   // GEGLU [8C][Kp = C] fragment-major (gamma folded), bias', u
+  const bf16_t* wm_hi; const bf16_t* wm_lo; const float* bm;                    // merged [C][Kp = 5C] fragment-major, bias
+  const float* res;                               // block input [M, C] fp32
+  float* out; float* stats16;                     // [M, C] fp32; [M/32, C/16, 2] or null
+  bf16_t* out_hi; bf16_t* out_lo;                 // optional split planes of the output
+};
+bool chain_ff_supported(const ChainFFParams& p, int precision);
+hipError_t launch_chain_ff(const ChainFFParams& p, int precision, hipStream_t st);
+
 // cross-attention K/V of one block, fp32 [B*L, 2C] (k | v) -> MFMA-fragment-major split planes (ChainParams xa_*)
 hipError_t launch_kv_frag(const float* kv, bf16_t* kf_hi, bf16_t* kf_lo, bf16_t* vf_hi, bf16_t* vf_lo, int B, int L, int C, int H,
                           hipStream_t st);

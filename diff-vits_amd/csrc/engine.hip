@@ -1113,6 +1113,52 @@ struct Builder {
     probe(tb + "attn2", h3, Tn, C);
     }
 
+    // C = 128 blocks: LN3 -> GEGLU -> merged ff.net.2 + proj_out + residual as ONE row-block launch (k_chain_ff; the
+    // 4C-wide product never leaves LDS).  DVITS_CHAIN_FF=0 restores the two GEMMs.
+    {
+      static const bool ff_off = [] { const char* e = getenv("DVITS_CHAIN_FF"); return e && e[0] == '0'; }();
+      ChainFFParams fp{};
+      fp.M = M; fp.C = C; fp.T = Tn;
+      if (!ff_off && merged_ffproj && chain_on && !arena.exact && l3.stat && x.stat16 && chain_ff_supported(fp, prec)) {
+        const std::string mw = tb + "__ffproj.weight", mb = tb + "__ffproj.bias";
+        if (!dry && !u->packed.count(p + "ffproj")) {
+          const float* Wo = W(p + "proj_out.weight"); const float* W2 = W(tb + "ff.net.2.weight");
+          const float* bo = W(p + "proj_out.bias"); const float* b2 = W(tb + "ff.net.2.bias");
+          float* dw = derived(mw, {C, 4 * C});
+          float* db = derived(mb, {C});
+          if (!Wo || !W2 || !bo || !b2 || !dw || !db) return Act{};
+          (void)launch_matmul_f32(Wo, W2, dw, C, C, 4 * C, pack_stream);
+          (void)launch_fold_bias(Wo, bo, b2, db, C, C, 0, 0, pack_stream);
+        }
+        const PackedW* w_m = pack(p + "ffproj", C, 5 * C, {{p + "proj_out.weight", 1, C, 1, C, 0, 0, "", 0}, {mw, 0, 4 * C, 1, 4 * C, C, 0, "", 0}},
+                                  {{mb, "", "", "", C, 0, 0, 0}});
+        if (!w_m || !frag(w_gg) || !frag(w_m)) return Act{};
+        Act out{};
+        out.p = alloc((size_t)M * C); out.C = C; out.T = Tn; alloc_stat(out, true);
+        fp.a_hi = l3.pl.hi; fp.a_lo = l3.pl.lo; fp.rowstat = l3.stat; fp.ln_eps = 1e-5f;
+        fp.wg_hi = w_gg->fhi; fp.wg_lo = w_gg->flo; fp.bg = w_gg->bias; fp.ug = w_gg->u;
+        fp.wm_hi = w_m->fhi; fp.wm_lo = w_m->flo; fp.bm = w_m->bias;
+        fp.res = x.p; fp.out = out.p; fp.stats16 = out.stat16;
+        if (want_planes) {
+          Planes pl = alloc_planes((size_t)M * C);
+          out.pl_hi = pl.hi; out.pl_lo = pl.lo; fp.out_hi = pl.hi; fp.out_lo = pl.lo;
+        }
+        cur_kind = "chain";
+        cur_flops = 2.0 * (double)M * C * (8.0 * C + 5.0 * C);
+        {
+          char buf[96];
+          snprintf(buf, sizeof(buf), "LN+GEGLU+ffproj+res M=%d C=%d", M, C);
+          cur_desc = buf;
+        }
+        if (!dry) u->flops += cur_flops;
+        const int pr = prec;
+        emit(ops, [fp, pr](hipStream_t st) { return launch_chain_ff(fp, pr, st); });
+        ln_release(l3);
+        release(h3);
+        probe(p.substr(0, p.size() - 1), out.p, Tn, C);
+        return out;
+      }
+    }
     // GEGLU feed-forward: the GEGLU product and the FF output only feed GEMMs -> split planes only
     Planes gg = alloc_planes((size_t)M * 4 * C);
     {

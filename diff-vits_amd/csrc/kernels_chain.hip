@@ -606,6 +606,247 @@ __global__ __launch_bounds__((XA || (SA && NS >= 3)) ? NT : NT_LAUNCH) void k_ch
   DV_CTRACE(9);
 }
 
+// ---------------------------------------------------------------------------------------
+// k_chain_ff (ChainFFParams): LN3 -> GEGLU -> merged ff.net.2 + proj_out + residual of a C = 128 transformer block as one
+// row-block launch.  As separate GEMMs the two take 29 + 18 us at the bench shape (M = 8192: a [M, 8C] GEMM whose
+// 4C-wide product makes an HBM round trip, then a K = 5C GEMM); a workgroup that owns 32 rows streams 0.85 MB of weights
+// and keeps the product in LDS.
+//   stage A: 8 waves = 8 packed 64-column blocks per pass ([32 a | 32 gate]: both fragments in one wave, full K = C, no
+//            k-group hand-over), two passes -> a * gelu(gate) as split planes [32 rows x 4C] in LDS
+//   stage B: 4 column-fragment owners x 2 k-groups over K = 5C = [h3 planes | product planes], then bias + residual,
+//            fp32 rows + 32x16 block statistics for the next GroupNorm
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(NT_LAUNCH) void k_chain_ff(const ChainFFParams p) {
+  extern __shared__ __attribute__((aligned(1024))) char smem[];
+  constexpr int C = 128, A_CH = 2, G_CH = 8;                 // 64-channel chunks of h3 / of the GEGLU product
+  constexpr int A_PL = A_CH * CHUNK_PL, G_PL = G_CH * CHUNK_PL;
+  char* const a_reg = smem;                                  // [2 planes][2 chunks][32 rows][128 B]
+  char* const g_reg = smem + 2 * A_PL;                       // [2 planes][8 chunks][32 rows][128 B]
+  char* const red_reg = g_reg + 2 * G_PL;                    // 16 KiB k-group hand-over
+  __shared__ __attribute__((aligned(16))) float2 s_ln[BM];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  if (wave == NWV) {                                         // ninth wave: L2 prefetch of the weight planes (see k_chain2)
+    __shared__ __attribute__((aligned(256))) unsigned s_pf[64];
+    const int xw = blockIdx.x >> 3, nxw = (gridDim.x + 7) >> 3;
+    const int lg = 8 * C * C / 64, lm = 5 * C * C / 64;      // 128-byte lines per plane
+    const int total = 2 * (lg + lm), per = (total + nxw - 1) / nxw, end = min(total, (xw + 1) * per);
+    for (int ln = xw * per + lane; ln < end; ln += 64) {
+      const char* src;
+      if (ln < lg) src = reinterpret_cast<const char*>(p.wg_hi) + (size_t)ln * 128;
+      else if (ln < 2 * lg) src = reinterpret_cast<const char*>(p.wg_lo) + (size_t)(ln - lg) * 128;
+      else if (ln < 2 * lg + lm) src = reinterpret_cast<const char*>(p.wm_hi) + (size_t)(ln - 2 * lg) * 128;
+      else src = reinterpret_cast<const char*>(p.wm_lo) + (size_t)(ln - 2 * lg - lm) * 128;
+      glds4(src, (unsigned)(size_t)s_pf);
+    }
+    const char* r0 = reinterpret_cast<const char*>(p.res + (size_t)blockIdx.x * BM * C);
+    for (int ln = lane; ln < BM * C / 32; ln += 64) glds4(r0 + (size_t)ln * 128, (unsigned)(size_t)s_pf);
+    for (int ln = lane; ln < 8 * C / 32; ln += 64) {
+      glds4(reinterpret_cast<const char*>(p.bg) + (size_t)ln * 128, (unsigned)(size_t)s_pf);
+      glds4(reinterpret_cast<const char*>(p.ug) + (size_t)ln * 128, (unsigned)(size_t)s_pf);
+    }
+    return;
+  }
+  const int l31 = lane & 31, lh = lane >> 5;
+  const int m0 = blockIdx.x * BM;
+  const unsigned a_base = (unsigned)(size_t)a_reg;
+  const int d_row = lane >> 3, d_slot = lane & 7;
+  struct BFrag { bf16x8 h, l; };
+
+  // ---- h3 planes -> LDS (LDS-DMA), LayerNorm row statistics from the producer's partials ----
+  for (int idx = wave; idx < A_CH * 4; idx += NWV) {
+    const int c = idx >> 2, r8 = idx & 3, row = r8 * 8 + d_row;
+    const size_t e = (size_t)(m0 + row) * C + c * 64 + ((d_slot ^ swz(row)) << 3);
+    const unsigned dst = a_base + (unsigned)(c * CHUNK_PL + r8 * 1024);
+    glds16(p.a_hi + e, dst);
+    glds16(p.a_lo + e, dst + A_PL);
+  }
+  // stage A weights: unit U = pass * 16 + ks * 2 + f  (f: 0 = the `a` fragment, 1 = the gate fragment of this wave's block)
+  constexpr int UA = 32;
+  auto load_a_unit = [&](int U) __attribute__((always_inline)) {
+    const int nf = 2 * ((U >> 4) * 8 + wave) + (U & 1), ks = (U & 15) >> 1;
+    const size_t e = ((size_t)(nf * 8 + ks) * 64 + lane) * 8;
+    BFrag f;
+    f.h = *reinterpret_cast<const bf16x8*>(p.wg_hi + e);
+    f.l = *reinterpret_cast<const bf16x8*>(p.wg_lo + e);
+    return f;
+  };
+  BFrag bq[DEPTH];
+#pragma unroll
+  for (int j = 0; j < DEPTH; ++j) bq[j] = load_a_unit(j);
+  __builtin_amdgcn_sched_barrier(0);
+  if (tid < BM) {
+    const float2* src = reinterpret_cast<const float2*>(p.rowstat) + (size_t)(m0 + tid) * (C / 32);
+    float2 v[C / 32];
+#pragma unroll
+    for (int k = 0; k < C / 32; ++k) v[k] = src[k];
+    float s1 = 0.f;
+#pragma unroll
+    for (int k = 0; k < C / 32; ++k) s1 += v[k].x;
+    const float inv_c = 1.0f / (float)C, mean = s1 * inv_c;
+    float m2 = 0.f;
+#pragma unroll
+    for (int k = 0; k < C / 32; ++k) { const float dm = v[k].x * (1.0f / 32.0f) - mean; m2 += v[k].y + 32.0f * dm * dm; }
+    s_ln[tid] = make_float2(mean, 1.0f / sqrtf(m2 * inv_c + p.ln_eps));
+  }
+  wait_vmcnt<0>();
+  __syncthreads();
+
+  // ================= stage A: GEGLU =================
+  {
+    auto read_a = [&](int ks, bf16x8& h, bf16x8& l) __attribute__((always_inline)) {
+      const int c16 = ks * 2 + lh;
+      const int off = (c16 >> 3) * CHUNK_PL + l31 * 128 + (((c16 & 7) ^ swz(l31)) << 4);
+      h = *reinterpret_cast<const bf16x8*>(a_reg + off);
+      l = *reinterpret_cast<const bf16x8*>(a_reg + A_PL + off);
+    };
+    const float2 st = s_ln[l31];
+#pragma unroll
+    for (int ps = 0; ps < 2; ++ps) {
+      f32x16 acc[2];
+#pragma unroll
+      for (int f = 0; f < 2; ++f)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[f][r] = 0.f;
+      bf16x8 ah, al;
+#pragma unroll
+      for (int uu = 0; uu < 16; ++uu) {
+        const int U = ps * 16 + uu;
+        if ((uu & 1) == 0) read_a(uu >> 1, ah, al);
+        const BFrag f = bq[U % DEPTH];
+        acc[uu & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.h, al, acc[uu & 1], 0, 0, 0);
+        acc[uu & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.l, ah, acc[uu & 1], 0, 0, 0);
+        acc[uu & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.h, ah, acc[uu & 1], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (U + DEPTH < UA) bq[U % DEPTH] = load_a_unit(U + DEPTH);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      // LayerNorm finish + bias, a * gelu(gate) -> product columns blk * 32 + (8g + 4lh + e) as split planes in LDS
+      const int blk = ps * 8 + wave;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int cl = 8 * g + 4 * lh;
+        const float4 ua = *reinterpret_cast<const float4*>(p.ug + blk * 64 + cl), ugt = *reinterpret_cast<const float4*>(p.ug + blk * 64 + 32 + cl);
+        const float4 ba = *reinterpret_cast<const float4*>(p.bg + blk * 64 + cl), bgt = *reinterpret_cast<const float4*>(p.bg + blk * 64 + 32 + cl);
+        const float ua_[4] = {ua.x, ua.y, ua.z, ua.w}, ug_[4] = {ugt.x, ugt.y, ugt.z, ugt.w};
+        const float ba_[4] = {ba.x, ba.y, ba.z, ba.w}, bg_[4] = {bgt.x, bgt.y, bgt.z, bgt.w};
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float a = st.y * (acc[0][4 * g + e] - st.x * ua_[e]) + ba_[e];
+          const float gt = st.y * (acc[1][4 * g + e] - st.x * ug_[e]) + bg_[e];
+          v[e] = a * gelu_erf(gt);
+        }
+        uint2 hw, lw;
+        hw.x = pk(v[0], v[1]); hw.y = pk(v[2], v[3]);
+        lw.x = pk(v[0] - __uint_as_float(hw.x << 16), v[1] - __uint_as_float(hw.x & 0xffff0000u));
+        lw.y = pk(v[2] - __uint_as_float(hw.y << 16), v[3] - __uint_as_float(hw.y & 0xffff0000u));
+        const int n = blk * 32 + cl, c = n >> 6, s16 = (n & 63) >> 3;
+        const int off = c * CHUNK_PL + l31 * 128 + ((s16 ^ swz(l31)) << 4) + ((n & 7) >> 2) * 8;
+        *reinterpret_cast<uint2*>(g_reg + off) = hw;
+        *reinterpret_cast<uint2*>(g_reg + G_PL + off) = lw;
+      }
+    }
+  }
+  // ================= stage B: [h3 | product] x merged weights =================
+  const int wn = wave & 3, kg = wave >> 2;
+  constexpr int KSB = 5 * C / 16, KHB = KSB / 2;              // 40 k-steps, 20 per k-group
+  auto load_b_unit = [&](int u) __attribute__((always_inline)) {
+    const size_t e = ((size_t)(wn * KSB + kg * KHB + u) * 64 + lane) * 8;
+    BFrag f;
+    f.h = *reinterpret_cast<const bf16x8*>(p.wm_hi + e);
+    f.l = *reinterpret_cast<const bf16x8*>(p.wm_lo + e);
+    return f;
+  };
+#pragma unroll
+  for (int j = 0; j < DEPTH; ++j) bq[j] = load_b_unit(j);
+  __builtin_amdgcn_sched_barrier(0);
+  __syncthreads();                                           // product planes complete
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  {
+    auto read_b = [&](int u, bf16x8& h, bf16x8& l) __attribute__((always_inline)) {
+      const int ks = kg * KHB + u;
+      if (ks < C / 16) {
+        const int c16 = ks * 2 + lh;
+        const int off = (c16 >> 3) * CHUNK_PL + l31 * 128 + (((c16 & 7) ^ swz(l31)) << 4);
+        h = *reinterpret_cast<const bf16x8*>(a_reg + off);
+        l = *reinterpret_cast<const bf16x8*>(a_reg + A_PL + off);
+      } else {
+        const int c16 = (ks - C / 16) * 2 + lh;
+        const int off = (c16 >> 3) * CHUNK_PL + l31 * 128 + (((c16 & 7) ^ swz(l31)) << 4);
+        h = *reinterpret_cast<const bf16x8*>(g_reg + off);
+        l = *reinterpret_cast<const bf16x8*>(g_reg + G_PL + off);
+      }
+    };
+    bf16x8 ah[2], al[2];
+    read_b(0, ah[0], al[0]);
+#pragma unroll
+    for (int u = 0; u < KHB; ++u) {
+      const int cur = u & 1;
+      if (u + 1 < KHB) read_b(u + 1, ah[cur ^ 1], al[cur ^ 1]);
+      const BFrag f = bq[u % DEPTH];
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.h, al[cur], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.l, ah[cur], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.h, ah[cur], acc, 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      if (u + DEPTH < KHB) bq[u % DEPTH] = load_b_unit(u + DEPTH);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  {
+    float* red = reinterpret_cast<float*>(red_reg);
+    if (kg == 1) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) red[(wn * 16 + r) * 64 + lane] = acc[r];
+    }
+    __syncthreads();
+    if (kg == 1) return;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] += red[(wn * 16 + r) * 64 + lane];
+  }
+  // epilogue: + bias + block residual -> fp32 (+ planes), 32x16 block statistics (sum, M2 about the block mean)
+  {
+    const int m = m0 + l31, nf = wn * 32 + 4 * lh;
+    float vv[16];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const float4 bv = *reinterpret_cast<const float4*>(p.bm + nf + 8 * g);
+      const float4 rr = *reinterpret_cast<const float4*>(p.res + (size_t)m * C + nf + 8 * g);
+      vv[4 * g] = acc[4 * g] + bv.x + rr.x; vv[4 * g + 1] = acc[4 * g + 1] + bv.y + rr.y;
+      vv[4 * g + 2] = acc[4 * g + 2] + bv.z + rr.z; vv[4 * g + 3] = acc[4 * g + 3] + bv.w + rr.w;
+    }
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const size_t o4 = (size_t)m * C + nf + 8 * g;
+      *reinterpret_cast<float4*>(p.out + o4) = make_float4(vv[4 * g], vv[4 * g + 1], vv[4 * g + 2], vv[4 * g + 3]);
+      if (p.out_hi) {
+        uint2 hw, lw;
+        hw.x = pk(vv[4 * g], vv[4 * g + 1]); hw.y = pk(vv[4 * g + 2], vv[4 * g + 3]);
+        lw.x = pk(vv[4 * g] - __uint_as_float(hw.x << 16), vv[4 * g + 1] - __uint_as_float(hw.x & 0xffff0000u));
+        lw.y = pk(vv[4 * g + 2] - __uint_as_float(hw.y << 16), vv[4 * g + 3] - __uint_as_float(hw.y & 0xffff0000u));
+        *reinterpret_cast<uint2*>(p.out_hi + o4) = hw;
+        *reinterpret_cast<uint2*>(p.out_lo + o4) = lw;
+      }
+    }
+    if (p.stats16) {
+      float a1[2] = {0.f, 0.f}, a2[2] = {0.f, 0.f};
+#pragma unroll
+      for (int r = 0; r < 16; ++r) a1[r >> 3] += vv[r];
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) { a1[0] += __shfl_xor(a1[0], o); a1[1] += __shfl_xor(a1[1], o); }
+      const float mb[2] = {a1[0] * (1.0f / 512.0f), a1[1] * (1.0f / 512.0f)};
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { const float dv = vv[r] - mb[r >> 3]; a2[r >> 3] = fmaf(dv, dv, a2[r >> 3]); }
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) { a2[0] += __shfl_xor(a2[0], o); a2[1] += __shfl_xor(a2[1], o); }
+      if (lane < 2)
+        reinterpret_cast<float2*>(p.stats16)[(size_t)blockIdx.x * (C / 16) + wn * 2 + lane] =
+            make_float2(lane ? a1[1] : a1[0], lane ? a2[1] : a2[0]);
+    }
+  }
+}
+
 // cross-attention K / V of one block, fp32 rows [B*L, 2C] (k | v), head h = columns [h*d, h*d + d) -> split-bf16 MFMA
 // fragments: K fragment (tile t, k-step ks): lane (l31, lh) = K[key t*32 + l31][ks*16 + lh*8 .. +8];  V^T fragment (tile t,
 // k-block kb, channel block nb): lane (l31, lh) = V[key(j)][nb*32 + l31], j = 0..7, key(j) = t*32 + kb*16 + (j < 4 ? 4 lh + j :
@@ -677,8 +918,22 @@ hipError_t launch_one(const ChainParams& p, hipStream_t st) {
 
 }  // namespace
 
+static constexpr int FF_SMEM = 2 * 2 * CHUNK_PL + 2 * 8 * CHUNK_PL + 16384;
+bool chain_ff_supported(const ChainFFParams& p, int precision) {
+  return precision == 0 && p.C == 128 && p.M % 32 == 0 && p.T % 32 == 0 && p.M % p.T == 0;
+}
+hipError_t launch_chain_ff(const ChainFFParams& p, int precision, hipStream_t st) {
+  if (!chain_ff_supported(p, precision)) return hipErrorInvalidValue;
+  if (!p.a_hi || !p.a_lo || !p.rowstat || !p.wg_hi || !p.wg_lo || !p.bg || !p.ug || !p.wm_hi || !p.wm_lo || !p.bm || !p.res || !p.out ||
+      (p.out_hi && !p.out_lo))
+    return hipErrorInvalidValue;
+  hipLaunchKernelGGL(k_chain_ff, dim3(p.M / BM), dim3(NT_LAUNCH), FF_SMEM, st, p);
+  return hipGetLastError();
+}
+
 hipError_t chain_init() {
   hipError_t e;
+  if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_chain_ff), hipFuncAttributeMaxDynamicSharedMemorySize, FF_SMEM)) != hipSuccess) return e;
   if ((e = init_one<1, 0>()) != hipSuccess) return e;
   if ((e = init_one<2, 0>()) != hipSuccess) return e;
   if ((e = init_one<3, 0>()) != hipSuccess) return e;
