@@ -168,6 +168,10 @@ def lifecycle_extras(dev, precision):
             ts.append(1e3 * (time.perf_counter() - t0))
     out["b1_T300_L150_unipc30_latency_ms"] = sorted(ts)[len(ts) // 2]
     out["b1_T300_mel_frames_per_s"] = 300.0 / (out["b1_T300_L150_unipc30_latency_ms"] * 1e-3)
+    # GEMMs that finish their consumer's GroupNorm in the epilogue (in-launch hand-over); the flag must stay 0
+    n_ho, bad = eng.handover_status()
+    n_ho2, bad2 = e2.handover_status()
+    out["in_epilogue_groupnorm_gemms"] = {"B1_T256": n_ho, "B1_T300": n_ho2, "timed_out": int(bool(bad or bad2))}
     return out
 
 
@@ -348,6 +352,10 @@ def main():
         }
     if not args.no_roofline and world == 1:
         result["extra"] = lifecycle_extras(dev, args.precision)
+        n_ho, bad = eng.handover_status()
+        result["extra"]["in_epilogue_groupnorm_gemms"]["bench_shape"] = n_ho
+        if bad or result["extra"]["in_epilogue_groupnorm_gemms"]["timed_out"]:
+            raise SystemExit("bench: an in-kernel GroupNorm hand-over timed out - results invalid")
     if not args.no_cpu_baseline and world == 1:        # reported at N = 1 only (rank 0's host cores, bounded sample)
         result["cpu_baseline"] = cpu_baseline(sd, B, T, L, S)
         result["speedup_vs_cpu_baseline"] = frames_per_s / result["cpu_baseline"]["value"] / world

@@ -8,7 +8,8 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libdvits_hip.so")
+# (DVITS_LIB_FILE: development aid - load another in-tree build of the same library, e.g. for same-box A/B runs)
+LIB_PATH = os.environ.get("DVITS_LIB_FILE") or os.path.join(_HERE, "libdvits_hip.so")
 CSRC = os.path.join(_HERE, "csrc")
 
 PREC_BF16X3, PREC_BF16 = 0, 1

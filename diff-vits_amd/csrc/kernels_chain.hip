@@ -42,6 +42,10 @@ namespace {
 constexpr int BM = 32, NWV = 8, NT = 64 * NWV, NT_LAUNCH = NT + 64;   // + one L2-prefetch wave
 constexpr int CHUNK_PL = BM * 128;                 // one 64-channel chunk of the resident A operand, one plane
 constexpr int DEPTH = 6;                           // weight fragments (hi + lo: 8 VGPRs each) in flight per wave
+#ifndef DV_DEPTH_FF
+#define DV_DEPTH_FF 6
+#endif
+constexpr int DEPTH_FF = DV_DEPTH_FF;              // k_chain_ff (one accumulator fragment per wave: registers to spare)
 
 __device__ __forceinline__ int swz(int row) { return (row >> 1) & 7; }
 __device__ __forceinline__ unsigned pk(float lo, float hi) { return dv_cvt_pk_bf16(lo, hi); }
@@ -670,9 +674,9 @@ __global__ __launch_bounds__(NT_LAUNCH) void k_chain_ff(const ChainFFParams p) {
     f.l = *reinterpret_cast<const bf16x8*>(p.wg_lo + e);
     return f;
   };
-  BFrag bq[DEPTH];
+  BFrag bq[DEPTH_FF];
 #pragma unroll
-  for (int j = 0; j < DEPTH; ++j) bq[j] = load_a_unit(j);
+  for (int j = 0; j < DEPTH_FF; ++j) bq[j] = load_a_unit(j);
   __builtin_amdgcn_sched_barrier(0);
   if (tid < BM) {
     const float2* src = reinterpret_cast<const float2*>(p.rowstat) + (size_t)(m0 + tid) * (C / 32);
@@ -712,12 +716,12 @@ __global__ __launch_bounds__(NT_LAUNCH) void k_chain_ff(const ChainFFParams p) {
       for (int uu = 0; uu < 16; ++uu) {
         const int U = ps * 16 + uu;
         if ((uu & 1) == 0) read_a(uu >> 1, ah, al);
-        const BFrag f = bq[U % DEPTH];
+        const BFrag f = bq[U % DEPTH_FF];
         acc[uu & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.h, al, acc[uu & 1], 0, 0, 0);
         acc[uu & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.l, ah, acc[uu & 1], 0, 0, 0);
         acc[uu & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.h, ah, acc[uu & 1], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
-        if (U + DEPTH < UA) bq[U % DEPTH] = load_a_unit(U + DEPTH);
+        if (U + DEPTH_FF < UA) bq[U % DEPTH_FF] = load_a_unit(U + DEPTH_FF);
         __builtin_amdgcn_sched_barrier(0);
       }
       // LayerNorm finish + bias, a * gelu(gate) -> product columns blk * 32 + (8g + 4lh + e) as split planes in LDS
@@ -758,7 +762,7 @@ __global__ __launch_bounds__(NT_LAUNCH) void k_chain_ff(const ChainFFParams p) {
     return f;
   };
 #pragma unroll
-  for (int j = 0; j < DEPTH; ++j) bq[j] = load_b_unit(j);
+  for (int j = 0; j < DEPTH_FF; ++j) bq[j] = load_b_unit(j);
   __builtin_amdgcn_sched_barrier(0);
   __syncthreads();                                           // product planes complete
   f32x16 acc;
@@ -785,12 +789,12 @@ __global__ __launch_bounds__(NT_LAUNCH) void k_chain_ff(const ChainFFParams p) {
     for (int u = 0; u < KHB; ++u) {
       const int cur = u & 1;
       if (u + 1 < KHB) read_b(u + 1, ah[cur ^ 1], al[cur ^ 1]);
-      const BFrag f = bq[u % DEPTH];
+      const BFrag f = bq[u % DEPTH_FF];
       acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.h, al[cur], acc, 0, 0, 0);
       acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.l, ah[cur], acc, 0, 0, 0);
       acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.h, ah[cur], acc, 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
-      if (u + DEPTH < KHB) bq[u % DEPTH] = load_b_unit(u + DEPTH);
+      if (u + DEPTH_FF < KHB) bq[u % DEPTH_FF] = load_b_unit(u + DEPTH_FF);
       __builtin_amdgcn_sched_barrier(0);
     }
   }
