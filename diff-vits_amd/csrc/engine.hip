@@ -1039,6 +1039,11 @@ struct Builder {
         cp.w1_hi = w_o1->fhi; cp.w1_lo = w_o1->flo; cp.Kp1 = w_o1->Kp; cp.b1 = w_o1->bias; cp.res = h; cp.out1 = h2;
         cp.w2_hi = w_q2->fhi; cp.w2_lo = w_q2->flo; cp.Kp2 = w_q2->Kp; cp.b2 = w_q2->bias; cp.u2 = w_q2->u;
         cp.passes = 1; cp.out2 = q2; cp.ldo2 = C; cp.ln_eps = 1e-5f;
+        {   // few row blocks: the 128-column groups of to_q are shared out over C / 128 workgroups per row block
+          static const bool off = [] { const char* e = getenv("DVITS_CHAIN_SPLIT"); return e && e[0] == '0'; }();
+          const int rbs = M / 32, cus = n_cu > 0 ? n_cu : 256, nsg = C / 128;
+          cp.nsplit = (!off && nsg >= 2 && rbs * nsg <= cus) ? nsg : 1;
+        }
         chain(ops, cp, "to_out+res+LN+to_q");
       }
       release(ao); release(h);

@@ -50,7 +50,7 @@ constexpr int DEPTH_FF = DV_DEPTH_FF;              // k_chain_ff (one accumulato
 __device__ __forceinline__ int swz(int row) { return (row >> 1) & 7; }
 __device__ __forceinline__ unsigned pk(float lo, float hi) { return dv_cvt_pk_bf16(lo, hi); }
 
-template <int NS, int AMODE, bool XA = false, bool SA = false>
+template <int NS, int AMODE, bool XA = false, bool SA = false, bool CS = false>
 __global__ __launch_bounds__((XA || (SA && NS >= 3)) ? NT : NT_LAUNCH) void k_chain2(const ChainParams p) {
   extern __shared__ __attribute__((aligned(1024))) char smem[];
   constexpr int CH = 2 * NS;                       // 64-channel chunks of the A operand
@@ -105,10 +105,12 @@ __global__ __launch_bounds__((XA || (SA && NS >= 3)) ? NT : NT_LAUNCH) void k_ch
   // nsplit workgroups per row block (amode 1 with several stage-2 passes, few row blocks): each repeats stage 1 (cheap:
   // the kernel is bound by the weight stream, not by MFMA) and runs its share of the passes - a third of the q | k | v
   // weights per workgroup on three times the CUs.  Part 0 writes out1.
-  const int nsp = (AMODE == 1 && !XA && p.nsplit > 1) ? p.nsplit : 1;
+  // CS (amode 0, one stage-2 pass): the parts share out the stage-2 COLUMNS instead - part k computes fragment group k
+  // (128 columns) of the second GEMM.
+  const int nsp = (((AMODE == 1 && !XA) || CS) && p.nsplit > 1) ? p.nsplit : 1;
   const int rb = nsp == 1 ? (int)blockIdx.x : (int)blockIdx.x / nsp, part = (int)blockIdx.x - rb * nsp;
   const int npass_all = SA ? 3 : p.passes;
-  const int ps_lo = (part * npass_all + nsp - 1) / nsp, ps_hi = ((part + 1) * npass_all + nsp - 1) / nsp;
+  const int ps_lo = CS ? 0 : (part * npass_all + nsp - 1) / nsp, ps_hi = CS ? npass_all : ((part + 1) * npass_all + nsp - 1) / nsp;
   const int m0 = rb * BM;
   const unsigned a_base = (unsigned)(size_t)a_reg;
   const int d_row = lane >> 3, d_slot = lane & 7;
@@ -118,24 +120,27 @@ __global__ __launch_bounds__((XA || (SA && NS >= 3)) ? NT : NT_LAUNCH) void k_ch
   // load per lane each from the fragment-major weights
   constexpr int KSTEPS = C / 16, KH = KSTEPS / 2, U = NS * KH;
   struct BFrag { bf16x8 h, l; };
-  auto load_unit = [&](const bf16_t* wf_hi, const bf16_t* wf_lo, int frag0, int u) {
-    const int ks = kg * KH + u / NS, nf = frag0 + (u % NS) * 4 + wn;
+  auto load_unit = [&](const bf16_t* wf_hi, const bf16_t* wf_lo, int frag0, int u, auto nsx_tag) {
+    constexpr int NSX = decltype(nsx_tag)::value;   // fragments per wave in this stage (NS, or 1 in a column-split stage)
+    const int ks = kg * KH + u / NSX, nf = frag0 + (u % NSX) * 4 + wn;
     const size_t e = ((size_t)(nf * KSTEPS + ks) * 64 + lane) * 8;
     BFrag f;
     f.h = *reinterpret_cast<const bf16x8*>(wf_hi + e);
     f.l = *reinterpret_cast<const bf16x8*>(wf_lo + e);
     return f;
   };
-  auto stage_prologue = [&](const bf16_t* wf_hi, const bf16_t* wf_lo, int frag0, BFrag (&bq)[DEPTH]) __attribute__((always_inline)) {
+  auto stage_prologue = [&](const bf16_t* wf_hi, const bf16_t* wf_lo, int frag0, BFrag (&bq)[DEPTH], auto nsx_tag) __attribute__((always_inline)) {
+    constexpr int NSX = decltype(nsx_tag)::value;
 #pragma unroll
     for (int j = 0; j < DEPTH; ++j)
-      if (j < U) bq[j] = load_unit(wf_hi, wf_lo, frag0, j);
+      if (j < NSX * KH) bq[j] = load_unit(wf_hi, wf_lo, frag0, j, nsx_tag);
     __builtin_amdgcn_sched_barrier(0);
   };
   // swap_tag: the activations are the FIRST MFMA operand - the accumulator is then the tile itself, lane = output column,
   // registers = rows 8g + 4lh + e (used for V: that register image IS the V^T operand fragment of the attention kernel)
-  auto stage_loop = [&](const bf16_t* wf_hi, const bf16_t* wf_lo, int frag0, BFrag (&bq)[DEPTH], f32x16 (&acc)[NS], auto swap_tag) __attribute__((always_inline)) {
+  auto stage_loop = [&](const bf16_t* wf_hi, const bf16_t* wf_lo, int frag0, BFrag (&bq)[DEPTH], f32x16 (&acc)[NS], auto swap_tag, auto nsx_tag) __attribute__((always_inline)) {
     constexpr bool SWAP = decltype(swap_tag)::value;
+    constexpr int NSX = decltype(nsx_tag)::value, UX = NSX * KH;
     // A fragment of k-step ksl (this wave's k-half): read one k-step ahead of its MFMAs (LDS latency off the chain)
     auto read_a = [&](int ksl, bf16x8& h, bf16x8& l) {
       const int c16 = (kg * KH + ksl) * 2 + lh;                    // 16-byte chunk of the row: k-step * 2 + half
@@ -146,22 +151,22 @@ __global__ __launch_bounds__((XA || (SA && NS >= 3)) ? NT : NT_LAUNCH) void k_ch
     bf16x8 ah[2], al[2];
     read_a(0, ah[0], al[0]);
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int ksl = u / NS, cur = ksl & 1;
-      if (u % NS == 0 && ksl + 1 < KH) read_a(ksl + 1, ah[cur ^ 1], al[cur ^ 1]);
+    for (int u = 0; u < UX; ++u) {
+      const int ksl = u / NSX, cur = ksl & 1;
+      if (u % NSX == 0 && ksl + 1 < KH) read_a(ksl + 1, ah[cur ^ 1], al[cur ^ 1]);
       const BFrag f = bq[u % DEPTH];
       if (SWAP) {
-        acc[u % NS] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[cur], f.h, acc[u % NS], 0, 0, 0);
-        acc[u % NS] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[cur], f.l, acc[u % NS], 0, 0, 0);
-        acc[u % NS] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[cur], f.h, acc[u % NS], 0, 0, 0);
+        acc[u % NSX] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[cur], f.h, acc[u % NSX], 0, 0, 0);
+        acc[u % NSX] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[cur], f.l, acc[u % NSX], 0, 0, 0);
+        acc[u % NSX] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[cur], f.h, acc[u % NSX], 0, 0, 0);
       } else {
-        acc[u % NS] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.h, al[cur], acc[u % NS], 0, 0, 0);
-        acc[u % NS] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.l, ah[cur], acc[u % NS], 0, 0, 0);
-        acc[u % NS] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.h, ah[cur], acc[u % NS], 0, 0, 0);
+        acc[u % NSX] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.h, al[cur], acc[u % NSX], 0, 0, 0);
+        acc[u % NSX] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.l, ah[cur], acc[u % NSX], 0, 0, 0);
+        acc[u % NSX] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.h, ah[cur], acc[u % NSX], 0, 0, 0);
       }
       // pinned: without the scheduling barriers hipcc sinks every prefetch down to its use (load -> vmcnt(0) -> MFMA)
       __builtin_amdgcn_sched_barrier(0);
-      if (u + DEPTH < U) bq[u % DEPTH] = load_unit(wf_hi, wf_lo, frag0, u + DEPTH);
+      if (u + DEPTH < UX) bq[u % DEPTH] = load_unit(wf_hi, wf_lo, frag0, u + DEPTH, nsx_tag);
       __builtin_amdgcn_sched_barrier(0);
     }
   };
@@ -196,7 +201,7 @@ __global__ __launch_bounds__((XA || (SA && NS >= 3)) ? NT : NT_LAUNCH) void k_ch
     }
   }
   BFrag bq[DEPTH];
-  stage_prologue(p.w1_hi, p.w1_lo, 0, bq);         // the first weight fragments fly under the A operand's arrival / conversion
+  stage_prologue(p.w1_hi, p.w1_lo, 0, bq, std::integral_constant<int, NS>{});   // the first weight fragments fly under the A operand's arrival / conversion
   if (AMODE == 1) {
     // GroupNorm of the fp32 rows, once per row-block: table of this utterance, then convert
     const int T = p.T, b_item = m0 / T;
@@ -278,9 +283,12 @@ __global__ __launch_bounds__((XA || (SA && NS >= 3)) ? NT : NT_LAUNCH) void k_ch
   for (int ns = 0; ns < NS; ++ns)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[ns][r] = 0.f;
-  stage_loop(p.w1_hi, p.w1_lo, 0, bq, acc, std::false_type{});
+  stage_loop(p.w1_hi, p.w1_lo, 0, bq, acc, std::false_type{}, std::integral_constant<int, NS>{});
   DV_CTRACE(3);
-  stage_prologue(p.w2_hi, p.w2_lo, ps_lo * (C / 32), bq);   // the second GEMM's first fragments fly during the hand-over and the epilogue
+  // the second GEMM's first fragments fly during the hand-over and the epilogue
+  using Ns2 = std::integral_constant<int, CS ? 1 : NS>;
+  const int cs_frag0 = CS ? part * 4 : 0;          // column split: this part's fragment group
+  stage_prologue(p.w2_hi, p.w2_lo, ps_lo * (C / 32) + cs_frag0, bq, Ns2{});
   kgroup_reduce(acc, red_reg);                     // (its leading barrier: every wave is done reading the A operand)
   DV_CTRACE(4);
   // epilogue 1 (k-group 0): x1 = acc + b1 (+ res) -> out1 fp32, raw split planes into the A region, row partials
@@ -348,9 +356,9 @@ __global__ __launch_bounds__((XA || (SA && NS >= 3)) ? NT : NT_LAUNCH) void k_ch
     for (int ns = 0; ns < NS; ++ns)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[ns][r] = 0.f;
-    stage_loop(p.w2_hi, p.w2_lo, ps * (C / 32), bq, acc, std::integral_constant<bool, MODE == 2>{});
+    stage_loop(p.w2_hi, p.w2_lo, ps * (C / 32) + cs_frag0, bq, acc, std::integral_constant<bool, MODE == 2>{}, Ns2{});
     if (ps == 0) DV_CTRACE(6);
-    if (ps + 1 < npass) stage_prologue(p.w2_hi, p.w2_lo, (ps + 1) * (C / 32), bq);
+    if (ps + 1 < npass) stage_prologue(p.w2_hi, p.w2_lo, (ps + 1) * (C / 32) + cs_frag0, bq, Ns2{});
     kgroup_reduce(acc, red_reg);
     if (ps == 0) DV_CTRACE(7);
     if (MODE == 2) {
@@ -389,8 +397,8 @@ __global__ __launch_bounds__((XA || (SA && NS >= 3)) ? NT : NT_LAUNCH) void k_ch
       const int m = m0 + l31;
       const float2 st = s_ln[l31];
 #pragma unroll
-      for (int ns = 0; ns < NS; ++ns) {
-        const int nf = ps * C + ns * 128 + wn * 32 + 4 * lh;
+      for (int ns = 0; ns < (CS ? 1 : NS); ++ns) {
+        const int nf = ps * C + (CS ? part : ns) * 128 + wn * 32 + 4 * lh;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
           const int n = nf + 8 * g;
@@ -442,7 +450,7 @@ __global__ __launch_bounds__((XA || (SA && NS >= 3)) ? NT : NT_LAUNCH) void k_ch
     // ================= cross attention: wave h = head h, 32 queries, keys / values as MFMA fragments from global =================
     // Same arithmetic as k_attention (attn_tile.h): S^T = K Q^T and O^T += V^T P^T with split-bf16 operands (3 products),
     // scores in the log2 domain, online softmax lane-local (lane = query, registers = keys), P never leaves registers.
-    stage_prologue(p.w3_hi, p.w3_lo, 0, bq);        // the output projection's first weight fragments fly under the attention
+    stage_prologue(p.w3_hi, p.w3_lo, 0, bq, std::integral_constant<int, NS>{});   // the output projection's first weight fragments fly under the attention
     __syncthreads();                               // query planes complete
     constexpr int d = 16 * NS, KSq = NS, NBv = NS == 3 ? 2 : 1;     // 8 heads: d = C / 8
     const int nT = p.xa_nT;
@@ -569,7 +577,7 @@ __global__ __launch_bounds__((XA || (SA && NS >= 3)) ? NT : NT_LAUNCH) void k_ch
     for (int ns = 0; ns < NS; ++ns)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[ns][r] = 0.f;
-    stage_loop(p.w3_hi, p.w3_lo, 0, bq, acc, std::false_type{});
+    stage_loop(p.w3_hi, p.w3_lo, 0, bq, acc, std::false_type{}, std::integral_constant<int, NS>{});
     kgroup_reduce(acc, red_reg);
     if (kg == 0) {
       const int m = m0 + l31;
@@ -908,15 +916,15 @@ __global__ __launch_bounds__(64) void k_relayout_frag(const bf16_t* __restrict__
   *reinterpret_cast<uint4*>(dst + ((size_t)(nf * ksteps + ks) * 64 + lane) * 8) = v;
 }
 
-template <int NS, int AMODE, bool XA = false, bool SA = false>
+template <int NS, int AMODE, bool XA = false, bool SA = false, bool CS = false>
 hipError_t init_one() {
   const int smem = 2 * 2 * NS * CHUNK_PL + NS * 16384;
-  return hipFuncSetAttribute(reinterpret_cast<const void*>(k_chain2<NS, AMODE, XA, SA>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+  return hipFuncSetAttribute(reinterpret_cast<const void*>(k_chain2<NS, AMODE, XA, SA, CS>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
 }
-template <int NS, int AMODE, bool XA = false, bool SA = false>
+template <int NS, int AMODE, bool XA = false, bool SA = false, bool CS = false>
 hipError_t launch_one(const ChainParams& p, hipStream_t st) {
   const int smem = 2 * 2 * NS * CHUNK_PL + NS * 16384;
-  hipLaunchKernelGGL((k_chain2<NS, AMODE, XA, SA>), dim3((p.M / BM) * ((AMODE == 1 && !XA && p.nsplit > 1) ? p.nsplit : 1)), dim3((XA || (SA && NS >= 3)) ? NT : NT_LAUNCH), smem, st, p);
+  hipLaunchKernelGGL((k_chain2<NS, AMODE, XA, SA, CS>), dim3((p.M / BM) * ((((AMODE == 1 && !XA) || CS) && p.nsplit > 1) ? p.nsplit : 1)), dim3((XA || (SA && NS >= 3)) ? NT : NT_LAUNCH), smem, st, p);
   return hipGetLastError();
 }
 
@@ -949,6 +957,8 @@ hipError_t chain_init() {
   if ((e = init_one<1, 1, false, true>()) != hipSuccess) return e;
   if ((e = init_one<2, 1, false, true>()) != hipSuccess) return e;
   if ((e = init_one<3, 1, false, true>()) != hipSuccess) return e;
+  if ((e = init_one<2, 0, false, false, true>()) != hipSuccess) return e;
+  if ((e = init_one<3, 0, false, false, true>()) != hipSuccess) return e;
   if ((e = init_one<1, 0, true>()) != hipSuccess) return e;
   return init_one<2, 0, true>();   // (C = 384 with the attention inside needs > 256 VGPRs: it keeps the separate launches)
 }
@@ -985,7 +995,10 @@ bool chain2_supported(const ChainParams& p, int precision) {
         !p.rowstat3)
       return false;
   }
-  if (p.nsplit < 0 || p.nsplit > 3 || (p.nsplit > 1 && (p.amode != 1 || p.nsplit > p.passes))) return false;
+  if (p.nsplit < 0 || p.nsplit > 3) return false;
+  if (p.nsplit > 1 && p.amode == 1 && p.nsplit > p.passes) return false;
+  // amode 0: the parts share out the 128-column groups of the one stage-2 pass
+  if (p.nsplit > 1 && p.amode == 0 && (p.xa_kf_hi || p.passes != 1 || p.nsplit != p.C / 128 || p.C > 384)) return false;
   if (p.sa_kf_hi) {                                                    // q | k | v with K / V as attention fragments
     if (p.amode != 1 || p.passes != 3 || p.C > 384 || !p.sa_kf_lo || !p.sa_vf_hi || !p.sa_vf_lo) return false;
   }
@@ -1004,6 +1017,7 @@ hipError_t launch_chain2(const ChainParams& p, int precision, hipStream_t st) {
   const int ns = p.C / 128;
   if (p.xa_kf_hi) return ns == 1 ? launch_one<1, 0, true>(p, st) : launch_one<2, 0, true>(p, st);
   if (p.sa_kf_hi) return ns == 1 ? launch_one<1, 1, false, true>(p, st) : (ns == 2 ? launch_one<2, 1, false, true>(p, st) : launch_one<3, 1, false, true>(p, st));
+  if (p.amode == 0 && p.nsplit > 1) return ns == 2 ? launch_one<2, 0, false, false, true>(p, st) : launch_one<3, 0, false, false, true>(p, st);
   if (p.amode == 0)
     return ns == 1 ? launch_one<1, 0>(p, st) : (ns == 2 ? launch_one<2, 0>(p, st) : (ns == 3 ? launch_one<3, 0>(p, st) : launch_one<4, 0>(p, st)));
   return ns == 1 ? launch_one<1, 1>(p, st) : (ns == 2 ? launch_one<2, 1>(p, st) : (ns == 3 ? launch_one<3, 1>(p, st) : launch_one<4, 1>(p, st)));
