@@ -124,8 +124,10 @@ template <int BK> struct Tiles {
   using T2 = GemmTile<64, 64, BK, 2, 2, (BK == 64 ? 2 : 1)>;   // 8 waves at BK = 64 (k-split pairs)
   using T2S = GemmTile<64, 64, BK, 2, 2, 1>;
   using T2G = GemmTile<64, 64, BK, 2, 1>;
-  using T3 = GemmTile<64, 32, BK, 2, 1>;
-  using T4 = GemmTile<32, 32, BK, 1, 1>;
+  // (small tiles with ONE k-group - 2 / 1 waves - measured 1500 cycles per k-tile against 1030 for the 8-wave 64x64 tile
+  // although they move fewer bytes: too few waves to keep the LDS-DMA queue full.  With 64-deep k-tiles they run two k-groups.)
+  using T3 = GemmTile<64, 32, BK, 2, 1, (BK == 64 ? 2 : 1)>;
+  using T4 = GemmTile<32, 32, BK, 1, 1, (BK == 64 ? 2 : 1)>;
   using T4G = GemmTile<32, 64, BK, 1, 1>;
   static hipError_t init() {
     hipError_t e;
