@@ -105,6 +105,7 @@ __global__ __launch_bounds__(64 * NW) void k_attention_frag(const AttnFragParams
   constexpr int NSTG = 3;
   constexpr int NI = 2 * (KBL + VBL);                   // DMA instructions per pair
   constexpr int CPW = (NI + NW - 1) / NW;               // per wave (at most)
+  asm volatile("" ::"s"(p.q), "s"(p.vf_lo), "s"(p.v_t), "s"(p.bias), "s"(p.o_lo), "s"(p.no_xcd_map));   // all argument lines at once
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l31 = lane & 31, lh = lane >> 5;
   int qblk, h, b;

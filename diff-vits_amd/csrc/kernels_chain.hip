@@ -62,6 +62,9 @@ __global__ __launch_bounds__((XA || (SA && NS >= 3)) ? NT : NT_LAUNCH) void k_ch
   __shared__ __attribute__((aligned(16))) float2 s_ln[BM];   // per row (mean, rstd)
   __shared__ __attribute__((aligned(16))) float s_gscale[AMODE ? C : 4], s_gshift[AMODE ? C : 4];
 
+  // (every 64-byte line of the argument block is requested at once: see k_gemm)
+  asm volatile("" ::"s"(p.M), "s"(p.gamma), "s"(p.w1_lo), "s"(p.out1), "s"(p.u2), "s"(p.xa_kf_hi), "s"(p.xa_bias), "s"(p.w3_lo),
+               "s"(p.out3_lo), "s"(p.sa_vf_lo), "s"(p.nsplit));
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   // ---- ninth wave: L2 prefetch, then it leaves ----
   // Every workgroup streams ALL weights, the workgroups of an XCD walk the same addresses at the same pace, and an L2 does
@@ -636,6 +639,7 @@ __global__ __launch_bounds__(NT_LAUNCH) void k_chain_ff(const ChainFFParams p) {
   char* const g_reg = smem + 2 * A_PL;                       // [2 planes][8 chunks][32 rows][128 B]
   char* const red_reg = g_reg + 2 * G_PL;                    // 16 KiB k-group hand-over
   __shared__ __attribute__((aligned(16))) float2 s_ln[BM];
+  asm volatile("" ::"s"(p.M), "s"(p.rowstat), "s"(p.wg_lo), "s"(p.wm_hi), "s"(p.res), "s"(p.out_lo));
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   if (wave == NWV) {                                         // ninth wave: L2 prefetch of the weight planes (see k_chain2)
     __shared__ __attribute__((aligned(256))) unsigned s_pf[64];

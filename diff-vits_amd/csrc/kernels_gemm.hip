@@ -31,18 +31,22 @@ __global__ __launch_bounds__(64 * WM * WN * KS) void k_gemm(const GemmParams p) 
   extern __shared__ __attribute__((aligned(1024))) char smem[];
   // XCD-aware tile order (workgroup b runs on XCD b % 8; each XCD has its own L2, which starts cold): an XCD's workgroups
   // form a rectangle of the tile grid so that its L2 fetches (rows / xm) of A and (columns / xn) of W once.
+  // every 64-byte line of the argument block is requested NOW, together: the tile mapping below branches on a field of
+  // the last line, and the loads of the tile routine would otherwise only be issued once that branch has resolved (two
+  // dependent scalar-cache misses at the head of every workgroup: measured +300 cycles)
+  asm volatile("" ::"s"(p.seg[0].a0_hi), "s"(p.seg[1].a0_hi), "s"(p.seg[1].pad), "s"(p.T_in), "s"(p.w_hi), "s"(p.M), "s"(p.res),
+               "s"(p.out_hi), "s"(p.zero_page), "s"(p.ln_u), "s"(p.gnx.xchg), "s"(p.gnx.y_hi), "s"(p.xcd_n), "s"(p.xcd_inv_tn));
   const int n_tiles_n = (p.N + BN - 1) / BN;
   const int nwg = gridDim.x;
   int bid = blockIdx.x;
   if (p.xcd_n > 0) {
     // launch_gemm checked: 8 | nwg; (k-slices) x xm x xn = 8; xm | row tiles, xn | column tiles
-    const int n_tiles_m = (p.M + BM - 1) / BM;
-    const int xs = (p.sk_mode == 1 || p.sk_mode == 3) ? p.sk_split : 1, xn = p.xcd_n, xm = 8 / (xs * xn);
+    // (xs, xm, xn are powers of two; the one real division - by the rectangle's width - is a multiply by the host's
+    // 16-bit reciprocal, exact for i < 1024: this runs before the first DMA can be issued)
     const int x = bid & 7, i = bid >> 3;
-    const int ks_i = x / (xm * xn), r = x - ks_i * (xm * xn), xm_i = r / xn, xn_i = r - xm_i * xn;
-    const int tn = n_tiles_n / xn, tm = n_tiles_m / xm;
-    const int lm = i / tn, ln = i - lm * tn;
-    gemm_tile<BM, BN, BK, WM, WN, NSPLIT, KS, false, AF>(p, (xm_i * tm + lm) * BM, (xn_i * tn + ln) * BN, smem, ks_i);
+    const int ks_i = x >> p.xcd_sh_mn, r = x & ((1 << p.xcd_sh_mn) - 1), xm_i = r >> p.xcd_sh_n, xn_i = r & (p.xcd_n - 1);
+    const int lm = (i * p.xcd_inv_tn) >> 16, ln = i - lm * p.xcd_tn;
+    gemm_tile<BM, BN, BK, WM, WN, NSPLIT, KS, false, AF>(p, (xm_i * p.xcd_tm + lm) * BM, (xn_i * p.xcd_tn + ln) * BN, smem, ks_i);
     return;
   }
   {
@@ -343,7 +347,12 @@ hipError_t launch_gemm(const GemmParams& pin, int precision, hipStream_t st) {
       const double cost = (double)p.N / xn * ktot + (double)p.M / xm * chans;
       if (best_xn == 0 || cost < best * 0.97) { best = cost; best_xn = xn; }
     }
-    if (env_xn != 0) p.xcd_n = best_xn;
+    if (env_xn != 0 && best_xn > 0 && tm * tn * xs / 8 <= 1024) {
+      const int xm = 8 / (xs * best_xn);
+      auto lg2 = [](int v) { int s2 = 0; while ((1 << s2) < v) ++s2; return s2; };
+      p.xcd_n = best_xn; p.xcd_sh_n = lg2(best_xn); p.xcd_sh_mn = lg2(xm * best_xn);
+      p.xcd_tn = tn / best_xn; p.xcd_tm = tm / xm; p.xcd_inv_tn = (65536 + p.xcd_tn - 1) / p.xcd_tn;
+    }
   }
   const GemmTune& tune = gemm_tune();
   const int big_tiles = ((p.M + 127) / 128) * ((p.N + 127) / 128);
