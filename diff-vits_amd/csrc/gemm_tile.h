@@ -1,6 +1,9 @@
 // Implicit-GEMM tile routine shared by the per-launch kernel (kernels_gemm.hip) and the persistent per-XCD schedule
 // (persist.hip).  See kernels_gemm.hip for the design notes.
 #pragma once
+#ifndef DV_AS_EXP
+#define DV_AS_EXP 0   // development knob (trace experiments on the AS tile); 0 in every shipped build
+#endif
 #include "dv_common.h"
 #include "dv_device.h"
 
@@ -52,18 +55,25 @@ __device__ __forceinline__ unsigned cvt_pk_bf16(float lo, float hi) { return dv_
 // correct but measured ~1800 cycles per k-tile against 960 for the plain kernel: sixteen waves meeting at every k-tile
 // barrier with the VALU pipe of each SIMD shared between them - DESIGN.md.]  The k-tile order is chunk-major (segment ->
 // concat half -> 64-channel chunk -> tap); tiles never span utterances (T_out % BM == 0).
-template <int BM, int BN, int BK, int WM, int WN, int NSPLIT, int KS, bool SC1, bool AF = false>
+// AS ("A slab"): the k = 3 convs read their input three times - the A tiles of the three taps are the same rows shifted by
+// one frame - and the k-loop is bound by the bytes that go through the LDS-DMA path (32 KiB per 64x64x64 k-tile, ~1000
+// cycles against 384 of MFMA).  AS tiles walk the k-range CHUNK-major (64-channel chunk -> tap): the chunk's BM rows are
+// DMA'd ONCE into a slab slot (+ the two halo rows t0 - 1, t0 + BM by one more instruction of wave 0), the three taps
+// read it at row offsets -1 / 0 / +1, and only the weights stream per k-tile: 65 KiB instead of 96 per chunk.
+template <int BM, int BN, int BK, int WM, int WN, int NSPLIT, int KS, bool SC1, bool AF = false, bool AS = false>
 __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int m0, const int n0, char* smem, const int ksel = 0) {
   constexpr int FM = BM / (WM * 32), FN = BN / (WN * 32);
   constexpr int NWQ = WM * WN;                       // waves per k-group (1, 2 or 4)
   constexpr int NWV = NWQ * KS;                      // waves per workgroup
   static_assert(!AF || (BK == 64 && !SC1), "AF tiles: 64-deep k-tiles, per-launch kernel");
+  static_assert(!AS || (BK == 64 && !SC1 && !AF && BM == 64), "AS tiles: 64 rows, 64-deep k-tiles, per-launch kernel");
+  constexpr bool CM = AF || AS;                      // chunk-major k-tile order, weights-only ring
   constexpr bool SPLIT = NSPLIT == 3;
   constexpr int NPL = SPLIT ? 2 : 1;                 // planes per operand
   constexpr int ROWB = BK * 2;                       // LDS row pitch (bytes), unpadded
   constexpr int CPR = ROWB / 16;                     // 16-byte chunks per row: 4 (BK=32) or 8 (BK=64)
   constexpr int RPI = 64 / CPR;                      // rows per wave-instruction
-  constexpr int A_PL = AF ? 0 : BM * ROWB, B_PL = BN * ROWB;  // bytes per plane tile in the ring (AF: weights only)
+  constexpr int A_PL = CM ? 0 : BM * ROWB, B_PL = BN * ROWB;  // bytes per plane tile in the ring (AF: weights only)
   constexpr int STAGE = (A_PL + B_PL) * NPL;
   constexpr int AF_CH = BM == 64 ? 5 : 11;           // AF: chunks per phase (slab = AF_CH x (BM+2) rows x 128 B per plane)
   constexpr int CH_PL = (BM + 2) * ROWB;             // AF: one chunk of one plane
@@ -72,11 +82,11 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int m0, con
 #define DV_NSTAGE_64 4
 #endif
   // LDS ring depth: NSTAGE-1 tiles in flight (DV_NSTAGE_64: experiment knob for the 64x64 tiles' occupancy)
-  constexpr int NSTAGE = AF ? 3 : ((BM == 64 && BN == 64 && !SC1) ? DV_NSTAGE_64 : ((4 * STAGE <= 160 * 1024) ? 4 : 3));
-  constexpr int A_IPW = AF ? 0 : BM / RPI / NWV, B_IPW = BN / RPI / NWV;   // DMA instructions per wave per plane
+  constexpr int NSTAGE = AF ? 3 : AS ? 4 : ((BM == 64 && BN == 64 && !SC1) ? DV_NSTAGE_64 : ((4 * STAGE <= 160 * 1024) ? 4 : 3));
+  constexpr int A_IPW = CM ? 0 : BM / RPI / NWV, B_IPW = BN / RPI / NWV;   // DMA instructions per wave per plane
   constexpr int A_IPW1 = A_IPW ? A_IPW : 1;          // (array extents)
   constexpr int LPT = (A_IPW + B_IPW) * NPL;         // DMA instructions per thread per k-tile
-  static_assert((AF || BM % (RPI * NWV) == 0) && BN % (RPI * NWV) == 0, "tile rows must split over the waves");
+  static_assert((CM || BM % (RPI * NWV) == 0) && BN % (RPI * NWV) == 0, "tile rows must split over the waves");
   DV_TRACE(0);
 #ifdef DV_GEMM_TRACING
   if (threadIdx.x == 0 && blockIdx.x < 8192) {
@@ -134,10 +144,13 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int m0, con
   if (p.sk_mode == 1 || p.sk_mode == 3) { kt0 = ksel * total_kt / p.sk_split; nk = (ksel + 1) * total_kt / p.sk_split - kt0; }
   if (p.sk_mode == 2) nk = 0;
   // ---- AF: position in the chunk-major k-tile order, wave-uniform.  koff() = packed-K element offset of the tile ----
-  struct AfIt { int seg, half, col, tap, taps, c0, c1, kbase, pad; };
+  // (AS: the segment's plane pointers ride along in scalar registers - a segment-descriptor load from argument memory
+  // inside the k-loop sits on every wave's critical path)
+  struct AfIt { int seg, half, col, tap, taps, c0, c1, kbase, pad; const bf16_t* h0; const bf16_t* l0; const bf16_t* h1; const bf16_t* l1; };
   auto af_enter = [&](AfIt& s) {
     const GemmSeg& sg = p.seg[s.seg < p.nseg ? s.seg : 0];
     s.taps = sg.taps; s.c0 = sg.c0; s.c1 = sg.c1; s.pad = sg.pad;
+    if (AS) { s.h0 = sg.a0_hi; s.l0 = sg.a0_lo; s.h1 = sg.a1_hi; s.l1 = sg.a1_lo; }
     s.kbase = s.seg == 0 ? 0 : p.seg[0].taps * (p.seg[0].c0 + p.seg[0].c1);
   };
   auto af_next = [&](AfIt& s) {
@@ -152,7 +165,7 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int m0, con
   };
   auto af_koff = [&](const AfIt& s) { return s.kbase + s.tap * (s.c0 + s.c1) + (s.half ? s.c0 : 0) + s.col; };
   AfIt af0{};                                        // first tile of this workgroup's k-range
-  if (AF) {
+  if (CM) {
     af_enter(af0);
     if (p.sk_mode == 3) {                            // the split point moves to the next chunk boundary (a slab is per chunk)
       int cut = total_kt / p.sk_split;
@@ -204,7 +217,7 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int m0, con
       else glds16(asrc[u], st_base + (unsigned)(((q * NWV + wave) * RPI) * ROWB + pl * A_PL));
     } else {
       const int q = (u - A_IPW * NPL) / NPL, pl = (u - A_IPW * NPL) % NPL;
-      const size_t o = b_off[q] + (AF ? (size_t)af_issue_koff * 2 : (size_t)kt * (BK * 2));
+      const size_t o = b_off[q] + (CM ? (size_t)af_issue_koff * 2 : (size_t)kt * (BK * 2));
       glds16(reinterpret_cast<const char*>(pl ? p.w_lo : p.w_hi) + o,
              st_base + (unsigned)(NPL * A_PL + ((q * NWV + wave) * RPI) * ROWB + pl * B_PL));
     }
@@ -222,15 +235,47 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int m0, con
     }
   };
   AfIt af_is = af0;              // AF: tile being issued (runs NSTAGE-1 tiles ahead of the one being multiplied)
+  // ---- AS: slab slots behind the weight ring: [BM rows hi | BM rows lo | halo: row -1 hi, row BM hi, row -1 lo, row BM lo] ----
+  constexpr int AS_MAIN_PL = BM * ROWB, AS_SLOT = AS_MAIN_PL * NPL + 1024, AS_NSLOT = 4;
+  constexpr int AS_IPW = AS ? BM / RPI / NWV : 0;    // main-row DMA instructions per wave per plane
+  const int as_b = AS ? m0 / p.T_out : 0, as_t0 = AS ? m0 - as_b * p.T_out : 0;
+  int as_issued = 0, as_cur = 0;                     // chunks issued / chunk of the tile being multiplied
+  int as_seq = 0;                                    // (DV_AS_EXP 4: sequential weight tiles)
+  const int as_ls = DV_AS_EXP == 5 ? 0 : AS_IPW * NPL + ((DV_AS_EXP != 1 && wave == 0) ? 1 : 0);   // this wave's DMA instructions per slab
+  auto issue_slab = [&](const AfIt& c) {
+    if (DV_AS_EXP == 5) { ++as_issued; return; }
+    const bf16_t* hi = c.half ? c.h1 : c.h0;
+    const bf16_t* lo = c.half ? c.l1 : c.l0;
+    const int ld = c.half ? c.c1 : c.c0;
+    const unsigned dst0 = smem_base + (unsigned)(NSTAGE * STAGE + (as_issued % AS_NSLOT) * AS_SLOT);
+    const size_t row0 = (size_t)as_b * p.T_in;
+#pragma unroll
+    for (int q = 0; q < AS_IPW; ++q) {
+      const int r = (q * NWV + wave) * RPI + l_row;
+      const size_t e = (row0 + as_t0 + r) * ld + c.col + ((l_slot ^ swz(r)) << 3);
+      glds16(hi + e, dst0 + (unsigned)(((q * NWV + wave) * RPI) * ROWB));
+      if (SPLIT) glds16(lo + e, dst0 + (unsigned)(AS_MAIN_PL + ((q * NWV + wave) * RPI) * ROWB));
+    }
+    if (DV_AS_EXP == 1 ? false : wave == 0) {   // halo rows t0 - 1 and t0 + BM of both planes: one lane-linear instruction (lanes 32.. repeat)
+      const int which = (lane >> 3) & 3, ch = lane & 7;
+      const int t = (which & 1) ? as_t0 + BM : as_t0 - 1;
+      const bf16_t* pl = (which >> 1) ? lo : hi;
+      const bool ok = t >= 0 && t < p.T_in && pl != nullptr;   // conv zero padding beyond the utterance
+      const void* src = ok ? (const void*)(pl + (row0 + t) * ld + c.col + ch * 8) : (const void*)p.zero_page;
+      glds16(src, dst0 + (unsigned)(AS_MAIN_PL * NPL));
+    }
+    ++as_issued;
+  };
   auto issue = [&](int kt) {     // whole tile at once (prologue)
-    if (AF) af_issue_koff = af_koff(af_is);
+    if (AS && af_is.tap == 0) issue_slab(af_is);
+    if (CM) af_issue_koff = (AS && DV_AS_EXP == 4) ? (as_seq++) * 64 : af_koff(af_is);
     else prep_a();
 #pragma unroll
     for (int u = 0; u < LPT; ++u) issue_unit(kt, u);
-    if (AF) af_next(af_is);
+    if (CM) af_next(af_is);
     else advance();
   };
-  if (!AF && kt0 > 0) {                              // second k-half: move the source state to its first tile
+  if (!CM && kt0 > 0) {                              // second k-half: move the source state to its first tile
     for (int t = 0; t < kt0; ++t) advance();
 #pragma unroll
     for (int q = 0; q < B_IPW; ++q) b_off[q] += (size_t)kt0 * (BK * 2);
@@ -291,8 +336,9 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int m0, con
   auto step = [&](int kt, auto issue_tag) {
     constexpr bool ISSUE = decltype(issue_tag)::value;
     const char* base = smem + (kt % NSTAGE) * STAGE;
-    const char* a_hi = AF ? smem + NSTAGE * STAGE + af_ci * CH_PL : base;
-    const char* a_lo = AF ? a_hi + SLAB_PL : base + A_PL;
+    const char* a_hi = AF ? smem + NSTAGE * STAGE + af_ci * CH_PL : AS ? smem + NSTAGE * STAGE + (as_cur % AS_NSLOT) * AS_SLOT : base;
+    const char* a_lo = AF ? a_hi + SLAB_PL : AS ? a_hi + AS_MAIN_PL : base + A_PL;
+    const int as_d = (AS && DV_AS_EXP != 3) ? af_cs.tap - af_cs.pad : 0;   // AS: tap j of a conv padded by `pad` reads slab row + j - pad
     const char* b_hi = base + NPL * A_PL;
     const char* b_lo = b_hi + B_PL;
     // AF: slab row 0 is frame t0 - 1; tap j of a conv padded by `pad` reads row + j + 1 - pad
@@ -303,10 +349,16 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int m0, con
       const int chunk = (kgrp * NKS + ks0) * 2 + lh;
 #pragma unroll
       for (int i = 0; i < FM; ++i) {
-        const int row = (wm * FM + i) * 32 + l31 + af_rowoff;
-        const int off = row * ROWB + ((chunk ^ swz(row)) << 4);
+        const int row = (wm * FM + i) * 32 + l31 + af_rowoff + as_d;
+        int off = row * ROWB + ((chunk ^ swz(row)) << 4), off_lo = off;
+        if (AS) {                                    // rows -1 / BM live in the slot's halo (one lane per fragment)
+          const int hoff = AS_MAIN_PL * NPL + (row < 0 ? 0 : ROWB) + (chunk << 4);
+          const bool inb = DV_AS_EXP == 2 ? true : (unsigned)row < (unsigned)BM;
+          off = inb ? off : hoff;
+          off_lo = inb ? off_lo : hoff + 2 * ROWB - AS_MAIN_PL;
+        }
         ah[ks0][i] = *reinterpret_cast<const bf16x8*>(a_hi + off);
-        if (SPLIT) al[ks0][i] = *reinterpret_cast<const bf16x8*>(a_lo + off);
+        if (SPLIT) al[ks0][i] = *reinterpret_cast<const bf16x8*>(a_lo + off_lo);
       }
 #pragma unroll
       for (int j = 0; j < FN; ++j) {
@@ -316,6 +368,9 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int m0, con
         if (SPLIT) bl[ks0][j] = *reinterpret_cast<const bf16x8*>(b_lo + off);
       }
     }
+    // (AS: without this hipcc sinks every fragment read down to its MFMA - read, wait, multiply, read, ... - and the LDS
+    // latency of all eight reads is exposed: measured 1280 cycles per k-tile in this block)
+    if (AS) __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
       // (independent accumulators per k-step: consecutive MFMAs alternate chains)
@@ -334,14 +389,17 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int m0, con
         }
       if (ISSUE) {
         __builtin_amdgcn_sched_barrier(0);
-        if (c == 0) { if (AF) af_issue_koff = af_koff(af_is); else prep_a(); }
+        if (c == 0) {
+          if (AS && af_is.tap == 0) issue_slab(af_is);
+          if (CM) af_issue_koff = (AS && DV_AS_EXP == 4) ? (as_seq++) * 64 : af_koff(af_is); else prep_a();
+        }
 #pragma unroll
         for (int u = c * LPT / NCH; u < (c + 1) * LPT / NCH; ++u) issue_unit(kt + NSTAGE - 1, u);
         __builtin_amdgcn_sched_barrier(0);
       }
     }
-    if (ISSUE) { if (AF) af_next(af_is); else advance(); }
-    if (AF) { af_next(af_cs); if (af_cs.tap == 0) ++af_ci; }
+    if (ISSUE) { if (CM) af_next(af_is); else advance(); }
+    if (CM) { af_next(af_cs); if (af_cs.tap == 0) { ++af_ci; ++as_cur; } }
   };
 
   // accumulator fragment (i, j), lane (l31, lh), register r = 4*g + e  holds
@@ -567,6 +625,67 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int m0, con
   // ---- main loop: wait(tile kt) -> barrier -> multiply tile kt with the DMA of tile kt+NSTAGE-1 interleaved ----
   // NSTAGE-1 tiles are in flight; the counted vmcnt leaves the younger ones outstanding across the barrier
   DV_TRACE(10);    // residual prefetch / LayerNorm rows / bias DMA issued
+  if constexpr (AS) {
+    // Per wave, tile j carries LPT weight instructions plus, if it opens a chunk, the slab's (issued just before: older).
+    // Before tile kt is multiplied, everything up to its weights must have landed; what may stay in flight is exactly
+    // the instructions of tiles kt + 1 and kt + 2 (n1 + n2).
+    auto cnt_next = [&]() { return LPT + (af_is.tap == 0 ? as_ls : 0); };   // of the tile `issue` / step() sends next
+    auto wait_n = [&](int n) {
+      switch (n) {
+        case 1: wait_vmcnt<1>(); break;   case 2: wait_vmcnt<2>(); break;   case 3: wait_vmcnt<3>(); break;
+        case 4: wait_vmcnt<4>(); break;   case 5: wait_vmcnt<5>(); break;   case 6: wait_vmcnt<6>(); break;
+        case 7: wait_vmcnt<7>(); break;   case 8: wait_vmcnt<8>(); break;   case 9: wait_vmcnt<9>(); break;
+        case 10: wait_vmcnt<10>(); break;
+        default: wait_vmcnt<0>(); break;
+      }
+    };
+    static_assert(LPT <= 2 && NSTAGE == 4, "AS wait table: at most 2 x (2 + 3) instructions in flight");
+    int n1 = 0, n2 = 0;
+    if (nk > 0) issue(0);
+    if (nk > 1) { n1 = cnt_next(); issue(1); }
+    if (nk > 2) { n2 = cnt_next(); issue(2); }
+    DV_TRACE(1);
+#ifdef DV_GEMM_TRACING
+    unsigned long long tr_vm = 0, tr_bar = 0, tr_step = 0;
+#endif
+    // (two loops, one step() variant each: with both variants inside one loop hipcc keeps the accumulator in different
+    // registers on the two paths and copies all sixteen back every iteration)
+    int kt = 0;
+    for (; kt + 3 < nk; ++kt) {
+#ifdef DV_GEMM_TRACING
+      const unsigned long long tr0 = __builtin_amdgcn_s_memtime();
+#endif
+      wait_n(n1 + n2);
+#ifdef DV_GEMM_TRACING
+      const unsigned long long tr1 = __builtin_amdgcn_s_memtime();
+#endif
+      __builtin_amdgcn_s_barrier();                  // tile kt (and its slab) visible; every wave is done with tile kt - 1
+#ifdef DV_GEMM_TRACING
+      const unsigned long long tr2 = __builtin_amdgcn_s_memtime();
+      if (kt == 0) DV_TRACE(2);
+#endif
+      n1 = n2;
+      n2 = cnt_next();
+      step(kt, std::true_type{});
+#ifdef DV_GEMM_TRACING
+      tr_vm += tr1 - tr0; tr_bar += tr2 - tr1; tr_step += __builtin_amdgcn_s_memtime() - tr2;
+#endif
+    }
+    for (; kt < nk; ++kt) {                          // drain: nothing left to issue
+      wait_n(n1 + n2);
+      __builtin_amdgcn_s_barrier();
+#ifdef DV_GEMM_TRACING
+      if (kt == 0) DV_TRACE(2);
+#endif
+      n1 = n2; n2 = 0;
+      step(kt, std::false_type{});
+    }
+#ifdef DV_GEMM_TRACING
+    if (threadIdx.x == 0 && blockIdx.x < 8192) {
+      g_gemm_trace[blockIdx.x * 16 + 12] = tr_vm; g_gemm_trace[blockIdx.x * 16 + 13] = tr_bar; g_gemm_trace[blockIdx.x * 16 + 14] = tr_step;
+    }
+#endif
+  } else {
 #pragma unroll
   for (int t = 0; t < NSTAGE - 1; ++t) {
     if (t < nk) issue(t);
@@ -619,8 +738,9 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int m0, con
 #endif
   }
 #ifdef DV_GEMM_TRACING
-  if (AF && threadIdx.x == 0 && blockIdx.x < 8192) {   // AF: the prologue-split slots carry the steady loop's wait sums
-    g_gemm_trace[blockIdx.x * 16 + 8] = tr_vm; g_gemm_trace[blockIdx.x * 16 + 9] = tr_bar; g_gemm_trace[blockIdx.x * 16 + 10] = tr_step;
+  if (threadIdx.x == 0 && blockIdx.x < 8192) {   // the steady loop's wait sums (AF: also in the prologue-split slots)
+    g_gemm_trace[blockIdx.x * 16 + 12] = tr_vm; g_gemm_trace[blockIdx.x * 16 + 13] = tr_bar; g_gemm_trace[blockIdx.x * 16 + 14] = tr_step;
+    if (AF) { g_gemm_trace[blockIdx.x * 16 + 8] = tr_vm; g_gemm_trace[blockIdx.x * 16 + 9] = tr_bar; g_gemm_trace[blockIdx.x * 16 + 10] = tr_step; }
   }
 #endif
   for (; kt < nk; ++kt) {                            // drain: nothing left to issue
@@ -636,6 +756,7 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int m0, con
     step(kt, std::false_type{});
     --af_ph_tiles; --af_left;
   }
+  }   // (!AS)
 
   if (NACC > 1) {
 #pragma unroll
@@ -729,7 +850,7 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int m0, con
 
   // ---- epilogue ----
   DV_TRACE(4);
-  const bool gnx = !SC1 && !AF && p.gnx.xchg != nullptr;
+  const bool gnx = !SC1 && !AF && p.gnx.xchg != nullptr;   // (AS tiles too)
   // store 4 consecutive columns of one row: fp32 and/or split bf16 planes
   auto store4 = [&](size_t o, int nb, const float* v) {
     if (vec4) {

@@ -15,7 +15,7 @@ import torch
 import diff_vits_amd  # noqa
 from diff_vits_amd import _lib as L
 
-L.LIB_PATH = os.path.join(os.path.dirname(L.LIB_PATH), "libdvits_hip_trace.so")
+L.LIB_PATH = os.environ.get("DVITS_TRACE_LIB") or os.path.join(os.path.dirname(L.LIB_PATH), "libdvits_hip_trace.so")
 lib = L.lib()
 lib.dv_debug_gemm_trace.restype = C.c_int
 lib.dv_debug_gemm_trace.argtypes = [C.c_void_p, C.c_int]
@@ -24,15 +24,27 @@ shapes = [(8192, 128, 128), (4096, 256, 2048), (1024, 3072, 512), (2048, 384, 30
           (4096, 256, 256), (2048, 384, 384)]
 # "af:BxTxCinxCoutxk" traces the fused GroupNorm -> conv tiles (dv_op_gn_conv1d) instead of a plain linear
 af_shapes = [tuple(int(v) for v in a[3:].split("x")) for a in sys.argv[1:] if a.startswith("af:")]
-plain = [a for a in sys.argv[1:] if not a.startswith("af:")]
+# "conv:BxTxCinxCoutxk" traces a plain conv1d (dv_op_conv1d; with DVITS_SLAB=1 a k = 3 conv with 64-multiples runs on the A-slab tile)
+conv_shapes = [tuple(int(v) for v in a[5:].split("x")) for a in sys.argv[1:] if a.startswith("conv:")]
+plain = [a for a in sys.argv[1:] if not a.startswith("af:") and not a.startswith("conv:")]
 if plain:
     shapes = [tuple(int(v) for v in a.split("x")) for a in plain]
-elif af_shapes:
+elif af_shapes or conv_shapes:
     shapes = []
 NWG = 8192
 buf = np.zeros((NWG, 16), dtype=np.uint64)
-for spec in shapes + [("af",) + a for a in af_shapes]:
-    if spec[0] == "af":
+for spec in shapes + [("af",) + a for a in af_shapes] + [("conv",) + a for a in conv_shapes]:
+    if spec[0] == "conv":
+        _, Bn, Tn, Ci, Co, kk = spec
+        M, K, N = Bn * Tn, Ci * kk, Co
+        x = torch.randn(Bn, Ci, Tn, device="cuda")
+        w = torch.randn(Co, Ci, kk, device="cuda") / K ** 0.5
+        b = torch.randn(N, device="cuda")
+        y = torch.empty(Bn, Co, Tn, device="cuda")
+
+        def run():
+            L.check(lib.dv_op_conv1d(L.ptr(x), L.ptr(w), L.ptr(b), L.ptr(y), Bn, Ci, Tn, Co, kk, 1, 0, 0, None))
+    elif spec[0] == "af":
         _, Bn, Tn, Ci, Co, kk = spec
         M, K, N = Bn * Tn, Ci * kk, Co
         x = torch.randn(M, Ci, device="cuda")
@@ -70,6 +82,8 @@ for spec in shapes + [("af",) + a for a in af_shapes]:
     n = int(live.sum())
     t = t[live]
     pro = np.stack([t[:, 8] - t[:, 0], t[:, 9] - t[:, 8], t[:, 10] - t[:, 9], t[:, 11] - t[:, 10], t[:, 1] - t[:, 11]], 1)
+    print("   k-loop sums of thread 0 (median cyc): waits for its DMA %d | waits at the barrier %d | multiplies + issues %d"
+          % tuple(np.median(t[:, 12:15], 0)))
     if spec[0] != "af":
         print("   prologue split (median cyc): kernarg-ready %d | row geometry %d | bias/residual/LN setup %d | issue tile 0 %d | "
               "issue tiles 1.. %d" % tuple(np.median(pro, 0)))
