@@ -70,7 +70,8 @@ import numpy as np, torch, torch.nn.functional as F
 import diff_vits_amd
 from diff_vits_amd import _lib as L, synth
 for (B, Cin, T, Cout, prec) in ((8, 384, 256, 384, 0), (2, 128, 1024, 256, 0), (4, 256, 128, 128, 1), (1, 64, 64, 64, 0)):
-    x = synth.normal(3, "x", (B, Cin, T)); w = synth.normal(3, "w", (Cout, Cin, 3)) / np.sqrt(3 * Cin); b = 0.1 * synth.normal(3, "b", (Cout,))
+    x = synth.normal(3, "x", (B, Cin, T)); w = synth.normal(3, "w", (Cout, Cin, 3), 1.0 / np.sqrt(3 * Cin)); b = synth.normal(3, "b", (Cout,), 0.1)
+    x, w, b = (a.astype(np.float32) for a in (x, w, b))
     ref = F.conv1d(torch.from_numpy(x), torch.from_numpy(w), torch.from_numpy(b), padding=1)
     y = torch.empty(ref.shape, device="cuda")
     dx, dw, db = (torch.from_numpy(a).cuda() for a in (x, w, b))
