@@ -617,6 +617,51 @@ def test_groupnorm_finished_in_producer_epilogue_matches_separate_launch():
     assert rel_l2(outs[1], outs[0]) < 2e-5
 
 
+@pytest.mark.parametrize("B,T,L", [(16, 128, 40), (3, 256, 77), (1, 64, 10), (2, 2048, 300), (5, 512, 256), (1, 320, 150)])
+def test_fused_schedule_matches_plain_schedule_across_shapes(B, T, L):
+    """The round-2 schedule (GroupNorm in the producer's epilogue, fragment attention, row-block chains shared out over
+    workgroups, k_chain_ff, XCD rectangles) against the one-launch-per-op schedule of the same engine on shapes the golden
+    vectors do not cover: more utterances than fit the in-launch hand-over (B = 16: the GEMM grids exceed the CU count and
+    must fall back), utterance counts that leave XCDs ragged, one short utterance, T = 2048, prompts that are not a
+    multiple of 32.  Same weights, same arithmetic, different summation order: float32-rounding agreement; no hand-over
+    timed out; repeatable bit for bit."""
+    from diff_vits_amd import synth
+    from diff_vits_amd.unet1d.unet_1d_condition import UNet1DConditionModel
+    kw = UNET_CASES["cfg1"][0]
+    with torch.device("meta"):
+        shapes = {k: tuple(v.shape) for k, v in UNet1DConditionModel(**kw).state_dict().items()}
+    sd = {k: torch.from_numpy(v) for k, v in synth.make_state_dict(shapes, seed=4321).items()}
+    x = torch.from_numpy(synth.normal(11, "x", (B, 80, T))).cuda()
+    cond = torch.from_numpy(synth.normal(11, "c", (B, 128, T))).cuda()
+    enc = torch.from_numpy(synth.normal(11, "e", (B, L, 128))).cuda()
+    mask = torch.ones(B, L, dtype=torch.bool)
+    mask[0, L // 2:] = False                      # one utterance with a shorter prompt
+    mask = mask.cuda()
+    t = torch.full((B,), 123.0, device="cuda")
+    knobs = ("DVITS_GNX", "DVITS_ATTN_FRAG", "DVITS_CHAIN_SPLIT", "DVITS_CHAIN_FF", "DVITS_XCD_N", "DVITS_CHAIN", "DVITS_STAT16")
+    outs = []
+    for plain in (True, False):
+        for k in knobs:
+            if plain:
+                os.environ[k] = "0"
+        try:
+            m = UNet1DConditionModel(backend="hip", **kw).eval()
+            m.load_state_dict(sd)
+            m = m.cuda()
+            with torch.no_grad():
+                y = m(torch.cat([x, cond], 1), t, enc, encoder_attention_mask=mask).sample
+                y2 = m(torch.cat([x, cond], 1), t, enc, encoder_attention_mask=mask).sample
+            torch.cuda.synchronize()
+            assert torch.equal(y, y2)
+            assert m.hip_engine().handover_status()[1] == 0
+            outs.append(y.cpu().numpy())
+        finally:
+            for k in knobs:
+                os.environ.pop(k, None)
+    assert np.isfinite(outs[1]).all()
+    assert rel_l2(outs[1], outs[0]) < 5e-5, rel_l2(outs[1], outs[0])
+
+
 def test_persistent_per_xcd_schedule_matches_per_launch():
     """DVITS_PERSIST=1 (csrc/persist.hip): the body of a forward as ONE launch with XCD-local barriers, utterance b on
     XCD b % 8.  Same kernels' tile routines (L1-bypassing loads), different tile menu: agreement with the per-launch
