@@ -49,8 +49,8 @@ struct AfParams {
 // the buffer), reduces them (fp64, fixed order) and writes y = SiLU(GN(v) * (1 + tscale) + tshift) as split planes
 // straight from the accumulator registers: the consumer's k_gn_apply launch and the fp32 round trip of the
 // intermediate disappear.  No counters and no read-modify-write atomics: a launch inside a hipGraph cannot be told its
-// sequence number, and a counter round trip sits on every workgroup's critical path.  All waiting workgroups must be
-// resident at once: launch_gemm refuses grids larger than the device's CU count (gemm_gnx_plan()).
+// sequence number, and a counter round trip sits on every workgroup's critical path.  ALL workgroups of the launch must
+// be resident at once: launch_gemm refuses grids larger than the device's CU count (gemm_gnx_plan()).
 struct GnxParams {
   unsigned long long* xchg;      // null: off.  [M / 32][N / 16] (sum | M2 << 32) words of THIS op, EMPTY before the launch
   unsigned* status;              // set to 1 if a wait timed out (results invalid; the host checks after the run)
@@ -248,6 +248,7 @@ struct PersistSync {
 // launchers (each enqueues on `st` and returns hipGetLastError())
 hipError_t launch_gemm(const GemmParams& p, int precision, hipStream_t st);
 hipError_t gemm_init();   // one-time kernel attribute setup (call outside stream capture)
+void gemm_env_refresh();  // re-read launch_gemm's environment knobs (called by every prepare)
 hipError_t attn_init();
 hipError_t launch_attention(const AttnParams& p, hipStream_t st);
 

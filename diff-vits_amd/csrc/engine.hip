@@ -500,8 +500,8 @@ struct Builder {
   // every level has whole 16-channel blocks per GroupNorm group: all tensors carry block statistics (16x fewer entries
   // for k_gn_apply to reduce, cheaper producer epilogue); otherwise (tiny / duration-predictor configurations) per-column slabs
   bool stat16_everywhere() const {
-    static const bool off = [] { const char* e = getenv("DVITS_STAT16"); return e && e[0] == '0'; }();
-    if (off || arena.exact) return false;
+    const char* e16 = getenv("DVITS_STAT16");      // (read per prepare: tests flip it inside one process)
+    if ((e16 && e16[0] == '0') || arena.exact) return false;
     const int G = u->cfg.norm_num_groups;
     for (int i = 0; i < u->cfg.n_levels; ++i)
       if (u->cfg.block_out_channels[i] % G != 0 || (u->cfg.block_out_channels[i] / G) % 16 != 0) return false;
@@ -979,7 +979,8 @@ struct Builder {
         cp.passes = 3; cp.out2 = qkv; cp.ldo2 = sa_frag ? C : 3 * C; cp.ln_eps = 1e-5f;
         if (sa_frag) { cp.sa_kf_hi = kf.hi; cp.sa_kf_lo = kf.lo; cp.sa_vf_hi = vf.hi; cp.sa_vf_lo = vf.lo; }
         {   // few row blocks: share the three passes out (DVITS_CHAIN_SPLIT=0: one workgroup per row block)
-          static const bool off = [] { const char* e = getenv("DVITS_CHAIN_SPLIT"); return e && e[0] == '0'; }();
+          const char* es = getenv("DVITS_CHAIN_SPLIT");
+          const bool off = es && es[0] == '0';
           const int rbs = M / 32, cus = n_cu > 0 ? n_cu : 256;
           cp.nsplit = off ? 1 : (rbs * 3 <= cus ? 3 : (rbs * 2 <= cus ? 2 : 1));
         }
@@ -1040,7 +1041,8 @@ struct Builder {
         cp.w2_hi = w_q2->fhi; cp.w2_lo = w_q2->flo; cp.Kp2 = w_q2->Kp; cp.b2 = w_q2->bias; cp.u2 = w_q2->u;
         cp.passes = 1; cp.out2 = q2; cp.ldo2 = C; cp.ln_eps = 1e-5f;
         {   // few row blocks: the 128-column groups of to_q are shared out over C / 128 workgroups per row block
-          static const bool off = [] { const char* e = getenv("DVITS_CHAIN_SPLIT"); return e && e[0] == '0'; }();
+          const char* es = getenv("DVITS_CHAIN_SPLIT");
+          const bool off = es && es[0] == '0';
           const int rbs = M / 32, cus = n_cu > 0 ? n_cu : 256, nsg = C / 128;
           cp.nsplit = (!off && nsg >= 2 && rbs * nsg <= cus) ? nsg : 1;
         }
@@ -1121,7 +1123,8 @@ struct Builder {
     // C = 128 blocks: LN3 -> GEGLU -> merged ff.net.2 + proj_out + residual as ONE row-block launch (k_chain_ff; the
     // 4C-wide product never leaves LDS).  DVITS_CHAIN_FF=0 restores the two GEMMs.
     {
-      static const bool ff_off = [] { const char* e = getenv("DVITS_CHAIN_FF"); return e && e[0] == '0'; }();
+      const char* eff = getenv("DVITS_CHAIN_FF");
+      const bool ff_off = eff && eff[0] == '0';
       ChainFFParams fp{};
       fp.M = M; fp.C = C; fp.T = Tn;
       if (!ff_off && merged_ffproj && chain_on && !arena.exact && l3.stat && x.stat16 && chain_ff_supported(fp, prec)) {
@@ -1772,6 +1775,7 @@ extern "C" int dv_unet_prepare(dv_unet* u, int32_t B, int32_t T, int32_t L, int3
   }
   HIPCHK(hipDeviceSynchronize());
   HIPCHK(gemm_init());
+  gemm_env_refresh();
   HIPCHK(attn_init());
   HIPCHK(chain_init());
   // a new shape re-plans the schedule; the packed weights survive unless the weights or the precision changed
@@ -1883,6 +1887,7 @@ extern "C" int dv_penc_prepare(dv_penc* p, int32_t B, int32_t L, int32_t precisi
   dv_unet* u = &p->core;
   HIPCHK(hipDeviceSynchronize());
   HIPCHK(gemm_init());
+  gemm_env_refresh();
   HIPCHK(attn_init());
   unet_release_prepared(u);
   u->B = B; u->T = L; u->L = L; u->precision = precision; u->force_up = 0;
@@ -1957,9 +1962,17 @@ extern "C" int dv_unet_handover_status(dv_unet* u, int32_t* n_ops, int32_t* time
   return DV_OK;
 }
 int dv_unet_health(const dv_unet* u) {
-  if (u->gnx_status && *(volatile unsigned*)u->gnx_status)
-    return dv_fail(DV_ERR_HIP, "an earlier launch's in-kernel GroupNorm hand-over timed out (its results are invalid); "
-                               "DVITS_GNX=0 runs GroupNorm as separate launches");
+  if (u->gnx_status && *(volatile unsigned*)u->gnx_status) {
+    const volatile unsigned* st = u->gnx_status;
+    const GemmParams* hit = nullptr;
+    for (const auto& gp : u->gemm_store)
+      if (gp->gnx.xchg && (unsigned)(size_t)gp->gnx.xchg == st[1]) hit = gp.get();
+    return dv_fail(DV_ERR_HIP, "an earlier launch's in-kernel GroupNorm hand-over timed out (its results are invalid): GEMM M=%d N=%d "
+                               "T_out=%d taps=%d split-K=%d, workgroup %u, group %u, %u entries missing; DVITS_GNX=0 runs GroupNorm "
+                               "as separate launches",
+                   hit ? hit->M : -1, hit ? hit->N : -1, hit ? hit->T_out : -1, hit ? hit->seg[0].taps : -1,
+                   hit ? (hit->sk_buf ? hit->sk_split : 0) : -1, st[2], st[3], st[4]);
+  }
   return DV_OK;
 }
 
@@ -2150,6 +2163,7 @@ extern "C" int dv_op_conv1d(const float* x, const float* w, const float* bias, f
   if (!x || !w || !y || (k != 1 && k != 3) || (stride != 1 && stride != 2)) return dv_fail(DV_ERR_INVALID, "dv_op_conv1d: bad argument");
   hipStream_t st = (hipStream_t)stream;
   HIPCHK(gemm_init());
+  gemm_env_refresh();
   HIPCHK(attn_init());
   const bool x3 = precision == DV_PREC_BF16X3;
   const int cpad = rup(Cin, 32), Kp = k * cpad, Npad = rup(Cout, 128);
@@ -2187,6 +2201,7 @@ extern "C" int dv_op_gn_conv1d(const float* x_cl, const float* gamma, const floa
     return dv_fail(DV_ERR_INVALID, "dv_op_gn_conv1d: needs T %% 32 == 0, Cin %% 64 == 0 (<= 1024), whole 16-channel blocks per group");
   hipStream_t st = (hipStream_t)stream;
   HIPCHK(gemm_init());
+  gemm_env_refresh();
   const bool x3 = precision == DV_PREC_BF16X3;
   const int Kp = k * Cin, Npad = rup(Cout, 128);
   OpScratch sc;
@@ -2221,6 +2236,7 @@ extern "C" int dv_op_linear(const float* x, const float* w, const float* bias, f
   if (!x || !w || !y || K % 32 != 0) return dv_fail(DV_ERR_INVALID, "dv_op_linear: K must be a multiple of 32");
   hipStream_t st = (hipStream_t)stream;
   HIPCHK(gemm_init());
+  gemm_env_refresh();
   HIPCHK(attn_init());
   const bool x3 = precision == DV_PREC_BF16X3;
   const int Npad = rup(N, 128);

@@ -1089,7 +1089,11 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int m0, con
         }
         if (__all(ok)) break;
         if (spins > (1 << 18)) {
-          if (lane == 0) __hip_atomic_store(p.gnx.status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+          if (lane == 0) {               // which GEMM, which workgroup, which group: reported by the next host call
+            p.gnx.status[1] = (unsigned)(size_t)p.gnx.xchg; p.gnx.status[2] = blockIdx.x; p.gnx.status[3] = (unsigned)g;
+            p.gnx.status[4] = (unsigned)__builtin_popcountll(__ballot(!ok));
+            __hip_atomic_store(p.gnx.status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+          }
           break;
         }
         __builtin_amdgcn_s_sleep(1);

@@ -288,6 +288,10 @@ int gemm_candidates(const GemmParams& p, int* out, int cap) {
   return n;
 }
 
+// environment knobs of launch_gemm that tests flip inside one process: re-read whenever an engine is prepared
+static int g_env_xn = [] { const char* e = getenv("DVITS_XCD_N"); return e ? atoi(e) : -1; }();
+void gemm_env_refresh() { const char* e = getenv("DVITS_XCD_N"); g_env_xn = e ? atoi(e) : -1; }
+
 // Tile (BM x BN) the shape heuristic of launch_gemm picks for a non-AF, non-GEGLU GEMM (kept in step with
 // Tiles<BK>::launch below; used to plan the in-epilogue GroupNorm: its tiles must not span utterances and must all be resident)
 static void gemm_pick_tile(const GemmParams& p, int& bm, int& bn) {
@@ -318,12 +322,14 @@ int gemm_gnx_plan(const GemmParams& p, int n_cu) {
   gemm_pick_tile(p, bm, bn);
   if (p.T_out % bm != 0 || p.N % bn != 0) return 0;
   if ((p.T_out / 32) * (cpg / 16) > 256) return 0;     // entries of one group: four per lane of the reducing wave
-  // every workgroup that waits must be resident: (finishing) tiles <= compute units; the first arrivers of a fused
-  // split-K pair leave without waiting, so only the tile count matters there too
+  // Every workgroup of the launch must be resident at once - INCLUDING both halves of a fused split-K pair, although the
+  // first arriver of a pair leaves without waiting: workgroups are bound to XCD id % 8, so a second round could only
+  // start on CUs freed on ITS XCD, and an XCD whose first-round workgroups all happen to be the waiting finishers frees
+  // none (found by the bounded poll at M = 1024, N = 384, 2 x 192 workgroups: flagged time-outs, not a hang).
   const int tiles = (p.M / bm) * (p.N / bn);
   const bool pair = p.sk_buf && p.sk_split == 2 && p.sk_ticket;
   if (p.sk_buf && !pair) return 0;                   // two-launch split-K: not supported with the in-epilogue GroupNorm
-  if (pair ? tiles >= n_cu : tiles > n_cu) return 0;
+  if ((pair ? 2 * tiles : tiles) > n_cu) return 0;
   return (p.M / 32) * (p.N / 16);
 }
 
@@ -364,7 +370,7 @@ hipError_t launch_gemm(const GemmParams& pin, int precision, hipStream_t st) {
   // (N / xn) x K of W plus (M / xm) x channels of A.  DVITS_XCD_N=<1|2|4|8> forces xn where it divides, 0 = row bands.
   p.xcd_n = 0;
   if (p.force_tile == GT_AUTO && !p.af) {
-    static const int env_xn = [] { const char* e = getenv("DVITS_XCD_N"); return e ? atoi(e) : -1; }();
+    const int env_xn = g_env_xn;
     int bm, bn;
     gemm_pick_tile(p, bm, bn);
     const int tm = (p.M + bm - 1) / bm, tn = (p.N + bn - 1) / bn;

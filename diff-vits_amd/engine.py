@@ -3,6 +3,7 @@
 prepares the kernel schedule for the current (B, T, L) and runs forwards on the current
 HIP stream.  torch is used only for device memory and streams.
 """
+import collections
 import ctypes as C
 import os
 
@@ -37,20 +38,58 @@ class UNetEngine:
         self.in_channels, self.out_channels = c.in_channels, c.out_channels
         self.cross_dim = c.cross_attention_dim
         self.n_up = len(chans) - 1
-        self._h = C.c_void_p()
-        _lib.check(_lib.lib().dv_unet_create(C.byref(c), C.byref(self._h)), "dv_unet_create")
-        self._weight_sig = None
-        self._prepared = None
+        self._cfg = c
+        # Prepared schedules are kept per shape (LRU of native handles, DVITS_PLAN_CACHE entries, default 4): utterances of
+        # a length seen before replay their schedule - and the sampler its captured hipGraph - instead of re-planning
+        # (~8 ms) and re-capturing (~100 ms for a 30-step loop).  Every handle owns its packed weights (~260 MB for the
+        # 64.7 M-parameter denoiser in split-bf16 + fragment-major copies: nothing against 288 GB).
+        self._plans = collections.OrderedDict()     # (B, T, L, precision, force_up) -> _Slot
+        self._cap = max(1, int(os.environ.get("DVITS_PLAN_CACHE", "4")))
+        self._cur = self._new_slot()
+        self._sig = None                # current signature of the module's parameters / buffers
         self.precision = None
         self.cond_serial = 0            # bumped by every set_cond (callers that cache conditioning compare it)
-        self.prepare_serial = 0         # bumped whenever the schedule is really rebuilt (the engine then needs set_cond again)
+        self.prepare_serial = 0         # bumped whenever another schedule becomes current (the caller must set_cond again)
+        self.plan_builds = 0            # native prepares really run (a cached shape does not count)
         self._fwd_cond = None           # forward(): the (enc, mask) tensors the engine is currently conditioned on
+
+    class _Slot:
+        __slots__ = ("h", "weight_sig", "prepared", "cond_keepalive")
+
+        def __init__(self, h):
+            self.h, self.weight_sig, self.prepared, self.cond_keepalive = h, None, None, None
+
+    def _new_slot(self):
+        h = C.c_void_p()
+        _lib.check(_lib.lib().dv_unet_create(C.byref(self._cfg), C.byref(h)), "dv_unet_create")
+        return UNetEngine._Slot(h)
+
+    # the current schedule's native handle / key (read by the samplers, the bench and the tests)
+    @property
+    def _h(self):
+        return self._cur.h
+
+    @property
+    def _prepared(self):
+        return self._cur.prepared
+
+    @_prepared.setter
+    def _prepared(self, v):
+        self._cur.prepared = v
+        if v is None:                    # forget every cached schedule (weights / precision changed, or a test asks)
+            for sl in self._plans.values():
+                if sl is not self._cur and sl.h and sl.h.value:
+                    _lib.lib().dv_unet_destroy(sl.h)
+                    sl.h = C.c_void_p()
+            self._plans.clear()
 
     def __del__(self):
         try:
-            if getattr(self, "_h", None) and self._h.value:
-                _lib.lib().dv_unet_destroy(self._h)
-                self._h = C.c_void_p()
+            slots = {id(sl): sl for sl in list(getattr(self, "_plans", {}).values()) + [getattr(self, "_cur", None)] if sl is not None}
+            for sl in slots.values():
+                if sl.h and sl.h.value:
+                    _lib.lib().dv_unet_destroy(sl.h)
+                    sl.h = C.c_void_p()
         except Exception:
             pass
 
@@ -65,23 +104,30 @@ class UNetEngine:
         # counter of every parameter / buffer; load_state_dict, .to() and in-place updates all move one of them
         m = self.module
         sig = tuple((v.data_ptr(), v._version) for v in m.parameters()) + tuple((v.data_ptr(), v._version) for v in m.buffers())
-        if sig != self._weight_sig:
-            sd = m.state_dict()
-            L = _lib.lib()
-            for name, t in sd.items():
-                if not t.is_cuda:
-                    raise RuntimeError("backend='hip' needs the module on a GPU (parameter %s is on %s); "
-                                       "call .to('cuda') or construct with backend='torch'" % (name, t.device))
-                t32 = t.detach().to(torch.float32).contiguous()
-                shape = (C.c_int64 * t32.dim())(*t32.shape)
-                _lib.check(L.dv_unet_set_weight(self._h, name.encode(), _lib.ptr(t32), shape, t32.dim()),
-                           "dv_unet_set_weight(%s)" % name)
-            torch.cuda.synchronize()
-            self._weight_sig = sig
+        if sig != self._sig:             # new parameters: every cached schedule is stale
+            self._sig = sig
             self._prepared = None
         if precision != self.precision:
             self.precision = precision
             self._prepared = None
+        self._upload(self._cur)
+
+    def _upload(self, slot):
+        """Give `slot`'s native handle the module's current parameters if it does not have them yet."""
+        if slot.weight_sig == self._sig:
+            return
+        L = _lib.lib()
+        for name, t in self.module.state_dict().items():
+            if not t.is_cuda:
+                raise RuntimeError("backend='hip' needs the module on a GPU (parameter %s is on %s); "
+                                   "call .to('cuda') or construct with backend='torch'" % (name, t.device))
+            t32 = t.detach().to(torch.float32).contiguous()
+            shape = (C.c_int64 * t32.dim())(*t32.shape)
+            _lib.check(L.dv_unet_set_weight(slot.h, name.encode(), _lib.ptr(t32), shape, t32.dim()),
+                       "dv_unet_set_weight(%s)" % name)
+        torch.cuda.synchronize()
+        slot.weight_sig = self._sig
+        slot.prepared = None
 
     # ------------------------------------------------------------------ schedule
     def prepare(self, B, T, L, force_upsample_size=None):
@@ -90,12 +136,29 @@ class UNetEngine:
             up = 2 ** self.n_up
             force_upsample_size = (self.in_channels % up != 0) or (T % up != 0)
         key = (B, T, L, self.precision, bool(force_upsample_size))
-        if key != self._prepared:
-            _lib.check(_lib.lib().dv_unet_prepare(self._h, B, T, L, _PRECISIONS[self.precision],
+        if key == self._cur.prepared:
+            return key
+        # another shape becomes current: a cached schedule if there is one, else a free / the least recently used handle
+        slot = self._plans.get(key)
+        if slot is None:
+            if self._cur.prepared is None and self._cur not in self._plans.values():
+                slot = self._cur                                  # the very first schedule of this engine
+            elif len(self._plans) < self._cap:
+                slot = self._new_slot()
+            else:
+                _, slot = self._plans.popitem(last=False)         # evict: its handle is re-planned (packed weights kept)
+                slot.prepared = None
+        self._upload(slot)
+        if slot.prepared != key:
+            _lib.check(_lib.lib().dv_unet_prepare(slot.h, B, T, L, _PRECISIONS[self.precision],
                                                   int(bool(force_upsample_size))), "dv_unet_prepare")
-            self._prepared = key
-            self.prepare_serial += 1
-            self._fwd_cond = None
+            slot.prepared = key
+            self.plan_builds += 1
+        self._plans[key] = slot
+        self._plans.move_to_end(key)
+        self._cur = slot
+        self.prepare_serial += 1         # (a cached schedule still holds ITS last conditioning: callers must set_cond again)
+        self._fwd_cond = None
         return key
 
     def set_cond(self, enc, bias=None):
@@ -103,7 +166,7 @@ class UNetEngine:
         enc = enc.detach().to(torch.float32).contiguous()
         if bias is not None:
             bias = bias.detach().to(torch.float32).reshape(enc.shape[0], enc.shape[1]).contiguous()
-        self._cond_keepalive = (enc, bias)
+        self._cur.cond_keepalive = (enc, bias)
         self.cond_serial += 1
         _lib.check(_lib.lib().dv_unet_set_cond(self._h, _lib.ptr(enc), _lib.ptr(bias), _lib.stream_ptr()),
                    "dv_unet_set_cond")

@@ -131,6 +131,8 @@ class Plan:
             raise ValueError("Unsupported skip_type {}, need to be 'logSNR' or 'time_uniform' or 'time_quadratic'"
                              .format(skip_type))
         betas = np.ascontiguousarray(betas, dtype=np.float32)
+        self._args = (solver, betas, steps, order, skip_type, lower_order_final, t_start, t_end, denoise_to_zero)
+        self._per_shape = {}          # captured graphs live in the native plan, one per plan: a copy per input shape
         self._h = C.c_void_p()
         L.check(L.lib().dv_sampler_plan_ex(solver, betas.ctypes.data_as(C.c_void_p), len(betas), steps, order,
                                            L.SKIP[skip_type], int(bool(lower_order_final)),
@@ -153,6 +155,18 @@ class Plan:
         self.events = np.zeros((ne.value, 9), dtype=np.int32)
         self.n_slots = ns.value
         L.check(L.lib().dv_plan_events(self._h, None, self.events.ctypes.data_as(C.c_void_p), None), "dv_plan_events")
+
+    def for_shape(self, shape):
+        """The plan whose captured hipGraph belongs to inputs of this shape (this one for the first shape seen, a copy
+        for every further one: utterances of alternating lengths then replay their graphs instead of re-capturing)."""
+        if not self._per_shape:
+            self._per_shape[shape] = self
+        if shape not in self._per_shape:
+            if len(self._per_shape) >= 8:                      # bounded: drop the oldest copy
+                old = next(k for k in self._per_shape if self._per_shape[k] is not self)
+                del self._per_shape[old]
+            self._per_shape[shape] = Plan(*self._args)
+        return self._per_shape[shape]
 
     def __del__(self):
         try:
@@ -215,24 +229,24 @@ class NativeUNetModel:
         eng.prepare(B, T, self.enc.shape[1])
         bias = self.unet._bias_from_mask(self.mask, torch.float32)
         eng.set_cond(self.enc, bias)
-        key = (x.shape, x.device)
-        if getattr(self, "_xbuf_key", None) != key:
-            self._xbuf = torch.empty(x.shape, device=x.device, dtype=torch.float32)
-            self._xbuf_key = key
-        self._xbuf.copy_(x)
-        # the condition goes through a persistent buffer as well: the captured graph is keyed on its address, so a new
-        # utterance of the same shape replays the graph instead of re-capturing steps x ~220 launches
-        cond = None
-        if self.cond is not None:
-            ckey = (tuple(self.cond.shape), self.cond.device)
-            if getattr(self, "_cbuf_key", None) != ckey:
-                self._cbuf = torch.empty(self.cond.shape, device=self.cond.device, dtype=torch.float32)
-                self._cbuf_key = ckey
-            self._cbuf.copy_(self.cond)
-            cond = self._cbuf
-        L.check(L.lib().dv_sampler_run(plan.handle, eng.handle, L.ptr(self._xbuf), L.ptr(cond), L.stream_ptr()),
+        # Persistent input / condition buffers per shape: the captured graph is keyed on their addresses (and on the
+        # engine's schedule handle), so a new utterance of a shape seen before replays its graph instead of re-capturing
+        # steps x ~160 launches.  (Bounded: the engine keeps DVITS_PLAN_CACHE schedules.)
+        bufs = self.__dict__.setdefault("_bufs", {})
+        key = (tuple(x.shape), None if self.cond is None else tuple(self.cond.shape), str(x.device))
+        if key not in bufs:
+            if len(bufs) >= 8:
+                bufs.pop(next(iter(bufs)))
+            bufs[key] = (torch.empty(x.shape, device=x.device, dtype=torch.float32),
+                         None if self.cond is None else torch.empty(self.cond.shape, device=self.cond.device, dtype=torch.float32))
+        xbuf, cbuf = bufs[key]
+        xbuf.copy_(x)
+        if cbuf is not None:
+            cbuf.copy_(self.cond)
+        plan = plan.for_shape((key, eng.handle.value))
+        L.check(L.lib().dv_sampler_run(plan.handle, eng.handle, L.ptr(xbuf), L.ptr(cbuf), L.stream_ptr()),
                 "dv_sampler_run")
-        return self._xbuf.clone()
+        return xbuf.clone()
 
 
 def sample_with_plan(plan, model_fn, noise_schedule, x, intermediates=None):

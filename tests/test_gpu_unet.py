@@ -662,6 +662,41 @@ def test_fused_schedule_matches_plain_schedule_across_shapes(B, T, L):
     assert rel_l2(outs[1], outs[0]) < 5e-5, rel_l2(outs[1], outs[0])
 
 
+def test_schedules_and_graphs_are_kept_per_utterance_length():
+    """Serving sees utterances of a few recurring lengths.  The engine keeps a prepared schedule per (B, T, L) (LRU of
+    native handles, DVITS_PLAN_CACHE, default 4) and the sampler a captured hipGraph per shape: a length seen before
+    costs neither a re-plan nor a re-capture - same results bit for bit, no further native prepare."""
+    from diff_vits_amd import synth
+    from diff_vits_amd.sampler import uni_pc
+    from diff_vits_amd.unet1d.unet_1d_condition import UNet1DConditionModel
+    kw = UNET_CASES["cfg1"][0]
+    with torch.device("meta"):
+        shapes = {k: tuple(v.shape) for k, v in UNet1DConditionModel(**kw).state_dict().items()}
+    m = UNet1DConditionModel(backend="hip", **kw).eval()
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in synth.make_state_dict(shapes, seed=99).items()})
+    m = m.cuda()
+    ns = uni_pc.NoiseScheduleVP("discrete", betas=torch.from_numpy(synth.make_betas()))
+    runs = {}
+    lengths = [(192, 60), (300, 150), (128, 33)]
+    for rnd in range(3):
+        for T, L in lengths:
+            x, cond, enc, mask = (torch.from_numpy(a).cuda() for a in synth.make_inputs(1, 80, T, L, seed=5))
+            native = runs.setdefault("model", uni_pc.NativeUNetModel(m, cond, enc, mask))
+            native.cond, native.enc, native.mask = cond, enc, mask
+            solver = runs.setdefault("solver", uni_pc.UniPC(uni_pc.model_wrapper(native, ns, model_type="x_start"), ns, variant="bh2"))
+            with torch.no_grad():
+                y = solver.sample(x, steps=6, order=2)
+            torch.cuda.synchronize()
+            if rnd == 0:
+                runs[(T, L)] = y.clone()
+            else:
+                assert torch.equal(y, runs[(T, L)]), (rnd, T, L)
+        if rnd == 0:
+            builds = m.hip_engine().plan_builds
+    assert builds == len(lengths) and m.hip_engine().plan_builds == builds     # rounds 2 and 3: cached schedules only
+    assert m.hip_engine().handover_status()[1] == 0
+
+
 def test_persistent_per_xcd_schedule_matches_per_launch():
     """DVITS_PERSIST=1 (csrc/persist.hip): the body of a forward as ONE launch with XCD-local barriers, utterance b on
     XCD b % 8.  Same kernels' tile routines (L1-bypassing loads), different tile menu: agreement with the per-launch
