@@ -168,6 +168,17 @@ def lifecycle_extras(dev, precision):
             ts.append(1e3 * (time.perf_counter() - t0))
     out["b1_T300_L150_unipc30_latency_ms"] = sorted(ts)[len(ts) // 2]
     out["b1_T300_mel_frames_per_s"] = 300.0 / (out["b1_T300_L150_unipc30_latency_ms"] * 1e-3)
+    # utterances of recurring lengths: schedules (engine LRU) and captured graphs (per-shape sampler plans) are reused
+    lat = {}
+    with torch.no_grad():
+        for rnd in range(2):
+            for T2, L2 in ((300, 150), (192, 60), (416, 200)):
+                xa, ca, ea, ma = (torch.from_numpy(a).to(dev) for a in synth.make_inputs(1, 80, T2, L2, seed=78))
+                native.cond, native.enc, native.mask = ca, ea, ma
+                torch.cuda.synchronize()
+                t0 = time.perf_counter(); solver.sample(xa, steps=30, order=2); torch.cuda.synchronize()
+                lat.setdefault("T%d" % T2, []).append(round(1e3 * (time.perf_counter() - t0), 2))
+    out["b1_unipc30_latency_ms_first_then_repeat"] = lat
     # GEMMs that finish their consumer's GroupNorm in the epilogue (in-launch hand-over); the flag must stay 0
     n_ho, bad = eng.handover_status()
     n_ho2, bad2 = e2.handover_status()
