@@ -255,7 +255,8 @@ hipError_t launch_attention(const AttnParams& p, hipStream_t st);
 // misc kernels (kernels_misc.hip)
 // (B,C,T) x | cond -> channels-last split planes [B*T, cpad] (zero padded)
 hipError_t launch_pack_input(const float* x, int cx, const float* cond, int cc, bf16_t* out_hi, bf16_t* out_lo, int cpad,
-                             int B, int T, hipStream_t st);
+                             int B, int T, hipStream_t st,
+                             unsigned long long* reset = nullptr, size_t reset_words = 0);   // (+ the GnxParams exchange words set to all ones)
 // fp32 [n] -> split planes
 hipError_t launch_split(const float* in, bf16_t* hi, bf16_t* lo, int64_t n, hipStream_t st);
 // GroupNorm (+temb scale/shift) (+SiLU) of the channel concat [a0 | a1] -> split planes [B*T, c0+c1].
@@ -317,9 +318,8 @@ hipError_t launch_small_linear(const float* in, int ldin, const float* W, const 
                                hipStream_t st);
 // the same on transposed weights Wt [K, N] (lane = output column; wide N, M <= 16), and the one-off transpose
 hipError_t launch_small_linear_t(const float* in, int ldin, const float* Wt, const float* b, const float* add, float* out,
-                                 int ldo, int M, int K, int N, int silu_in, int silu_out, hipStream_t st);
+                                 int ldo, int M, int K, int N, int silu_in, int silu_out, hipStream_t st, int add_rows = 0);   // add_rows > 0: `add` has that many rows, row r uses add[r % add_rows]
 hipError_t launch_transpose_f32(const float* src, float* dst, int R, int Cc, hipStream_t st);
-// (reset / reset_words: 8-byte words the kernel also sets to all ones - the GnxParams exchange buffers; even count)
 hipError_t launch_timestep_sincos(const float* t, float* out, int B, int dim, hipStream_t st, unsigned long long* reset = nullptr,
                                   size_t reset_words = 0);
 hipError_t launch_layernorm_rows(const float* x, const float* g, const float* b, float* out, int M, int C,

@@ -186,7 +186,20 @@ struct dv_unet {
   bool keep_intermediates = false;
   // per-call I/O (read by the ops when they are enqueued)
   struct { const float* x = nullptr; int cx = 0; const float* cond = nullptr; const float* t = nullptr; float* y = nullptr;
-           const float* enc = nullptr; const float* mask = nullptr; } io;
+           const float* enc = nullptr; const float* mask = nullptr;
+           const float* tp_base = nullptr; } io;   // tp_base: this evaluation's rows of the batched time_emb_proj table, or null
+  // Time-embedding chain of ALL evaluations of a sampler run in one pass (dv_unet_temb_all): the timesteps of a compiled
+  // loop are known up front, so sincos -> linear_1 -> linear_2 (+ pooled text) -> the 22 time_emb_proj GEMVs leave the
+  // per-step schedule (4 launches per step) for 5 launches per run.  Row r of every buffer = (evaluation r / B, item r % B).
+  struct TembCtx {
+    bool ok = false;
+    int begin = 0, end = 0;                  // step_ops [begin, end): the per-step chain, skipped when tp_base is set
+    int C0 = 0, E = 0, tt = 0;
+    const float* w1T = nullptr; const float* b1 = nullptr; const float* w2T = nullptr; const float* b2 = nullptr;
+    const float* WtT = nullptr; const float* bt = nullptr; const float* aug_emb = nullptr;
+    const float* tproj_arena = nullptr;      // the per-step table the schedule's operations point into
+    float* tsin = nullptr; float* h1 = nullptr; float* emb = nullptr; float* tproj_all = nullptr; int rows_cap = 0;
+  } temb;
   int64_t generation = 0;
 };
 
@@ -202,6 +215,9 @@ static void unet_release_prepared(dv_unet* u, bool keep_packed = false) {
   u->zero_page = nullptr;
   u->sk_tickets = nullptr;
   u->gnx_pool = nullptr; u->gnx_words = 0; u->gnx_ops = 0;
+  for (float* b : {u->temb.tsin, u->temb.h1, u->temb.emb, u->temb.tproj_all}) if (b) (void)hipFree(b);
+  u->temb = dv_unet::TembCtx{};
+  u->io.tp_base = nullptr;
   if (!keep_packed) unet_release_packed(u);
   if (u->slab) (void)hipFree(u->slab);
   u->slab = nullptr; u->slab_bytes = 0;
@@ -658,7 +674,14 @@ struct Builder {
       u->gemm_store.emplace_back(new GemmParams(g));
       const GemmParams* gp = u->gemm_store.back().get();
       cur_gp = gp;
-      emit(ops, [gp, p](hipStream_t st) { return launch_gemm(*gp, p, st); }, pok ? &po : nullptr);
+      dv_unet* uu = u;
+      emit(ops, [gp, p, uu](hipStream_t st) {
+        if (!uu->io.tp_base || !gp->gnx.xchg || !gp->gnx.tscale) return launch_gemm(*gp, p, st);
+        GemmParams g2 = *gp;                 // this evaluation's rows of the batched time_emb_proj table
+        g2.gnx.tscale = uu->io.tp_base + (gp->gnx.tscale - uu->temb.tproj_arena);
+        g2.gnx.tshift = uu->io.tp_base + (gp->gnx.tshift - uu->temb.tproj_arena);
+        return launch_gemm(g2, p, st);
+      }, pok ? &po : nullptr);
     }
     if (g.sk_buf) release((const void*)g.sk_buf);
   }
@@ -695,8 +718,14 @@ struct Builder {
       cur_kind = "gn_partial";
       emit(ops, [=](hipStream_t st) { return launch_gn_partial(a0.p, a0.C, a1.p, a1.C, part, Bn, Tn, G, nchunk, st); });
       cur_kind = "gn_finalize";
+      dv_unet* uu = u;
       emit(ops, [=](hipStream_t st) {
-        return launch_gn_finalize(part, nchunk, gamma, beta, tscale, tshift, ld_t, sc, sh, nullptr, nullptr, Bn, Tn, C, G, eps, st);
+        const float* ts = tscale; const float* tb = tshift;
+        if (uu->io.tp_base && ts) {          // this evaluation's rows of the batched time_emb_proj table
+          ts = uu->io.tp_base + (tscale - uu->temb.tproj_arena);
+          tb = uu->io.tp_base + (tshift - uu->temb.tproj_arena);
+        }
+        return launch_gn_finalize(part, nchunk, gamma, beta, ts, tb, ld_t, sc, sh, nullptr, nullptr, Bn, Tn, C, G, eps, st);
       });
       release(part);
       gp.scale_in = sc; gp.shift_in = sh;
@@ -717,7 +746,16 @@ struct Builder {
       po.gn_rpb = (Tn + po.gn_chunks - 1) / po.gn_chunks;
       po.gn_chunks = (Tn + po.gn_rpb - 1) / po.gn_rpb;
     }
-    emit(ops, [gp](hipStream_t st) { return launch_gn_apply(gp, st); }, (fast && !fast16) ? &po : nullptr);
+    {
+      dv_unet* uu = u;
+      emit(ops, [gp, uu](hipStream_t st) {
+        if (!uu->io.tp_base || !gp.tscale) return launch_gn_apply(gp, st);
+        GnApplyParams g2 = gp;               // this evaluation's rows of the batched time_emb_proj table
+        g2.tscale = uu->io.tp_base + (gp.tscale - uu->temb.tproj_arena);
+        g2.tshift = uu->io.tp_base + (gp.tshift - uu->temb.tproj_arena);
+        return launch_gn_apply(g2, st);
+      }, (fast && !fast16) ? &po : nullptr);
+    }
     if (sc) { release(sc); release(sh); }
     return out;
   }
@@ -1433,8 +1471,8 @@ struct Builder {
     {
       float* tsin = alloc((size_t)B * C0);
       float* h1 = alloc((size_t)B * E);
-      // (the forward's first kernel also resets the exchange words of the in-epilogue GroupNorms: GnxParams)
-      emit(S, [=](hipStream_t st) { return launch_timestep_sincos(uu->io.t, tsin, Bn, C0, st, uu->gnx_pool, uu->gnx_words); });
+      const int temb_begin = (int)S.size();
+      emit(S, [=](hipStream_t st) { return launch_timestep_sincos(uu->io.t, tsin, Bn, C0, st); });
       const float* w1 = W("time_embedding.linear_1.weight"); const float* b1 = W("time_embedding.linear_1.bias");
       const float* w2 = W("time_embedding.linear_2.weight"); const float* b2 = W("time_embedding.linear_2.bias");
       if (Bn <= 16) {   // lane-per-column kernel on transposed weights (built once): a quarter of the row-per-wave kernel's time
@@ -1448,6 +1486,7 @@ struct Builder {
         }
         emit(S, [=](hipStream_t st) { return launch_small_linear_t(tsin, C0, w1T, b1, nullptr, h1, E, Bn, C0, E, 0, 1, st); });
         emit(S, [=](hipStream_t st) { return launch_small_linear_t(h1, E, w2T, b2, aug_emb, emb, E, Bn, E, E, 0, 0, st); });
+        if (!dry) { u->temb.w1T = w1T; u->temb.w2T = w2T; u->temb.b1 = b1; u->temb.b2 = b2; u->temb.aug_emb = aug_emb; }
       } else {
         emit(S, [=](hipStream_t st) { return launch_small_linear(tsin, C0, w1, b1, nullptr, h1, E, Bn, C0, E, 0, 1, st); });
         emit(S, [=](hipStream_t st) { return launch_small_linear(h1, E, w2, b2, aug_emb, emb, E, Bn, E, E, 0, 0, st); });
@@ -1461,6 +1500,10 @@ struct Builder {
           (void)launch_transpose_f32(Wt, WtT, tt, E, pack_stream);
         }
         emit(S, [=](hipStream_t st) { return launch_small_linear_t(emb, E, WtT, bt, nullptr, tp, tt, Bn, E, tt, 1, 0, st); });
+        if (!dry && !arena.exact && !fuse_gn) {   // (B <= 16: the batched chain runs the same kernels on row chunks - identical bits per row)
+          u->temb.WtT = WtT; u->temb.bt = bt; u->temb.C0 = C0; u->temb.E = E; u->temb.tt = tt; u->temb.tproj_arena = tp;
+          u->temb.begin = temb_begin; u->temb.end = (int)S.size(); u->temb.ok = true;
+        }
       } else {
         emit(S, [=](hipStream_t st) { return launch_small_linear(emb, E, Wt, bt, nullptr, tp, tt, Bn, E, tt, 1, 0, st); });
       }
@@ -1470,7 +1513,8 @@ struct Builder {
     const int cin = c.in_channels, cpad = rup(cin, 32);
     Planes xin = alloc_planes((size_t)B * T * cpad);
     emit(S, [=](hipStream_t st) {
-      return launch_pack_input(uu->io.x, uu->io.cx, uu->io.cond, cin - uu->io.cx, xin.hi, xin.lo, cpad, Bn, Tn, st);
+      // (it precedes every GEMM of the forward: it also resets the exchange words of the in-epilogue GroupNorms, GnxParams)
+      return launch_pack_input(uu->io.x, uu->io.cx, uu->io.cond, cin - uu->io.cx, xin.hi, xin.lo, cpad, Bn, Tn, st, uu->gnx_pool, uu->gnx_words);
     });
     const PackedW* wci = pack("conv_in", C0, 3 * cpad, {{"conv_in.weight", 1, cin, 3, cpad, 0, 0, "", 0}},
                               {{"conv_in.bias", "", "", "", C0, 0, 0, 0}});
@@ -1976,14 +2020,51 @@ int dv_unet_health(const dv_unet* u) {
   return DV_OK;
 }
 
-// internal: enqueue one forward (used by dv_unet_forward and the sampler)
-int dv_unet_enqueue(dv_unet* u, const float* x, int cx, const float* cond, const float* t, float* y, hipStream_t st) {
+// internal (sampler): the time-embedding chain of n_evals evaluations (t_all [n_evals, B]) in one pass; returns 1 if this
+// schedule cannot batch it (then the per-step chain runs as usual), 0 when the table is enqueued, < 0 on error
+int dv_unet_temb_all(dv_unet* u, const float* t_all, int n_evals, hipStream_t st) {
+  if (!u->prepared || !u->cond_set) return dv_fail(DV_ERR_STATE, "dv_unet_temb_all before prepare / set_cond");
+  static const bool off = [] { const char* e = getenv("DVITS_TEMB_BATCH"); return e && e[0] == '0'; }();
+  dv_unet::TembCtx& c = u->temb;
+  if (off || !c.ok || n_evals < 1 || u->persist_on || u->keep_intermediates) return 1;
+  const int R = n_evals * u->B;
+  if (R > c.rows_cap) {
+    HIPCHK(hipDeviceSynchronize());
+    for (float* b : {c.tsin, c.h1, c.emb, c.tproj_all}) if (b) (void)hipFree(b);
+    c.tsin = c.h1 = c.emb = c.tproj_all = nullptr; c.rows_cap = 0;
+    HIPCHK(hipMalloc((void**)&c.tsin, (size_t)R * c.C0 * 4));
+    HIPCHK(hipMalloc((void**)&c.h1, (size_t)R * c.E * 4));
+    HIPCHK(hipMalloc((void**)&c.emb, (size_t)R * c.E * 4));
+    HIPCHK(hipMalloc((void**)&c.tproj_all, (size_t)R * c.tt * 4));
+    c.rows_cap = R;
+  }
+  HIPCHK(launch_timestep_sincos(t_all, c.tsin, R, c.C0, st));
+  HIPCHK(launch_small_linear_t(c.tsin, c.C0, c.w1T, c.b1, nullptr, c.h1, c.E, R, c.C0, c.E, 0, 1, st));
+  HIPCHK(launch_small_linear_t(c.h1, c.E, c.w2T, c.b2, c.aug_emb, c.emb, c.E, R, c.E, c.E, 0, 0, st, u->B));
+  HIPCHK(launch_small_linear_t(c.emb, c.E, c.WtT, c.bt, nullptr, c.tproj_all, c.tt, R, c.E, c.tt, 1, 0, st));
+  return 0;
+}
+
+// internal: enqueue one forward (used by dv_unet_forward and the sampler).  eval_idx >= 0: the time-embedding rows of
+// that evaluation were computed by dv_unet_temb_all - the per-step chain is skipped
+int dv_unet_enqueue(dv_unet* u, const float* x, int cx, const float* cond, const float* t, float* y, hipStream_t st, int eval_idx) {
   if (!u->prepared) return dv_fail(DV_ERR_STATE, "forward before dv_unet_prepare");
   if (int hrc = dv_unet_health(u)) return hrc;
+  const bool batched = eval_idx >= 0 && u->temb.ok && u->temb.tproj_all && !u->persist_on;
+  u->io.tp_base = batched ? u->temb.tproj_all + (size_t)eval_idx * u->B * u->temb.tt : nullptr;
+  struct TpReset { dv_unet* u; ~TpReset() { u->io.tp_base = nullptr; } } tp_reset{u};
   if (!u->cond_set) return dv_fail(DV_ERR_STATE, "forward before dv_unet_set_cond");
   if (cx <= 0 || cx > u->cfg.in_channels || (cx < u->cfg.in_channels && !cond))
     return dv_fail(DV_ERR_INVALID, "forward: cx=%d inconsistent with in_channels=%d / cond", cx, u->cfg.in_channels);
   u->io.x = x; u->io.cx = cx; u->io.cond = cond; u->io.t = t; u->io.y = y;
+  if (batched) {
+    for (int i = 0; i < (int)u->step_ops.size(); ++i) {
+      if (i >= u->temb.begin && i < u->temb.end) continue;
+      hipError_t e = u->step_ops[i](st);
+      if (e != hipSuccess) return dv_fail(DV_ERR_HIP, "forward: op %d failed to launch: %s", i, hipGetErrorString(e));
+    }
+    return DV_OK;
+  }
   if (!u->persist_on) return run_ops(u->step_ops, st, "forward");
   for (int i = 0; i < u->p_begin; ++i) {
     hipError_t e = u->step_ops[i](st);
@@ -2028,7 +2109,7 @@ extern "C" int dv_unet_persist_status(dv_unet* u, int32_t* n_ops, int32_t* error
 
 extern "C" int dv_unet_forward(dv_unet* u, const float* x, int32_t cx, const float* cond, const float* t, float* y, void* stream) {
   if (!u || !x || !t || !y) return dv_fail(DV_ERR_INVALID, "dv_unet_forward: null argument");
-  return dv_unet_enqueue(u, x, cx, cond, t, y, (hipStream_t)stream);
+  return dv_unet_enqueue(u, x, cx, cond, t, y, (hipStream_t)stream, -1);
 }
 
 extern "C" int dv_unet_forward_timed(dv_unet* u, const float* x, int32_t cx, const float* cond, const float* t, float* y,

@@ -17,7 +17,13 @@
 __global__ __launch_bounds__(256) void k_pack_input(const float* __restrict__ x, int cx,
                                                      const float* __restrict__ cond, int cc,
                                                      bf16_t* __restrict__ out_hi, bf16_t* __restrict__ out_lo,
-                                                     int cpad, int T) {
+                                                     int cpad, int T, unsigned long long* __restrict__ reset, size_t reset_words) {
+  // (this kernel precedes every GEMM of a forward: the exchange words of the in-epilogue GroupNorms - GnxParams - start EMPTY)
+  {
+    const size_t nthr = (size_t)gridDim.x * gridDim.y * gridDim.z * blockDim.x;
+    const size_t me = ((size_t)(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * blockDim.x + threadIdx.x;
+    for (size_t k = me * 2; k < reset_words; k += nthr * 2) *reinterpret_cast<ulonglong2*>(reset + k) = make_ulonglong2(~0ull, ~0ull);
+  }
   __shared__ float tile[32][33];
   const int b = blockIdx.z, c0 = blockIdx.y * 32, t0 = blockIdx.x * 32;
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // ty 0..7
@@ -46,9 +52,10 @@ __global__ __launch_bounds__(256) void k_pack_input(const float* __restrict__ x,
 }
 
 hipError_t launch_pack_input(const float* x, int cx, const float* cond, int cc, bf16_t* out_hi, bf16_t* out_lo, int cpad,
-                             int B, int T, hipStream_t st) {
+                             int B, int T, hipStream_t st, unsigned long long* reset, size_t reset_words) {
+  if (reset_words & 1) return hipErrorInvalidValue;
   dim3 grid((T + 31) / 32, (cpad + 31) / 32, B);
-  hipLaunchKernelGGL(k_pack_input, grid, dim3(256), 0, st, x, cx, cond, cc, out_hi, out_lo, cpad, T);
+  hipLaunchKernelGGL(k_pack_input, grid, dim3(256), 0, st, x, cx, cond, cc, out_hi, out_lo, cpad, T, reset, reset ? reset_words : (size_t)0);
   return hipGetLastError();
 }
 
@@ -517,13 +524,17 @@ template <int MR>
 __global__ __launch_bounds__(512) void k_small_linear_t(const float* __restrict__ in, int ldin, const float* __restrict__ Wt,
                                                          const float* __restrict__ bias, const float* __restrict__ add,
                                                          float* __restrict__ out, int ldo, int M, int K, int N, int silu_in,
-                                                         int silu_out) {
+                                                         int silu_out, int add_rows) {
   // workgroup = 64 output columns x 8 k-eighths (one wave each): 232 workgroups for N = 14848, 64 sequential
   // k-steps per lane with 16 weight loads in flight (the 30 MB table is streamed every step: bytes in flight per CU
   // are what sets the rate - four waves per workgroup reached 1.5 TB/s); the eight partial sums meet in LDS
   extern __shared__ float s_in[];        // [K][MR] activated input, row index fastest; then [8][64][MR] partials
   float* s_part = s_in + K * MR;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // blockIdx.y: chunk of MR rows (a batch of evaluations: every row's sum runs in the same order as in a one-chunk launch)
+  const int row0 = blockIdx.y * MR;
+  in += (size_t)row0 * ldin; out += (size_t)row0 * ldo;
+  M = min(MR, M - row0);
   for (int i = tid; i < K * MR; i += 512) {
     const int k = i / MR, m = i - k * MR;
     float xv = m < M ? in[(size_t)m * ldin + k] : 0.f;
@@ -557,7 +568,7 @@ __global__ __launch_bounds__(512) void k_small_linear_t(const float* __restrict_
       if (m < M) {
         v += bv;
         if (silu_out) v = v / (1.0f + __expf(-v));
-        if (add) v += add[(size_t)m * ldo + n];
+        if (add) v += add[(size_t)(add_rows > 0 ? (row0 + m) % add_rows : row0 + m) * ldo + n];
         out[(size_t)m * ldo + n] = v;
       }
     }
@@ -565,11 +576,12 @@ __global__ __launch_bounds__(512) void k_small_linear_t(const float* __restrict_
 }
 
 hipError_t launch_small_linear_t(const float* in, int ldin, const float* Wt, const float* b, const float* add, float* out,
-                                 int ldo, int M, int K, int N, int silu_in, int silu_out, hipStream_t st) {
-  if (M > 16 || ((size_t)K * 16 + 512 * 16) * sizeof(float) > 64 * 1024) return hipErrorInvalidValue;
-  const dim3 grid((N + 63) / 64);
-  if (M <= 8) hipLaunchKernelGGL(k_small_linear_t<8>, grid, dim3(512), ((size_t)K * 8 + 512 * 8) * 4, st, in, ldin, Wt, b, add, out, ldo, M, K, N, silu_in, silu_out);
-  else hipLaunchKernelGGL(k_small_linear_t<16>, grid, dim3(512), ((size_t)K * 16 + 512 * 16) * 4, st, in, ldin, Wt, b, add, out, ldo, M, K, N, silu_in, silu_out);
+                                 int ldo, int M, int K, int N, int silu_in, int silu_out, hipStream_t st, int add_rows) {
+  if (((size_t)K * 16 + 512 * 16) * sizeof(float) > 64 * 1024) return hipErrorInvalidValue;
+  // more than 16 rows (a batch of evaluations): chunks of 8 rows over blockIdx.y - per row the same arithmetic, bit for bit
+  const dim3 grid((N + 63) / 64, M > 16 ? (M + 7) / 8 : 1);
+  if (M <= 8 || M > 16) hipLaunchKernelGGL(k_small_linear_t<8>, grid, dim3(512), ((size_t)K * 8 + 512 * 8) * 4, st, in, ldin, Wt, b, add, out, ldo, M, K, N, silu_in, silu_out, add_rows);
+  else hipLaunchKernelGGL(k_small_linear_t<16>, grid, dim3(512), ((size_t)K * 16 + 512 * 16) * 4, st, in, ldin, Wt, b, add, out, ldo, M, K, N, silu_in, silu_out, add_rows);
   return hipGetLastError();
 }
 
@@ -603,9 +615,7 @@ hipError_t launch_small_linear(const float* in, int ldin, const float* W, const 
 __global__ void k_timestep_sincos(const float* __restrict__ t, float* __restrict__ out, int B, int dim,
                                   unsigned long long* __restrict__ reset, size_t reset_words) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  // first kernel of a forward: the exchange words of the in-epilogue GroupNorms (GnxParams) start EMPTY (all ones)
-  for (size_t k = (size_t)i * 2; k < reset_words; k += (size_t)gridDim.x * blockDim.x * 2)
-    *reinterpret_cast<ulonglong2*>(reset + k) = make_ulonglong2(~0ull, ~0ull);
+  (void)reset; (void)reset_words;
   const int half = dim >> 1;
   if (i >= B * half) return;
   const int b = i / half, j = i - b * half;
@@ -620,8 +630,7 @@ hipError_t launch_timestep_sincos(const float* t, float* out, int B, int dim, hi
                                   size_t reset_words) {
   const int n = B * (dim / 2);
   if (reset_words & 1) return hipErrorInvalidValue;
-  const size_t want = std::max<size_t>((n + 255) / 256, std::min<size_t>(256, (reset_words / 2 + 255) / 256));
-  hipLaunchKernelGGL(k_timestep_sincos, dim3((unsigned)want), dim3(256), 0, st, t, out, B, dim, reset, reset ? reset_words : 0);
+  hipLaunchKernelGGL(k_timestep_sincos, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, t, out, B, dim, reset, reset ? reset_words : 0);
   return hipGetLastError();
 }
 

@@ -25,7 +25,8 @@
 
 int dv_fail(int code, const char* fmt, ...);
 struct dv_unet;
-int dv_unet_enqueue(dv_unet* u, const float* x, int cx, const float* cond, const float* t, float* y, hipStream_t st);
+int dv_unet_enqueue(dv_unet* u, const float* x, int cx, const float* cond, const float* t, float* y, hipStream_t st, int eval_idx);
+int dv_unet_temb_all(dv_unet* u, const float* t_all, int n_evals, hipStream_t st);
 int dv_unet_dims(const dv_unet* u, int* B, int* T, int* cin, int* cout, int64_t* gen);
 int dv_unet_health(const dv_unet* u);
 
@@ -520,20 +521,32 @@ extern "C" int dv_sampler_run(dv_plan* p, dv_unet* u, float* x_inout, const floa
   int rc = plan_buffers(p, numel, B);
   if (rc != DV_OK) return rc;
   hipStream_t st = (hipStream_t)stream;
-  auto eval = [&](hipStream_t s) {
+  // the time-embedding chain of every evaluation runs once, at the head of the loop (the timesteps of the plan are known)
+  const int nfe = (int)p->t_input.size();
+  auto eval = [&](hipStream_t s, bool batched) {
     return [=](const float* src, int idx, float* dst) {
-      return dv_unet_enqueue(u, src, cout, cond, p->d_tin + (size_t)idx * B, dst, s);
+      return dv_unet_enqueue(u, src, cout, cond, p->d_tin + (size_t)idx * B, dst, s, batched ? idx : -1);
     };
   };
   const char* ng = getenv("DVITS_NO_GRAPH");
-  if (ng && ng[0] == '1') return run_events(p, x_inout, numel, eval(st), st);
+  if (ng && ng[0] == '1') {
+    const int tb = dv_unet_temb_all(u, p->d_tin, nfe, st);
+    if (tb < 0) return tb;
+    return run_events(p, x_inout, numel, eval(st, tb == 0), st);
+  }
 
   if (!(p->exec && p->key.u == u && p->key.gen == gen && p->key.x == x_inout && p->key.cond == cond)) {
     plan_drop_graph(p);
     if (!p->cap_stream) HIPCHK(hipStreamCreateWithFlags(&p->cap_stream, hipStreamNonBlocking));
     hipGraph_t graph = nullptr;
+    {   // (buffers of the batched chain are sized outside the capture)
+      const int tb0 = dv_unet_temb_all(u, p->d_tin, nfe, st);
+      if (tb0 < 0) return tb0;
+      HIPCHK(hipStreamSynchronize(st));
+    }
     HIPCHK(hipStreamBeginCapture(p->cap_stream, hipStreamCaptureModeThreadLocal));
-    rc = run_events(p, x_inout, numel, eval(p->cap_stream), p->cap_stream);
+    const int tb = dv_unet_temb_all(u, p->d_tin, nfe, p->cap_stream);
+    rc = tb < 0 ? tb : run_events(p, x_inout, numel, eval(p->cap_stream, tb == 0), p->cap_stream);
     hipError_t ce = hipStreamEndCapture(p->cap_stream, &graph);
     if (rc != DV_OK) { if (graph) (void)hipGraphDestroy(graph); return rc; }
     if (ce != hipSuccess) return dv_fail(DV_ERR_HIP, "hipStreamEndCapture failed: %s", hipGetErrorString(ce));

@@ -697,6 +697,21 @@ def test_schedules_and_graphs_are_kept_per_utterance_length():
     assert m.hip_engine().handover_status()[1] == 0
 
 
+def test_batched_time_embedding_chain_is_bit_identical():
+    """Inside the native sampler loop the time-embedding chain (sincos -> linear_1 -> linear_2 + pooled text -> the 22
+    time_emb_proj GEMVs) of ALL evaluations runs once at the head of the graph (dv_unet_temb_all: the timesteps of a
+    compiled loop are known) instead of 4 launches per step; every consumer (k_gn_apply, k_gn_finalize, the in-epilogue
+    GroupNorm) reads its evaluation's rows.  Same kernels on row chunks: the samples are bit-identical to the per-step
+    chain (a child process with DVITS_TEMB_BATCH=0), for row counts on both sides of the kernels' chunking."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "temb_check.py")], capture_output=True, text=True, timeout=900, cwd=root)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("B=")]
+    assert r.returncode == 0 and len(lines) >= 6, r.stdout[-2000:] + r.stderr[-2000:]
+    assert all("equal=True" in ln for ln in lines), lines
+
+
 def test_persistent_per_xcd_schedule_matches_per_launch():
     """DVITS_PERSIST=1 (csrc/persist.hip): the body of a forward as ONE launch with XCD-local barriers, utterance b on
     XCD b % 8.  Same kernels' tile routines (L1-bypassing loads), different tile menu: agreement with the per-launch
