@@ -356,7 +356,10 @@ def main():
             "avg_op_us_event_pair_per_operation": 1e3 * g[2] / g[0], "achieved_event_pair_per_launch": achieved_evpair,
             "per_kind_ms_per_forward": {k: v[2] / reps for k, v in agg.items()},
             "per_kind_operations": {k: v[0] // reps for k, v in agg.items()},   # a split-K GEMM pair is one operation
-            "forward": {"launches": n_launch, "algorithmic_gflop": flops_model(B, T, L) / 1e9,
+            "forward": {"launches": n_launch,
+                        # inside the sampler graph the time-embedding chain (4 launches) runs once per run, not per step
+                        "launches_inside_sampler_loop": n_launch - (4 if (B <= 16 and os.environ.get("DVITS_TEMB_BATCH") != "0") else 0),
+                        "algorithmic_gflop": flops_model(B, T, L) / 1e9,
                         "engine_counted_gflop": flops_fwd / 1e9, "ms_in_graph": fwd_ms,
                         "tflops": flops_model(B, T, L) / (fwd_ms * 1e-3) / 1e12,
                         "frac_of_peak": flops_model(B, T, L) / (fwd_ms * 1e-3) / 1e12 / peak},
