@@ -223,6 +223,9 @@ def main():
     model, sd = build_model(dev, args.precision)
     replicas = [model] + [build_model(dev, args.precision)[0] for _ in range(NS - 1)]
     streams = [torch.cuda.Stream(device=dev) for _ in range(NS)] if NS > 1 else [None]
+    if NS > 1:      # engines driven side by side on one device: no in-launch GroupNorm hand-over (dv_unet_set_exclusive)
+        for r in replicas:
+            r.hip_engine(args.precision).set_exclusive(False)
 
     # synthetic inputs: this rank's noise/content shard is generated locally (zero traffic); the
     # conditioning of the whole job lives on rank 0 and is broadcast over RCCL before every run

@@ -165,6 +165,7 @@ struct dv_unet {
   size_t gnx_words = 0;                      // words in use by the prepared schedule
   unsigned* gnx_status = nullptr;
   int gnx_ops = 0;
+  bool exclusive = true;                     // false: other streams may run kernels beside this handle's (no in-launch waits)
   std::vector<OpFn> step_ops, cond_ops;
   // GEMM launch parameters live here (stable addresses): the prepare-time tuner rewrites their tile choice in place
   std::vector<std::unique_ptr<GemmParams>> gemm_store;
@@ -595,7 +596,7 @@ struct Builder {
   int n_cu = [] { int d = 0, n = 0; if (hipGetDevice(&d) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, d) != hipSuccess) n = 0; return n; }();
   bool gnx_setup(GemmParams& g, const std::string& pre, float eps, const float* tscale, const float* tshift, int ld_t, bool silu,
                  Planes* y) {
-    if (!gnx_on || arena.exact || autotune_on() || !g.stats16 || n_cu <= 0) return false;
+    if (!gnx_on || !u->exclusive || arena.exact || autotune_on() || !g.stats16 || n_cu <= 0) return false;
     GemmParams t = g;
     t.B = B;
     t.gnx = GnxParams{};
@@ -1999,6 +2000,12 @@ extern "C" int dv_unet_set_cond(dv_unet* u, const float* enc, const float* mask_
 // In-kernel hand-over health (GnxParams): *n_ops = GEMMs of the schedule that finish their consumer's GroupNorm in the
 // epilogue; *timed_out = 1 if any such launch since prepare gave up waiting (its results are invalid).  No device
 // synchronisation: the flag lives in host memory the kernels write through; complete after the stream has drained.
+extern "C" int dv_unet_set_exclusive(dv_unet* u, int32_t exclusive) {
+  if (!u) return dv_fail(DV_ERR_INVALID, "dv_unet_set_exclusive: null handle");
+  if (u->exclusive != (exclusive != 0)) { u->exclusive = exclusive != 0; u->prepared = false; }   // takes effect at the next prepare
+  return DV_OK;
+}
+
 extern "C" int dv_unet_handover_status(dv_unet* u, int32_t* n_ops, int32_t* timed_out) {
   if (!u || !u->prepared) return dv_fail(DV_ERR_STATE, "dv_unet_handover_status before prepare");
   if (n_ops) *n_ops = u->gnx_ops;

@@ -62,7 +62,21 @@ class UNetEngine:
     def _new_slot(self):
         h = C.c_void_p()
         _lib.check(_lib.lib().dv_unet_create(C.byref(self._cfg), C.byref(h)), "dv_unet_create")
+        if not getattr(self, "_exclusive", True):
+            _lib.check(_lib.lib().dv_unet_set_exclusive(h, 0), "dv_unet_set_exclusive")
         return UNetEngine._Slot(h)
+
+    def set_exclusive(self, exclusive):
+        """exclusive=False: this engine's kernels may run beside kernels of other streams (e.g. several engines driven
+        concurrently on one device) - the in-launch GroupNorm hand-over, which needs every workgroup of a launch resident
+        at once, is then not used (see dv_unet_set_exclusive).  Takes effect at the next prepare."""
+        self._exclusive = bool(exclusive)
+        slots = {id(sl): sl for sl in list(self._plans.values()) + [self._cur]}
+        for sl in slots.values():
+            _lib.check(_lib.lib().dv_unet_set_exclusive(sl.h, int(self._exclusive)), "dv_unet_set_exclusive")
+            sl.prepared = None
+        self._plans.clear()
+        self._fwd_cond = None
 
     # the current schedule's native handle / key (read by the samplers, the bench and the tests)
     @property

@@ -145,6 +145,12 @@ int dv_unet_persist_status(dv_unet* u, int32_t* n_ops, int32_t* error_flag);
  * results of that launch are invalid and every later dv_unet_forward / dv_sampler_run on this handle fails with
  * DV_ERR_HIP.  Does not synchronise: meaningful once the stream has drained. */
 int dv_unet_handover_status(dv_unet* u, int32_t* n_ops, int32_t* timed_out);
+/* The in-launch waits above assume that the launch has the device to itself (every workgroup resident at once): true
+ * for one stream, or for several streams that never run kernels of such handles side by side.  A host that drives
+ * several handles CONCURRENTLY on different streams of one device must call this with exclusive = 0 before
+ * dv_unet_prepare (GroupNorm then runs as separate launches on that handle); two such GEMMs sharing the CUs could wait
+ * for each other's queued workgroups - the bounded wait turns that into DV_ERR_HIP, not a hang, but the run is lost. */
+int dv_unet_set_exclusive(dv_unet* u, int32_t exclusive);
 /* Profiling aid: s_memtime stamps taken by one workgroup of XCD 0 after every operation of the last persistent launch;
  * returns the number of stamps written (operations + 1) or a negative error; *first_op = schedule index of the first
  * operation inside the launch (pairs with dv_unet_op_info). */

@@ -697,6 +697,40 @@ def test_schedules_and_graphs_are_kept_per_utterance_length():
     assert m.hip_engine().handover_status()[1] == 0
 
 
+def test_non_exclusive_engines_run_side_by_side_on_two_streams():
+    """Two engines driven concurrently on two streams of one device: with set_exclusive(False) their schedules hold no
+    in-launch wait (the hand-over needs every workgroup of a launch resident - two such GEMMs sharing the CUs could wait
+    for each other's queued workgroups), the results equal the single-stream ones and nothing times out."""
+    from diff_vits_amd.unet1d.unet_1d_condition import UNet1DConditionModel
+    kw, sd, sample, t, enc, mask = unet_case("cfg1")
+    args = (torch.from_numpy(sample).cuda(), torch.from_numpy(t).cuda(), torch.from_numpy(enc).cuda())
+    dm = torch.from_numpy(mask).cuda()
+    models = []
+    for _ in range(2):
+        m = UNet1DConditionModel(backend="hip", **kw).eval()
+        m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+        m = m.cuda()
+        m.hip_engine().set_exclusive(False)
+        models.append(m)
+    streams = [torch.cuda.Stream() for _ in models]
+    outs = []
+    with torch.no_grad():
+        ref = models[0](*args, encoder_attention_mask=dm).sample.clone()
+        torch.cuda.synchronize()
+        for rnd in range(5):
+            ys = []
+            for m, st in zip(models, streams):
+                with torch.cuda.stream(st):
+                    ys.append(m(*args, encoder_attention_mask=dm).sample)
+            torch.cuda.synchronize()
+            outs.append(ys)
+    for ys in outs:
+        for y in ys:
+            assert torch.equal(y, ref)
+    for m in models:
+        assert m.hip_engine().handover_status() == (0, 0)
+
+
 def test_batched_time_embedding_chain_is_bit_identical():
     """Inside the native sampler loop the time-embedding chain (sincos -> linear_1 -> linear_2 + pooled text -> the 22
     time_emb_proj GEMVs) of ALL evaluations runs once at the head of the graph (dv_unet_temb_all: the timesteps of a
