@@ -28,7 +28,7 @@ if __name__ == "__main__":
         B, steps = int(sys.argv[2]), int(sys.argv[3])
         np.save(sys.argv[4], run(B, steps))
         sys.exit(0)
-    for B, steps in ((2, 8), (2, 10), (1, 16), (8, 2), (3, 5), (16, 1)):
+    for B, steps in ((2, 8), (2, 10), (1, 16), (8, 2), (3, 5), (16, 2)):
         a = run(B, steps)
         f = "/tmp/temb_ref_%d_%d.npy" % (B, steps)
         subprocess.run([sys.executable, __file__, "child", str(B), str(steps), f], env=dict(os.environ, DVITS_TEMB_BATCH="0"), check=True)
