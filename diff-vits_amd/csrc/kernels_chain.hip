@@ -29,7 +29,18 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 #ifdef DV_GEMM_TRACE
 // development build only (make trace): per-workgroup s_memtime stamps of the chain kernel's phases (tools/chain_trace.py)
 __device__ unsigned long long g_chain_trace[8192 * 16];
-#define DV_CTRACE(i) do { if (threadIdx.x == 0 && blockIdx.x < 8192) g_chain_trace[blockIdx.x * 16 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+// which launches stamp: C (0 = any), amode (-1 = any), with the cross attention inside (-1 = any) - set by the tool
+__device__ int g_chain_sel[3] = {0, -1, -1};
+#define DV_CTRACE(i) do { if (threadIdx.x == 0 && blockIdx.x < 8192 && (g_chain_sel[0] == 0 || g_chain_sel[0] == p.C) && \
+    (g_chain_sel[1] < 0 || g_chain_sel[1] == p.amode) && (g_chain_sel[2] < 0 || g_chain_sel[2] == (p.xa_kf_hi != nullptr))) \
+    g_chain_trace[blockIdx.x * 16 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+extern "C" int dv_debug_chain_trace_select(int C, int amode, int xa) {
+  const int h[3] = {C, amode, xa};
+  hipError_t e = hipMemcpyToSymbol(HIP_SYMBOL(g_chain_sel), h, sizeof(h));
+  void* d = nullptr;
+  if (e == hipSuccess) e = hipGetSymbolAddress(&d, HIP_SYMBOL(g_chain_trace));
+  return (int)(e != hipSuccess ? e : hipMemset(d, 0, sizeof(g_chain_trace)));
+}
 extern "C" int dv_debug_chain_trace(unsigned long long* host, int n_wg) {
   return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_chain_trace), (size_t)n_wg * 16 * sizeof(unsigned long long));
 }

@@ -19,6 +19,8 @@ import bench  # noqa: E402
 from diff_vits_amd import synth  # noqa: E402
 
 B, T = int(sys.argv[1]) if len(sys.argv) > 1 else 8, int(sys.argv[2]) if len(sys.argv) > 2 else 1024
+# optional selection: C amode xa  (e.g. 384 1 0 = the norm+proj_in+LN+q|k|v chain of the 384-channel level)
+SEL = [int(v) for v in sys.argv[3:6]] if len(sys.argv) >= 6 else None
 dev = torch.device("cuda", 0)
 model, _ = bench.build_model(dev, "bf16x3")
 x, cond, enc, mask = (torch.from_numpy(v).to(dev) for v in synth.make_inputs(B, 80, T, 256))
@@ -26,6 +28,10 @@ eng = model.hip_engine()
 eng.prepare(B, T, 256)
 eng.set_cond(enc, None)
 t = torch.full((B,), 500.0, device=dev)
+if SEL:
+    lib.dv_debug_chain_trace_select.restype = C.c_int
+    lib.dv_debug_chain_trace_select.argtypes = [C.c_int, C.c_int, C.c_int]
+    assert lib.dv_debug_chain_trace_select(*SEL) == 0
 for _ in range(3):
     eng.eval(x, cond, t)
 torch.cuda.synchronize()
@@ -39,7 +45,7 @@ live = tt[:, 9] > 0
 tt = tt[live]
 names = ["args+setup -> A requested", "A operand complete (barrier)", "stage-1 k-loop", "hand-over (2 barriers)", "epilogue 1 + LN rows",
          "stage-2 k-loop (pass 0)", "hand-over", "epilogue 2 (pass 0)", "rest"]
-print("last chain launch of the forward: %d workgroups" % int(live.sum()))
+print("%s chain launch of the forward: %d workgroups" % ("last selected (C=%d amode=%d xa=%d)" % tuple(SEL) if SEL else "last", int(live.sum())))
 for i, nm in enumerate(names):
     d = tt[:, i + 1] - tt[:, i]
     print("   %-32s median %6d cyc  p90 %6d" % (nm, np.median(d), np.percentile(d, 90)))
