@@ -939,7 +939,8 @@ hipError_t init_one() {
 template <int NS, int AMODE, bool XA = false, bool SA = false, bool CS = false>
 hipError_t launch_one(const ChainParams& p, hipStream_t st) {
   const int smem = 2 * 2 * NS * CHUNK_PL + NS * 16384;
-  hipLaunchKernelGGL((k_chain2<NS, AMODE, XA, SA, CS>), dim3((p.M / BM) * ((((AMODE == 1 && !XA) || CS) && p.nsplit > 1) ? p.nsplit : 1)), dim3((XA || (SA && NS >= 3)) ? NT : NT_LAUNCH), smem, st, p);
+  static const bool no_pf = [] { const char* e = getenv("DVITS_CHAIN_PF"); return e && e[0] == '0'; }();   // experiment knob: no L2-prefetch wave
+  hipLaunchKernelGGL((k_chain2<NS, AMODE, XA, SA, CS>), dim3((p.M / BM) * ((((AMODE == 1 && !XA) || CS) && p.nsplit > 1) ? p.nsplit : 1)), dim3((XA || (SA && NS >= 3) || no_pf) ? NT : NT_LAUNCH), smem, st, p);
   return hipGetLastError();
 }
 
