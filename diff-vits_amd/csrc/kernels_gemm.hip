@@ -182,7 +182,7 @@ template <int BK> struct Tiles {
       if (cnt(64, 64) >= min_wg) return T2G::launch(p, x3, st);
       return T4G::launch(p, x3, st);
     }
-    static const int t1_min = [] { const char* e = getenv("DVITS_GEMM_T1"); return e ? atoi(e) : (1 << 30); }();   // experiment knob
+    static const int t1_min = [] { const char* e = getenv("DVITS_GEMM_T1"); return e ? atoi(e) : 256; }();   // 128x64 tiles from 256 of them (>= 512 64x64 tiles: two rounds otherwise) - B >= 16 shapes
     if (BK == 64 && cnt(128, 64) >= t1_min) return T1::launch(p, x3, st);
     if (cnt(64, 64) >= min_wg) return ksplit ? T2::launch(p, x3, st) : T2S::launch(p, x3, st);
     if (cnt(64, 32) >= min_wg) return T3::launch(p, x3, st);
@@ -306,7 +306,7 @@ static void gemm_pick_tile(const GemmParams& p, int& bm, int& bn) {
     if (cnt(64, 64) >= min_wg) { bm = 64; bn = 64; return; }
     bm = 32; bn = 64; return;
   }
-  static const int t1_min = [] { const char* e = getenv("DVITS_GEMM_T1"); return e ? atoi(e) : (1 << 30); }();
+  static const int t1_min = [] { const char* e = getenv("DVITS_GEMM_T1"); return e ? atoi(e) : 256; }();
   if (k64 && cnt(128, 64) >= t1_min) { bm = 128; bn = 64; return; }
   if (cnt(64, 64) >= min_wg) { bm = 64; bn = 64; return; }
   if (cnt(64, 32) >= min_wg) { bm = 64; bn = 32; return; }
