@@ -490,6 +490,7 @@ __global__ __launch_bounds__((XA || (SA && NS >= 3)) ? NT : NT_LAUNCH) void k_ch
     const bf16x8* vfl = reinterpret_cast<const bf16x8*>(p.xa_vf_lo) + bh * nT * 2 * NBv * 64 + lane;
     const float* bias = p.xa_bias + (size_t)b_item * nT * 32 + 4 * lh;
     __syncthreads();                               // every wave holds its query fragments: the A region may be rewritten
+    DV_CTRACE(10);
     // K / V fragments and the key bias of tile t + 1 are requested before tile t is multiplied (pinned like the weight
     // prefetch: the loads have no consumer in the current iteration and would otherwise sink to their use)
     struct KVT { bf16x8 kh[KSq], kl[KSq], vh[2][NBv], vl[2][NBv]; float4 bv[4]; };
@@ -585,14 +586,18 @@ __global__ __launch_bounds__((XA || (SA && NS >= 3)) ? NT : NT_LAUNCH) void k_ch
           }
         }
     }
+    DV_CTRACE(11);
     __syncthreads();                               // attention output complete = A operand of stage 3
+    DV_CTRACE(12);
     // ================= stage 3: x3 = O W3^T + b3 + x1 -> fp32, raw planes and LayerNorm row partials in global =================
 #pragma unroll
     for (int ns = 0; ns < NS; ++ns)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[ns][r] = 0.f;
     stage_loop(p.w3_hi, p.w3_lo, 0, bq, acc, std::false_type{}, std::integral_constant<int, NS>{});
+    DV_CTRACE(13);
     kgroup_reduce(acc, red_reg);
+    DV_CTRACE(14);
     if (kg == 0) {
       const int m = m0 + l31;
 #pragma unroll

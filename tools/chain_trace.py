@@ -50,3 +50,9 @@ for i, nm in enumerate(names):
     d = tt[:, i + 1] - tt[:, i]
     print("   %-32s median %6d cyc  p90 %6d" % (nm, np.median(d), np.percentile(d, 90)))
 print("   %-32s median %6d cyc" % ("whole workgroup", np.median(tt[:, 9] - tt[:, 0])))
+if (tt[:, 10] > 0).all():       # the cross-attention tail stamps its own phases (thread 0 = head 0)
+    xs = [("stage-2 epilogue -> queries in registers", 8, 10), ("cross attention (head 0)", 10, 11), ("wait for the other heads", 11, 12),
+          ("stage-3 k-loop", 12, 13), ("hand-over", 13, 14), ("epilogue 3 (+ residual, planes, LN partials)", 14, 9)]
+    for nm, a, b in xs:
+        d = tt[:, b] - tt[:, a]
+        print("   %-44s median %6d cyc  p90 %6d" % (nm, np.median(d), np.percentile(d, 90)))
