@@ -21,7 +21,10 @@ sys.path.insert(0, ROOT)
 def spawn_ranks(n):
     """`python bench.py --gpus N` without a launcher: start N rank processes of this script (one per GPU, RCCL
     rendezvous on 127.0.0.1) and exit with the worst of their codes.  Runs before torch / the HIP library are imported,
-    so the parent never touches a GPU; the children are fresh processes, not re-execs of an initialised one."""
+    so the parent never touches a GPU; the children are fresh processes, not re-execs of an initialised one.
+    The children are polled: as soon as one exits non-zero the siblings are terminated (they would otherwise sit in
+    `init_process_group` / a collective until the RCCL time-out), so a rank failure returns within seconds."""
+    import signal
     import socket
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -33,9 +36,46 @@ def spawn_ranks(n):
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), DVITS_BENCH_SPAWNED="1")
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+
+    def stop_all(sig=signal.SIGTERM):
+        for q in procs:
+            if q.poll() is None:
+                try:
+                    q.send_signal(sig)
+                except OSError:
+                    pass
+
     rc = 0
-    for p in procs:
-        rc = max(rc, abs(p.wait()))
+    deadline = time.time() + float(os.environ.get("DVITS_BENCH_JOB_TIMEOUT_S", "3600"))
+    try:
+        live = list(procs)
+        while live:
+            for q in list(live):
+                code = q.poll()
+                if code is None:
+                    continue
+                live.remove(q)
+                if code != 0:
+                    rc = max(rc, abs(code) or 1)
+            if rc != 0 and live:                       # a rank died: do not wait for the others' collective time-outs
+                sys.stderr.write("bench: a rank exited with code %d - stopping the other %d rank(s)\n" % (rc, len(live)))
+                stop_all()
+                t_kill = time.time() + 10.0
+                while any(q.poll() is None for q in live) and time.time() < t_kill:
+                    time.sleep(0.1)
+                stop_all(signal.SIGKILL)
+                for q in live:
+                    q.wait()
+                break
+            if time.time() > deadline:
+                sys.stderr.write("bench: job time-out - stopping all ranks\n")
+                stop_all(signal.SIGKILL)
+                rc = max(rc, 124)
+                break
+            time.sleep(0.05)
+    except KeyboardInterrupt:
+        stop_all(signal.SIGKILL)
+        rc = 130
     sys.exit(rc)
 
 
@@ -63,6 +103,13 @@ UNET_KW = dict(in_channels=208, out_channels=80, block_out_channels=(128, 256, 3
                cross_attention_dim=128, attention_head_dim=8, addition_embed_type="text",
                resnet_time_scale_shift="scale_shift")
 PEAK_TFLOPS = {"bf16x3": 2500.0 / 3.0, "bf16": 2500.0}     # dense bf16 MFMA peak (MI355X_MICROARCH.md); x3 = 3 products
+PARITY_T = 500.0          # timestep of the forward whose output is compared with the oracle's in the bench line
+PARITY_TOL = 1e-3         # BASELINE.json north_star: UNet output <= 1e-3 relative error
+# --dry-run-cpu: the rank path of this script (spawn -> env -> init_process_group -> shard.sharded_sample -> MAX-reduce ->
+# rank-0 JSON) without a GPU: gloo, the package's explicit torch backend, a tiny denoiser configuration
+DRY_KW = dict(in_channels=24, out_channels=8, block_out_channels=(32, 64, 96, 128), norm_num_groups=8,
+              cross_attention_dim=32, attention_head_dim=8, addition_embed_type="text",
+              resnet_time_scale_shift="scale_shift", addition_embed_type_num_heads=8)
 
 
 def flops_model(B, T, L):
@@ -70,15 +117,28 @@ def flops_model(B, T, L):
     return B * (31.67e6 * T + 4349.0 * T * T + 7286.0 * T * L + 2.23e6 * L + 0.04e9)
 
 
-def build_model(device, precision):
+def build_model(device, precision, dry=False):
+    kw = DRY_KW if dry else UNET_KW
     with torch.device("meta"):
-        shapes = {k: tuple(v.shape) for k, v in UNet1DConditionModel(**UNET_KW).state_dict().items()}
+        shapes = {k: tuple(v.shape) for k, v in UNet1DConditionModel(**kw).state_dict().items()}
     sd = {k: torch.from_numpy(v) for k, v in synth.make_state_dict(shapes, seed=1234).items()}
-    m = UNet1DConditionModel(backend="hip", **UNET_KW).eval()
+    m = UNet1DConditionModel(backend="torch" if dry else "hip", **kw).eval()
     m.load_state_dict(sd)
     m = m.to(device)
-    m.hip_engine(precision)
+    if not dry:
+        m.hip_engine(precision)
     return m, sd
+
+
+def enc_dim_of(dry):
+    return DRY_KW["cross_attention_dim"] if dry else UNET_KW["cross_attention_dim"]
+
+
+def pmc_identity_ok(pj):
+    """The committed PMC figures belong to ONE build of the kernels: tools/pmc_roofline.py stamps them with the library's
+    dv_version() (which carries a hash of csrc/).  They are reported only while that still is the loaded library."""
+    from diff_vits_amd import _lib
+    return isinstance(pj, dict) and pj.get("build", {}).get("dv_version") == _lib.lib().dv_version().decode()
 
 
 def cpu_baseline(sd, B, T, L, solver_steps, sample_steps=2):
@@ -96,15 +156,16 @@ def cpu_baseline(sd, B, T, L, solver_steps, sample_steps=2):
     avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     # ascending; "all" only on hosts with <= 64 CPUs (one forward on 256 threads of a 256-CPU box took 134 s in round 2:
     # oversubscribed intra-op pools), and the sweep stops as soon as a count is clearly past the optimum
-    counts = sorted({min(c, avail) for c in (8, 16, 32, 64)} | ({avail} if avail <= 64 else set()))
-    t_in = torch.full((B,), 500.0)
+    counts = sorted({min(c, avail) for c in (8, 16, 24, 32, 48, 64)} | ({avail} if avail <= 64 else set()))
+    t_in = torch.full((B,), PARITY_T)
     t_all0 = time.perf_counter()
     sweep = {}
+    y_ref = None
     with torch.no_grad():
         for c in counts:
             torch.set_num_threads(c)
             t0 = time.perf_counter()
-            model(x, t_in)                                          # warm-up (thread pool, allocator, oneDNN primitives)
+            y_ref = model(x, t_in)                                  # warm-up (thread pool, allocator, oneDNN primitives)
             warm = time.perf_counter() - t0
             if sweep and warm > 4.0 * min(sweep.values()):          # far past the optimum: do not spend the budget here
                 sweep[c] = warm
@@ -115,8 +176,10 @@ def cpu_baseline(sd, B, T, L, solver_steps, sample_steps=2):
                 model(x, t_in)
                 ts.append(time.perf_counter() - t0)
             sweep[c] = statistics.median(ts)
-            if sweep[c] > 1.3 * min(sweep.values()) or time.perf_counter() - t_all0 > 30.0:
-                break                                               # past the optimum / bounded
+            # past the optimum (two counts in a row slower than the best so far) / bounded
+            worse = [k for k in sweep if sweep[k] > 1.3 * min(sweep.values())]
+            if len(worse) >= 2 or time.perf_counter() - t_all0 > 40.0:
+                break
         best = min(sweep, key=sweep.get)
         torch.set_num_threads(best)
         runs = []
@@ -133,7 +196,7 @@ def cpu_baseline(sd, B, T, L, solver_steps, sample_steps=2):
                       "threads (best of the sweep; %d CPUs in the affinity mask), scaled x%.1f"
                       % (len(runs), sample_steps, solver_steps, B, T, L, best, avail, solver_steps / sample_steps),
             "seconds_sampled": time.perf_counter() - t_all0,
-            "thread_sweep_forward_s": {str(k): round(v, 4) for k, v in sweep.items()}}
+            "thread_sweep_forward_s": {str(k): round(v, 4) for k, v in sweep.items()}}, y_ref
 
 
 def lifecycle_extras(dev, precision):
@@ -200,7 +263,19 @@ def main():
                     help="split the per-GPU batch into this many concurrent sub-batches (own engine + HIP stream each)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--dry-run-cpu", action="store_true",
+                    help="GPU-less rehearsal of the multi-rank path: gloo, torch backend, tiny configuration (tests)")
+    ap.add_argument("--dist-timeout", type=float, default=float(os.environ.get("DVITS_DIST_TIMEOUT_S", "180")),
+                    help="seconds a rank waits in the rendezvous / a collective before it gives up")
     args = ap.parse_args()
+    dry = args.dry_run_cpu
+    if dry:      # small enough for 8 ranks on a few CPU cores; explicit flags still win
+        defaults = {"batch": 2, "frames": 24, "prompt": 10, "solver_steps": 4}
+        for k, v in defaults.items():
+            if getattr(args, k) == ap.get_default(k):
+                setattr(args, k, v)
+        args.no_roofline = args.no_cpu_baseline = True
+        torch.set_num_threads(1)
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -208,19 +283,31 @@ def main():
     if world != args.gpus:
         raise SystemExit("--gpus %d does not match WORLD_SIZE %d (run `python bench.py --gpus N`, which starts the N "
                          "ranks itself, or torchrun --nproc-per-node N bench.py --gpus N)" % (args.gpus, world))
-    if torch.cuda.device_count() < world:
+    if not dry and torch.cuda.device_count() < world:
         raise SystemExit("--gpus %d: only %d GPU(s) visible" % (world, torch.cuda.device_count()))
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    if os.environ.get("DVITS_BENCH_FAIL_RANK") == str(rank):     # fault injection for the sibling-kill test
+        raise SystemExit("bench: injected failure on rank %d" % rank)
+    if dry:
+        dev = torch.device("cpu")
+    else:
+        torch.cuda.set_device(local_rank)
+        dev = torch.device("cuda", local_rank)
     if world > 1:
+        import datetime
         import torch.distributed as dist
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        tmo = datetime.timedelta(seconds=args.dist_timeout)
+        if dry:
+            dist.init_process_group("gloo", rank=rank, world_size=world, timeout=tmo)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev, timeout=tmo)
 
     B, T, L, S = args.batch, args.frames, args.prompt, args.solver_steps
     NS = max(1, args.streams)
     if B % NS != 0:
         raise SystemExit("--batch must be divisible by --streams")
-    model, sd = build_model(dev, args.precision)
+    if dry and NS != 1:
+        raise SystemExit("--dry-run-cpu runs one sub-batch per rank")
+    model, sd = build_model(dev, args.precision, dry)
     replicas = [model] + [build_model(dev, args.precision)[0] for _ in range(NS - 1)]
     streams = [torch.cuda.Stream(device=dev) for _ in range(NS)] if NS > 1 else [None]
     if NS > 1:      # engines driven side by side on one device: no in-launch GroupNorm hand-over (dv_unet_set_exclusive)
@@ -229,15 +316,17 @@ def main():
 
     # synthetic inputs: this rank's noise/content shard is generated locally (zero traffic); the
     # conditioning of the whole job lives on rank 0 and is broadcast over RCCL before every run
-    x_np, cond_np, _, _ = synth.make_inputs(B, 80, T, L, seed=1234 + rank)
+    CM = DRY_KW["out_channels"] if dry else 80       # mel channels
+    in_kw = dict(cond_channels=DRY_KW["in_channels"] - CM, enc_dim=DRY_KW["cross_attention_dim"]) if dry else {}
+    x_np, cond_np, _, _ = synth.make_inputs(B, CM, T, L, seed=1234 + rank, **in_kw)
     x_T = torch.from_numpy(x_np).to(dev)
     cond = torch.from_numpy(cond_np).to(dev)
     G = world * B
     if rank == 0:
-        enc_all = np.concatenate([synth.make_inputs(B, 80, 8, L, seed=1234 + r)[2] for r in range(world)])
+        enc_all = np.concatenate([synth.make_inputs(B, CM, 8, L, seed=1234 + r, **in_kw)[2] for r in range(world)])
         enc_g = torch.from_numpy(enc_all).to(dev)
     else:
-        enc_g = torch.empty((G, L, 128), device=dev)
+        enc_g = torch.empty((G, L, enc_dim_of(dry)), device=dev)
     mask_g = torch.ones((G, L), dtype=torch.bool, device=dev)
 
     ns = dpm_solver.NoiseScheduleVP("discrete", betas=torch.from_numpy(synth.make_betas()))
@@ -274,7 +363,8 @@ def main():
     def barrier():
         if world > 1:
             torch.distributed.barrier()
-        torch.cuda.synchronize()
+        if not dry:
+            torch.cuda.synchronize()
 
     with torch.no_grad():
         for _ in range(args.warmup):
@@ -285,11 +375,16 @@ def main():
             out = one_run()
         barrier()
         dt = time.perf_counter() - t0
+    rank_ms = [1e3 * dt / args.steps]                # per-rank ms per step: a straggler shows up as max >> min
     if world > 1:
         tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        every = torch.empty((world,), device=dev, dtype=torch.float64)
+        torch.distributed.all_gather_into_tensor(every, tt)
+        rank_ms = [1e3 * float(v) / args.steps for v in every.tolist()]
         torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
         dt = float(tt.item())
     assert torch.isfinite(out).all()
+    assert out.shape[0] == G, "the gathered mels must cover the global batch"
 
     if rank != 0:
         if world > 1:
@@ -304,11 +399,16 @@ def main():
         "dtype": "%s (bf16 MFMA operands%s, fp32 accumulate / fp32 activations)" % (
             args.precision, " split hi+lo, 3 products" if args.precision == "bf16x3" else ""),
         "data": "synthetic",
-        "config": {"workload": "B=%d/GPU, C=80, T=%d, L=%d, %d-step DPM-Solver++(2M) multistep, UNet1DConditionModel "
-                               "(128,256,384,512), seeded random-init weights" % (B, T, L, S),
+        "config": {"workload": "B=%d/GPU, C=%d, T=%d, L=%d, %d-step DPM-Solver++(2M) multistep, UNet1DConditionModel "
+                               "%s, seeded random-init weights" % (B, CM, T, L, S, tuple((DRY_KW if dry else UNET_KW)["block_out_channels"])),
                    "global_batch": G, "concurrent_sub_batches_per_gpu": NS,
                    "rccl_world_size": torch.distributed.get_world_size() if world > 1 else 1, "parallelism": "dp%d (batch-sharded, RCCL broadcast of conditioning + all-gather of mels)" % world},
+        "per_rank_ms_per_step": {"min": min(rank_ms), "max": max(rank_ms), "ranks": [round(v, 3) for v in rank_ms]},
     }
+    if dry:
+        result["dry_run_cpu"] = True                 # a rehearsal of the rank path on CPU (gloo, torch backend): not a measurement
+        result["dtype"] = "fp32 (torch backend, CPU dry run)"
+        result["config"]["parallelism"] = "dp%d (batch-sharded, gloo broadcast of conditioning + all-gather of mels)" % world
 
     # ---- roofline of the dominant kernel family (implicit GEMM), timed live with HIP events ----
     if not args.no_roofline:
@@ -341,15 +441,22 @@ def main():
         # these are the figures of the committed rocprofv3 --pmc passes over this same command (tools/pmc_roofline.py)
         traffic = traffic_src = hbm_gbps = mfma_util = None
         pmc_families = None
-        tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r02_pmc_roofline.json")
+        tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r03_pmc_roofline.json")
+        pj = None
         if os.path.exists(tpath) and args.precision == "bf16x3" and (B, T, L) == (8, 1024, 256):
             with open(tpath) as f:
                 pj = json.load(f)
+        if pj is not None and not pmc_identity_ok(pj):
+            from diff_vits_amd import _lib
+            traffic_src = ("stale: profiles/r03_pmc_roofline.json was collected on build %r, the loaded library is %r - PMC "
+                           "fields withheld" % (pj.get("build", {}).get("dv_version"), _lib.lib().dv_version().decode()))
+        elif pj is not None:
             traffic, hbm_gbps, mfma_util = (pj["gemm"][k] for k in ("hbm_bytes_per_launch", "hbm_gbps", "mfma_util"))
             pmc_families = {k: {kk: v[kk] for kk in ("launches", "avg_us_kernel_trace", "hbm_bytes_per_launch", "hbm_gbps", "mfma_util")}
                             for k, v in pj.items() if isinstance(v, dict)}
-            traffic_src = ("profiles/r02_pmc_roofline.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, KiB; SQ_VALU_MFMA_BUSY_CYCLES / "
-                           "(1024 SIMDs x kernel duration x 2.4 GHz); separate passes, eager launches)")
+            traffic_src = ("profiles/r03_pmc_roofline.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, KiB; SQ_VALU_MFMA_BUSY_CYCLES / "
+                           "(1024 SIMDs x kernel duration x 2.4 GHz); separate passes, eager launches; build %s, git %s)"
+                           % (pj["build"].get("dv_version"), pj["build"].get("git_head")))
         result["roofline"] = {
             "bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
             "traffic": traffic, "traffic_source": traffic_src, "hbm_gbps": hbm_gbps, "mfma_util": mfma_util,
@@ -374,8 +481,24 @@ def main():
         if bad or result["extra"]["in_epilogue_groupnorm_gemms"]["timed_out"]:
             raise SystemExit("bench: an in-kernel GroupNorm hand-over timed out - results invalid")
     if not args.no_cpu_baseline and world == 1:        # reported at N = 1 only (rank 0's host cores, bounded sample)
-        result["cpu_baseline"] = cpu_baseline(sd, B, T, L, S)
+        result["cpu_baseline"], y_ref = cpu_baseline(sd, B, T, L, S)
         result["speedup_vs_cpu_baseline"] = frames_per_s / result["cpu_baseline"]["value"] / world
+        # the metric is frames/s PLUS the UNet-output error against the reference restatement -
+        # one HIP forward on the inputs of the oracle forward the baseline leg just ran (same seed, t = PARITY_T)
+        xo, co, eo, mo = (torch.from_numpy(a).to(dev) for a in synth.make_inputs(B, 80, T, L, seed=1234))
+        with torch.no_grad():
+            y = model(torch.cat([xo, co], 1), torch.full((B,), PARITY_T, device=dev), eo, encoder_attention_mask=mo).sample
+        y = y.double().cpu()
+        yr = y_ref.double()
+        par = {"unet_rel_l2": float((y - yr).norm() / yr.norm()),
+               "unet_max_abs_rel": float((y - yr).abs().max() / yr.abs().max()),
+               "unet_parity": "one denoiser forward at the bench shape (B=%d, T=%d, L=%d, t=%.0f) on MI355X vs oracle/unet_ref.py "
+                              "(torch-CPU fp32) on the same inputs; budget %.0e" % (B, T, L, PARITY_T, PARITY_TOL)}
+        result.setdefault("extra", {}).update(par)
+        if not (par["unet_rel_l2"] <= PARITY_TOL and par["unet_max_abs_rel"] <= PARITY_TOL):
+            print(json.dumps(result))
+            raise SystemExit("bench: UNet output differs from the oracle by %.3e (rel-L2) / %.3e (max-abs-rel) > %.0e"
+                             % (par["unet_rel_l2"], par["unet_max_abs_rel"], PARITY_TOL))
     print(json.dumps(result))
     if world > 1:
         torch.distributed.destroy_process_group()

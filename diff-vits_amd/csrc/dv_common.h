@@ -69,6 +69,8 @@ struct GemmParams {
   float up_scale;               // UP_SIZE: (float)T_in / T_virt, as ATen computes it
   const bf16_t* w_hi;           // [N_pad, Kp] bf16, row n = output channel, k contiguous
   const bf16_t* w_lo;           // low-order split (null in bf16 mode)
+  const bf16_t* wf_hi;          // the same planes FRAGMENT-major (launch_relayout_frag) or null: enables the BD tile (gemm_tile.h)
+  const bf16_t* wf_lo;
   int Kp;                       // packed K
   int N_pad;                    // rows present in w_hi/w_lo (multiple of 128)
   const float* bias;            // [N] (GEGLU: packed order) or null
@@ -114,6 +116,8 @@ int gemm_gnx_plan(const GemmParams& p, int n_cu);
 // tile menu ids (kernels_gemm.hip); GT_BK64 is or-ed in when the tile runs 64-deep k-tiles
 enum { GT_AUTO = 0, GT_T0 = 1, GT_T1 = 2, GT_T2 = 3, GT_T2S = 4, GT_T2G = 5, GT_T3 = 6, GT_T4 = 7, GT_T4G = 8, GT_AF64 = 9, GT_AF32 = 10,
        GT_BK64 = 0x100 };
+// true if launch_gemm can run this GEMM on the BD tile (fragment-major weights in registers, activation slabs in LDS)
+bool gemm_bd_supported(const GemmParams& p);
 // true if launch_gemm can run this GEMM (p.af = 1) on the tiles that produce the A operand in-kernel
 bool gemm_af_supported(const GemmParams& p);
 // candidate tiles (force_tile values) that can run this GEMM; returns the count written to out[cap]

@@ -8,6 +8,7 @@
 #include "../../include/dvits_hip.h"
 #include "dv_common.h"
 
+#include <atomic>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -29,7 +30,16 @@ int dv_fail(int code, const char* fmt, ...) {
   return code;
 }
 extern "C" const char* dv_last_error(void) { return g_err; }
-extern "C" const char* dv_version(void) { return "dvits_hip 0.1 gfx950"; }
+#ifndef DV_SRC_HASH
+#define DV_SRC_HASH "unknown"
+#endif
+// the build identity: profiles/*_pmc_roofline.json is stamped with it and bench.py reports those figures only while it
+// still is the loaded library's (csrc/Makefile hashes every kernel source into DV_SRC_HASH)
+extern "C" const char* dv_version(void) { return "dvits_hip 0.3 gfx950 src=" DV_SRC_HASH; }
+// Schedule generations are PROCESS-global and monotonic: a captured sampler graph is keyed on (handle address,
+// generation), and a destroyed handle's address can be handed out again by `new` - with a per-handle counter the new
+// handle's first prepare would reproduce the old key and replay a graph that points into freed memory.
+static std::atomic<int64_t> g_generation{0};
 
 #define HIPCHK(expr)                                                                                  \
   do {                                                                                                \
@@ -1885,7 +1895,7 @@ extern "C" int dv_unet_prepare(dv_unet* u, int32_t B, int32_t T, int32_t L, int3
   HIPCHK(hipDeviceSynchronize());
   u->prepared = true;
   u->weights_dirty = false;
-  u->generation++;
+  u->generation = ++g_generation;
   return DV_OK;
 }
 
@@ -1959,7 +1969,7 @@ extern "C" int dv_penc_prepare(dv_penc* p, int32_t B, int32_t L, int32_t precisi
   HIPCHK(hipDeviceSynchronize());
   u->prepared = true;
   u->weights_dirty = false;
-  u->generation++;
+  u->generation = ++g_generation;
   return DV_OK;
 }
 
@@ -2036,14 +2046,19 @@ int dv_unet_temb_all(dv_unet* u, const float* t_all, int n_evals, hipStream_t st
   if (off || !c.ok || n_evals < 1 || u->persist_on || u->keep_intermediates) return 1;
   const int R = n_evals * u->B;
   if (R > c.rows_cap) {
-    HIPCHK(hipDeviceSynchronize());
-    for (float* b : {c.tsin, c.h1, c.emb, c.tproj_all}) if (b) (void)hipFree(b);
-    c.tsin = c.h1 = c.emb = c.tproj_all = nullptr; c.rows_cap = 0;
-    HIPCHK(hipMalloc((void**)&c.tsin, (size_t)R * c.C0 * 4));
-    HIPCHK(hipMalloc((void**)&c.h1, (size_t)R * c.E * 4));
-    HIPCHK(hipMalloc((void**)&c.emb, (size_t)R * c.E * 4));
-    HIPCHK(hipMalloc((void**)&c.tproj_all, (size_t)R * c.tt * 4));
-    c.rows_cap = R;
+    // A larger table (a plan with more evaluations).  The old buffers are NOT freed: captured graphs of other plans
+    // (sampler.hip keys them on handle / generation / x / cond, not on this table) have their addresses baked in - the
+    // head-of-loop chain writes them and every GroupNorm of that graph reads them - and stay valid as long as they live.
+    // They move to the schedule's owned list (released with it); growth is geometric, so at most a few generations exist.
+    for (float* b : {c.tsin, c.h1, c.emb, c.tproj_all}) if (b) u->owned.push_back(b);
+    c.tsin = c.h1 = c.emb = c.tproj_all = nullptr;
+    const int cap = std::max(R, c.rows_cap + c.rows_cap / 2);
+    c.rows_cap = 0;
+    HIPCHK(hipMalloc((void**)&c.tsin, (size_t)cap * c.C0 * 4));
+    HIPCHK(hipMalloc((void**)&c.h1, (size_t)cap * c.E * 4));
+    HIPCHK(hipMalloc((void**)&c.emb, (size_t)cap * c.E * 4));
+    HIPCHK(hipMalloc((void**)&c.tproj_all, (size_t)cap * c.tt * 4));
+    c.rows_cap = cap;
   }
   HIPCHK(launch_timestep_sincos(t_all, c.tsin, R, c.C0, st));
   HIPCHK(launch_small_linear_t(c.tsin, c.C0, c.w1T, c.b1, nullptr, c.h1, c.E, R, c.C0, c.E, 0, 1, st));

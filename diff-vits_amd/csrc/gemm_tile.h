@@ -1,8 +1,10 @@
 // Implicit-GEMM tile routine shared by the per-launch kernel (kernels_gemm.hip) and the persistent per-XCD schedule
 // (persist.hip).  See kernels_gemm.hip for the design notes.
 #pragma once
-#ifndef DV_AS_EXP
-#define DV_AS_EXP 0   // development knob (trace experiments on the AS tile); 0 in every shipped build
+#ifndef DV_GEMM_EXP
+// development knob (trace experiments on the plain tile's k-loop, WRONG results): 1 = B fragments read from LDS once, not per
+// k-tile; 2 = 1 + no B DMA; 3 = 2 + A fragments read once; 4 = no DMA inside the loop at all.  0 in every shipped build
+#define DV_GEMM_EXP 0
 #endif
 #include "dv_common.h"
 #include "dv_device.h"
@@ -55,25 +57,38 @@ __device__ __forceinline__ unsigned cvt_pk_bf16(float lo, float hi) { return dv_
 // correct but measured ~1800 cycles per k-tile against 960 for the plain kernel: sixteen waves meeting at every k-tile
 // barrier with the VALU pipe of each SIMD shared between them - DESIGN.md.]  The k-tile order is chunk-major (segment ->
 // concat half -> 64-channel chunk -> tap); tiles never span utterances (T_out % BM == 0).
-// AS ("A slab"): the k = 3 convs read their input three times - the A tiles of the three taps are the same rows shifted by
-// one frame - and the k-loop is bound by the bytes that go through the LDS-DMA path (32 KiB per 64x64x64 k-tile, ~1000
-// cycles against 384 of MFMA).  AS tiles walk the k-range CHUNK-major (64-channel chunk -> tap): the chunk's BM rows are
-// DMA'd ONCE into a slab slot (+ the two halo rows t0 - 1, t0 + BM by one more instruction of wave 0), the three taps
-// read it at row offsets -1 / 0 / +1, and only the weights stream per k-tile: 65 KiB instead of 96 per chunk.
-template <int BM, int BN, int BK, int WM, int WN, int NSPLIT, int KS, bool SC1, bool AF = false, bool AS = false>
+// BD ("B direct"): the tile of the stride-1 convs and linears whose channel counts are multiples of 64.  Measured on the
+// plain tile (trace builds with parts of the k-loop removed, profiles/r03_gemm_kloop_ablation_*.txt): its 64x64x64 k-tile takes
+// ~1100 cycles against 384 of MFMA although the waits for the DMA are ~zero - the loop is bound by LDS bandwidth (32 KiB of DMA
+// writes + 64 KiB of fragment reads per k-tile at 128 B/clk: every operand element is read by two waves), by the vector-memory
+// issue of 32 DMA instructions per k-tile, and by eight waves meeting at a barrier per k-tile in lock step (LDS reads, then
+// MFMAs).  BD removes the weights from LDS altogether and makes the activations cross it once per CHUNK instead of per tap:
+//   * W is read FRAGMENT-major (engine: k_relayout_frag copies) straight into registers, one coalesced 16-byte load per lane
+//     and plane per k-tile, DEPTH k-tiles ahead; the waves are laid out 1 x 2 (rows x columns) x 4 k-groups, so no two waves
+//     of a workgroup load the same weight fragment;
+//   * the k-range is walked CHUNK-major (segment -> concat half -> 64-channel chunk -> tap): a chunk's 64 rows (+ the two halo
+//     rows t0 - 1, t0 + 64 of a k = 3 conv) are DMA'd ONCE into a slab slot, AH chunks ahead, and the taps read it at row
+//     offsets -1 / 0 / +1: one barrier per chunk, 16.5 KiB of LDS writes + 32 KiB of reads per k-tile (k = 1) or per THREE
+//     k-tiles' worth of MFMAs... (k = 3: 16.5 + 96 KiB per three k-tiles);
+//   * per k-tile a wave issues 4 LDS reads, 6 MFMAs and 2 global loads (plain tile: 8 LDS reads, 6 MFMAs, 4 DMA instructions
+//     + their address arithmetic).
+// [Round 2's "AS" tile - the slab alone, weights still through the LDS ring, 2 x 2 waves - was slower than the plain tile and
+// is replaced by this one.]
+template <int BM, int BN, int BK, int WM, int WN, int NSPLIT, int KS, bool SC1, bool AF = false, bool BD = false>
 __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int m0, const int n0, char* smem, const int ksel = 0) {
   constexpr int FM = BM / (WM * 32), FN = BN / (WN * 32);
   constexpr int NWQ = WM * WN;                       // waves per k-group (1, 2 or 4)
   constexpr int NWV = NWQ * KS;                      // waves per workgroup
   static_assert(!AF || (BK == 64 && !SC1), "AF tiles: 64-deep k-tiles, per-launch kernel");
-  static_assert(!AS || (BK == 64 && !SC1 && !AF && BM == 64), "AS tiles: 64 rows, 64-deep k-tiles, per-launch kernel");
-  constexpr bool CM = AF || AS;                      // chunk-major k-tile order, weights-only ring
+  static_assert(!BD || (BK == 64 && !SC1 && !AF && BM == 64 && BN == 64 && WM == 1 && WN == 2 && KS == 4),
+                "BD tile: 64 x 64 x 64, 1 x 2 waves x 4 k-groups, per-launch kernel");
+  constexpr bool CM = AF || BD;                      // chunk-major k-tile order
   constexpr bool SPLIT = NSPLIT == 3;
   constexpr int NPL = SPLIT ? 2 : 1;                 // planes per operand
   constexpr int ROWB = BK * 2;                       // LDS row pitch (bytes), unpadded
   constexpr int CPR = ROWB / 16;                     // 16-byte chunks per row: 4 (BK=32) or 8 (BK=64)
   constexpr int RPI = 64 / CPR;                      // rows per wave-instruction
-  constexpr int A_PL = CM ? 0 : BM * ROWB, B_PL = BN * ROWB;  // bytes per plane tile in the ring (AF: weights only)
+  constexpr int A_PL = CM ? 0 : BM * ROWB, B_PL = BD ? 0 : BN * ROWB;  // bytes per plane tile in the ring (AF: weights only; BD: no ring)
   constexpr int STAGE = (A_PL + B_PL) * NPL;
   constexpr int AF_CH = BM == 64 ? 5 : 11;           // AF: chunks per phase (slab = AF_CH x (BM+2) rows x 128 B per plane)
   constexpr int CH_PL = (BM + 2) * ROWB;             // AF: one chunk of one plane
@@ -82,11 +97,12 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int m0, con
 #define DV_NSTAGE_64 4
 #endif
   // LDS ring depth: NSTAGE-1 tiles in flight (DV_NSTAGE_64: experiment knob for the 64x64 tiles' occupancy)
-  constexpr int NSTAGE = AF ? 3 : AS ? 4 : ((BM == 64 && BN == 64 && !SC1) ? DV_NSTAGE_64 : ((4 * STAGE <= 160 * 1024) ? 4 : 3));
-  constexpr int A_IPW = CM ? 0 : BM / RPI / NWV, B_IPW = BN / RPI / NWV;   // DMA instructions per wave per plane
-  constexpr int A_IPW1 = A_IPW ? A_IPW : 1;          // (array extents)
+  constexpr int NSTAGE = AF ? 3 : BD ? 1 : ((BM == 64 && BN == 64 && !SC1) ? DV_NSTAGE_64 : ((4 * STAGE <= 160 * 1024) ? 4 : 3));
+  constexpr int A_IPW = CM ? 0 : BM / RPI / NWV, B_IPW = BD ? 0 : BN / RPI / NWV;   // DMA instructions per wave per plane
+  constexpr int A_IPW1 = A_IPW ? A_IPW : 1, B_IPW1 = B_IPW ? B_IPW : 1;   // (array extents)
   constexpr int LPT = (A_IPW + B_IPW) * NPL;         // DMA instructions per thread per k-tile
-  static_assert((CM || BM % (RPI * NWV) == 0) && BN % (RPI * NWV) == 0, "tile rows must split over the waves");
+  constexpr int LPT_W = (DV_GEMM_EXP >= 2 && !CM) ? A_IPW * NPL : LPT;   // ... that the counted waits see (experiments)
+  static_assert((CM || BM % (RPI * NWV) == 0) && (BD || BN % (RPI * NWV) == 0), "tile rows must split over the waves");
   DV_TRACE(0);
 #ifdef DV_GEMM_TRACING
   if (threadIdx.x == 0 && blockIdx.x < 8192) {
@@ -129,7 +145,7 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int m0, con
     arow_t[q] = m - arow_b[q] * p.T_out;
     a_chunk[q] = l_slot ^ swz(r);                     // source chunk that lands in this lane's slot
   }
-  size_t b_off[B_IPW];
+  size_t b_off[B_IPW1];
 #pragma unroll
   for (int q = 0; q < B_IPW; ++q) {
     const int r = (q * NWV + wave) * RPI + l_row;
@@ -144,13 +160,13 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int m0, con
   if (p.sk_mode == 1 || p.sk_mode == 3) { kt0 = ksel * total_kt / p.sk_split; nk = (ksel + 1) * total_kt / p.sk_split - kt0; }
   if (p.sk_mode == 2) nk = 0;
   // ---- AF: position in the chunk-major k-tile order, wave-uniform.  koff() = packed-K element offset of the tile ----
-  // (AS: the segment's plane pointers ride along in scalar registers - a segment-descriptor load from argument memory
+  // (BD: the segment's plane pointers ride along in scalar registers - a segment-descriptor load from argument memory
   // inside the k-loop sits on every wave's critical path)
   struct AfIt { int seg, half, col, tap, taps, c0, c1, kbase, pad; const bf16_t* h0; const bf16_t* l0; const bf16_t* h1; const bf16_t* l1; };
   auto af_enter = [&](AfIt& s) {
     const GemmSeg& sg = p.seg[s.seg < p.nseg ? s.seg : 0];
     s.taps = sg.taps; s.c0 = sg.c0; s.c1 = sg.c1; s.pad = sg.pad;
-    if (AS) { s.h0 = sg.a0_hi; s.l0 = sg.a0_lo; s.h1 = sg.a1_hi; s.l1 = sg.a1_lo; }
+    if (BD) { s.h0 = sg.a0_hi; s.l0 = sg.a0_lo; s.h1 = sg.a1_hi; s.l1 = sg.a1_lo; }
     s.kbase = s.seg == 0 ? 0 : p.seg[0].taps * (p.seg[0].c0 + p.seg[0].c1);
   };
   auto af_next = [&](AfIt& s) {
@@ -216,6 +232,7 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int m0, con
       if (SC1) glds16_sc1(asrc[u], st_base + (unsigned)(((q * NWV + wave) * RPI) * ROWB + pl * A_PL));
       else glds16(asrc[u], st_base + (unsigned)(((q * NWV + wave) * RPI) * ROWB + pl * A_PL));
     } else {
+      if (DV_GEMM_EXP >= 2 && !CM) return;
       const int q = (u - A_IPW * NPL) / NPL, pl = (u - A_IPW * NPL) % NPL;
       const size_t o = b_off[q] + (CM ? (size_t)af_issue_koff * 2 : (size_t)kt * (BK * 2));
       glds16(reinterpret_cast<const char*>(pl ? p.w_lo : p.w_hi) + o,
@@ -235,40 +252,39 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int m0, con
     }
   };
   AfIt af_is = af0;              // AF: tile being issued (runs NSTAGE-1 tiles ahead of the one being multiplied)
-  // ---- AS: slab slots behind the weight ring: [BM rows hi | BM rows lo | halo: row -1 hi, row BM hi, row -1 lo, row BM lo] ----
-  constexpr int AS_MAIN_PL = BM * ROWB, AS_SLOT = AS_MAIN_PL * NPL + 1024, AS_NSLOT = 4;
-  constexpr int AS_IPW = AS ? BM / RPI / NWV : 0;    // main-row DMA instructions per wave per plane
-  const int as_b = AS ? m0 / p.T_out : 0, as_t0 = AS ? m0 - as_b * p.T_out : 0;
-  int as_issued = 0, as_cur = 0;                     // chunks issued / chunk of the tile being multiplied
-  int as_seq = 0;                                    // (DV_AS_EXP 4: sequential weight tiles)
-  const int as_ls = DV_AS_EXP == 5 ? 0 : AS_IPW * NPL + ((DV_AS_EXP != 1 && wave == 0) ? 1 : 0);   // this wave's DMA instructions per slab
-  auto issue_slab = [&](const AfIt& c) {
-    if (DV_AS_EXP == 5) { ++as_issued; return; }
+  // ---- BD: slab slots [BM rows hi | BM rows lo | halo: row -1 hi, row BM hi, row -1 lo, row BM lo] ----
+  constexpr int BD_MAIN_PL = BM * ROWB, BD_SLOT = BD_MAIN_PL * NPL + 1024;
+  constexpr int BD_AH = 6, BD_NSLOT = BD_AH + 1;     // chunks in flight; slot of chunk c + AH = slot of chunk c - 1 (finished)
+  constexpr int BD_IPW = BD ? BM / RPI / NWV : 0;    // main-row DMA instructions per wave per plane
+  const int bd_b = BD ? m0 / p.T_out : 0, bd_t0 = BD ? m0 - bd_b * p.T_out : 0;
+  int bd_vm = 0;                                     // vector-memory loads this wave has issued since the k-loop's prologue began
+  // DMA of chunk c (at tap 0) into `slot`; returns nothing, counts this wave's instructions in bd_vm
+  auto issue_slab = [&](const AfIt& c, int slot) {
     const bf16_t* hi = c.half ? c.h1 : c.h0;
     const bf16_t* lo = c.half ? c.l1 : c.l0;
     const int ld = c.half ? c.c1 : c.c0;
-    const unsigned dst0 = smem_base + (unsigned)(NSTAGE * STAGE + (as_issued % AS_NSLOT) * AS_SLOT);
-    const size_t row0 = (size_t)as_b * p.T_in;
+    const unsigned dst0 = smem_base + (unsigned)(slot * BD_SLOT);
+    const size_t row0 = (size_t)bd_b * p.T_in;
 #pragma unroll
-    for (int q = 0; q < AS_IPW; ++q) {
+    for (int q = 0; q < BD_IPW; ++q) {
       const int r = (q * NWV + wave) * RPI + l_row;
-      const size_t e = (row0 + as_t0 + r) * ld + c.col + ((l_slot ^ swz(r)) << 3);
+      const size_t e = (row0 + bd_t0 + r) * ld + c.col + ((l_slot ^ swz(r)) << 3);
       glds16(hi + e, dst0 + (unsigned)(((q * NWV + wave) * RPI) * ROWB));
-      if (SPLIT) glds16(lo + e, dst0 + (unsigned)(AS_MAIN_PL + ((q * NWV + wave) * RPI) * ROWB));
+      if (SPLIT) glds16(lo + e, dst0 + (unsigned)(BD_MAIN_PL + ((q * NWV + wave) * RPI) * ROWB));
     }
-    if (DV_AS_EXP == 1 ? false : wave == 0) {   // halo rows t0 - 1 and t0 + BM of both planes: one lane-linear instruction (lanes 32.. repeat)
+    bd_vm += BD_IPW * NPL;
+    if (wave == 0 && c.taps > 1) {   // halo rows t0 - 1 and t0 + BM of both planes: one lane-linear instruction (lanes 32.. repeat)
       const int which = (lane >> 3) & 3, ch = lane & 7;
-      const int t = (which & 1) ? as_t0 + BM : as_t0 - 1;
+      const int t = (which & 1) ? bd_t0 + BM : bd_t0 - 1;
       const bf16_t* pl = (which >> 1) ? lo : hi;
       const bool ok = t >= 0 && t < p.T_in && pl != nullptr;   // conv zero padding beyond the utterance
       const void* src = ok ? (const void*)(pl + (row0 + t) * ld + c.col + ch * 8) : (const void*)p.zero_page;
-      glds16(src, dst0 + (unsigned)(AS_MAIN_PL * NPL));
+      glds16(src, dst0 + (unsigned)(BD_MAIN_PL * NPL));
+      bd_vm += 1;
     }
-    ++as_issued;
   };
   auto issue = [&](int kt) {     // whole tile at once (prologue)
-    if (AS && af_is.tap == 0) issue_slab(af_is);
-    if (CM) af_issue_koff = (AS && DV_AS_EXP == 4) ? (as_seq++) * 64 : af_koff(af_is);
+    if (CM) af_issue_koff = af_koff(af_is);
     else prep_a();
 #pragma unroll
     for (int u = 0; u < LPT; ++u) issue_unit(kt, u);
@@ -333,12 +349,13 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int m0, con
   constexpr int NCH = NKS * NTERM;                   // MFMA groups per k-tile
   AfIt af_cs = af0;              // AF: tile being multiplied
   int af_ci = 0;                 // AF: its chunk's index inside the resident phase
+  bf16x8 ahK[NKS][FM], alK[NKS][FM], bhK[NKS][FN], blK[NKS][FN];   // (DV_GEMM_EXP: fragments read once)
+  bool exp_first = true;
   auto step = [&](int kt, auto issue_tag) {
-    constexpr bool ISSUE = decltype(issue_tag)::value;
+    constexpr bool ISSUE = decltype(issue_tag)::value && !(DV_GEMM_EXP == 4 && !CM);
     const char* base = smem + (kt % NSTAGE) * STAGE;
-    const char* a_hi = AF ? smem + NSTAGE * STAGE + af_ci * CH_PL : AS ? smem + NSTAGE * STAGE + (as_cur % AS_NSLOT) * AS_SLOT : base;
-    const char* a_lo = AF ? a_hi + SLAB_PL : AS ? a_hi + AS_MAIN_PL : base + A_PL;
-    const int as_d = (AS && DV_AS_EXP != 3) ? af_cs.tap - af_cs.pad : 0;   // AS: tap j of a conv padded by `pad` reads slab row + j - pad
+    const char* a_hi = AF ? smem + NSTAGE * STAGE + af_ci * CH_PL : base;
+    const char* a_lo = AF ? a_hi + SLAB_PL : base + A_PL;
     const char* b_hi = base + NPL * A_PL;
     const char* b_lo = b_hi + B_PL;
     // AF: slab row 0 is frame t0 - 1; tap j of a conv padded by `pad` reads row + j + 1 - pad
@@ -349,28 +366,30 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int m0, con
       const int chunk = (kgrp * NKS + ks0) * 2 + lh;
 #pragma unroll
       for (int i = 0; i < FM; ++i) {
-        const int row = (wm * FM + i) * 32 + l31 + af_rowoff + as_d;
-        int off = row * ROWB + ((chunk ^ swz(row)) << 4), off_lo = off;
-        if (AS) {                                    // rows -1 / BM live in the slot's halo (one lane per fragment)
-          const int hoff = AS_MAIN_PL * NPL + (row < 0 ? 0 : ROWB) + (chunk << 4);
-          const bool inb = DV_AS_EXP == 2 ? true : (unsigned)row < (unsigned)BM;
-          off = inb ? off : hoff;
-          off_lo = inb ? off_lo : hoff + 2 * ROWB - AS_MAIN_PL;
-        }
+        const int row = (wm * FM + i) * 32 + l31 + af_rowoff;
+        const int off = row * ROWB + ((chunk ^ swz(row)) << 4), off_lo = off;
+        if (DV_GEMM_EXP == 3 && !CM) {
+          if (exp_first) { ahK[ks0][i] = *reinterpret_cast<const bf16x8*>(a_hi + off); if (SPLIT) alK[ks0][i] = *reinterpret_cast<const bf16x8*>(a_lo + off_lo); }
+          ah[ks0][i] = ahK[ks0][i]; if (SPLIT) al[ks0][i] = alK[ks0][i];
+        } else {
         ah[ks0][i] = *reinterpret_cast<const bf16x8*>(a_hi + off);
         if (SPLIT) al[ks0][i] = *reinterpret_cast<const bf16x8*>(a_lo + off_lo);
+        }
       }
 #pragma unroll
       for (int j = 0; j < FN; ++j) {
         const int row = (wn * FN + j) * 32 + l31;
         const int off = row * ROWB + ((chunk ^ swz(row)) << 4);
+        if (DV_GEMM_EXP >= 1 && DV_GEMM_EXP <= 3 && !CM) {
+          if (exp_first) { bhK[ks0][j] = *reinterpret_cast<const bf16x8*>(b_hi + off); if (SPLIT) blK[ks0][j] = *reinterpret_cast<const bf16x8*>(b_lo + off); }
+          bh[ks0][j] = bhK[ks0][j]; if (SPLIT) bl[ks0][j] = blK[ks0][j];
+        } else {
         bh[ks0][j] = *reinterpret_cast<const bf16x8*>(b_hi + off);
         if (SPLIT) bl[ks0][j] = *reinterpret_cast<const bf16x8*>(b_lo + off);
+        }
       }
     }
-    // (AS: without this hipcc sinks every fragment read down to its MFMA - read, wait, multiply, read, ... - and the LDS
-    // latency of all eight reads is exposed: measured 1280 cycles per k-tile in this block)
-    if (AS) __builtin_amdgcn_sched_barrier(0);
+    exp_first = false;
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
       // (independent accumulators per k-step: consecutive MFMAs alternate chains)
@@ -390,8 +409,7 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int m0, con
       if (ISSUE) {
         __builtin_amdgcn_sched_barrier(0);
         if (c == 0) {
-          if (AS && af_is.tap == 0) issue_slab(af_is);
-          if (CM) af_issue_koff = (AS && DV_AS_EXP == 4) ? (as_seq++) * 64 : af_koff(af_is); else prep_a();
+          if (CM) af_issue_koff = af_koff(af_is); else prep_a();
         }
 #pragma unroll
         for (int u = c * LPT / NCH; u < (c + 1) * LPT / NCH; ++u) issue_unit(kt + NSTAGE - 1, u);
@@ -399,7 +417,7 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int m0, con
       }
     }
     if (ISSUE) { if (CM) af_next(af_is); else advance(); }
-    if (CM) { af_next(af_cs); if (af_cs.tap == 0) { ++af_ci; ++as_cur; } }
+    if (CM) { af_next(af_cs); if (af_cs.tap == 0) ++af_ci; }
   };
 
   // accumulator fragment (i, j), lane (l31, lh), register r = 4*g + e  holds
@@ -439,6 +457,7 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int m0, con
   if (PRE_RES && p.epi == EPI_RESIDUAL && p.sk_mode != 1) {   // (mode 3: half of the workgroups prefetch in vain)
 #pragma unroll
     for (int i = 0; i < FM; ++i) {
+      if (BD && i != kgrp) continue;                 // (BD: k-group i finishes row fragment i)
       const size_t ro = (size_t)min(m0 + (wm * FM + i) * 32 + l31, p.M - 1) * p.ldres;
 #pragma unroll
       for (int j = 0; j < FN; ++j) load_row16(p.res, ro, n0 + (wn * FN + j) * 32 + 4 * lh, &rpre[(j * FM + i) * 16]);
@@ -625,64 +644,125 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int m0, con
   // ---- main loop: wait(tile kt) -> barrier -> multiply tile kt with the DMA of tile kt+NSTAGE-1 interleaved ----
   // NSTAGE-1 tiles are in flight; the counted vmcnt leaves the younger ones outstanding across the barrier
   DV_TRACE(10);    // residual prefetch / LayerNorm rows / bias DMA issued
-  if constexpr (AS) {
-    // Per wave, tile j carries LPT weight instructions plus, if it opens a chunk, the slab's (issued just before: older).
-    // Before tile kt is multiplied, everything up to its weights must have landed; what may stay in flight is exactly
-    // the instructions of tiles kt + 1 and kt + 2 (n1 + n2).
-    auto cnt_next = [&]() { return LPT + (af_is.tap == 0 ? as_ls : 0); };   // of the tile `issue` / step() sends next
+  if constexpr (BD) {
+    // ---- BD k-loop ----
+    // Per wave the in-order vector-memory queue holds, after the prologue's odds and ends, only slab DMAs (asm, counted in
+    // bd_vm) and weight units (compiler-visible loads, NPL per unit, counted in bd_vm as they are requested).  mark[j] =
+    // bd_vm right after the slab of the j-th chunk in flight was issued: when that chunk is opened, exactly bd_vm - mark[0]
+    // younger loads may still be outstanding (loads complete in order), so `vmcnt(bd_vm - mark[0])` waits for the slab and
+    // for nothing younger.  The marks shift by one per chunk: static register indices.
+    constexpr int DEPTH = 8;                         // weight units in flight per wave (hi + lo fragment: 8 VGPRs each)
+    struct BFrag { bf16x8 h, l; };
+    BFrag bq[DEPTH];
+    const int ksteps = p.Kp >> 4;
+    const size_t wf_base = ((size_t)((n0 >> 5) + wn) * ksteps + kgrp) * 512 + lane * 8;   // + (packed k / 16) * 512
+    AfIt b_it = af0;                                 // tile whose weight unit is requested next
+    int b_left = nk;
+    auto load_b = [&](BFrag& f) {
+      const size_t e = wf_base + (size_t)(af_koff(b_it) >> 4) * 512;
+      f.h = *reinterpret_cast<const bf16x8*>(p.wf_hi + e);
+      if (SPLIT) f.l = *reinterpret_cast<const bf16x8*>(p.wf_lo + e);
+      af_next(b_it); --b_left;
+      bd_vm += NPL;
+    };
     auto wait_n = [&](int n) {
       switch (n) {
-        case 1: wait_vmcnt<1>(); break;   case 2: wait_vmcnt<2>(); break;   case 3: wait_vmcnt<3>(); break;
-        case 4: wait_vmcnt<4>(); break;   case 5: wait_vmcnt<5>(); break;   case 6: wait_vmcnt<6>(); break;
-        case 7: wait_vmcnt<7>(); break;   case 8: wait_vmcnt<8>(); break;   case 9: wait_vmcnt<9>(); break;
-        case 10: wait_vmcnt<10>(); break;
+#define DV_W(k) case k: wait_vmcnt<k>(); break;
+        DV_W(1) DV_W(2) DV_W(3) DV_W(4) DV_W(5) DV_W(6) DV_W(7) DV_W(8) DV_W(9) DV_W(10) DV_W(11) DV_W(12) DV_W(13) DV_W(14) DV_W(15)
+        DV_W(16) DV_W(17) DV_W(18) DV_W(19) DV_W(20) DV_W(21) DV_W(22) DV_W(23) DV_W(24) DV_W(25) DV_W(26) DV_W(27) DV_W(28) DV_W(29)
+        DV_W(30) DV_W(31) DV_W(32) DV_W(33) DV_W(34) DV_W(35) DV_W(36) DV_W(37) DV_W(38) DV_W(39) DV_W(40)
+#undef DV_W
         default: wait_vmcnt<0>(); break;
       }
     };
-    static_assert(LPT <= 2 && NSTAGE == 4, "AS wait table: at most 2 x (2 + 3) instructions in flight");
-    int n1 = 0, n2 = 0;
-    if (nk > 0) issue(0);
-    if (nk > 1) { n1 = cnt_next(); issue(1); }
-    if (nk > 2) { n2 = cnt_next(); issue(2); }
+    static_assert((BD_AH - 1) * (BD_IPW * NPL + 1) + DEPTH * NPL <= 40, "BD wait table");
+    // slabs of the first AH chunks, then the first DEPTH weight units
+    AfIt s_it = af0;                                 // chunk whose slab is issued next (at tap 0)
+    int s_left = nk, s_slot = 0;                     // tiles not yet covered by an issued slab; slot of the next slab
+    int mark[BD_AH];
+    auto next_slab = [&]() {
+      if (s_left > 0) {
+        issue_slab(s_it, s_slot);
+        s_left -= s_it.taps;
+        s_it.tap = s_it.taps - 1; af_next(s_it);     // first tile of the next chunk
+      }
+      s_slot = s_slot + 1 == BD_NSLOT ? 0 : s_slot + 1;
+    };
+#pragma unroll
+    for (int j = 0; j < BD_AH; ++j) { next_slab(); mark[j] = bd_vm; }
+#pragma unroll
+    for (int j = 0; j < DEPTH; ++j)
+      if (b_left > 0) load_b(bq[j]);
+    __builtin_amdgcn_sched_barrier(0);
     DV_TRACE(1);
+    AfIt cs = af0;                                   // tile being multiplied
+    int c_slot = 0;                                  // its chunk's slot
+    bf16x8 ah[2][FM], al[2][FM];
+    // fragments of tap `tap` of the chunk in slot c_slot: slab row = tile row + tap - pad; rows -1 / BM live in the halo
+    auto read_a = [&](int buf, int tap, int pad) {
+      const char* a_hi = smem + c_slot * BD_SLOT;
+      const int d = tap - pad, chunk = kgrp * 2 + lh;
+#pragma unroll
+      for (int i = 0; i < FM; ++i) {
+        const int row = i * 32 + l31 + d;
+        const bool inb = (unsigned)row < (unsigned)BM;
+        const int hoff = BD_MAIN_PL * NPL + (row < 0 ? 0 : ROWB) + (chunk << 4);
+        const int off = inb ? row * ROWB + ((chunk ^ swz(row)) << 4) : hoff;
+        ah[buf][i] = *reinterpret_cast<const bf16x8*>(a_hi + off);
+        if (SPLIT) al[buf][i] = *reinterpret_cast<const bf16x8*>(a_hi + (inb ? off + BD_MAIN_PL : hoff + 2 * ROWB));
+      }
+    };
 #ifdef DV_GEMM_TRACING
-    unsigned long long tr_vm = 0, tr_bar = 0, tr_step = 0;
+    unsigned long long tr_vm = 0, tr_bar = 0;
 #endif
-    // (two loops, one step() variant each: with both variants inside one loop hipcc keeps the accumulator in different
-    // registers on the two paths and copies all sixteen back every iteration)
-    int kt = 0;
-    for (; kt + 3 < nk; ++kt) {
+    for (int t0 = 0; t0 < nk; t0 += DEPTH) {
+#pragma unroll
+      for (int u = 0; u < DEPTH; ++u) {
+        if (t0 + u < nk) {                           // (wave-uniform)
+          constexpr int dummy = 0; (void)dummy;
+          const int buf = u & 1;
+          if (cs.tap == 0) {
+            // open the chunk: its slab has landed (this wave's part), every wave is done with the previous chunk
 #ifdef DV_GEMM_TRACING
-      const unsigned long long tr0 = __builtin_amdgcn_s_memtime();
+            const unsigned long long tr0 = __builtin_amdgcn_s_memtime();
 #endif
-      wait_n(n1 + n2);
+            wait_n(bd_vm - mark[0]);
 #ifdef DV_GEMM_TRACING
-      const unsigned long long tr1 = __builtin_amdgcn_s_memtime();
+            const unsigned long long tr1 = __builtin_amdgcn_s_memtime();
 #endif
-      __builtin_amdgcn_s_barrier();                  // tile kt (and its slab) visible; every wave is done with tile kt - 1
+            __builtin_amdgcn_s_barrier();
 #ifdef DV_GEMM_TRACING
-      const unsigned long long tr2 = __builtin_amdgcn_s_memtime();
-      if (kt == 0) DV_TRACE(2);
+            tr_vm += tr1 - tr0; tr_bar += __builtin_amdgcn_s_memtime() - tr1;
+            if (t0 + u == 0) DV_TRACE(2);
 #endif
-      n1 = n2;
-      n2 = cnt_next();
-      step(kt, std::true_type{});
-#ifdef DV_GEMM_TRACING
-      tr_vm += tr1 - tr0; tr_bar += tr2 - tr1; tr_step += __builtin_amdgcn_s_memtime() - tr2;
-#endif
-    }
-    for (; kt < nk; ++kt) {                          // drain: nothing left to issue
-      wait_n(n1 + n2);
-      __builtin_amdgcn_s_barrier();
-#ifdef DV_GEMM_TRACING
-      if (kt == 0) DV_TRACE(2);
-#endif
-      n1 = n2; n2 = 0;
-      step(kt, std::false_type{});
+#pragma unroll
+            for (int j = 0; j + 1 < BD_AH; ++j) mark[j] = mark[j + 1];
+            next_slab();                             // into the slot of the chunk just finished
+            mark[BD_AH - 1] = bd_vm;
+            read_a(buf, 0, cs.pad);
+          }
+          if (cs.tap + 1 < cs.taps) read_a(buf ^ 1, cs.tap + 1, cs.pad);   // next tap's fragments fly under this tap's MFMAs
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int term = 0; term < NTERM; ++term)
+#pragma unroll
+            for (int i = 0; i < FM; ++i) {
+              if (SPLIT && term == 0) acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bq[u].h, al[buf][i], acc[i][0], 0, 0, 0);
+              else if (SPLIT && term == 1) acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bq[u].l, ah[buf][i], acc[i][0], 0, 0, 0);
+              else acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bq[u].h, ah[buf][i], acc[i][0], 0, 0, 0);
+            }
+          // pinned: without the scheduling barriers hipcc sinks the refill down to its use (load -> wait -> MFMA)
+          __builtin_amdgcn_sched_barrier(0);
+          if (b_left > 0) load_b(bq[u]);
+          __builtin_amdgcn_sched_barrier(0);
+          af_next(cs);
+          if (cs.tap == 0) c_slot = c_slot + 1 == BD_NSLOT ? 0 : c_slot + 1;
+        }
+      }
     }
 #ifdef DV_GEMM_TRACING
     if (threadIdx.x == 0 && blockIdx.x < 8192) {
-      g_gemm_trace[blockIdx.x * 16 + 12] = tr_vm; g_gemm_trace[blockIdx.x * 16 + 13] = tr_bar; g_gemm_trace[blockIdx.x * 16 + 14] = tr_step;
+      g_gemm_trace[blockIdx.x * 16 + 12] = tr_vm; g_gemm_trace[blockIdx.x * 16 + 13] = tr_bar; g_gemm_trace[blockIdx.x * 16 + 14] = 0;
     }
 #endif
   } else {
@@ -722,7 +802,7 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int m0, con
 #ifdef DV_GEMM_TRACING
     const unsigned long long tr0 = __builtin_amdgcn_s_memtime();
 #endif
-    wait_vmcnt<(NSTAGE - 2) * LPT>();
+    wait_vmcnt<(DV_GEMM_EXP == 4 && !CM) ? 0 : (NSTAGE - 2) * LPT_W>();
 #ifdef DV_GEMM_TRACING
     const unsigned long long tr1 = __builtin_amdgcn_s_memtime();
 #endif
@@ -746,8 +826,8 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int m0, con
   for (; kt < nk; ++kt) {                            // drain: nothing left to issue
     af_boundary();
     const int younger = min(NSTAGE - 2, nk - 1 - kt);
-    if (younger >= 2) wait_vmcnt<2 * LPT>();
-    else if (younger == 1) wait_vmcnt<LPT>();
+    if (younger >= 2) wait_vmcnt<2 * LPT_W>();
+    else if (younger == 1) wait_vmcnt<LPT_W>();
     else wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();
 #ifdef DV_GEMM_TRACING
@@ -756,7 +836,7 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int m0, con
     step(kt, std::false_type{});
     --af_ph_tiles; --af_left;
   }
-  }   // (!AS)
+  }   // (!BD)
 
   if (NACC > 1) {
 #pragma unroll
@@ -795,7 +875,34 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int m0, con
       }
     }
   }
-  auto my_frag_row = [&](int i) { return !SPLIT_EPI || ((i & 1) == kgrp); };
+  // BD (KS == 4, FM == 2): k-group i < FM collects row fragment i from the other three groups and runs its epilogue;
+  // k-groups 2 and 3 hand over and leave
+  if constexpr (BD) {
+    __builtin_amdgcn_s_barrier();                    // every wave is done reading the slabs
+    float* red = reinterpret_cast<float*>(smem);     // [k-group][fragment][16 registers][2 waves x 64 lanes]
+#pragma unroll
+    for (int i = 0; i < FM; ++i) {
+      if (i != kgrp) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) red[((kgrp * FM + i) * 16 + r) * (64 * NWQ) + wq * 64 + lane] = acc[i][0][r];
+      }
+    }
+    __syncthreads();
+    if (kgrp >= FM) return;
+#pragma unroll
+    for (int i = 0; i < FM; ++i) {
+      if (i == kgrp) {
+#pragma unroll
+        for (int g = 0; g < KS; ++g) {
+          if (g != kgrp) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][0][r] += red[((g * FM + i) * 16 + r) * (64 * NWQ) + wq * 64 + lane];
+          }
+        }
+      }
+    }
+  }
+  auto my_frag_row = [&](int i) { return BD ? (i == kgrp) : (!SPLIT_EPI || ((i & 1) == kgrp)); };
   if (p.sk_mode == 3) {                              // fused split-K pair: hand over, or finish
     float4* d0 = reinterpret_cast<float4*>(p.sk_buf) + (size_t)ksel * sk_slice + sk_tile + wq * 64 + lane;
 #pragma unroll
@@ -850,7 +957,7 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int m0, con
 
   // ---- epilogue ----
   DV_TRACE(4);
-  const bool gnx = !SC1 && !AF && p.gnx.xchg != nullptr;   // (AS tiles too)
+  const bool gnx = !SC1 && !AF && p.gnx.xchg != nullptr;   // (BD tiles too)
   // store 4 consecutive columns of one row: fp32 and/or split bf16 planes
   auto store4 = [&](size_t o, int nb, const float* v) {
     if (vec4) {
@@ -1062,7 +1169,7 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int m0, con
       if (p.gnx.tshift) ptb = p.gnx.tshift[(size_t)bq * p.gnx.ld_t + c];
     }
     // statistics of the groups this tile's columns belong to: one wave per group, fp64, fixed order (deterministic)
-    constexpr int NWA = (KS == 2 && !SPLIT_EPI) ? NWQ : NWV;   // waves still here
+    constexpr int NWA = BD ? NWQ * FM : ((KS == 2 && !SPLIT_EPI) ? NWQ : NWV);   // waves still here
     __shared__ float2 s_gst[BN / 16 + 1];
     __shared__ __attribute__((aligned(16))) float s_gA[BN < 64 ? 64 : BN], s_gB[BN < 64 ? 64 : BN];
     const int g_lo = n0 / cpg, g_hi = (min(n0 + BN, p.N) - 1) / cpg;

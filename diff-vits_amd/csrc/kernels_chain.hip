@@ -61,38 +61,55 @@ constexpr int DEPTH_FF = DV_DEPTH_FF;              // k_chain_ff (one accumulato
 __device__ __forceinline__ int swz(int row) { return (row >> 1) & 7; }
 __device__ __forceinline__ unsigned pk(float lo, float hi) { return dv_cvt_pk_bf16(lo, hi); }
 
+#ifndef DV_CHAIN_PFMODE
+// 0: ninth (L2-prefetch) wave wherever round 2 had it (some instantiations then spill at the 168-VGPR cap of a 576-thread
+// workgroup); 1: ninth wave only where the kernel fits 168 VGPRs, no prefetch elsewhere; 2: like 1, and the instantiations
+// without a ninth wave issue the prefetch from their eight compute waves (behind their first operand loads)
+#define DV_CHAIN_PFMODE 2
+#endif
+// Does this instantiation run the ninth wave?  A 576-thread workgroup puts three waves on one SIMD: 168 VGPRs per lane.
+// The cross-attention variants (~230 VGPRs) and every instantiation that spilled at 168 (amode 1 at C = 256, everything at
+// C = 384: 12-144 bytes of scratch per lane, tools/kernel_resources.py) run eight waves with the full 256.
+template <int NS, int AMODE, bool XA, bool SA, bool CS>
+constexpr bool chain_pf_wave() {
+  if (XA) return false;
+  if (DV_CHAIN_PFMODE == 0) return !(SA && NS >= 3);
+  return NS == 1 || (NS == 2 && AMODE == 0);
+}
+
 template <int NS, int AMODE, bool XA = false, bool SA = false, bool CS = false>
-__global__ __launch_bounds__((XA || (SA && NS >= 3)) ? NT : NT_LAUNCH) void k_chain2(const ChainParams p) {
+__global__ __launch_bounds__((chain_pf_wave<NS, AMODE, XA, SA, CS>() ? NT_LAUNCH : NT)) void k_chain2(const ChainParams p) {
   extern __shared__ __attribute__((aligned(1024))) char smem[];
   constexpr int CH = 2 * NS;                       // 64-channel chunks of the A operand
   constexpr int A_PL = CH * CHUNK_PL;              // bytes per plane of the resident A operand
   constexpr int C = 128 * NS;
+  constexpr bool PFW = chain_pf_wave<NS, AMODE, XA, SA, CS>();
   char* const a_reg = smem;                        // [2 planes][CH][32 rows][128 B]
   char* const red_reg = smem + 2 * A_PL;           // k-group hand-over (NS * 16 KiB); GroupNorm entries before stage 1
   __shared__ float2 s_rowp[BM][16];                // LayerNorm row partials per 32-column block (sum, M2 about the block mean)
   __shared__ __attribute__((aligned(16))) float2 s_ln[BM];   // per row (mean, rstd)
   __shared__ __attribute__((aligned(16))) float s_gscale[AMODE ? C : 4], s_gshift[AMODE ? C : 4];
+  __shared__ __attribute__((aligned(256))) unsigned s_pf[64];
 
   // (every 64-byte line of the argument block is requested at once: see k_gemm)
   asm volatile("" ::"s"(p.M), "s"(p.gamma), "s"(p.w1_lo), "s"(p.out1), "s"(p.u2), "s"(p.xa_kf_hi), "s"(p.xa_bias), "s"(p.w3_lo),
                "s"(p.out3_lo), "s"(p.sa_vf_lo), "s"(p.nsplit));
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  // ---- ninth wave: L2 prefetch, then it leaves ----
+  // ---- L2 prefetch ----
   // Every workgroup streams ALL weights, the workgroups of an XCD walk the same addresses at the same pace, and an L2 does
   // not survive a kernel boundary: without help every fragment load of every wave waits for an HBM / fabric fill
   // (measured 40-50 GB/s per CU).  The workgroups of an XCD (observed placement: block b on XCD b % 8 - a speed
   // assumption only) each touch one slice of the weight planes at launch, one 128-byte line per lane through LDS-DMA into
   // a scratch word (no VGPR destination, the wave's own vmcnt), so the L2 fills with thousands of requests in flight
-  // while the eight compute waves start on their first fragments.
-  // (the cross-attention variant runs without it: a ninth wave caps the kernel at 168 VGPRs and it needs ~230)
-  // (so does the C = 384 fragment-output variant: at 168 VGPRs it spills ~600 bytes per lane)
-  if (!XA && !(SA && NS >= 3) && wave == NWV) {
-    __shared__ __attribute__((aligned(256))) unsigned s_pf[64];
+  // while the compute waves start on their first fragments.  Issued by a ninth wave that then leaves (instantiations that
+  // fit the 168 VGPRs a 576-thread workgroup allows), or shared out over the eight compute waves (w of nw) behind their
+  // first operand loads.
+  auto l2_prefetch = [&](int w, int nw) __attribute__((always_inline)) {
     const int xw = blockIdx.x >> 3, nxw = (gridDim.x + 7) >> 3;
     const int l1 = C * C / 64, l2 = p.passes * l1, l3 = XA ? l1 : 0;   // 128-byte lines per plane of stage 1 / 2 / 3
     const int total = 2 * (l1 + l2 + l3), per = (total + nxw - 1) / nxw;
     const int end = min(total, (xw + 1) * per);
-    for (int ln = xw * per + lane; ln < end; ln += 64) {
+    for (int ln = xw * per + w * 64 + lane; ln < end; ln += 64 * nw) {
       const char* src;
       if (ln < l1) src = reinterpret_cast<const char*>(p.w1_hi) + (size_t)ln * 128;
       else if (ln < 2 * l1) src = reinterpret_cast<const char*>(p.w1_lo) + (size_t)(ln - l1) * 128;
@@ -104,16 +121,18 @@ __global__ __launch_bounds__((XA || (SA && NS >= 3)) ? NT : NT_LAUNCH) void k_ch
     }
     if (p.res) {                                   // this workgroup's residual rows (read by the first epilogue)
       const char* r0 = reinterpret_cast<const char*>(p.res + (size_t)(blockIdx.x / (p.nsplit > 1 && AMODE == 1 && !XA ? p.nsplit : 1)) * BM * C);
-      for (int ln = lane; ln < BM * C / 32; ln += 64) glds4(r0 + (size_t)ln * 128, (unsigned)(size_t)s_pf);
+      for (int ln = w * 64 + lane; ln < BM * C / 32; ln += 64 * nw) glds4(r0 + (size_t)ln * 128, (unsigned)(size_t)s_pf);
     }
     // the epilogues' bias / LayerNorm-u vectors (their first touch would be a dependent cold miss inside the epilogue)
-    for (int ln = lane; ln < C / 32; ln += 64) glds4(reinterpret_cast<const char*>(p.b1) + (size_t)ln * 128, (unsigned)(size_t)s_pf);
-    for (int ln = lane; ln < p.passes * C / 32; ln += 64) {
-      glds4(reinterpret_cast<const char*>(p.b2) + (size_t)ln * 128, (unsigned)(size_t)s_pf);
-      glds4(reinterpret_cast<const char*>(p.u2) + (size_t)ln * 128, (unsigned)(size_t)s_pf);
+    if (w == 0) {
+      for (int ln = lane; ln < C / 32; ln += 64) glds4(reinterpret_cast<const char*>(p.b1) + (size_t)ln * 128, (unsigned)(size_t)s_pf);
+      for (int ln = lane; ln < p.passes * C / 32; ln += 64) {
+        glds4(reinterpret_cast<const char*>(p.b2) + (size_t)ln * 128, (unsigned)(size_t)s_pf);
+        glds4(reinterpret_cast<const char*>(p.u2) + (size_t)ln * 128, (unsigned)(size_t)s_pf);
+      }
     }
-    return;
-  }
+  };
+  if (PFW && wave == NWV) { l2_prefetch(0, 1); return; }
   DV_CTRACE(0);
   const int wn = wave & 3, kg = wave >> 2, l31 = lane & 31, lh = lane >> 5;
   // nsplit workgroups per row block (amode 1 with several stage-2 passes, few row blocks): each repeats stage 1 (cheap:
@@ -216,6 +235,7 @@ __global__ __launch_bounds__((XA || (SA && NS >= 3)) ? NT : NT_LAUNCH) void k_ch
   }
   BFrag bq[DEPTH];
   stage_prologue(p.w1_hi, p.w1_lo, 0, bq, std::integral_constant<int, NS>{});   // the first weight fragments fly under the A operand's arrival / conversion
+  if (!PFW && !XA && DV_CHAIN_PFMODE == 2) l2_prefetch(wave, NWV);
   if (AMODE == 1) {
     // GroupNorm of the fp32 rows, once per row-block: table of this utterance, then convert
     const int T = p.T, b_item = m0 / T;
@@ -945,7 +965,8 @@ template <int NS, int AMODE, bool XA = false, bool SA = false, bool CS = false>
 hipError_t launch_one(const ChainParams& p, hipStream_t st) {
   const int smem = 2 * 2 * NS * CHUNK_PL + NS * 16384;
   static const bool no_pf = [] { const char* e = getenv("DVITS_CHAIN_PF"); return e && e[0] == '0'; }();   // experiment knob: no L2-prefetch wave
-  hipLaunchKernelGGL((k_chain2<NS, AMODE, XA, SA, CS>), dim3((p.M / BM) * ((((AMODE == 1 && !XA) || CS) && p.nsplit > 1) ? p.nsplit : 1)), dim3((XA || (SA && NS >= 3) || no_pf) ? NT : NT_LAUNCH), smem, st, p);
+  hipLaunchKernelGGL((k_chain2<NS, AMODE, XA, SA, CS>), dim3((p.M / BM) * ((((AMODE == 1 && !XA) || CS) && p.nsplit > 1) ? p.nsplit : 1)),
+                     dim3((!chain_pf_wave<NS, AMODE, XA, SA, CS>() || no_pf) ? NT : NT_LAUNCH), smem, st, p);
   return hipGetLastError();
 }
 
@@ -970,11 +991,9 @@ hipError_t chain_init() {
   if ((e = init_one<1, 0>()) != hipSuccess) return e;
   if ((e = init_one<2, 0>()) != hipSuccess) return e;
   if ((e = init_one<3, 0>()) != hipSuccess) return e;
-  if ((e = init_one<4, 0>()) != hipSuccess) return e;
   if ((e = init_one<1, 1>()) != hipSuccess) return e;
   if ((e = init_one<2, 1>()) != hipSuccess) return e;
   if ((e = init_one<3, 1>()) != hipSuccess) return e;
-  if ((e = init_one<4, 1>()) != hipSuccess) return e;
   if ((e = init_one<1, 1, false, true>()) != hipSuccess) return e;
   if ((e = init_one<2, 1, false, true>()) != hipSuccess) return e;
   if ((e = init_one<3, 1, false, true>()) != hipSuccess) return e;
@@ -1040,6 +1059,6 @@ hipError_t launch_chain2(const ChainParams& p, int precision, hipStream_t st) {
   if (p.sa_kf_hi) return ns == 1 ? launch_one<1, 1, false, true>(p, st) : (ns == 2 ? launch_one<2, 1, false, true>(p, st) : launch_one<3, 1, false, true>(p, st));
   if (p.amode == 0 && p.nsplit > 1) return ns == 2 ? launch_one<2, 0, false, false, true>(p, st) : launch_one<3, 0, false, false, true>(p, st);
   if (p.amode == 0)
-    return ns == 1 ? launch_one<1, 0>(p, st) : (ns == 2 ? launch_one<2, 0>(p, st) : (ns == 3 ? launch_one<3, 0>(p, st) : launch_one<4, 0>(p, st)));
-  return ns == 1 ? launch_one<1, 1>(p, st) : (ns == 2 ? launch_one<2, 1>(p, st) : (ns == 3 ? launch_one<3, 1>(p, st) : launch_one<4, 1>(p, st)));
+    return ns == 1 ? launch_one<1, 0>(p, st) : (ns == 2 ? launch_one<2, 0>(p, st) : launch_one<3, 0>(p, st));
+  return ns == 1 ? launch_one<1, 1>(p, st) : (ns == 2 ? launch_one<2, 1>(p, st) : launch_one<3, 1>(p, st));
 }

@@ -26,7 +26,7 @@
 #include <cstdlib>
 #include <type_traits>
 
-template <int BM, int BN, int BK, int WM, int WN, int NSPLIT, int KS, bool AF = false, bool AS = false>
+template <int BM, int BN, int BK, int WM, int WN, int NSPLIT, int KS, bool AF = false, bool BD = false>
 __global__ __launch_bounds__(64 * WM * WN * KS) void k_gemm(const GemmParams p) {
   extern __shared__ __attribute__((aligned(1024))) char smem[];
   // XCD-aware tile order (workgroup b runs on XCD b % 8; each XCD has its own L2, which starts cold): an XCD's workgroups
@@ -46,7 +46,7 @@ __global__ __launch_bounds__(64 * WM * WN * KS) void k_gemm(const GemmParams p) 
     const int x = bid & 7, i = bid >> 3;
     const int ks_i = x >> p.xcd_sh_mn, r = x & ((1 << p.xcd_sh_mn) - 1), xm_i = r >> p.xcd_sh_n, xn_i = r & (p.xcd_n - 1);
     const int lm = (i * p.xcd_inv_tn) >> 16, ln = i - lm * p.xcd_tn;
-    gemm_tile<BM, BN, BK, WM, WN, NSPLIT, KS, false, AF, AS>(p, (xm_i * p.xcd_tm + lm) * BM, (xn_i * p.xcd_tn + ln) * BN, smem, ks_i);
+    gemm_tile<BM, BN, BK, WM, WN, NSPLIT, KS, false, AF, BD>(p, (xm_i * p.xcd_tm + lm) * BM, (xn_i * p.xcd_tn + ln) * BN, smem, ks_i);
     return;
   }
   {
@@ -59,7 +59,7 @@ __global__ __launch_bounds__(64 * WM * WN * KS) void k_gemm(const GemmParams p) 
     ksel = bid / tiles;
     bid -= ksel * tiles;
   }
-  gemm_tile<BM, BN, BK, WM, WN, NSPLIT, KS, false, AF, AS>(p, (bid / n_tiles_n) * BM, (bid % n_tiles_n) * BN, smem, ksel);
+  gemm_tile<BM, BN, BK, WM, WN, NSPLIT, KS, false, AF, BD>(p, (bid / n_tiles_n) * BM, (bid % n_tiles_n) * BN, smem, ksel);
 }
 
 template <int BM, int BN, int BK, int WM, int WN, int NSPLIT, int KS>
@@ -109,34 +109,33 @@ struct GemmTileAF {
 using AF64 = GemmTileAF<64, 64, 2, 2, 2>;
 using AF32 = GemmTileAF<32, 64, 1, 2, 2>;
 
-// AS tile (A slab, gemm_tile.h): the 64x64x64 tile of the k = 3 convs - ring of 4 weight stages + 4 slab slots
+// BD tile (gemm_tile.h): weights fragment-major straight into registers, activations through per-chunk slab slots
 template <int NSPLIT>
-struct GemmCfgAS {
+struct GemmCfgBD {
   static constexpr int NPL = NSPLIT == 3 ? 2 : 1;
-  static constexpr int SMEM = 4 * 64 * 128 * NPL + 4 * (64 * 128 * NPL + 1024);
+  static constexpr int SMEM = 7 * (64 * 128 * NPL + 1024) > 65536 ? 7 * (64 * 128 * NPL + 1024) : 65536;   // (>= the k-group hand-over: 64 KiB)
   static hipError_t init() {
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm<64, 64, 64, 2, 2, NSPLIT, 2, false, true>),
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm<64, 64, 64, 1, 2, NSPLIT, 4, false, true>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
   }
   static hipError_t launch(const GemmParams& p, hipStream_t st) {
     const int tiles = (p.M / 64) * ((p.N + 63) / 64) * (p.sk_mode == 3 ? p.sk_split : 1);
-    hipLaunchKernelGGL((k_gemm<64, 64, 64, 2, 2, NSPLIT, 2, false, true>), dim3(tiles), dim3(512), SMEM, st, p);
+    hipLaunchKernelGGL((k_gemm<64, 64, 64, 1, 2, NSPLIT, 4, false, true>), dim3(tiles), dim3(512), SMEM, st, p);
     return hipGetLastError();
   }
 };
-// Can this GEMM run on the AS tile?  A k = 3 segment (that is where the slab pays), whole 64-channel chunks, 64-frame
-// tiles inside one utterance, plain row gather.
-static bool gemm_as_supported(const GemmParams& p) {
-  if (p.af || p.stride != 1 || p.up_mode != UP_NONE || p.T_in != p.T_out || p.T_out % 64 != 0 || p.M != p.B * p.T_out) return false;
-  if (p.ln_stat || p.epi == EPI_GEGLU || p.sk_mode == 1 || p.sk_mode == 2) return false;
-  bool k3 = false;
+// Can this GEMM run on the BD tile?  Fragment-major weights present, whole 64-channel chunks, 64-frame tiles inside one
+// utterance, plain row gather (stride 1, no upsample), k = 1 / 3 segments with 'same' padding, no GEGLU epilogue (its
+// [32 a | 32 gate] column blocks must sit in ONE wave; BD's waves own 32 columns).
+bool gemm_bd_supported(const GemmParams& p) {
+  if (!p.wf_hi || p.af || p.stride != 1 || p.up_mode != UP_NONE || p.T_in != p.T_out || p.T_out % 64 != 0 || p.M != p.B * p.T_out) return false;
+  if (p.epi == EPI_GEGLU || p.epi == EPI_STORE_NCT || p.sk_mode == 1 || p.sk_mode == 2 || p.Kp % 16 != 0 || p.N % 32 != 0) return false;
   for (int s2 = 0; s2 < p.nseg; ++s2) {
     const GemmSeg& sg = p.seg[s2];
     if (sg.c0 % 64 != 0 || sg.c1 % 64 != 0 || sg.c0 <= 0 || (sg.taps != 1 && sg.taps != 3) || sg.pad != (sg.taps - 1) / 2) return false;
     if (!sg.a0_hi || (sg.c1 > 0 && !sg.a1_hi)) return false;
-    k3 = k3 || sg.taps == 3;
   }
-  return k3;
+  return true;
 }
 
 template <int BM, int BN, int BK, int WM, int WN, int KS = 1>
@@ -208,8 +207,8 @@ hipError_t gemm_init() {
   if (e != hipSuccess) return e;
   if ((e = Tiles<64>::init()) != hipSuccess) return e;
   if ((e = AF64::init()) != hipSuccess) return e;
-  if ((e = GemmCfgAS<3>::init()) != hipSuccess) return e;
-  if ((e = GemmCfgAS<1>::init()) != hipSuccess) return e;
+  if ((e = GemmCfgBD<3>::init()) != hipSuccess) return e;
+  if ((e = GemmCfgBD<1>::init()) != hipSuccess) return e;
   return AF32::init();
 }
 
@@ -290,7 +289,11 @@ int gemm_candidates(const GemmParams& p, int* out, int cap) {
 
 // environment knobs of launch_gemm that tests flip inside one process: re-read whenever an engine is prepared
 static int g_env_xn = [] { const char* e = getenv("DVITS_XCD_N"); return e ? atoi(e) : -1; }();
-void gemm_env_refresh() { const char* e = getenv("DVITS_XCD_N"); g_env_xn = e ? atoi(e) : -1; }
+static int g_env_bd = [] { const char* e = getenv("DVITS_GEMM_BD"); return e ? atoi(e) : 1; }();
+void gemm_env_refresh() {
+  const char* e = getenv("DVITS_XCD_N"); g_env_xn = e ? atoi(e) : -1;
+  e = getenv("DVITS_GEMM_BD"); g_env_bd = e ? atoi(e) : 1;
+}
 
 // Tile (BM x BN) the shape heuristic of launch_gemm picks for a non-AF, non-GEGLU GEMM (kept in step with
 // Tiles<BK>::launch below; used to plan the in-epilogue GroupNorm: its tiles must not span utterances and must all be resident)
@@ -405,15 +408,12 @@ hipError_t launch_gemm(const GemmParams& pin, int precision, hipStream_t st) {
     p.seg[s].nkt = p.seg[s].taps * (p.seg[s].c0 + p.seg[s].c1) / bk;
   }
   if (ft != GT_AUTO) return bk == 64 ? Tiles<64>::launch_forced(p, x3, ft, st) : Tiles<32>::launch_forced(p, x3, ft, st);
-  {   // k = 3 convs on the 64x64 tile: the A-slab variant.  Parity-green, opt-in (DVITS_SLAB=1): measured SLOWER than the
-      // plain tile (k-loop 30.0 k vs 20.8 k cycles at M = 2048, K = 1152, N = 384) although it moves a third fewer bytes -
-      // DESIGN.md section 4 has the trace numbers and what was ruled out.
-    static const bool slab_off = [] { const char* e = getenv("DVITS_SLAB"); return !(e && e[0] == '1'); }();
+  {   // 64x64x64 tiles with fragment-major weights at hand: the BD tile (DVITS_GEMM_BD=0 keeps the plain tile: A/B runs)
     int bm, bn;
     gemm_pick_tile(p, bm, bn);
-    if (!slab_off && !big && bk == 64 && bm == 64 && bn == 64 && tune.ksplit && gemm_as_supported(p)) {
+    if (g_env_bd && !big && bk == 64 && bm == 64 && bn == 64 && tune.ksplit && (!x3 || p.wf_lo) && gemm_bd_supported(p)) {
       for (int s2 = 0; s2 < p.nseg; ++s2) p.seg[s2].nkt = p.seg[s2].taps * (p.seg[s2].c0 + p.seg[s2].c1) / 64;
-      return x3 ? GemmCfgAS<3>::launch(p, st) : GemmCfgAS<1>::launch(p, st);
+      return x3 ? GemmCfgBD<3>::launch(p, st) : GemmCfgBD<1>::launch(p, st);
     }
   }
   if (big) return tune.ksplit ? Tiles<32>::T0::launch(p, x3, st) : Tiles<32>::T0S::launch(p, x3, st);

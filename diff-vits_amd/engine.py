@@ -71,11 +71,10 @@ class UNetEngine:
         concurrently on one device) - the in-launch GroupNorm hand-over, which needs every workgroup of a launch resident
         at once, is then not used (see dv_unet_set_exclusive).  Takes effect at the next prepare."""
         self._exclusive = bool(exclusive)
-        slots = {id(sl): sl for sl in list(self._plans.values()) + [self._cur]}
-        for sl in slots.values():
-            _lib.check(_lib.lib().dv_unet_set_exclusive(sl.h, int(self._exclusive)), "dv_unet_set_exclusive")
-            sl.prepared = None
-        self._plans.clear()
+        # every cached schedule is stale: the handles of the non-current slots are destroyed (each holds its packed
+        # weights and slab), the current one is flagged and re-planned by the next prepare
+        self._prepared = None
+        _lib.check(_lib.lib().dv_unet_set_exclusive(self._cur.h, int(self._exclusive)), "dv_unet_set_exclusive")
         self._fwd_cond = None
 
     # the current schedule's native handle / key (read by the samplers, the bench and the tests)

@@ -974,3 +974,73 @@ def test_merged_ff_proj_out_matches_two_step(gold):
     g = gold("unet_oddT.npz")["y"]
     assert rel_l2(y.cpu().numpy(), g) < 2e-4 and rel_l2(y2.cpu().numpy(), g) < 2e-4
     assert rel_l2(y.cpu().numpy(), y2.cpu().numpy()) < 5e-5 and n_two == n_merged + 16
+
+
+def test_plans_with_different_nfe_share_one_engine_safely():
+    """a plan with MORE evaluations makes dv_unet_temb_all grow its time-embedding table; the graph a
+    plan with fewer evaluations captured earlier has the old table's addresses baked in.  The old buffers must stay alive
+    (they used to be freed: replaying plan A after plan B read and wrote freed memory).  A (8 evaluations) -> B (20) -> A
+    again on the same engine and shape: A's replay is bit-identical to its first run, and B matches its own step-by-step run."""
+    from diff_vits_amd import synth
+    from diff_vits_amd.sampler import dpm_solver
+    m, kw, sd, *_ = _build("cfg1")
+    x, cond, enc, mask = (torch.from_numpy(a).cuda() for a in synth.make_inputs(2, 80, 128, 64, seed=3))
+    ns = dpm_solver.NoiseScheduleVP("discrete", betas=torch.from_numpy(synth.make_betas()))
+    native = dpm_solver.NativeUNetModel(m, cond, enc, mask)
+    fn = dpm_solver.model_wrapper(native, ns, model_type="x_start")
+    sa = dpm_solver.DPM_Solver(fn, ns, algorithm_type="dpmsolver++")
+    sb = dpm_solver.DPM_Solver(fn, ns, algorithm_type="dpmsolver++")
+    with torch.no_grad():
+        a1 = sa.sample(x.clone(), steps=8, order=2, skip_type="time_uniform", method="multistep")
+        b1 = sb.sample(x.clone(), steps=20, order=2, skip_type="time_uniform", method="multistep")   # grows the table
+        filler = [torch.full((1 << 20,), float(i), device="cuda") for i in range(16)]                 # reuse freed memory, if any
+        a2 = sa.sample(x.clone(), steps=8, order=2, skip_type="time_uniform", method="multistep")    # replays A's graph
+        b2 = sb.sample(x.clone(), steps=20, order=2, skip_type="time_uniform", method="multistep")
+    torch.cuda.synchronize()
+    del filler
+    assert torch.isfinite(a2).all() and torch.equal(a1, a2)
+    assert torch.equal(b1, b2)
+    n_ho, bad = m.hip_engine().handover_status()
+    assert bad == 0
+
+
+def test_recycled_engine_handle_never_replays_a_stale_graph():
+    """schedule generations are process-global, so a handle that `new` places at a destroyed
+    handle's address cannot reproduce the (handle, generation) key of a captured graph.  Weights change between two runs
+    of one solver (every cached schedule handle is destroyed and re-created): the second result follows the new weights."""
+    from diff_vits_amd import synth
+    from diff_vits_amd.sampler import dpm_solver
+    m, kw, sd, *_ = _build("tiny")
+    kwt, B, T, L, _, _ = UNET_CASES["tiny"]
+    x, cond, enc, mask = (torch.from_numpy(a).cuda() for a in synth.make_inputs(B, 8, T, L, cond_channels=16, enc_dim=32, seed=5))
+    ns = dpm_solver.NoiseScheduleVP("discrete", betas=torch.from_numpy(synth.make_betas()))
+    native = dpm_solver.NativeUNetModel(m, cond, enc, mask)
+    solver = dpm_solver.DPM_Solver(dpm_solver.model_wrapper(native, ns, model_type="x_start"), ns, algorithm_type="dpmsolver++")
+    with torch.no_grad():
+        o1 = solver.sample(x.clone(), steps=4, order=2)
+        for _ in range(3):        # destroy / re-create the native handles a few times: addresses get recycled
+            with torch.no_grad():
+                m.conv_out.bias.add_(0.25)
+            o2 = solver.sample(x.clone(), steps=4, order=2)
+            native2 = dpm_solver.NativeUNetModel(m, cond, enc, mask)
+            ref = dpm_solver.DPM_Solver(dpm_solver.model_wrapper(native2, ns, model_type="x_start"), ns,
+                                        algorithm_type="dpmsolver++").sample(x.clone(), steps=4, order=2)
+            assert not torch.equal(o1, o2)
+            assert torch.equal(o2, ref)
+            o1 = o2
+
+
+def test_set_exclusive_destroys_cached_schedules():
+    """set_exclusive() used to drop the cached slots without destroying their native handles."""
+    m, *_ = _build("tiny")
+    eng = m.hip_engine()
+    for T in (32, 64, 96):
+        eng.prepare(1, T, 8)
+    slots = [sl for sl in eng._plans.values() if sl is not eng._cur]
+    assert len(slots) == 2 and all(sl.h.value for sl in slots)
+    eng.set_exclusive(False)
+    assert all(not sl.h.value for sl in slots) and not eng._plans      # native handles destroyed, not just forgotten
+    eng.prepare(1, 32, 8)
+    assert eng.handover_status()[0] == 0          # non-exclusive: no in-epilogue GroupNorm
+    eng.set_exclusive(True)
+    eng.prepare(1, 32, 8)
