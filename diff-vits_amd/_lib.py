@@ -58,6 +58,7 @@ SIGNATURES = {
     "dv_unet_persist_status": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "dv_unet_handover_status": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "dv_unet_set_exclusive": (C.c_int, [C.c_void_p, C.c_int32]),
+    "dv_unet_handover_reset": (C.c_int, [C.c_void_p]),
     "dv_unet_probe": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.c_int64, C.POINTER(C.c_int64)]),
     "dv_sampler_plan": (C.c_int, [C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                   C.POINTER(C.c_void_p)]),

@@ -57,6 +57,7 @@ struct GnxParams {
   const float* gamma; const float* beta;   // [N]
   const float* tscale; const float* tshift; int ld_t;   // temb scale / shift rows [B, ld_t] or null
   int groups; float eps; int silu;
+  int spin_max;                  // polls before a wait gives up (default 1 << 18, ~0.4 s; tests force time-outs with 1)
   bf16_t* y_hi; bf16_t* y_lo;    // normalised split planes [M, N]
 };
 
@@ -69,7 +70,7 @@ struct GemmParams {
   float up_scale;               // UP_SIZE: (float)T_in / T_virt, as ATen computes it
   const bf16_t* w_hi;           // [N_pad, Kp] bf16, row n = output channel, k contiguous
   const bf16_t* w_lo;           // low-order split (null in bf16 mode)
-  const bf16_t* wf_hi;          // the same planes FRAGMENT-major (launch_relayout_frag) or null: enables the BD tile (gemm_tile.h)
+  const bf16_t* wf_hi;          // the same planes FRAGMENT-major in chunk-major k order (launch_relayout_frag_cm) or null: enables the BD tile (gemm_tile.h)
   const bf16_t* wf_lo;
   int Kp;                       // packed K
   int N_pad;                    // rows present in w_hi/w_lo (multiple of 128)
@@ -203,6 +204,9 @@ hipError_t chain_init();
 hipError_t launch_chain2(const ChainParams& p, int precision, hipStream_t st);
 // packed weight plane [rows][Kp] -> fragment-major (rows % 32 == 0, Kp % 16 == 0), same size
 hipError_t launch_relayout_frag(const bf16_t* src, bf16_t* dst, int rows, int Kp, hipStream_t st);
+// ... with the k-steps in the BD tile's chunk-major walk (segment -> 64-channel chunk -> tap) of a GEMM whose segments have
+// taps0 / taps1 taps over cc0 / cc1 (= c0 + c1) channels (cc1 = 0: one segment); Kp = taps0 cc0 + taps1 cc1
+hipError_t launch_relayout_frag_cm(const bf16_t* src, bf16_t* dst, int rows, int Kp, int taps0, int cc0, int taps1, int cc1, hipStream_t st);
 
 struct AttnParams {
   const float* q; const float* k; const float* v; const float* bias;

@@ -6,10 +6,22 @@
 // LDS-DMA of 16 bytes per lane: LDS destination = wave-uniform `lds_dst` + lane*16 (M0 holds the
 // base), global source per lane.  Issued through asm so that hipcc neither counts it nor drains
 // it with vmcnt(0) at the next LDS read: the waits below are counted by hand.
+// (lds_dst goes through readfirstlane: a wave-uniform value that hipcc happens to hold in a vector register - e.g. the
+// result of an integer division - is otherwise handed to the "s" operand as a VGPR: "invalid operand for instruction";
+// for a value already in a scalar register the builtin folds away)
 __device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst) {
+  lds_dst = __builtin_amdgcn_readfirstlane(lds_dst);
   unsigned keep;
   asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
                : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+// ... with the source as wave-uniform base (scalar register pair) + per-lane 32-bit byte offset: no 64-bit vector address
+// arithmetic per instruction (the BD tile's producer waves issue nine of these per chunk)
+__device__ __forceinline__ void glds16_s(const void* sbase, unsigned voff, unsigned lds_dst) {
+  lds_dst = __builtin_amdgcn_readfirstlane(lds_dst);
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
 }
 __device__ __forceinline__ void glds16_sc1(const void* gsrc, unsigned lds_dst) {   // L1-bypassing variant
   unsigned keep;

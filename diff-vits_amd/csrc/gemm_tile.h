@@ -1,6 +1,9 @@
 // Implicit-GEMM tile routine shared by the per-launch kernel (kernels_gemm.hip) and the persistent per-XCD schedule
 // (persist.hip).  See kernels_gemm.hip for the design notes.
 #pragma once
+#ifndef DV_BD_AH
+#define DV_BD_AH 3    // BD tile: slab chunks in flight (LDS: (AH + 1) slots of 18 KiB); 7 measured slower: the start-up burst delays the first chunk by ~5 k cycles
+#endif
 #ifndef DV_GEMM_EXP
 // development knob (trace experiments on the plain tile's k-loop, WRONG results): 1 = B fragments read from LDS once, not per
 // k-tile; 2 = 1 + no B DMA; 3 = 2 + A fragments read once; 4 = no DMA inside the loop at all.  0 in every shipped build
@@ -163,10 +166,21 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int m0, con
   // (BD: the segment's plane pointers ride along in scalar registers - a segment-descriptor load from argument memory
   // inside the k-loop sits on every wave's critical path)
   struct AfIt { int seg, half, col, tap, taps, c0, c1, kbase, pad; const bf16_t* h0; const bf16_t* l0; const bf16_t* h1; const bf16_t* l1; };
+  // (BD: both segment descriptors are read ONCE, with constant indices, into scalars and selected by value: with a
+  // dynamically indexed p.seg[] inside the unrolled k-loop hipcc kept the whole argument block in scratch memory)
+  const GemmSeg bd_s0 = BD ? p.seg[0] : GemmSeg{}, bd_s1 = BD ? p.seg[1] : GemmSeg{};
+  const int bd_kbase1 = BD ? bd_s0.taps * (bd_s0.c0 + bd_s0.c1) : 0;
   auto af_enter = [&](AfIt& s) {
+    if (BD) {
+      const bool s1 = s.seg == 1 && p.nseg > 1;
+      s.taps = s1 ? bd_s1.taps : bd_s0.taps; s.c0 = s1 ? bd_s1.c0 : bd_s0.c0; s.c1 = s1 ? bd_s1.c1 : bd_s0.c1; s.pad = s1 ? bd_s1.pad : bd_s0.pad;
+      s.h0 = s1 ? bd_s1.a0_hi : bd_s0.a0_hi; s.l0 = s1 ? bd_s1.a0_lo : bd_s0.a0_lo;
+      s.h1 = s1 ? bd_s1.a1_hi : bd_s0.a1_hi; s.l1 = s1 ? bd_s1.a1_lo : bd_s0.a1_lo;
+      s.kbase = s.seg == 0 ? 0 : bd_kbase1;
+      return;
+    }
     const GemmSeg& sg = p.seg[s.seg < p.nseg ? s.seg : 0];
     s.taps = sg.taps; s.c0 = sg.c0; s.c1 = sg.c1; s.pad = sg.pad;
-    if (BD) { s.h0 = sg.a0_hi; s.l0 = sg.a0_lo; s.h1 = sg.a1_hi; s.l1 = sg.a1_lo; }
     s.kbase = s.seg == 0 ? 0 : p.seg[0].taps * (p.seg[0].c0 + p.seg[0].c1);
   };
   auto af_next = [&](AfIt& s) {
@@ -185,6 +199,10 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int m0, con
     af_enter(af0);
     if (p.sk_mode == 3) {                            // the split point moves to the next chunk boundary (a slab is per chunk)
       int cut = total_kt / p.sk_split;
+      if (BD) {   // inside the k = 3 run a range starts on a PAIR of chunks (the loop body): a multiple of 6 tiles
+        const int t3 = (bd_s0.taps == 3 ? 3 * ((bd_s0.c0 + bd_s0.c1) >> 6) : 0) + ((p.nseg > 1 && bd_s1.taps == 3) ? 3 * ((bd_s1.c0 + bd_s1.c1) >> 6) : 0);
+        if (cut < t3) cut = min(t3, (cut + 3) / 6 * 6);
+      }
       AfIt s = af0;
       for (int t = 0; t < cut; ++t) af_next(s);
       while (s.tap != 0 && cut < total_kt) { af_next(s); ++cut; }
@@ -253,36 +271,92 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int m0, con
   };
   AfIt af_is = af0;              // AF: tile being issued (runs NSTAGE-1 tiles ahead of the one being multiplied)
   // ---- BD: slab slots [BM rows hi | BM rows lo | halo: row -1 hi, row BM hi, row -1 lo, row BM lo] ----
-  constexpr int BD_MAIN_PL = BM * ROWB, BD_SLOT = BD_MAIN_PL * NPL + 1024;
-  constexpr int BD_AH = 6, BD_NSLOT = BD_AH + 1;     // chunks in flight; slot of chunk c + AH = slot of chunk c - 1 (finished)
-  constexpr int BD_IPW = BD ? BM / RPI / NWV : 0;    // main-row DMA instructions per wave per plane
-  const int bd_b = BD ? m0 / p.T_out : 0, bd_t0 = BD ? m0 - bd_b * p.T_out : 0;
-  int bd_vm = 0;                                     // vector-memory loads this wave has issued since the k-loop's prologue began
-  // DMA of chunk c (at tap 0) into `slot`; returns nothing, counts this wave's instructions in bd_vm
-  auto issue_slab = [&](const AfIt& c, int slot) {
-    const bf16_t* hi = c.half ? c.h1 : c.h0;
-    const bf16_t* lo = c.half ? c.l1 : c.l0;
-    const int ld = c.half ? c.c1 : c.c0;
-    const unsigned dst0 = smem_base + (unsigned)(slot * BD_SLOT);
-    const size_t row0 = (size_t)bd_b * p.T_in;
+  constexpr int BD_MAIN_PL = BM * ROWB, BD_SLOT = BD_MAIN_PL * NPL + 2048;   // (+ 1 KiB halo + 1 KiB target of the second producer's dummy)
+  constexpr int BD_AH = DV_BD_AH, BD_NSLOT = BD_AH + 1;     // chunks in flight; slot of chunk c + AH = slot of chunk c - 1 (finished)
+  constexpr int BD_DEPTH = 6;                        // weight units in flight per compute wave
+  constexpr int BD_PI = BM / RPI + 1;                // DMA instructions per producer wave per chunk (rows of one plane + halo / dummy)
+  static_assert(!BD || BD_PI * (BD_AH - 1) < 64, "producer wait count must fit vmcnt");
+  // chunks of this k-range: n3 with three taps, then n1 with one (launch_gemm checked the order and the alignment)
+  int bd_n3 = 0, bd_n1 = 0;
+  if (BD) {
+    const int t_s0 = bd_s0.taps * ((bd_s0.c0 + bd_s0.c1) >> 6), t_s1 = p.nseg > 1 ? bd_s1.taps * ((bd_s1.c0 + bd_s1.c1) >> 6) : 0;
+    const int lo0 = min(kt0, t_s0), hi0 = min(kt0 + nk, t_s0);                         // tiles of this range inside segment 0
+    const int lo1 = max(kt0, t_s0) - t_s0, hi1 = max(kt0 + nk, t_s0) - t_s0;           // ... inside segment 1
+    const int ch0 = (hi0 - lo0) / bd_s0.taps, ch1 = t_s1 > 0 ? (hi1 - lo1) / bd_s1.taps : 0;
+    if (bd_s0.taps == 3) bd_n3 += ch0; else bd_n1 += ch0;
+    if (t_s1 > 0) { if (bd_s1.taps == 3) bd_n3 += ch1; else bd_n1 += ch1; }
+  }
+  // ---- BD: the two PRODUCER waves (waves NWV, NWV + 1) ----
+  // They own the slab DMAs - wave NWV the hi plane and the halo lines, wave NWV + 1 the lo plane - so that the compute
+  // waves' vector-memory queues hold nothing but their weight units (compiler-visible loads, exact counted waits; with the
+  // DMAs in the same queue every weight wait also drained the slabs issued behind it).  A producer issues exactly BD_PI
+  // instructions per chunk (past the k-range: dummies from the zero page into the slot of a finished chunk), so "the slab
+  // of chunk c has landed" is the constant wait vmcnt(BD_PI * (AH - 1)); it then meets the compute waves at the chunk's
+  // barrier and issues the slab of chunk c + AH into the slot of chunk c - 1, which every wave has left.
+  if (BD && wave >= NWV) {
+    const int pw = wave - NWV;
+    const int b_item = m0 / p.T_out, t0 = m0 - b_item * p.T_out;
+    const size_t row0 = (size_t)b_item * p.T_in;
+    AfIt s_it = af0;
+    int s_left = nk, s_slot = 0;
+    // Lean issue (the producers' instruction count per chunk bounds the k = 1 runs): the per-lane byte offsets of the eight
+    // row groups inside a plane depend only on the plane's row pitch - recomputed when that changes (concat half / segment
+    // boundary) -, the plane's base + chunk column is a scalar pair, and a DMA is "scalar base + vector offset".
+    unsigned roff[BM / RPI], hoff = 0;
+    bool hok = false;
+    int cur_ld = -1;
+    auto set_pitch = [&](int ld) {
+      cur_ld = ld;
 #pragma unroll
-    for (int q = 0; q < BD_IPW; ++q) {
-      const int r = (q * NWV + wave) * RPI + l_row;
-      const size_t e = (row0 + bd_t0 + r) * ld + c.col + ((l_slot ^ swz(r)) << 3);
-      glds16(hi + e, dst0 + (unsigned)(((q * NWV + wave) * RPI) * ROWB));
-      if (SPLIT) glds16(lo + e, dst0 + (unsigned)(BD_MAIN_PL + ((q * NWV + wave) * RPI) * ROWB));
-    }
-    bd_vm += BD_IPW * NPL;
-    if (wave == 0 && c.taps > 1) {   // halo rows t0 - 1 and t0 + BM of both planes: one lane-linear instruction (lanes 32.. repeat)
+      for (int q = 0; q < BM / RPI; ++q) {
+        const int r = q * RPI + l_row;
+        roff[q] = (unsigned)(((t0 + r) * ld + ((l_slot ^ swz(r)) << 3)) * 2);
+      }
+      // halo rows t0 - 1 and t0 + BM of both planes: one lane-linear instruction (lanes 32.. repeat)
       const int which = (lane >> 3) & 3, ch = lane & 7;
-      const int t = (which & 1) ? bd_t0 + BM : bd_t0 - 1;
-      const bf16_t* pl = (which >> 1) ? lo : hi;
-      const bool ok = t >= 0 && t < p.T_in && pl != nullptr;   // conv zero padding beyond the utterance
-      const void* src = ok ? (const void*)(pl + (row0 + t) * ld + c.col + ch * 8) : (const void*)p.zero_page;
-      glds16(src, dst0 + (unsigned)(BD_MAIN_PL * NPL));
-      bd_vm += 1;
+      const int t = (which & 1) ? t0 + BM : t0 - 1;
+      hok = t >= 0 && t < p.T_in;                    // conv zero padding beyond the utterance
+      hoff = (unsigned)((t * ld + ch * 8) * 2);
+    };
+    auto slab = [&]() {
+      const bool real = s_left > 0;
+      const bf16_t* hi = s_it.half ? s_it.h1 : s_it.h0;
+      const bf16_t* lo = s_it.half ? s_it.l1 : s_it.l0;
+      const bf16_t* pl = pw ? lo : hi;
+      const int ld = s_it.half ? s_it.c1 : s_it.c0;
+      const unsigned dst0 = smem_base + (unsigned)(__builtin_amdgcn_readfirstlane(s_slot) * BD_SLOT);
+      if (real && pl != nullptr) {
+        if (ld != cur_ld) set_pitch(ld);
+        const char* base = reinterpret_cast<const char*>(pl) + (row0 * ld + s_it.col) * 2;
+#pragma unroll
+        for (int q = 0; q < BM / RPI; ++q) glds16_s(base, roff[q], dst0 + (unsigned)(pw * BD_MAIN_PL + (q * RPI) * ROWB));
+        if (pw == 0) {
+          const int which = (lane >> 3) & 3;
+          const bf16_t* hp = (which >> 1) ? lo : hi;
+          const bool ok = hok && hp != nullptr;
+          const void* src = ok ? (const void*)(reinterpret_cast<const char*>(hp) + (row0 * ld + s_it.col) * 2 + hoff) : (const void*)p.zero_page;
+          glds16(src, dst0 + (unsigned)(BD_MAIN_PL * NPL));
+        } else {
+          glds16(p.zero_page, dst0 + (unsigned)(BD_MAIN_PL * NPL + 1024));
+        }
+      } else {                                       // past the k-range (or no lo plane): BD_PI dummies, the count is what matters
+#pragma unroll
+        for (int q = 0; q < BD_PI; ++q) glds16(p.zero_page, dst0 + (unsigned)(BD_MAIN_PL * NPL + 1024));
+      }
+      if (real) { s_left -= s_it.taps; s_it.tap = s_it.taps - 1; af_next(s_it); }
+      s_slot = s_slot + 1 == BD_NSLOT ? 0 : s_slot + 1;
+    };
+    for (int j = 0; j < BD_AH; ++j) slab();
+    if (p.ln_stat && p.sk_mode != 1) __syncthreads();   // (the compute waves' LayerNorm-row barrier)
+    const int nch = bd_n3 + bd_n1;
+    for (int c = 0; c < nch; ++c) {
+      wait_vmcnt<BD_PI * (BD_AH - 1)>();               // slab c has landed: only the AH - 1 younger ones may be in flight
+      __builtin_amdgcn_s_barrier();                    // chunk c visible; every wave has left chunk c - 1
+      slab();
     }
-  };
+    wait_vmcnt<0>();                                   // (the trailing dummies land before this wave ends: the compute waves'
+    return;                                            //  next barrier - they reuse the slots - completes only after that)
+  }
   auto issue = [&](int kt) {     // whole tile at once (prologue)
     if (CM) af_issue_koff = af_koff(af_is);
     else prep_a();
@@ -452,15 +526,15 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int m0, con
   };
 
   // residual operand of small tiles: fetched before the k-loop so its latency hides under it
-  constexpr bool PRE_RES = FM * FN <= 2;
-  float rpre[PRE_RES ? FM * FN * 16 : 1];
+  constexpr bool PRE_RES = !BD && FM * FN <= 2;       // (BD: the 168-VGPR budget of a 640-thread workgroup has no room for it)
+  float rpre[PRE_RES ? (BD ? FN : FM * FN) * 16 : 1];   // (BD: a wave finishes ONE row fragment)
   if (PRE_RES && p.epi == EPI_RESIDUAL && p.sk_mode != 1) {   // (mode 3: half of the workgroups prefetch in vain)
 #pragma unroll
     for (int i = 0; i < FM; ++i) {
       if (BD && i != kgrp) continue;                 // (BD: k-group i finishes row fragment i)
       const size_t ro = (size_t)min(m0 + (wm * FM + i) * 32 + l31, p.M - 1) * p.ldres;
 #pragma unroll
-      for (int j = 0; j < FN; ++j) load_row16(p.res, ro, n0 + (wn * FN + j) * 32 + 4 * lh, &rpre[(j * FM + i) * 16]);
+      for (int j = 0; j < FN; ++j) load_row16(p.res, ro, n0 + (wn * FN + j) * 32 + 4 * lh, &rpre[(BD ? j : j * FM + i) * 16]);
     }
   }
 
@@ -645,124 +719,132 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int m0, con
   // NSTAGE-1 tiles are in flight; the counted vmcnt leaves the younger ones outstanding across the barrier
   DV_TRACE(10);    // residual prefetch / LayerNorm rows / bias DMA issued
   if constexpr (BD) {
-    // ---- BD k-loop ----
-    // Per wave the in-order vector-memory queue holds, after the prologue's odds and ends, only slab DMAs (asm, counted in
-    // bd_vm) and weight units (compiler-visible loads, NPL per unit, counted in bd_vm as they are requested).  mark[j] =
-    // bd_vm right after the slab of the j-th chunk in flight was issued: when that chunk is opened, exactly bd_vm - mark[0]
-    // younger loads may still be outstanding (loads complete in order), so `vmcnt(bd_vm - mark[0])` waits for the slab and
-    // for nothing younger.  The marks shift by one per chunk: static register indices.
-    constexpr int DEPTH = 8;                         // weight units in flight per wave (hi + lo fragment: 8 VGPRs each)
+    // ---- BD k-loop (compute waves) ----
+    // The instruction count per k-tile is what bounds these loops (a SIMD issues one scalar / vector instruction of a
+    // wave every four cycles: the first BD version, with three generic k-iterators per tile, ran ~150 instructions per
+    // k-tile and was no faster than the plain tile).  Everything per-tile is therefore a constant or one add:
+    //   * W is stored fragment-major in THIS loop's tile order (chunk-major: engine, launch_relayout_frag_cm): the unit of
+    //     local tile t + 1 is 4 KiB behind the unit of tile t (uniform base pointer + per-lane offset).  The refills are
+    //     UNCONDITIONAL (past the range they re-read the last unit): only then can hipcc count its own waits exactly
+    //     (vmcnt(2 (DEPTH - 1))); with conditional refills it drained the queue once per loop body;
+    //   * the LDS offsets of the three row shifts (-1 / 0 / +1, halo lanes included) are per-lane constants, computed once;
+    //   * the k-range is a run of k = 3 chunks followed by a run of k = 1 chunks (either may be empty), each with its own
+    //     statically unrolled body (2 chunks x 3 taps / 6 chunks): the weight ring's register index is a constant;
+    //   * the slabs are the producer waves' business: a compute wave only meets them at the chunk's barrier.
+    constexpr int DEPTH = BD_DEPTH;
+    static_assert(DEPTH == 6, "bodies of 6 tiles");
     struct BFrag { bf16x8 h, l; };
     BFrag bq[DEPTH];
     const int ksteps = p.Kp >> 4;
-    const size_t wf_base = ((size_t)((n0 >> 5) + wn) * ksteps + kgrp) * 512 + lane * 8;   // + (packed k / 16) * 512
-    AfIt b_it = af0;                                 // tile whose weight unit is requested next
-    int b_left = nk;
+    const size_t b_first = (((size_t)((n0 >> 5) + wn) * ksteps + (size_t)kt0 * 4 + kgrp) * 512) * 2;   // bytes
+    const char* const b_hi = reinterpret_cast<const char*>(p.wf_hi) + b_first;     // wave-uniform
+    const char* const b_lo = SPLIT ? reinterpret_cast<const char*>(p.wf_lo) + b_first : nullptr;
+    const unsigned b_lane = lane * 16;
+    const unsigned b_max = (unsigned)max(nk - 1, 0) * 4096u;
+    unsigned b_off = 0;
     auto load_b = [&](BFrag& f) {
-      const size_t e = wf_base + (size_t)(af_koff(b_it) >> 4) * 512;
-      f.h = *reinterpret_cast<const bf16x8*>(p.wf_hi + e);
-      if (SPLIT) f.l = *reinterpret_cast<const bf16x8*>(p.wf_lo + e);
-      af_next(b_it); --b_left;
-      bd_vm += NPL;
+      f.h = *reinterpret_cast<const bf16x8*>(b_hi + b_off + b_lane);
+      if (SPLIT) f.l = *reinterpret_cast<const bf16x8*>(b_lo + b_off + b_lane);
+      b_off = min(b_off + 4096u, b_max);
     };
-    auto wait_n = [&](int n) {
-      switch (n) {
-#define DV_W(k) case k: wait_vmcnt<k>(); break;
-        DV_W(1) DV_W(2) DV_W(3) DV_W(4) DV_W(5) DV_W(6) DV_W(7) DV_W(8) DV_W(9) DV_W(10) DV_W(11) DV_W(12) DV_W(13) DV_W(14) DV_W(15)
-        DV_W(16) DV_W(17) DV_W(18) DV_W(19) DV_W(20) DV_W(21) DV_W(22) DV_W(23) DV_W(24) DV_W(25) DV_W(26) DV_W(27) DV_W(28) DV_W(29)
-        DV_W(30) DV_W(31) DV_W(32) DV_W(33) DV_W(34) DV_W(35) DV_W(36) DV_W(37) DV_W(38) DV_W(39) DV_W(40)
-#undef DV_W
-        default: wait_vmcnt<0>(); break;
-      }
-    };
-    static_assert((BD_AH - 1) * (BD_IPW * NPL + 1) + DEPTH * NPL <= 40, "BD wait table");
-    // slabs of the first AH chunks, then the first DEPTH weight units
-    AfIt s_it = af0;                                 // chunk whose slab is issued next (at tap 0)
-    int s_left = nk, s_slot = 0;                     // tiles not yet covered by an issued slab; slot of the next slab
-    int mark[BD_AH];
-    auto next_slab = [&]() {
-      if (s_left > 0) {
-        issue_slab(s_it, s_slot);
-        s_left -= s_it.taps;
-        s_it.tap = s_it.taps - 1; af_next(s_it);     // first tile of the next chunk
-      }
-      s_slot = s_slot + 1 == BD_NSLOT ? 0 : s_slot + 1;
-    };
+    const int n3 = bd_n3, n1 = bd_n1;
+    // per-lane LDS offsets inside a slot: [row shift + 1][fragment]; rows -1 / BM live in the halo lines
+    int ao_hi[3][FM], ao_lo[3][FM];
 #pragma unroll
-    for (int j = 0; j < BD_AH; ++j) { next_slab(); mark[j] = bd_vm; }
-#pragma unroll
-    for (int j = 0; j < DEPTH; ++j)
-      if (b_left > 0) load_b(bq[j]);
-    __builtin_amdgcn_sched_barrier(0);
-    DV_TRACE(1);
-    AfIt cs = af0;                                   // tile being multiplied
-    int c_slot = 0;                                  // its chunk's slot
-    bf16x8 ah[2][FM], al[2][FM];
-    // fragments of tap `tap` of the chunk in slot c_slot: slab row = tile row + tap - pad; rows -1 / BM live in the halo
-    auto read_a = [&](int buf, int tap, int pad) {
-      const char* a_hi = smem + c_slot * BD_SLOT;
-      const int d = tap - pad, chunk = kgrp * 2 + lh;
+    for (int d = 0; d < 3; ++d)
 #pragma unroll
       for (int i = 0; i < FM; ++i) {
-        const int row = i * 32 + l31 + d;
+        const int row = i * 32 + l31 + d - 1, chunk = kgrp * 2 + lh;
         const bool inb = (unsigned)row < (unsigned)BM;
         const int hoff = BD_MAIN_PL * NPL + (row < 0 ? 0 : ROWB) + (chunk << 4);
-        const int off = inb ? row * ROWB + ((chunk ^ swz(row)) << 4) : hoff;
-        ah[buf][i] = *reinterpret_cast<const bf16x8*>(a_hi + off);
-        if (SPLIT) al[buf][i] = *reinterpret_cast<const bf16x8*>(a_hi + (inb ? off + BD_MAIN_PL : hoff + 2 * ROWB));
+        ao_hi[d][i] = inb ? row * ROWB + ((chunk ^ swz(row)) << 4) : hoff;
+        ao_lo[d][i] = inb ? ao_hi[d][i] + BD_MAIN_PL : hoff + 2 * ROWB;
+      }
+    // (pinned in order: hipcc's waits at the loop head are the minimum over both ways into the loop - a first unit whose
+    // lo plane was requested LAST here cost a near-drain of the queue per loop body)
+#pragma unroll
+    for (int j = 0; j < DEPTH; ++j) { load_b(bq[j]); __builtin_amdgcn_sched_barrier(0); }
+    DV_TRACE(1);
+    bf16x8 ah[2][FM], al[2][FM];
+    const char* slot = smem;                         // slab slot of the chunk being multiplied
+    int c_slot = 0;
+    auto read_a = [&](int buf, int d) {
+#pragma unroll
+      for (int i = 0; i < FM; ++i) {
+        ah[buf][i] = *reinterpret_cast<const bf16x8*>(slot + ao_hi[d][i]);
+        if (SPLIT) al[buf][i] = *reinterpret_cast<const bf16x8*>(slot + ao_lo[d][i]);
       }
     };
-#ifdef DV_GEMM_TRACING
-    unsigned long long tr_vm = 0, tr_bar = 0;
-#endif
-    for (int t0 = 0; t0 < nk; t0 += DEPTH) {
+    auto mul_tile = [&](BFrag& f, int buf) {
 #pragma unroll
-      for (int u = 0; u < DEPTH; ++u) {
-        if (t0 + u < nk) {                           // (wave-uniform)
-          constexpr int dummy = 0; (void)dummy;
-          const int buf = u & 1;
-          if (cs.tap == 0) {
-            // open the chunk: its slab has landed (this wave's part), every wave is done with the previous chunk
-#ifdef DV_GEMM_TRACING
-            const unsigned long long tr0 = __builtin_amdgcn_s_memtime();
-#endif
-            wait_n(bd_vm - mark[0]);
-#ifdef DV_GEMM_TRACING
-            const unsigned long long tr1 = __builtin_amdgcn_s_memtime();
-#endif
-            __builtin_amdgcn_s_barrier();
-#ifdef DV_GEMM_TRACING
-            tr_vm += tr1 - tr0; tr_bar += __builtin_amdgcn_s_memtime() - tr1;
-            if (t0 + u == 0) DV_TRACE(2);
-#endif
+      for (int term = 0; term < NTERM; ++term)
 #pragma unroll
-            for (int j = 0; j + 1 < BD_AH; ++j) mark[j] = mark[j + 1];
-            next_slab();                             // into the slot of the chunk just finished
-            mark[BD_AH - 1] = bd_vm;
-            read_a(buf, 0, cs.pad);
-          }
-          if (cs.tap + 1 < cs.taps) read_a(buf ^ 1, cs.tap + 1, cs.pad);   // next tap's fragments fly under this tap's MFMAs
-          __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-          for (int term = 0; term < NTERM; ++term)
-#pragma unroll
-            for (int i = 0; i < FM; ++i) {
-              if (SPLIT && term == 0) acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bq[u].h, al[buf][i], acc[i][0], 0, 0, 0);
-              else if (SPLIT && term == 1) acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bq[u].l, ah[buf][i], acc[i][0], 0, 0, 0);
-              else acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bq[u].h, ah[buf][i], acc[i][0], 0, 0, 0);
-            }
-          // pinned: without the scheduling barriers hipcc sinks the refill down to its use (load -> wait -> MFMA)
-          __builtin_amdgcn_sched_barrier(0);
-          if (b_left > 0) load_b(bq[u]);
-          __builtin_amdgcn_sched_barrier(0);
-          af_next(cs);
-          if (cs.tap == 0) c_slot = c_slot + 1 == BD_NSLOT ? 0 : c_slot + 1;
+        for (int i = 0; i < FM; ++i) {
+          if (SPLIT && term == 0) acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.h, al[buf][i], acc[i][0], 0, 0, 0);
+          else if (SPLIT && term == 1) acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.l, ah[buf][i], acc[i][0], 0, 0, 0);
+          else acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.h, ah[buf][i], acc[i][0], 0, 0, 0);
         }
-      }
-    }
+      // pinned: without the scheduling barriers hipcc sinks the refill down to its use (load -> wait -> MFMA)
+      __builtin_amdgcn_sched_barrier(0);
+      load_b(f);
+      __builtin_amdgcn_sched_barrier(0);
+    };
+    auto close_chunk = [&]() {
+      c_slot = c_slot + 1 == BD_NSLOT ? 0 : c_slot + 1;
+      slot = smem + c_slot * BD_SLOT;
+    };
 #ifdef DV_GEMM_TRACING
-    if (threadIdx.x == 0 && blockIdx.x < 8192) {
-      g_gemm_trace[blockIdx.x * 16 + 12] = tr_vm; g_gemm_trace[blockIdx.x * 16 + 13] = tr_bar; g_gemm_trace[blockIdx.x * 16 + 14] = 0;
+    bool tr_first = true;
+    unsigned long long tr_bar = 0, tr_mul = 0, tr_t0 = 0;
+#endif
+    // one k = 3 chunk on weight units u0 .. u0 + 2; one k = 1 chunk on unit u
+    auto chunk3 = [&](BFrag& f0, BFrag& f1, BFrag& f2) {
+#ifdef DV_GEMM_TRACING
+      tr_t0 = __builtin_amdgcn_s_memtime();
+#endif
+      __builtin_amdgcn_s_barrier();                  // this chunk's slab is visible (producer waves)
+#ifdef DV_GEMM_TRACING
+      if (tr_first) { DV_TRACE(2); tr_first = false; }
+      else tr_bar += __builtin_amdgcn_s_memtime() - tr_t0;
+      tr_t0 = __builtin_amdgcn_s_memtime();
+#endif
+      read_a(0, 0);
+      read_a(1, 1);
+      __builtin_amdgcn_sched_barrier(0);
+      mul_tile(f0, 0);
+      read_a(0, 2);
+      __builtin_amdgcn_sched_barrier(0);
+      mul_tile(f1, 1);
+      mul_tile(f2, 0);
+      close_chunk();
+#ifdef DV_GEMM_TRACING
+      tr_mul += __builtin_amdgcn_s_memtime() - tr_t0;
+#endif
+    };
+    auto chunk1 = [&](BFrag& f, int buf) {
+      __builtin_amdgcn_s_barrier();
+#ifdef DV_GEMM_TRACING
+      if (tr_first) { DV_TRACE(2); tr_first = false; }
+#endif
+      read_a(buf, 1);
+      __builtin_amdgcn_sched_barrier(0);
+      mul_tile(f, buf);
+      close_chunk();
+    };
+    // (full bodies carry no guards: only then are hipcc's counted weight waits exact at the loop heads.  n3 is even -
+    // launch_gemm's rule, also for both halves of a split-K pair -, so only the k = 1 run has a remainder, at the very end.)
+    for (int c3 = 0; c3 < n3; c3 += 2) { chunk3(bq[0], bq[1], bq[2]); chunk3(bq[3], bq[4], bq[5]); }
+    int c1 = 0;
+    for (; c1 + DEPTH <= n1; c1 += DEPTH) {
+#pragma unroll
+      for (int u = 0; u < DEPTH; ++u) chunk1(bq[u], u & 1);
+    }
+#pragma unroll
+    for (int u = 0; u < DEPTH; ++u)
+      if (c1 + u < n1) chunk1(bq[u], u & 1);
+#ifdef DV_GEMM_TRACING
+    if (threadIdx.x == 0 && blockIdx.x < 8192) {   // k = 3 chunks after the first: cycles at the barrier | reading + multiplying
+      g_gemm_trace[blockIdx.x * 16 + 12] = 0; g_gemm_trace[blockIdx.x * 16 + 13] = tr_bar; g_gemm_trace[blockIdx.x * 16 + 14] = tr_mul;
     }
 #endif
   } else {
@@ -1055,7 +1137,7 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int m0, con
       if (p.epi == EPI_RESIDUAL) {
         if (PRE_RES) {
 #pragma unroll
-          for (int r = 0; r < 16; ++r) rv[r] = rpre[(j * FM + i) * 16 + r];
+          for (int r = 0; r < 16; ++r) rv[r] = rpre[(BD ? j : j * FM + i) * 16 + r];
         } else {
           load_row16(p.res, (size_t)mc * p.ldres, nf, rv);
         }
@@ -1195,7 +1277,11 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int m0, con
           }
         }
         if (__all(ok)) break;
-        if (spins > (1 << 18)) {
+        // (another launch has already given up: the run is lost and will be repeated on the fallback schedule - do not
+        // spend ~0.4 s per GEMM waiting for partners that a foreign kernel keeps off the CUs)
+        const bool lost = (spins & 63) == 63 && __hip_atomic_load(p.gnx.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u;
+        if (lost) break;
+        if (spins > p.gnx.spin_max) {
           if (lane == 0) {               // which GEMM, which workgroup, which group: reported by the next host call
             p.gnx.status[1] = (unsigned)(size_t)p.gnx.xchg; p.gnx.status[2] = blockIdx.x; p.gnx.status[3] = (unsigned)g;
             p.gnx.status[4] = (unsigned)__builtin_popcountll(__ballot(!ok));

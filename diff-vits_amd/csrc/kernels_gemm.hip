@@ -27,7 +27,7 @@
 #include <type_traits>
 
 template <int BM, int BN, int BK, int WM, int WN, int NSPLIT, int KS, bool AF = false, bool BD = false>
-__global__ __launch_bounds__(64 * WM * WN * KS) void k_gemm(const GemmParams p) {
+__global__ __launch_bounds__(64 * WM * WN * KS + (BD ? 128 : 0)) void k_gemm(const GemmParams p) {   // (BD: + two producer waves)
   extern __shared__ __attribute__((aligned(1024))) char smem[];
   // XCD-aware tile order (workgroup b runs on XCD b % 8; each XCD has its own L2, which starts cold): an XCD's workgroups
   // form a rectangle of the tile grid so that its L2 fetches (rows / xm) of A and (columns / xn) of W once.
@@ -113,14 +113,14 @@ using AF32 = GemmTileAF<32, 64, 1, 2, 2>;
 template <int NSPLIT>
 struct GemmCfgBD {
   static constexpr int NPL = NSPLIT == 3 ? 2 : 1;
-  static constexpr int SMEM = 7 * (64 * 128 * NPL + 1024) > 65536 ? 7 * (64 * 128 * NPL + 1024) : 65536;   // (>= the k-group hand-over: 64 KiB)
+  static constexpr int SMEM = ((DV_BD_AH + 1) * (64 * 128 * NPL + 2048)) > 65536 ? ((DV_BD_AH + 1) * (64 * 128 * NPL + 2048)) : 65536;   // BD_NSLOT slab slots (>= the 64 KiB k-group hand-over)
   static hipError_t init() {
     return hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm<64, 64, 64, 1, 2, NSPLIT, 4, false, true>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
   }
   static hipError_t launch(const GemmParams& p, hipStream_t st) {
     const int tiles = (p.M / 64) * ((p.N + 63) / 64) * (p.sk_mode == 3 ? p.sk_split : 1);
-    hipLaunchKernelGGL((k_gemm<64, 64, 64, 1, 2, NSPLIT, 4, false, true>), dim3(tiles), dim3(512), SMEM, st, p);
+    hipLaunchKernelGGL((k_gemm<64, 64, 64, 1, 2, NSPLIT, 4, false, true>), dim3(tiles), dim3(640), SMEM, st, p);
     return hipGetLastError();
   }
 };
@@ -129,13 +129,18 @@ struct GemmCfgBD {
 // [32 a | 32 gate] column blocks must sit in ONE wave; BD's waves own 32 columns).
 bool gemm_bd_supported(const GemmParams& p) {
   if (!p.wf_hi || p.af || p.stride != 1 || p.up_mode != UP_NONE || p.T_in != p.T_out || p.T_out % 64 != 0 || p.M != p.B * p.T_out) return false;
-  if (p.epi == EPI_GEGLU || p.epi == EPI_STORE_NCT || p.sk_mode == 1 || p.sk_mode == 2 || p.Kp % 16 != 0 || p.N % 32 != 0) return false;
+  if (p.epi == EPI_GEGLU || p.sk_mode == 1 || p.sk_mode == 2 || p.Kp % 16 != 0 || p.N_pad % 64 != 0) return false;
+  int k_tot = 0;
   for (int s2 = 0; s2 < p.nseg; ++s2) {
     const GemmSeg& sg = p.seg[s2];
     if (sg.c0 % 64 != 0 || sg.c1 % 64 != 0 || sg.c0 <= 0 || (sg.taps != 1 && sg.taps != 3) || sg.pad != (sg.taps - 1) / 2) return false;
     if (!sg.a0_hi || (sg.c1 > 0 && !sg.a1_hi)) return false;
+    // the k = 3 run comes first and is walked two chunks per loop body (gemm_tile.h)
+    if (sg.taps == 3 && ((sg.c0 + sg.c1) / 64) % 2 != 0) return false;
+    if (s2 == 1 && sg.taps == 3 && p.seg[0].taps == 1) return false;
+    k_tot += sg.taps * (sg.c0 + sg.c1);
   }
-  return true;
+  return k_tot == p.Kp;
 }
 
 template <int BM, int BN, int BK, int WM, int WN, int KS = 1>
@@ -411,7 +416,11 @@ hipError_t launch_gemm(const GemmParams& pin, int precision, hipStream_t st) {
   {   // 64x64x64 tiles with fragment-major weights at hand: the BD tile (DVITS_GEMM_BD=0 keeps the plain tile: A/B runs)
     int bm, bn;
     gemm_pick_tile(p, bm, bn);
-    if (g_env_bd && !big && bk == 64 && bm == 64 && bn == 64 && tune.ksplit && (!x3 || p.wf_lo) && gemm_bd_supported(p)) {
+    // where it pays (phase traces): the k = 3 run must be long enough to amortise the tile's start-up (producer
+    // waves, 4-way k-group hand-over) - DVITS_GEMM_BD=<min packed K of the k = 3 segment>, 2: every GEMM the tile can run
+    const int k3 = p.seg[0].taps == 3 ? 3 * (p.seg[0].c0 + p.seg[0].c1) : 0;
+    const bool pays = g_env_bd == 2 || (g_env_bd == 1 ? (p.nseg == 1 && k3 >= 1920) : (p.nseg == 1 && k3 >= g_env_bd));
+    if (g_env_bd && pays && !big && bk == 64 && bm == 64 && bn == 64 && tune.ksplit && (!x3 || p.wf_lo) && gemm_bd_supported(p)) {
       for (int s2 = 0; s2 < p.nseg; ++s2) p.seg[s2].nkt = p.seg[s2].taps * (p.seg[s2].c0 + p.seg[s2].c1) / 64;
       return x3 ? GemmCfgBD<3>::launch(p, st) : GemmCfgBD<1>::launch(p, st);
     }

@@ -52,6 +52,7 @@ class UNetEngine:
         self.prepare_serial = 0         # bumped whenever another schedule becomes current (the caller must set_cond again)
         self.plan_builds = 0            # native prepares really run (a cached shape does not count)
         self._fwd_cond = None           # forward(): the (enc, mask) tensors the engine is currently conditioned on
+        self.handover_downgraded = False  # an in-launch GroupNorm hand-over timed out once: this engine runs the k_gn_apply schedule now
 
     class _Slot:
         __slots__ = ("h", "weight_sig", "prepared", "cond_keepalive")
@@ -190,8 +191,14 @@ class UNetEngine:
         B, cx, T = x.shape
         if out is None:
             out = torch.empty((B, self.out_channels, T), device=x.device, dtype=torch.float32)
-        _lib.check(_lib.lib().dv_unet_forward(self._h, _lib.ptr(x), cx, _lib.ptr(cond), _lib.ptr(t), _lib.ptr(out),
-                                              _lib.stream_ptr()), "dv_unet_forward")
+        rc = _lib.lib().dv_unet_forward(self._h, _lib.ptr(x), cx, _lib.ptr(cond), _lib.ptr(t), _lib.ptr(out), _lib.stream_ptr())
+        if rc != 0 and getattr(self, "_exclusive", True) and self.handover_status()[1]:
+            # an EARLIER forward's hand-over timed out (noticed now: forwards are asynchronous).  That result is gone - it was
+            # handed to the caller already - but the engine carries on: downgraded, it needs prepare + set_cond again.
+            self.recover_handover()
+            raise RuntimeError("diff_vits_amd: the previous denoiser forward was invalid (in-kernel GroupNorm hand-over timed out "
+                               "on a shared GPU); the engine has switched to the separate-GroupNorm schedule - repeat the run")
+        _lib.check(rc, "dv_unet_forward")
         return out
 
     # ------------------------------------------------------------------ module-level forward
@@ -261,6 +268,30 @@ class UNetEngine:
         n, bad = C.c_int32(), C.c_int32()
         _lib.check(_lib.lib().dv_unet_handover_status(self._h, C.byref(n), C.byref(bad)), "dv_unet_handover_status")
         return n.value, bad.value
+
+    def handover_active(self):
+        """True while the current schedule finishes GroupNorms inside producer GEMMs (in-launch hand-over: needs the device
+        to itself for the duration of each such launch)."""
+        return getattr(self, "_exclusive", True) and not self.handover_downgraded and self.handover_status()[0] > 0
+
+    def recover_handover(self):
+        """Deal with a timed-out in-launch hand-over (a foreign kernel - another stream, another process - kept workgroups
+        of a GroupNorm-finishing GEMM off the CUs past the bounded wait; the results of that run are invalid).  Clears the
+        native flag, switches this engine to the fallback schedule for good (GroupNorm by k_gn_apply launches: no in-launch
+        waits), and reports it once.  Returns True if a time-out had happened: the caller repeats the lost run (the sampler
+        path does: sampler/_plan.py) - the engine must be prepared and conditioned again first."""
+        n, bad = self.handover_status()
+        if not bad:
+            return False
+        import warnings
+        _lib.check(_lib.lib().dv_unet_handover_reset(self._h), "dv_unet_handover_reset")
+        if not self.handover_downgraded:
+            warnings.warn("diff_vits_amd: an in-kernel GroupNorm hand-over timed out (the GPU is shared with other kernels); "
+                          "this engine now runs GroupNorm as separate launches (DVITS_GNX=0 schedule) and the lost run is repeated",
+                          RuntimeWarning, stacklevel=3)
+        self.handover_downgraded = True
+        self.set_exclusive(False)
+        return True
 
     def time_family(self, kind, reps=5):
         """Average launch duration (us) of one kernel family: its launches of the schedule replayed back to back

@@ -4,6 +4,7 @@ ops on whatever device the tensors live on) and its native execution (hipGraph r
 UNet schedule + fused update kernels) when the model is this package's UNet.
 """
 import ctypes as C
+import os
 import importlib
 
 import numpy as np
@@ -208,6 +209,11 @@ class Plan:
         return x
 
 
+# DVITS_HANDOVER_VERIFY=0: do not wait for a sampler run to drain in order to check its in-launch hand-overs (a time-out is
+# then only noticed - loudly - by the NEXT call on the engine, and the lost run is not repeated): measurement aid
+_VERIFY_HANDOVER = os.environ.get("DVITS_HANDOVER_VERIFY", "1") != "0"
+
+
 class NativeUNetModel:
     """Opt-in marker for the fully native loop: pass an instance as `model` to `model_wrapper`
     (model_type='x_start').  It is also a plain callable `(x, t_input) -> x0`, so every other
@@ -225,6 +231,20 @@ class NativeUNetModel:
         """hipGraph replay of the whole loop (dv_sampler_run).  Returns a new tensor."""
         L = _lib()
         eng = self.unet.hip_engine()
+        out = self._run_plan_once(plan, x, eng, L)
+        # In-launch GroupNorm hand-overs need the device to themselves; on a shared GPU one may time out (bounded wait, flag in
+        # host memory).  Checked once per RUN, after it has drained: the engine then drops to the separate-GroupNorm schedule
+        # for good and the run is repeated on it - degraded, not dead (VERDICT r2 #6).
+        if _VERIFY_HANDOVER and eng.handover_active():
+            torch.cuda.current_stream().synchronize()
+            if eng.recover_handover():
+                out = self._run_plan_once(plan, x, eng, L)
+                torch.cuda.current_stream().synchronize()
+                if eng.handover_status()[1]:
+                    raise RuntimeError("in-kernel hand-over timed out on the fallback schedule (it has none): internal error")
+        return out
+
+    def _run_plan_once(self, plan, x, eng, L):
         B, C_, T = x.shape
         eng.prepare(B, T, self.enc.shape[1])
         bias = self.unet._bias_from_mask(self.mask, torch.float32)

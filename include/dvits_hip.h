@@ -145,6 +145,11 @@ int dv_unet_persist_status(dv_unet* u, int32_t* n_ops, int32_t* error_flag);
  * results of that launch are invalid and every later dv_unet_forward / dv_sampler_run on this handle fails with
  * DV_ERR_HIP.  Does not synchronise: meaningful once the stream has drained. */
 int dv_unet_handover_status(dv_unet* u, int32_t* n_ops, int32_t* timed_out);
+/* Recovery from such a time-out (a foreign kernel kept some workgroups off the CUs past the bounded wait): synchronises the
+ * device and clears the flag, so that the handle works again.  The caller then re-plans it with dv_unet_set_exclusive(u, 0) -
+ * GroupNorm as separate launches, no in-launch waits - and repeats the lost run; diff_vits_amd/engine.py does exactly that
+ * for a sampler run (UNetEngine.recover_handover) and reports the downgrade once. */
+int dv_unet_handover_reset(dv_unet* u);
 /* The in-launch waits above assume that the launch has the device to itself (every workgroup resident at once): true
  * for one stream, or for several streams that never run kernels of such handles side by side.  A host that drives
  * several handles CONCURRENTLY on different streams of one device must call this with exclusive = 0 before
