@@ -12,6 +12,7 @@ typedef unsigned short bf16_t;   // raw bfloat16 bits
 // nearest upsample, channel-concat of two source tensors) from activations that their
 // producers already stored as split bf16 planes (hi = bf16(x), lo = bf16(x - hi)).
 // ---------------------------------------------------------------------------------------
+enum { DV_ZERO_PAGE_BYTES = 32768 };   // >= 2 bytes x the widest A row (channels of one source tensor) + 16
 enum { EPI_STORE = 0, EPI_RESIDUAL = 1, EPI_GEGLU = 2, EPI_STORE_NCT = 3 };
 enum { UP_NONE = 0, UP_X2 = 1, UP_SIZE = 2 };
 
@@ -85,7 +86,8 @@ struct GemmParams {
   int ldo;
   float* stats;                 // [ceil(M/32), N, 2] per 32-row block column (sum, sumsq) or null
   float* stats16;               // [M/32, N/16, 2] per (32-row, 16-column) block (sum, sumsq) or null (N % 16 == 0)
-  const bf16_t* zero_page;      // >= 16 bytes of zeros (source of padded / out-of-range rows)
+  const bf16_t* zero_page;      // DV_ZERO_PAGE_BYTES of zeros (source of padded / out-of-range rows: a lane that reads it walks
+                                // along a row's k-tiles inside it - 2 bytes per channel of the widest source tensor)
   // LayerNorm fused across two GEMMs (reference attention.py:157,176,189): the PRODUCER of x writes per-row
   // partial (sum, squared deviations from the block mean) over each 32-column block of its output; the CONSUMER multiplies the raw x by the
   // gamma-folded weights and finishes y = rstd*(acc - mean*u[n]) + bias'[n] in its epilogue.

@@ -166,7 +166,7 @@ struct dv_unet {
   int packed_prec = -1;
   std::map<std::string, PackedW> packed;
   char* slab = nullptr; size_t slab_bytes = 0;
-  bf16_t* zero_page = nullptr;               // 256 zero bytes: source of padded rows for the LDS-DMA
+  bf16_t* zero_page = nullptr;               // DV_ZERO_PAGE_BYTES zero bytes: source of padded rows for the LDS-DMA
   unsigned* sk_tickets = nullptr;            // per-tile arrival counters of the fused split-K pairs (zero between launches)
   // GroupNorm finished in the producer GEMM's epilogue (GnxParams): the ops' exchange words (one pool, reset to EMPTY by
   // the first kernel of every forward) and the time-out flag, in host memory the device writes through (read without a
@@ -621,7 +621,7 @@ struct Builder {
   // restores the k_gn_apply launch): fills g.gnx and allocates the normalised planes; false if launch_gemm would refuse.
   // Call after g's segments, epilogue and statistics slab are set.
   bool gnx_on = [] { const char* e = getenv("DVITS_GNX"); return !(e && e[0] == '0'); }();
-  bool bd_on = [] { const char* e = getenv("DVITS_GEMM_BD"); return !(e && e[0] == '0'); }();   // (no fragment-major copies when the BD tile is off)
+  bool bd_on = [] { const char* e = getenv("DVITS_GEMM_BD"); return e && atoi(e) != 0; }();   // (no fragment-major copies while the BD tile is off: the default)
   size_t gnx_used = 0;
   // polls before an in-launch wait gives up; DVITS_GNX_SPIN=<n> is a test hook (1: every wait that is not satisfied at once
   // times out - exercises the fallback path of engine.py deterministically)
@@ -1387,8 +1387,8 @@ struct Builder {
       }
       if (!u->zero_page) {
         void* z = nullptr;
-        if (hipMalloc(&z, 256) != hipSuccess) return dv_fail(DV_ERR_HIP, "hipMalloc(zero page) failed");
-        (void)hipMemsetAsync(z, 0, 256, pack_stream);
+        if (hipMalloc(&z, DV_ZERO_PAGE_BYTES) != hipSuccess) return dv_fail(DV_ERR_HIP, "hipMalloc(zero page) failed");
+        (void)hipMemsetAsync(z, 0, DV_ZERO_PAGE_BYTES, pack_stream);
         u->owned.push_back(z);
         u->zero_page = reinterpret_cast<bf16_t*>(z);
       }
@@ -1724,8 +1724,8 @@ struct Builder {
     dv_unet* uu = u;
     if (!dry && !u->zero_page) {
       void* z = nullptr;
-      if (hipMalloc(&z, 256) != hipSuccess) return dv_fail(DV_ERR_HIP, "hipMalloc(zero page) failed");
-      (void)hipMemsetAsync(z, 0, 256, pack_stream);
+      if (hipMalloc(&z, DV_ZERO_PAGE_BYTES) != hipSuccess) return dv_fail(DV_ERR_HIP, "hipMalloc(zero page) failed");
+      (void)hipMemsetAsync(z, 0, DV_ZERO_PAGE_BYTES, pack_stream);
       u->owned.push_back(z);
       u->zero_page = reinterpret_cast<bf16_t*>(z);
     }
@@ -2316,7 +2316,7 @@ extern "C" int dv_op_conv1d(const float* x, const float* w, const float* bias, f
   bf16_t* xl = x3 ? sc.get<bf16_t>((size_t)B * T * cpad * 2, st, false) : nullptr;
   bf16_t* hi = sc.get<bf16_t>((size_t)Npad * Kp * 2, st, true);
   bf16_t* lo = x3 ? sc.get<bf16_t>((size_t)Npad * Kp * 2, st, true) : nullptr;
-  bf16_t* zp = sc.get<bf16_t>(256, st, true);
+  bf16_t* zp = sc.get<bf16_t>(DV_ZERO_PAGE_BYTES, st, true);
   if (!xh || !hi || !zp || (x3 && (!xl || !lo))) return dv_fail(DV_ERR_HIP, "dv_op_conv1d: hipMalloc failed");
   HIPCHK(launch_pack_input(x, Cin, nullptr, 0, xh, xl, cpad, B, T, st));
   PackSpec s{};
@@ -2360,7 +2360,7 @@ extern "C" int dv_op_gn_conv1d(const float* x_cl, const float* gamma, const floa
   float* st16 = sc.get<float>((size_t)(B * T / 32) * (Cin / 16) * 2 * sizeof(float), st, false);
   bf16_t* hi = sc.get<bf16_t>((size_t)Npad * Kp * 2, st, true);
   bf16_t* lo = x3 ? sc.get<bf16_t>((size_t)Npad * Kp * 2, st, true) : nullptr;
-  bf16_t* zp = sc.get<bf16_t>(256, st, true);
+  bf16_t* zp = sc.get<bf16_t>(DV_ZERO_PAGE_BYTES, st, true);
   if (!st16 || !hi || !zp || (x3 && !lo)) return dv_fail(DV_ERR_HIP, "dv_op_gn_conv1d: hipMalloc failed");
   HIPCHK(launch_stat16(x_cl, st16, B * T, Cin, st));
   PackSpec s{};
@@ -2397,7 +2397,7 @@ extern "C" int dv_op_linear(const float* x, const float* w, const float* bias, f
   bf16_t* xl = x3 ? sc.get<bf16_t>((size_t)M * K * 2, st, false) : nullptr;
   bf16_t* hi = sc.get<bf16_t>((size_t)Npad * K * 2, st, true);
   bf16_t* lo = x3 ? sc.get<bf16_t>((size_t)Npad * K * 2, st, true) : nullptr;
-  bf16_t* zp = sc.get<bf16_t>(256, st, true);
+  bf16_t* zp = sc.get<bf16_t>(DV_ZERO_PAGE_BYTES, st, true);
   if (!xh || !hi || !zp || (x3 && (!xl || !lo))) return dv_fail(DV_ERR_HIP, "dv_op_linear: hipMalloc failed");
   HIPCHK(launch_split(x, xh, xl, (int64_t)M * K, st));
   PackSpec s{};

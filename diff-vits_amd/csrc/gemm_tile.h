@@ -148,12 +148,17 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int m0, con
     arow_t[q] = m - arow_b[q] * p.T_out;
     a_chunk[q] = l_slot ^ swz(r);                     // source chunk that lands in this lane's slot
   }
+  // (plain tiles: 32-bit per-lane byte offset beside a wave-uniform base that moves with the k-tile - the DMA is then
+  // "scalar base + vector offset", no 64-bit vector arithmetic per instruction; the weight planes are < 4 GiB)
   size_t b_off[B_IPW1];
+  unsigned b_off32[B_IPW1];
 #pragma unroll
   for (int q = 0; q < B_IPW; ++q) {
     const int r = (q * NWV + wave) * RPI + l_row;
     b_off[q] = ((size_t)(n0 + r) * p.Kp + (l_slot ^ swz(r)) * 8) * 2;   // byte offset at kt = 0
+    b_off32[q] = (unsigned)b_off[q];
   }
+  unsigned b_kbase = 0;                              // byte offset of this range's first k-tile inside a weight row
 
   // Source of the k-tile being issued, kept in wave-uniform registers and advanced incrementally: the segment
   // descriptor (kernel-argument memory) is only re-read when a source tensor / tap is exhausted, never on the
@@ -229,6 +234,17 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int m0, con
   // moves the source state to the next k-tile.  The main loop spreads the units between its MFMA groups.
   const void* asrc[A_IPW1 * NPL];
   int af_issue_koff = 0;                             // AF: packed-K offset of the tile being issued
+  // Inside one run (same source tensor, same tap) the next k-tile's rows are the same rows BK channels on: the pointers just
+  // move by BK * 2 bytes - two vector instructions per pointer instead of the ~30 of the full row arithmetic below, which
+  // runs only when a run begins (a_fresh).  [The k-loop is bound by instruction ISSUE - a SIMD issues one instruction of a
+  // wave every four cycles, two waves share it: ~95 instructions per k-tile per wave were ~800 of the ~1050 cycles per
+  // k-tile; profiles/r03_gemm_kloop_ablation_*.txt.]  Lanes that read the zero page (conv padding, rows >= M) move along
+  // inside it: it is DV_ZERO_PAGE_BYTES long, longer than the widest row.
+  bool a_fresh = true;
+  auto prep_a_next = [&]() {
+#pragma unroll
+    for (int u = 0; u < A_IPW * NPL; ++u) asrc[u] = reinterpret_cast<const char*>(asrc[u]) + BK * 2;
+  };
   auto prep_a = [&]() {
 #pragma unroll
     for (int q = 0; q < A_IPW; ++q) {
@@ -252,13 +268,18 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int m0, con
     } else {
       if (DV_GEMM_EXP >= 2 && !CM) return;
       const int q = (u - A_IPW * NPL) / NPL, pl = (u - A_IPW * NPL) % NPL;
-      const size_t o = b_off[q] + (CM ? (size_t)af_issue_koff * 2 : (size_t)kt * (BK * 2));
-      glds16(reinterpret_cast<const char*>(pl ? p.w_lo : p.w_hi) + o,
-             st_base + (unsigned)(NPL * A_PL + ((q * NWV + wave) * RPI) * ROWB + pl * B_PL));
+      const unsigned dst = st_base + (unsigned)(NPL * A_PL + ((q * NWV + wave) * RPI) * ROWB + pl * B_PL);
+      if (CM) {
+        const size_t o = b_off[q] + (size_t)af_issue_koff * 2;
+        glds16(reinterpret_cast<const char*>(pl ? p.w_lo : p.w_hi) + o, dst);
+      } else {
+        glds16_s(reinterpret_cast<const char*>(pl ? p.w_lo : p.w_hi) + (b_kbase + (unsigned)kt * (BK * 2)), b_off32[q], dst);
+      }
     }
   };
   auto advance = [&]() {
     cur_col += BK;
+    a_fresh = cur_col == cur_ld;
     if (cur_col == cur_ld) {     // wave-uniform, once per (source tensor, tap)
       const GemmSeg& sg = p.seg[ld_seg];
       if (ld_half == 0 && sg.c1 > 0) ld_half = 1;
@@ -359,7 +380,8 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int m0, con
   }
   auto issue = [&](int kt) {     // whole tile at once (prologue)
     if (CM) af_issue_koff = af_koff(af_is);
-    else prep_a();
+    else if (a_fresh) prep_a();
+    else prep_a_next();
 #pragma unroll
     for (int u = 0; u < LPT; ++u) issue_unit(kt, u);
     if (CM) af_next(af_is);
@@ -369,6 +391,8 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int m0, con
     for (int t = 0; t < kt0; ++t) advance();
 #pragma unroll
     for (int q = 0; q < B_IPW; ++q) b_off[q] += (size_t)kt0 * (BK * 2);
+    b_kbase = (unsigned)kt0 * (BK * 2);
+    a_fresh = true;                                  // (the range may begin in the middle of a run: full row arithmetic first)
   }
 
   f32x16 acc[FM][FN];
@@ -483,7 +507,7 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int m0, con
       if (ISSUE) {
         __builtin_amdgcn_sched_barrier(0);
         if (c == 0) {
-          if (CM) af_issue_koff = af_koff(af_is); else prep_a();
+          if (CM) af_issue_koff = af_koff(af_is); else if (a_fresh) prep_a(); else prep_a_next();
         }
 #pragma unroll
         for (int u = c * LPT / NCH; u < (c + 1) * LPT / NCH; ++u) issue_unit(kt + NSTAGE - 1, u);

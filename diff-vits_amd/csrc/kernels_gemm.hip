@@ -294,10 +294,10 @@ int gemm_candidates(const GemmParams& p, int* out, int cap) {
 
 // environment knobs of launch_gemm that tests flip inside one process: re-read whenever an engine is prepared
 static int g_env_xn = [] { const char* e = getenv("DVITS_XCD_N"); return e ? atoi(e) : -1; }();
-static int g_env_bd = [] { const char* e = getenv("DVITS_GEMM_BD"); return e ? atoi(e) : 1; }();
+static int g_env_bd = [] { const char* e = getenv("DVITS_GEMM_BD"); return e ? atoi(e) : 0; }();
 void gemm_env_refresh() {
   const char* e = getenv("DVITS_XCD_N"); g_env_xn = e ? atoi(e) : -1;
-  e = getenv("DVITS_GEMM_BD"); g_env_bd = e ? atoi(e) : 1;
+  e = getenv("DVITS_GEMM_BD"); g_env_bd = e ? atoi(e) : 0;
 }
 
 // Tile (BM x BN) the shape heuristic of launch_gemm picks for a non-AF, non-GEGLU GEMM (kept in step with
@@ -345,6 +345,8 @@ hipError_t launch_gemm(const GemmParams& pin, int precision, hipStream_t st) {
   GemmParams p = pin;
   const bool x3 = precision == 0;
   if (!p.zero_page || (x3 && !p.w_lo)) return hipErrorInvalidValue;
+  for (int s2 = 0; s2 < p.nseg; ++s2)     // (a lane on the zero page walks a row's k-tiles inside it: gemm_tile.h prep_a_next)
+    if (2 * (size_t)p.seg[s2].c0 + 256 > DV_ZERO_PAGE_BYTES || 2 * (size_t)p.seg[s2].c1 + 256 > DV_ZERO_PAGE_BYTES) return hipErrorInvalidValue;
   if (p.gnx.xchg && p.sk_mode == 0) {            // (checked once, before the split-K recursion)
     static const int n_cu = [] { int d = 0, n = 0; (void)hipGetDevice(&d); (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, d); return n; }();
     if (!p.gnx.status || !p.gnx.y_hi || !p.gnx.gamma || !p.gnx.beta || gemm_gnx_plan(p, n_cu) <= 0) return hipErrorInvalidValue;
@@ -416,8 +418,10 @@ hipError_t launch_gemm(const GemmParams& pin, int precision, hipStream_t st) {
   {   // 64x64x64 tiles with fragment-major weights at hand: the BD tile (DVITS_GEMM_BD=0 keeps the plain tile: A/B runs)
     int bm, bn;
     gemm_pick_tile(p, bm, bn);
-    // where it pays (phase traces): the k = 3 run must be long enough to amortise the tile's start-up (producer
-    // waves, 4-way k-group hand-over) - DVITS_GEMM_BD=<min packed K of the k = 3 segment>, 2: every GEMM the tile can run
+    // OFF by default (DVITS_GEMM_BD unset / 0): measured in the forward it only wins for single-segment k = 3 convs with
+    // K >= 1920 (-5..7 % per launch) and loses below (start-up of the producer waves, 4-way k-group hand-over, an epilogue
+    // squeezed into 168 VGPRs): +-0 end to end - DESIGN.md section 4.  DVITS_GEMM_BD=1: those convs; =<n> > 2: single-segment
+    // k = 3 convs with packed K >= n; =2: every GEMM the tile can run (the parity tests).
     const int k3 = p.seg[0].taps == 3 ? 3 * (p.seg[0].c0 + p.seg[0].c1) : 0;
     const bool pays = g_env_bd == 2 || (g_env_bd == 1 ? (p.nseg == 1 && k3 >= 1920) : (p.nseg == 1 && k3 >= g_env_bd));
     if (g_env_bd && pays && !big && bk == 64 && bm == 64 && bn == 64 && tune.ksplit && (!x3 || p.wf_lo) && gemm_bd_supported(p)) {

@@ -1147,3 +1147,31 @@ assert eng.handover_status()[1] == 0
 print("ok")
 """)
     assert "ok" in out
+
+
+def test_bd_tile_schedule_matches_default(gold):
+    """DVITS_GEMM_BD=2: every GEMM the BD tile can run takes it (k_gemm<64,64,64,1,2,*,4,false,true>: fragment-major weights in
+    chunk-major k order straight into registers, activation slabs DMA'd once per 64-channel chunk by two producer waves, the
+    three taps of a conv reading shifted rows; incl. two-segment GEMMs - conv2 + folded 1x1 shortcut -, concatenated inputs,
+    the in-epilogue GroupNorm and the fused split-K pair).  Same products as the plain tile in another summation order:
+    agreement to float32 rounding with the default schedule, and both meet the reference's golden output."""
+    from diff_vits_amd.unet1d.unet_1d_condition import UNet1DConditionModel
+    kw, sd, sample, t, enc, mask = unet_case("cfg1")
+    outs = []
+    for bd in ("0", "2"):
+        os.environ["DVITS_GEMM_BD"] = bd
+        try:
+            m = UNet1DConditionModel(backend="hip", **kw).eval()
+            m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+            m = m.cuda()
+            with torch.no_grad():
+                y = m(torch.from_numpy(sample).cuda(), torch.from_numpy(t).cuda(), torch.from_numpy(enc).cuda(),
+                      encoder_attention_mask=torch.from_numpy(mask).cuda()).sample
+            outs.append(y.cpu().numpy())
+            assert m.hip_engine().handover_status()[1] == 0
+        finally:
+            os.environ.pop("DVITS_GEMM_BD", None)
+    g = gold("unet_cfg1.npz")["y"]
+    assert rel_l2(outs[0], g) < 2e-4 and rel_l2(outs[1], g) < 2e-4
+    assert rel_l2(outs[1], outs[0]) < 5e-5
+    assert not np.array_equal(outs[0], outs[1])       # (the BD schedule really ran: another summation order somewhere)
