@@ -453,7 +453,7 @@ def main():
         elif pj is not None:
             traffic, hbm_gbps, mfma_util = (pj["gemm"][k] for k in ("hbm_bytes_per_launch", "hbm_gbps", "mfma_util"))
             pmc_families = {k: {kk: v[kk] for kk in ("launches", "avg_us_kernel_trace", "hbm_bytes_per_launch", "hbm_gbps", "mfma_util")}
-                            for k, v in pj.items() if isinstance(v, dict)}
+                            for k, v in pj.items() if isinstance(v, dict) and "launches" in v}
             traffic_src = ("profiles/r03_pmc_roofline.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, KiB; SQ_VALU_MFMA_BUSY_CYCLES / "
                            "(1024 SIMDs x kernel duration x 2.4 GHz); separate passes, eager launches; build %s, git %s)"
                            % (pj["build"].get("dv_version"), pj["build"].get("git_head")))

@@ -25,25 +25,6 @@ struct GemmSeg {
   int nkt;             // k-tiles of this segment = taps * (c0+c1) / BK   (set by the launcher)
 };
 
-// A operand produced inside the GEMM ("AF" tiles, gemm_tile.h): instead of split planes written by a separate
-// GroupNorm-apply launch, the conv reads the producer's fp32 rows itself, applies GroupNorm (+ temb scale/shift) (+ SiLU)
-// and the hi/lo split on its producer waves, and the taps of a k=3 conv read shifted windows of ONE LDS slab
-// (reference resnet.py:591-641: norm1 -> SiLU -> conv1, norm2 (+temb) -> SiLU -> conv2; transformer_1d.py:264-268:
-// norm -> proj_in; unet_1d_condition.py:1027-1031: conv_norm_out -> SiLU -> conv_out).
-struct AfSrc {
-  const float* x;        // fp32 channels-last [B*T, C]
-  const float* stat16;   // [B*T/32][C/16][2]: (sum, sum of squares) per 32-frame x 16-channel block, written by x's producer
-  int C, pad_;
-};
-struct AfParams {
-  AfSrc src[2][2];       // [segment][half of the channel concat]; segment 1 (1x1 shortcut) is always read raw
-  int mode0;             // segment 0: 1 = normalise, 2 = normalise + SiLU  (segment 1: raw split)
-  int groups;
-  const float* gamma; const float* beta;                     // GroupNorm affine over segment 0's concat channels
-  const float* tscale; const float* tshift; int ld_t;        // temb scale / shift rows [B, ld_t], or null
-  float eps;
-};
-
 // GroupNorm of the GEMM's OWN output finished in its epilogue (gemm_tile.h "GNX"): every workgroup publishes the
 // 32x16-block statistics of its tile in an exchange buffer (8-byte words, written through), polls the words of its
 // groups until all of the utterance's tiles have published (EMPTY = all ones; the first kernel of every forward resets
@@ -107,8 +88,6 @@ struct GemmParams {
   int sk_mode;                  // internal: 0 single launch, 1 k-slice pass (dump), 2 epilogue pass, 3 fused pair
   unsigned* sk_ticket;          // per-tile arrival counters (zero between launches) for the fused pair, or null: two launches
   int force_tile;               // 0: launch_gemm's shape heuristic; else a GT_* tile of the menu (set by the prepare-time tuner)
-  int af;                       // 1: A operand produced in-kernel from afp (plane pointers of seg[] unused); T_out % 32 == 0
-  AfParams afp;
   GnxParams gnx;                // GroupNorm of the output in the epilogue (needs stats16)
   int xcd_n;                    // internal (launch_gemm): XCDs the columns are split over (0: row bands of the tile grid)
   int xcd_sh_n, xcd_sh_mn, xcd_tn, xcd_tm, xcd_inv_tn;   // internal: log2 xn, log2 (xm xn), rectangle width / height in tiles, ceil(2^16 / width)
@@ -117,12 +96,10 @@ struct GemmParams {
 // more workgroups than `n_cu` compute units, unsupported epilogue)
 int gemm_gnx_plan(const GemmParams& p, int n_cu);
 // tile menu ids (kernels_gemm.hip); GT_BK64 is or-ed in when the tile runs 64-deep k-tiles
-enum { GT_AUTO = 0, GT_T0 = 1, GT_T1 = 2, GT_T2 = 3, GT_T2S = 4, GT_T2G = 5, GT_T3 = 6, GT_T4 = 7, GT_T4G = 8, GT_AF64 = 9, GT_AF32 = 10,
+enum { GT_AUTO = 0, GT_T0 = 1, GT_T1 = 2, GT_T2 = 3, GT_T2S = 4, GT_T2G = 5, GT_T3 = 6, GT_T4 = 7, GT_T4G = 8,
        GT_BK64 = 0x100 };
 // true if launch_gemm can run this GEMM on the BD tile (fragment-major weights in registers, activation slabs in LDS)
 bool gemm_bd_supported(const GemmParams& p);
-// true if launch_gemm can run this GEMM (p.af = 1) on the tiles that produce the A operand in-kernel
-bool gemm_af_supported(const GemmParams& p);
 // candidate tiles (force_tile values) that can run this GEMM; returns the count written to out[cap]
 int gemm_candidates(const GemmParams& p, int* out, int cap);
 // number of k-slices launch_gemm should run this GEMM in (0: single launch); env DVITS_SPLITK tunes / disables

@@ -407,7 +407,7 @@ struct Builder {
   }
   // descriptor of a GEMM for the persistent schedule, or false if its shape is outside what persist.hip instantiates
   bool persist_gemm(const GemmParams& gin, PersistOp& po) {
-    if (prec != DV_PREC_BF16X3 || gin.epi == EPI_STORE_NCT || !gin.w_lo || gin.af) return false;
+    if (prec != DV_PREC_BF16X3 || gin.epi == EPI_STORE_NCT || !gin.w_lo) return false;
     bool k64 = true;
     for (int s2 = 0; s2 < gin.nseg; ++s2) k64 = k64 && gin.seg[s2].c0 % 64 == 0 && gin.seg[s2].c1 % 64 == 0;
     int cfg, bm, bk;
@@ -502,19 +502,10 @@ struct Builder {
     return pl;
   }
   void release(const Planes& pl) { if (pl.hi) release((const void*)pl.hi); if (pl.lo) release((const void*)pl.lo); }
-  // GroupNorm statistics of a GEMM output for its consumer, written by the GEMM's epilogue: k_gn_apply reduces a
-  // per-column slab (default).  DVITS_FUSE_GN=1: the consumer conv normalises its own operand from per-(32-frame,
-  // 16-channel)-block statistics (AF tiles, gemm_tile.h) and the k_gn_apply launches disappear.  Built, parity-green and
-  // OFF by default: measured slower - an N-tiled conv repeats the elementwise GroupNorm + SiLU +
-  // hi/lo split of its rows in every 64-column tile (2-8x), and that conversion costs more vector-ALU time per element
-  // than the tile's MFMAs.
-  bool fuse_gn = [] { const char* e = getenv("DVITS_FUSE_GN"); return e && e[0] == '1'; }();
-  // a tensor carries 32x16-block statistics iff every GroupNorm over it (alone or concatenated with another such
-  // tensor) has whole 16-channel blocks per group and 64-channel chunks: then every consumer can take the fused path
-  bool af_tensor(int Tn, int C) const {
-    const int G = u->cfg.norm_num_groups;
-    return fuse_gn && !arena.exact && Tn % 32 == 0 && C % 64 == 0 && C % G == 0 && (C / G) % 16 == 0;
-  }
+  // GroupNorm statistics of a GEMM output for its consumer are written by the GEMM's epilogue (k_gn_apply / the chain kernels /
+  // the in-epilogue GroupNorm reduce them).  [Round 2 also had the CONSUMER conv normalise its own operand ("AF" tiles,
+  // DVITS_FUSE_GN=1): parity-green but slower - an N-tiled conv repeats the elementwise GroupNorm + SiLU + hi/lo split of its
+  // rows in every 64-column tile - and removed in round 3; DESIGN.md section 4 keeps the measurements.]
   void alloc_stat(Act& a, bool want16 = false) {
     // 32-row blocks of the flat [B*T] row space must not span utterances: T % 32 == 0, or ONE utterance (its last block is
     // partial: rows beyond M contribute zeros) - the single-utterance case is the real inference call (B = 1, any T)
@@ -522,7 +513,7 @@ struct Builder {
       if (B == 1) a.stat = alloc((size_t)((a.T + 31) / 32) * a.C * 2);
       return;
     }
-    if (want16 || af_tensor(a.T, a.C) || stat16_everywhere()) a.stat16 = alloc((size_t)(B * a.T / 32) * (a.C / 16) * 2);
+    if (want16 || stat16_everywhere()) a.stat16 = alloc((size_t)(B * a.T / 32) * (a.C / 16) * 2);
     else a.stat = alloc((size_t)(B * a.T / 32) * a.C * 2);
   }
   // every level has whole 16-channel blocks per GroupNorm group: all tensors carry block statistics (16x fewer entries
@@ -586,37 +577,6 @@ struct Builder {
     const int pr = prec;
     emit(ops, [cp, pr](hipStream_t st) { return launch_chain2(cp, pr, st); });
   }
-  // Fill the in-kernel GroupNorm of [a0 | a1] (+ temb scale/shift) (+ SiLU) as segment 0's operand of `g` (k taps), and
-  // optionally the raw [r0 | r1] as segment 1 (1x1 shortcut).  False if the shapes are outside what the AF tiles take.
-  bool af_setup(GemmParams& g, Act a0, Act a1, int taps, const std::string& pre, float eps, const float* tscale,
-                const float* tshift, int ld_t, bool silu, const Act* r0 = nullptr, const Act* r1 = nullptr) {
-    if (!fuse_gn || !a0.stat16 || (a1.C > 0 && !a1.stat16)) return false;
-    g.af = 1;
-    g.seg[0] = GemmSeg{}; g.seg[0].c0 = a0.C; g.seg[0].c1 = a1.C; g.seg[0].taps = taps; g.seg[0].pad = (taps - 1) / 2;
-    g.afp = AfParams{};
-    g.afp.src[0][0] = AfSrc{a0.p, a0.stat16, a0.C, 0};
-    g.afp.src[0][1] = AfSrc{a1.p, a1.stat16, a1.C, 0};
-    g.afp.mode0 = silu ? 2 : 1; g.afp.groups = u->cfg.norm_num_groups;
-    g.afp.gamma = W(pre + ".weight"); g.afp.beta = W(pre + ".bias"); g.afp.eps = eps;
-    g.afp.tscale = tscale; g.afp.tshift = tshift; g.afp.ld_t = ld_t;
-    g.nseg = 1;
-    if (r0) {
-      g.seg[1] = GemmSeg{}; g.seg[1].c0 = r0->C; g.seg[1].c1 = r1 ? r1->C : 0; g.seg[1].taps = 1; g.seg[1].pad = 0;
-      g.afp.src[1][0] = AfSrc{r0->p, nullptr, r0->C, 0};
-      if (r1 && r1->C > 0) g.afp.src[1][1] = AfSrc{r1->p, nullptr, r1->C, 0};
-      g.nseg = 2;
-    }
-    if (dry) {   // weights are not resolved in the dry pass: check with placeholders
-      GemmParams t = g; t.B = B;
-      t.afp.gamma = t.afp.beta = reinterpret_cast<const float*>(0x1000);
-      if (!gemm_af_supported(t)) { g.af = 0; return false; }
-      return true;
-    }
-    GemmParams t = g; t.B = B;
-    if (!gemm_af_supported(t)) { g.af = 0; return false; }
-    return true;
-  }
-
   // GroupNorm (+ temb scale/shift) (+ SiLU) of a GEMM's own output finished in ITS epilogue (gemm_tile.h GNX; DVITS_GNX=0
   // restores the k_gn_apply launch): fills g.gnx and allocates the normalised planes; false if launch_gemm would refuse.
   // Call after g's segments, epilogue and statistics slab are set.
@@ -694,7 +654,7 @@ struct Builder {
     {
       char buf[128];
       snprintf(buf, sizeof(buf), "M=%d N=%d K=%d taps=%d nseg=%d epi=%d stride=%d up=%d%s%s%s", g.M, g.N, k_real, g.seg[0].taps,
-               g.nseg, g.epi, g.stride, g.up_mode, (g.stats || g.stats16) ? " +stats" : "", g.af ? " +gn" : "",
+               g.nseg, g.epi, g.stride, g.up_mode, (g.stats || g.stats16) ? " +stats" : "", "",
                g.gnx.xchg ? " +gnx" : "");
       cur_desc = buf;
     }
@@ -849,20 +809,10 @@ struct Builder {
     const int toff = tproj_off[p];
     Planes n2x;                   // norm2(h) planes written by conv1's own epilogue (gnx_setup), if it can
     bool gnx1 = false;
-    // both convs of a block take the fused path or neither (conv2's folded shortcut reads the raw fp32 input)
-    bool fused = false;
     {
-      GemmParams t1 = gp_base(Tn, M, cout), t2 = gp_base(Tn, M, cout);
-      fused = af_setup(t1, x0, x1, 3, p + "norm1", eps, nullptr, nullptr, 0, true) &&
-              af_setup(t2, h, Act{}, 3, p + "norm2", eps, nullptr, nullptr, 0, true, shortcut ? &x0 : nullptr, shortcut ? &x1 : nullptr);
-    }
-    {
-      // fused: conv1 normalises [x0 | x1] itself (GroupNorm + SiLU on its producer waves); else k_gn_apply -> planes
       GemmParams g = gp_base(Tn, M, cout);
       g.out = h.p; stat_out(g, h);
-      if (fused && af_setup(g, x0, x1, 3, p + "norm1", eps, nullptr, nullptr, 0, true)) gemm(ops, g, w1, 3 * cin);
-      else {
-        g.af = 0;
+      {
         Planes n1;
         if (x1.C == 0 && x0.n_hi && x0.n_pre == p + "norm1" && (!shortcut || x0.pl_hi)) {   // normalised by its producer
           n1.hi = x0.n_hi; n1.lo = x0.n_lo;
@@ -898,13 +848,7 @@ struct Builder {
         out.pl_hi = pl.hi; out.pl_lo = pl.lo; g.out_hi = pl.hi; g.out_lo = pl.lo;
       }
       const bool offered = next_norm.set;
-      // fused: conv2 normalises h (GroupNorm + temb scale/shift + SiLU) and splits the raw [x0 | x1] of the folded
-      // 1x1 shortcut itself; it needs the raw fp32 input, so both convs of a block are fused or neither
-      if (fused && af_setup(g, h, Act{}, 3, p + "norm2", eps, tproj + toff, tproj + toff + cout, tproj_total, true,
-                            shortcut ? &x0 : nullptr, shortcut ? &x1 : nullptr))
-        gemm(ops, g, w2, K2);
-      else {
-        g.af = 0;
+      {
         Planes n2 = gnx1 ? n2x : norm_apply(ops, h, Act{}, p + "norm2", eps, tproj + toff, tproj + toff + cout, tproj_total, true, nullptr);
         g.seg[0] = seg(n2, cout, Planes{}, 0, 3, 1);
         g.nseg = 1;
@@ -1037,7 +981,7 @@ struct Builder {
     };
     auto ln_release = [&](LnIn& in) { release(in.pl); if (in.stat) release(in.stat); };
 
-    const bool chained = chain_ok(Tn, C) && x.stat16 && !af_tensor(Tn, C);
+    const bool chained = chain_ok(Tn, C) && x.stat16;
     float* h3 = nullptr;
     LnIn l3;
     if (chained && !(frag(w_in) && frag(w_qkv) && frag(w_o1) && frag(w_q2))) return Act{};
@@ -1146,14 +1090,13 @@ struct Builder {
       probe(tb + "attn2", h3, Tn, C);
       }
     } else {
-    // GN(eps 1e-6) -> 1x1 proj_in (fused: proj_in normalises x itself)
+    // GN(eps 1e-6) -> 1x1 proj_in
     float* h = alloc((size_t)M * C);
     LnIn l1;
     {
       GemmParams g = gp_base(Tn, M, C);
       g.out = h; l1 = ln_produce(g);
-      if (af_setup(g, x, Act{}, 1, p + "norm", 1e-6f, nullptr, nullptr, 0, false)) gemm(ops, g, w_in, C);
-      else {
+      {
         Planes gn = norm_apply(ops, x, Act{}, p + "norm", 1e-6f, nullptr, nullptr, 0, false, nullptr);
         g.seg[0] = seg(gn, C, Planes{}, 0, 1, 0);
         gemm(ops, g, w_in, C);
@@ -1544,7 +1487,7 @@ struct Builder {
           (void)launch_transpose_f32(Wt, WtT, tt, E, pack_stream);
         }
         emit(S, [=](hipStream_t st) { return launch_small_linear_t(emb, E, WtT, bt, nullptr, tp, tt, Bn, E, tt, 1, 0, st); });
-        if (!dry && !arena.exact && !fuse_gn) {   // (B <= 16: the batched chain runs the same kernels on row chunks - identical bits per row)
+        if (!dry && !arena.exact) {   // (B <= 16: the batched chain runs the same kernels on row chunks - identical bits per row)
           u->temb.WtT = WtT; u->temb.bt = bt; u->temb.C0 = C0; u->temb.E = E; u->temb.tt = tt; u->temb.tproj_arena = tp;
           u->temb.begin = temb_begin; u->temb.end = (int)S.size(); u->temb.ok = true;
         }
@@ -1667,7 +1610,7 @@ struct Builder {
       if (h.n_hi && h.n_pre == "conv_norm_out") {   // normalised by its producer's epilogue
         nf.hi = h.n_hi; nf.lo = h.n_lo;
         g.seg[0] = seg(nf, C0, Planes{}, 0, 3, 1);
-      } else if (!af_setup(g, h, Act{}, 3, "conv_norm_out", c.norm_eps, nullptr, nullptr, 0, true)) {
+      } else {
         nf = norm_apply(S, h, Act{}, "conv_norm_out", c.norm_eps, nullptr, nullptr, 0, true, nullptr);
         g.seg[0] = seg(nf, C0, Planes{}, 0, 3, 1);
       }
@@ -2341,44 +2284,6 @@ extern "C" int dv_op_conv1d(const float* x, const float* w, const float* bias, f
   g.w_hi = hi; g.w_lo = lo; g.Kp = Kp; g.N_pad = Npad; g.bias = bias;
   g.M = B * g.T_out; g.N = Cout; g.epi = EPI_STORE_NCT; g.out = y; g.ldo = Cout; g.zero_page = zp;
   HIPCHK(launch_gemm(g, precision, st));
-  HIPCHK(hipStreamSynchronize(st));
-  return DV_OK;
-}
-
-extern "C" int dv_op_gn_conv1d(const float* x_cl, const float* gamma, const float* beta, const float* tscale, const float* tshift,
-                               const float* w, const float* bias, float* y, int32_t B, int32_t Cin, int32_t T, int32_t Cout,
-                               int32_t k, int32_t groups, float eps, int32_t silu, int32_t precision, void* stream) {
-  if (!x_cl || !gamma || !beta || !w || !y || (k != 1 && k != 3)) return dv_fail(DV_ERR_INVALID, "dv_op_gn_conv1d: bad argument");
-  if (T % 32 != 0 || Cin % 64 != 0 || groups <= 0 || Cin % groups != 0 || (Cin / groups) % 16 != 0 || Cin > 1024)
-    return dv_fail(DV_ERR_INVALID, "dv_op_gn_conv1d: needs T %% 32 == 0, Cin %% 64 == 0 (<= 1024), whole 16-channel blocks per group");
-  hipStream_t st = (hipStream_t)stream;
-  HIPCHK(gemm_init());
-  gemm_env_refresh();
-  const bool x3 = precision == DV_PREC_BF16X3;
-  const int Kp = k * Cin, Npad = rup(Cout, 128);
-  OpScratch sc;
-  float* st16 = sc.get<float>((size_t)(B * T / 32) * (Cin / 16) * 2 * sizeof(float), st, false);
-  bf16_t* hi = sc.get<bf16_t>((size_t)Npad * Kp * 2, st, true);
-  bf16_t* lo = x3 ? sc.get<bf16_t>((size_t)Npad * Kp * 2, st, true) : nullptr;
-  bf16_t* zp = sc.get<bf16_t>(DV_ZERO_PAGE_BYTES, st, true);
-  if (!st16 || !hi || !zp || (x3 && !lo)) return dv_fail(DV_ERR_HIP, "dv_op_gn_conv1d: hipMalloc failed");
-  HIPCHK(launch_stat16(x_cl, st16, B * T, Cin, st));
-  PackSpec s{};
-  s.src = w; s.N = Cout; s.kind = 1; s.C = Cin; s.taps = k; s.c_pad = Cin; s.k_off = 0; s.n_off = 0;
-  HIPCHK(launch_pack_weight(s, hi, lo, Kp, st));
-  GemmParams g{};
-  g.seg[0].c0 = Cin; g.seg[0].taps = k; g.seg[0].pad = (k - 1) / 2;
-  g.nseg = 1; g.B = B; g.T_in = g.T_out = g.T_virt = T; g.stride = 1; g.up_mode = UP_NONE;
-  g.w_hi = hi; g.w_lo = lo; g.Kp = Kp; g.N_pad = Npad; g.bias = bias;
-  g.M = B * T; g.N = Cout; g.epi = EPI_STORE_NCT; g.out = y; g.ldo = Cout; g.zero_page = zp;
-  g.af = 1;
-  g.afp.src[0][0] = AfSrc{x_cl, st16, Cin, 0};
-  g.afp.mode0 = silu ? 2 : 1; g.afp.groups = groups; g.afp.gamma = gamma; g.afp.beta = beta; g.afp.eps = eps;
-  g.afp.tscale = tscale; g.afp.tshift = tshift; g.afp.ld_t = Cin;
-  if (const char* e = getenv("DVITS_AF_DEBUG")) g.af |= atoi(e) << 1;     // trace build only (gemm_tile.h)
-  if (const char* e = getenv("DVITS_AF_TILE")) g.force_tile = atoi(e) == 32 ? GT_AF32 : (atoi(e) == 64 ? GT_AF64 : 0);
-  hipError_t le = launch_gemm(g, precision, st);
-  if (le != hipSuccess) return dv_fail(DV_ERR_HIP, "dv_op_gn_conv1d: launch failed: %s", hipGetErrorString(le));
   HIPCHK(hipStreamSynchronize(st));
   return DV_OK;
 }

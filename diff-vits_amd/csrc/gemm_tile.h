@@ -51,15 +51,6 @@ __device__ __forceinline__ unsigned cvt_pk_bf16(float lo, float hi) { return dv_
 // stores and takes a ticket from the tile's agent-scope counter; the first to arrive leaves, the second adds the
 // partner's dump (system-scope loads, after the atomic) and runs the epilogue.  No workgroup ever waits for another.
 // Measured: worth ~25 % on the K >= 1536 GEMMs of the 128-frame level, ~1 % of a forward.
-// AF ("A fused"): the A operand is not DMA'd from split planes written by a GroupNorm-apply launch but PRODUCED in the
-// workgroup from the producer's fp32 rows: GroupNorm (+ temb scale/shift) (+ SiLU) and the hi/lo split happen once per
-// PHASE - up to AF_CH 64-channel chunks of BM + 2 frames (the k = 3 halo) converted by ALL waves into an LDS slab that
-// stays resident while the k-loop multiplies its (chunk, tap) tiles, streaming only the weights through the DMA ring.
-// The taps of a k = 3 conv read shifted row windows of the slab, so the conv reads its input once (fp32) instead of three
-// times (planes).  [A first version with dedicated producer waves converting one chunk ahead of the MFMA waves was
-// correct but measured ~1800 cycles per k-tile against 960 for the plain kernel: sixteen waves meeting at every k-tile
-// barrier with the VALU pipe of each SIMD shared between them - DESIGN.md.]  The k-tile order is chunk-major (segment ->
-// concat half -> 64-channel chunk -> tap); tiles never span utterances (T_out % BM == 0).
 // BD ("B direct"): the tile of the stride-1 convs and linears whose channel counts are multiples of 64.  Measured on the
 // plain tile (trace builds with parts of the k-loop removed, profiles/r03_gemm_kloop_ablation_*.txt): its 64x64x64 k-tile takes
 // ~1100 cycles against 384 of MFMA although the waits for the DMA are ~zero - the loop is bound by LDS bandwidth (32 KiB of DMA
@@ -77,30 +68,26 @@ __device__ __forceinline__ unsigned cvt_pk_bf16(float lo, float hi) { return dv_
 //     + their address arithmetic).
 // [Round 2's "AS" tile - the slab alone, weights still through the LDS ring, 2 x 2 waves - was slower than the plain tile and
 // is replaced by this one.]
-template <int BM, int BN, int BK, int WM, int WN, int NSPLIT, int KS, bool SC1, bool AF = false, bool BD = false>
+template <int BM, int BN, int BK, int WM, int WN, int NSPLIT, int KS, bool SC1, bool BD = false>
 __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int m0, const int n0, char* smem, const int ksel = 0) {
   constexpr int FM = BM / (WM * 32), FN = BN / (WN * 32);
   constexpr int NWQ = WM * WN;                       // waves per k-group (1, 2 or 4)
   constexpr int NWV = NWQ * KS;                      // waves per workgroup
-  static_assert(!AF || (BK == 64 && !SC1), "AF tiles: 64-deep k-tiles, per-launch kernel");
-  static_assert(!BD || (BK == 64 && !SC1 && !AF && BM == 64 && BN == 64 && WM == 1 && WN == 2 && KS == 4),
+  static_assert(!BD || (BK == 64 && !SC1 && BM == 64 && BN == 64 && WM == 1 && WN == 2 && KS == 4),
                 "BD tile: 64 x 64 x 64, 1 x 2 waves x 4 k-groups, per-launch kernel");
-  constexpr bool CM = AF || BD;                      // chunk-major k-tile order
+  constexpr bool CM = BD;                            // chunk-major k-tile order (no LDS ring)
   constexpr bool SPLIT = NSPLIT == 3;
   constexpr int NPL = SPLIT ? 2 : 1;                 // planes per operand
   constexpr int ROWB = BK * 2;                       // LDS row pitch (bytes), unpadded
   constexpr int CPR = ROWB / 16;                     // 16-byte chunks per row: 4 (BK=32) or 8 (BK=64)
   constexpr int RPI = 64 / CPR;                      // rows per wave-instruction
-  constexpr int A_PL = CM ? 0 : BM * ROWB, B_PL = BD ? 0 : BN * ROWB;  // bytes per plane tile in the ring (AF: weights only; BD: no ring)
+  constexpr int A_PL = CM ? 0 : BM * ROWB, B_PL = BD ? 0 : BN * ROWB;  // bytes per plane tile in the ring (BD: no ring)
   constexpr int STAGE = (A_PL + B_PL) * NPL;
-  constexpr int AF_CH = BM == 64 ? 5 : 11;           // AF: chunks per phase (slab = AF_CH x (BM+2) rows x 128 B per plane)
-  constexpr int CH_PL = (BM + 2) * ROWB;             // AF: one chunk of one plane
-  constexpr int SLAB_PL = AF_CH * CH_PL, SLAB = SLAB_PL * NPL;
 #ifndef DV_NSTAGE_64
 #define DV_NSTAGE_64 4
 #endif
   // LDS ring depth: NSTAGE-1 tiles in flight (DV_NSTAGE_64: experiment knob for the 64x64 tiles' occupancy)
-  constexpr int NSTAGE = AF ? 3 : BD ? 1 : ((BM == 64 && BN == 64 && !SC1) ? DV_NSTAGE_64 : ((4 * STAGE <= 160 * 1024) ? 4 : 3));
+  constexpr int NSTAGE = BD ? 1 : ((BM == 64 && BN == 64 && !SC1) ? DV_NSTAGE_64 : ((4 * STAGE <= 160 * 1024) ? 4 : 3));
   constexpr int A_IPW = CM ? 0 : BM / RPI / NWV, B_IPW = BD ? 0 : BN / RPI / NWV;   // DMA instructions per wave per plane
   constexpr int A_IPW1 = A_IPW ? A_IPW : 1, B_IPW1 = B_IPW ? B_IPW : 1;   // (array extents)
   constexpr int LPT = (A_IPW + B_IPW) * NPL;         // DMA instructions per thread per k-tile
@@ -167,7 +154,7 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int m0, con
   int kt0 = 0, nk = total_kt;                        // this launch's k-tiles: [kt0, kt0 + nk)
   if (p.sk_mode == 1 || p.sk_mode == 3) { kt0 = ksel * total_kt / p.sk_split; nk = (ksel + 1) * total_kt / p.sk_split - kt0; }
   if (p.sk_mode == 2) nk = 0;
-  // ---- AF: position in the chunk-major k-tile order, wave-uniform.  koff() = packed-K element offset of the tile ----
+  // ---- BD: position in the chunk-major k-tile order (segment -> concat half -> 64-channel chunk -> tap), wave-uniform ----
   // (BD: the segment's plane pointers ride along in scalar registers - a segment-descriptor load from argument memory
   // inside the k-loop sits on every wave's critical path)
   struct AfIt { int seg, half, col, tap, taps, c0, c1, kbase, pad; const bf16_t* h0; const bf16_t* l0; const bf16_t* h1; const bf16_t* l1; };
@@ -182,11 +169,7 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int m0, con
       s.h0 = s1 ? bd_s1.a0_hi : bd_s0.a0_hi; s.l0 = s1 ? bd_s1.a0_lo : bd_s0.a0_lo;
       s.h1 = s1 ? bd_s1.a1_hi : bd_s0.a1_hi; s.l1 = s1 ? bd_s1.a1_lo : bd_s0.a1_lo;
       s.kbase = s.seg == 0 ? 0 : bd_kbase1;
-      return;
     }
-    const GemmSeg& sg = p.seg[s.seg < p.nseg ? s.seg : 0];
-    s.taps = sg.taps; s.c0 = sg.c0; s.c1 = sg.c1; s.pad = sg.pad;
-    s.kbase = s.seg == 0 ? 0 : p.seg[0].taps * (p.seg[0].c0 + p.seg[0].c1);
   };
   auto af_next = [&](AfIt& s) {
     if (++s.tap == s.taps) {
@@ -198,7 +181,6 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int m0, con
       }
     }
   };
-  auto af_koff = [&](const AfIt& s) { return s.kbase + s.tap * (s.c0 + s.c1) + (s.half ? s.c0 : 0) + s.col; };
   AfIt af0{};                                        // first tile of this workgroup's k-range
   if (CM) {
     af_enter(af0);
@@ -233,7 +215,6 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int m0, con
   // prep_a() forms the A source addresses of the tile being issued; issue_unit() sends one unit; advance()
   // moves the source state to the next k-tile.  The main loop spreads the units between its MFMA groups.
   const void* asrc[A_IPW1 * NPL];
-  int af_issue_koff = 0;                             // AF: packed-K offset of the tile being issued
   // Inside one run (same source tensor, same tap) the next k-tile's rows are the same rows BK channels on: the pointers just
   // move by BK * 2 bytes - two vector instructions per pointer instead of the ~30 of the full row arithmetic below, which
   // runs only when a run begins (a_fresh).  [The k-loop is bound by instruction ISSUE - a SIMD issues one instruction of a
@@ -269,12 +250,7 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int m0, con
       if (DV_GEMM_EXP >= 2 && !CM) return;
       const int q = (u - A_IPW * NPL) / NPL, pl = (u - A_IPW * NPL) % NPL;
       const unsigned dst = st_base + (unsigned)(NPL * A_PL + ((q * NWV + wave) * RPI) * ROWB + pl * B_PL);
-      if (CM) {
-        const size_t o = b_off[q] + (size_t)af_issue_koff * 2;
-        glds16(reinterpret_cast<const char*>(pl ? p.w_lo : p.w_hi) + o, dst);
-      } else {
-        glds16_s(reinterpret_cast<const char*>(pl ? p.w_lo : p.w_hi) + (b_kbase + (unsigned)kt * (BK * 2)), b_off32[q], dst);
-      }
+      glds16_s(reinterpret_cast<const char*>(pl ? p.w_lo : p.w_hi) + (b_kbase + (unsigned)kt * (BK * 2)), b_off32[q], dst);
     }
   };
   auto advance = [&]() {
@@ -290,7 +266,6 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int m0, con
       if (ld_seg < p.nseg) enter();
     }
   };
-  AfIt af_is = af0;              // AF: tile being issued (runs NSTAGE-1 tiles ahead of the one being multiplied)
   // ---- BD: slab slots [BM rows hi | BM rows lo | halo: row -1 hi, row BM hi, row -1 lo, row BM lo] ----
   constexpr int BD_MAIN_PL = BM * ROWB, BD_SLOT = BD_MAIN_PL * NPL + 2048;   // (+ 1 KiB halo + 1 KiB target of the second producer's dummy)
   constexpr int BD_AH = DV_BD_AH, BD_NSLOT = BD_AH + 1;     // chunks in flight; slot of chunk c + AH = slot of chunk c - 1 (finished)
@@ -379,13 +354,11 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int m0, con
     return;                                            //  next barrier - they reuse the slots - completes only after that)
   }
   auto issue = [&](int kt) {     // whole tile at once (prologue)
-    if (CM) af_issue_koff = af_koff(af_is);
-    else if (a_fresh) prep_a();
+    if (a_fresh) prep_a();
     else prep_a_next();
 #pragma unroll
     for (int u = 0; u < LPT; ++u) issue_unit(kt, u);
-    if (CM) af_next(af_is);
-    else advance();
+    advance();
   };
   if (!CM && kt0 > 0) {                              // second k-half: move the source state to its first tile
     for (int t = 0; t < kt0; ++t) advance();
@@ -402,17 +375,6 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int m0, con
     for (int j = 0; j < FN; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-  // AF tiles run ONE MFMA wave per SIMD with a single 32x32 fragment: twelve MFMAs per k-tile chained on one accumulator
-  // expose the MFMA result latency (measured: ~1800 cycles per k-tile).  Each 16-deep k-step gets its own accumulator
-  // (four independent chains, summed once before the epilogue).
-  constexpr int NACC = (AF && FM * FN == 1) ? (BK / 16 / KS) : 1;
-  f32x16 accq[NACC > 1 ? NACC - 1 : 1];
-  if (NACC > 1) {
-#pragma unroll
-    for (int a = 0; a < NACC - 1; ++a)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) accq[a][r] = 0.f;
-  }
   constexpr bool SPLIT_EPI = KS == 2 && FM % 2 == 0;
   const int l31 = lane & 31, lh = lane >> 5;
   // split-K dump: [slice][tile][fragment][4 column groups][64 * NWQ lanes] float4
@@ -445,26 +407,22 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int m0, con
   constexpr int NKS = BK / 16 / KS;                  // 16-deep k-steps per wave per k-tile
   constexpr int NTERM = SPLIT ? 3 : 1;
   constexpr int NCH = NKS * NTERM;                   // MFMA groups per k-tile
-  AfIt af_cs = af0;              // AF: tile being multiplied
-  int af_ci = 0;                 // AF: its chunk's index inside the resident phase
   bf16x8 ahK[NKS][FM], alK[NKS][FM], bhK[NKS][FN], blK[NKS][FN];   // (DV_GEMM_EXP: fragments read once)
   bool exp_first = true;
   auto step = [&](int kt, auto issue_tag) {
     constexpr bool ISSUE = decltype(issue_tag)::value && !(DV_GEMM_EXP == 4 && !CM);
     const char* base = smem + (kt % NSTAGE) * STAGE;
-    const char* a_hi = AF ? smem + NSTAGE * STAGE + af_ci * CH_PL : base;
-    const char* a_lo = AF ? a_hi + SLAB_PL : base + A_PL;
+    const char* a_hi = base;
+    const char* a_lo = base + A_PL;
     const char* b_hi = base + NPL * A_PL;
     const char* b_lo = b_hi + B_PL;
-    // AF: slab row 0 is frame t0 - 1; tap j of a conv padded by `pad` reads row + j + 1 - pad
-    const int af_rowoff = AF ? af_cs.tap + 1 - af_cs.pad : 0;
     bf16x8 ah[NKS][FM], al[NKS][FM], bh[NKS][FN], bl[NKS][FN];
 #pragma unroll
     for (int ks0 = 0; ks0 < NKS; ++ks0) {
       const int chunk = (kgrp * NKS + ks0) * 2 + lh;
 #pragma unroll
       for (int i = 0; i < FM; ++i) {
-        const int row = (wm * FM + i) * 32 + l31 + af_rowoff;
+        const int row = (wm * FM + i) * 32 + l31;
         const int off = row * ROWB + ((chunk ^ swz(row)) << 4), off_lo = off;
         if (DV_GEMM_EXP == 3 && !CM) {
           if (exp_first) { ahK[ks0][i] = *reinterpret_cast<const bf16x8*>(a_hi + off); if (SPLIT) alK[ks0][i] = *reinterpret_cast<const bf16x8*>(a_lo + off_lo); }
@@ -491,12 +449,12 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int m0, con
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
       // (independent accumulators per k-step: consecutive MFMAs alternate chains)
-      const int ks0 = NACC > 1 ? c % NKS : c / NTERM, term = NACC > 1 ? c / NKS : c % NTERM;
+      const int ks0 = c / NTERM, term = c % NTERM;
 #pragma unroll
       for (int i = 0; i < FM; ++i)
 #pragma unroll
         for (int j = 0; j < FN; ++j) {
-          f32x16& ac = (NACC > 1 && ks0 > 0) ? accq[ks0 - 1] : acc[i][j];
+          f32x16& ac = acc[i][j];
           if (SPLIT && term == 0)
             ac = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh[ks0][j], al[ks0][i], ac, 0, 0, 0);
           else if (SPLIT && term == 1)
@@ -507,15 +465,14 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int m0, con
       if (ISSUE) {
         __builtin_amdgcn_sched_barrier(0);
         if (c == 0) {
-          if (CM) af_issue_koff = af_koff(af_is); else if (a_fresh) prep_a(); else prep_a_next();
+          if (a_fresh) prep_a(); else prep_a_next();
         }
 #pragma unroll
         for (int u = c * LPT / NCH; u < (c + 1) * LPT / NCH; ++u) issue_unit(kt + NSTAGE - 1, u);
         __builtin_amdgcn_sched_barrier(0);
       }
     }
-    if (ISSUE) { if (CM) af_next(af_is); else advance(); }
-    if (CM) { af_next(af_cs); if (af_cs.tap == 0) ++af_ci; }
+    if (ISSUE) advance();
   };
 
   // accumulator fragment (i, j), lane (l31, lh), register r = 4*g + e  holds
@@ -598,146 +555,6 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int m0, con
     const int n = min(n0 + wave * 64 + lane, p.N - 1);
     glds4((const void*)(p.ln_u + n), (unsigned)(size_t)s_u + wave * 256);
   }
-
-  // ---- AF: GroupNorm table of this utterance, and the phase converter (all waves) ----
-  constexpr int NT_ALL = 64 * NWV;
-  __shared__ __attribute__((aligned(16))) float s_gscale[AF ? 1024 : 4], s_gshift[AF ? 1024 : 4];
-  const int af_T = p.T_out, af_b = AF ? m0 / p.T_out : 0, af_t0 = AF ? m0 - af_b * p.T_out : 0;
-  auto af_table = [&]() {
-    // scale[c] = rstd*gamma*(1+ts), shift[c] = (beta - mean*rstd*gamma)*(1+ts) + tb over segment 0's concat channels.
-    // Latency matters (the first multiply waits for it): the per-channel parameters are fetched first (independent of
-    // the statistics); the utterance's block entries (sum, M2 about the block mean) are fetched by all threads at once
-    // into the last ring stage (the weight prologue fills stages 0 .. NSTAGE-2 only); every wave then reduces ALL groups
-    // from there (64 / G lanes per group, one pass in fp64) and the channel owner picks its group's (mean, rstd).
-    const int G = p.afp.groups, c0s = p.seg[0].c0, ctot = c0s + p.seg[0].c1, cg = ctot / G, nvb = cg >> 4, RB = af_T >> 5;
-    constexpr int CPT = (1024 + NT_ALL - 1) / NT_ALL;
-    float pg[CPT], pb[CPT], pts[CPT], ptb[CPT];
-#pragma unroll
-    for (int k = 0; k < CPT; ++k) {
-      const int cc = min(tid + k * NT_ALL, ctot - 1);
-      pg[k] = p.afp.gamma[cc];
-      pb[k] = p.afp.beta[cc];
-      pts[k] = p.afp.tscale ? p.afp.tscale[(size_t)af_b * p.afp.ld_t + cc] : 0.0f;
-      ptb[k] = p.afp.tshift ? p.afp.tshift[(size_t)af_b * p.afp.ld_t + cc] : 0.0f;
-    }
-    const int nblk = ctot >> 4, n_ent = RB * nblk;
-    float2* s_ent = reinterpret_cast<float2*>(smem + (NSTAGE - 1) * STAGE);
-    for (int e0 = 0; e0 < n_ent; e0 += 2 * NT_ALL) {
-      float2 ev[2];
-#pragma unroll
-      for (int k = 0; k < 2; ++k) {
-        const int e = min(e0 + k * NT_ALL + tid, n_ent - 1);
-        const int rb = e / nblk, vb = e - rb * nblk;
-        const int half = vb * 16 >= c0s;
-        const AfSrc& a = p.afp.src[0][half];
-        const int vbl = half ? vb - (c0s >> 4) : vb;
-        ev[k] = reinterpret_cast<const float2*>(a.stat16)[(size_t)(af_b * RB + rb) * (a.C >> 4) + vbl];
-      }
-#pragma unroll
-      for (int k = 0; k < 2; ++k) {
-        const int e = e0 + k * NT_ALL + tid;
-        if (e < n_ent) s_ent[e] = ev[k];
-      }
-    }
-    __syncthreads();
-    const int lpg = 64 / G;                          // lanes per group (G a power of two <= 64)
-    const int g = lane / lpg, sub = lane - g * lpg;
-    // M2_b + sum_b^2 / 512 = the block's sum of squares; accumulated in fp64 (the one fp64 subtraction below is harmless)
-    double s1 = 0, q = 0;
-    for (int i0 = sub; i0 < RB * nvb; i0 += 4 * lpg) {
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const int i = i0 + k * lpg;
-        const int rb = i / nvb;
-        const float2 v = s_ent[min(rb * nblk + g * nvb + (i - rb * nvb), n_ent - 1)];
-        if (i < RB * nvb) {
-          s1 += (double)v.x;
-          q += (double)v.y + (double)v.x * (double)v.x * (1.0 / 512.0);
-        }
-      }
-    }
-    for (int o = lpg >> 1; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o); q += __shfl_xor(q, o); }
-    const double n = (double)cg * (double)af_T;
-    const double mean_d = s1 / n;
-    double var = q / n - mean_d * mean_d;
-    var = var > 0 ? var : 0;
-    const float mean = (float)mean_d, rstd = 1.0f / sqrtf((float)var + p.afp.eps);
-#pragma unroll
-    for (int k = 0; k < CPT; ++k) {
-      const int cc = tid + k * NT_ALL;
-      const int src_lane = min(cc, ctot - 1) / cg * lpg;
-      const float gm = __shfl(mean, src_lane), gr = __shfl(rstd, src_lane);
-      if (cc < ctot) {
-        const float a = gr * pg[k];
-        const float ts = 1.0f + pts[k];
-        s_gscale[cc] = a * ts;
-        s_gshift[cc] = fmaf(pb[k] - gm * a, ts, ptb[k]);
-      }
-    }
-    __syncthreads();
-  };
-  // Convert the chunks [c, c + n) of the k-range (c at tap 0) into the slab: task = (slab row, 4-channel group); a
-  // thread keeps its 4-channel group (NT_ALL % 16 == 0).  Loads are unconditional (clamped row, zeroed afterwards): a
-  // per-element "load or zero" select makes hipcc branch around each load and wait for it.
-  auto af_convert = [&](AfIt c, int n) {
-    constexpr int TASKS = (BM + 2) * 16, RNDS = (TASKS + NT_ALL - 1) / NT_ALL;
-    const int c4 = tid & 15;
-    for (int ci = 0; ci < n; ++ci) {
-      const AfSrc& a = p.afp.src[c.seg][c.half];
-      const int mode = c.seg == 0 ? p.afp.mode0 : 0;
-      const float* base = a.x + (size_t)af_b * af_T * a.C + c.col + c4 * 4;
-      const int ldc = a.C;
-      float4 rv[RNDS];
-#pragma unroll
-      for (int j = 0; j < RNDS; ++j) {
-        const int srow = min((j * NT_ALL + tid) >> 4, BM + 1);
-        const int t = af_t0 - 1 + srow;
-        rv[j] = *reinterpret_cast<const float4*>(base + (size_t)min(max(t, 0), af_T - 1) * ldc);
-      }
-      float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (mode) {
-        const int tab = (c.half ? c.c0 : 0) + c.col + c4 * 4;
-        sc = *reinterpret_cast<const float4*>(s_gscale + tab);
-        sh = *reinterpret_cast<const float4*>(s_gshift + tab);
-      }
-      char* sl = smem + NSTAGE * STAGE + ci * CH_PL;
-#pragma unroll
-      for (int j = 0; j < RNDS; ++j) {
-        const int id = j * NT_ALL + tid;
-        if (id >= TASKS) continue;
-        const int srow = id >> 4;
-        const int t = af_t0 - 1 + srow;
-        float v[4] = {rv[j].x, rv[j].y, rv[j].z, rv[j].w};
-        const float scv[4] = {sc.x, sc.y, sc.z, sc.w}, shv[4] = {sh.x, sh.y, sh.z, sh.w};
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          v[e] = fmaf(v[e], scv[e], shv[e]);
-          if (mode == 2) v[e] = v[e] * __builtin_amdgcn_rcpf(1.0f + __expf(-v[e]));   // SiLU
-          // conv zero padding pads the NORMALISED tensor: frames outside the utterance are zeros, not norm(0)
-          if (t < 0 || t >= af_T) v[e] = 0.f;
-        }
-        uint2 hw, lw;
-        hw.x = cvt_pk_bf16(v[0], v[1]); hw.y = cvt_pk_bf16(v[2], v[3]);
-        lw.x = cvt_pk_bf16(v[0] - __uint_as_float(hw.x << 16), v[1] - __uint_as_float(hw.x & 0xffff0000u));
-        lw.y = cvt_pk_bf16(v[2] - __uint_as_float(hw.y << 16), v[3] - __uint_as_float(hw.y & 0xffff0000u));
-        const int off = srow * ROWB + (((c4 >> 1) ^ swz(srow)) << 4) + (c4 & 1) * 8;
-        *reinterpret_cast<uint2*>(sl + off) = hw;
-        if (SPLIT) *reinterpret_cast<uint2*>(sl + SLAB_PL + off) = lw;
-      }
-      c.tap = c.taps - 1;
-      af_next(c);
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // slab writes landed before this wave reaches the k-tile barrier
-  };
-  // chunks / tiles of the next phase starting at chunk state c with `left` tiles of the range remaining
-  auto af_phase = [&](AfIt c, int left, int& n_chunks, int& n_tiles) {
-    n_chunks = 0; n_tiles = 0;
-    while (n_chunks < AF_CH && n_tiles < left) {
-      n_tiles += c.taps; ++n_chunks;
-      c.tap = c.taps - 1;
-      af_next(c);
-    }
-  };
 
   // ---- main loop: wait(tile kt) -> barrier -> multiply tile kt with the DMA of tile kt+NSTAGE-1 interleaved ----
   // NSTAGE-1 tiles are in flight; the counted vmcnt leaves the younger ones outstanding across the barrier
@@ -880,23 +697,6 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int m0, con
 #endif
   }
   DV_TRACE(1);
-  AfIt af_pc = af0;              // AF: first chunk of the phase being multiplied
-  int af_ph_tiles = 0, af_ph_chunks = 0, af_left = nk;
-  if (AF) {
-    if (p.afp.mode0) af_table();
-    af_phase(af_pc, af_left, af_ph_chunks, af_ph_tiles);
-    af_convert(af_pc, af_ph_chunks);                 // (visible after the first k-tile barrier)
-  }
-  // AF: a phase ends -> every wave has finished reading the slab (barrier), convert the next phase, go on
-  auto af_boundary = [&]() {
-    if (AF && af_ph_tiles == 0 && af_left > 0) {
-      __syncthreads();
-      for (int c = 0; c < af_ph_chunks; ++c) { af_pc.tap = af_pc.taps - 1; af_next(af_pc); }
-      af_phase(af_pc, af_left, af_ph_chunks, af_ph_tiles);
-      af_convert(af_pc, af_ph_chunks);
-      af_ci = 0;
-    }
-  };
   // steady state: tile kt+NSTAGE-1 is issued while tile kt is multiplied; NSTAGE-2 younger tiles stay in flight
   const int n_steady = nk - (NSTAGE - 1);
   int kt = 0;
@@ -904,7 +704,6 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int m0, con
   unsigned long long tr_vm = 0, tr_bar = 0, tr_step = 0;
 #endif
   for (; kt < n_steady; ++kt) {
-    af_boundary();
 #ifdef DV_GEMM_TRACING
     const unsigned long long tr0 = __builtin_amdgcn_s_memtime();
 #endif
@@ -918,19 +717,16 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int m0, con
     if (kt == 0) DV_TRACE(2);
 #endif
     step(kt, std::true_type{});                      // DMA overwrites the stage tile kt-1 was read from
-    --af_ph_tiles; --af_left;
 #ifdef DV_GEMM_TRACING
     tr_vm += tr1 - tr0; tr_bar += tr2 - tr1; tr_step += __builtin_amdgcn_s_memtime() - tr2;
 #endif
   }
 #ifdef DV_GEMM_TRACING
-  if (threadIdx.x == 0 && blockIdx.x < 8192) {   // the steady loop's wait sums (AF: also in the prologue-split slots)
+  if (threadIdx.x == 0 && blockIdx.x < 8192) {   // the steady loop's wait sums
     g_gemm_trace[blockIdx.x * 16 + 12] = tr_vm; g_gemm_trace[blockIdx.x * 16 + 13] = tr_bar; g_gemm_trace[blockIdx.x * 16 + 14] = tr_step;
-    if (AF) { g_gemm_trace[blockIdx.x * 16 + 8] = tr_vm; g_gemm_trace[blockIdx.x * 16 + 9] = tr_bar; g_gemm_trace[blockIdx.x * 16 + 10] = tr_step; }
   }
 #endif
   for (; kt < nk; ++kt) {                            // drain: nothing left to issue
-    af_boundary();
     const int younger = min(NSTAGE - 2, nk - 1 - kt);
     if (younger >= 2) wait_vmcnt<2 * LPT_W>();
     else if (younger == 1) wait_vmcnt<LPT_W>();
@@ -940,16 +736,9 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int m0, con
     if (kt == 0) DV_TRACE(2);
 #endif
     step(kt, std::false_type{});
-    --af_ph_tiles; --af_left;
   }
   }   // (!BD)
 
-  if (NACC > 1) {
-#pragma unroll
-    for (int a = 0; a < NACC - 1; ++a)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[0][0][r] += accq[a][r];
-  }
   if (nk == 0) { wait_vmcnt<0>(); __syncthreads(); }   // epilogue-only launch: the bias DMA has landed
   DV_TRACE(3);
   // KS == 2: add the two k-groups' partial accumulators through LDS (lane-linear, conflict-free).  With an even
@@ -1063,7 +852,7 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int m0, con
 
   // ---- epilogue ----
   DV_TRACE(4);
-  const bool gnx = !SC1 && !AF && p.gnx.xchg != nullptr;   // (BD tiles too)
+  const bool gnx = !SC1 && p.gnx.xchg != nullptr;   // (BD tiles too)
   // store 4 consecutive columns of one row: fp32 and/or split bf16 planes
   auto store4 = [&](size_t o, int nb, const float* v) {
     if (vec4) {

@@ -26,7 +26,7 @@
 #include <cstdlib>
 #include <type_traits>
 
-template <int BM, int BN, int BK, int WM, int WN, int NSPLIT, int KS, bool AF = false, bool BD = false>
+template <int BM, int BN, int BK, int WM, int WN, int NSPLIT, int KS, bool BD = false>
 __global__ __launch_bounds__(64 * WM * WN * KS + (BD ? 128 : 0)) void k_gemm(const GemmParams p) {   // (BD: + two producer waves)
   extern __shared__ __attribute__((aligned(1024))) char smem[];
   // XCD-aware tile order (workgroup b runs on XCD b % 8; each XCD has its own L2, which starts cold): an XCD's workgroups
@@ -46,7 +46,7 @@ __global__ __launch_bounds__(64 * WM * WN * KS + (BD ? 128 : 0)) void k_gemm(con
     const int x = bid & 7, i = bid >> 3;
     const int ks_i = x >> p.xcd_sh_mn, r = x & ((1 << p.xcd_sh_mn) - 1), xm_i = r >> p.xcd_sh_n, xn_i = r & (p.xcd_n - 1);
     const int lm = (i * p.xcd_inv_tn) >> 16, ln = i - lm * p.xcd_tn;
-    gemm_tile<BM, BN, BK, WM, WN, NSPLIT, KS, false, AF, BD>(p, (xm_i * p.xcd_tm + lm) * BM, (xn_i * p.xcd_tn + ln) * BN, smem, ks_i);
+    gemm_tile<BM, BN, BK, WM, WN, NSPLIT, KS, false, BD>(p, (xm_i * p.xcd_tm + lm) * BM, (xn_i * p.xcd_tn + ln) * BN, smem, ks_i);
     return;
   }
   {
@@ -59,7 +59,7 @@ __global__ __launch_bounds__(64 * WM * WN * KS + (BD ? 128 : 0)) void k_gemm(con
     ksel = bid / tiles;
     bid -= ksel * tiles;
   }
-  gemm_tile<BM, BN, BK, WM, WN, NSPLIT, KS, false, AF, BD>(p, (bid / n_tiles_n) * BM, (bid % n_tiles_n) * BN, smem, ksel);
+  gemm_tile<BM, BN, BK, WM, WN, NSPLIT, KS, false, BD>(p, (bid / n_tiles_n) * BM, (bid % n_tiles_n) * BN, smem, ksel);
 }
 
 template <int BM, int BN, int BK, int WM, int WN, int NSPLIT, int KS>
@@ -78,49 +78,18 @@ struct GemmCfg {
   }
 };
 
-// AF tiles (A operand produced in-kernel, gemm_tile.h): 64-deep k-tiles, ring of 3 weight stages + a resident slab of
-// AF_CH chunks x (BM + 2) normalised rows
-template <int BM, int BN, int WM, int WN, int KS, int NSPLIT>
-struct GemmCfgAF {
-  static constexpr int NPL = NSPLIT == 3 ? 2 : 1;
-  static constexpr int AF_CH = BM == 64 ? 5 : 11;
-  static constexpr int SMEM = 3 * BN * 128 * NPL + AF_CH * (BM + 2) * 128 * NPL;
-  static hipError_t init() {
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm<BM, BN, 64, WM, WN, NSPLIT, KS, true>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
-  }
-  static hipError_t launch(const GemmParams& p, hipStream_t st) {
-    const int tiles = (p.M / BM) * ((p.N + BN - 1) / BN) * (p.sk_mode == 3 ? p.sk_split : 1);
-    hipLaunchKernelGGL((k_gemm<BM, BN, 64, WM, WN, NSPLIT, KS, true>), dim3(tiles), dim3(64 * WM * WN * KS), SMEM, st, p);
-    return hipGetLastError();
-  }
-};
-template <int BM, int BN, int WM, int WN, int KS>
-struct GemmTileAF {
-  static hipError_t init() {
-    hipError_t e = GemmCfgAF<BM, BN, WM, WN, KS, 3>::init();
-    return e != hipSuccess ? e : GemmCfgAF<BM, BN, WM, WN, KS, 1>::init();
-  }
-  static hipError_t launch(const GemmParams& p, bool x3, hipStream_t st) {
-    return x3 ? GemmCfgAF<BM, BN, WM, WN, KS, 3>::launch(p, st) : GemmCfgAF<BM, BN, WM, WN, KS, 1>::launch(p, st);
-  }
-};
-// 64x64: two k-groups of four waves (two per SIMD); 32x64: two k-groups of two waves
-using AF64 = GemmTileAF<64, 64, 2, 2, 2>;
-using AF32 = GemmTileAF<32, 64, 1, 2, 2>;
-
 // BD tile (gemm_tile.h): weights fragment-major straight into registers, activations through per-chunk slab slots
 template <int NSPLIT>
 struct GemmCfgBD {
   static constexpr int NPL = NSPLIT == 3 ? 2 : 1;
   static constexpr int SMEM = ((DV_BD_AH + 1) * (64 * 128 * NPL + 2048)) > 65536 ? ((DV_BD_AH + 1) * (64 * 128 * NPL + 2048)) : 65536;   // BD_NSLOT slab slots (>= the 64 KiB k-group hand-over)
   static hipError_t init() {
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm<64, 64, 64, 1, 2, NSPLIT, 4, false, true>),
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm<64, 64, 64, 1, 2, NSPLIT, 4, true>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
   }
   static hipError_t launch(const GemmParams& p, hipStream_t st) {
     const int tiles = (p.M / 64) * ((p.N + 63) / 64) * (p.sk_mode == 3 ? p.sk_split : 1);
-    hipLaunchKernelGGL((k_gemm<64, 64, 64, 1, 2, NSPLIT, 4, false, true>), dim3(tiles), dim3(640), SMEM, st, p);
+    hipLaunchKernelGGL((k_gemm<64, 64, 64, 1, 2, NSPLIT, 4, true>), dim3(tiles), dim3(640), SMEM, st, p);
     return hipGetLastError();
   }
 };
@@ -128,7 +97,7 @@ struct GemmCfgBD {
 // utterance, plain row gather (stride 1, no upsample), k = 1 / 3 segments with 'same' padding, no GEGLU epilogue (its
 // [32 a | 32 gate] column blocks must sit in ONE wave; BD's waves own 32 columns).
 bool gemm_bd_supported(const GemmParams& p) {
-  if (!p.wf_hi || p.af || p.stride != 1 || p.up_mode != UP_NONE || p.T_in != p.T_out || p.T_out % 64 != 0 || p.M != p.B * p.T_out) return false;
+  if (!p.wf_hi || p.stride != 1 || p.up_mode != UP_NONE || p.T_in != p.T_out || p.T_out % 64 != 0 || p.M != p.B * p.T_out) return false;
   if (p.epi == EPI_GEGLU || p.sk_mode == 1 || p.sk_mode == 2 || p.Kp % 16 != 0 || p.N_pad % 64 != 0) return false;
   int k_tot = 0;
   for (int s2 = 0; s2 < p.nseg; ++s2) {
@@ -211,29 +180,9 @@ hipError_t gemm_init() {
   hipError_t e = Tiles<32>::init();
   if (e != hipSuccess) return e;
   if ((e = Tiles<64>::init()) != hipSuccess) return e;
-  if ((e = AF64::init()) != hipSuccess) return e;
   if ((e = GemmCfgBD<3>::init()) != hipSuccess) return e;
   if ((e = GemmCfgBD<1>::init()) != hipSuccess) return e;
-  return AF32::init();
-}
-
-// Can this GEMM run on the AF tiles?  (the engine asks before it plans a fused GroupNorm -> conv)
-bool gemm_af_supported(const GemmParams& p) {
-  if (p.stride != 1 || p.up_mode != UP_NONE || p.T_in != p.T_out || p.T_out % 32 != 0 || p.M != p.B * p.T_out) return false;
-  if (p.ln_stat || p.epi == EPI_GEGLU) return false;
-  for (int s = 0; s < p.nseg; ++s) {
-    const GemmSeg& sg = p.seg[s];
-    if (sg.c0 % 64 != 0 || sg.c1 % 64 != 0 || sg.c0 <= 0 || (sg.taps != 1 && sg.taps != 3) || sg.pad != (sg.taps - 1) / 2) return false;
-    if (!p.afp.src[s][0].x || p.afp.src[s][0].C != sg.c0 || (sg.c1 > 0 && (!p.afp.src[s][1].x || p.afp.src[s][1].C != sg.c1))) return false;
-  }
-  if (p.nseg > 1 && p.seg[1].taps != 1) return false;
-  if (p.afp.mode0) {
-    const int ctot = p.seg[0].c0 + p.seg[0].c1, G = p.afp.groups;
-    if (G <= 0 || G > 64 || (G & (G - 1)) != 0 || ctot > 1024 || ctot % G != 0 || (ctot / G) % 16 != 0 || !p.afp.gamma || !p.afp.beta) return false;
-    if (!p.afp.src[0][0].stat16 || (p.seg[0].c1 > 0 && !p.afp.src[0][1].stat16)) return false;
-    if ((p.T_out / 32) * (ctot / 16) > 1024) return false;      // block entries of one utterance are staged in a ring stage (8 KiB in bf16 mode)
-  }
-  return true;
+  return hipSuccess;
 }
 
 // Tunables (env DVITS_GEMM_CFG="big,min_wg,bk64"): workgroup-count threshold for the 128x128x32 tile,
@@ -300,7 +249,7 @@ void gemm_env_refresh() {
   e = getenv("DVITS_GEMM_BD"); g_env_bd = e ? atoi(e) : 0;
 }
 
-// Tile (BM x BN) the shape heuristic of launch_gemm picks for a non-AF, non-GEGLU GEMM (kept in step with
+// Tile (BM x BN) the shape heuristic of launch_gemm picks for a non-GEGLU GEMM (kept in step with
 // Tiles<BK>::launch below; used to plan the in-epilogue GroupNorm: its tiles must not span utterances and must all be resident)
 static void gemm_pick_tile(const GemmParams& p, int& bm, int& bn) {
   const GemmTune& tune = gemm_tune();
@@ -322,7 +271,7 @@ static void gemm_pick_tile(const GemmParams& p, int& bm, int& bn) {
 }
 
 int gemm_gnx_plan(const GemmParams& p, int n_cu) {
-  if (p.af || p.force_tile != GT_AUTO || (p.epi != EPI_STORE && p.epi != EPI_RESIDUAL) || !p.stats16 || p.rowmask || p.relu) return 0;
+  if (p.force_tile != GT_AUTO || (p.epi != EPI_STORE && p.epi != EPI_RESIDUAL) || !p.stats16 || p.rowmask || p.relu) return 0;
   if (p.M != p.B * p.T_out || p.gnx.groups <= 0 || p.N % p.gnx.groups != 0) return 0;
   const int cpg = p.N / p.gnx.groups;
   if (cpg % 16 != 0 || p.N % 16 != 0) return 0;
@@ -351,19 +300,6 @@ hipError_t launch_gemm(const GemmParams& pin, int precision, hipStream_t st) {
     static const int n_cu = [] { int d = 0, n = 0; (void)hipGetDevice(&d); (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, d); return n; }();
     if (!p.gnx.status || !p.gnx.y_hi || !p.gnx.gamma || !p.gnx.beta || gemm_gnx_plan(p, n_cu) <= 0) return hipErrorInvalidValue;
   }
-  if (p.af) {
-    if (!gemm_af_supported(p)) return hipErrorInvalidValue;
-    // split-K: only the one-launch pair (ticket hand-over); the k-range is cut at a chunk boundary inside the kernel
-    if (p.sk_buf && p.sk_split == 2 && p.sk_ticket) p.sk_mode = 3;
-    else { p.sk_buf = nullptr; p.sk_split = 0; p.sk_mode = 0; p.sk_ticket = nullptr; }
-    for (int s = 0; s < p.nseg; ++s) p.seg[s].nkt = p.seg[s].taps * (p.seg[s].c0 + p.seg[s].c1) / 64;
-    static const int env_tile = [] { const char* e = getenv("DVITS_AF_TILE"); return e ? atoi(e) : 0; }();   // experiment knob: 32 / 64
-    const int ft = (p.force_tile & 0xff) ? (p.force_tile & 0xff) : (env_tile == 32 ? GT_AF32 : 0);
-    const bool t64 = p.T_out % 64 == 0;
-    if (ft == GT_AF64 && !t64) return hipErrorInvalidValue;
-    const bool use64 = ft == GT_AF64 || (ft != GT_AF32 && t64);
-    return use64 ? AF64::launch(p, x3, st) : AF32::launch(p, x3, st);
-  }
   if (p.sk_buf && p.sk_split == 2 && p.sk_ticket && p.sk_mode == 0) {
     p.sk_mode = 3;                                     // both k-halves and the epilogue in one launch
     return launch_gemm(p, precision, st);
@@ -379,7 +315,7 @@ hipError_t launch_gemm(const GemmParams& pin, int precision, hipStream_t st) {
   // XCD rectangle (k_gemm): split the columns over xn of the 8 XCDs where that lowers what one L2 has to fetch -
   // (N / xn) x K of W plus (M / xm) x channels of A.  DVITS_XCD_N=<1|2|4|8> forces xn where it divides, 0 = row bands.
   p.xcd_n = 0;
-  if (p.force_tile == GT_AUTO && !p.af) {
+  if (p.force_tile == GT_AUTO) {
     const int env_xn = g_env_xn;
     int bm, bn;
     gemm_pick_tile(p, bm, bn);

@@ -845,8 +845,8 @@ hipError_t launch_lincomb(float* out, const float* x, const float* m0, const flo
 
 
 // ---- 32x16-block statistics of a channels-last fp32 tensor [M, C] -> stat16 [M/32, C/16, 2] = (sum, squared deviations
-// from the block's own mean): what a GEMM epilogue writes beside its output for the consumer conv that normalises its own
-// operand (gemm_tile.h, AF tiles).  Standalone form for tensors that did not come out of such an epilogue.
+// from the block's own mean): what a GEMM epilogue writes beside its output for the GroupNorm of its consumer.
+// Standalone form for tensors that did not come out of such an epilogue.
 __global__ __launch_bounds__(64) void k_stat16(const float* __restrict__ x, float* __restrict__ stat16, int M, int C) {
   const int rb = blockIdx.x, cb = blockIdx.y, lane = threadIdx.x;
   const int row = rb * 32 + (lane >> 1), col = cb * 16 + (lane & 1) * 8;

@@ -241,15 +241,6 @@ int dv_penc_stats(dv_penc* p, int64_t* n_launch, double* flops);
  * frames first (0 = none).  w: [Cout, Cin, k] float32, bias [Cout] or NULL. */
 int dv_op_conv1d(const float* x, const float* w, const float* bias, float* y, int32_t B, int32_t Cin, int32_t T,
                  int32_t Cout, int32_t k, int32_t stride, int32_t up_T, int32_t precision, void* stream);
-/* y[B,Cout,T] = conv1d(silu?(GroupNorm(x) * (1 + tscale) + tshift)), k = 1 or 3, padding (k-1)/2, as ONE launch of the
- * implicit-GEMM kernel whose producer waves normalise the operand (reference resnet.py:591-641: norm -> SiLU -> conv;
- * transformer_1d.py:264-268: norm -> proj_in).  x_cl: CHANNELS-LAST [B*T, Cin] float32 (the engine's activation layout);
- * gamma/beta [Cin]; tscale/tshift [B, Cin] or NULL (temb scale/shift, resnet.py:622-625); w [Cout, Cin, k]; bias [Cout] or
- * NULL; y channels-first.  Needs T % 32 == 0, Cin % 64 == 0, (Cin / groups) % 16 == 0 - the shapes the engine fuses. */
-int dv_op_gn_conv1d(const float* x_cl, const float* gamma, const float* beta, const float* tscale, const float* tshift,
-                    const float* w, const float* bias, float* y, int32_t B, int32_t Cin, int32_t T, int32_t Cout,
-                    int32_t k, int32_t groups, float eps, int32_t silu, int32_t precision, void* stream);
-
 /* y[M,N] = x[M,K] @ w[N,K]^T + bias */
 int dv_op_linear(const float* x, const float* w, const float* bias, float* y, int32_t M, int32_t K, int32_t N,
                  int32_t precision, void* stream);

@@ -22,18 +22,16 @@ lib.dv_debug_gemm_trace.argtypes = [C.c_void_p, C.c_int]
 
 shapes = [(8192, 128, 128), (4096, 256, 2048), (1024, 3072, 512), (2048, 384, 3072), (2048, 1536, 384),
           (4096, 256, 256), (2048, 384, 384)]
-# "af:BxTxCinxCoutxk" traces the fused GroupNorm -> conv tiles (dv_op_gn_conv1d) instead of a plain linear
-af_shapes = [tuple(int(v) for v in a[3:].split("x")) for a in sys.argv[1:] if a.startswith("af:")]
-# "conv:BxTxCinxCoutxk" traces a plain conv1d (dv_op_conv1d; with DVITS_SLAB=1 a k = 3 conv with 64-multiples runs on the A-slab tile)
+# "conv:BxTxCinxCoutxk" traces a conv1d (dv_op_conv1d; with DVITS_GEMM_BD=2 a stride-1 conv with 64-multiples of channels runs on the BD tile)
 conv_shapes = [tuple(int(v) for v in a[5:].split("x")) for a in sys.argv[1:] if a.startswith("conv:")]
-plain = [a for a in sys.argv[1:] if not a.startswith("af:") and not a.startswith("conv:")]
+plain = [a for a in sys.argv[1:] if not a.startswith("conv:")]
 if plain:
     shapes = [tuple(int(v) for v in a.split("x")) for a in plain]
-elif af_shapes or conv_shapes:
+elif conv_shapes:
     shapes = []
 NWG = 8192
 buf = np.zeros((NWG, 16), dtype=np.uint64)
-for spec in shapes + [("af",) + a for a in af_shapes] + [("conv",) + a for a in conv_shapes]:
+for spec in shapes + [("conv",) + a for a in conv_shapes]:
     if spec[0] == "conv":
         _, Bn, Tn, Ci, Co, kk = spec
         M, K, N = Bn * Tn, Ci * kk, Co
@@ -44,18 +42,6 @@ for spec in shapes + [("af",) + a for a in af_shapes] + [("conv",) + a for a in 
 
         def run():
             L.check(lib.dv_op_conv1d(L.ptr(x), L.ptr(w), L.ptr(b), L.ptr(y), Bn, Ci, Tn, Co, kk, 1, 0, 0, None))
-    elif spec[0] == "af":
-        _, Bn, Tn, Ci, Co, kk = spec
-        M, K, N = Bn * Tn, Ci * kk, Co
-        x = torch.randn(M, Ci, device="cuda")
-        w = torch.randn(Co, Ci, kk, device="cuda") / K ** 0.5
-        b = torch.randn(N, device="cuda")
-        gam, bet = torch.ones(Ci, device="cuda"), torch.zeros(Ci, device="cuda")
-        y = torch.empty(Bn, Co, Tn, device="cuda")
-
-        def run():
-            L.check(lib.dv_op_gn_conv1d(L.ptr(x), L.ptr(gam), L.ptr(bet), None, None, L.ptr(w), L.ptr(b), L.ptr(y), Bn, Ci, Tn,
-                                        Co, kk, 8, 1e-5, 1, 0, None))
     else:
         M, K, N = spec
         x = torch.randn(M, K, device="cuda")
@@ -84,12 +70,9 @@ for spec in shapes + [("af",) + a for a in af_shapes] + [("conv",) + a for a in 
     pro = np.stack([t[:, 8] - t[:, 0], t[:, 9] - t[:, 8], t[:, 10] - t[:, 9], t[:, 11] - t[:, 10], t[:, 1] - t[:, 11]], 1)
     print("   k-loop sums of thread 0 (median cyc): waits for its DMA %d | waits at the barrier %d | multiplies + issues %d"
           % tuple(np.median(t[:, 12:15], 0)))
-    if spec[0] != "af":
+    if True:
         print("   prologue split (median cyc): kernarg-ready %d | row geometry %d | bias/residual/LN setup %d | issue tile 0 %d | "
               "issue tiles 1.. %d" % tuple(np.median(pro, 0)))
-    if spec[0] == "af":
-        print("   steady k-loop sums (median cyc): wave 0 waits for its DMA %d | waits at the barrier %d | multiplies %d"
-              % tuple(np.median(t[:, 8:11], 0)))
     ph = np.stack([t[:, 1] - t[:, 0], t[:, 2] - t[:, 1], t[:, 3] - t[:, 2], t[:, 4] - t[:, 3], t[:, 5] - t[:, 4],
                    t[:, 5] - t[:, 0]], 1)
     wall = t[:, 7]

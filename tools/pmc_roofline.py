@@ -9,7 +9,7 @@ hipGraph replay; the program itself directly after `--`):
     rocprofv3 --pmc FETCH_SIZE --output-format csv -d $R/gpurun_out/p_fetch -- $CMD
     rocprofv3 --pmc WRITE_SIZE --output-format csv -d $R/gpurun_out/p_write -- $CMD
     rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $R/gpurun_out/p_mfma -- $CMD
-    python3 tools/pmc_roofline.py gpurun_out/p_stats gpurun_out/p_fetch gpurun_out/p_write gpurun_out/p_mfma > profiles/r02_pmc_roofline.json
+    python3 tools/pmc_roofline.py gpurun_out/p_stats gpurun_out/p_fetch gpurun_out/p_write gpurun_out/p_mfma > profiles/r03_pmc_roofline.json
 
 Units / corrections (MI355X_MICROARCH.md): FETCH_SIZE and WRITE_SIZE are KiB; on gfx950 FETCH_SIZE tallies the 128-byte
 requests of wide coalesced reads at 64 bytes, so the read side is doubled; Infinity-Cache hits are counted, not excluded.
@@ -68,6 +68,17 @@ def main():
                     "mfma_busy_cycles_per_launch": busy, "sq_busy_cycles_per_launch": m.get("SQ_BUSY_CYCLES", (0.0, 0))[0],
                     "grbm_gui_active_per_launch": act, "mfma_util_raw_grbm": busy / (act * 1024) if act else None,
                     "mfma_util": busy / (1024 * us * 2400.0) if us else None}
+    # build identity: bench.py reports these figures only while the loaded library still is this build (dv_version() carries a
+    # hash of csrc/); the commit is passed in by the caller (the GPU box has no .git): argv[5]
+    try:
+        import os
+        sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        import diff_vits_amd  # noqa: F401
+        from diff_vits_amd import _lib
+        ver = _lib.lib().dv_version().decode()
+    except Exception as e:      # pragma: no cover
+        ver = "unknown (%s)" % e
+    out["build"] = {"dv_version": ver, "git_head": sys.argv[5] if len(sys.argv) > 5 else None}
     out["note"] = ("rocprofv3 --pmc passes (FETCH_SIZE | WRITE_SIZE | SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE) and a "
                    "--kernel-trace pass over bench.py, eager launches; FETCH_SIZE doubled (gfx950); Infinity-Cache hits counted; "
                    "mfma_util = MFMA busy cycles / (1024 SIMDs x kernel duration x 2.4 GHz)")
