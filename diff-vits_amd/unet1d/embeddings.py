@@ -5,7 +5,8 @@ names, so reference checkpoints load unchanged).
 `TextTimeEmbedding` is also imported directly by the reference's prior
 (reference model3.py:40, 744), which is why it is a public symbol here.
 These torch forwards are the `backend="torch"` path (training / CPU use); on a GPU the
-UNet runs them inside the HIP engine (csrc/cond.hip) instead.
+UNet runs them inside the HIP engine instead (csrc/engine.hip: the hoisted conditioning of `dv_unet_set_cond`,
+csrc/kernels_misc.hip: k_timestep_sincos / k_small_linear(_t) / k_mean_token / k_pool_attn / k_ln_rows).
 """
 import math
 
