@@ -580,7 +580,9 @@ struct Builder {
   // GroupNorm (+ temb scale/shift) (+ SiLU) of a GEMM's own output finished in ITS epilogue (gemm_tile.h GNX; DVITS_GNX=0
   // restores the k_gn_apply launch): fills g.gnx and allocates the normalised planes; false if launch_gemm would refuse.
   // Call after g's segments, epilogue and statistics slab are set.
-  bool gnx_on = [] { const char* e = getenv("DVITS_GNX"); return !(e && e[0] == '0'); }();
+  // (a CU mask - HSA_CU_MASK / ROC_GLOBAL_CU_MASK - takes CUs away without hipDeviceAttributeMultiprocessorCount knowing:
+  // the residency bound of the in-launch hand-over would be wrong, so it is not planned at all then)
+  bool gnx_on = [] { const char* e = getenv("DVITS_GNX"); return !(e && e[0] == '0') && !getenv("HSA_CU_MASK") && !getenv("ROC_GLOBAL_CU_MASK"); }();
   bool bd_on = [] { const char* e = getenv("DVITS_GEMM_BD"); return e && atoi(e) != 0; }();   // (no fragment-major copies while the BD tile is off: the default)
   size_t gnx_used = 0;
   // polls before an in-launch wait gives up; DVITS_GNX_SPIN=<n> is a test hook (1: every wait that is not satisfied at once
