@@ -92,8 +92,12 @@ hipError_t attn_init() {
 // (one ds_read_b128 per lane, conflict-free, no swizzle, no padding) and the whole fp32 -> planes conversion stage of
 // k_attention - its vector-ALU work, its LDS round trip, its pipeline stage - is gone.  Ring of three 64-key pairs,
 // counted waits (a wave knows how many DMA instructions of a pair are its own), one barrier per pair.
+// KSP = 2 (the short levels: T <= 256 frames leave half of the CUs without a workgroup, and a wave's key loop - bound by
+// the softmax's vector-ALU issue - is the whole critical path): two waves share a query block, wave half kh takes the
+// sub-tile kh of every 64-key pair (same ring, same DMAs, half the work per wave per pair), and the two partial
+// (m, l, O) are merged through LDS once, behind the loop.  A workgroup then covers 32 NW / 2 queries: twice the workgroups.
 // ---------------------------------------------------------------------------------------
-template <int DP, int NW, int NSPLIT>
+template <int DP, int NW, int NSPLIT, int KSP = 1>
 __global__ __launch_bounds__(64 * NW) void k_attention_frag(const AttnFragParams p) {
   extern __shared__ __attribute__((aligned(1024))) char lds[];
   constexpr bool SPLIT = NSPLIT == 3;
@@ -105,13 +109,17 @@ __global__ __launch_bounds__(64 * NW) void k_attention_frag(const AttnFragParams
   constexpr int NSTG = 3;
   constexpr int NI = 2 * (KBL + VBL);                   // DMA instructions per pair
   constexpr int CPW = (NI + NW - 1) / NW;               // per wave (at most)
+  constexpr int NQ = NW / KSP;                          // query blocks (of 32) per workgroup
+  constexpr int NU = 2 / KSP;                           // sub-tiles of a pair a wave multiplies
+  static_assert(KSP == 1 || (KSP == 2 && NW % 2 == 0), "key split: two wave halves");
   asm volatile("" ::"s"(p.q), "s"(p.vf_lo), "s"(p.v_t), "s"(p.bias), "s"(p.o_lo), "s"(p.no_xcd_map));   // all argument lines at once
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l31 = lane & 31, lh = lane >> 5;
   int qblk, h, b;
-  attn_block_of(blockIdx.x, (p.Tq + 32 * NW - 1) / (32 * NW), p.H, p.B, qblk, h, b, p.no_xcd_map == 0);
+  attn_block_of(blockIdx.x, (p.Tq + 32 * NQ - 1) / (32 * NQ), p.H, p.B, qblk, h, b, p.no_xcd_map == 0);
   const int d = p.d;
-  const int qi = qblk * (32 * NW) + wave * 32 + l31;
+  const int qg = KSP == 2 ? wave % NQ : wave, kh = KSP == 2 ? wave / NQ : 0;   // query block of this wave, its key half
+  const int qi = qblk * (32 * NQ) + qg * 32 + l31;
   const bool q_ok = qi < p.Tq;
   constexpr float LOG2E = 1.44269504088896340736f;
   const float qscale = p.scale * LOG2E;
@@ -196,57 +204,59 @@ __global__ __launch_bounds__(64 * NW) void k_attention_frag(const AttnFragParams
     const char* base0 = lds + (it % NSTG) * PAIR;
     const bool last = it + 1 == nit;
 
-    f32x16 s[2];
+    // (KSP == 2: this wave multiplies sub-tile kh of the pair only; s[] / the loops below are indexed by uu, u = u0 + uu)
+    const int u0 = KSP == 2 ? kh : 0;
+    f32x16 s[NU];
 #pragma unroll
-    for (int u = 0; u < 2; ++u)
+    for (int u = 0; u < NU; ++u)
 #pragma unroll
       for (int r = 0; r < 16; ++r) s[u][r] = 0.f;
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
-      bf16x8 kh[2], kl[2];
+      bf16x8 kfh[NU], kfl[NU];
 #pragma unroll
-      for (int u = 0; u < 2; ++u) {
-        kh[u] = *reinterpret_cast<const bf16x8*>(base0 + u * SUB + ks * 1024 + lane * 16);
-        if (SPLIT) kl[u] = *reinterpret_cast<const bf16x8*>(base0 + u * SUB + (KS + ks) * 1024 + lane * 16);
+      for (int u = 0; u < NU; ++u) {
+        kfh[u] = *reinterpret_cast<const bf16x8*>(base0 + (u0 + u) * SUB + ks * 1024 + lane * 16);
+        if (SPLIT) kfl[u] = *reinterpret_cast<const bf16x8*>(base0 + (u0 + u) * SUB + (KS + ks) * 1024 + lane * 16);
       }
       if (SPLIT) {
 #pragma unroll
-        for (int u = 0; u < 2; ++u) s[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kl[u], qh[ks], s[u], 0, 0, 0);
+        for (int u = 0; u < NU; ++u) s[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfl[u], qh[ks], s[u], 0, 0, 0);
 #pragma unroll
-        for (int u = 0; u < 2; ++u) s[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh[u], ql[ks], s[u], 0, 0, 0);
+        for (int u = 0; u < NU; ++u) s[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfh[u], ql[ks], s[u], 0, 0, 0);
       }
 #pragma unroll
-      for (int u = 0; u < 2; ++u) s[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh[u], qh[ks], s[u], 0, 0, 0);
+      for (int u = 0; u < NU; ++u) s[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfh[u], qh[ks], s[u], 0, 0, 0);
     }
     if (p.bias != nullptr) {                   // key bias (log2 domain; -1e30 beyond Tk)
       const float* bl = reinterpret_cast<const float*>(base0 + 2 * SUB);
 #pragma unroll
-      for (int u = 0; u < 2; ++u)
+      for (int u = 0; u < NU; ++u)
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-          const float4 bv = *reinterpret_cast<const float4*>(bl + u * 32 + 8 * g + 4 * lh);
+          const float4 bv = *reinterpret_cast<const float4*>(bl + (u0 + u) * 32 + 8 * g + 4 * lh);
           s[u][4 * g] += bv.x; s[u][4 * g + 1] += bv.y; s[u][4 * g + 2] += bv.z; s[u][4 * g + 3] += bv.w;
         }
     }
     if (last && (p.Tk & 63) != 0) {            // keys past Tk of the last pair (a trailing odd sub-tile re-reads the last one)
 #pragma unroll
-      for (int u = 0; u < 2; ++u)
+      for (int u = 0; u < NU; ++u)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const int key = (2 * it + u) * 32 + 8 * (r >> 2) + 4 * lh + (r & 3);
+          const int key = (2 * it + u0 + u) * 32 + 8 * (r >> 2) + 4 * lh + (r & 3);
           if (key >= p.Tk) s[u][r] = -1e30f;
         }
     }
     float tmax = m_run;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) tmax = __builtin_fmaxf(__builtin_fmaxf(tmax, s[0][r]), s[1][r]);
+    for (int r = 0; r < 16; ++r) tmax = NU == 2 ? __builtin_fmaxf(__builtin_fmaxf(tmax, s[0][r]), s[NU - 1][r]) : __builtin_fmaxf(tmax, s[0][r]);
     const float m_new = fmaxf(tmax, __shfl_xor(tmax, 32));
     const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
     m_run = m_new;
     const f32x2 mneg = {-m_new, -m_new};
     f32x2 psum = {0.f, 0.f};
 #pragma unroll
-    for (int u = 0; u < 2; ++u)
+    for (int u = 0; u < NU; ++u)
 #pragma unroll
       for (int r = 0; r < 16; r += 2) {
         f32x2 v = {s[u][r], s[u][r + 1]};
@@ -264,8 +274,8 @@ __global__ __launch_bounds__(64 * NW) void k_attention_frag(const AttnFragParams
         for (int r = 0; r < 16; ++r) o[nb][r] *= alpha;
     }
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      const char* vbase = base0 + u * SUB + KBL * 1024;
+    for (int u = 0; u < NU; ++u) {
+      const char* vbase = base0 + (u0 + u) * SUB + KBL * 1024;
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb) {
         u32x4 hw, lw;
@@ -298,6 +308,29 @@ __global__ __launch_bounds__(64 * NW) void k_attention_frag(const AttnFragParams
       }
     }
   }
+  if (KSP == 2) {
+    // merge the two key halves of a query block: half 1 hands (m, l, O) over through LDS (the ring is free now), half 0
+    // rescales both to the common maximum, adds, and goes on to the store
+    __syncthreads();                                       // every wave has left the key loop: the ring is free
+    float* mg = reinterpret_cast<float*>(lds) + (size_t)qg * (2 + 16 * NB) * 64;
+    if (kh == 1) {
+      mg[lane] = m_run; mg[64 + lane] = l_run;
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) mg[(2 + nb * 16 + r) * 64 + lane] = o[nb][r];
+    }
+    __syncthreads();
+    if (kh == 1) return;
+    const float m1 = mg[lane], l1 = mg[64 + lane];
+    const float m = fmaxf(m_run, m1);
+    const float a0 = __builtin_amdgcn_exp2f(m_run - m), a1 = __builtin_amdgcn_exp2f(m1 - m);
+    l_run = l_run * a0 + l1 * a1;
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[nb][r] = o[nb][r] * a0 + mg[(2 + nb * 16 + r) * 64 + lane] * a1;
+  }
   const float inv = 1.0f / (l_run + __shfl_xor(l_run, 32));
   if (q_ok) {
     const size_t obase = ((size_t)b * p.Tq + qi) * p.ldo + h * d;
@@ -326,17 +359,18 @@ __global__ __launch_bounds__(64 * NW) void k_attention_frag(const AttnFragParams
 
 template <int DP, int NW>
 static constexpr int frag_smem(int npl) { return 3 * (2 * (DP / 16 + 2 * ((DP + 31) / 32)) * npl * 1024 + 256); }
-template <int DP, int NW>
+template <int DP, int NW, int KSP = 1>
 static void launch_att_frag(const AttnFragParams& p, dim3 grid, hipStream_t st) {
   const int smem3 = frag_smem<DP, NW>(2), smem1 = frag_smem<DP, NW>(1);
-  if (p.nsplit == 3) hipLaunchKernelGGL((k_attention_frag<DP, NW, 3>), grid, dim3(64 * NW), smem3, st, p);
-  else hipLaunchKernelGGL((k_attention_frag<DP, NW, 1>), grid, dim3(64 * NW), smem1, st, p);
+  if (p.nsplit == 3) hipLaunchKernelGGL((k_attention_frag<DP, NW, 3, KSP>), grid, dim3(64 * NW), smem3, st, p);
+  else hipLaunchKernelGGL((k_attention_frag<DP, NW, 1, KSP>), grid, dim3(64 * NW), smem1, st, p);
 }
-template <int DP, int NW>
+template <int DP, int NW, int KSP = 1>
 static hipError_t init_att_frag() {
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_attention_frag<DP, NW, 3>),
+  static_assert(KSP == 1 || (NW / 2) * (2 + 16 * ((DP + 31) / 32)) * 256 <= frag_smem<DP, NW>(1), "merge buffer fits the ring");
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_attention_frag<DP, NW, 3, KSP>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, frag_smem<DP, NW>(2));
-  return e != hipSuccess ? e : hipFuncSetAttribute(reinterpret_cast<const void*>(k_attention_frag<DP, NW, 1>),
+  return e != hipSuccess ? e : hipFuncSetAttribute(reinterpret_cast<const void*>(k_attention_frag<DP, NW, 1, KSP>),
                                                    hipFuncAttributeMaxDynamicSharedMemorySize, frag_smem<DP, NW>(1));
 }
 static hipError_t attn_frag_init() {
@@ -344,7 +378,9 @@ static hipError_t attn_frag_init() {
 #define ATTF_INIT(DP)                                                  \
   if (e == hipSuccess) e = init_att_frag<DP, 8>();                     \
   if (e == hipSuccess) e = init_att_frag<DP, 4>();                     \
-  if (e == hipSuccess) e = init_att_frag<DP, 2>();
+  if (e == hipSuccess) e = init_att_frag<DP, 2>();                     \
+  if (e == hipSuccess) e = init_att_frag<DP, 8, 2>();                  \
+  if (e == hipSuccess) e = init_att_frag<DP, 4, 2>();
   ATTF_INIT(16) ATTF_INIT(32) ATTF_INIT(48) ATTF_INIT(64)
 #undef ATTF_INIT
   return e;
@@ -366,10 +402,17 @@ hipError_t launch_attention_frag(const AttnFragParams& pin, hipStream_t st) {
   static const int nw8_min = [] { const char* e = getenv("DVITS_ATTNF_NW8"); return e ? atoi(e) : 1100; }();
   static const int nw4_min = [] { const char* e = getenv("DVITS_ATTNF_NW4"); return e ? atoi(e) : 64; }();
   const int nw = waves >= nw8_min ? 8 : (waves >= nw4_min ? 4 : 2);
-  dim3 grid(((p.Tq + 32 * nw - 1) / (32 * nw)) * p.H * p.B);
-#define ATTF(DP)                                             \
-  if (nw == 8) launch_att_frag<DP, 8>(p, grid, st);          \
-  else if (nw == 4) launch_att_frag<DP, 4>(p, grid, st);     \
+  // Key split inside the workgroup (KSP = 2) where the plain grid leaves CUs without a workgroup and there are at least two
+  // 64-key pairs to share out: the short levels (T <= 256: 64-128 workgroups of four waves).  DVITS_ATTNF_KSP=<max plain
+  // workgroups> (default 160; 0: never).
+  static const int ksp_max = [] { const char* e = getenv("DVITS_ATTNF_KSP"); return e ? atoi(e) : 160; }();
+  const int plain_wgs = ((p.Tq + 32 * nw - 1) / (32 * nw)) * p.H * p.B;
+  const bool ksp = nw >= 4 && plain_wgs <= ksp_max && p.Tk > 64;
+  const int nq = ksp ? nw / 2 : nw;
+  dim3 grid(((p.Tq + 32 * nq - 1) / (32 * nq)) * p.H * p.B);
+#define ATTF(DP)                                                            \
+  if (nw == 8) { if (ksp) launch_att_frag<DP, 8, 2>(p, grid, st); else launch_att_frag<DP, 8>(p, grid, st); }          \
+  else if (nw == 4) { if (ksp) launch_att_frag<DP, 4, 2>(p, grid, st); else launch_att_frag<DP, 4>(p, grid, st); }     \
   else launch_att_frag<DP, 2>(p, grid, st);
   if (p.d == 16) { ATTF(16) } else if (p.d == 32) { ATTF(32) } else if (p.d == 48) { ATTF(48) } else { ATTF(64) }
 #undef ATTF
