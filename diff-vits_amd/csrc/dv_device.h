@@ -83,6 +83,11 @@ __device__ __forceinline__ void glds4_sc1(const void* gsrc, unsigned lds_dst) {
   asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off sc1\n\ts_mov_b32 m0, %0"
                : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
 }
+#ifndef DV_ATTN_PLO
+// 1: the probabilities P of an attention tile enter P V as split bf16 (hi + lo: three products); 0: as one bf16 (two products:
+// P_hi V_hi + P_hi V_lo) - experiment knob, see DESIGN.md
+#define DV_ATTN_PLO 1
+#endif
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");

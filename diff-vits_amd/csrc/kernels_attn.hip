@@ -283,7 +283,7 @@ __global__ __launch_bounds__(64 * NW) void k_attention_frag(const AttnFragParams
         hw.z = apk(s[u][kb * 8 + 4], s[u][kb * 8 + 5]); hw.w = apk(s[u][kb * 8 + 6], s[u][kb * 8 + 7]);
         const bf16x8 ph = __builtin_bit_cast(bf16x8, hw);
         bf16x8 pl;
-        if (SPLIT) {
+        if (SPLIT && DV_ATTN_PLO) {
           auto lo_pair = [&](unsigned h2, float x0, float x1) {
             const f32x2 x = {x0, x1}, hf = {bf_lo(h2), bf_hi(h2)};
             const f32x2 dlt = x - hf;
@@ -301,7 +301,7 @@ __global__ __launch_bounds__(64 * NW) void k_attention_frag(const AttnFragParams
           if (SPLIT) {
             const bf16x8 vl = *reinterpret_cast<const bf16x8*>(vbase + (2 * NB + kb * NB + nb) * 1024 + lane * 16);
             o[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vl, ph, o[nb], 0, 0, 0);
-            o[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, pl, o[nb], 0, 0, 0);
+            if (DV_ATTN_PLO) o[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, pl, o[nb], 0, 0, 0);
           }
           o[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, ph, o[nb], 0, 0, 0);
         }

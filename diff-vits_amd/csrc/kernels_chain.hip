@@ -573,13 +573,13 @@ __global__ __launch_bounds__((chain_pf_wave<NS, AMODE, XA, SA, CS>() ? NT_LAUNCH
           const float x0 = sc[kb * 8 + 2 * e], x1 = sc[kb * 8 + 2 * e + 1];
           const unsigned h2 = pk(x0, x1);
           hw[e] = h2;
-          lw[e] = pk(x0 - __uint_as_float(h2 << 16), x1 - __uint_as_float(h2 & 0xffff0000u));
+          lw[e] = DV_ATTN_PLO ? pk(x0 - __uint_as_float(h2 << 16), x1 - __uint_as_float(h2 & 0xffff0000u)) : 0u;
         }
         const bf16x8 ph = __builtin_bit_cast(bf16x8, hw), pl = __builtin_bit_cast(bf16x8, lw);
 #pragma unroll
         for (int nb = 0; nb < NBv; ++nb) {
           o[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cur.vl[kb][nb], ph, o[nb], 0, 0, 0);
-          o[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cur.vh[kb][nb], pl, o[nb], 0, 0, 0);
+          if (DV_ATTN_PLO) o[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cur.vh[kb][nb], pl, o[nb], 0, 0, 0);
           o[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cur.vh[kb][nb], ph, o[nb], 0, 0, 0);
         }
       }
