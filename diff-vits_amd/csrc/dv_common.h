@@ -91,6 +91,9 @@ struct GemmParams {
   GnxParams gnx;                // GroupNorm of the output in the epilogue (needs stats16)
   int xcd_n;                    // internal (launch_gemm): XCDs the columns are split over (0: row bands of the tile grid)
   int xcd_sh_n, xcd_sh_mn, xcd_tn, xcd_tm, xcd_inv_tn;   // internal: log2 xn, log2 (xm xn), rectangle width / height in tiles, ceil(2^16 / width)
+#ifdef DV_GEMM_TRACE
+  int trace;                    // development build (make trace): this launch stamps its phases (gemm_tile.h DV_TRACE)
+#endif
 };
 // exchange words a GNX GEMM needs (M / 32 * N / 16), or 0 if launch_gemm would refuse it (tile shape vs T_out / groups,
 // more workgroups than `n_cu` compute units, unsupported epilogue)

@@ -19,6 +19,11 @@ __device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst) {
 // arithmetic per instruction (the BD tile's producer waves issue nine of these per chunk)
 __device__ __forceinline__ void glds16_s(const void* sbase, unsigned voff, unsigned lds_dst) {
   lds_dst = __builtin_amdgcn_readfirstlane(lds_dst);
+  {   // (a wave-uniform value that hipcc happens to hold in vector registers does not satisfy the "s" constraint)
+    const unsigned long long b = reinterpret_cast<unsigned long long>(sbase);
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)b), hi = __builtin_amdgcn_readfirstlane((unsigned)(b >> 32));
+    sbase = reinterpret_cast<const void*>(((unsigned long long)hi << 32) | lo);
+  }
   unsigned keep;
   asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
                : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
@@ -101,6 +106,79 @@ typedef __bf16 dv_bf16x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ unsigned dv_cvt_pk_bf16(float lo, float hi) {
   const dv_f32x2 v = {lo, hi};
   return __builtin_bit_cast(unsigned, __builtin_convertvector(v, dv_bf16x2));
+}
+
+// ---- cross-lane helpers ----
+// Sum over the 64 lanes of a wave, the same value in every lane, fixed order (deterministic): four DPP adds inside each row of 16
+// lanes, then the four row sums through scalar registers - instead of six dependent ds_bpermute round trips through the LDS
+// crossbar (~100 cycles each on a wave's critical path in the epilogues).
+template <int CTRL>
+__device__ __forceinline__ float dv_dpp_f32(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float dv_readlane_f32(float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); }
+__device__ __forceinline__ float wave_sum64(float v) {
+  v += dv_dpp_f32<0xB1>(v);     // quad_perm [1,0,3,2]
+  v += dv_dpp_f32<0x4E>(v);     // quad_perm [2,3,0,1]
+  v += dv_dpp_f32<0x141>(v);    // row_half_mirror
+  v += dv_dpp_f32<0x140>(v);    // row_mirror
+  return (dv_readlane_f32(v, 0) + dv_readlane_f32(v, 16)) + (dv_readlane_f32(v, 32) + dv_readlane_f32(v, 48));
+}
+template <int CTRL>
+__device__ __forceinline__ double dv_dpp_f64(double v) {
+  const long long b = __double_as_longlong(v);
+  const unsigned lo = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)b, CTRL, 0xf, 0xf, true);
+  const unsigned hi = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)((unsigned long long)b >> 32), CTRL, 0xf, 0xf, true);
+  return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+__device__ __forceinline__ double dv_readlane_f64(double v, int l) {
+  const long long b = __double_as_longlong(v);
+  const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)b, l);
+  const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)((unsigned long long)b >> 32), l);
+  return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+__device__ __forceinline__ double wave_sum64(double v) {
+  v += dv_dpp_f64<0xB1>(v);
+  v += dv_dpp_f64<0x4E>(v);
+  v += dv_dpp_f64<0x141>(v);
+  v += dv_dpp_f64<0x140>(v);
+  return (dv_readlane_f64(v, 0) + dv_readlane_f64(v, 16)) + (dv_readlane_f64(v, 32) + dv_readlane_f64(v, 48));
+}
+// Lane pair (l, l + 32) of a wave, each holding dword `a` (its part of column group g) and dword `b` (... of group g + 1):
+// afterwards the lower lane holds (its own a, the upper lane's a) and the upper lane (the lower lane's b, its own b) - one
+// v_permlane32_swap (gfx950).  The transposed-accumulator epilogues use it so that a lane owns 8 consecutive columns of a bf16
+// plane instead of 4: 16-byte stores, 32 contiguous bytes per row and instruction.  [8-byte stores that leave 16 B per row are
+// ~240 cycles of issue EACH (partial 32-byte sectors); 16-byte ones ~100: tools/micro/store_pattern.hip.]
+__device__ __forceinline__ void pair_swap32(unsigned& a, unsigned& b) {
+  const auto r = __builtin_amdgcn_permlane32_swap(a, b, false, false);
+  a = r[0]; b = r[1];
+}
+// Split bf16 planes of 16 values of one row in the transposed-accumulator layout (v[4g + e] = column 8g + 4lh + e of a 32-column
+// fragment, lh = lane >> 5): `o` = element offset of the fragment's first column in this lane's row.  Both lanes of a pair must be active.
+// `pairs` (wave-uniform): bit 0 / bit 1 = the fragment's columns 0-15 / 16-31 exist (attention heads of 16 / 48 channels).
+__device__ __forceinline__ void store_planes16(unsigned short* hi, unsigned short* lo, size_t o, int lh, const float* v, int pairs = 3) {
+  unsigned h[8], l[8];
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    h[2 * g] = dv_cvt_pk_bf16(v[4 * g], v[4 * g + 1]);
+    h[2 * g + 1] = dv_cvt_pk_bf16(v[4 * g + 2], v[4 * g + 3]);
+    if (lo) {
+      l[2 * g] = dv_cvt_pk_bf16(v[4 * g] - __uint_as_float(h[2 * g] << 16), v[4 * g + 1] - __uint_as_float(h[2 * g] & 0xffff0000u));
+      l[2 * g + 1] = dv_cvt_pk_bf16(v[4 * g + 2] - __uint_as_float(h[2 * g + 1] << 16), v[4 * g + 3] - __uint_as_float(h[2 * g + 1] & 0xffff0000u));
+    }
+  }
+#pragma unroll
+  for (int G = 0; G < 4; G += 2) {     // groups (G, G + 1): the lower lane takes columns 8G .. 8G + 7, the upper lane 8G + 8 .. 8G + 15
+    if (!((pairs >> (G >> 1)) & 1)) continue;
+    pair_swap32(h[2 * G], h[2 * G + 2]);
+    pair_swap32(h[2 * G + 1], h[2 * G + 3]);
+    *reinterpret_cast<uint4*>(hi + o + 8 * (G + lh)) = make_uint4(h[2 * G], h[2 * G + 1], h[2 * G + 2], h[2 * G + 3]);
+    if (lo) {
+      pair_swap32(l[2 * G], l[2 * G + 2]);
+      pair_swap32(l[2 * G + 1], l[2 * G + 3]);
+      *reinterpret_cast<uint4*>(lo + o + 8 * (G + lh)) = make_uint4(l[2 * G], l[2 * G + 1], l[2 * G + 2], l[2 * G + 3]);
+    }
+  }
 }
 
 // GELU with the exact-erf definition (reference unet1d/activations / F.gelu default), erf by Abramowitz-Stegun 7.1.26

@@ -17,11 +17,13 @@
 #if defined(DV_GEMM_TRACE) && defined(DV_GEMM_TRACE_OWNER)
 #define DV_GEMM_TRACING 1
 // development build only (make trace): per-workgroup s_memtime stamps of the kernel's phases
-__device__ unsigned long long g_gemm_trace[8192 * 16];
-#define DV_TRACE(i) do { if (threadIdx.x == 0 && blockIdx.x < 8192) g_gemm_trace[blockIdx.x * 16 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
-#define DV_TRACE_P(i, first) do { if ((int)threadIdx.x == (first) && blockIdx.x < 8192) g_gemm_trace[blockIdx.x * 16 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+// (DV_TR_W slots per workgroup; p.trace: launch_gemm stamps every launch, or only the one chosen by dv_debug_gemm_trace_select)
+#define DV_TR_W 32
+__device__ unsigned long long g_gemm_trace[8192 * DV_TR_W];
+#define DV_TRACE(i) do { if (p.trace && threadIdx.x == 0 && blockIdx.x < 8192) g_gemm_trace[blockIdx.x * DV_TR_W + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#define DV_TRACE_P(i, first) do { if (p.trace && (int)threadIdx.x == (first) && blockIdx.x < 8192) g_gemm_trace[blockIdx.x * DV_TR_W + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
 extern "C" int dv_debug_gemm_trace(unsigned long long* host, int n_wg) {
-  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_gemm_trace), (size_t)n_wg * 16 * sizeof(unsigned long long));
+  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_gemm_trace), (size_t)n_wg * DV_TR_W * sizeof(unsigned long long));
 }
 extern "C" int dv_debug_gemm_trace_clear() {
   void* d = nullptr;
@@ -95,12 +97,12 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int m0, con
   static_assert((CM || BM % (RPI * NWV) == 0) && (BD || BN % (RPI * NWV) == 0), "tile rows must split over the waves");
   DV_TRACE(0);
 #ifdef DV_GEMM_TRACING
-  if (threadIdx.x == 0 && blockIdx.x < 8192) {
+  if (p.trace && threadIdx.x == 0 && blockIdx.x < 8192) {
     unsigned xcc, hw;
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
-    g_gemm_trace[blockIdx.x * 16 + 6] = ((unsigned long long)xcc << 32) | hw;
-    g_gemm_trace[blockIdx.x * 16 + 7] = wall_clock64();
+    g_gemm_trace[blockIdx.x * DV_TR_W + 6] = ((unsigned long long)xcc << 32) | hw;
+    g_gemm_trace[blockIdx.x * DV_TR_W + 7] = wall_clock64();
   }
 #endif
   // touch one field of every 64-byte line of the argument block up front: the scalar loads go out together and
@@ -201,7 +203,9 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int m0, con
   const bf16_t* cur_hi; const bf16_t* cur_lo;
   int cur_ld, cur_col, cur_toff;
   auto enter = [&]() {
-    const GemmSeg& sg = p.seg[ld_seg];
+    // (readfirstlane: the index is wave-uniform by construction; where hipcc cannot prove it, a vector-indexed p.seg[] sends the
+    // whole argument block through scratch memory)
+    const GemmSeg& sg = p.seg[__builtin_amdgcn_readfirstlane(ld_seg)];
     cur_hi = ld_half ? sg.a1_hi : sg.a0_hi;
     cur_lo = ld_half ? sg.a1_lo : sg.a0_lo;
     cur_ld = ld_half ? sg.c1 : sg.c0;
@@ -257,7 +261,7 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int m0, con
     cur_col += BK;
     a_fresh = cur_col == cur_ld;
     if (cur_col == cur_ld) {     // wave-uniform, once per (source tensor, tap)
-      const GemmSeg& sg = p.seg[ld_seg];
+      const GemmSeg& sg = p.seg[__builtin_amdgcn_readfirstlane(ld_seg)];
       if (ld_half == 0 && sg.c1 > 0) ld_half = 1;
       else {
         ld_half = 0;
@@ -684,8 +688,8 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int m0, con
     for (int u = 0; u < DEPTH; ++u)
       if (c1 + u < n1) chunk1(bq[u], u & 1);
 #ifdef DV_GEMM_TRACING
-    if (threadIdx.x == 0 && blockIdx.x < 8192) {   // k = 3 chunks after the first: cycles at the barrier | reading + multiplying
-      g_gemm_trace[blockIdx.x * 16 + 12] = 0; g_gemm_trace[blockIdx.x * 16 + 13] = tr_bar; g_gemm_trace[blockIdx.x * 16 + 14] = tr_mul;
+    if (p.trace && threadIdx.x == 0 && blockIdx.x < 8192) {   // k = 3 chunks after the first: cycles at the barrier | reading + multiplying
+      g_gemm_trace[blockIdx.x * DV_TR_W + 12] = 0; g_gemm_trace[blockIdx.x * DV_TR_W + 13] = tr_bar; g_gemm_trace[blockIdx.x * DV_TR_W + 14] = tr_mul;
     }
 #endif
   } else {
@@ -722,8 +726,8 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int m0, con
 #endif
   }
 #ifdef DV_GEMM_TRACING
-  if (threadIdx.x == 0 && blockIdx.x < 8192) {   // the steady loop's wait sums
-    g_gemm_trace[blockIdx.x * 16 + 12] = tr_vm; g_gemm_trace[blockIdx.x * 16 + 13] = tr_bar; g_gemm_trace[blockIdx.x * 16 + 14] = tr_step;
+  if (p.trace && threadIdx.x == 0 && blockIdx.x < 8192) {   // the steady loop's wait sums
+    g_gemm_trace[blockIdx.x * DV_TR_W + 12] = tr_vm; g_gemm_trace[blockIdx.x * DV_TR_W + 13] = tr_bar; g_gemm_trace[blockIdx.x * DV_TR_W + 14] = tr_step;
   }
 #endif
   for (; kt < nk; ++kt) {                            // drain: nothing left to issue
@@ -798,6 +802,7 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int m0, con
     }
   }
   auto my_frag_row = [&](int i) { return BD ? (i == kgrp) : (!SPLIT_EPI || ((i & 1) == kgrp)); };
+  DV_TRACE(22);                                      // k-groups added up
   if (p.sk_mode == 3) {                              // fused split-K pair: hand over, or finish
     float4* d0 = reinterpret_cast<float4*>(p.sk_buf) + (size_t)ksel * sk_slice + sk_tile + wq * 64 + lane;
 #pragma unroll
@@ -906,29 +911,36 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int m0, con
         const int m = m0 + rl;
         if (m >= p.M) continue;
         const float2 st = p.ln_stat ? s_ln[rl] : make_float2(0.f, 1.f);
+        float v[16];
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          float v[4];
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const int r = 4 * g + e;
-            float a = acc[i][0][r], gt = acc[i][1][r];
-            if (p.ln_stat) {
-              a = st.y * (a - st.x * ua[r]);
-              gt = st.y * (gt - st.x * ug[r]);
-            }
-            v[e] = (a + ba[r]) * gelu_erf(gt + bg[r]);
+        for (int r = 0; r < 16; ++r) {
+          float a = acc[i][0][r], gt = acc[i][1][r];
+          if (p.ln_stat) {
+            a = st.y * (a - st.x * ua[r]);
+            gt = st.y * (gt - st.x * ug[r]);
           }
-          // output column of packed `a` column nb: 32 per 64-column block; nb < N  <=>  oc-run inside N/2
-          store4((size_t)m * p.ldo + blk * 32 + 8 * g + 4 * lh, nca + 8 * g, v);
+          v[r] = (a + ba[r]) * gelu_erf(gt + bg[r]);
+        }
+        // output column of packed `a` column nb: 32 per 64-column block; nb < N  <=>  oc-run inside N/2
+        if (!BD && vec4 && p.out_hi && !p.out && n0 + wn * 64 + 64 <= p.N) {   // (wave-uniform) whole block inside N: 16-byte plane stores
+          store_planes16(p.out_hi, p.out_lo, (size_t)m * p.ldo + blk * 32, lh, v);
+        } else {
+#pragma unroll
+          for (int g = 0; g < 4; ++g) store4((size_t)m * p.ldo + blk * 32 + 8 * g + 4 * lh, nca + 8 * g, &v[4 * g]);
         }
       }
     }
     DV_TRACE(5);
     return;
   }
+  // `full` (wave-uniform): all 32 columns of the fragment lie inside N and 16-byte accesses are allowed - the stores and the
+  // residual loads then run without per-column guards / per-store branches (the guarded store4 form costs ~40 instructions and 8
+  // branches per 16-byte store, ~1.5 k cycles per fragment with one wave per SIMD left to hide nothing: tools/gemm_trace_fwd.py).
+  // [Two full instantiations of this loop body (guards compiled out) made hipcc lose the wave-uniformity of the k-range state in
+  // several tiles - the argument block went through scratch memory; the runtime flag keeps one body.]
 #pragma unroll
   for (int j = 0; j < FN; ++j) {
+    const bool full = !BD && vec4 && n0 + (wn * FN + j) * 32 + 32 <= p.N;
     const int nf = n0 + (wn * FN + j) * 32 + 4 * lh;   // column of g = 0, e = 0
     float bv[16], un[16];
 #pragma unroll
@@ -951,6 +963,13 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int m0, con
         if (PRE_RES) {
 #pragma unroll
           for (int r = 0; r < 16; ++r) rv[r] = rpre[(BD ? j : j * FM + i) * 16 + r];
+        } else if (full && !SC1) {
+          const float* rp = p.res + (size_t)mc * p.ldres + nf;
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const float4 a = *reinterpret_cast<const float4*>(rp + 8 * g);
+            rv[4 * g] = a.x; rv[4 * g + 1] = a.y; rv[4 * g + 2] = a.z; rv[4 * g + 3] = a.w;
+          }
         } else {
           load_row16(p.res, (size_t)mc * p.ldres, nf, rv);
         }
@@ -969,6 +988,7 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int m0, con
         v *= rmask;
         vv[r] = (m_ok && n < p.N) ? v : 0.f;
       }
+      if (i == 0 && j == 0) DV_TRACE(16);            // bias / residual / LayerNorm applied (first fragment)
       if (gnx) {                                     // the values stay in registers for the normalising second pass
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][j][r] = vv[r];
@@ -984,9 +1004,20 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int m0, con
           }
         }
       } else if (m_ok) {
+        if (full) {                                  // planes as 16-byte stores: dv_device.h store_planes16
+          const size_t ob = (size_t)m * p.ldo + nf;
+          if (p.out) {
 #pragma unroll
-        for (int g = 0; g < 4; ++g) store4((size_t)m * p.ldo + nf + 8 * g, nf + 8 * g, &vv[4 * g]);
+            for (int g = 0; g < 4; ++g)
+              *reinterpret_cast<float4*>(p.out + ob + 8 * g) = make_float4(vv[4 * g], vv[4 * g + 1], vv[4 * g + 2], vv[4 * g + 3]);
+          }
+          if (p.out_hi) store_planes16(p.out_hi, p.out_lo, ob - 4 * lh, lh, vv);
+        } else {
+#pragma unroll
+          for (int g = 0; g < 4; ++g) store4((size_t)m * p.ldo + nf + 8 * g, nf + 8 * g, &vv[4 * g]);
+        }
       }
+      if (i == 0 && j == 0) DV_TRACE(17);            // stores issued (first fragment)
       if (p.rowstat_out) {   // row partials over this fragment's 32 columns (LayerNorm of the consumer)
         const int nblk_total = (p.N + 31) >> 5;
         const int cb = (n0 + (wn * FN + j) * 32) >> 5;
@@ -1033,13 +1064,21 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int m0, con
         float a1[2] = {0.f, 0.f}, a2[2] = {0.f, 0.f};
 #pragma unroll
         for (int r = 0; r < 16; ++r) a1[r >> 3] += vv[r];
+        // (wave sums by DPP + scalar registers: dv_device.h; the BD tile, at its 168-register cap, keeps the shuffle butterflies)
+        auto wsum = [&](float v) {
+          if constexpr (BD) {
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) { a1[0] += __shfl_xor(a1[0], o); a1[1] += __shfl_xor(a1[1], o); }
+            for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+            return v;
+          } else {
+            return wave_sum64(v);
+          }
+        };
+        a1[0] = wsum(a1[0]); a1[1] = wsum(a1[1]);
         const float mb[2] = {a1[0] * (1.0f / 512.0f), a1[1] * (1.0f / 512.0f)};
 #pragma unroll
         for (int r = 0; r < 16; ++r) { const float dv = vv[r] - mb[r >> 3]; a2[r >> 3] = fmaf(dv, dv, a2[r >> 3]); }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) { a2[0] += __shfl_xor(a2[0], o); a2[1] += __shfl_xor(a2[1], o); }
+        a2[0] = wsum(a2[0]); a2[1] = wsum(a2[1]);
         const int cb0 = (n0 + (wn * FN + j) * 32) >> 4;
         if (lane < 2 && mrow0 < p.M && (cb0 + lane) * 16 < p.N) {
           float2* const dst = reinterpret_cast<float2*>(p.stats16) + (size_t)(mrow0 >> 5) * (p.N >> 4) + cb0 + lane;
@@ -1052,7 +1091,8 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int m0, con
         }
       }
     }
-  }
+    }
+  DV_TRACE(18);                                      // statistics of every fragment written
   if (gnx) {
     // ---- GroupNorm of this GEMM's own output (GnxParams, dv_common.h) ----
     const int cpg = p.N / p.gnx.groups, bq = m0 / p.T_out;
@@ -1069,6 +1109,7 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int m0, con
     __shared__ __attribute__((aligned(16))) float s_gA[BN < 64 ? 64 : BN], s_gB[BN < 64 ? 64 : BN];
     const int g_lo = n0 / cpg, g_hi = (min(n0 + BN, p.N) - 1) / cpg;
     const int RB = p.T_out >> 5, nvb = cpg >> 4, ncb = p.N >> 4;
+    DV_TRACE(19);
     for (int g = g_lo + wave; g <= g_hi; g += NWA) {
       // poll the group's entries until none is EMPTY (all ones: the forward's first kernel resets the exchange words;
       // a published (sum, M2) is finite).  All tiles of the utterance are resident and arrive within the spread of the
@@ -1113,8 +1154,12 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int m0, con
           q += m2 + sx * sx * (1.0 / 512.0);         // = the block's sum of squares
         }
       }
+      if constexpr (BD) {
 #pragma unroll
-      for (int o = 32; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o); q += __shfl_xor(q, o); }
+        for (int o = 32; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o); q += __shfl_xor(q, o); }
+      } else {
+        s1 = wave_sum64(s1); q = wave_sum64(q);
+      }
       if (lane == 0) {
         const double n = (double)cpg * (double)p.T_out, mean = s1 / n;
         double var = q / n - mean * mean;
@@ -1122,7 +1167,9 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int m0, con
         s_gst[g - g_lo] = make_float2((float)mean, (float)(1.0 / sqrt(var + (double)p.gnx.eps)));
       }
     }
+    DV_TRACE(20);                                    // this wave's groups are reduced
     __syncthreads();
+    DV_TRACE(21);                                    // ... every wave's
     if (tid < BN) {
       const float2 st = s_gst[min(n0 + tid, p.N - 1) / cpg - g_lo];
       const float a = st.y * pg;
@@ -1138,6 +1185,23 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int m0, con
         if (!my_frag_row(i)) continue;
         const int m = m0 + (wm * FM + i) * 32 + l31;
         if (m >= p.M) continue;
+        const int nfr = n0 + (wn * FN + j) * 32;
+        if (!BD && nfr + 32 <= p.N) {                  // (wave-uniform) the whole fragment: 16-byte plane stores
+          float y[16];
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const float4 sa = *reinterpret_cast<const float4*>(s_gA + cl + 8 * g);
+            const float4 sb = *reinterpret_cast<const float4*>(s_gB + cl + 8 * g);
+            y[4 * g] = fmaf(acc[i][j][4 * g], sa.x, sb.x); y[4 * g + 1] = fmaf(acc[i][j][4 * g + 1], sa.y, sb.y);
+            y[4 * g + 2] = fmaf(acc[i][j][4 * g + 2], sa.z, sb.z); y[4 * g + 3] = fmaf(acc[i][j][4 * g + 3], sa.w, sb.w);
+          }
+          if (p.gnx.silu) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) y[r] = y[r] * __builtin_amdgcn_rcpf(1.0f + __expf(-y[r]));
+          }
+          store_planes16(p.gnx.y_hi, p.gnx.y_lo, (size_t)m * p.N + nfr, lh, y);
+          continue;
+        }
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
           if (n0 + cl + 8 * g >= p.N) continue;
@@ -1147,7 +1211,7 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int m0, con
                         fmaf(acc[i][j][4 * g + 2], sa.z, sb.z), fmaf(acc[i][j][4 * g + 3], sa.w, sb.w)};
           if (p.gnx.silu) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) y[e] = y[e] / (1.0f + __expf(-y[e]));
+            for (int e = 0; e < 4; ++e) y[e] = BD ? y[e] / (1.0f + __expf(-y[e])) : y[e] * __builtin_amdgcn_rcpf(1.0f + __expf(-y[e]));
           }
           const size_t o = (size_t)m * p.N + n0 + cl + 8 * g;
           const unsigned h01 = cvt_pk_bf16(y[0], y[1]), h23 = cvt_pk_bf16(y[2], y[3]);

@@ -335,25 +335,40 @@ __global__ __launch_bounds__(64 * NW) void k_attention_frag(const AttnFragParams
   if (q_ok) {
     const size_t obase = ((size_t)b * p.Tq + qi) * p.ldo + h * d;
 #pragma unroll
-    for (int nb = 0; nb < NB; ++nb)
+    for (int nb = 0; nb < NB; ++nb) {
+      float v16[16];
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int dv = nb * 32 + 8 * g + 4 * lh - row0;   // channel of the head held by registers 4g .. 4g+3
-        if (dv >= 0 && dv < d) {
-          const float4 v = make_float4(o[nb][4 * g] * inv, o[nb][4 * g + 1] * inv, o[nb][4 * g + 2] * inv, o[nb][4 * g + 3] * inv);
-          if (p.o) *reinterpret_cast<float4*>(p.o + obase + dv) = v;
-          if (p.o_hi) {
+      for (int r = 0; r < 16; ++r) v16[r] = o[nb][r] * inv;
+      if (p.o) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int dv = nb * 32 + 8 * g + 4 * lh - row0;   // channel of the head held by registers 4g .. 4g+3
+          if (dv >= 0 && dv < d) *reinterpret_cast<float4*>(p.o + obase + dv) = make_float4(v16[4 * g], v16[4 * g + 1], v16[4 * g + 2], v16[4 * g + 3]);
+        }
+      }
+      // split bf16 planes for the to_out GEMM (hi = rne(v), lo = rne(v - hi)) as 16-byte stores: the lanes of a pair exchange halves
+      // (dv_device.h store_planes16).  The head occupies fragment columns row0 .. row0 + d - 1 (multiples of 16): per 16-column half
+      if (p.o_hi && ((d | row0) & 15) != 0) {         // heads of 8 / 24 ... channels: 8-byte stores, guarded per 4 columns
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int dv = nb * 32 + 8 * g + 4 * lh - row0;
+          if (dv >= 0 && dv < d) {
             uint2 hh, ll;
-            hh.x = apk(v.x, v.y); hh.y = apk(v.z, v.w);
+            hh.x = apk(v16[4 * g], v16[4 * g + 1]); hh.y = apk(v16[4 * g + 2], v16[4 * g + 3]);
             *reinterpret_cast<uint2*>(p.o_hi + obase + dv) = hh;
             if (p.o_lo) {
-              ll.x = apk(v.x - bf_lo(hh.x), v.y - bf_hi(hh.x));
-              ll.y = apk(v.z - bf_lo(hh.y), v.w - bf_hi(hh.y));
+              ll.x = apk(v16[4 * g] - bf_lo(hh.x), v16[4 * g + 1] - bf_hi(hh.x));
+              ll.y = apk(v16[4 * g + 2] - bf_lo(hh.y), v16[4 * g + 3] - bf_hi(hh.y));
               *reinterpret_cast<uint2*>(p.o_lo + obase + dv) = ll;
             }
           }
         }
+      } else if (p.o_hi) {
+        const int c0 = nb * 32 - row0, c1 = c0 + 16;   // head channel of the fragment's columns 0 / 16
+        const int pairs = ((c0 >= 0 && c0 < d) ? 1 : 0) | ((c1 >= 0 && c1 < d) ? 2 : 0);
+        store_planes16(p.o_hi, p.o_lo, (size_t)((long long)obase + c0), lh, v16, pairs);
       }
+    }
   }
 }
 

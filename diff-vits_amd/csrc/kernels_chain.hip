@@ -632,16 +632,10 @@ __global__ __launch_bounds__((chain_pf_wave<NS, AMODE, XA, SA, CS>() ? NT_LAUNCH
           vv[4 * g + 2] = acc[ns][4 * g + 2] + bv.z + rr.z; vv[4 * g + 3] = acc[ns][4 * g + 3] + bv.w + rr.w;
         }
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const size_t o4 = (size_t)m * C + nf + 8 * g;
-          *reinterpret_cast<float4*>(p.out3 + o4) = make_float4(vv[4 * g], vv[4 * g + 1], vv[4 * g + 2], vv[4 * g + 3]);
-          uint2 hw, lw;
-          hw.x = pk(vv[4 * g], vv[4 * g + 1]); hw.y = pk(vv[4 * g + 2], vv[4 * g + 3]);
-          lw.x = pk(vv[4 * g] - __uint_as_float(hw.x << 16), vv[4 * g + 1] - __uint_as_float(hw.x & 0xffff0000u));
-          lw.y = pk(vv[4 * g + 2] - __uint_as_float(hw.y << 16), vv[4 * g + 3] - __uint_as_float(hw.y & 0xffff0000u));
-          *reinterpret_cast<uint2*>(p.out3_hi + o4) = hw;
-          *reinterpret_cast<uint2*>(p.out3_lo + o4) = lw;
-        }
+        for (int g = 0; g < 4; ++g)
+          *reinterpret_cast<float4*>(p.out3 + (size_t)m * C + nf + 8 * g) = make_float4(vv[4 * g], vv[4 * g + 1], vv[4 * g + 2], vv[4 * g + 3]);
+        // split planes as 16-byte stores (lane pairs exchange halves: dv_device.h store_planes16)
+        store_planes16(p.out3_hi, p.out3_lo, (size_t)m * C + nf - 4 * lh, lh, vv);
         float a = 0.f, q = 0.f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) a += vv[r];
@@ -869,29 +863,18 @@ __global__ __launch_bounds__(NT_LAUNCH) void k_chain_ff(const ChainFFParams p) {
       vv[4 * g + 2] = acc[4 * g + 2] + bv.z + rr.z; vv[4 * g + 3] = acc[4 * g + 3] + bv.w + rr.w;
     }
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      const size_t o4 = (size_t)m * C + nf + 8 * g;
-      *reinterpret_cast<float4*>(p.out + o4) = make_float4(vv[4 * g], vv[4 * g + 1], vv[4 * g + 2], vv[4 * g + 3]);
-      if (p.out_hi) {
-        uint2 hw, lw;
-        hw.x = pk(vv[4 * g], vv[4 * g + 1]); hw.y = pk(vv[4 * g + 2], vv[4 * g + 3]);
-        lw.x = pk(vv[4 * g] - __uint_as_float(hw.x << 16), vv[4 * g + 1] - __uint_as_float(hw.x & 0xffff0000u));
-        lw.y = pk(vv[4 * g + 2] - __uint_as_float(hw.y << 16), vv[4 * g + 3] - __uint_as_float(hw.y & 0xffff0000u));
-        *reinterpret_cast<uint2*>(p.out_hi + o4) = hw;
-        *reinterpret_cast<uint2*>(p.out_lo + o4) = lw;
-      }
-    }
+    for (int g = 0; g < 4; ++g)
+      *reinterpret_cast<float4*>(p.out + (size_t)m * C + nf + 8 * g) = make_float4(vv[4 * g], vv[4 * g + 1], vv[4 * g + 2], vv[4 * g + 3]);
+    if (p.out_hi) store_planes16(p.out_hi, p.out_lo, (size_t)m * C + nf - 4 * lh, lh, vv);   // 16-byte plane stores (dv_device.h)
     if (p.stats16) {
       float a1[2] = {0.f, 0.f}, a2[2] = {0.f, 0.f};
 #pragma unroll
       for (int r = 0; r < 16; ++r) a1[r >> 3] += vv[r];
-#pragma unroll
-      for (int o = 32; o > 0; o >>= 1) { a1[0] += __shfl_xor(a1[0], o); a1[1] += __shfl_xor(a1[1], o); }
+      a1[0] = wave_sum64(a1[0]); a1[1] = wave_sum64(a1[1]);
       const float mb[2] = {a1[0] * (1.0f / 512.0f), a1[1] * (1.0f / 512.0f)};
 #pragma unroll
       for (int r = 0; r < 16; ++r) { const float dv = vv[r] - mb[r >> 3]; a2[r >> 3] = fmaf(dv, dv, a2[r >> 3]); }
-#pragma unroll
-      for (int o = 32; o > 0; o >>= 1) { a2[0] += __shfl_xor(a2[0], o); a2[1] += __shfl_xor(a2[1], o); }
+      a2[0] = wave_sum64(a2[0]); a2[1] = wave_sum64(a2[1]);
       if (lane < 2)
         reinterpret_cast<float2*>(p.stats16)[(size_t)blockIdx.x * (C / 16) + wn * 2 + lane] =
             make_float2(lane ? a1[1] : a1[0], lane ? a2[1] : a2[0]);

@@ -290,8 +290,30 @@ int gemm_gnx_plan(const GemmParams& p, int n_cu) {
   return (p.M / 32) * (p.N / 16);
 }
 
+#ifdef DV_GEMM_TRACE
+// development build: which launch_gemm call stamps its phases (-1: every one; n: the n-th call since the selection), and what it was
+static int g_trace_sel = -1, g_trace_no = 0;
+static char g_trace_desc[256] = "";
+extern "C" int dv_debug_gemm_trace_select(int n) { g_trace_sel = n; g_trace_no = 0; g_trace_desc[0] = 0; return 0; }
+extern "C" int dv_debug_gemm_trace_desc(char* out, int cap) { snprintf(out, (size_t)cap, "%s", g_trace_desc); return g_trace_no; }
+#endif
+
 hipError_t launch_gemm(const GemmParams& pin, int precision, hipStream_t st) {
   GemmParams p = pin;
+#ifdef DV_GEMM_TRACE
+  if (pin.sk_mode == 0) {                            // (not the split-K recursion below)
+    p.trace = g_trace_sel < 0 || g_trace_no == g_trace_sel;
+    if (p.trace) {
+      int k = 0;
+      for (int s2 = 0; s2 < p.nseg; ++s2) k += p.seg[s2].taps * (p.seg[s2].c0 + p.seg[s2].c1);
+      snprintf(g_trace_desc, sizeof(g_trace_desc), "M=%d N=%d K=%d taps=%d nseg=%d epi=%d stride=%d up=%d%s%s%s%s%s%s split=%d%s",
+               p.M, p.N, k, p.seg[0].taps, p.nseg, p.epi, p.stride, p.up_mode, p.stats ? " +colstats" : "", p.stats16 ? " +stats16" : "",
+               p.gnx.xchg ? " +gnx" : "", p.out_hi ? " +planes" : "", p.rowstat_out ? " +rowstat" : "", p.ln_stat ? " +ln" : "",
+               p.sk_buf ? p.sk_split : 0, (p.sk_buf && p.sk_ticket && p.sk_split == 2) ? "f" : "");
+    }
+    ++g_trace_no;
+  }
+#endif
   const bool x3 = precision == 0;
   if (!p.zero_page || (x3 && !p.w_lo)) return hipErrorInvalidValue;
   for (int s2 = 0; s2 < p.nseg; ++s2)     // (a lane on the zero page walks a row's k-tiles inside it: gemm_tile.h prep_a_next)
