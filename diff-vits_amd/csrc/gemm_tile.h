@@ -517,9 +517,25 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int m0, con
 #pragma unroll
     for (int i = 0; i < FM; ++i) {
       if (BD && i != kgrp) continue;                 // (BD: k-group i finishes row fragment i)
+      // (only the waves that will run this fragment's epilogue: with two k-groups and one row fragment the second group hands
+      // its sums over and leaves - its prefetch was 16 KiB of loads per workgroup for nothing)
+      if (!BD && KS == 2 && ((FM % 2 == 0) ? ((i & 1) != kgrp) : (kgrp != 0))) continue;
       const size_t ro = (size_t)min(m0 + (wm * FM + i) * 32 + l31, p.M - 1) * p.ldres;
 #pragma unroll
-      for (int j = 0; j < FN; ++j) load_row16(p.res, ro, n0 + (wn * FN + j) * 32 + 4 * lh, &rpre[(BD ? j : j * FM + i) * 16]);
+      for (int j = 0; j < FN; ++j) {
+        const int nfj = n0 + (wn * FN + j) * 32;
+        float* dst = &rpre[(BD ? j : j * FM + i) * 16];
+        if (!SC1 && vec4 && nfj + 32 <= p.N) {       // (wave-uniform) whole fragment inside N: four unguarded 16-byte loads
+          const float* rp = p.res + ro + nfj + 4 * lh;
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const float4 a = *reinterpret_cast<const float4*>(rp + 8 * g);
+            dst[4 * g] = a.x; dst[4 * g + 1] = a.y; dst[4 * g + 2] = a.z; dst[4 * g + 3] = a.w;
+          }
+        } else {
+          load_row16(p.res, ro, nfj + 4 * lh, dst);
+        }
+      }
     }
   }
 
@@ -750,7 +766,7 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int m0, con
   // their half, so all eight waves share the (store- and GELU-bound) epilogue; otherwise group 1 hands everything over.
   if (KS == 2) {
     __builtin_amdgcn_s_barrier();                    // every wave is done reading the ring
-    float* red = reinterpret_cast<float*>(smem);
+    float4* red4 = reinterpret_cast<float4*>(smem);  // (16-byte LDS accesses, lane-linear: a quarter of the instructions of the dword form)
 #pragma unroll
     for (int i = 0; i < FM; ++i) {
       const bool mine = SPLIT_EPI ? ((i & 1) == kgrp) : (kgrp == 0);
@@ -758,7 +774,9 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int m0, con
 #pragma unroll
         for (int j = 0; j < FN; ++j)
 #pragma unroll
-          for (int r = 0; r < 16; ++r) red[((i * FN + j) * 16 + r) * (64 * NWQ) + wq * 64 + lane] = acc[i][j][r];
+          for (int g = 0; g < 4; ++g)
+            red4[((i * FN + j) * 4 + g) * (64 * NWQ) + wq * 64 + lane] =
+                make_float4(acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]);
       }
     }
     __syncthreads();
@@ -770,7 +788,10 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int m0, con
 #pragma unroll
         for (int j = 0; j < FN; ++j)
 #pragma unroll
-          for (int r = 0; r < 16; ++r) acc[i][j][r] += red[((i * FN + j) * 16 + r) * (64 * NWQ) + wq * 64 + lane];
+          for (int g = 0; g < 4; ++g) {
+            const float4 v = red4[((i * FN + j) * 4 + g) * (64 * NWQ) + wq * 64 + lane];
+            acc[i][j][4 * g] += v.x; acc[i][j][4 * g + 1] += v.y; acc[i][j][4 * g + 2] += v.z; acc[i][j][4 * g + 3] += v.w;
+          }
       }
     }
   }
@@ -944,10 +965,16 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int m0, con
     const int nf = n0 + (wn * FN + j) * 32 + 4 * lh;   // column of g = 0, e = 0
     float bv[16], un[16];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int n = nf + 8 * (r >> 2) + (r & 3);
-      bv[r] = s_bias[(wn * FN + j) * 32 + 4 * lh + 8 * (r >> 2) + (r & 3)];
-      un[r] = (p.ln_stat && n < p.N) ? s_u[(wn * FN + j) * 32 + 4 * lh + 8 * (r >> 2) + (r & 3)] : 0.f;
+    for (int g = 0; g < 4; ++g) {                    // (16-byte LDS reads; columns >= N hold the bias of column N - 1 / are masked below)
+      const float4 b4 = *reinterpret_cast<const float4*>(s_bias + (wn * FN + j) * 32 + 4 * lh + 8 * g);
+      bv[4 * g] = b4.x; bv[4 * g + 1] = b4.y; bv[4 * g + 2] = b4.z; bv[4 * g + 3] = b4.w;
+    }
+    if (BD || p.ln_stat) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int n = nf + 8 * (r >> 2) + (r & 3);
+        un[r] = (p.ln_stat && n < p.N) ? s_u[(wn * FN + j) * 32 + 4 * lh + 8 * (r >> 2) + (r & 3)] : 0.f;
+      }
     }
 #pragma unroll
     for (int i = 0; i < FM; ++i) {
@@ -974,20 +1001,53 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int m0, con
           load_row16(p.res, (size_t)mc * p.ldres, nf, rv);
         }
       }
-      const float2 st = p.ln_stat ? s_ln[rl] : make_float2(0.f, 1.f);
-      const float rmask = p.rowmask ? p.rowmask[mc] : 1.0f;
+      // (one wave-uniform branch per step instead of sixteen selects each; same operations in the same order)
       float vv[16];
+      if constexpr (BD) {                            // (the BD tile, at its 168-register cap, keeps the compact per-value form)
+        const float2 st = p.ln_stat ? s_ln[rl] : make_float2(0.f, 1.f);
+        const float rmask = p.rowmask ? p.rowmask[mc] : 1.0f;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int n = nf + 8 * (r >> 2) + (r & 3);
-        float v = acc[i][j][r];
-        if (p.ln_stat) v = st.y * (v - st.x * un[r]);
-        v += bv[r];
-        if (p.epi == EPI_RESIDUAL) v += rv[r];
-        if (p.relu) v = fmaxf(v, 0.f);
-        v *= rmask;
-        vv[r] = (m_ok && n < p.N) ? v : 0.f;
+        for (int r = 0; r < 16; ++r) {
+          const int n = nf + 8 * (r >> 2) + (r & 3);
+          float v = acc[i][j][r];
+          if (p.ln_stat) v = st.y * (v - st.x * un[r]);
+          v += bv[r];
+          if (p.epi == EPI_RESIDUAL) v += rv[r];
+          if (p.relu) v = fmaxf(v, 0.f);
+          v *= rmask;
+          vv[r] = (m_ok && n < p.N) ? v : 0.f;
+        }
+      } else {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) vv[r] = acc[i][j][r];
+      if (p.ln_stat) {
+        const float2 st = s_ln[rl];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) vv[r] = st.y * (vv[r] - st.x * un[r]);
       }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) vv[r] += bv[r];
+      if (p.epi == EPI_RESIDUAL) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) vv[r] += rv[r];
+      }
+      if (p.relu) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) vv[r] = fmaxf(vv[r], 0.f);
+      }
+      if (p.rowmask) {
+        const float rmask = p.rowmask[mc];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) vv[r] *= rmask;
+      }
+      if (full) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) vv[r] = m_ok ? vv[r] : 0.f;
+      } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) vv[r] = (m_ok && nf + 8 * (r >> 2) + (r & 3) < p.N) ? vv[r] : 0.f;
+      }
+      }   // (!BD)
       if (i == 0 && j == 0) DV_TRACE(16);            // bias / residual / LayerNorm applied (first fragment)
       if (gnx) {                                     // the values stay in registers for the normalising second pass
 #pragma unroll

@@ -207,18 +207,40 @@ __global__ __launch_bounds__((chain_pf_wave<NS, AMODE, XA, SA, CS>() ? NT_LAUNCH
   auto kgroup_reduce = [&](f32x16 (&acc)[NS], char* buf) __attribute__((always_inline)) {
     float* red = reinterpret_cast<float*>(buf);
     __syncthreads();                               // the buffer's previous readers are done; every wave has left its k-loop
+    if constexpr (PFW) {                           // (nine-wave instantiations sit at the 168-VGPR cap: dword form, no temporaries)
+      if (kg == 1) {
+#pragma unroll
+        for (int ns = 0; ns < NS; ++ns)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) red[((ns * 4 + wn) * 16 + r) * 64 + lane] = acc[ns][r];
+      }
+      __syncthreads();
+      if (kg == 0) {
+#pragma unroll
+        for (int ns = 0; ns < NS; ++ns)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[ns][r] += red[((ns * 4 + wn) * 16 + r) * 64 + lane];
+      }
+      return;
+    }
+    // (16-byte LDS accesses, lane-linear: a quarter of the instructions of the dword form)
+    float4* red4 = reinterpret_cast<float4*>(red);
     if (kg == 1) {
 #pragma unroll
       for (int ns = 0; ns < NS; ++ns)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) red[((ns * 4 + wn) * 16 + r) * 64 + lane] = acc[ns][r];
+        for (int g = 0; g < 4; ++g)
+          red4[((ns * 4 + wn) * 4 + g) * 64 + lane] = make_float4(acc[ns][4 * g], acc[ns][4 * g + 1], acc[ns][4 * g + 2], acc[ns][4 * g + 3]);
     }
     __syncthreads();
     if (kg == 0) {
 #pragma unroll
       for (int ns = 0; ns < NS; ++ns)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[ns][r] += red[((ns * 4 + wn) * 16 + r) * 64 + lane];
+        for (int g = 0; g < 4; ++g) {
+          const float4 v = red4[((ns * 4 + wn) * 4 + g) * 64 + lane];
+          acc[ns][4 * g] += v.x; acc[ns][4 * g + 1] += v.y; acc[ns][4 * g + 2] += v.z; acc[ns][4 * g + 3] += v.w;
+        }
     }
   };
 
@@ -842,14 +864,18 @@ __global__ __launch_bounds__(NT_LAUNCH) void k_chain_ff(const ChainFFParams p) {
   }
   {
     float* red = reinterpret_cast<float*>(red_reg);
+    float4* red4 = reinterpret_cast<float4*>(red);   // (16-byte LDS accesses, lane-linear)
     if (kg == 1) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) red[(wn * 16 + r) * 64 + lane] = acc[r];
+      for (int g = 0; g < 4; ++g) red4[(wn * 4 + g) * 64 + lane] = make_float4(acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]);
     }
     __syncthreads();
     if (kg == 1) return;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] += red[(wn * 16 + r) * 64 + lane];
+    for (int g = 0; g < 4; ++g) {
+      const float4 v = red4[(wn * 4 + g) * 64 + lane];
+      acc[4 * g] += v.x; acc[4 * g + 1] += v.y; acc[4 * g + 2] += v.z; acc[4 * g + 3] += v.w;
+    }
   }
   // epilogue: + bias + block residual -> fp32 (+ planes), 32x16 block statistics (sum, M2 about the block mean)
   {
