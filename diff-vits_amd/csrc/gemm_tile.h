@@ -513,6 +513,7 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int m0, con
   // residual operand of small tiles: fetched before the k-loop so its latency hides under it
   constexpr bool PRE_RES = !BD && FM * FN <= 2;       // (BD: the 168-VGPR budget of a 640-thread workgroup has no room for it)
   float rpre[PRE_RES ? (BD ? FN : FM * FN) * 16 : 1];   // (BD: a wave finishes ONE row fragment)
+  auto res_prefetch = [&]() __attribute__((always_inline)) {
   if (PRE_RES && p.epi == EPI_RESIDUAL && p.sk_mode != 1) {   // (mode 3: half of the workgroups prefetch in vain)
 #pragma unroll
     for (int i = 0; i < FM; ++i) {
@@ -538,6 +539,7 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int m0, con
       }
     }
   }
+  };
 
   // fused LayerNorm (consumer side): per-row mean / rstd of this tile's rows from the producer's partials
   __shared__ float2 s_ln[BM];
@@ -564,17 +566,21 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int m0, con
 
   // bias of this tile's columns -> LDS by DMA, oldest in the queue: landed before the first tile's wait returns
   __shared__ __attribute__((aligned(16))) float s_bias[BN < 64 ? 64 : BN];
-  if (wave < (BN + 63) / 64) {
-    const int n = min(n0 + wave * 64 + lane, p.N - 1);
-    glds4(p.bias ? (const void*)(p.bias + n) : (const void*)p.zero_page, (unsigned)(size_t)s_bias + wave * 256);
-  }
   // LayerNorm consumer: u[n] of this tile's columns the same way (a global load at the head of the epilogue would be a
   // dependent L2 round trip on every workgroup's critical path)
   __shared__ __attribute__((aligned(16))) float s_u[BN < 64 ? 64 : BN];
-  if (p.ln_stat && wave < (BN + 63) / 64) {
-    const int n = min(n0 + wave * 64 + lane, p.N - 1);
-    glds4((const void*)(p.ln_u + n), (unsigned)(size_t)s_u + wave * 256);
-  }
+  auto aux_loads = [&]() __attribute__((always_inline)) {
+    if (wave < (BN + 63) / 64) {
+      const int n = min(n0 + wave * 64 + lane, p.N - 1);
+      glds4(p.bias ? (const void*)(p.bias + n) : (const void*)p.zero_page, (unsigned)(size_t)s_bias + wave * 256);
+    }
+    if (p.ln_stat && wave < (BN + 63) / 64) {
+      const int n = min(n0 + wave * 64 + lane, p.N - 1);
+      glds4((const void*)(p.ln_u + n), (unsigned)(size_t)s_u + wave * 256);
+    }
+    res_prefetch();
+  };
+  aux_loads();   // (ahead of the k-tiles: issued right behind the first tile's DMAs instead, prologue + first-tile wait grew by ~5 % in the per-launch trace)
 
   // ---- main loop: wait(tile kt) -> barrier -> multiply tile kt with the DMA of tile kt+NSTAGE-1 interleaved ----
   // NSTAGE-1 tiles are in flight; the counted vmcnt leaves the younger ones outstanding across the barrier
