@@ -30,7 +30,7 @@ if plain:
 elif conv_shapes:
     shapes = []
 NWG = 8192
-buf = np.zeros((NWG, 16), dtype=np.uint64)
+buf = np.zeros((NWG, 32), dtype=np.uint64)      # DV_TR_W stamps per workgroup (gemm_tile.h)
 for spec in shapes + [("conv",) + a for a in conv_shapes]:
     if spec[0] == "conv":
         _, Bn, Tn, Ci, Co, kk = spec
