@@ -39,12 +39,13 @@ __device__ __forceinline__ void glds16_sc1(const void* gsrc, unsigned lds_dst) {
 // Written as relaxed system-scope atomics on 64-bit halves (the compiler emits global_store/load_dwordx2 sc0 sc1 and
 // tracks the loads' completion itself; an asm load whose result is consumed after a separate asm wait is not safe -
 // the compiler may copy the destination registers before the wait).
+// (the STORE is one 16-byte instruction in assembly - a store has no result for the compiler to mishandle, the caller's
+// wait_vmcnt<0> covers it; as two 8-byte atomic stores a lane-linear dump was 8-byte pieces at a 16-byte stride: partial 32-byte
+// sectors, the slow ~240-cycles-per-instruction form of tools/micro/store_pattern.hip)
 __device__ __forceinline__ void st_handover16(float4* p, float4 v) {
-  unsigned long long* q = reinterpret_cast<unsigned long long*>(p);
-  const unsigned long long lo = (unsigned long long)__float_as_uint(v.x) | ((unsigned long long)__float_as_uint(v.y) << 32);
-  const unsigned long long hi = (unsigned long long)__float_as_uint(v.z) | ((unsigned long long)__float_as_uint(v.w) << 32);
-  __hip_atomic_store(q, lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-  __hip_atomic_store(q + 1, hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  typedef float f32x4_t __attribute__((ext_vector_type(4)));
+  const f32x4_t r = {v.x, v.y, v.z, v.w};
+  asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(r) : "memory");
 }
 __device__ __forceinline__ float4 ld_handover16(const float4* p) {
   const unsigned long long* q = reinterpret_cast<const unsigned long long*>(p);

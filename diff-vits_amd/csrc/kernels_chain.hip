@@ -261,6 +261,14 @@ __global__ __launch_bounds__((chain_pf_wave<NS, AMODE, XA, SA, CS>() ? NT_LAUNCH
   if (AMODE == 1) {
     // GroupNorm of the fp32 rows, once per row-block: table of this utterance, then convert
     const int T = p.T, b_item = m0 / T;
+    // (the rows are requested FIRST: their cold-miss latency runs under the table's loads, reductions and barriers)
+    constexpr int TASKS = BM * (C / 4), RNDS = (TASKS + NT - 1) / NT;    // (row, 4-channel group); NT % (C/4) may be != 0
+    float4 rv[RNDS];
+#pragma unroll
+    for (int j = 0; j < RNDS; ++j) {
+      const int id = min(j * NT + tid, TASKS - 1), row = id / (C / 4), c4 = id - row * (C / 4);
+      rv[j] = *reinterpret_cast<const float4*>(p.x + (size_t)(m0 + row) * C + c4 * 4);
+    }
     {
       const int G = p.groups, cg = C / G, nvb = cg >> 4, RB = T >> 5, nblk = C >> 4, n_ent = RB * nblk;
       const int cc = min(tid, C - 1);
@@ -299,13 +307,6 @@ __global__ __launch_bounds__((chain_pf_wave<NS, AMODE, XA, SA, CS>() ? NT_LAUNCH
       const float gm = __shfl(mean, src_lane), gr = __shfl(rstd, src_lane);
       if (tid < C) { const float a = gr * pg; s_gscale[tid] = a; s_gshift[tid] = pb - gm * a; }
       __syncthreads();
-    }
-    constexpr int TASKS = BM * (C / 4), RNDS = (TASKS + NT - 1) / NT;    // (row, 4-channel group); NT % (C/4) may be != 0
-    float4 rv[RNDS];
-#pragma unroll
-    for (int j = 0; j < RNDS; ++j) {
-      const int id = min(j * NT + tid, TASKS - 1), row = id / (C / 4), c4 = id - row * (C / 4);
-      rv[j] = *reinterpret_cast<const float4*>(p.x + (size_t)(m0 + row) * C + c4 * 4);
     }
 #pragma unroll
     for (int j = 0; j < RNDS; ++j) {
