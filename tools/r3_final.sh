@@ -9,7 +9,7 @@ cd $R
 timeout 2400 python -m pytest tests -x -q -m gpu > $O/pytest.log 2>&1
 echo "pytest rc=$?" >> $O/pytest.log
 tail -5 $O/pytest.log
-bash tools/profile_job.sh r03 ee7067e > $O/profile_job.log 2>&1
+bash tools/profile_job.sh r03 b9ded7f > $O/profile_job.log 2>&1
 tail -3 $O/profile_job.log
 cp gpurun_out/r03_pmc_roofline.json profiles/r03_pmc_roofline.json   # (so that the bench line below can quote it: same build)
 timeout 1200 python bench.py > $O/bench_final.json 2> $O/bench_final.err
@@ -21,3 +21,4 @@ print("value=%.0f ms_per_step=%.2f frac=%.4f cpu=%.0f rel_l2=%s" % (d["value"], 
 print(d["roofline"]["traffic_source"])
 PY
 timeout 300 python tools/gemm_trace.py > $O/gemm_trace.txt 2>&1
+timeout 900 python tools/gemm_trace_fwd.py > $O/gemm_trace_fwd.txt 2>&1
