@@ -292,7 +292,7 @@ __device__ __forceinline__ void attn_tile(const AttnParams& p, const int qblk, c
     float tmax = m_run;
 #pragma unroll
     for (int r = 0; r < 16; ++r) tmax = __builtin_fmaxf(__builtin_fmaxf(tmax, s[0][r]), s[1][r]);   // v_max3_f32
-    const float m_new = fmaxf(tmax, __shfl_xor(tmax, 32));
+    const float m_new = pair_max32(tmax);
     const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
     m_run = m_new;
     const f32x2 mneg = {-m_new, -m_new};
@@ -355,7 +355,7 @@ __device__ __forceinline__ void attn_tile(const AttnParams& p, const int qblk, c
   }
 
   DV_ATRACE(6);                  // key loop done
-  const float l_tot = l_run + __shfl_xor(l_run, 32);
+  const float l_tot = pair_sum32(l_run);
   const float inv = 1.0f / l_tot;
   if (q_ok) {
     const size_t obase = ((size_t)b * p.Tq + qi) * p.ldo + h * d;

@@ -154,6 +154,20 @@ __device__ __forceinline__ void pair_swap32(unsigned& a, unsigned& b) {
   const auto r = __builtin_amdgcn_permlane32_swap(a, b, false, false);
   a = r[0]; b = r[1];
 }
+// value op value-of-the-lane-32-away (the two half-waves of a 32x32 MFMA accumulator hold the two halves of a row): one
+// v_permlane32_swap on two copies of the value instead of a ds_bpermute round trip (~100+ cycles of dependent latency - it sits
+// inside the key loop of every attention kernel).  After the swap the lower lanes hold (own, partner), the upper (partner, own):
+// a commutative op on the pair needs no select.
+__device__ __forceinline__ float pair_sum32(float v) {
+  unsigned a = __float_as_uint(v), b = a;
+  pair_swap32(a, b);
+  return __uint_as_float(a) + __uint_as_float(b);
+}
+__device__ __forceinline__ float pair_max32(float v) {
+  unsigned a = __float_as_uint(v), b = a;
+  pair_swap32(a, b);
+  return fmaxf(__uint_as_float(a), __uint_as_float(b));
+}
 // Split bf16 planes of 16 values of one row in the transposed-accumulator layout (v[4g + e] = column 8g + 4lh + e of a 32-column
 // fragment, lh = lane >> 5): `o` = element offset of the fragment's first column in this lane's row.  Both lanes of a pair must be active.
 // `pairs` (wave-uniform): bit 0 / bit 1 = the fragment's columns 0-15 / 16-31 exist (attention heads of 16 / 48 channels).

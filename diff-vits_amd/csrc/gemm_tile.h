@@ -1090,11 +1090,11 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int m0, con
         float a = 0.f, q = 0.f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) a += vv[r];
-        a += __shfl_xor(a, 32);
+        a = pair_sum32(a);
         const float mb = a * (1.0f / 32.0f);           // block mean; q = squared deviations from it
 #pragma unroll
         for (int r = 0; r < 16; ++r) q += (vv[r] - mb) * (vv[r] - mb);
-        q += __shfl_xor(q, 32);
+        q = pair_sum32(q);
         if (lh == 0 && m_ok && cb < nblk_total)
           reinterpret_cast<float2*>(p.rowstat_out)[(size_t)m * nblk_total + cb] = make_float2(a, q);
       }

@@ -250,7 +250,7 @@ __global__ __launch_bounds__(64 * NW) void k_attention_frag(const AttnFragParams
     float tmax = m_run;
 #pragma unroll
     for (int r = 0; r < 16; ++r) tmax = NU == 2 ? __builtin_fmaxf(__builtin_fmaxf(tmax, s[0][r]), s[NU - 1][r]) : __builtin_fmaxf(tmax, s[0][r]);
-    const float m_new = fmaxf(tmax, __shfl_xor(tmax, 32));
+    const float m_new = pair_max32(tmax);
     const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
     m_run = m_new;
     const f32x2 mneg = {-m_new, -m_new};
@@ -331,7 +331,7 @@ __global__ __launch_bounds__(64 * NW) void k_attention_frag(const AttnFragParams
 #pragma unroll
       for (int r = 0; r < 16; ++r) o[nb][r] = o[nb][r] * a0 + mg[(2 + nb * 16 + r) * 64 + lane] * a1;
   }
-  const float inv = 1.0f / (l_run + __shfl_xor(l_run, 32));
+  const float inv = 1.0f / pair_sum32(l_run);
   if (q_ok) {
     const size_t obase = ((size_t)b * p.Tq + qi) * p.ldo + h * d;
 #pragma unroll

@@ -379,11 +379,11 @@ __global__ __launch_bounds__((chain_pf_wave<NS, AMODE, XA, SA, CS>() ? NT_LAUNCH
       float a = 0.f, q = 0.f;
 #pragma unroll
       for (int r = 0; r < 16; ++r) a += vv[r];
-      a += __shfl_xor(a, 32);
+      a = pair_sum32(a);
       const float mb = a * (1.0f / 32.0f);
 #pragma unroll
       for (int r = 0; r < 16; ++r) q += (vv[r] - mb) * (vv[r] - mb);
-      q += __shfl_xor(q, 32);
+      q = pair_sum32(q);
       if (lh == 0) s_rowp[l31][ns * 4 + wn] = make_float2(a, q);
     }
   }
@@ -574,7 +574,7 @@ __global__ __launch_bounds__((chain_pf_wave<NS, AMODE, XA, SA, CS>() ? NT_LAUNCH
       float tmax = m_run;
 #pragma unroll
       for (int r = 0; r < 16; ++r) tmax = fmaxf(tmax, sc[r]);
-      const float m_new = fmaxf(tmax, __shfl_xor(tmax, 32));
+      const float m_new = pair_max32(tmax);
       const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
       m_run = m_new;
       float psum = 0.f;
@@ -609,7 +609,7 @@ __global__ __launch_bounds__((chain_pf_wave<NS, AMODE, XA, SA, CS>() ? NT_LAUNCH
       cur = nxt;
     }
     {
-      const float inv = 1.0f / (l_run + __shfl_xor(l_run, 32));
+      const float inv = 1.0f / pair_sum32(l_run);
       // O (lane = query row, registers = channels 8g + 4lh + e of block nb) -> split planes in the A region, columns of head h
 #pragma unroll
       for (int nb = 0; nb < NBv; ++nb)
@@ -662,11 +662,11 @@ __global__ __launch_bounds__((chain_pf_wave<NS, AMODE, XA, SA, CS>() ? NT_LAUNCH
         float a = 0.f, q = 0.f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) a += vv[r];
-        a += __shfl_xor(a, 32);
+        a = pair_sum32(a);
         const float mb = a * (1.0f / 32.0f);
 #pragma unroll
         for (int r = 0; r < 16; ++r) q += (vv[r] - mb) * (vv[r] - mb);
-        q += __shfl_xor(q, 32);
+        q = pair_sum32(q);
         if (lh == 0) reinterpret_cast<float2*>(p.rowstat3)[(size_t)m * (C / 32) + ns * 4 + wn] = make_float2(a, q);
       }
     }

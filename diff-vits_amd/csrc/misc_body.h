@@ -9,11 +9,9 @@ __device__ __forceinline__ float wave_sum(float v) {
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
   return v;
 }
-__device__ __forceinline__ double wave_sum_d(double v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-  return v;
-}
+// (all call sites run with the whole wave active: DPP adds inside each row of 16 lanes + four row sums through scalar registers,
+// dv_device.h wave_sum64 - the twelve dependent ds_bpermute pairs of the butterfly were the head of every k_gn_apply workgroup)
+__device__ __forceinline__ double wave_sum_d(double v) { return wave_sum64(v); }
 __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
