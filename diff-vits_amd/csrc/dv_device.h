@@ -196,6 +196,28 @@ __device__ __forceinline__ void store_planes16(unsigned short* hi, unsigned shor
   }
 }
 
+// ... of 8 values: v[4g + e] = column 8g + 4lh + e of a 16-column half fragment (g < 2); `o` = element offset of the half's first column
+__device__ __forceinline__ void store_planes8(unsigned short* hi, unsigned short* lo, size_t o, int lh, const float* v) {
+  unsigned h[4], l[4];
+#pragma unroll
+  for (int g = 0; g < 2; ++g) {
+    h[2 * g] = dv_cvt_pk_bf16(v[4 * g], v[4 * g + 1]);
+    h[2 * g + 1] = dv_cvt_pk_bf16(v[4 * g + 2], v[4 * g + 3]);
+    if (lo) {
+      l[2 * g] = dv_cvt_pk_bf16(v[4 * g] - __uint_as_float(h[2 * g] << 16), v[4 * g + 1] - __uint_as_float(h[2 * g] & 0xffff0000u));
+      l[2 * g + 1] = dv_cvt_pk_bf16(v[4 * g + 2] - __uint_as_float(h[2 * g + 1] << 16), v[4 * g + 3] - __uint_as_float(h[2 * g + 1] & 0xffff0000u));
+    }
+  }
+  pair_swap32(h[0], h[2]);
+  pair_swap32(h[1], h[3]);
+  *reinterpret_cast<uint4*>(hi + o + 8 * lh) = make_uint4(h[0], h[1], h[2], h[3]);
+  if (lo) {
+    pair_swap32(l[0], l[2]);
+    pair_swap32(l[1], l[3]);
+    *reinterpret_cast<uint4*>(lo + o + 8 * lh) = make_uint4(l[0], l[1], l[2], l[3]);
+  }
+}
+
 // GELU with the exact-erf definition (reference unet1d/activations / F.gelu default), erf by Abramowitz-Stegun 7.1.26
 // (|error| <= 1.5e-7): branch-free, one v_exp_f32 and one v_rcp_f32, ~20 issue slots instead of erff()'s two divergent
 // polynomial branches.  1 + erf is formed without cancellation on the negative side: measured max |error| of the GELU

@@ -483,6 +483,13 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int m0, con
   //   row m = m0 + (wm*FM+i)*32 + l31,  column n = n0 + (wn*FN+j)*32 + 8*g + 4*lh + e
   // vector (16-byte) epilogue accesses need every row pitch and N to be a multiple of 4
   const bool vec4 = ((p.N | p.ldo | (p.epi == EPI_RESIDUAL ? p.ldres : 0)) & 3) == 0;
+  // Half-fragment epilogue (64x64-class tiles with two k-groups and ONE fragment per wave): instead of k-group 1 handing its
+  // sums over and leaving - the epilogue then runs on one wave per SIMD, where nothing hides a latency - the groups exchange
+  // column halves and EACH finishes 16 of the fragment's 32 columns (registers 0-7 of group 0, 8-15 of group 1: exactly the two
+  // 16-column statistics blocks).  Workgroup-uniform; the cases it does not cover take the full path below.
+  constexpr bool HALF_OK = !BD && !SC1 && KS == 2 && FM == 1 && FN == 1;
+  const bool half_mode = HALF_OK && p.sk_mode == 0 && vec4 && n0 + BN <= p.N && !p.stats && !p.rowstat_out &&
+                         (p.epi == EPI_STORE || p.epi == EPI_RESIDUAL) && nk > 0;
   auto load4 = [&](const float* base, size_t row_off, int nb, float* dst) {   // dst[0..3] = base[row_off + nb + e]
     if (vec4) {
       const float4 v = nb < p.N ? ld_mut4<SC1>(base + row_off + nb) : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -514,6 +521,17 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int m0, con
   constexpr bool PRE_RES = !BD && FM * FN <= 2;       // (BD: the 168-VGPR budget of a 640-thread workgroup has no room for it)
   float rpre[PRE_RES ? (BD ? FN : FM * FN) * 16 : 1];   // (BD: a wave finishes ONE row fragment)
   auto res_prefetch = [&]() __attribute__((always_inline)) {
+  if (HALF_OK && half_mode) {                      // this wave's 16 columns: two 16-byte loads
+    if (p.epi == EPI_RESIDUAL) {
+      const float* rp = p.res + (size_t)min(m0 + wm * 32 + l31, p.M - 1) * p.ldres + n0 + wn * 32 + kgrp * 16 + 4 * lh;
+#pragma unroll
+      for (int g = 0; g < 2; ++g) {
+        const float4 a = *reinterpret_cast<const float4*>(rp + 8 * g);
+        rpre[4 * g] = a.x; rpre[4 * g + 1] = a.y; rpre[4 * g + 2] = a.z; rpre[4 * g + 3] = a.w;
+      }
+    }
+    return;
+  }
   if (PRE_RES && p.epi == EPI_RESIDUAL && p.sk_mode != 1) {   // (mode 3: half of the workgroups prefetch in vain)
 #pragma unroll
     for (int i = 0; i < FM; ++i) {
@@ -765,8 +783,205 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int m0, con
   }
   }   // (!BD)
 
+  // ---- in-epilogue GroupNorm, first half (GnxParams, dv_common.h): wait for the statistics of the groups this tile's columns
+  // belong to and build the tile's per-column affine in LDS (s_gA, s_gB); `nwa` = waves of the workgroup that are still here ----
+  __shared__ float2 s_gst[BN / 16 + 1];
+  __shared__ __attribute__((aligned(16))) float s_gA[BN < 64 ? 64 : BN], s_gB[BN < 64 ? 64 : BN];
+  auto gnx_table = [&](const int nwa) __attribute__((always_inline)) {
+    const int cpg = p.N / p.gnx.groups, bq = m0 / p.T_out;
+    float pg = 0.f, pb = 0.f, pts = 1.f, ptb = 0.f;  // this thread's column: affine + temb scale / shift (independent of the statistics)
+    if (tid < BN) {
+      const int c = min(n0 + tid, p.N - 1);
+      pg = p.gnx.gamma[c]; pb = p.gnx.beta[c];
+      if (p.gnx.tscale) pts = 1.0f + p.gnx.tscale[(size_t)bq * p.gnx.ld_t + c];
+      if (p.gnx.tshift) ptb = p.gnx.tshift[(size_t)bq * p.gnx.ld_t + c];
+    }
+    // statistics of the groups this tile's columns belong to: one wave per group, fp64, fixed order (deterministic)
+    const int g_lo = n0 / cpg, g_hi = (min(n0 + BN, p.N) - 1) / cpg;
+    const int RB = p.T_out >> 5, nvb = cpg >> 4, ncb = p.N >> 4;
+    DV_TRACE(19);
+    for (int g = g_lo + wave; g <= g_hi; g += nwa) {
+      // poll the group's entries until none is EMPTY (all ones: the forward's first kernel resets the exchange words;
+      // a published (sum, M2) is finite).  All tiles of the utterance are resident and arrive within the spread of the
+      // workgroups' k-loops; a lane re-reads only what it has not seen yet; bounded and flagged, never a hang
+      constexpr int EPL = 4;                         // entries per lane: up to 256 per group (gemm_gnx_plan checks)
+      unsigned long long w[EPL];
+#pragma unroll
+      for (int k = 0; k < EPL; ++k) w[k] = ~0ull;
+      const int ne = RB * nvb;
+      for (int spins = 0;; ++spins) {
+        bool ok = true;
+#pragma unroll
+        for (int k = 0; k < EPL; ++k) {
+          const int e = lane + 64 * k;
+          if (e < ne && w[k] == ~0ull) {
+            const int rb = e / nvb, vb = e - rb * nvb;
+            w[k] = __hip_atomic_load(p.gnx.xchg + (size_t)(bq * RB + rb) * ncb + g * nvb + vb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            ok = ok && w[k] != ~0ull;
+          }
+        }
+        if (__all(ok)) break;
+        // (another launch has already given up: the run is lost and will be repeated on the fallback schedule - do not
+        // spend ~0.4 s per GEMM waiting for partners that a foreign kernel keeps off the CUs)
+        const bool lost = (spins & 63) == 63 && __hip_atomic_load(p.gnx.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u;
+        if (lost) break;
+        if (spins > p.gnx.spin_max) {
+          if (lane == 0) {               // which GEMM, which workgroup, which group: reported by the next host call
+            p.gnx.status[1] = (unsigned)(size_t)p.gnx.xchg; p.gnx.status[2] = blockIdx.x; p.gnx.status[3] = (unsigned)g;
+            p.gnx.status[4] = (unsigned)__builtin_popcountll(__ballot(!ok));
+            __hip_atomic_store(p.gnx.status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+          }
+          break;
+        }
+        __builtin_amdgcn_s_sleep(1);
+      }
+      double s1 = 0.0, q = 0.0;
+#pragma unroll
+      for (int k = 0; k < EPL; ++k) {
+        if (lane + 64 * k < ne) {
+          const double sx = (double)__uint_as_float((unsigned)w[k]), m2 = (double)__uint_as_float((unsigned)(w[k] >> 32));
+          s1 += sx;
+          q += m2 + sx * sx * (1.0 / 512.0);         // = the block's sum of squares
+        }
+      }
+      if constexpr (BD) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o); q += __shfl_xor(q, o); }
+      } else {
+        s1 = wave_sum64(s1); q = wave_sum64(q);
+      }
+      if (lane == 0) {
+        const double n = (double)cpg * (double)p.T_out, mean = s1 / n;
+        double var = q / n - mean * mean;
+        var = var > 0 ? var : 0;
+        s_gst[g - g_lo] = make_float2((float)mean, (float)(1.0 / sqrt(var + (double)p.gnx.eps)));
+      }
+    }
+    DV_TRACE(20);                                    // this wave's groups are reduced
+    __syncthreads();
+    DV_TRACE(21);                                    // ... every wave's
+    if (tid < BN) {
+      const float2 st = s_gst[min(n0 + tid, p.N - 1) / cpg - g_lo];
+      const float a = st.y * pg;
+      s_gA[tid] = a * pts;
+      s_gB[tid] = fmaf(pb - st.x * a, pts, ptb);
+    }
+    __syncthreads();
+  };
+
   if (nk == 0) { wait_vmcnt<0>(); __syncthreads(); }   // epilogue-only launch: the bias DMA has landed
   DV_TRACE(3);
+  // ---- half-fragment epilogue (half_mode above): both k-groups stay, each finishes 16 columns of its wave pair's fragment ----
+  if constexpr (HALF_OK) {
+    if (half_mode) {
+      __builtin_amdgcn_s_barrier();                  // every wave is done reading the ring
+      float4* red4 = reinterpret_cast<float4*>(smem);
+      // hand the OTHER group's column half over: group 0 its registers 8-15, group 1 its registers 0-7
+#pragma unroll
+      for (int g = 0; g < 2; ++g) {
+        const int a = 4 * g, b = 8 + 4 * g;
+        red4[((kgrp * NWQ + wq) * 2 + g) * 64 + lane] =
+            kgrp ? make_float4(acc[0][0][a], acc[0][0][a + 1], acc[0][0][a + 2], acc[0][0][a + 3])
+                 : make_float4(acc[0][0][b], acc[0][0][b + 1], acc[0][0][b + 2], acc[0][0][b + 3]);
+      }
+      __syncthreads();
+      float vv[8];
+#pragma unroll
+      for (int g = 0; g < 2; ++g) {
+        const float4 o4 = red4[(((kgrp ^ 1) * NWQ + wq) * 2 + g) * 64 + lane];
+        const int a = 4 * g, b = 8 + 4 * g;
+        // (group 0's sums first, as on the full path: acc(group 0) + acc(group 1))
+        vv[a] = kgrp ? o4.x + acc[0][0][b] : acc[0][0][a] + o4.x;
+        vv[a + 1] = kgrp ? o4.y + acc[0][0][b + 1] : acc[0][0][a + 1] + o4.y;
+        vv[a + 2] = kgrp ? o4.z + acc[0][0][b + 2] : acc[0][0][a + 2] + o4.z;
+        vv[a + 3] = kgrp ? o4.w + acc[0][0][b + 3] : acc[0][0][a + 3] + o4.w;
+      }
+      DV_TRACE(22);
+      DV_TRACE(4);
+      const bool gnx_h = p.gnx.xchg != nullptr;
+      const int coff = kgrp * 16;                    // this wave's columns inside the fragment
+      const int ncol = n0 + wn * 32 + coff;          // first of them
+      const int rl = wm * 32 + l31, m = m0 + rl, mrow0 = m0 + wm * 32;
+      const bool m_ok = m < p.M;
+#pragma unroll
+      for (int g = 0; g < 2; ++g) {
+        const int cl = wn * 32 + coff + 4 * lh + 8 * g;                    // tile-local column of e = 0
+        if (p.ln_stat) {
+          const float2 st = s_ln[rl];
+          const float4 u4 = *reinterpret_cast<const float4*>(s_u + cl);
+          vv[4 * g] = st.y * (vv[4 * g] - st.x * u4.x); vv[4 * g + 1] = st.y * (vv[4 * g + 1] - st.x * u4.y);
+          vv[4 * g + 2] = st.y * (vv[4 * g + 2] - st.x * u4.z); vv[4 * g + 3] = st.y * (vv[4 * g + 3] - st.x * u4.w);
+        }
+        const float4 b4 = *reinterpret_cast<const float4*>(s_bias + cl);
+        vv[4 * g] += b4.x; vv[4 * g + 1] += b4.y; vv[4 * g + 2] += b4.z; vv[4 * g + 3] += b4.w;
+      }
+      if (p.epi == EPI_RESIDUAL) {
+#pragma unroll
+        for (int r = 0; r < 8; ++r) vv[r] += rpre[r];
+      }
+      if (p.relu) {
+#pragma unroll
+        for (int r = 0; r < 8; ++r) vv[r] = fmaxf(vv[r], 0.f);
+      }
+      if (p.rowmask) {
+        const float rmask = p.rowmask[m_ok ? m : p.M - 1];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) vv[r] *= rmask;
+      }
+#pragma unroll
+      for (int r = 0; r < 8; ++r) vv[r] = m_ok ? vv[r] : 0.f;
+      DV_TRACE(16);
+      if (m_ok) {
+        const size_t ob = (size_t)m * p.ldo + ncol;
+        if (p.out) {
+#pragma unroll
+          for (int g = 0; g < 2; ++g)
+            *reinterpret_cast<float4*>(p.out + ob + 4 * lh + 8 * g) = make_float4(vv[4 * g], vv[4 * g + 1], vv[4 * g + 2], vv[4 * g + 3]);
+        }
+        if (p.out_hi) store_planes8(p.out_hi, p.out_lo, ob, lh, vv);
+      }
+      DV_TRACE(17);
+      if (p.stats16) {                               // this wave's 32 x 16 block: (sum, squared deviations about its own mean)
+        float a1 = 0.f, a2 = 0.f;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) a1 += vv[r];
+        a1 = wave_sum64(a1);
+        const float mb = a1 * (1.0f / 512.0f);
+#pragma unroll
+        for (int r = 0; r < 8; ++r) { const float dv = vv[r] - mb; a2 = fmaf(dv, dv, a2); }
+        a2 = wave_sum64(a2);
+        if (lane == 0 && mrow0 < p.M) {
+          const size_t e = (size_t)(mrow0 >> 5) * (p.N >> 4) + (ncol >> 4);
+          reinterpret_cast<float2*>(p.stats16)[e] = make_float2(a1, a2);
+          if (gnx_h)
+            __hip_atomic_store(p.gnx.xchg + e, (unsigned long long)__float_as_uint(a1) | ((unsigned long long)__float_as_uint(a2) << 32),
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+      }
+      DV_TRACE(18);
+      if (gnx_h) {
+        gnx_table(NWV);
+        if (m_ok) {
+          float y[8];
+#pragma unroll
+          for (int g = 0; g < 2; ++g) {
+            const int cl = wn * 32 + coff + 4 * lh + 8 * g;
+            const float4 sa = *reinterpret_cast<const float4*>(s_gA + cl);
+            const float4 sb = *reinterpret_cast<const float4*>(s_gB + cl);
+            y[4 * g] = fmaf(vv[4 * g], sa.x, sb.x); y[4 * g + 1] = fmaf(vv[4 * g + 1], sa.y, sb.y);
+            y[4 * g + 2] = fmaf(vv[4 * g + 2], sa.z, sb.z); y[4 * g + 3] = fmaf(vv[4 * g + 3], sa.w, sb.w);
+          }
+          if (p.gnx.silu) {
+#pragma unroll
+            for (int r = 0; r < 8; ++r) y[r] = y[r] * __builtin_amdgcn_rcpf(1.0f + __expf(-y[r]));
+          }
+          store_planes8(p.gnx.y_hi, p.gnx.y_lo, (size_t)m * p.N + ncol, lh, y);
+        }
+      }
+      DV_TRACE(5);
+      return;
+    }
+  }
   // KS == 2: add the two k-groups' partial accumulators through LDS (lane-linear, conflict-free).  With an even
   // number of row fragments each k-group keeps the sums of ITS fragments (i % 2 == kgrp) and both run the epilogue on
   // their half, so all eight waves share the (store- and GELU-bound) epilogue; otherwise group 1 hands everything over.
@@ -1161,88 +1376,7 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int m0, con
   DV_TRACE(18);                                      // statistics of every fragment written
   if (gnx) {
     // ---- GroupNorm of this GEMM's own output (GnxParams, dv_common.h) ----
-    const int cpg = p.N / p.gnx.groups, bq = m0 / p.T_out;
-    float pg = 0.f, pb = 0.f, pts = 1.f, ptb = 0.f;  // this thread's column: affine + temb scale / shift (independent of the statistics)
-    if (tid < BN) {
-      const int c = min(n0 + tid, p.N - 1);
-      pg = p.gnx.gamma[c]; pb = p.gnx.beta[c];
-      if (p.gnx.tscale) pts = 1.0f + p.gnx.tscale[(size_t)bq * p.gnx.ld_t + c];
-      if (p.gnx.tshift) ptb = p.gnx.tshift[(size_t)bq * p.gnx.ld_t + c];
-    }
-    // statistics of the groups this tile's columns belong to: one wave per group, fp64, fixed order (deterministic)
-    constexpr int NWA = BD ? NWQ * FM : ((KS == 2 && !SPLIT_EPI) ? NWQ : NWV);   // waves still here
-    __shared__ float2 s_gst[BN / 16 + 1];
-    __shared__ __attribute__((aligned(16))) float s_gA[BN < 64 ? 64 : BN], s_gB[BN < 64 ? 64 : BN];
-    const int g_lo = n0 / cpg, g_hi = (min(n0 + BN, p.N) - 1) / cpg;
-    const int RB = p.T_out >> 5, nvb = cpg >> 4, ncb = p.N >> 4;
-    DV_TRACE(19);
-    for (int g = g_lo + wave; g <= g_hi; g += NWA) {
-      // poll the group's entries until none is EMPTY (all ones: the forward's first kernel resets the exchange words;
-      // a published (sum, M2) is finite).  All tiles of the utterance are resident and arrive within the spread of the
-      // workgroups' k-loops; a lane re-reads only what it has not seen yet; bounded and flagged, never a hang
-      constexpr int EPL = 4;                         // entries per lane: up to 256 per group (gemm_gnx_plan checks)
-      unsigned long long w[EPL];
-#pragma unroll
-      for (int k = 0; k < EPL; ++k) w[k] = ~0ull;
-      const int ne = RB * nvb;
-      for (int spins = 0;; ++spins) {
-        bool ok = true;
-#pragma unroll
-        for (int k = 0; k < EPL; ++k) {
-          const int e = lane + 64 * k;
-          if (e < ne && w[k] == ~0ull) {
-            const int rb = e / nvb, vb = e - rb * nvb;
-            w[k] = __hip_atomic_load(p.gnx.xchg + (size_t)(bq * RB + rb) * ncb + g * nvb + vb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            ok = ok && w[k] != ~0ull;
-          }
-        }
-        if (__all(ok)) break;
-        // (another launch has already given up: the run is lost and will be repeated on the fallback schedule - do not
-        // spend ~0.4 s per GEMM waiting for partners that a foreign kernel keeps off the CUs)
-        const bool lost = (spins & 63) == 63 && __hip_atomic_load(p.gnx.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u;
-        if (lost) break;
-        if (spins > p.gnx.spin_max) {
-          if (lane == 0) {               // which GEMM, which workgroup, which group: reported by the next host call
-            p.gnx.status[1] = (unsigned)(size_t)p.gnx.xchg; p.gnx.status[2] = blockIdx.x; p.gnx.status[3] = (unsigned)g;
-            p.gnx.status[4] = (unsigned)__builtin_popcountll(__ballot(!ok));
-            __hip_atomic_store(p.gnx.status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-          }
-          break;
-        }
-        __builtin_amdgcn_s_sleep(1);
-      }
-      double s1 = 0.0, q = 0.0;
-#pragma unroll
-      for (int k = 0; k < EPL; ++k) {
-        if (lane + 64 * k < ne) {
-          const double sx = (double)__uint_as_float((unsigned)w[k]), m2 = (double)__uint_as_float((unsigned)(w[k] >> 32));
-          s1 += sx;
-          q += m2 + sx * sx * (1.0 / 512.0);         // = the block's sum of squares
-        }
-      }
-      if constexpr (BD) {
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o); q += __shfl_xor(q, o); }
-      } else {
-        s1 = wave_sum64(s1); q = wave_sum64(q);
-      }
-      if (lane == 0) {
-        const double n = (double)cpg * (double)p.T_out, mean = s1 / n;
-        double var = q / n - mean * mean;
-        var = var > 0 ? var : 0;
-        s_gst[g - g_lo] = make_float2((float)mean, (float)(1.0 / sqrt(var + (double)p.gnx.eps)));
-      }
-    }
-    DV_TRACE(20);                                    // this wave's groups are reduced
-    __syncthreads();
-    DV_TRACE(21);                                    // ... every wave's
-    if (tid < BN) {
-      const float2 st = s_gst[min(n0 + tid, p.N - 1) / cpg - g_lo];
-      const float a = st.y * pg;
-      s_gA[tid] = a * pts;
-      s_gB[tid] = fmaf(pb - st.x * a, pts, ptb);
-    }
-    __syncthreads();
+    gnx_table(BD ? NWQ * FM : ((KS == 2 && !SPLIT_EPI) ? NWQ : NWV));   // (waves still here)
 #pragma unroll
     for (int j = 0; j < FN; ++j) {
       const int cl = (wn * FN + j) * 32 + 4 * lh;    // tile-local column of g = 0, e = 0
