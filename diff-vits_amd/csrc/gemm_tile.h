@@ -471,16 +471,8 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int m0, con
         if (c == 0) {
           if (a_fresh) prep_a(); else prep_a_next();
         }
-        // The next tile's DMA units go out behind the FIRST MFMA group (DV_GEMM_DMA_GROUPS = 1), not spread over all NCH of them:
-        // requested ~half a k-tile earlier, more bytes are in flight under the multiplies - +0.7..1.0 % end to end; ahead of the
-        // first group +0.15 %, over two / three groups -0.3 % (profiles/r03_ab_dma_issue_spread.txt).  [The same sensitivity,
-        // the other way: one barrier per PAIR of k-tiles with nothing in flight at the barrier lost 7.6 %.]
-#ifndef DV_GEMM_DMA_GROUPS
-#define DV_GEMM_DMA_GROUPS 1
-#endif
-        constexpr int NSP = (DV_GEMM_DMA_GROUPS > 0 && DV_GEMM_DMA_GROUPS < NCH) ? DV_GEMM_DMA_GROUPS : NCH;
 #pragma unroll
-        for (int u = min(c, NSP) * LPT / NSP; u < min(c + 1, NSP) * LPT / NSP; ++u) issue_unit(kt + NSTAGE - 1, u);
+        for (int u = c * LPT / NCH; u < (c + 1) * LPT / NCH; ++u) issue_unit(kt + NSTAGE - 1, u);
         __builtin_amdgcn_sched_barrier(0);
       }
     }
