@@ -487,8 +487,9 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int m0, con
   // sums over and leaving - the epilogue then runs on one wave per SIMD, where nothing hides a latency - the groups exchange
   // column halves and EACH finishes 16 of the fragment's 32 columns (registers 0-7 of group 0, 8-15 of group 1: exactly the two
   // 16-column statistics blocks).  Workgroup-uniform; the cases it does not cover take the full path below.
+  const bool al8 = ((p.N | p.ldo) & 7) == 0;        // row pitches of the bf16 planes are multiples of 16 bytes: 16-byte plane stores are aligned
   constexpr bool HALF_OK = !BD && !SC1 && KS == 2 && FM == 1 && FN == 1;
-  const bool half_mode = HALF_OK && p.sk_mode == 0 && vec4 && n0 + BN <= p.N && !p.stats && !p.rowstat_out &&
+  const bool half_mode = HALF_OK && p.sk_mode == 0 && vec4 && al8 && n0 + BN <= p.N && !p.stats && !p.rowstat_out &&
                          (p.epi == EPI_STORE || p.epi == EPI_RESIDUAL) && nk > 0;
   auto load4 = [&](const float* base, size_t row_off, int nb, float* dst) {   // dst[0..3] = base[row_off + nb + e]
     if (vec4) {
@@ -1164,7 +1165,7 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int m0, con
           v[r] = (a + ba[r]) * gelu_erf(gt + bg[r]);
         }
         // output column of packed `a` column nb: 32 per 64-column block; nb < N  <=>  oc-run inside N/2
-        if (!BD && vec4 && p.out_hi && !p.out && n0 + wn * 64 + 64 <= p.N) {   // (wave-uniform) whole block inside N: 16-byte plane stores
+        if (!BD && vec4 && al8 && p.out_hi && !p.out && n0 + wn * 64 + 64 <= p.N) {   // (wave-uniform) whole block inside N: 16-byte plane stores
           store_planes16(p.out_hi, p.out_lo, (size_t)m * p.ldo + blk * 32, lh, v);
         } else {
 #pragma unroll
@@ -1182,7 +1183,7 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int m0, con
   // several tiles - the argument block went through scratch memory; the runtime flag keeps one body.]
 #pragma unroll
   for (int j = 0; j < FN; ++j) {
-    const bool full = !BD && vec4 && n0 + (wn * FN + j) * 32 + 32 <= p.N;
+    const bool full = !BD && vec4 && al8 && n0 + (wn * FN + j) * 32 + 32 <= p.N;
     const int nf = n0 + (wn * FN + j) * 32 + 4 * lh;   // column of g = 0, e = 0
     float bv[16], un[16];
 #pragma unroll
@@ -1386,7 +1387,7 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int m0, con
         const int m = m0 + (wm * FM + i) * 32 + l31;
         if (m >= p.M) continue;
         const int nfr = n0 + (wn * FN + j) * 32;
-        if (!BD && nfr + 32 <= p.N) {                  // (wave-uniform) the whole fragment: 16-byte plane stores
+        if (!BD && al8 && nfr + 32 <= p.N) {           // (wave-uniform) the whole fragment: 16-byte plane stores
           float y[16];
 #pragma unroll
           for (int g = 0; g < 4; ++g) {
