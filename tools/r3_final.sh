@@ -9,7 +9,7 @@ cd $R
 timeout 2400 python -m pytest tests -x -q -m gpu > $O/pytest.log 2>&1
 echo "pytest rc=$?" >> $O/pytest.log
 tail -5 $O/pytest.log
-bash tools/profile_job.sh r03 92e26d9 > $O/profile_job.log 2>&1
+bash tools/profile_job.sh r03 425603b > $O/profile_job.log 2>&1
 tail -3 $O/profile_job.log
 cp gpurun_out/r03_pmc_roofline.json profiles/r03_pmc_roofline.json   # (so that the bench line below can quote it: same build)
 timeout 1200 python bench.py > $O/bench_final.json 2> $O/bench_final.err
