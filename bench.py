@@ -249,6 +249,65 @@ def lifecycle_extras(dev, precision):
     return out
 
 
+def time_sampler(model, dev, B, T, L, kind, steps, runs=2, seed=4321):
+    """ms per complete sampler run (median of `runs` after one warm-up run that plans the shape and captures the graph)."""
+    from diff_vits_amd.sampler import uni_pc
+    x, cond, enc, mask = (torch.from_numpy(a).to(dev) for a in synth.make_inputs(B, 80, T, L, seed=seed))
+    betas = torch.from_numpy(synth.make_betas())
+    if kind == "unipc":
+        ns = uni_pc.NoiseScheduleVP("discrete", betas=betas)
+        native = uni_pc.NativeUNetModel(model, cond, enc, mask)
+        solver = uni_pc.UniPC(uni_pc.model_wrapper(native, ns, model_type="x_start"), ns, variant="bh2")
+        run = lambda: solver.sample(x, steps=steps, order=2)                                           # noqa: E731
+    else:
+        ns = dpm_solver.NoiseScheduleVP("discrete", betas=betas)
+        native = dpm_solver.NativeUNetModel(model, cond, enc, mask)
+        solver = dpm_solver.DPM_Solver(dpm_solver.model_wrapper(native, ns, model_type="x_start"), ns, algorithm_type="dpmsolver++")
+        run = lambda: solver.sample(x, steps=steps, order=2, skip_type="time_uniform", method="multistep")   # noqa: E731
+    ts = []
+    with torch.no_grad():
+        out = run()
+        torch.cuda.synchronize()
+        for _ in range(runs):
+            t0 = time.perf_counter(); out = run(); torch.cuda.synchronize()
+            ts.append(1e3 * (time.perf_counter() - t0))
+    assert torch.isfinite(out).all()
+    return sorted(ts)[len(ts) // 2]
+
+
+def other_configs(dev, model, sd, precision, S, y_ref):
+    """The single-GPU BASELINE.json configurations beside the headline, a few seconds in all:
+    config 2 in the fast precision mode (one bf16 product; outside the 1e-3 parity budget - its error is reported beside
+    it), config 4 (UniPC-bh2, 20 steps, B=1, T=2048 long-form) and the headline shapes at 16 utterances per GPU."""
+    out = {}
+    peak = PEAK_TFLOPS[precision]
+    # config 4: UniPC (sampler/uni_pc.py), 20 steps, order 2, one utterance of 2048 frames
+    ms = time_sampler(model, dev, 1, 2048, 256, "unipc", 20)
+    out["config4_unipc20_T2048_B1"] = {"value": 2048.0 / (ms * 1e-3), "unit": "mel-frames/s", "ms_per_run": ms,
+                                       "frac_of_peak": 20 * flops_model(1, 2048, 256) / (ms * 1e-3) / 1e12 / peak,
+                                       "precision": precision}
+    ms = time_sampler(model, dev, 16, 1024, 256, "dpm", S)
+    out["b16"] = {"value": 16 * 1024.0 / (ms * 1e-3), "unit": "mel-frames/s", "ms_per_run": ms,
+                  "frac_of_peak": S * flops_model(16, 1024, 256) / (ms * 1e-3) / 1e12 / peak, "precision": precision}
+    if precision == "bf16x3":
+        fast, _ = build_model(dev, "bf16")
+        ms = time_sampler(fast, dev, 8, 1024, 256, "dpm", S)
+        fm = {"value": 8 * 1024.0 / (ms * 1e-3), "unit": "mel-frames/s", "ms_per_run": ms,
+              "frac_of_peak": S * flops_model(8, 1024, 256) / (ms * 1e-3) / 1e12 / PEAK_TFLOPS["bf16"],
+              "precision": "bf16 (one product per contraction; NOT the parity mode)"}
+        if y_ref is not None:
+            xo, co, eo, mo = (torch.from_numpy(a).to(dev) for a in synth.make_inputs(8, 80, 1024, 256, seed=1234))
+            with torch.no_grad():
+                y = fast(torch.cat([xo, co], 1), torch.full((8,), PARITY_T, device=dev), eo, encoder_attention_mask=mo).sample
+            y = y.double().cpu()
+            yr = y_ref.double()
+            fm["unet_rel_l2"] = float((y - yr).norm() / yr.norm())
+            fm["unet_max_abs_rel"] = float((y - yr).abs().max() / yr.abs().max())
+        out["bf16_fast_mode"] = fm
+        del fast
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -263,6 +322,8 @@ def main():
                     help="split the per-GPU batch into this many concurrent sub-batches (own engine + HIP stream each)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="skip extra.{bf16_fast_mode, config4_unipc20_T2048_B1, b16} (the other single-GPU BASELINE configurations)")
     ap.add_argument("--dry-run-cpu", action="store_true",
                     help="GPU-less rehearsal of the multi-rank path: gloo, torch backend, tiny configuration (tests)")
     ap.add_argument("--dist-timeout", type=float, default=float(os.environ.get("DVITS_DIST_TIMEOUT_S", "180")),
@@ -274,7 +335,7 @@ def main():
         for k, v in defaults.items():
             if getattr(args, k) == ap.get_default(k):
                 setattr(args, k, v)
-        args.no_roofline = args.no_cpu_baseline = True
+        args.no_roofline = args.no_cpu_baseline = args.no_other_configs = True
         torch.set_num_threads(1)
 
     rank = int(os.environ.get("RANK", "0"))
@@ -385,6 +446,21 @@ def main():
         dt = float(tt.item())
     assert torch.isfinite(out).all()
     assert out.shape[0] == G, "the gathered mels must cover the global batch"
+    # Which schedule did every rank time?  (GEMMs that finish a GroupNorm in their epilogue, time-out flag, downgraded to the
+    # separate-GroupNorm schedule): a rank whose in-launch hand-over timed out - RCCL kernels on a side stream are exactly the
+    # foreign work that can trip the bounded poll - has repeated runs on the slower fallback schedule; the line must say so.
+    ho_ranks = None
+    if not dry:
+        eng0 = model.hip_engine()
+        n_ho_r, bad_r = eng0.handover_status()
+        mine = [int(n_ho_r), int(bool(bad_r)), int(bool(eng0.handover_downgraded))]
+        if world > 1:
+            hv = torch.tensor(mine, device=dev, dtype=torch.int64)
+            hall = torch.empty((world, 3), device=dev, dtype=torch.int64)
+            torch.distributed.all_gather_into_tensor(hall, hv)
+            ho_ranks = hall.tolist()
+        else:
+            ho_ranks = [mine]
 
     if rank != 0:
         if world > 1:
@@ -405,6 +481,13 @@ def main():
                    "rccl_world_size": torch.distributed.get_world_size() if world > 1 else 1, "parallelism": "dp%d (batch-sharded, RCCL broadcast of conditioning + all-gather of mels)" % world},
         "per_rank_ms_per_step": {"min": min(rank_ms), "max": max(rank_ms), "ranks": [round(v, 3) for v in rank_ms]},
     }
+    if ho_ranks is not None:
+        result["per_rank_in_epilogue_groupnorm"] = {"gemms": [r[0] for r in ho_ranks], "timed_out": [r[1] for r in ho_ranks],
+                                                    "downgraded_to_separate_groupnorm": [r[2] for r in ho_ranks]}
+        if any(r[1] or r[2] for r in ho_ranks):
+            print(json.dumps(result))
+            raise SystemExit("bench: an in-kernel GroupNorm hand-over timed out on rank(s) %s (is the GPU shared?) - not the default "
+                             "schedule's number" % [i for i, r in enumerate(ho_ranks) if r[1] or r[2]])
     if dry:
         result["dry_run_cpu"] = True                 # a rehearsal of the rank path on CPU (gloo, torch backend): not a measurement
         result["dtype"] = "fp32 (torch backend, CPU dry run)"
@@ -501,6 +584,9 @@ def main():
             print(json.dumps(result))
             raise SystemExit("bench: UNet output differs from the oracle by %.3e (rel-L2) / %.3e (max-abs-rel) > %.0e"
                              % (par["unet_rel_l2"], par["unet_max_abs_rel"], PARITY_TOL))
+    if world == 1 and not dry and not args.no_other_configs and (B, T, L) == (8, 1024, 256):
+        y_ref_ = locals().get("y_ref")
+        result.setdefault("extra", {}).update(other_configs(dev, model, sd, args.precision, S, y_ref_))
     print(json.dumps(result))
     if world > 1:
         torch.distributed.destroy_process_group()

@@ -72,6 +72,7 @@ SIGNATURES = {
     "dv_sampler_run_custom": (C.c_int, [C.c_void_p, MODEL_FN, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     "dv_op_conv1d": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_int32] * 8 + [C.c_void_p]),
     "dv_op_linear": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_int32] * 4 + [C.c_void_p]),
+    "dv_op_linear_planes": (C.c_int, [C.c_void_p] * 6 + [C.c_int32] * 6 + [C.c_void_p]),
     "dv_op_group_stats": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_int32] * 4 + [C.c_float, C.c_void_p]),
     "dv_op_attention": (C.c_int, [C.c_void_p] * 5 + [C.c_int32] * 5 + [C.c_void_p]),
 }

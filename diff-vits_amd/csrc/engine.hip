@@ -2256,6 +2256,8 @@ extern "C" int dv_op_conv1d(const float* x, const float* w, const float* bias, f
   HIPCHK(attn_init());
   const bool x3 = precision == DV_PREC_BF16X3;
   const int cpad = rup(Cin, 32), Kp = k * cpad, Npad = rup(Cout, 128);
+  if (2 * (size_t)cpad + 256 > DV_ZERO_PAGE_BYTES)
+    return dv_fail(DV_ERR_INVALID, "dv_op_conv1d: Cin = %d exceeds the %d channels one source tensor may have", Cin, (DV_ZERO_PAGE_BYTES - 256) / 2);
   OpScratch sc;
   bf16_t* xh = sc.get<bf16_t>((size_t)B * T * cpad * 2, st, false);
   bf16_t* xl = x3 ? sc.get<bf16_t>((size_t)B * T * cpad * 2, st, false) : nullptr;
@@ -2267,15 +2269,17 @@ extern "C" int dv_op_conv1d(const float* x, const float* w, const float* bias, f
   PackSpec s{};
   s.src = w; s.N = Cout; s.kind = 1; s.C = Cin; s.taps = k; s.c_pad = cpad; s.k_off = 0; s.n_off = 0;
   HIPCHK(launch_pack_weight(s, hi, lo, Kp, st));
-  bf16_t* fhi = sc.get<bf16_t>((size_t)Npad * Kp * 2, st, false);
-  bf16_t* flo = x3 ? sc.get<bf16_t>((size_t)Npad * Kp * 2, st, false) : nullptr;
-  if (!fhi || (x3 && !flo)) return dv_fail(DV_ERR_HIP, "dv_op_conv1d: hipMalloc failed");
-  if (cpad % 64 == 0) {
+  GemmParams g{};
+  // fragment-major copies only while the BD tile is on (DVITS_GEMM_BD; off by default)
+  static const bool bd_env = [] { const char* e = getenv("DVITS_GEMM_BD"); return e && atoi(e) != 0; }();
+  if (bd_env && cpad % 64 == 0) {
+    bf16_t* fhi = sc.get<bf16_t>((size_t)Npad * Kp * 2, st, false);
+    bf16_t* flo = x3 ? sc.get<bf16_t>((size_t)Npad * Kp * 2, st, false) : nullptr;
+    if (!fhi || (x3 && !flo)) return dv_fail(DV_ERR_HIP, "dv_op_conv1d: hipMalloc failed");
     HIPCHK(launch_relayout_frag_cm(hi, fhi, Npad, Kp, k, cpad, 1, 0, st));
     if (x3) HIPCHK(launch_relayout_frag_cm(lo, flo, Npad, Kp, k, cpad, 1, 0, st));
-  } else fhi = flo = nullptr;
-  GemmParams g{};
-  g.wf_hi = fhi; g.wf_lo = flo;
+    g.wf_hi = fhi; g.wf_lo = flo;
+  }
   g.seg[0].a0_hi = xh; g.seg[0].a0_lo = xl; g.seg[0].c0 = cpad; g.seg[0].taps = k; g.seg[0].pad = (k - 1) / 2;
   g.nseg = 1; g.B = B; g.T_in = T;
   g.T_virt = up_T > 0 ? up_T : T;
@@ -2290,10 +2294,15 @@ extern "C" int dv_op_conv1d(const float* x, const float* w, const float* bias, f
   return DV_OK;
 }
 
-extern "C" int dv_op_linear(const float* x, const float* w, const float* bias, float* y, int32_t M, int32_t K, int32_t N,
-                            int32_t precision, void* stream) {
-  if (!x || !w || !y || K % 32 != 0) return dv_fail(DV_ERR_INVALID, "dv_op_linear: K must be a multiple of 32");
-  hipStream_t st = (hipStream_t)stream;
+// y = x W^T + bias through k_gemm; output as fp32 [M, ldo] (y) and / or split bf16 planes [M, ldo] (y_hi, y_lo);
+// geglu: W = [value rows | gate rows] (N = 2 x N_out, reference activations GEGLU: hidden * gelu(gate)), output N / 2 columns
+static int op_linear(const float* x, const float* w, const float* bias, float* y, bf16_t* y_hi, bf16_t* y_lo, int M, int K, int N, int ldo,
+                     int geglu, int precision, hipStream_t st, const char* what) {
+  if (!x || !w || (!y && !y_hi) || K % 32 != 0) return dv_fail(DV_ERR_INVALID, "%s: K must be a multiple of 32 (and an output is needed)", what);
+  if (geglu && (N % 64 != 0 || y)) return dv_fail(DV_ERR_INVALID, "%s: GEGLU needs N %% 64 == 0 and writes planes only", what);
+  const int n_out = geglu ? N / 2 : N;
+  if (ldo < n_out) return dv_fail(DV_ERR_INVALID, "%s: ldo %d < %d output columns", what, ldo, n_out);
+  if (2 * (size_t)K + 256 > DV_ZERO_PAGE_BYTES) return dv_fail(DV_ERR_INVALID, "%s: K = %d exceeds the %d channels one source tensor may have", what, K, (DV_ZERO_PAGE_BYTES - 256) / 2);
   HIPCHK(gemm_init());
   gemm_env_refresh();
   HIPCHK(attn_init());
@@ -2305,27 +2314,44 @@ extern "C" int dv_op_linear(const float* x, const float* w, const float* bias, f
   bf16_t* hi = sc.get<bf16_t>((size_t)Npad * K * 2, st, true);
   bf16_t* lo = x3 ? sc.get<bf16_t>((size_t)Npad * K * 2, st, true) : nullptr;
   bf16_t* zp = sc.get<bf16_t>(DV_ZERO_PAGE_BYTES, st, true);
-  if (!xh || !hi || !zp || (x3 && (!xl || !lo))) return dv_fail(DV_ERR_HIP, "dv_op_linear: hipMalloc failed");
+  float* pb = (geglu && bias) ? sc.get<float>((size_t)Npad * 4, st, true) : nullptr;
+  if (!xh || !hi || !zp || (x3 && (!xl || !lo)) || (geglu && bias && !pb)) return dv_fail(DV_ERR_HIP, "%s: hipMalloc failed", what);
   HIPCHK(launch_split(x, xh, xl, (int64_t)M * K, st));
   PackSpec s{};
-  s.src = w; s.N = N; s.kind = 0; s.C = K; s.taps = 1; s.c_pad = K;
+  s.src = w; s.N = N; s.kind = 0; s.C = K; s.taps = 1; s.c_pad = K; s.geglu = geglu;
   HIPCHK(launch_pack_weight(s, hi, lo, K, st));
-  bf16_t* fhi = sc.get<bf16_t>((size_t)Npad * K * 2, st, false);
-  bf16_t* flo = x3 ? sc.get<bf16_t>((size_t)Npad * K * 2, st, false) : nullptr;
-  if (!fhi || (x3 && !flo)) return dv_fail(DV_ERR_HIP, "dv_op_linear: hipMalloc failed");
-  if (K % 64 == 0) {
+  if (pb) HIPCHK(launch_fold_bias(nullptr, bias, nullptr, pb, N, K, 0, 1, st));   // bias in the packed [32 a | 32 gate] column order
+  GemmParams g{};
+  // fragment-major copies only while the BD tile is on (DVITS_GEMM_BD; off by default)
+  static const bool bd_env = [] { const char* e = getenv("DVITS_GEMM_BD"); return e && atoi(e) != 0; }();
+  if (bd_env && K % 64 == 0 && !geglu) {
+    bf16_t* fhi = sc.get<bf16_t>((size_t)Npad * K * 2, st, false);
+    bf16_t* flo = x3 ? sc.get<bf16_t>((size_t)Npad * K * 2, st, false) : nullptr;
+    if (!fhi || (x3 && !flo)) return dv_fail(DV_ERR_HIP, "%s: hipMalloc failed", what);
     HIPCHK(launch_relayout_frag_cm(hi, fhi, Npad, K, 1, K, 1, 0, st));
     if (x3) HIPCHK(launch_relayout_frag_cm(lo, flo, Npad, K, 1, K, 1, 0, st));
-  } else fhi = flo = nullptr;
-  GemmParams g{};
-  g.wf_hi = fhi; g.wf_lo = flo;
+    g.wf_hi = fhi; g.wf_lo = flo;
+  }
   g.seg[0].a0_hi = xh; g.seg[0].a0_lo = xl; g.seg[0].c0 = K; g.seg[0].taps = 1;
   g.nseg = 1; g.B = 1; g.T_in = g.T_out = g.T_virt = M; g.stride = 1;
-  g.w_hi = hi; g.w_lo = lo; g.Kp = K; g.N_pad = Npad; g.bias = bias;
-  g.M = M; g.N = N; g.epi = EPI_STORE; g.out = y; g.ldo = N; g.zero_page = zp;
-  HIPCHK(launch_gemm(g, precision, st));
+  g.w_hi = hi; g.w_lo = lo; g.Kp = K; g.N_pad = Npad; g.bias = geglu ? pb : bias;
+  g.M = M; g.N = N; g.epi = geglu ? EPI_GEGLU : EPI_STORE; g.out = y; g.out_hi = y_hi; g.out_lo = y_lo; g.ldo = ldo; g.zero_page = zp;
+  hipError_t e = launch_gemm(g, precision, st);
+  if (e != hipSuccess) return dv_fail(DV_ERR_HIP, "%s: launch failed: %s", what, hipGetErrorString(e));
   HIPCHK(hipStreamSynchronize(st));
   return DV_OK;
+}
+
+extern "C" int dv_op_linear(const float* x, const float* w, const float* bias, float* y, int32_t M, int32_t K, int32_t N,
+                            int32_t precision, void* stream) {
+  return op_linear(x, w, bias, y, nullptr, nullptr, M, K, N, N, 0, precision, (hipStream_t)stream, "dv_op_linear");
+}
+
+extern "C" int dv_op_linear_planes(const float* x, const float* w, const float* bias, float* y, uint16_t* y_hi, uint16_t* y_lo, int32_t M,
+                                   int32_t K, int32_t N, int32_t ldo, int32_t geglu, int32_t precision, void* stream) {
+  if (!y_hi || (precision == DV_PREC_BF16X3 && !y_lo)) return dv_fail(DV_ERR_INVALID, "dv_op_linear_planes: plane outputs are required");
+  return op_linear(x, w, bias, y, y_hi, precision == DV_PREC_BF16X3 ? y_lo : nullptr, M, K, N, ldo, geglu, precision, (hipStream_t)stream,
+                   "dv_op_linear_planes");
 }
 
 extern "C" int dv_op_group_stats(const float* x, float* mean, float* rstd, int32_t B, int32_t T, int32_t C, int32_t groups,

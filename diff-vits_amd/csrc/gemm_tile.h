@@ -239,7 +239,7 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int m0, con
       st = p.up_mode == UP_X2 ? (ts >> 1) : st;
       st = p.up_mode == UP_SIZE ? min((int)floorf((float)ts * p.up_scale), p.T_in - 1) : st;
       const size_t e = ((size_t)arow_b[q] * p.T_in + st) * cur_ld + cur_col + a_chunk[q] * 8;
-      // conv zero padding / rows >= M read a 16-byte zero page instead
+      // conv zero padding / rows >= M read the zero page instead (DV_ZERO_PAGE_BYTES: the lane then walks the row's k-tiles inside it)
       asrc[q * NPL] = ok ? (const void*)(cur_hi + e) : (const void*)p.zero_page;
       if (SPLIT) asrc[q * NPL + 1] = ok ? (const void*)(cur_lo + e) : (const void*)p.zero_page;
     }
@@ -937,7 +937,7 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int m0, con
         if (p.out) {
 #pragma unroll
           for (int g = 0; g < 2; ++g)
-            *reinterpret_cast<float4*>(p.out + ob + 4 * lh + 8 * g) = make_float4(vv[4 * g], vv[4 * g + 1], vv[4 * g + 2], vv[4 * g + 3]);
+            dv_st16(p.out + ob + 4 * lh + 8 * g, make_float4(vv[4 * g], vv[4 * g + 1], vv[4 * g + 2], vv[4 * g + 3]));
         }
         if (p.out_hi) store_planes8(p.out_hi, p.out_lo, ob, lh, vv);
       }
@@ -1291,7 +1291,7 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int m0, con
           if (p.out) {
 #pragma unroll
             for (int g = 0; g < 4; ++g)
-              *reinterpret_cast<float4*>(p.out + ob + 8 * g) = make_float4(vv[4 * g], vv[4 * g + 1], vv[4 * g + 2], vv[4 * g + 3]);
+              dv_st16(p.out + ob + 8 * g, make_float4(vv[4 * g], vv[4 * g + 1], vv[4 * g + 2], vv[4 * g + 3]));
           }
           if (p.out_hi) store_planes16(p.out_hi, p.out_lo, ob - 4 * lh, lh, vv);
         } else {

@@ -366,7 +366,7 @@ __global__ __launch_bounds__((chain_pf_wave<NS, AMODE, XA, SA, CS>() ? NT_LAUNCH
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const int n = nf + 8 * g;
-        if (part == 0) *reinterpret_cast<float4*>(p.out1 + (size_t)m * C + n) = make_float4(vv[4 * g], vv[4 * g + 1], vv[4 * g + 2], vv[4 * g + 3]);
+        if (part == 0) dv_st16(p.out1 + (size_t)m * C + n, make_float4(vv[4 * g], vv[4 * g + 1], vv[4 * g + 2], vv[4 * g + 3]));
         uint2 hw, lw;
         hw.x = pk(vv[4 * g], vv[4 * g + 1]); hw.y = pk(vv[4 * g + 2], vv[4 * g + 3]);
         lw.x = pk(vv[4 * g] - __uint_as_float(hw.x << 16), vv[4 * g + 1] - __uint_as_float(hw.x & 0xffff0000u));
@@ -445,8 +445,8 @@ __global__ __launch_bounds__((chain_pf_wave<NS, AMODE, XA, SA, CS>() ? NT_LAUNCH
               lp[2 * gg + 1] = pk(x2 - __uint_as_float(h23 << 16), x3 - __uint_as_float(h23 & 0xffff0000u));
             }
             const size_t eo = ((((size_t)rb * (C / 32) + ns * 4 + wn) * 2 + kb) * 64 + lane) * 8;
-            *reinterpret_cast<uint4*>(p.sa_vf_hi + eo) = hw;
-            *reinterpret_cast<uint4*>(p.sa_vf_lo + eo) = lw;
+            dv_st16(p.sa_vf_hi + eo, hw);
+            dv_st16(p.sa_vf_lo + eo, lw);
           }
         }
       }
@@ -475,9 +475,9 @@ __global__ __launch_bounds__((chain_pf_wave<NS, AMODE, XA, SA, CS>() ? NT_LAUNCH
             lw.y = pk(o.z - __uint_as_float(hw.y << 16), o.w - __uint_as_float(hw.y & 0xffff0000u));
             const int nk = n - C;
             const size_t eo = (((size_t)rb * (C / 16) + (nk >> 4)) * 64 + (g & 1) * 32 + l31) * 8 + lh * 4;
-            *reinterpret_cast<uint2*>(p.sa_kf_hi + eo) = hw;
-            *reinterpret_cast<uint2*>(p.sa_kf_lo + eo) = lw;
-          } else if (!XA) *reinterpret_cast<float4*>(p.out2 + (size_t)m * p.ldo2 + n) = o;
+            dv_st8(p.sa_kf_hi + eo, hw);
+            dv_st8(p.sa_kf_lo + eo, lw);
+          } else if (!XA) dv_st16(p.out2 + (size_t)m * p.ldo2 + n, o);
           else {
             // the query of the cross attention stays in the workgroup: pre-scaled (d^-1/2 log2 e) split planes in the A
             // region (the planes of x1 are dead: every wave has left the stage-2 k-loop)
@@ -656,7 +656,7 @@ __global__ __launch_bounds__((chain_pf_wave<NS, AMODE, XA, SA, CS>() ? NT_LAUNCH
         }
 #pragma unroll
         for (int g = 0; g < 4; ++g)
-          *reinterpret_cast<float4*>(p.out3 + (size_t)m * C + nf + 8 * g) = make_float4(vv[4 * g], vv[4 * g + 1], vv[4 * g + 2], vv[4 * g + 3]);
+          dv_st16(p.out3 + (size_t)m * C + nf + 8 * g, make_float4(vv[4 * g], vv[4 * g + 1], vv[4 * g + 2], vv[4 * g + 3]));
         // split planes as 16-byte stores (lane pairs exchange halves: dv_device.h store_planes16)
         store_planes16(p.out3_hi, p.out3_lo, (size_t)m * C + nf - 4 * lh, lh, vv);
         float a = 0.f, q = 0.f;
@@ -891,7 +891,7 @@ __global__ __launch_bounds__(NT_LAUNCH) void k_chain_ff(const ChainFFParams p) {
     }
 #pragma unroll
     for (int g = 0; g < 4; ++g)
-      *reinterpret_cast<float4*>(p.out + (size_t)m * C + nf + 8 * g) = make_float4(vv[4 * g], vv[4 * g + 1], vv[4 * g + 2], vv[4 * g + 3]);
+      dv_st16(p.out + (size_t)m * C + nf + 8 * g, make_float4(vv[4 * g], vv[4 * g + 1], vv[4 * g + 2], vv[4 * g + 3]));
     if (p.out_hi) store_planes16(p.out_hi, p.out_lo, (size_t)m * C + nf - 4 * lh, lh, vv);   // 16-byte plane stores (dv_device.h)
     if (p.stats16) {
       float a1[2] = {0.f, 0.f}, a2[2] = {0.f, 0.f};
@@ -1058,7 +1058,7 @@ hipError_t launch_relayout_frag_cm(const bf16_t* src, bf16_t* dst, int rows, int
 
 bool chain2_supported(const ChainParams& p, int precision) {
   if (precision != 0) return false;                                  // split-bf16 mode only
-  if (p.C != 128 && p.C != 256 && p.C != 384) return false;   // (512 is instantiated; measured slower than one launch per GEMM)
+  if (p.C != 128 && p.C != 256 && p.C != 384) return false;   // (C = 512 was measured slower than one launch per GEMM; its instantiations were removed in round 3)
   if (p.M % 32 != 0 || p.T % 32 != 0 || p.M % p.T != 0 || p.passes < 1) return false;
   if (p.Kp1 != p.C || p.Kp2 != p.C) return false;
   if (p.xa_kf_hi) {                                                    // cross-attention tail: wave = head

@@ -168,12 +168,12 @@ __device__ __forceinline__ void gn_apply_body(const GnApplyParams& p, int rows_p
     uint2 h, l;
     split4(y, h, l);
     const size_t o = (row * ctot + c) >> 2;
-    reinterpret_cast<uint2*>(p.out_hi)[o] = h;
-    if (p.out_lo) reinterpret_cast<uint2*>(p.out_lo)[o] = l;
+    dv_st8(reinterpret_cast<uint2*>(p.out_hi) + o, h);
+    if (p.out_lo) dv_st8(reinterpret_cast<uint2*>(p.out_lo) + o, l);
     if (p.raw_hi) {
       split4(v, h, l);
-      reinterpret_cast<uint2*>(p.raw_hi)[o] = h;
-      if (p.raw_lo) reinterpret_cast<uint2*>(p.raw_lo)[o] = l;
+      dv_st8(reinterpret_cast<uint2*>(p.raw_hi) + o, h);
+      if (p.raw_lo) dv_st8(reinterpret_cast<uint2*>(p.raw_lo) + o, l);
     }
   }
 }

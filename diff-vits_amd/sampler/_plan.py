@@ -209,9 +209,6 @@ class Plan:
         return x
 
 
-# DVITS_HANDOVER_VERIFY=0: do not wait for a sampler run to drain in order to check its in-launch hand-overs (a time-out is
-# then only noticed - loudly - by the NEXT call on the engine, and the lost run is not repeated): measurement aid
-_VERIFY_HANDOVER = os.environ.get("DVITS_HANDOVER_VERIFY", "1") != "0"
 
 
 class NativeUNetModel:
@@ -228,14 +225,20 @@ class NativeUNetModel:
         return self.unet(sample, t_input, self.enc, encoder_attention_mask=self.mask).sample
 
     def run_plan(self, plan, x):
-        """hipGraph replay of the whole loop (dv_sampler_run).  Returns a new tensor."""
+        """hipGraph replay of the whole loop (dv_sampler_run).  Returns a new tensor.
+
+        Blocks the host until the run has drained while the engine's schedule uses in-launch GroupNorm hand-overs (the
+        default on a GPU the process has to itself): the hand-overs are verified before the result is returned and a lost
+        run is repeated.  Callers that overlap host work / another stream with the replay set
+        `unet.hip_engine().verify_handover = False` (or DVITS_HANDOVER_VERIFY=0): the run is then asynchronous, a time-out
+        is reported by the next call on the engine and the lost run is not repeated."""
         L = _lib()
         eng = self.unet.hip_engine()
         out = self._run_plan_once(plan, x, eng, L)
         # In-launch GroupNorm hand-overs need the device to themselves; on a shared GPU one may time out (bounded wait, flag in
         # host memory).  Checked once per RUN, after it has drained: the engine then drops to the separate-GroupNorm schedule
         # for good and the run is repeated on it - degraded, not dead (VERDICT r2 #6).
-        if _VERIFY_HANDOVER and eng.handover_active():
+        if eng.verify_handover and eng.handover_active():
             torch.cuda.current_stream().synchronize()
             if eng.recover_handover():
                 out = self._run_plan_once(plan, x, eng, L)
@@ -264,8 +267,8 @@ class NativeUNetModel:
         if cbuf is not None:
             cbuf.copy_(self.cond)
         plan = plan.for_shape((key, eng.handle.value))
-        L.check(L.lib().dv_sampler_run(plan.handle, eng.handle, L.ptr(xbuf), L.ptr(cbuf), L.stream_ptr()),
-                "dv_sampler_run")
+        eng.check_or_recover(L.lib().dv_sampler_run(plan.handle, eng.handle, L.ptr(xbuf), L.ptr(cbuf), L.stream_ptr()),
+                             "dv_sampler_run")
         return xbuf.clone()
 
 

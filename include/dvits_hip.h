@@ -244,6 +244,14 @@ int dv_op_conv1d(const float* x, const float* w, const float* bias, float* y, in
 /* y[M,N] = x[M,K] @ w[N,K]^T + bias */
 int dv_op_linear(const float* x, const float* w, const float* bias, float* y, int32_t M, int32_t K, int32_t N,
                  int32_t precision, void* stream);
+/* The same contraction with the result leaving the GEMM epilogue as split bf16 planes (hi = bf16(y), lo = bf16(y - hi);
+ * uint16 bit patterns, [M, ldo] each; y_lo ignored in bf16 mode) - the form every contraction of the denoiser hands to the
+ * next one - and optionally as fp32 y [M, ldo] as well (NULL: planes only).  Any N and any pitch ldo >= N are legal (the
+ * 16-byte plane stores of the epilogue are taken only when N and ldo are multiples of 8: tests/test_gpu_ops.py drives the
+ * other paths).  geglu = 1: w = [value rows | gate rows] (N = 2 x N_out, N % 64 == 0; reference unet1d/attention.py GEGLU),
+ * the planes receive N_out columns of value * gelu(gate), y must be NULL. */
+int dv_op_linear_planes(const float* x, const float* w, const float* bias, float* y, uint16_t* y_hi, uint16_t* y_lo, int32_t M,
+                        int32_t K, int32_t N, int32_t ldo, int32_t geglu, int32_t precision, void* stream);
 /* GroupNorm statistics over a channels-last tensor x[B*T, C]: mean/rstd [B, groups]. */
 int dv_op_group_stats(const float* x, float* mean, float* rstd, int32_t B, int32_t T, int32_t C, int32_t groups,
                       float eps, void* stream);

@@ -102,6 +102,79 @@ def test_linear(M, K, N):
     assert rel_l2(y.cpu().numpy(), ref.numpy()) < 1e-4
 
 
+def _split_planes(y):
+    """hi = bf16(y), lo = bf16(y - hi) as uint16 bit patterns (round to nearest even, like v_cvt_pk_bf16_f32)."""
+    t = torch.from_numpy(np.ascontiguousarray(y))
+    hi = t.to(torch.bfloat16)
+    lo = (t - hi.float()).to(torch.bfloat16)
+    return hi.view(torch.int16).numpy().view(np.uint16), lo.view(torch.int16).numpy().view(np.uint16)
+
+
+@pytest.mark.parametrize("M,K,N,ldo", [
+    # N % 8 != 0 and / or a plane row pitch that is not a multiple of 8 elements (16 bytes): the 16-byte plane stores of the
+    # epilogue (store_planes16 / store_planes8: lane-pair exchange, uint4 stores) must NOT be taken - VERDICT r3 #8: the
+    # alignment guard of commit 425603b had no test; before it these cases faulted or tore rows
+    (100, 64, 17, 17), (100, 64, 17, 19), (70, 128, 100, 100), (70, 128, 100, 104), (70, 128, 100, 108), (200, 64, 132, 132),
+    (200, 64, 132, 140), (129, 256, 128, 132), (129, 256, 128, 130), (64, 64, 64, 68),
+    # ... and the aligned shapes that DO take them (whole fragments, half-fragment epilogue of the two-k-group tiles)
+    (128, 256, 128, 128), (4096, 128, 256, 256), (300, 64, 96, 104), (2048, 384, 384, 384),
+])
+def test_linear_planes_any_pitch(M, K, N, ldo):
+    """Split-plane outputs of the GEMM epilogue at every alignment class of (N, pitch): bit-equal to the planes split on the
+    host from the SAME launch's fp32 output, the fp32 output equal to the plain fp32 launch, and not a byte written past a
+    row's N columns."""
+    L = _lib()
+    x, w, b = _synth("x", (M, K)), _synth("w", (N, K), 1 / np.sqrt(K)), _synth("b", (N,), 0.1)
+    dx, dw, db = _dev(x), _dev(w), _dev(b)
+    y0 = torch.empty((M, N), device="cuda")
+    L.check(L.lib().dv_op_linear(L.ptr(dx), L.ptr(dw), L.ptr(db), L.ptr(y0), M, K, N, 0, None), "dv_op_linear")
+    fill = 0x7fc1                                                     # a NaN pattern no result can take
+    for with_f32 in (True, False):
+        y = torch.full((M, ldo), float("nan"), device="cuda")
+        hi = torch.full((M, ldo), fill, dtype=torch.int32, device="cuda").to(torch.int16)
+        lo = hi.clone()
+        L.check(L.lib().dv_op_linear_planes(L.ptr(dx), L.ptr(dw), L.ptr(db), L.ptr(y) if with_f32 else None, L.ptr(hi), L.ptr(lo),
+                                            M, K, N, ldo, 0, 0, None), "dv_op_linear_planes")
+        torch.cuda.synchronize()
+        h = hi.cpu().numpy().view(np.uint16); l = lo.cpu().numpy().view(np.uint16)
+        ref = y0.cpu().numpy()
+        if with_f32:
+            yy = y.cpu().numpy()
+            assert np.array_equal(yy[:, :N], ref)                     # same tile, same summation order: bit-equal
+            assert np.isnan(yy[:, N:]).all()
+        rh, rl = _split_planes(ref)
+        assert np.array_equal(h[:, :N], rh), "hi plane differs at %s" % (np.argwhere(h[:, :N] != rh)[:4],)
+        assert np.array_equal(l[:, :N], rl), "lo plane differs at %s" % (np.argwhere(l[:, :N] != rl)[:4],)
+        assert (h[:, N:] == fill).all() and (l[:, N:] == fill).all(), "bytes written past a row's N columns"
+
+
+@pytest.mark.parametrize("M,K,No,ldo", [(96, 64, 96, 96), (96, 64, 96, 100), (200, 128, 160, 164), (130, 64, 32, 36), (4096, 256, 1024, 1024)])
+def test_linear_planes_geglu_any_pitch(M, K, No, ldo):
+    """GEGLU epilogue (value * gelu(gate), reference unet1d/attention.py GEGLU) -> split planes at aligned and unaligned
+    pitches, against the fp64 product split on the host (within the split-bf16 contraction's error) and, for the unaligned
+    pitches, bit-equal to the aligned launch's planes (the store path must not change a value)."""
+    L = _lib()
+    x, w, b = _synth("x", (M, K)), _synth("w", (2 * No, K), 1 / np.sqrt(K)), _synth("b", (2 * No,), 0.1)
+    dx, dw, db = _dev(x), _dev(w), _dev(b)
+    z = torch.from_numpy(x).double() @ torch.from_numpy(w).double().t() + torch.from_numpy(b).double()
+    ref = (z[:, :No] * F.gelu(z[:, No:])).numpy()
+    outs = {}
+    for pitch in sorted({No, ldo}):
+        hi = torch.full((M, pitch), 0x7fc1, dtype=torch.int32, device="cuda").to(torch.int16)
+        lo = hi.clone()
+        L.check(L.lib().dv_op_linear_planes(L.ptr(dx), L.ptr(dw), L.ptr(db), None, L.ptr(hi), L.ptr(lo), M, K, 2 * No, pitch, 1, 0, None),
+                "dv_op_linear_planes(geglu)")
+        torch.cuda.synchronize()
+        h = hi.cpu().numpy().view(np.uint16); l = lo.cpu().numpy().view(np.uint16)
+        assert (h[:, No:] == 0x7fc1).all() and (l[:, No:] == 0x7fc1).all()
+        val = (torch.from_numpy(h[:, :No].copy().view(np.int16)).view(torch.bfloat16).double()
+               + torch.from_numpy(l[:, :No].copy().view(np.int16)).view(torch.bfloat16).double()).numpy()
+        assert rel_l2(val, ref) < 3e-5
+        outs[pitch] = (h[:, :No].copy(), l[:, :No].copy())
+    if ldo != No:
+        assert np.array_equal(outs[No][0], outs[ldo][0]) and np.array_equal(outs[No][1], outs[ldo][1])
+
+
 @pytest.mark.parametrize("B,T,C,G", [(2, 40, 32, 8), (8, 1024, 128, 8), (2, 100, 896, 8), (3, 7, 1024, 8), (2, 300, 96, 8)])
 def test_group_stats(B, T, C, G):
     L = _lib()

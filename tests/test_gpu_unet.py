@@ -1114,6 +1114,41 @@ print("ok")
     assert "ok" in out
 
 
+def test_handover_timeout_in_a_module_level_forward_is_repeated_before_the_result_leaves():
+    """the eager path - `unet(sample, t, enc, ...)` of an unmodified reference caller, a Python-driven
+    solver loop, the bench's parity forward - used to hand a timed-out forward's garbage to the caller and notice at the NEXT
+    call.  Now the result is verified before it leaves the engine: forced time-out (DVITS_GNX_SPIN=-1) -> one warning, the
+    engine downgraded, and the very first forward already returns the fallback schedule's (right) tensor; a Python-driven
+    20-step loop (plan.run_python through `return_intermediate`) agrees with the undisturbed engine's."""
+    out = _handover_child(_HANDOVER_SETUP + r"""
+ref_m = build(exclusive=False)
+t = torch.full((B,), 500.0, device="cuda")
+with torch.no_grad():
+    ref = ref_m(torch.cat([x, cond], 1), t, enc, encoder_attention_mask=mask).sample
+    ref_loop = solver(ref_m).sample(x.clone(), steps=5, order=2, return_intermediate=True)[0]
+m = build()
+eng = m.hip_engine()
+with warnings.catch_warnings(record=True) as w, torch.no_grad():
+    warnings.simplefilter("always")
+    y = m(torch.cat([x, cond], 1), t, enc, encoder_attention_mask=mask).sample
+    y2 = m(torch.cat([x, cond], 1), t, enc, encoder_attention_mask=mask).sample
+torch.cuda.synchronize()
+msgs = [str(i.message) for i in w if "hand-over timed out" in str(i.message)]
+assert len(msgs) == 1, msgs
+assert eng.handover_downgraded and eng.handover_status() == (0, 0), eng.handover_status()
+assert torch.equal(y, ref) and torch.equal(y2, ref), float((y - ref).abs().max())
+m2 = build()
+with warnings.catch_warnings(record=True) as w2, torch.no_grad():
+    warnings.simplefilter("always")
+    loop = solver(m2).sample(x.clone(), steps=5, order=2, return_intermediate=True)[0]
+torch.cuda.synchronize()
+assert m2.hip_engine().handover_downgraded
+assert torch.equal(loop, ref_loop), float((loop - ref_loop).abs().max())
+print("ok")
+""", DVITS_GNX_SPIN="-1")
+    assert "ok" in out
+
+
 def test_default_engine_survives_a_competing_kernel_stream():
     """The same on a genuinely shared GPU: a loop of large matmuls on a side stream for the whole of a 20-step run of the
     DEFAULT engine (in-launch hand-overs on).  Whether or not a hand-over times out, the mel is right (bit-equal to the

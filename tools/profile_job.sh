@@ -4,7 +4,7 @@
 #   and the per-operation profile.  Usage (from the repo root, via gpurun):  bash tools/profile_job.sh <tag>
 set -u
 TAG=${1:-r03}
-GIT_HEAD=${2:-unknown}
+GIT_HEAD=${2:-$(git -C ${GRAFT_REPO_ROOT:-$PWD} rev-parse --short HEAD 2>/dev/null || echo unknown)}
 R=${GRAFT_REPO_ROOT:-$PWD}
 mkdir -p $R/gpurun_out
 cd /tmp && export TMPDIR=/tmp DVITS_NO_GRAPH=1

@@ -1,8 +1,8 @@
 #!/bin/bash
-# round-3: what the driver runs at round end - build check is local; here: the -m gpu suite, smoke(), the default bench line
+# what the driver runs at round end - build check is local; here: the -m gpu suite, smoke(), the default bench line
 set -u
 R=${GRAFT_REPO_ROOT:-$PWD}
-O=$R/gpurun_out/r3check
+O=$R/gpurun_out/${1:-check}
 mkdir -p $O
 cd $R
 timeout 2400 python -m pytest tests -x -q -m gpu > $O/pytest.log 2>&1; echo "pytest rc=$?" >> $O/pytest.log; tail -4 $O/pytest.log
