@@ -45,7 +45,7 @@ __device__ __forceinline__ void glds16_sc1(const void* gsrc, unsigned lds_dst) {
 __device__ __forceinline__ void st_handover16(float4* p, float4 v) {
   typedef float f32x4_t __attribute__((ext_vector_type(4)));
   const f32x4_t r = {v.x, v.y, v.z, v.w};
-  asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(r) : "memory");
+  asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" ::"v"(p), "v"(r) : "memory");   // (s_nop: store-data hazard, see dv_st16)
 }
 __device__ __forceinline__ float4 ld_handover16(const float4* p) {
   const unsigned long long* q = reinterpret_cast<const unsigned long long*>(p);
@@ -94,10 +94,10 @@ __device__ __forceinline__ void glds4_sc1(const void* gsrc, unsigned lds_dst) {
 // P_hi V_hi + P_hi V_lo) - experiment knob, see DESIGN.md
 #define DV_ATTN_PLO 1
 #endif
-// Bulk result stores (activations, planes, fragments) of the epilogues.  DV_WT_STORES=1: written THROUGH the XCD's L2
-// (`sc0 sc1`) - nothing of a tensor stays dirty in the L2 for the end-of-kernel write-back to flush (the L2 does not survive
-// the kernel boundary anyway: consumers read from the memory side).  tools/micro/overlap.hip: a chain of kernels that write
-// 8 MiB each takes 2.35 us per kernel with write-through stores against 2.95 us with plain ones.
+// Bulk result stores (activations, planes, fragments) of the epilogues: one place for their cache policy.  DV_WT_STORES=1
+// (experiment, round 4): written THROUGH the XCD's L2 (`sc0 sc1`), so that nothing of a tensor stays dirty for the
+// end-of-kernel write-back.  tools/micro/overlap.hip: a chain of kernels that only WRITE 8 MiB each takes 2.35 us per kernel
+// that way against 2.95 us - but in the forward it LOSES 3.4 % (profiles/r04_ab_write_through.txt): the default stays plain.
 #ifndef DV_WT_STORES
 #define DV_WT_STORES 0
 #endif
@@ -106,7 +106,9 @@ typedef unsigned dv_u32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void dv_st16(void* p, uint4 v) {
 #if DV_WT_STORES
   const dv_u32x4 r = {v.x, v.y, v.z, v.w};
-  asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(r) : "memory");
+  // (s_nop: a VMEM store of more than 64 bits reads its data registers late - a VALU write to them needs wait states the
+  // compiler's hazard recogniser inserts for its own stores but cannot see for one inside an asm block)
+  asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" ::"v"(p), "v"(r) : "memory");
 #else
   *reinterpret_cast<uint4*>(p) = v;
 #endif
