@@ -118,6 +118,7 @@ __device__ __forceinline__ void attn_tile(const AttnParams& p, const int qblk, c
   constexpr bool GEO_REGS = KPW <= 4;
   const float* dma_src[GEO_REGS ? KPW : 1];
   int dma_row[GEO_REGS ? KPW : 1], dma_ld[GEO_REGS ? KPW : 1];
+  const int tk_pitch = p.Tk_pitch > 0 ? p.Tk_pitch : p.Tk;   // key rows per utterance in k / v (padded row spaces: > Tk)
   auto dma_geo = [&](int j, const float*& base, int& row, int& ld) {
     const int task = (wave + j * NW) * 64 + lane;
     const int which = task / (32 * CPR), rem = task - which * (32 * CPR);
@@ -125,7 +126,7 @@ __device__ __forceinline__ void attn_tile(const AttnParams& p, const int qblk, c
     const int c4 = (rem - row * CPR) * 4;
     const int cc = c4 < d ? c4 : 0;
     ld = which ? p.ldv : p.ldk;
-    base = (which ? p.v + (size_t)b * p.Tk * p.ldv : p.k + (size_t)b * p.Tk * p.ldk) + h * d + cc;
+    base = (which ? p.v + (size_t)b * tk_pitch * p.ldv : p.k + (size_t)b * tk_pitch * p.ldk) + h * d + cc;
   };
   if (GEO_REGS) {
 #pragma unroll

@@ -47,6 +47,13 @@ struct GemmParams {
   GemmSeg seg[2];
   int nseg;
   int B, T_out, T_in, T_virt;   // T_virt: length after the (virtual) nearest upsample
+  // Utterances whose length is not a multiple of 32 (the real inference call: any T) live in a row space PADDED to whole
+  // 32-frame blocks per level, so that the row-block kernels, the 32x16 block statistics and the in-epilogue GroupNorm run
+  // for any T: T_out / T_in are then the row PITCH per utterance (frames incl. padding: row m = b * T_out + t) and Tv_out /
+  // Tv_in the frames that exist (0: same as the pitch).  Padding rows are excluded everywhere a frame count enters: a conv
+  // tap that lands on one reads zeros (T_virt bounds the gather), their outputs are written as zeros, the block statistics
+  // of an utterance's last block cover its valid rows only, self-attention masks them as keys.
+  int Tv_out, Tv_in;
   int stride;
   int up_mode;                  // UP_*
   float up_scale;               // UP_SIZE: (float)T_in / T_virt, as ATen computes it
@@ -123,7 +130,8 @@ inline size_t gemm_splitk_bytes(int M, int N, int split) {
 // row-block (amode 1: norm -> proj_in -> LN -> to_q/to_k/to_v, transformer_1d.py:264-268 + attention.py:157-160).
 // ---------------------------------------------------------------------------------------
 struct ChainParams {
-  int M, C, T;                   // rows (= B * T, T % 32 == 0), channels (128, 256, 384 or 512)
+  int M, C, T;                   // rows (= B * T, T % 32 == 0: the row pitch per utterance), channels (128, 256, 384 or 512)
+  int Tv;                        // frames that exist per utterance (0: T); amode 1: the GroupNorm statistics cover these only
   int amode;
   const bf16_t* a_hi; const bf16_t* a_lo;                       // amode 0: [M, C] planes
   const float* x; const float* stat16;                          // amode 1: fp32 [M, C] and its 32x16-block statistics
@@ -164,7 +172,8 @@ struct ChainParams {
 // planes) -> merged ff.net.2 + proj_out over [h3 | product] (K = 5C) + bias + block residual -> fp32 output + 32x16
 // GroupNorm block statistics (+ split planes).  Reference attention.py:189-203 + transformer_1d.py:300-326.
 struct ChainFFParams {
-  int M, C, T;                                    // rows (T % 32 == 0), C = 128
+  int M, C, T;                                    // rows (T % 32 == 0: row pitch per utterance), C = 128
+  int Tv;                                         // frames that exist per utterance (0: T): the output statistics cover these only
   const bf16_t* a_hi; const bf16_t* a_lo;         // raw split planes of h3 [M, C]
   const float* rowstat; float ln_eps;             // LayerNorm row partials of h3 [M, C/32, 2]
   const bf16_t* wg_hi; const bf16_t* wg_lo; const float* bg; const float* ug;   // GEGLU [8C][Kp = C] fragment-major (gamma folded), bias', u
@@ -196,6 +205,7 @@ struct AttnParams {
   bf16_t* o_hi; bf16_t* o_lo;   // split-plane output (consumed by the to_out GEMM) or null
   int ldq, ldk, ldv, ldo;       // row strides (floats); head h occupies columns [h*d, h*d+d)
   int B, H, Tq, Tk, d;
+  int Tk_pitch;                 // key rows per utterance in k / v (0: Tk) - padded row spaces: keys [Tk, Tk_pitch) do not exist
   float scale;
   int nsplit;                   // 3: split-bf16 (hi*hi + lo*hi + hi*lo), 1: single bf16 product
   int no_xcd_map;               // internal (launcher): 1 = plain block order (DVITS_ATTN_XCD=0, experiments)
@@ -244,9 +254,10 @@ hipError_t launch_attention(const AttnParams& p, hipStream_t st);
 
 // misc kernels (kernels_misc.hip)
 // (B,C,T) x | cond -> channels-last split planes [B*T, cpad] (zero padded)
+// (Tp >= T: row pitch per utterance of the planes, rows [T, Tp) zero)
 hipError_t launch_pack_input(const float* x, int cx, const float* cond, int cc, bf16_t* out_hi, bf16_t* out_lo, int cpad,
                              int B, int T, hipStream_t st,
-                             unsigned long long* reset = nullptr, size_t reset_words = 0);   // (+ the GnxParams exchange words set to all ones)
+                             unsigned long long* reset = nullptr, size_t reset_words = 0, int Tp = 0);   // (+ the GnxParams exchange words set to all ones)
 // fp32 [n] -> split planes
 hipError_t launch_split(const float* in, bf16_t* hi, bf16_t* lo, int64_t n, hipStream_t st);
 // GroupNorm (+temb scale/shift) (+SiLU) of the channel concat [a0 | a1] -> split planes [B*T, c0+c1].
@@ -264,7 +275,8 @@ struct GnApplyParams {
   const float* tscale; const float* tshift; int ld_t;
   int silu;
   bf16_t* out_hi; bf16_t* out_lo; bf16_t* raw_hi; bf16_t* raw_lo;
-  int B, T;
+  int B, T;            // T: row pitch per utterance (frames incl. padding)
+  int Tv;              // frames that exist (0: T) - the statistics of the last 32-row block cover these only
 };
 hipError_t launch_gn_apply(const GnApplyParams& p, hipStream_t st);
 

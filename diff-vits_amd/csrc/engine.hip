@@ -138,8 +138,9 @@ struct PackedW {
   int Kp = 0, N = 0, N_pad = 0;
 };
 
-struct Act {   // channels-last fp32 [B*T, C] (+ GN statistics) (+ split planes when the consumer is a resampling conv)
-  float* p = nullptr; int C = 0, T = 0;
+struct Act {   // channels-last fp32 [B*Tp, C] (+ GN statistics) (+ split planes when the consumer is a resampling conv)
+  float* p = nullptr; int C = 0, T = 0;   // T: frames that exist per utterance
+  int Tp = 0;                 // row pitch per utterance (Builder::pitch: T, or T rounded up to whole 32-frame blocks - GemmParams Tv_out)
   float* stat = nullptr;      // per-column slab [B*T/32, C, 2] (consumer: k_gn_apply), or
   float* stat16 = nullptr;    // per 32x16-block statistics [B*T/32, C/16, 2] (consumer: a conv that normalises its own operand)
   bf16_t* pl_hi = nullptr; bf16_t* pl_lo = nullptr;
@@ -150,7 +151,7 @@ struct Act {   // channels-last fp32 [B*T, C] (+ GN statistics) (+ split planes 
 
 typedef std::function<hipError_t(hipStream_t)> OpFn;
 
-struct Probe { std::string name; float* p; int T, C; };
+struct Probe { std::string name; float* p; int T, C, Tp; };
 
 struct dv_unet {
   dv_unet_cfg cfg{};
@@ -423,7 +424,7 @@ struct Builder {
     return true;
   }
   void probe(const std::string& name, const float* p, int T_, int C_) {
-    if (!dry && u->keep_intermediates) u->probes.push_back(Probe{name, const_cast<float*>(p), T_, C_});
+    if (!dry && u->keep_intermediates) u->probes.push_back(Probe{name, const_cast<float*>(p), T_, C_, T_ > 1 ? pitch(T_) : T_});
   }
 
   // ---- weight packing (only in the real pass; device work on pack_stream)
@@ -507,15 +508,23 @@ struct Builder {
   // DVITS_FUSE_GN=1): parity-green but slower - an N-tiled conv repeats the elementwise GroupNorm + SiLU + hi/lo split of its
   // rows in every 64-column tile - and removed in round 3; DESIGN.md section 4 keeps the measurements.]
   void alloc_stat(Act& a, bool want16 = false) {
-    // 32-row blocks of the flat [B*T] row space must not span utterances: T % 32 == 0, or ONE utterance (its last block is
-    // partial: rows beyond M contribute zeros) - the single-utterance case is the real inference call (B = 1, any T)
-    if (a.T % 32 != 0) {
-      if (B == 1) a.stat = alloc((size_t)((a.T + 31) / 32) * a.C * 2);
+    // 32-row blocks of the flat [B*Tp] row space must not span utterances: Tp % 32 == 0 (the padded row space of pitch()
+    // makes that so for any T), or ONE utterance whose last block is partial (rows beyond M contribute zeros: the per-column
+    // slab of configurations without whole 16-channel blocks per group)
+    if (a.Tp % 32 != 0) {
+      if (B == 1) a.stat = alloc((size_t)((a.Tp + 31) / 32) * a.C * 2);
       return;
     }
-    if (want16 || stat16_everywhere()) a.stat16 = alloc((size_t)(B * a.T / 32) * (a.C / 16) * 2);
-    else a.stat = alloc((size_t)(B * a.T / 32) * a.C * 2);
+    if (want16 || stat16_everywhere()) a.stat16 = alloc((size_t)(B * a.Tp / 32) * (a.C / 16) * 2);
+    else a.stat = alloc((size_t)(B * a.Tp / 32) * a.C * 2);
   }
+  // Row pitch per utterance of a level with Tl frames.  Real utterances have any length (reference tts_infer.py:46-74,
+  // resnet.py:157-160: T is arbitrary): wherever the fused schedule can run at all (32x16 block statistics at every level,
+  // no exact-size arena) every level is padded to whole 32-frame blocks INSIDE the engine - the row-block chains, the block
+  // statistics and the in-epilogue GroupNorm then run for any T and any B; the padding rows are kept out of every frame
+  // count (GemmParams Tv_out).  DVITS_PAD_T=0 restores the unpadded row space (general-shape GroupNorm kernels, no chains).
+  bool pad_on = [] { const char* e = getenv("DVITS_PAD_T"); return !(e && e[0] == '0'); }();
+  int pitch(int Tl) const { return (pad_on && Tl % 32 != 0 && stat16_everywhere()) ? rup(Tl, 32) : Tl; }
   // every level has whole 16-channel blocks per GroupNorm group: all tensors carry block statistics (16x fewer entries
   // for k_gn_apply to reduce, cheaper producer epilogue); otherwise (tiny / duration-predictor configurations) per-column slabs
   bool stat16_everywhere() const {
@@ -704,12 +713,12 @@ struct Builder {
   // General path (T % 32 != 0): k_gn_partial + k_gn_finalize build the per-(b,c) affine first.
   Planes norm_apply(std::vector<OpFn>& ops, Act a0, Act a1, const std::string& pre, float eps, const float* tscale,
                     const float* tshift, int ld_t, bool silu, Planes* raw_out) {
-    const int G = u->cfg.norm_num_groups, C = a0.C + a1.C, Tn = a0.T;
+    const int G = u->cfg.norm_num_groups, C = a0.C + a1.C, Tn = a0.T, Tp = a0.Tp;
     GnApplyParams gp{};
     gp.a0 = a0.p; gp.a1 = a1.p; gp.c0 = a0.C; gp.c1 = a1.C;
     gp.gamma = W(pre + ".weight"); gp.beta = W(pre + ".bias"); gp.eps = eps; gp.groups = G;
     gp.tscale = tscale; gp.tshift = tshift; gp.ld_t = ld_t; gp.silu = silu ? 1 : 0;
-    gp.B = B; gp.T = Tn;
+    gp.B = B; gp.T = Tp; gp.Tv = Tn;
     float* sc = nullptr; float* sh = nullptr;
     const bool fast16 = a0.stat16 && (a1.C == 0 || a1.stat16) && ((a0.C + a1.C) / G) % 16 == 0 && a0.C % 16 == 0;
     const bool fast = fast16 || (a0.stat && (a1.C == 0 || a1.stat));
@@ -736,9 +745,9 @@ struct Builder {
       release(part);
       gp.scale_in = sc; gp.shift_in = sh;
     }
-    Planes out = alloc_planes((size_t)B * Tn * C);
+    Planes out = alloc_planes((size_t)B * Tp * C);
     gp.out_hi = out.hi; gp.out_lo = out.lo;
-    if (raw_out) { *raw_out = alloc_planes((size_t)B * Tn * C); gp.raw_hi = raw_out->hi; gp.raw_lo = raw_out->lo; }
+    if (raw_out) { *raw_out = alloc_planes((size_t)B * Tp * C); gp.raw_hi = raw_out->hi; gp.raw_lo = raw_out->lo; }
     cur_kind = "gn_apply";
     {
       char buf[96];
@@ -748,9 +757,9 @@ struct Builder {
     PersistOp po{};
     if (fast) {
       po.type = POP_GN; po.gn = gp;
-      po.gn_chunks = std::max(1, std::min(Tn / 4, 64 / G));
-      po.gn_rpb = (Tn + po.gn_chunks - 1) / po.gn_chunks;
-      po.gn_chunks = (Tn + po.gn_rpb - 1) / po.gn_rpb;
+      po.gn_chunks = std::max(1, std::min(Tp / 4, 64 / G));
+      po.gn_rpb = (Tp + po.gn_chunks - 1) / po.gn_chunks;
+      po.gn_chunks = (Tp + po.gn_rpb - 1) / po.gn_rpb;
     }
     {
       dv_unet* uu = u;
@@ -782,10 +791,17 @@ struct Builder {
     return out;
   }
 
+  // GEMM over a level of Tn frames per utterance: row pitch pitch(Tn) (M = B * pitch), Tn of them exist
   GemmParams gp_base(int Tn, int M, int N) {
     GemmParams g{};
-    g.nseg = 1; g.T_out = g.T_in = g.T_virt = Tn; g.stride = 1; g.up_mode = UP_NONE;
+    g.nseg = 1; g.T_out = g.T_in = pitch(Tn); g.Tv_out = g.Tv_in = g.T_virt = Tn; g.stride = 1; g.up_mode = UP_NONE;
     g.M = M; g.N = N; g.epi = EPI_STORE; g.ldo = N; g.ldres = N;
+    return g;
+  }
+  // ... over a plain row space of `rows` rows per item (conditioning schedule, prompt encoder: nothing is padded there)
+  GemmParams gp_rows(int rows, int M, int N) {
+    GemmParams g = gp_base(rows, M, N);
+    g.T_out = g.T_in = rows;
     return g;
   }
 
@@ -798,14 +814,14 @@ struct Builder {
   // shortcut as a second K-segment | + identity residual)
   Act resnet(std::vector<OpFn>& ops, const std::string& p, Act x0, Act x1, int cout, bool want_planes = false,
              bool stat16_out = false) {
-    const int cin = x0.C + x1.C, Tn = x0.T, M = B * Tn;
+    const int cin = x0.C + x1.C, Tn = x0.T, Tp = x0.Tp, M = B * Tp;
     const float eps = u->cfg.norm_eps;
     const bool shortcut = has(p + "conv_shortcut.weight");
     const PackedW* w1 = pack(p + "conv1", cout, 3 * cin, {{p + "conv1.weight", 1, cin, 3, cin, 0, 0, "", 0}},
                              {{p + "conv1.bias", "", "", "", cout, 0, 0, 0}});
     if (!w1) return Act{};
     Act h{};
-    h.p = alloc((size_t)M * cout); h.C = cout; h.T = Tn; alloc_stat(h);
+    h.p = alloc((size_t)M * cout); h.C = cout; h.T = Tn; h.Tp = Tp; alloc_stat(h);
     Planes raw;
     bool raw_made = false;
     const int toff = tproj_off[p];
@@ -840,7 +856,7 @@ struct Builder {
     const PackedW* w2 = pack(p + "conv2", cout, K2, pcs, bps);
     if (!w2) return Act{};
     Act out{};
-    out.p = alloc((size_t)M * cout); out.C = cout; out.T = Tn; alloc_stat(out, stat16_out);   // (its consumer is a chain)
+    out.p = alloc((size_t)M * cout); out.C = cout; out.T = Tn; out.Tp = Tp; alloc_stat(out, stat16_out);   // (its consumer is a chain)
     {
       GemmParams g = gp_base(Tn, M, cout);
       if (!shortcut) { g.epi = EPI_RESIDUAL; g.res = x0.p; g.ldres = cout; }
@@ -880,9 +896,10 @@ struct Builder {
   }
 
   Planes attention(std::vector<OpFn>& ops, const float* q, int ldq, const float* k, const float* v, int ldkv, const float* bias,
-                   int Tq, int Tk, int C) {
+                   int Tq, int Tk, int C, int Tk_pitch = 0) {
     Planes o = alloc_planes((size_t)B * Tq * C);
     AttnParams a{};
+    a.Tk_pitch = Tk_pitch;
     a.q = q; a.k = k; a.v = v; a.bias = bias; a.o = nullptr; a.o_hi = o.hi; a.o_lo = o.lo;
     a.ldq = ldq; a.ldk = ldkv; a.ldv = ldkv; a.ldo = C;
     a.B = B; a.H = u->cfg.num_heads; a.Tq = Tq; a.Tk = Tk; a.d = C / u->cfg.num_heads;
@@ -935,7 +952,7 @@ struct Builder {
 
   // Transformer2DModel + BasicTransformerBlock (reference transformer_1d.py:191-326, attention.py:130-203)
   Act transformer(std::vector<OpFn>& ops, const std::string& p, Act x, bool want_planes = false) {
-    const int C = x.C, Tn = x.T, M = B * Tn, D = u->cfg.cross_attention_dim;
+    const int C = x.C, Tn = x.T, Tp = x.Tp, M = B * Tp, D = u->cfg.cross_attention_dim;
     const std::string tb = p + "transformer_blocks.0.";
     const PackedW* w_in = pack(p + "proj_in", C, C, {{p + "proj_in.weight", 1, C, 1, C, 0, 0, "", 0}},
                                {{p + "proj_in.bias", "", "", "", C, 0, 0, 0}});
@@ -983,7 +1000,7 @@ struct Builder {
     };
     auto ln_release = [&](LnIn& in) { release(in.pl); if (in.stat) release(in.stat); };
 
-    const bool chained = chain_ok(Tn, C) && x.stat16;
+    const bool chained = chain_ok(Tp, C) && x.stat16;
     float* h3 = nullptr;
     LnIn l3;
     if (chained && !(frag(w_in) && frag(w_qkv) && frag(w_o1) && frag(w_q2))) return Act{};
@@ -999,7 +1016,7 @@ struct Builder {
       if (sa_frag) { kf = alloc_planes((size_t)M * C); vf = alloc_planes((size_t)M * C); }
       {
         ChainParams cp{};
-        cp.M = M; cp.C = C; cp.T = Tn; cp.amode = 1;
+        cp.M = M; cp.C = C; cp.T = Tp; cp.Tv = Tn; cp.amode = 1;
         cp.x = x.p; cp.stat16 = x.stat16; cp.gamma = W(p + "norm.weight"); cp.beta = W(p + "norm.bias"); cp.gn_eps = 1e-6f;
         cp.groups = u->cfg.norm_num_groups;
         cp.w1_hi = w_in->fhi; cp.w1_lo = w_in->flo; cp.Kp1 = w_in->Kp; cp.b1 = w_in->bias; cp.res = nullptr; cp.out1 = h;
@@ -1020,15 +1037,15 @@ struct Builder {
         AttnFragParams a{};
         a.q = qkv; a.ldq = C;
         a.kf_hi = kf.hi; a.kf_lo = kf.lo; a.vf_hi = vf.hi; a.vf_lo = vf.lo;
-        const int nT = Tn / 32;
+        const int nT = Tp / 32;
         a.k_b = nT * (C / 16); a.k_h = dh / 16; a.k_t = C / 16;
         a.v_b = nT * (C / 32) * 2; a.v_h = 0; a.v_t = (C / 32) * 2; a.v_kb = 1; a.v_nb = 2; a.self_layout = 1;
         a.bias = nullptr; a.bias_ld = 0;
-        ao = attention_frag(ops, a, Tn, Tn, C);
+        ao = attention_frag(ops, a, Tp, Tn, C);       // (queries: every row of the padded space; keys: the frames that exist)
         release(kf); release(vf);
-      } else ao = attention(ops, qkv, 3 * C, qkv + C, qkv + 2 * C, 3 * C, nullptr, Tn, Tn, C);
+      } else ao = attention(ops, qkv, 3 * C, qkv + C, qkv + 2 * C, 3 * C, nullptr, Tp, Tn, C, Tp);
       release(qkv);
-      if (xa_ok(Tn, C) && cross_frag.count(p)) {
+      if (xa_ok(Tp, C) && cross_frag.count(p)) {
         // chain 2 with the cross attention inside: to_out + residual -> LN2 -> to_q -> cross attention (wave = head, K / V
         // of the prompt as hoisted MFMA fragments) -> to_out + residual -> LN3 partials   (4 launches -> 1)
         if (!frag(w_o2)) return Act{};
@@ -1040,7 +1057,7 @@ struct Builder {
         {
           const XFrag& xf = cross_frag[p];
           ChainParams cp{};
-          cp.M = M; cp.C = C; cp.T = Tn; cp.amode = 0;
+          cp.M = M; cp.C = C; cp.T = Tp; cp.Tv = Tn; cp.amode = 0;
           cp.a_hi = ao.hi; cp.a_lo = ao.lo;
           cp.w1_hi = w_o1->fhi; cp.w1_lo = w_o1->flo; cp.Kp1 = w_o1->Kp; cp.b1 = w_o1->bias; cp.res = h; cp.out1 = h2;
           cp.w2_hi = w_q2->fhi; cp.w2_lo = w_q2->flo; cp.Kp2 = w_q2->Kp; cp.b2 = w_q2->bias; cp.u2 = w_q2->u;
@@ -1051,7 +1068,7 @@ struct Builder {
           cp.w3_hi = w_o2->fhi; cp.w3_lo = w_o2->flo; cp.b3 = w_o2->bias;
           cp.out3 = h3; cp.out3_hi = l3.pl.hi; cp.out3_lo = l3.pl.lo; cp.rowstat3 = l3.stat;
           chain(ops, cp, "to_out+res+LN+to_q+xattn+to_out+res");
-          if (!dry) { u->flops += 4.0 * B * u->cfg.num_heads * (double)Tn * L * cp.xa_d + 2.0 * (double)M * C * C; }
+          if (!dry) { u->flops += 4.0 * B * u->cfg.num_heads * (double)Tp * L * cp.xa_d + 2.0 * (double)M * C * C; }
         }
         release(ao); release(h);
         probe(tb + "attn1", h2, Tn, C);
@@ -1063,7 +1080,7 @@ struct Builder {
       float* q2 = alloc((size_t)M * C);
       {
         ChainParams cp{};
-        cp.M = M; cp.C = C; cp.T = Tn; cp.amode = 0;
+        cp.M = M; cp.C = C; cp.T = Tp; cp.Tv = Tn; cp.amode = 0;
         cp.a_hi = ao.hi; cp.a_lo = ao.lo;
         cp.w1_hi = w_o1->fhi; cp.w1_lo = w_o1->flo; cp.Kp1 = w_o1->Kp; cp.b1 = w_o1->bias; cp.res = h; cp.out1 = h2;
         cp.w2_hi = w_q2->fhi; cp.w2_lo = w_q2->flo; cp.Kp2 = w_q2->Kp; cp.b2 = w_q2->bias; cp.u2 = w_q2->u;
@@ -1079,8 +1096,8 @@ struct Builder {
       release(ao); release(h);
       probe(tb + "attn1", h2, Tn, C);
       float* kv = cross_kv[p];
-      if (attn_frag_on && !arena.exact && cross_frag.count(p)) ao = cross_attention_frag(ops, p, q2, Tn, C);
-      else ao = attention(ops, q2, C, kv, kv + C, 2 * C, mask_bias, Tn, L, C);
+      if (attn_frag_on && !arena.exact && cross_frag.count(p)) ao = cross_attention_frag(ops, p, q2, Tp, C);
+      else ao = attention(ops, q2, C, kv, kv + C, 2 * C, mask_bias, Tp, L, C);
       release(q2);
       h3 = alloc((size_t)M * C);
       {
@@ -1114,7 +1131,7 @@ struct Builder {
       g.out = qkv; ln_consume(g, l1, h, w_qkv); gemm(ops, g, w_qkv, C);
     }
     ln_release(l1);
-    Planes ao = attention(ops, qkv, 3 * C, qkv + C, qkv + 2 * C, 3 * C, nullptr, Tn, Tn, C);
+    Planes ao = attention(ops, qkv, 3 * C, qkv + C, qkv + 2 * C, 3 * C, nullptr, Tp, Tn, C, Tp);   // (keys: the frames that exist)
     release(qkv);
     float* h2 = alloc((size_t)M * C);
     LnIn l2;
@@ -1134,8 +1151,8 @@ struct Builder {
     }
     ln_release(l2);
     float* kv = cross_kv[p];
-    if (attn_frag_on && !arena.exact && cross_frag.count(p)) ao = cross_attention_frag(ops, p, q2, Tn, C);
-    else ao = attention(ops, q2, C, kv, kv + C, 2 * C, mask_bias, Tn, L, C);
+    if (attn_frag_on && !arena.exact && cross_frag.count(p)) ao = cross_attention_frag(ops, p, q2, Tp, C);
+    else ao = attention(ops, q2, C, kv, kv + C, 2 * C, mask_bias, Tp, L, C);
     release(q2);
     h3 = alloc((size_t)M * C);
     {
@@ -1153,7 +1170,7 @@ struct Builder {
       const char* eff = getenv("DVITS_CHAIN_FF");
       const bool ff_off = eff && eff[0] == '0';
       ChainFFParams fp{};
-      fp.M = M; fp.C = C; fp.T = Tn;
+      fp.M = M; fp.C = C; fp.T = Tp; fp.Tv = Tn;
       if (!ff_off && merged_ffproj && chain_on && !arena.exact && l3.stat && x.stat16 && chain_ff_supported(fp, prec)) {
         const std::string mw = tb + "__ffproj.weight", mb = tb + "__ffproj.bias";
         if (!dry && !u->packed.count(p + "ffproj")) {
@@ -1169,7 +1186,7 @@ struct Builder {
                                   {{mb, "", "", "", C, 0, 0, 0}});
         if (!w_m || !frag(w_gg) || !frag(w_m)) return Act{};
         Act out{};
-        out.p = alloc((size_t)M * C); out.C = C; out.T = Tn; alloc_stat(out, true);
+        out.p = alloc((size_t)M * C); out.C = C; out.T = Tn; out.Tp = Tp; alloc_stat(out, true);
         fp.a_hi = l3.pl.hi; fp.a_lo = l3.pl.lo; fp.rowstat = l3.stat; fp.ln_eps = 1e-5f;
         fp.wg_hi = w_gg->fhi; fp.wg_lo = w_gg->flo; fp.bg = w_gg->bias; fp.ug = w_gg->u;
         fp.wm_hi = w_m->fhi; fp.wm_lo = w_m->flo; fp.bm = w_m->bias;
@@ -1219,7 +1236,7 @@ struct Builder {
                                 {{mb, "", "", "", C, 0, 0, 0}});
       if (!w_m) return Act{};
       Act out{};
-      out.p = alloc((size_t)M * C); out.C = C; out.T = Tn; alloc_stat(out);
+      out.p = alloc((size_t)M * C); out.C = C; out.T = Tn; out.Tp = Tp; alloc_stat(out);
       {
         GemmParams g = gp_base(Tn, M, C);
         g.seg[0] = seg(l3.pl, C, Planes{}, 0, 1, 0);
@@ -1248,7 +1265,7 @@ struct Builder {
     if (h4f) probe(tb + "ff", h4f, Tn, C);
 
     Act out{};
-    out.p = alloc((size_t)M * C); out.C = C; out.T = Tn; alloc_stat(out);
+    out.p = alloc((size_t)M * C); out.C = C; out.T = Tn; out.Tp = Tp; alloc_stat(out);
     {
       GemmParams g = gp_base(Tn, M, C); g.seg[0] = seg(h4, C, Planes{}, 0, 1, 0);
       g.epi = EPI_RESIDUAL; g.res = x.p; g.out = out.p; stat_out(g, out);
@@ -1273,23 +1290,25 @@ struct Builder {
     if (!w) return Act{};
     Planes xs;
     if (x.pl_hi) { xs.hi = x.pl_hi; xs.lo = x.pl_lo; }
-    else xs = split(ops, x.p, (size_t)B * x.T * C);
+    else xs = split(ops, x.p, (size_t)B * x.Tp * C);
     GemmParams g = gp_base(x.T, 0, C);
     g.seg[0] = seg(xs, C, Planes{}, 0, 3, 1);
-    g.T_in = x.T;
-    if (down) { g.T_virt = x.T; g.stride = 2; g.up_mode = UP_NONE; g.T_out = (x.T + 2 - 3) / 2 + 1; }
+    g.T_in = x.Tp; g.Tv_in = x.T;
+    int T_new;                                           // frames of the result that exist
+    if (down) { g.T_virt = x.T; g.stride = 2; g.up_mode = UP_NONE; T_new = (x.T + 2 - 3) / 2 + 1; }
     else {
-      g.stride = 1; g.T_out = g.T_virt = T_target;
+      g.stride = 1; T_new = g.T_virt = T_target;
       if (u->force_up) { g.up_mode = UP_SIZE; g.up_scale = (float)x.T / (float)T_target; }
       else g.up_mode = UP_X2;
     }
+    g.Tv_out = T_new; g.T_out = pitch(T_new);
     Act out{};
-    out.p = alloc((size_t)B * g.T_out * C); out.C = C; out.T = g.T_out; alloc_stat(out);
+    out.p = alloc((size_t)B * g.T_out * C); out.C = C; out.T = T_new; out.Tp = g.T_out; alloc_stat(out);
     g.M = B * g.T_out; g.out = out.p; stat_out(g, out);
     offer_next(g, out);
     gemm(ops, g, w, 3 * C);
     release(xs);
-    probe(p.substr(0, p.size() - 1), out.p, g.T_out, C);
+    probe(p.substr(0, p.size() - 1), out.p, T_new, C);
     return out;
   }
 
@@ -1373,7 +1392,7 @@ struct Builder {
       xbias = alloc((size_t)B * nT * 32);
       int lvl_T = T;
       std::map<int, int> T_of_C;   // frames at the level of each channel count (the transformer of C runs at T_l)
-      for (int i = 0; i < n; ++i) { T_of_C[c.block_out_channels[i]] = lvl_T; lvl_T = (lvl_T + 2 - 3) / 2 + 1; }
+      for (int i = 0; i < n; ++i) { T_of_C[c.block_out_channels[i]] = pitch(lvl_T); lvl_T = (lvl_T + 2 - 3) / 2 + 1; }
       for (auto& x : xformers) {
         const int C = x.second;
         // fragments feed the in-chain cross attention (xa_ok) or k_attention_frag (any block with 16-channel head groups)
@@ -1409,7 +1428,7 @@ struct Builder {
       Planes seqs = split(K, seq, (size_t)B * (L + 1) * D);
       float* kvp = alloc((size_t)B * (L + 1) * 2 * D);
       {
-        GemmParams g = gp_base(L + 1, B * (L + 1), 2 * D);
+        GemmParams g = gp_rows(L + 1, B * (L + 1), 2 * D);
         g.seg[0] = seg(seqs, D, Planes{}, 0, 1, 0);
         g.out = kvp;
         gemm(K, g, wkv, D);
@@ -1435,7 +1454,7 @@ struct Builder {
         const PackedW* w = pack(tb + "kv2", 2 * C, D,
                                 {{tb + "attn2.to_k.weight", 0, D, 1, D, 0, 0, "", 0}, {tb + "attn2.to_v.weight", 0, D, 1, D, 0, C, "", 0}}, {});
         if (!w) return dv_fail(DV_ERR_MISSING_WEIGHT, "%s", err.c_str());
-        GemmParams g = gp_base(L, B * L, 2 * C);
+        GemmParams g = gp_rows(L, B * L, 2 * C);
         g.seg[0] = seg(encs, D, Planes{}, 0, 1, 0);
         g.out = cross_kv[x.first];
         gemm(K, g, w, D);
@@ -1500,18 +1519,19 @@ struct Builder {
       probe("emb", emb, 1, E);
     }
     const int cin = c.in_channels, cpad = rup(cin, 32);
-    Planes xin = alloc_planes((size_t)B * T * cpad);
+    const int Tp0 = pitch(T);                            // row pitch of the first level (padding rows: zeros)
+    Planes xin = alloc_planes((size_t)B * Tp0 * cpad);
     emit(S, [=](hipStream_t st) {
       // (it precedes every GEMM of the forward: it also resets the exchange words of the in-epilogue GroupNorms, GnxParams)
-      return launch_pack_input(uu->io.x, uu->io.cx, uu->io.cond, cin - uu->io.cx, xin.hi, xin.lo, cpad, Bn, Tn, st, uu->gnx_pool, uu->gnx_words);
+      return launch_pack_input(uu->io.x, uu->io.cx, uu->io.cond, cin - uu->io.cx, xin.hi, xin.lo, cpad, Bn, Tn, st, uu->gnx_pool, uu->gnx_words, Tp0);
     });
     const PackedW* wci = pack("conv_in", C0, 3 * cpad, {{"conv_in.weight", 1, cin, 3, cpad, 0, 0, "", 0}},
                               {{"conv_in.bias", "", "", "", C0, 0, 0, 0}});
     if (!wci) return dv_fail(DV_ERR_MISSING_WEIGHT, "%s", err.c_str());
     Act h{};
-    h.p = alloc((size_t)B * T * C0); h.C = C0; h.T = T; alloc_stat(h);
+    h.p = alloc((size_t)B * Tp0 * C0); h.C = C0; h.T = T; h.Tp = Tp0; alloc_stat(h);
     {
-      GemmParams g = gp_base(T, B * T, C0);
+      GemmParams g = gp_base(T, B * Tp0, C0);
       g.seg[0] = seg(xin, cpad, Planes{}, 0, 3, 1);
       g.out = h.p; stat_out(g, h);
       announce_norm("down_blocks.0.resnets.0.norm1", has("down_blocks.0.resnets.0.conv_shortcut.weight"));
@@ -1535,7 +1555,7 @@ struct Builder {
         const std::string next_rp = j + 1 < lpb ? bp + "resnets." + std::to_string(j + 1) + "." : (i == n - 1 ? std::string("mid_block.resnets.0.") : std::string());
         if (!attn && !next_rp.empty()) announce_resnet(next_rp);
         Act r = resnet(S, bp + "resnets." + std::to_string(j) + ".", h, Act{}, c.block_out_channels[i], feeds_resampler && !attn,
-                       attn && chain_ok(h.T, c.block_out_channels[i]));
+                       attn && chain_ok(h.Tp, c.block_out_channels[i]));
         next_norm.set = false;
         if (!r.p) return dv_fail(DV_ERR_MISSING_WEIGHT, "%s", err.c_str());
         if (attn) {
@@ -1558,7 +1578,7 @@ struct Builder {
       }
     }
     {
-      Act r0 = resnet(S, "mid_block.resnets.0.", h, Act{}, h.C, false, chain_ok(h.T, h.C));
+      Act r0 = resnet(S, "mid_block.resnets.0.", h, Act{}, h.C, false, chain_ok(h.Tp, h.C));
       if (!r0.p) return dv_fail(DV_ERR_MISSING_WEIGHT, "%s", err.c_str());
       announce_resnet("mid_block.resnets.1.");
       Act a = transformer(S, "mid_block.attentions.0.", r0);
@@ -1579,7 +1599,7 @@ struct Builder {
         const bool feeds_resampler = !last && j == lpb;              // its output is the upsampler's input
         const bool final_op = last && j == lpb;                      // its output goes to conv_norm_out alone
         if (final_op && !attn) announce_norm("conv_norm_out", false);
-        Act r = resnet(S, bp + "resnets." + std::to_string(j) + ".", h, sk, cout, feeds_resampler && !attn, attn && chain_ok(h.T, cout));
+        Act r = resnet(S, bp + "resnets." + std::to_string(j) + ".", h, sk, cout, feeds_resampler && !attn, attn && chain_ok(h.Tp, cout));
         next_norm.set = false;
         if (!r.p) return dv_fail(DV_ERR_MISSING_WEIGHT, "%s", err.c_str());
         release_act(h);
@@ -1607,7 +1627,7 @@ struct Builder {
       const PackedW* wo = pack("conv_out", co, 3 * C0, {{"conv_out.weight", 1, C0, 3, C0, 0, 0, "", 0}},
                                {{"conv_out.bias", "", "", "", co, 0, 0, 0}});
       if (!wo) return dv_fail(DV_ERR_MISSING_WEIGHT, "%s", err.c_str());
-      GemmParams g = gp_base(T, B * T, co);
+      GemmParams g = gp_base(T, B * Tp0, co);
       Planes nf;
       if (h.n_hi && h.n_pre == "conv_norm_out") {   // normalised by its producer's epilogue
         nf.hi = h.n_hi; nf.lo = h.n_lo;
@@ -1708,7 +1728,7 @@ struct Builder {
     float* x = alloc((size_t)M * H);
     LnIn lin;
     {
-      GemmParams g = gp_base(Ln, M, H); g.seg[0] = seg(p0, cpad, Planes{}, 0, 1, 0);
+      GemmParams g = gp_rows(Ln, M, H); g.seg[0] = seg(p0, cpad, Planes{}, 0, 1, 0);
       g.out = x; g.rowmask = keep; lin = ln_produce(g, x); gemm(S, g, w_pre, Cin);
     }
     release(p0);
@@ -1731,7 +1751,7 @@ struct Builder {
       // self-attention: LayerNorm1 finished in the qkv GEMM, padded keys masked by the key bias
       float* qkv = alloc((size_t)M * 3 * H);
       {
-        GemmParams g = gp_base(Ln, M, 3 * H);
+        GemmParams g = gp_rows(Ln, M, 3 * H);
         g.out = qkv; ln_consume(g, lin, x, w_qkv); gemm(S, g, w_qkv, H);
       }
       ln_release(lin);
@@ -1739,7 +1759,7 @@ struct Builder {
       release(qkv);
       float* x2 = alloc((size_t)M * H);
       {
-        GemmParams g = gp_base(Ln, M, H); g.seg[0] = seg(ao, H, Planes{}, 0, 1, 0);
+        GemmParams g = gp_rows(Ln, M, H); g.seg[0] = seg(ao, H, Planes{}, 0, 1, 0);
         g.epi = EPI_RESIDUAL; g.res = x; g.out = x2; g.rowmask = keep; gemm(S, g, w_o, H);
       }
       release(ao); release(x);
@@ -1756,7 +1776,7 @@ struct Builder {
       }
       Planes hh = alloc_planes((size_t)M * 4 * H);
       {
-        GemmParams g = gp_base(Ln, M, 4 * H);
+        GemmParams g = gp_rows(Ln, M, 4 * H);
         g.seg[0] = seg(n2, H, Planes{}, 0, 1, 0);
         if (KS9 > 1) { g.seg[1] = seg(n2, H, Planes{}, 0, KS9 - 1, (KS9 - 1) / 2 - 1); g.nseg = 2; }
         g.relu = 1; g.out_hi = hh.hi; g.out_lo = hh.lo;
@@ -1765,7 +1785,7 @@ struct Builder {
       release(n2);
       float* x3 = alloc((size_t)M * H);
       {
-        GemmParams g = gp_base(Ln, M, H); g.seg[0] = seg(hh, 4 * H, Planes{}, 0, 1, 0);
+        GemmParams g = gp_rows(Ln, M, H); g.seg[0] = seg(hh, 4 * H, Planes{}, 0, 1, 0);
         g.epi = EPI_RESIDUAL; g.res = x2; g.out = x3; g.rowmask = keep; lin = ln_produce(g, x3); gemm(S, g, w_f2, 4 * H);
       }
       release(hh); release(x2);
@@ -1779,7 +1799,7 @@ struct Builder {
     if (!w_op) return dv_fail(DV_ERR_MISSING_WEIGHT, "%s", err.c_str());
     float* z = alloc((size_t)M * Cout);
     {
-      GemmParams g = gp_base(Ln, M, Cout);
+      GemmParams g = gp_rows(Ln, M, Cout);
       g.out = z; g.rowmask = keep; ln_consume(g, lin, x, w_op); gemm(S, g, w_op, H);
     }
     ln_release(lin); release(x);
@@ -2226,7 +2246,9 @@ extern "C" int dv_unet_probe(dv_unet* u, const char* name, float* host_out, int6
       if (!host_out) return DV_OK;
       if (capacity < n) return dv_fail(DV_ERR_INVALID, "probe buffer too small");
       HIPCHK(hipDeviceSynchronize());
-      HIPCHK(hipMemcpy(host_out, p.p, n * sizeof(float), hipMemcpyDeviceToHost));
+      // (rows of a padded row space - Builder::pitch - are skipped: B pieces of T frames, Tp frames apart)
+      HIPCHK(hipMemcpy2D(host_out, (size_t)p.T * p.C * sizeof(float), p.p, (size_t)p.Tp * p.C * sizeof(float),
+                         (size_t)p.T * p.C * sizeof(float), (size_t)u->B, hipMemcpyDeviceToHost));
       return DV_OK;
     }
   }

@@ -130,11 +130,12 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int m0, con
   for (int q = 0; q < A_IPW; ++q) {
     const int r = (q * NWV + wave) * RPI + l_row;     // row within the A tile
     int m = m0 + r;
-    const bool ok = m < p.M;
-    arow_ok |= (ok ? 1u : 0u) << q;
+    bool ok = m < p.M;
     m = ok ? m : 0;
     arow_b[q] = m / p.T_out;
     arow_t[q] = m - arow_b[q] * p.T_out;
+    ok = ok && arow_t[q] < p.Tv_out;                  // (padding rows of a padded row space: zeros in, zeros out)
+    arow_ok |= (ok ? 1u : 0u) << q;
     a_chunk[q] = l_slot ^ swz(r);                     // source chunk that lands in this lane's slot
   }
   // (plain tiles: 32-bit per-lane byte offset beside a wave-uniform base that moves with the k-tile - the DMA is then
@@ -237,7 +238,7 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int m0, con
       const bool ok = ((arow_ok >> q) & 1u) && ts >= 0 && ts < p.T_virt;
       int st = ts;
       st = p.up_mode == UP_X2 ? (ts >> 1) : st;
-      st = p.up_mode == UP_SIZE ? min((int)floorf((float)ts * p.up_scale), p.T_in - 1) : st;
+      st = p.up_mode == UP_SIZE ? min((int)floorf((float)ts * p.up_scale), p.Tv_in - 1) : st;
       const size_t e = ((size_t)arow_b[q] * p.T_in + st) * cur_ld + cur_col + a_chunk[q] * 8;
       // conv zero padding / rows >= M read the zero page instead (DV_ZERO_PAGE_BYTES: the lane then walks the row's k-tiles inside it)
       asrc[q * NPL] = ok ? (const void*)(cur_hi + e) : (const void*)p.zero_page;
@@ -491,6 +492,12 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int m0, con
   constexpr bool HALF_OK = !BD && !SC1 && KS == 2 && FM == 1 && FN == 1;
   const bool half_mode = HALF_OK && p.sk_mode == 0 && vec4 && al8 && n0 + BN <= p.N && !p.stats && !p.rowstat_out &&
                          (p.epi == EPI_STORE || p.epi == EPI_RESIDUAL) && nk > 0;
+  // padded row space (GemmParams Tv_out): rows [Tv_out, T_out) of every utterance do not exist - stored as zeros, kept out of
+  // the statistics.  `padded` is wave-uniform; the per-lane division only runs then.
+  const bool padded = p.Tv_out != p.T_out;
+  auto row_ok = [&](int m) { return m < p.M && (!padded || m - (m / p.T_out) * p.T_out < p.Tv_out); };
+  // frames that exist in the 32-row block that starts at row mr (32 unless the utterance's last, partial block)
+  auto blk_cnt = [&](int mr) { return padded ? min(32, p.Tv_out - (mr - (mr / p.T_out) * p.T_out)) : 32; };
   auto load4 = [&](const float* base, size_t row_off, int nb, float* dst) {   // dst[0..3] = base[row_off + nb + e]
     if (vec4) {
       const float4 v = nb < p.N ? ld_mut4<SC1>(base + row_off + nb) : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -842,7 +849,8 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int m0, con
         if (lane + 64 * k < ne) {
           const double sx = (double)__uint_as_float((unsigned)w[k]), m2 = (double)__uint_as_float((unsigned)(w[k] >> 32));
           s1 += sx;
-          q += m2 + sx * sx * (1.0 / 512.0);         // = the block's sum of squares
+          const int e = lane + 64 * k, cnt = min(32, p.Tv_out - 32 * (e / nvb));   // frames of row block e / nvb that exist
+          q += m2 + sx * sx / (double)(16 * cnt);    // = the block's sum of squares
         }
       }
       if constexpr (BD) {
@@ -852,7 +860,7 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int m0, con
         s1 = wave_sum64(s1); q = wave_sum64(q);
       }
       if (lane == 0) {
-        const double n = (double)cpg * (double)p.T_out, mean = s1 / n;
+        const double n = (double)cpg * (double)p.Tv_out, mean = s1 / n;
         double var = q / n - mean * mean;
         var = var > 0 ? var : 0;
         s_gst[g - g_lo] = make_float2((float)mean, (float)(1.0 / sqrt(var + (double)p.gnx.eps)));
@@ -903,7 +911,7 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int m0, con
       const int coff = kgrp * 16;                    // this wave's columns inside the fragment
       const int ncol = n0 + wn * 32 + coff;          // first of them
       const int rl = wm * 32 + l31, m = m0 + rl, mrow0 = m0 + wm * 32;
-      const bool m_ok = m < p.M;
+      const bool m_in = m < p.M, m_ok = row_ok(m);   // inside the tensor / a frame that exists (padded row spaces: dv_common.h)
 #pragma unroll
       for (int g = 0; g < 2; ++g) {
         const int cl = wn * 32 + coff + 4 * lh + 8 * g;                    // tile-local column of e = 0
@@ -925,14 +933,14 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int m0, con
         for (int r = 0; r < 8; ++r) vv[r] = fmaxf(vv[r], 0.f);
       }
       if (p.rowmask) {
-        const float rmask = p.rowmask[m_ok ? m : p.M - 1];
+        const float rmask = p.rowmask[m < p.M ? m : p.M - 1];
 #pragma unroll
         for (int r = 0; r < 8; ++r) vv[r] *= rmask;
       }
 #pragma unroll
       for (int r = 0; r < 8; ++r) vv[r] = m_ok ? vv[r] : 0.f;
       DV_TRACE(16);
-      if (m_ok) {
+      if (m_in) {                                    // (padding rows are stored as zeros)
         const size_t ob = (size_t)m * p.ldo + ncol;
         if (p.out) {
 #pragma unroll
@@ -947,9 +955,9 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int m0, con
 #pragma unroll
         for (int r = 0; r < 8; ++r) a1 += vv[r];
         a1 = wave_sum64(a1);
-        const float mb = a1 * (1.0f / 512.0f);
+        const float mb = padded ? a1 / (float)(16 * blk_cnt(mrow0)) : a1 * (1.0f / 512.0f);
 #pragma unroll
-        for (int r = 0; r < 8; ++r) { const float dv = vv[r] - mb; a2 = fmaf(dv, dv, a2); }
+        for (int r = 0; r < 8; ++r) { const float dv = (!padded || m_ok) ? vv[r] - mb : 0.f; a2 = fmaf(dv, dv, a2); }
         a2 = wave_sum64(a2);
         if (lane == 0 && mrow0 < p.M) {
           const size_t e = (size_t)(mrow0 >> 5) * (p.N >> 4) + (ncol >> 4);
@@ -962,7 +970,7 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int m0, con
       DV_TRACE(18);
       if (gnx_h) {
         gnx_table(NWV);
-        if (m_ok) {
+        if (m_in) {
           float y[8];
 #pragma unroll
           for (int g = 0; g < 2; ++g) {
@@ -1204,8 +1212,8 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int m0, con
       const int mrow0 = m0 + (wm * FM + i) * 32;
       const int rl = (wm * FM + i) * 32 + l31;
       const int m = m0 + rl;
-      const bool m_ok = m < p.M;
-      const int mc = m_ok ? m : p.M - 1;
+      const bool m_in = m < p.M, m_ok = row_ok(m);   // inside the tensor / a frame that exists
+      const int mc = m < p.M ? m : p.M - 1;
       // residual operand: 4 x 16-byte loads issued back to back (clamped row), one wait
       float rv[16];
       if (p.epi == EPI_RESIDUAL) {
@@ -1278,14 +1286,14 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int m0, con
       if (p.epi == EPI_STORE_NCT) {
         // [B, N, T_out]: the 32 lanes of a half-wave write 32 consecutive frames of one channel
         if (m_ok) {
-          const int b = m / p.T_out, t = m - b * p.T_out;
+          const int b = m / p.T_out, t = m - b * p.T_out;   // (row pitch T_out; the [B, N, Tv_out] result has no padding)
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
             const int n = nf + 8 * (r >> 2) + (r & 3);
-            if (n < p.N) p.out[((size_t)b * p.N + n) * p.T_out + t] = vv[r];
+            if (n < p.N) p.out[((size_t)b * p.N + n) * p.Tv_out + t] = vv[r];
           }
         }
-      } else if (m_ok) {
+      } else if (m_in) {                              // (padding rows are stored as zeros)
         if (full) {                                  // planes as 16-byte stores: dv_device.h store_planes16
           const size_t ob = (size_t)m * p.ldo + nf;
           if (p.out) {
@@ -1311,7 +1319,7 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int m0, con
 #pragma unroll
         for (int r = 0; r < 16; ++r) q += (vv[r] - mb) * (vv[r] - mb);
         q = pair_sum32(q);
-        if (lh == 0 && m_ok && cb < nblk_total)
+        if (lh == 0 && m_in && cb < nblk_total)
           reinterpret_cast<float2*>(p.rowstat_out)[(size_t)m * nblk_total + cb] = make_float2(a, q);
       }
       if (p.stats) {
@@ -1357,9 +1365,10 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int m0, con
           }
         };
         a1[0] = wsum(a1[0]); a1[1] = wsum(a1[1]);
-        const float mb[2] = {a1[0] * (1.0f / 512.0f), a1[1] * (1.0f / 512.0f)};
+        const float inv_n = padded ? 1.0f / (float)(16 * blk_cnt(mrow0)) : 1.0f / 512.0f;
+        const float mb[2] = {a1[0] * inv_n, a1[1] * inv_n};
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { const float dv = vv[r] - mb[r >> 3]; a2[r >> 3] = fmaf(dv, dv, a2[r >> 3]); }
+        for (int r = 0; r < 16; ++r) { const float dv = (!padded || m_ok) ? vv[r] - mb[r >> 3] : 0.f; a2[r >> 3] = fmaf(dv, dv, a2[r >> 3]); }
         a2[0] = wsum(a2[0]); a2[1] = wsum(a2[1]);
         const int cb0 = (n0 + (wn * FN + j) * 32) >> 4;
         if (lane < 2 && mrow0 < p.M && (cb0 + lane) * 16 < p.N) {

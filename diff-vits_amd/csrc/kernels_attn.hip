@@ -409,9 +409,9 @@ hipError_t launch_attention_frag(const AttnFragParams& pin, hipStream_t st) {
   if (p.d % 16 != 0 || p.d > 64 || p.d <= 0 || (p.nsplit != 1 && p.nsplit != 3) || !p.q || !p.kf_hi || !p.vf_hi) return hipErrorInvalidValue;
   if (p.nsplit == 3 && (!p.kf_lo || !p.vf_lo)) return hipErrorInvalidValue;
   if (p.self_layout && (p.d & 15)) return hipErrorInvalidValue;
-  // keys beyond Tk inside the last 32-key tile are zero fragments: only the bias row (-1e30 there) keeps them out of the
-  // softmax, so a ragged Tk needs one, and it must cover whole tiles
-  if (p.Tk % 32 != 0 && !p.bias) return hipErrorInvalidValue;
+  // keys beyond Tk inside the last 32-key tile (zero fragments of the hoisted prompt; finite padding rows of a padded self-
+  // attention row space) are kept out of the softmax by the kernel itself (key >= Tk -> -1e30 in the last pair); a bias row,
+  // if given, must cover whole tiles
   if (p.bias && p.bias_ld < (p.Tk + 31) / 32 * 32) return hipErrorInvalidValue;
   const long waves = (long)p.B * p.H * ((p.Tq + 31) / 32);
   static const int nw8_min = [] { const char* e = getenv("DVITS_ATTNF_NW8"); return e ? atoi(e) : 1100; }();

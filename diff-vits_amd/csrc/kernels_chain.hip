@@ -260,7 +260,7 @@ __global__ __launch_bounds__((chain_pf_wave<NS, AMODE, XA, SA, CS>() ? NT_LAUNCH
   if (!PFW && !XA && DV_CHAIN_PFMODE == 2) l2_prefetch(wave, NWV);
   if (AMODE == 1) {
     // GroupNorm of the fp32 rows, once per row-block: table of this utterance, then convert
-    const int T = p.T, b_item = m0 / T;
+    const int T = p.T, b_item = m0 / T, Tv = p.Tv > 0 ? p.Tv : T;   // row pitch / frames that exist (padded row spaces)
     // (the rows are requested FIRST: their cold-miss latency runs under the table's loads, reductions and barriers)
     constexpr int TASKS = BM * (C / 4), RNDS = (TASKS + NT - 1) / NT;    // (row, 4-channel group); NT % (C/4) may be != 0
     float4 rv[RNDS];
@@ -295,11 +295,11 @@ __global__ __launch_bounds__((chain_pf_wave<NS, AMODE, XA, SA, CS>() ? NT_LAUNCH
         for (int k = 0; k < 4; ++k) {
           const int i = i0 + k * lpg, rb = i / nvb;
           const float2 v = s_ent[min(rb * nblk + g * nvb + (i - rb * nvb), n_ent - 1)];
-          if (i < RB * nvb) { s1 += (double)v.x; q += (double)v.y + (double)v.x * (double)v.x * (1.0 / 512.0); }
+          if (i < RB * nvb) { s1 += (double)v.x; q += (double)v.y + (double)v.x * (double)v.x / (double)(16 * min(32, Tv - 32 * rb)); }
         }
       }
       for (int o = lpg >> 1; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o); q += __shfl_xor(q, o); }
-      const double n = (double)cg * (double)T, mean_d = s1 / n;
+      const double n = (double)cg * (double)Tv, mean_d = s1 / n;
       double var = q / n - mean_d * mean_d;
       var = var > 0 ? var : 0;
       const float mean = (float)mean_d, rstd = 1.0f / sqrtf((float)var + p.gn_eps);
@@ -894,13 +894,17 @@ __global__ __launch_bounds__(NT_LAUNCH) void k_chain_ff(const ChainFFParams p) {
       dv_st16(p.out + (size_t)m * C + nf + 8 * g, make_float4(vv[4 * g], vv[4 * g + 1], vv[4 * g + 2], vv[4 * g + 3]));
     if (p.out_hi) store_planes16(p.out_hi, p.out_lo, (size_t)m * C + nf - 4 * lh, lh, vv);   // 16-byte plane stores (dv_device.h)
     if (p.stats16) {
+      // (padded row spaces: the utterance's last row block holds cnt < 32 frames that exist - the others stay out)
+      const int Tv = p.Tv > 0 ? p.Tv : p.T, cnt = min(32, Tv - (m0 - (m0 / p.T) * p.T));
+      const bool r_ok = l31 < cnt;
       float a1[2] = {0.f, 0.f}, a2[2] = {0.f, 0.f};
 #pragma unroll
-      for (int r = 0; r < 16; ++r) a1[r >> 3] += vv[r];
+      for (int r = 0; r < 16; ++r) a1[r >> 3] += r_ok ? vv[r] : 0.f;
       a1[0] = wave_sum64(a1[0]); a1[1] = wave_sum64(a1[1]);
-      const float mb[2] = {a1[0] * (1.0f / 512.0f), a1[1] * (1.0f / 512.0f)};
+      const float inv_n = cnt == 32 ? 1.0f / 512.0f : 1.0f / (float)(16 * cnt);
+      const float mb[2] = {a1[0] * inv_n, a1[1] * inv_n};
 #pragma unroll
-      for (int r = 0; r < 16; ++r) { const float dv = vv[r] - mb[r >> 3]; a2[r >> 3] = fmaf(dv, dv, a2[r >> 3]); }
+      for (int r = 0; r < 16; ++r) { const float dv = r_ok ? vv[r] - mb[r >> 3] : 0.f; a2[r >> 3] = fmaf(dv, dv, a2[r >> 3]); }
       a2[0] = wave_sum64(a2[0]); a2[1] = wave_sum64(a2[1]);
       if (lane < 2)
         reinterpret_cast<float2*>(p.stats16)[(size_t)blockIdx.x * (C / 16) + wn * 2 + lane] =
@@ -1000,7 +1004,7 @@ hipError_t launch_one(const ChainParams& p, hipStream_t st) {
 
 static constexpr int FF_SMEM = 2 * 2 * CHUNK_PL + 2 * 8 * CHUNK_PL + 16384;
 bool chain_ff_supported(const ChainFFParams& p, int precision) {
-  return precision == 0 && p.C == 128 && p.M % 32 == 0 && p.T % 32 == 0 && p.M % p.T == 0;
+  return precision == 0 && p.C == 128 && p.M % 32 == 0 && p.T % 32 == 0 && p.M % p.T == 0 && p.Tv >= 0 && p.Tv <= p.T && (p.Tv == 0 || p.Tv > p.T - 32);
 }
 hipError_t launch_chain_ff(const ChainFFParams& p, int precision, hipStream_t st) {
   if (!chain_ff_supported(p, precision)) return hipErrorInvalidValue;
@@ -1060,6 +1064,7 @@ bool chain2_supported(const ChainParams& p, int precision) {
   if (precision != 0) return false;                                  // split-bf16 mode only
   if (p.C != 128 && p.C != 256 && p.C != 384) return false;   // (C = 512 was measured slower than one launch per GEMM; its instantiations were removed in round 3)
   if (p.M % 32 != 0 || p.T % 32 != 0 || p.M % p.T != 0 || p.passes < 1) return false;
+  if (p.Tv < 0 || p.Tv > p.T || (p.Tv > 0 && p.Tv <= p.T - 32)) return false;   // (padded row spaces: every row block holds a frame that exists)
   if (p.Kp1 != p.C || p.Kp2 != p.C) return false;
   if (p.xa_kf_hi) {                                                    // cross-attention tail: wave = head
     if (p.amode != 0 || p.passes != 1 || p.C % 8 != 0) return false;

@@ -98,6 +98,7 @@ struct GemmCfgBD {
 // [32 a | 32 gate] column blocks must sit in ONE wave; BD's waves own 32 columns).
 bool gemm_bd_supported(const GemmParams& p) {
   if (!p.wf_hi || p.stride != 1 || p.up_mode != UP_NONE || p.T_in != p.T_out || p.T_out % 64 != 0 || p.M != p.B * p.T_out) return false;
+  if ((p.Tv_out > 0 && p.Tv_out != p.T_out) || (p.Tv_in > 0 && p.Tv_in != p.T_in)) return false;   // (no padded row spaces)
   if (p.epi == EPI_GEGLU || p.sk_mode == 1 || p.sk_mode == 2 || p.Kp % 16 != 0 || p.N_pad % 64 != 0) return false;
   int k_tot = 0;
   for (int s2 = 0; s2 < p.nseg; ++s2) {
@@ -316,6 +317,10 @@ hipError_t launch_gemm(const GemmParams& pin, int precision, hipStream_t st) {
 #endif
   const bool x3 = precision == 0;
   if (!p.zero_page || (x3 && !p.w_lo)) return hipErrorInvalidValue;
+  // padded row spaces (GemmParams): 0 = no padding
+  if (p.Tv_out <= 0) p.Tv_out = p.T_out;
+  if (p.Tv_in <= 0) p.Tv_in = p.T_in;
+  if (p.Tv_out > p.T_out || p.Tv_in > p.T_in || ((p.stats16 || p.gnx.xchg) && p.Tv_out <= p.T_out - 32)) return hipErrorInvalidValue;
   for (int s2 = 0; s2 < p.nseg; ++s2)     // (a lane on the zero page walks a row's k-tiles inside it: gemm_tile.h prep_a_next)
     if (2 * (size_t)p.seg[s2].c0 + 256 > DV_ZERO_PAGE_BYTES || 2 * (size_t)p.seg[s2].c1 + 256 > DV_ZERO_PAGE_BYTES) return hipErrorInvalidValue;
   if (p.gnx.xchg && p.sk_mode == 0) {            // (checked once, before the split-K recursion)

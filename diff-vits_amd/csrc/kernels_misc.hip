@@ -17,7 +17,7 @@
 __global__ __launch_bounds__(256) void k_pack_input(const float* __restrict__ x, int cx,
                                                      const float* __restrict__ cond, int cc,
                                                      bf16_t* __restrict__ out_hi, bf16_t* __restrict__ out_lo,
-                                                     int cpad, int T, unsigned long long* __restrict__ reset, size_t reset_words) {
+                                                     int cpad, int T, int Tp, unsigned long long* __restrict__ reset, size_t reset_words) {
   // (this kernel precedes every GEMM of a forward: the exchange words of the in-epilogue GroupNorms - GnxParams - start EMPTY)
   {
     const size_t nthr = (size_t)gridDim.x * gridDim.y * gridDim.z * blockDim.x;
@@ -41,10 +41,10 @@ __global__ __launch_bounds__(256) void k_pack_input(const float* __restrict__ x,
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int t = t0 + ty + i * 8, c = c0 + tx;
-    if (t < T && c < cpad) {
+    if (t < Tp && c < cpad) {                           // (rows [T, Tp): zeros)
       bf16_t h, l;
       split1(tile[tx][ty + i * 8], h, l);
-      const size_t o = ((size_t)b * T + t) * cpad + c;
+      const size_t o = ((size_t)b * Tp + t) * cpad + c;
       out_hi[o] = h;
       if (out_lo) out_lo[o] = l;
     }
@@ -52,10 +52,12 @@ __global__ __launch_bounds__(256) void k_pack_input(const float* __restrict__ x,
 }
 
 hipError_t launch_pack_input(const float* x, int cx, const float* cond, int cc, bf16_t* out_hi, bf16_t* out_lo, int cpad,
-                             int B, int T, hipStream_t st, unsigned long long* reset, size_t reset_words) {
+                             int B, int T, hipStream_t st, unsigned long long* reset, size_t reset_words, int Tp) {
   if (reset_words & 1) return hipErrorInvalidValue;
-  dim3 grid((T + 31) / 32, (cpad + 31) / 32, B);
-  hipLaunchKernelGGL(k_pack_input, grid, dim3(256), 0, st, x, cx, cond, cc, out_hi, out_lo, cpad, T, reset, reset ? reset_words : (size_t)0);
+  if (Tp <= 0) Tp = T;
+  if (Tp < T) return hipErrorInvalidValue;
+  dim3 grid((Tp + 31) / 32, (cpad + 31) / 32, B);
+  hipLaunchKernelGGL(k_pack_input, grid, dim3(256), 0, st, x, cx, cond, cc, out_hi, out_lo, cpad, T, Tp, reset, reset ? reset_words : (size_t)0);
   return hipGetLastError();
 }
 
@@ -88,9 +90,12 @@ hipError_t launch_gn_apply(const GnApplyParams& p, hipStream_t st) {
   const int cg = ctot / p.groups;
   if (cg % 4 != 0 || p.c0 % 4 != 0 || cg > 512 || p.groups > 64) return hipErrorInvalidValue;
   // slab statistics: 32-row blocks must not span utterances (T % 32 == 0, or a single utterance whose last block is partial)
+  if (p.Tv < 0 || p.Tv > p.T) return hipErrorInvalidValue;
   if (!p.scale_in && p.st16_0) {
     if (p.T % 32 != 0 || cg % 16 != 0 || p.c0 % 16 != 0 || (p.c1 && !p.st16_1) || cg > 512) return hipErrorInvalidValue;
-  } else if (!p.scale_in && ((p.T % 32 != 0 && p.B != 1) || !p.slab0 || (p.c1 && !p.slab1))) return hipErrorInvalidValue;
+    if (p.Tv && p.Tv <= p.T - 32) return hipErrorInvalidValue;   // (every 32-row block holds at least one frame that exists)
+  } else if (p.Tv && p.Tv != p.T) return hipErrorInvalidValue;     // (padded row spaces carry block statistics)
+  else if (!p.scale_in && ((p.T % 32 != 0 && p.B != 1) || !p.slab0 || (p.c1 && !p.slab1))) return hipErrorInvalidValue;
   // ~1024 workgroups: (frame chunks) x groups x batch  (DVITS_GN_WGS: experiment knob)
   static const int target = [] { const char* e = getenv("DVITS_GN_WGS"); return e ? atoi(e) : 1024; }();
   int chunks = target / (p.groups * p.B);

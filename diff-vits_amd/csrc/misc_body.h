@@ -79,6 +79,7 @@ __device__ __forceinline__ void gn_apply_body(const GnApplyParams& p, int rows_p
     // block statistics: the group's RB x (cg / 16) entries are reduced by the first wave in one pass (fp64), while every
     // thread already holds the affine parameters of its channels (fetched before the statistics arrive)
     const int RB = p.T >> 5, nvb = cg >> 4;
+    const int Tv = p.Tv ? p.Tv : p.T;                  // frames that exist: the last block of a padded utterance is partial
     float pg[2], pb[2], pts[2], ptb[2];
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
@@ -97,14 +98,14 @@ __device__ __forceinline__ void gn_apply_body(const GnApplyParams& p, int rows_p
         const int nb = (first ? p.c0 : p.c1) >> 4, vbl = first ? vb : vb - (p.c0 >> 4);
         const float2 v = ld_mut2<SC1>(st + (size_t)(b * RB + rb) * nb + vbl);
         s1 += (double)v.x;
-        q += (double)v.y + (double)v.x * (double)v.x * (1.0 / 512.0);      // = the block's sum of squares
+        q += (double)v.y + (double)v.x * (double)v.x / (double)(16 * min(32, Tv - 32 * rb));   // = the block's sum of squares
       }
       s1 = wave_sum_d(s1);
       q = wave_sum_d(q);
       if (tid == 0) { s_red[0] = s1; s_red[1] = q; }
     }
     __syncthreads();
-    const double n = (double)cg * (double)p.T;
+    const double n = (double)cg * (double)Tv;
     const double mean = s_red[0] / n;
     double var = s_red[1] / n - mean * mean;
     var = var > 0 ? var : 0;
