@@ -54,6 +54,8 @@ struct GemmParams {
   // tap that lands on one reads zeros (T_virt bounds the gather), their outputs are written as zeros, the block statistics
   // of an utterance's last block cover its valid rows only, self-attention masks them as keys.
   int Tv_out, Tv_in;
+  unsigned tout_magic;          // internal (launch_gemm): ceil(2^32 / T_out) - row m's utterance is umulhi(m, magic), exact for m * T_out < 2^32;
+                                // 0 when T_out == 1.  (A division by a run-time value is ~25 vector instructions on every lane's critical path.)
   int stride;
   int up_mode;                  // UP_*
   float up_scale;               // UP_SIZE: (float)T_in / T_virt, as ATen computes it
@@ -102,6 +104,7 @@ struct GemmParams {
   int trace;                    // development build (make trace): this launch stamps its phases (gemm_tile.h DV_TRACE)
 #endif
 };
+inline unsigned gemm_tout_magic(int T_out) { return T_out <= 1 ? 0u : (unsigned)(((1ull << 32) + (unsigned)T_out - 1) / (unsigned)T_out); }
 // exchange words a GNX GEMM needs (M / 32 * N / 16), or 0 if launch_gemm would refuse it (tile shape vs T_out / groups,
 // more workgroups than `n_cu` compute units, unsupported epilogue)
 int gemm_gnx_plan(const GemmParams& p, int n_cu);

@@ -420,6 +420,9 @@ struct Builder {
     if (gin.T_out % bm != 0 || gin.M != B * gin.T_out) return false;
     po = PersistOp{};
     po.type = POP_GEMM; po.cfg = cfg; po.g = gin;
+    po.g.tout_magic = gemm_tout_magic(gin.T_out);      // (launch_gemm's normalisations: the persistent launch runs the tile routine directly)
+    if (po.g.Tv_out <= 0) po.g.Tv_out = po.g.T_out;
+    if (po.g.Tv_in <= 0) po.g.Tv_in = po.g.T_in;
     for (int s2 = 0; s2 < gin.nseg; ++s2) po.g.seg[s2].nkt = gin.seg[s2].taps * (gin.seg[s2].c0 + gin.seg[s2].c1) / bk;
     return true;
   }

@@ -124,6 +124,8 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int m0, con
   const int l_row = lane / CPR, l_slot = lane % CPR;
   auto swz = [](int row) { return CPR == 8 ? ((row >> 1) & 7) : ((row >> 2) & 3); };
 
+  // row m -> utterance m / T_out without a division (GemmParams tout_magic: exact for every row of the launch)
+  auto utt_of = [&](int m) { return p.tout_magic ? (int)__umulhi((unsigned)m, p.tout_magic) : m; };
   int arow_b[A_IPW1], arow_t[A_IPW1], a_chunk[A_IPW1];
   unsigned arow_ok = 0;
 #pragma unroll
@@ -132,7 +134,7 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int m0, con
     int m = m0 + r;
     bool ok = m < p.M;
     m = ok ? m : 0;
-    arow_b[q] = m / p.T_out;
+    arow_b[q] = utt_of(m);
     arow_t[q] = m - arow_b[q] * p.T_out;
     ok = ok && arow_t[q] < p.Tv_out;                  // (padding rows of a padded row space: zeros in, zeros out)
     arow_ok |= (ok ? 1u : 0u) << q;
@@ -495,9 +497,9 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int m0, con
   // padded row space (GemmParams Tv_out): rows [Tv_out, T_out) of every utterance do not exist - stored as zeros, kept out of
   // the statistics.  `padded` is wave-uniform; the per-lane division only runs then.
   const bool padded = p.Tv_out != p.T_out;
-  auto row_ok = [&](int m) { return m < p.M && (!padded || m - (m / p.T_out) * p.T_out < p.Tv_out); };
+  auto row_ok = [&](int m) { return m < p.M && (!padded || m - utt_of(m) * p.T_out < p.Tv_out); };
   // frames that exist in the 32-row block that starts at row mr (32 unless the utterance's last, partial block)
-  auto blk_cnt = [&](int mr) { return padded ? min(32, p.Tv_out - (mr - (mr / p.T_out) * p.T_out)) : 32; };
+  auto blk_cnt = [&](int mr) { return padded ? min(32, p.Tv_out - (mr - utt_of(mr) * p.T_out)) : 32; };
   auto load4 = [&](const float* base, size_t row_off, int nb, float* dst) {   // dst[0..3] = base[row_off + nb + e]
     if (vec4) {
       const float4 v = nb < p.N ? ld_mut4<SC1>(base + row_off + nb) : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -796,7 +798,7 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int m0, con
   __shared__ float2 s_gst[BN / 16 + 1];
   __shared__ __attribute__((aligned(16))) float s_gA[BN < 64 ? 64 : BN], s_gB[BN < 64 ? 64 : BN];
   auto gnx_table = [&](const int nwa) __attribute__((always_inline)) {
-    const int cpg = p.N / p.gnx.groups, bq = m0 / p.T_out;
+    const int cpg = p.N / p.gnx.groups, bq = utt_of(m0);
     float pg = 0.f, pb = 0.f, pts = 1.f, ptb = 0.f;  // this thread's column: affine + temb scale / shift (independent of the statistics)
     if (tid < BN) {
       const int c = min(n0 + tid, p.N - 1);
@@ -1286,7 +1288,7 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int m0, con
       if (p.epi == EPI_STORE_NCT) {
         // [B, N, T_out]: the 32 lanes of a half-wave write 32 consecutive frames of one channel
         if (m_ok) {
-          const int b = m / p.T_out, t = m - b * p.T_out;   // (row pitch T_out; the [B, N, Tv_out] result has no padding)
+          const int b = utt_of(m), t = m - b * p.T_out;     // (row pitch T_out; the [B, N, Tv_out] result has no padding)
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
             const int n = nf + 8 * (r >> 2) + (r & 3);

@@ -36,9 +36,18 @@ __global__ __launch_bounds__(64 * WM * WN * KS + (BD ? 128 : 0)) void k_gemm(con
   // dependent scalar-cache misses at the head of every workgroup: measured +300 cycles)
   asm volatile("" ::"s"(p.seg[0].a0_hi), "s"(p.seg[1].a0_hi), "s"(p.seg[1].pad), "s"(p.T_in), "s"(p.w_hi), "s"(p.M), "s"(p.res),
                "s"(p.out_hi), "s"(p.zero_page), "s"(p.ln_u), "s"(p.gnx.xchg), "s"(p.gnx.y_hi), "s"(p.xcd_n), "s"(p.xcd_inv_tn));
+  // ONE call site of the tile routine.  [Rounds 1-3 called it from both branches of the mapping: two inlined copies.  Waves
+  // leave the routine at different points (k-groups that hand their sums over), so the structurised control flow runs from the
+  // first copy's epilogue THROUGH the second copy under an empty exec mask - and hipcc's wait-count insertion, which knows
+  // nothing about exec, carried the first epilogue's pending loads (GroupNorm hand-over polls, affine parameters) into the
+  // second copy's k-loop: whenever the register allocator happened to reuse one of their destination registers for the
+  // k-loop's pointers it inserted `s_waitcnt vmcnt(0)` there - a full drain of the LDS-DMA queue per k-tile.  Round 4 hit
+  // that by adding two epilogue scalars: -10 % end to end, found by a same-box A/B.  tools/kloop_waits.py checks the
+  // assembly for it; tests/test_kernel_resources.py runs the check.]
   const int n_tiles_n = (p.N + BN - 1) / BN;
   const int nwg = gridDim.x;
   int bid = blockIdx.x;
+  int tm0, tn0, ksel = 0;
   if (p.xcd_n > 0) {
     // launch_gemm checked: 8 | nwg; (k-slices) x xm x xn = 8; xm | row tiles, xn | column tiles
     // (xs, xm, xn are powers of two; the one real division - by the rectangle's width - is a multiply by the host's
@@ -46,20 +55,20 @@ __global__ __launch_bounds__(64 * WM * WN * KS + (BD ? 128 : 0)) void k_gemm(con
     const int x = bid & 7, i = bid >> 3;
     const int ks_i = x >> p.xcd_sh_mn, r = x & ((1 << p.xcd_sh_mn) - 1), xm_i = r >> p.xcd_sh_n, xn_i = r & (p.xcd_n - 1);
     const int lm = (i * p.xcd_inv_tn) >> 16, ln = i - lm * p.xcd_tn;
-    gemm_tile<BM, BN, BK, WM, WN, NSPLIT, KS, false, BD>(p, (xm_i * p.xcd_tm + lm) * BM, (xn_i * p.xcd_tn + ln) * BN, smem, ks_i);
-    return;
+    tm0 = (xm_i * p.xcd_tm + lm) * BM; tn0 = (xn_i * p.xcd_tn + ln) * BN; ksel = ks_i;
+  } else {
+    {
+      const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+      bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    }
+    if (p.sk_mode == 1 || p.sk_mode == 3) {              // XCD-contiguous ids share a k-slice: an L2 holds one slice of A and W
+      const int tiles = nwg / p.sk_split;
+      ksel = bid / tiles;
+      bid -= ksel * tiles;
+    }
+    tm0 = (bid / n_tiles_n) * BM; tn0 = (bid % n_tiles_n) * BN;
   }
-  {
-    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
-    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-  }
-  int ksel = 0;
-  if (p.sk_mode == 1 || p.sk_mode == 3) {              // XCD-contiguous ids share a k-slice: an L2 holds one slice of A and W
-    const int tiles = nwg / p.sk_split;
-    ksel = bid / tiles;
-    bid -= ksel * tiles;
-  }
-  gemm_tile<BM, BN, BK, WM, WN, NSPLIT, KS, false, BD>(p, (bid / n_tiles_n) * BM, (bid % n_tiles_n) * BN, smem, ksel);
+  gemm_tile<BM, BN, BK, WM, WN, NSPLIT, KS, false, BD>(p, tm0, tn0, smem, ksel);
 }
 
 template <int BM, int BN, int BK, int WM, int WN, int NSPLIT, int KS>
@@ -321,6 +330,8 @@ hipError_t launch_gemm(const GemmParams& pin, int precision, hipStream_t st) {
   if (p.Tv_out <= 0) p.Tv_out = p.T_out;
   if (p.Tv_in <= 0) p.Tv_in = p.T_in;
   if (p.Tv_out > p.T_out || p.Tv_in > p.T_in || ((p.stats16 || p.gnx.xchg) && p.Tv_out <= p.T_out - 32)) return hipErrorInvalidValue;
+  if (p.T_out < 1 || (unsigned long long)(p.M > 0 ? p.M : 1) * (unsigned long long)p.T_out >= (1ull << 32)) return hipErrorInvalidValue;
+  p.tout_magic = gemm_tout_magic(p.T_out);
   for (int s2 = 0; s2 < p.nseg; ++s2)     // (a lane on the zero page walks a row's k-tiles inside it: gemm_tile.h prep_a_next)
     if (2 * (size_t)p.seg[s2].c0 + 256 > DV_ZERO_PAGE_BYTES || 2 * (size_t)p.seg[s2].c1 + 256 > DV_ZERO_PAGE_BYTES) return hipErrorInvalidValue;
   if (p.gnx.xchg && p.sk_mode == 0) {            // (checked once, before the split-K recursion)

@@ -615,8 +615,9 @@ def test_unet_unfused_layernorm_mode(gold):
         os.environ.pop("DVITS_FUSE_LN", None)
     assert rel_l2(y.cpu().numpy(), gold("unet_oddT.npz")["y"]) < 2e-4
     m2, *_ = _build("oddT")
-    # default schedule: 48 LayerNorm launches and (merged ff.net.2 + proj_out) 16 GEMM launches fewer
-    assert m2.hip_engine().prepare(2, 100, 50) and m2.hip_engine().stats()[0] == n_launch - 64
+    # default schedule: 48 LayerNorm launches and (merged ff.net.2 + proj_out) 16 GEMM launches fewer - and, on this odd
+    # length too since round 4 (padded row space), the row-block chains that need the fused LayerNorm
+    assert m2.hip_engine().prepare(2, 100, 50) and m2.hip_engine().stats()[0] <= n_launch - 64
 
 
 def test_row_block_chains_match_one_launch_per_gemm():

@@ -53,3 +53,18 @@ def test_vgpr_budget_matches_workgroup_size(kernels):
         if k.get("max_flat_workgroup_size", 0) > 512:
             assert k["vgpr_count"] <= 168, k
         assert k["vgpr_count"] + k.get("agpr_count", 0) <= 512, k
+
+
+def test_gemm_k_loops_keep_their_dma_queue():
+    """No `s_waitcnt vmcnt(0)` inside any steady-state k-loop of k_gemm (tools/kloop_waits.py: kernels_gemm.hip compiled to
+    assembly here, ~1 min).  The loop keeps three k-tiles of LDS-DMA in flight with hand-counted waits; a compiler-inserted
+    full drain per k-tile - a register-allocation accident hipcc's wait insertion is free to commit whenever a pending
+    compiler-visible load can reach the loop in the control-flow graph - cost 10 % end to end in round 4 and no test saw it."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import kloop_waits
+    loops = {k: v for k, v in kloop_waits.kloops(kloop_waits.compile_asm()).items() if "Lb1EEv" not in k}   # (not the opt-in BD tile)
+    assert len(loops) >= 20, "k_gemm instantiations not found in the assembly"
+    assert all(v for v in loops.values()), "a k_gemm instantiation without a recognisable k-loop: %s" % [k for k, v in loops.items() if not v]
+    bad = {k: v for k, v in loops.items() if any(l[4] for l in v)}
+    assert not bad, "k-loops that drain the LDS-DMA queue: %s" % bad
