@@ -61,8 +61,6 @@ struct GemmParams {
   float up_scale;               // UP_SIZE: (float)T_in / T_virt, as ATen computes it
   const bf16_t* w_hi;           // [N_pad, Kp] bf16, row n = output channel, k contiguous
   const bf16_t* w_lo;           // low-order split (null in bf16 mode)
-  const bf16_t* wf_hi;          // the same planes FRAGMENT-major in chunk-major k order (launch_relayout_frag_cm) or null: enables the BD tile (gemm_tile.h)
-  const bf16_t* wf_lo;
   int Kp;                       // packed K
   int N_pad;                    // rows present in w_hi/w_lo (multiple of 128)
   const float* bias;            // [N] (GEGLU: packed order) or null
@@ -111,8 +109,6 @@ int gemm_gnx_plan(const GemmParams& p, int n_cu);
 // tile menu ids (kernels_gemm.hip); GT_BK64 is or-ed in when the tile runs 64-deep k-tiles
 enum { GT_AUTO = 0, GT_T0 = 1, GT_T1 = 2, GT_T2 = 3, GT_T2S = 4, GT_T2G = 5, GT_T3 = 6, GT_T4 = 7, GT_T4G = 8,
        GT_BK64 = 0x100 };
-// true if launch_gemm can run this GEMM on the BD tile (fragment-major weights in registers, activation slabs in LDS)
-bool gemm_bd_supported(const GemmParams& p);
 // candidate tiles (force_tile values) that can run this GEMM; returns the count written to out[cap]
 int gemm_candidates(const GemmParams& p, int* out, int cap);
 // number of k-slices launch_gemm should run this GEMM in (0: single launch); env DVITS_SPLITK tunes / disables
@@ -198,9 +194,6 @@ hipError_t chain_init();
 hipError_t launch_chain2(const ChainParams& p, int precision, hipStream_t st);
 // packed weight plane [rows][Kp] -> fragment-major (rows % 32 == 0, Kp % 16 == 0), same size
 hipError_t launch_relayout_frag(const bf16_t* src, bf16_t* dst, int rows, int Kp, hipStream_t st);
-// ... with the k-steps in the BD tile's chunk-major walk (segment -> 64-channel chunk -> tap) of a GEMM whose segments have
-// taps0 / taps1 taps over cc0 / cc1 (= c0 + c1) channels (cc1 = 0: one segment); Kp = taps0 cc0 + taps1 cc1
-hipError_t launch_relayout_frag_cm(const bf16_t* src, bf16_t* dst, int rows, int Kp, int taps0, int cc0, int taps1, int cc1, hipStream_t st);
 
 struct AttnParams {
   const float* q; const float* k; const float* v; const float* bias;

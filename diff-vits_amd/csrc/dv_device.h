@@ -16,7 +16,7 @@ __device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst) {
                : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
 }
 // ... with the source as wave-uniform base (scalar register pair) + per-lane 32-bit byte offset: no 64-bit vector address
-// arithmetic per instruction (the BD tile's producer waves issue nine of these per chunk)
+// arithmetic per instruction (the weight DMAs of the k-loop)
 __device__ __forceinline__ void glds16_s(const void* sbase, unsigned voff, unsigned lds_dst) {
   lds_dst = __builtin_amdgcn_readfirstlane(lds_dst);
   {   // (a wave-uniform value that hipcc happens to hold in vector registers does not satisfy the "s" constraint)

@@ -133,7 +133,6 @@ struct RawW { float* p = nullptr; std::vector<int64_t> shape; size_t numel = 0; 
 struct PackedW {
   bf16_t* hi = nullptr; bf16_t* lo = nullptr; float* bias = nullptr;
   bf16_t* fhi = nullptr; bf16_t* flo = nullptr;   // fragment-major copies for the row-block chains (made on demand)
-  bf16_t* chi = nullptr; bf16_t* clo = nullptr;   // fragment-major copies in the BD tile's chunk-major k order (k_gemm; made on demand)
   float* u = nullptr;           // sum_k gamma[k]*W[n,k] (fused-LayerNorm consumers), packed row order
   int Kp = 0, N = 0, N_pad = 0;
 };
@@ -561,24 +560,6 @@ struct Builder {
         launch_relayout_frag(w->lo, w->flo, w->N_pad, w->Kp, pack_stream) != hipSuccess) { err = "relayout launch failed"; return false; }
     return true;
   }
-  // ... in the chunk-major k order the BD tile of k_gemm walks (gemm_tile.h), for the GEMM `g` that uses this weight
-  bool frag_cm(const PackedW* cw, const GemmParams& g) {
-    if (dry) return true;
-    PackedW* w = const_cast<PackedW*>(cw);
-    if (w->chi) return true;
-    const size_t elems = (size_t)w->N_pad * w->Kp;
-    if (hipMalloc((void**)&w->chi, elems * 2) != hipSuccess || (w->lo && hipMalloc((void**)&w->clo, elems * 2) != hipSuccess)) {
-      err = "hipMalloc(fragment-major weights) failed"; return false;
-    }
-    u->owned_w.push_back(w->chi);
-    if (w->clo) u->owned_w.push_back(w->clo);
-    const int t0 = g.seg[0].taps, cc0 = g.seg[0].c0 + g.seg[0].c1, t1 = g.nseg > 1 ? g.seg[1].taps : 1, cc1 = g.nseg > 1 ? g.seg[1].c0 + g.seg[1].c1 : 0;
-    if (launch_relayout_frag_cm(w->hi, w->chi, w->N_pad, w->Kp, t0, cc0, t1, cc1, pack_stream) != hipSuccess ||
-        (w->lo && launch_relayout_frag_cm(w->lo, w->clo, w->N_pad, w->Kp, t0, cc0, t1, cc1, pack_stream) != hipSuccess)) {
-      err = "relayout launch failed"; return false;
-    }
-    return true;
-  }
   void chain(std::vector<OpFn>& ops, const ChainParams& cp, const char* what) {
     cur_kind = "chain";
     cur_flops = 2.0 * (double)cp.M * cp.C * cp.C * (1 + cp.passes);
@@ -595,7 +576,6 @@ struct Builder {
   // (a CU mask - HSA_CU_MASK / ROC_GLOBAL_CU_MASK - takes CUs away without hipDeviceAttributeMultiprocessorCount knowing:
   // the residency bound of the in-launch hand-over would be wrong, so it is not planned at all then)
   bool gnx_on = [] { const char* e = getenv("DVITS_GNX"); return !(e && e[0] == '0') && !getenv("HSA_CU_MASK") && !getenv("ROC_GLOBAL_CU_MASK"); }();
-  bool bd_on = [] { const char* e = getenv("DVITS_GEMM_BD"); return e && atoi(e) != 0; }();   // (no fragment-major copies while the BD tile is off: the default)
   size_t gnx_used = 0;
   // polls before an in-launch wait gives up; DVITS_GNX_SPIN=<n> is a test hook (1: every wait that is not satisfied at once
   // times out - exercises the fallback path of engine.py deterministically)
@@ -654,15 +634,6 @@ struct Builder {
     if (!g.bias) g.bias = pw->bias;
     g.B = B;
     g.zero_page = u->zero_page;
-    {   // BD tile (gemm_tile.h): GEMMs it can run get fragment-major copies of their weights (made once per packed weight)
-      GemmParams t = g;
-      t.wf_hi = reinterpret_cast<const bf16_t*>(0x1000);
-      t.Kp = g.Kp;
-      if (!arena.exact && bd_on && gemm_bd_supported(t)) {
-        if (!frag_cm(pw, g)) return;
-        g.wf_hi = pw->chi; g.wf_lo = pw->clo;
-      }
-    }
     const int p = prec;
     cur_kind = "gemm"; cur_flops = 2.0 * (double)g.M * (double)g.N * (double)k_real;
     {
@@ -2295,16 +2266,6 @@ extern "C" int dv_op_conv1d(const float* x, const float* w, const float* bias, f
   s.src = w; s.N = Cout; s.kind = 1; s.C = Cin; s.taps = k; s.c_pad = cpad; s.k_off = 0; s.n_off = 0;
   HIPCHK(launch_pack_weight(s, hi, lo, Kp, st));
   GemmParams g{};
-  // fragment-major copies only while the BD tile is on (DVITS_GEMM_BD; off by default)
-  static const bool bd_env = [] { const char* e = getenv("DVITS_GEMM_BD"); return e && atoi(e) != 0; }();
-  if (bd_env && cpad % 64 == 0) {
-    bf16_t* fhi = sc.get<bf16_t>((size_t)Npad * Kp * 2, st, false);
-    bf16_t* flo = x3 ? sc.get<bf16_t>((size_t)Npad * Kp * 2, st, false) : nullptr;
-    if (!fhi || (x3 && !flo)) return dv_fail(DV_ERR_HIP, "dv_op_conv1d: hipMalloc failed");
-    HIPCHK(launch_relayout_frag_cm(hi, fhi, Npad, Kp, k, cpad, 1, 0, st));
-    if (x3) HIPCHK(launch_relayout_frag_cm(lo, flo, Npad, Kp, k, cpad, 1, 0, st));
-    g.wf_hi = fhi; g.wf_lo = flo;
-  }
   g.seg[0].a0_hi = xh; g.seg[0].a0_lo = xl; g.seg[0].c0 = cpad; g.seg[0].taps = k; g.seg[0].pad = (k - 1) / 2;
   g.nseg = 1; g.B = B; g.T_in = T;
   g.T_virt = up_T > 0 ? up_T : T;
@@ -2347,16 +2308,6 @@ static int op_linear(const float* x, const float* w, const float* bias, float* y
   HIPCHK(launch_pack_weight(s, hi, lo, K, st));
   if (pb) HIPCHK(launch_fold_bias(nullptr, bias, nullptr, pb, N, K, 0, 1, st));   // bias in the packed [32 a | 32 gate] column order
   GemmParams g{};
-  // fragment-major copies only while the BD tile is on (DVITS_GEMM_BD; off by default)
-  static const bool bd_env = [] { const char* e = getenv("DVITS_GEMM_BD"); return e && atoi(e) != 0; }();
-  if (bd_env && K % 64 == 0 && !geglu) {
-    bf16_t* fhi = sc.get<bf16_t>((size_t)Npad * K * 2, st, false);
-    bf16_t* flo = x3 ? sc.get<bf16_t>((size_t)Npad * K * 2, st, false) : nullptr;
-    if (!fhi || (x3 && !flo)) return dv_fail(DV_ERR_HIP, "%s: hipMalloc failed", what);
-    HIPCHK(launch_relayout_frag_cm(hi, fhi, Npad, K, 1, K, 1, 0, st));
-    if (x3) HIPCHK(launch_relayout_frag_cm(lo, flo, Npad, K, 1, K, 1, 0, st));
-    g.wf_hi = fhi; g.wf_lo = flo;
-  }
   g.seg[0].a0_hi = xh; g.seg[0].a0_lo = xl; g.seg[0].c0 = K; g.seg[0].taps = 1;
   g.nseg = 1; g.B = 1; g.T_in = g.T_out = g.T_virt = M; g.stride = 1;
   g.w_hi = hi; g.w_lo = lo; g.Kp = K; g.N_pad = Npad; g.bias = geglu ? pb : bias;

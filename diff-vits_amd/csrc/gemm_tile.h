@@ -1,9 +1,6 @@
 // Implicit-GEMM tile routine shared by the per-launch kernel (kernels_gemm.hip) and the persistent per-XCD schedule
 // (persist.hip).  See kernels_gemm.hip for the design notes.
 #pragma once
-#ifndef DV_BD_AH
-#define DV_BD_AH 3    // BD tile: slab chunks in flight (LDS: (AH + 1) slots of 18 KiB); 7 measured slower: the start-up burst delays the first chunk by ~5 k cycles
-#endif
 #ifndef DV_GEMM_EXP
 // development knob (trace experiments on the plain tile's k-loop, WRONG results): 1 = B fragments read from LDS once, not per
 // k-tile; 2 = 1 + no B DMA; 3 = 2 + A fragments read once; 4 = no DMA inside the loop at all.  0 in every shipped build
@@ -53,48 +50,28 @@ __device__ __forceinline__ unsigned cvt_pk_bf16(float lo, float hi) { return dv_
 // stores and takes a ticket from the tile's agent-scope counter; the first to arrive leaves, the second adds the
 // partner's dump (system-scope loads, after the atomic) and runs the epilogue.  No workgroup ever waits for another.
 // Measured: worth ~25 % on the K >= 1536 GEMMs of the 128-frame level, ~1 % of a forward.
-// BD ("B direct"): the tile of the stride-1 convs and linears whose channel counts are multiples of 64.  Measured on the
-// plain tile (trace builds with parts of the k-loop removed, profiles/r03_gemm_kloop_ablation_*.txt): its 64x64x64 k-tile takes
-// ~1100 cycles against 384 of MFMA although the waits for the DMA are ~zero - the loop is bound by LDS bandwidth (32 KiB of DMA
-// writes + 64 KiB of fragment reads per k-tile at 128 B/clk: every operand element is read by two waves), by the vector-memory
-// issue of 32 DMA instructions per k-tile, and by eight waves meeting at a barrier per k-tile in lock step (LDS reads, then
-// MFMAs).  BD removes the weights from LDS altogether and makes the activations cross it once per CHUNK instead of per tap:
-//   * W is read FRAGMENT-major (engine: k_relayout_frag copies) straight into registers, one coalesced 16-byte load per lane
-//     and plane per k-tile, DEPTH k-tiles ahead; the waves are laid out 1 x 2 (rows x columns) x 4 k-groups, so no two waves
-//     of a workgroup load the same weight fragment;
-//   * the k-range is walked CHUNK-major (segment -> concat half -> 64-channel chunk -> tap): a chunk's 64 rows (+ the two halo
-//     rows t0 - 1, t0 + 64 of a k = 3 conv) are DMA'd ONCE into a slab slot, AH chunks ahead, and the taps read it at row
-//     offsets -1 / 0 / +1: one barrier per chunk, 16.5 KiB of LDS writes + 32 KiB of reads per k-tile (k = 1) or per THREE
-//     k-tiles' worth of MFMAs... (k = 3: 16.5 + 96 KiB per three k-tiles);
-//   * per k-tile a wave issues 4 LDS reads, 6 MFMAs and 2 global loads (plain tile: 8 LDS reads, 6 MFMAs, 4 DMA instructions
-//     + their address arithmetic).
-// [Round 2's "AS" tile - the slab alone, weights still through the LDS ring, 2 x 2 waves - was slower than the plain tile and
-// is replaced by this one.]
-template <int BM, int BN, int BK, int WM, int WN, int NSPLIT, int KS, bool SC1, bool BD = false>
+template <int BM, int BN, int BK, int WM, int WN, int NSPLIT, int KS, bool SC1>
 __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int m0, const int n0, char* smem, const int ksel = 0) {
   constexpr int FM = BM / (WM * 32), FN = BN / (WN * 32);
   constexpr int NWQ = WM * WN;                       // waves per k-group (1, 2 or 4)
   constexpr int NWV = NWQ * KS;                      // waves per workgroup
-  static_assert(!BD || (BK == 64 && !SC1 && BM == 64 && BN == 64 && WM == 1 && WN == 2 && KS == 4),
-                "BD tile: 64 x 64 x 64, 1 x 2 waves x 4 k-groups, per-launch kernel");
-  constexpr bool CM = BD;                            // chunk-major k-tile order (no LDS ring)
   constexpr bool SPLIT = NSPLIT == 3;
   constexpr int NPL = SPLIT ? 2 : 1;                 // planes per operand
   constexpr int ROWB = BK * 2;                       // LDS row pitch (bytes), unpadded
   constexpr int CPR = ROWB / 16;                     // 16-byte chunks per row: 4 (BK=32) or 8 (BK=64)
   constexpr int RPI = 64 / CPR;                      // rows per wave-instruction
-  constexpr int A_PL = CM ? 0 : BM * ROWB, B_PL = BD ? 0 : BN * ROWB;  // bytes per plane tile in the ring (BD: no ring)
+  constexpr int A_PL = BM * ROWB, B_PL = BN * ROWB;  // bytes per plane tile in the ring
   constexpr int STAGE = (A_PL + B_PL) * NPL;
 #ifndef DV_NSTAGE_64
 #define DV_NSTAGE_64 4
 #endif
   // LDS ring depth: NSTAGE-1 tiles in flight (DV_NSTAGE_64: experiment knob for the 64x64 tiles' occupancy)
-  constexpr int NSTAGE = BD ? 1 : ((BM == 64 && BN == 64 && !SC1) ? DV_NSTAGE_64 : ((4 * STAGE <= 160 * 1024) ? 4 : 3));
-  constexpr int A_IPW = CM ? 0 : BM / RPI / NWV, B_IPW = BD ? 0 : BN / RPI / NWV;   // DMA instructions per wave per plane
-  constexpr int A_IPW1 = A_IPW ? A_IPW : 1, B_IPW1 = B_IPW ? B_IPW : 1;   // (array extents)
+  constexpr int NSTAGE = (BM == 64 && BN == 64 && !SC1) ? DV_NSTAGE_64 : ((4 * STAGE <= 160 * 1024) ? 4 : 3);
+  constexpr int A_IPW = BM / RPI / NWV, B_IPW = BN / RPI / NWV;   // DMA instructions per wave per plane
+  constexpr int A_IPW1 = A_IPW, B_IPW1 = B_IPW;
   constexpr int LPT = (A_IPW + B_IPW) * NPL;         // DMA instructions per thread per k-tile
-  constexpr int LPT_W = (DV_GEMM_EXP >= 2 && !CM) ? A_IPW * NPL : LPT;   // ... that the counted waits see (experiments)
-  static_assert((CM || BM % (RPI * NWV) == 0) && (BD || BN % (RPI * NWV) == 0), "tile rows must split over the waves");
+  constexpr int LPT_W = DV_GEMM_EXP >= 2 ? A_IPW * NPL : LPT;   // ... that the counted waits see (experiments)
+  static_assert(BM % (RPI * NWV) == 0 && BN % (RPI * NWV) == 0, "tile rows must split over the waves");
   DV_TRACE(0);
 #ifdef DV_GEMM_TRACING
   if (p.trace && threadIdx.x == 0 && blockIdx.x < 8192) {
@@ -159,49 +136,6 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int m0, con
   int kt0 = 0, nk = total_kt;                        // this launch's k-tiles: [kt0, kt0 + nk)
   if (p.sk_mode == 1 || p.sk_mode == 3) { kt0 = ksel * total_kt / p.sk_split; nk = (ksel + 1) * total_kt / p.sk_split - kt0; }
   if (p.sk_mode == 2) nk = 0;
-  // ---- BD: position in the chunk-major k-tile order (segment -> concat half -> 64-channel chunk -> tap), wave-uniform ----
-  // (BD: the segment's plane pointers ride along in scalar registers - a segment-descriptor load from argument memory
-  // inside the k-loop sits on every wave's critical path)
-  struct AfIt { int seg, half, col, tap, taps, c0, c1, kbase, pad; const bf16_t* h0; const bf16_t* l0; const bf16_t* h1; const bf16_t* l1; };
-  // (BD: both segment descriptors are read ONCE, with constant indices, into scalars and selected by value: with a
-  // dynamically indexed p.seg[] inside the unrolled k-loop hipcc kept the whole argument block in scratch memory)
-  const GemmSeg bd_s0 = BD ? p.seg[0] : GemmSeg{}, bd_s1 = BD ? p.seg[1] : GemmSeg{};
-  const int bd_kbase1 = BD ? bd_s0.taps * (bd_s0.c0 + bd_s0.c1) : 0;
-  auto af_enter = [&](AfIt& s) {
-    if (BD) {
-      const bool s1 = s.seg == 1 && p.nseg > 1;
-      s.taps = s1 ? bd_s1.taps : bd_s0.taps; s.c0 = s1 ? bd_s1.c0 : bd_s0.c0; s.c1 = s1 ? bd_s1.c1 : bd_s0.c1; s.pad = s1 ? bd_s1.pad : bd_s0.pad;
-      s.h0 = s1 ? bd_s1.a0_hi : bd_s0.a0_hi; s.l0 = s1 ? bd_s1.a0_lo : bd_s0.a0_lo;
-      s.h1 = s1 ? bd_s1.a1_hi : bd_s0.a1_hi; s.l1 = s1 ? bd_s1.a1_lo : bd_s0.a1_lo;
-      s.kbase = s.seg == 0 ? 0 : bd_kbase1;
-    }
-  };
-  auto af_next = [&](AfIt& s) {
-    if (++s.tap == s.taps) {
-      s.tap = 0; s.col += 64;
-      if (s.col == (s.half ? s.c1 : s.c0)) {
-        s.col = 0;
-        if (s.half == 0 && s.c1 > 0) s.half = 1;
-        else { s.half = 0; ++s.seg; af_enter(s); }
-      }
-    }
-  };
-  AfIt af0{};                                        // first tile of this workgroup's k-range
-  if (CM) {
-    af_enter(af0);
-    if (p.sk_mode == 3) {                            // the split point moves to the next chunk boundary (a slab is per chunk)
-      int cut = total_kt / p.sk_split;
-      if (BD) {   // inside the k = 3 run a range starts on a PAIR of chunks (the loop body): a multiple of 6 tiles
-        const int t3 = (bd_s0.taps == 3 ? 3 * ((bd_s0.c0 + bd_s0.c1) >> 6) : 0) + ((p.nseg > 1 && bd_s1.taps == 3) ? 3 * ((bd_s1.c0 + bd_s1.c1) >> 6) : 0);
-        if (cut < t3) cut = min(t3, (cut + 3) / 6 * 6);
-      }
-      AfIt s = af0;
-      for (int t = 0; t < cut; ++t) af_next(s);
-      while (s.tap != 0 && cut < total_kt) { af_next(s); ++cut; }
-      if (ksel == 0) { kt0 = 0; nk = cut; }
-      else { kt0 = cut; nk = total_kt - cut; af0 = s; }
-    }
-  }
   int ld_seg = 0, ld_tap = 0, ld_half = 0;
   const bf16_t* cur_hi; const bf16_t* cur_lo;
   int cur_ld, cur_col, cur_toff;
@@ -254,7 +188,7 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int m0, con
       if (SC1) glds16_sc1(asrc[u], st_base + (unsigned)(((q * NWV + wave) * RPI) * ROWB + pl * A_PL));
       else glds16(asrc[u], st_base + (unsigned)(((q * NWV + wave) * RPI) * ROWB + pl * A_PL));
     } else {
-      if (DV_GEMM_EXP >= 2 && !CM) return;
+      if (DV_GEMM_EXP >= 2) return;
       const int q = (u - A_IPW * NPL) / NPL, pl = (u - A_IPW * NPL) % NPL;
       const unsigned dst = st_base + (unsigned)(NPL * A_PL + ((q * NWV + wave) * RPI) * ROWB + pl * B_PL);
       glds16_s(reinterpret_cast<const char*>(pl ? p.w_lo : p.w_hi) + (b_kbase + (unsigned)kt * (BK * 2)), b_off32[q], dst);
@@ -273,93 +207,6 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int m0, con
       if (ld_seg < p.nseg) enter();
     }
   };
-  // ---- BD: slab slots [BM rows hi | BM rows lo | halo: row -1 hi, row BM hi, row -1 lo, row BM lo] ----
-  constexpr int BD_MAIN_PL = BM * ROWB, BD_SLOT = BD_MAIN_PL * NPL + 2048;   // (+ 1 KiB halo + 1 KiB target of the second producer's dummy)
-  constexpr int BD_AH = DV_BD_AH, BD_NSLOT = BD_AH + 1;     // chunks in flight; slot of chunk c + AH = slot of chunk c - 1 (finished)
-  constexpr int BD_DEPTH = 6;                        // weight units in flight per compute wave
-  constexpr int BD_PI = BM / RPI + 1;                // DMA instructions per producer wave per chunk (rows of one plane + halo / dummy)
-  static_assert(!BD || BD_PI * (BD_AH - 1) < 64, "producer wait count must fit vmcnt");
-  // chunks of this k-range: n3 with three taps, then n1 with one (launch_gemm checked the order and the alignment)
-  int bd_n3 = 0, bd_n1 = 0;
-  if (BD) {
-    const int t_s0 = bd_s0.taps * ((bd_s0.c0 + bd_s0.c1) >> 6), t_s1 = p.nseg > 1 ? bd_s1.taps * ((bd_s1.c0 + bd_s1.c1) >> 6) : 0;
-    const int lo0 = min(kt0, t_s0), hi0 = min(kt0 + nk, t_s0);                         // tiles of this range inside segment 0
-    const int lo1 = max(kt0, t_s0) - t_s0, hi1 = max(kt0 + nk, t_s0) - t_s0;           // ... inside segment 1
-    const int ch0 = (hi0 - lo0) / bd_s0.taps, ch1 = t_s1 > 0 ? (hi1 - lo1) / bd_s1.taps : 0;
-    if (bd_s0.taps == 3) bd_n3 += ch0; else bd_n1 += ch0;
-    if (t_s1 > 0) { if (bd_s1.taps == 3) bd_n3 += ch1; else bd_n1 += ch1; }
-  }
-  // ---- BD: the two PRODUCER waves (waves NWV, NWV + 1) ----
-  // They own the slab DMAs - wave NWV the hi plane and the halo lines, wave NWV + 1 the lo plane - so that the compute
-  // waves' vector-memory queues hold nothing but their weight units (compiler-visible loads, exact counted waits; with the
-  // DMAs in the same queue every weight wait also drained the slabs issued behind it).  A producer issues exactly BD_PI
-  // instructions per chunk (past the k-range: dummies from the zero page into the slot of a finished chunk), so "the slab
-  // of chunk c has landed" is the constant wait vmcnt(BD_PI * (AH - 1)); it then meets the compute waves at the chunk's
-  // barrier and issues the slab of chunk c + AH into the slot of chunk c - 1, which every wave has left.
-  if (BD && wave >= NWV) {
-    const int pw = wave - NWV;
-    const int b_item = m0 / p.T_out, t0 = m0 - b_item * p.T_out;
-    const size_t row0 = (size_t)b_item * p.T_in;
-    AfIt s_it = af0;
-    int s_left = nk, s_slot = 0;
-    // Lean issue (the producers' instruction count per chunk bounds the k = 1 runs): the per-lane byte offsets of the eight
-    // row groups inside a plane depend only on the plane's row pitch - recomputed when that changes (concat half / segment
-    // boundary) -, the plane's base + chunk column is a scalar pair, and a DMA is "scalar base + vector offset".
-    unsigned roff[BM / RPI], hoff = 0;
-    bool hok = false;
-    int cur_ld = -1;
-    auto set_pitch = [&](int ld) {
-      cur_ld = ld;
-#pragma unroll
-      for (int q = 0; q < BM / RPI; ++q) {
-        const int r = q * RPI + l_row;
-        roff[q] = (unsigned)(((t0 + r) * ld + ((l_slot ^ swz(r)) << 3)) * 2);
-      }
-      // halo rows t0 - 1 and t0 + BM of both planes: one lane-linear instruction (lanes 32.. repeat)
-      const int which = (lane >> 3) & 3, ch = lane & 7;
-      const int t = (which & 1) ? t0 + BM : t0 - 1;
-      hok = t >= 0 && t < p.T_in;                    // conv zero padding beyond the utterance
-      hoff = (unsigned)((t * ld + ch * 8) * 2);
-    };
-    auto slab = [&]() {
-      const bool real = s_left > 0;
-      const bf16_t* hi = s_it.half ? s_it.h1 : s_it.h0;
-      const bf16_t* lo = s_it.half ? s_it.l1 : s_it.l0;
-      const bf16_t* pl = pw ? lo : hi;
-      const int ld = s_it.half ? s_it.c1 : s_it.c0;
-      const unsigned dst0 = smem_base + (unsigned)(__builtin_amdgcn_readfirstlane(s_slot) * BD_SLOT);
-      if (real && pl != nullptr) {
-        if (ld != cur_ld) set_pitch(ld);
-        const char* base = reinterpret_cast<const char*>(pl) + (row0 * ld + s_it.col) * 2;
-#pragma unroll
-        for (int q = 0; q < BM / RPI; ++q) glds16_s(base, roff[q], dst0 + (unsigned)(pw * BD_MAIN_PL + (q * RPI) * ROWB));
-        if (pw == 0) {
-          const int which = (lane >> 3) & 3;
-          const bf16_t* hp = (which >> 1) ? lo : hi;
-          const bool ok = hok && hp != nullptr;
-          const void* src = ok ? (const void*)(reinterpret_cast<const char*>(hp) + (row0 * ld + s_it.col) * 2 + hoff) : (const void*)p.zero_page;
-          glds16(src, dst0 + (unsigned)(BD_MAIN_PL * NPL));
-        } else {
-          glds16(p.zero_page, dst0 + (unsigned)(BD_MAIN_PL * NPL + 1024));
-        }
-      } else {                                       // past the k-range (or no lo plane): BD_PI dummies, the count is what matters
-#pragma unroll
-        for (int q = 0; q < BD_PI; ++q) glds16(p.zero_page, dst0 + (unsigned)(BD_MAIN_PL * NPL + 1024));
-      }
-      if (real) { s_left -= s_it.taps; s_it.tap = s_it.taps - 1; af_next(s_it); }
-      s_slot = s_slot + 1 == BD_NSLOT ? 0 : s_slot + 1;
-    };
-    for (int j = 0; j < BD_AH; ++j) slab();
-    if (p.ln_stat && p.sk_mode != 1) __syncthreads();   // (the compute waves' LayerNorm-row barrier)
-    const int nch = bd_n3 + bd_n1;
-    for (int c = 0; c < nch; ++c) {
-      wait_vmcnt<BD_PI * (BD_AH - 1)>();               // slab c has landed: only the AH - 1 younger ones may be in flight
-      __builtin_amdgcn_s_barrier();                    // chunk c visible; every wave has left chunk c - 1
-      slab();
-    }
-    wait_vmcnt<0>();                                   // (the trailing dummies land before this wave ends: the compute waves'
-    return;                                            //  next barrier - they reuse the slots - completes only after that)
-  }
   auto issue = [&](int kt) {     // whole tile at once (prologue)
     if (a_fresh) prep_a();
     else prep_a_next();
@@ -367,7 +214,7 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int m0, con
     for (int u = 0; u < LPT; ++u) issue_unit(kt, u);
     advance();
   };
-  if (!CM && kt0 > 0) {                              // second k-half: move the source state to its first tile
+  if (kt0 > 0) {                                     // second k-half: move the source state to its first tile
     for (int t = 0; t < kt0; ++t) advance();
 #pragma unroll
     for (int q = 0; q < B_IPW; ++q) b_off[q] += (size_t)kt0 * (BK * 2);
@@ -417,7 +264,7 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int m0, con
   bf16x8 ahK[NKS][FM], alK[NKS][FM], bhK[NKS][FN], blK[NKS][FN];   // (DV_GEMM_EXP: fragments read once)
   bool exp_first = true;
   auto step = [&](int kt, auto issue_tag) {
-    constexpr bool ISSUE = decltype(issue_tag)::value && !(DV_GEMM_EXP == 4 && !CM);
+    constexpr bool ISSUE = decltype(issue_tag)::value && DV_GEMM_EXP != 4;
     const char* base = smem + (kt % NSTAGE) * STAGE;
     const char* a_hi = base;
     const char* a_lo = base + A_PL;
@@ -431,7 +278,7 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int m0, con
       for (int i = 0; i < FM; ++i) {
         const int row = (wm * FM + i) * 32 + l31;
         const int off = row * ROWB + ((chunk ^ swz(row)) << 4), off_lo = off;
-        if (DV_GEMM_EXP == 3 && !CM) {
+        if (DV_GEMM_EXP == 3) {
           if (exp_first) { ahK[ks0][i] = *reinterpret_cast<const bf16x8*>(a_hi + off); if (SPLIT) alK[ks0][i] = *reinterpret_cast<const bf16x8*>(a_lo + off_lo); }
           ah[ks0][i] = ahK[ks0][i]; if (SPLIT) al[ks0][i] = alK[ks0][i];
         } else {
@@ -443,7 +290,7 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int m0, con
       for (int j = 0; j < FN; ++j) {
         const int row = (wn * FN + j) * 32 + l31;
         const int off = row * ROWB + ((chunk ^ swz(row)) << 4);
-        if (DV_GEMM_EXP >= 1 && DV_GEMM_EXP <= 3 && !CM) {
+        if (DV_GEMM_EXP >= 1 && DV_GEMM_EXP <= 3) {
           if (exp_first) { bhK[ks0][j] = *reinterpret_cast<const bf16x8*>(b_hi + off); if (SPLIT) blK[ks0][j] = *reinterpret_cast<const bf16x8*>(b_lo + off); }
           bh[ks0][j] = bhK[ks0][j]; if (SPLIT) bl[ks0][j] = blK[ks0][j];
         } else {
@@ -491,7 +338,7 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int m0, con
   // column halves and EACH finishes 16 of the fragment's 32 columns (registers 0-7 of group 0, 8-15 of group 1: exactly the two
   // 16-column statistics blocks).  Workgroup-uniform; the cases it does not cover take the full path below.
   const bool al8 = ((p.N | p.ldo) & 7) == 0;        // row pitches of the bf16 planes are multiples of 16 bytes: 16-byte plane stores are aligned
-  constexpr bool HALF_OK = !BD && !SC1 && KS == 2 && FM == 1 && FN == 1;
+  constexpr bool HALF_OK = !SC1 && KS == 2 && FM == 1 && FN == 1;
   const bool half_mode = HALF_OK && p.sk_mode == 0 && vec4 && al8 && n0 + BN <= p.N && !p.stats && !p.rowstat_out &&
                          (p.epi == EPI_STORE || p.epi == EPI_RESIDUAL) && nk > 0;
   // padded row space (GemmParams Tv_out): rows [Tv_out, T_out) of every utterance do not exist - stored as zeros, kept out of
@@ -528,8 +375,8 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int m0, con
   };
 
   // residual operand of small tiles: fetched before the k-loop so its latency hides under it
-  constexpr bool PRE_RES = !BD && FM * FN <= 2;       // (BD: the 168-VGPR budget of a 640-thread workgroup has no room for it)
-  float rpre[PRE_RES ? (BD ? FN : FM * FN) * 16 : 1];   // (BD: a wave finishes ONE row fragment)
+  constexpr bool PRE_RES = FM * FN <= 2;
+  float rpre[PRE_RES ? FM * FN * 16 : 1];
   auto res_prefetch = [&]() __attribute__((always_inline)) {
   if (HALF_OK && half_mode) {                      // this wave's 16 columns: two 16-byte loads
     if (p.epi == EPI_RESIDUAL) {
@@ -545,15 +392,14 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int m0, con
   if (PRE_RES && p.epi == EPI_RESIDUAL && p.sk_mode != 1) {   // (mode 3: half of the workgroups prefetch in vain)
 #pragma unroll
     for (int i = 0; i < FM; ++i) {
-      if (BD && i != kgrp) continue;                 // (BD: k-group i finishes row fragment i)
       // (only the waves that will run this fragment's epilogue: with two k-groups and one row fragment the second group hands
       // its sums over and leaves - its prefetch was 16 KiB of loads per workgroup for nothing)
-      if (!BD && KS == 2 && ((FM % 2 == 0) ? ((i & 1) != kgrp) : (kgrp != 0))) continue;
+      if (KS == 2 && ((FM % 2 == 0) ? ((i & 1) != kgrp) : (kgrp != 0))) continue;
       const size_t ro = (size_t)min(m0 + (wm * FM + i) * 32 + l31, p.M - 1) * p.ldres;
 #pragma unroll
       for (int j = 0; j < FN; ++j) {
         const int nfj = n0 + (wn * FN + j) * 32;
-        float* dst = &rpre[(BD ? j : j * FM + i) * 16];
+        float* dst = &rpre[(j * FM + i) * 16];
         if (!SC1 && vec4 && nfj + 32 <= p.N) {       // (wave-uniform) whole fragment inside N: four unguarded 16-byte loads
           const float* rp = p.res + ro + nfj + 4 * lh;
 #pragma unroll
@@ -613,136 +459,6 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int m0, con
   // ---- main loop: wait(tile kt) -> barrier -> multiply tile kt with the DMA of tile kt+NSTAGE-1 interleaved ----
   // NSTAGE-1 tiles are in flight; the counted vmcnt leaves the younger ones outstanding across the barrier
   DV_TRACE(10);    // residual prefetch / LayerNorm rows / bias DMA issued
-  if constexpr (BD) {
-    // ---- BD k-loop (compute waves) ----
-    // The instruction count per k-tile is what bounds these loops (a SIMD issues one scalar / vector instruction of a
-    // wave every four cycles: the first BD version, with three generic k-iterators per tile, ran ~150 instructions per
-    // k-tile and was no faster than the plain tile).  Everything per-tile is therefore a constant or one add:
-    //   * W is stored fragment-major in THIS loop's tile order (chunk-major: engine, launch_relayout_frag_cm): the unit of
-    //     local tile t + 1 is 4 KiB behind the unit of tile t (uniform base pointer + per-lane offset).  The refills are
-    //     UNCONDITIONAL (past the range they re-read the last unit): only then can hipcc count its own waits exactly
-    //     (vmcnt(2 (DEPTH - 1))); with conditional refills it drained the queue once per loop body;
-    //   * the LDS offsets of the three row shifts (-1 / 0 / +1, halo lanes included) are per-lane constants, computed once;
-    //   * the k-range is a run of k = 3 chunks followed by a run of k = 1 chunks (either may be empty), each with its own
-    //     statically unrolled body (2 chunks x 3 taps / 6 chunks): the weight ring's register index is a constant;
-    //   * the slabs are the producer waves' business: a compute wave only meets them at the chunk's barrier.
-    constexpr int DEPTH = BD_DEPTH;
-    static_assert(DEPTH == 6, "bodies of 6 tiles");
-    struct BFrag { bf16x8 h, l; };
-    BFrag bq[DEPTH];
-    const int ksteps = p.Kp >> 4;
-    const size_t b_first = (((size_t)((n0 >> 5) + wn) * ksteps + (size_t)kt0 * 4 + kgrp) * 512) * 2;   // bytes
-    const char* const b_hi = reinterpret_cast<const char*>(p.wf_hi) + b_first;     // wave-uniform
-    const char* const b_lo = SPLIT ? reinterpret_cast<const char*>(p.wf_lo) + b_first : nullptr;
-    const unsigned b_lane = lane * 16;
-    const unsigned b_max = (unsigned)max(nk - 1, 0) * 4096u;
-    unsigned b_off = 0;
-    auto load_b = [&](BFrag& f) {
-      f.h = *reinterpret_cast<const bf16x8*>(b_hi + b_off + b_lane);
-      if (SPLIT) f.l = *reinterpret_cast<const bf16x8*>(b_lo + b_off + b_lane);
-      b_off = min(b_off + 4096u, b_max);
-    };
-    const int n3 = bd_n3, n1 = bd_n1;
-    // per-lane LDS offsets inside a slot: [row shift + 1][fragment]; rows -1 / BM live in the halo lines
-    int ao_hi[3][FM], ao_lo[3][FM];
-#pragma unroll
-    for (int d = 0; d < 3; ++d)
-#pragma unroll
-      for (int i = 0; i < FM; ++i) {
-        const int row = i * 32 + l31 + d - 1, chunk = kgrp * 2 + lh;
-        const bool inb = (unsigned)row < (unsigned)BM;
-        const int hoff = BD_MAIN_PL * NPL + (row < 0 ? 0 : ROWB) + (chunk << 4);
-        ao_hi[d][i] = inb ? row * ROWB + ((chunk ^ swz(row)) << 4) : hoff;
-        ao_lo[d][i] = inb ? ao_hi[d][i] + BD_MAIN_PL : hoff + 2 * ROWB;
-      }
-    // (pinned in order: hipcc's waits at the loop head are the minimum over both ways into the loop - a first unit whose
-    // lo plane was requested LAST here cost a near-drain of the queue per loop body)
-#pragma unroll
-    for (int j = 0; j < DEPTH; ++j) { load_b(bq[j]); __builtin_amdgcn_sched_barrier(0); }
-    DV_TRACE(1);
-    bf16x8 ah[2][FM], al[2][FM];
-    const char* slot = smem;                         // slab slot of the chunk being multiplied
-    int c_slot = 0;
-    auto read_a = [&](int buf, int d) {
-#pragma unroll
-      for (int i = 0; i < FM; ++i) {
-        ah[buf][i] = *reinterpret_cast<const bf16x8*>(slot + ao_hi[d][i]);
-        if (SPLIT) al[buf][i] = *reinterpret_cast<const bf16x8*>(slot + ao_lo[d][i]);
-      }
-    };
-    auto mul_tile = [&](BFrag& f, int buf) {
-#pragma unroll
-      for (int term = 0; term < NTERM; ++term)
-#pragma unroll
-        for (int i = 0; i < FM; ++i) {
-          if (SPLIT && term == 0) acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.h, al[buf][i], acc[i][0], 0, 0, 0);
-          else if (SPLIT && term == 1) acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.l, ah[buf][i], acc[i][0], 0, 0, 0);
-          else acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.h, ah[buf][i], acc[i][0], 0, 0, 0);
-        }
-      // pinned: without the scheduling barriers hipcc sinks the refill down to its use (load -> wait -> MFMA)
-      __builtin_amdgcn_sched_barrier(0);
-      load_b(f);
-      __builtin_amdgcn_sched_barrier(0);
-    };
-    auto close_chunk = [&]() {
-      c_slot = c_slot + 1 == BD_NSLOT ? 0 : c_slot + 1;
-      slot = smem + c_slot * BD_SLOT;
-    };
-#ifdef DV_GEMM_TRACING
-    bool tr_first = true;
-    unsigned long long tr_bar = 0, tr_mul = 0, tr_t0 = 0;
-#endif
-    // one k = 3 chunk on weight units u0 .. u0 + 2; one k = 1 chunk on unit u
-    auto chunk3 = [&](BFrag& f0, BFrag& f1, BFrag& f2) {
-#ifdef DV_GEMM_TRACING
-      tr_t0 = __builtin_amdgcn_s_memtime();
-#endif
-      __builtin_amdgcn_s_barrier();                  // this chunk's slab is visible (producer waves)
-#ifdef DV_GEMM_TRACING
-      if (tr_first) { DV_TRACE(2); tr_first = false; }
-      else tr_bar += __builtin_amdgcn_s_memtime() - tr_t0;
-      tr_t0 = __builtin_amdgcn_s_memtime();
-#endif
-      read_a(0, 0);
-      read_a(1, 1);
-      __builtin_amdgcn_sched_barrier(0);
-      mul_tile(f0, 0);
-      read_a(0, 2);
-      __builtin_amdgcn_sched_barrier(0);
-      mul_tile(f1, 1);
-      mul_tile(f2, 0);
-      close_chunk();
-#ifdef DV_GEMM_TRACING
-      tr_mul += __builtin_amdgcn_s_memtime() - tr_t0;
-#endif
-    };
-    auto chunk1 = [&](BFrag& f, int buf) {
-      __builtin_amdgcn_s_barrier();
-#ifdef DV_GEMM_TRACING
-      if (tr_first) { DV_TRACE(2); tr_first = false; }
-#endif
-      read_a(buf, 1);
-      __builtin_amdgcn_sched_barrier(0);
-      mul_tile(f, buf);
-      close_chunk();
-    };
-    // (full bodies carry no guards: only then are hipcc's counted weight waits exact at the loop heads.  n3 is even -
-    // launch_gemm's rule, also for both halves of a split-K pair -, so only the k = 1 run has a remainder, at the very end.)
-    for (int c3 = 0; c3 < n3; c3 += 2) { chunk3(bq[0], bq[1], bq[2]); chunk3(bq[3], bq[4], bq[5]); }
-    int c1 = 0;
-    for (; c1 + DEPTH <= n1; c1 += DEPTH) {
-#pragma unroll
-      for (int u = 0; u < DEPTH; ++u) chunk1(bq[u], u & 1);
-    }
-#pragma unroll
-    for (int u = 0; u < DEPTH; ++u)
-      if (c1 + u < n1) chunk1(bq[u], u & 1);
-#ifdef DV_GEMM_TRACING
-    if (p.trace && threadIdx.x == 0 && blockIdx.x < 8192) {   // k = 3 chunks after the first: cycles at the barrier | reading + multiplying
-      g_gemm_trace[blockIdx.x * DV_TR_W + 12] = 0; g_gemm_trace[blockIdx.x * DV_TR_W + 13] = tr_bar; g_gemm_trace[blockIdx.x * DV_TR_W + 14] = tr_mul;
-    }
-#endif
-  } else {
 #pragma unroll
   for (int t = 0; t < NSTAGE - 1; ++t) {
     if (t < nk) issue(t);
@@ -761,7 +477,7 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int m0, con
 #ifdef DV_GEMM_TRACING
     const unsigned long long tr0 = __builtin_amdgcn_s_memtime();
 #endif
-    wait_vmcnt<(DV_GEMM_EXP == 4 && !CM) ? 0 : (NSTAGE - 2) * LPT_W>();
+    wait_vmcnt<DV_GEMM_EXP == 4 ? 0 : (NSTAGE - 2) * LPT_W>();
 #ifdef DV_GEMM_TRACING
     const unsigned long long tr1 = __builtin_amdgcn_s_memtime();
 #endif
@@ -791,7 +507,6 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int m0, con
 #endif
     step(kt, std::false_type{});
   }
-  }   // (!BD)
 
   // ---- in-epilogue GroupNorm, first half (GnxParams, dv_common.h): wait for the statistics of the groups this tile's columns
   // belong to and build the tile's per-column affine in LDS (s_gA, s_gB); `nwa` = waves of the workgroup that are still here ----
@@ -855,12 +570,7 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int m0, con
           q += m2 + sx * sx / (double)(16 * cnt);    // = the block's sum of squares
         }
       }
-      if constexpr (BD) {
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o); q += __shfl_xor(q, o); }
-      } else {
-        s1 = wave_sum64(s1); q = wave_sum64(q);
-      }
+      s1 = wave_sum64(s1); q = wave_sum64(q);
       if (lane == 0) {
         const double n = (double)cpg * (double)p.Tv_out, mean = s1 / n;
         double var = q / n - mean * mean;
@@ -1027,34 +737,7 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int m0, con
       }
     }
   }
-  // BD (KS == 4, FM == 2): k-group i < FM collects row fragment i from the other three groups and runs its epilogue;
-  // k-groups 2 and 3 hand over and leave
-  if constexpr (BD) {
-    __builtin_amdgcn_s_barrier();                    // every wave is done reading the slabs
-    float* red = reinterpret_cast<float*>(smem);     // [k-group][fragment][16 registers][2 waves x 64 lanes]
-#pragma unroll
-    for (int i = 0; i < FM; ++i) {
-      if (i != kgrp) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) red[((kgrp * FM + i) * 16 + r) * (64 * NWQ) + wq * 64 + lane] = acc[i][0][r];
-      }
-    }
-    __syncthreads();
-    if (kgrp >= FM) return;
-#pragma unroll
-    for (int i = 0; i < FM; ++i) {
-      if (i == kgrp) {
-#pragma unroll
-        for (int g = 0; g < KS; ++g) {
-          if (g != kgrp) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][0][r] += red[((g * FM + i) * 16 + r) * (64 * NWQ) + wq * 64 + lane];
-          }
-        }
-      }
-    }
-  }
-  auto my_frag_row = [&](int i) { return BD ? (i == kgrp) : (!SPLIT_EPI || ((i & 1) == kgrp)); };
+  auto my_frag_row = [&](int i) { return !SPLIT_EPI || ((i & 1) == kgrp); };
   DV_TRACE(22);                                      // k-groups added up
   if (p.sk_mode == 3) {                              // fused split-K pair: hand over, or finish
     float4* d0 = reinterpret_cast<float4*>(p.sk_buf) + (size_t)ksel * sk_slice + sk_tile + wq * 64 + lane;
@@ -1110,7 +793,7 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int m0, con
 
   // ---- epilogue ----
   DV_TRACE(4);
-  const bool gnx = !SC1 && p.gnx.xchg != nullptr;   // (BD tiles too)
+  const bool gnx = !SC1 && p.gnx.xchg != nullptr;
   // store 4 consecutive columns of one row: fp32 and/or split bf16 planes
   auto store4 = [&](size_t o, int nb, const float* v) {
     if (vec4) {
@@ -1175,7 +858,7 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int m0, con
           v[r] = (a + ba[r]) * gelu_erf(gt + bg[r]);
         }
         // output column of packed `a` column nb: 32 per 64-column block; nb < N  <=>  oc-run inside N/2
-        if (!BD && vec4 && al8 && p.out_hi && !p.out && n0 + wn * 64 + 64 <= p.N) {   // (wave-uniform) whole block inside N: 16-byte plane stores
+        if (vec4 && al8 && p.out_hi && !p.out && n0 + wn * 64 + 64 <= p.N) {   // (wave-uniform) whole block inside N: 16-byte plane stores
           store_planes16(p.out_hi, p.out_lo, (size_t)m * p.ldo + blk * 32, lh, v);
         } else {
 #pragma unroll
@@ -1193,7 +876,7 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int m0, con
   // several tiles - the argument block went through scratch memory; the runtime flag keeps one body.]
 #pragma unroll
   for (int j = 0; j < FN; ++j) {
-    const bool full = !BD && vec4 && al8 && n0 + (wn * FN + j) * 32 + 32 <= p.N;
+    const bool full = vec4 && al8 && n0 + (wn * FN + j) * 32 + 32 <= p.N;
     const int nf = n0 + (wn * FN + j) * 32 + 4 * lh;   // column of g = 0, e = 0
     float bv[16], un[16];
 #pragma unroll
@@ -1201,7 +884,7 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int m0, con
       const float4 b4 = *reinterpret_cast<const float4*>(s_bias + (wn * FN + j) * 32 + 4 * lh + 8 * g);
       bv[4 * g] = b4.x; bv[4 * g + 1] = b4.y; bv[4 * g + 2] = b4.z; bv[4 * g + 3] = b4.w;
     }
-    if (BD || p.ln_stat) {
+    if (p.ln_stat) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int n = nf + 8 * (r >> 2) + (r & 3);
@@ -1221,7 +904,7 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int m0, con
       if (p.epi == EPI_RESIDUAL) {
         if (PRE_RES) {
 #pragma unroll
-          for (int r = 0; r < 16; ++r) rv[r] = rpre[(BD ? j : j * FM + i) * 16 + r];
+          for (int r = 0; r < 16; ++r) rv[r] = rpre[(j * FM + i) * 16 + r];
         } else if (full && !SC1) {
           const float* rp = p.res + (size_t)mc * p.ldres + nf;
 #pragma unroll
@@ -1235,21 +918,6 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int m0, con
       }
       // (one wave-uniform branch per step instead of sixteen selects each; same operations in the same order)
       float vv[16];
-      if constexpr (BD) {                            // (the BD tile, at its 168-register cap, keeps the compact per-value form)
-        const float2 st = p.ln_stat ? s_ln[rl] : make_float2(0.f, 1.f);
-        const float rmask = p.rowmask ? p.rowmask[mc] : 1.0f;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int n = nf + 8 * (r >> 2) + (r & 3);
-          float v = acc[i][j][r];
-          if (p.ln_stat) v = st.y * (v - st.x * un[r]);
-          v += bv[r];
-          if (p.epi == EPI_RESIDUAL) v += rv[r];
-          if (p.relu) v = fmaxf(v, 0.f);
-          v *= rmask;
-          vv[r] = (m_ok && n < p.N) ? v : 0.f;
-        }
-      } else {
 #pragma unroll
       for (int r = 0; r < 16; ++r) vv[r] = acc[i][j][r];
       if (p.ln_stat) {
@@ -1279,7 +947,6 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int m0, con
 #pragma unroll
         for (int r = 0; r < 16; ++r) vv[r] = (m_ok && nf + 8 * (r >> 2) + (r & 3) < p.N) ? vv[r] : 0.f;
       }
-      }   // (!BD)
       if (i == 0 && j == 0) DV_TRACE(16);            // bias / residual / LayerNorm applied (first fragment)
       if (gnx) {                                     // the values stay in registers for the normalising second pass
 #pragma unroll
@@ -1356,16 +1023,7 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int m0, con
         float a1[2] = {0.f, 0.f}, a2[2] = {0.f, 0.f};
 #pragma unroll
         for (int r = 0; r < 16; ++r) a1[r >> 3] += vv[r];
-        // (wave sums by DPP + scalar registers: dv_device.h; the BD tile, at its 168-register cap, keeps the shuffle butterflies)
-        auto wsum = [&](float v) {
-          if constexpr (BD) {
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-            return v;
-          } else {
-            return wave_sum64(v);
-          }
-        };
+        auto wsum = [&](float v) { return wave_sum64(v); };   // (DPP + scalar registers: dv_device.h)
         a1[0] = wsum(a1[0]); a1[1] = wsum(a1[1]);
         const float inv_n = padded ? 1.0f / (float)(16 * blk_cnt(mrow0)) : 1.0f / 512.0f;
         const float mb[2] = {a1[0] * inv_n, a1[1] * inv_n};
@@ -1388,7 +1046,7 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int m0, con
   DV_TRACE(18);                                      // statistics of every fragment written
   if (gnx) {
     // ---- GroupNorm of this GEMM's own output (GnxParams, dv_common.h) ----
-    gnx_table(BD ? NWQ * FM : ((KS == 2 && !SPLIT_EPI) ? NWQ : NWV));   // (waves still here)
+    gnx_table((KS == 2 && !SPLIT_EPI) ? NWQ : NWV);   // (waves still here)
 #pragma unroll
     for (int j = 0; j < FN; ++j) {
       const int cl = (wn * FN + j) * 32 + 4 * lh;    // tile-local column of g = 0, e = 0
@@ -1398,7 +1056,7 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int m0, con
         const int m = m0 + (wm * FM + i) * 32 + l31;
         if (m >= p.M) continue;
         const int nfr = n0 + (wn * FN + j) * 32;
-        if (!BD && al8 && nfr + 32 <= p.N) {           // (wave-uniform) the whole fragment: 16-byte plane stores
+        if (al8 && nfr + 32 <= p.N) {                  // (wave-uniform) the whole fragment: 16-byte plane stores
           float y[16];
 #pragma unroll
           for (int g = 0; g < 4; ++g) {
@@ -1423,7 +1081,7 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int m0, con
                         fmaf(acc[i][j][4 * g + 2], sa.z, sb.z), fmaf(acc[i][j][4 * g + 3], sa.w, sb.w)};
           if (p.gnx.silu) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) y[e] = BD ? y[e] / (1.0f + __expf(-y[e])) : y[e] * __builtin_amdgcn_rcpf(1.0f + __expf(-y[e]));
+            for (int e = 0; e < 4; ++e) y[e] = y[e] * __builtin_amdgcn_rcpf(1.0f + __expf(-y[e]));
           }
           const size_t o = (size_t)m * p.N + n0 + cl + 8 * g;
           const unsigned h01 = cvt_pk_bf16(y[0], y[1]), h23 = cvt_pk_bf16(y[2], y[3]);

@@ -970,22 +970,6 @@ __global__ __launch_bounds__(64) void k_relayout_frag(const bf16_t* __restrict__
   *reinterpret_cast<uint4*>(dst + ((size_t)(nf * ksteps + ks) * 64 + lane) * 8) = v;
 }
 
-// the same for the BD tile of k_gemm (gemm_tile.h): fragments in the k-order that tile WALKS - chunk-major: segment ->
-// 64-channel chunk of [c0 | c1] -> tap - instead of the packed order (segment -> tap -> channel), so that the weight unit
-// of the kernel's next k-tile is simply the next 4 KiB.  k-step ks_new = 4 * tile + sub  <-  ks_old = packed k / 16 + sub.
-__global__ __launch_bounds__(64) void k_relayout_frag_cm(const bf16_t* __restrict__ src, bf16_t* __restrict__ dst, int Kp, int ksteps,
-                                                         int taps0, int cc0, int taps1, int cc1) {
-  const int nf = blockIdx.x, ks = blockIdx.y, lane = threadIdx.x;
-  int tile = ks >> 2;
-  const int sub = ks & 3, nt0 = taps0 * (cc0 >> 6);
-  int koff;
-  if (tile < nt0) koff = (tile % taps0) * cc0 + (tile / taps0) * 64;
-  else { tile -= nt0; koff = taps0 * cc0 + (tile % taps1) * cc1 + (tile / taps1) * 64; }
-  const int ks_old = (koff >> 4) + sub;
-  const uint4 v = *reinterpret_cast<const uint4*>(src + (size_t)(nf * 32 + (lane & 31)) * Kp + ks_old * 16 + (lane >> 5) * 8);
-  *reinterpret_cast<uint4*>(dst + ((size_t)(nf * ksteps + ks) * 64 + lane) * 8) = v;
-}
-
 template <int NS, int AMODE, bool XA = false, bool SA = false, bool CS = false>
 hipError_t init_one() {
   const int smem = 2 * 2 * NS * CHUNK_PL + NS * 16384;
@@ -1049,14 +1033,6 @@ hipError_t launch_xbias(const float* mask_bias, float* out, int B, int L, int nT
 hipError_t launch_relayout_frag(const bf16_t* src, bf16_t* dst, int rows, int Kp, hipStream_t st) {
   if (rows % 32 != 0 || Kp % 16 != 0) return hipErrorInvalidValue;
   hipLaunchKernelGGL(k_relayout_frag, dim3(rows / 32, Kp / 16), dim3(64), 0, st, src, dst, Kp, Kp / 16);
-  return hipGetLastError();
-}
-
-hipError_t launch_relayout_frag_cm(const bf16_t* src, bf16_t* dst, int rows, int Kp, int taps0, int cc0, int taps1, int cc1, hipStream_t st) {
-  if (rows % 32 != 0 || Kp % 64 != 0 || taps0 < 1 || cc0 % 64 != 0 || cc0 <= 0 || (cc1 > 0 && (taps1 < 1 || cc1 % 64 != 0)) ||
-      taps0 * cc0 + (cc1 > 0 ? taps1 * cc1 : 0) != Kp)
-    return hipErrorInvalidValue;
-  hipLaunchKernelGGL(k_relayout_frag_cm, dim3(rows / 32, Kp / 16), dim3(64), 0, st, src, dst, Kp, Kp / 16, taps0, cc0, cc1 > 0 ? taps1 : 1, cc1);
   return hipGetLastError();
 }
 

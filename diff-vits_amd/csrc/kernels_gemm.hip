@@ -26,8 +26,8 @@
 #include <cstdlib>
 #include <type_traits>
 
-template <int BM, int BN, int BK, int WM, int WN, int NSPLIT, int KS, bool BD = false>
-__global__ __launch_bounds__(64 * WM * WN * KS + (BD ? 128 : 0)) void k_gemm(const GemmParams p) {   // (BD: + two producer waves)
+template <int BM, int BN, int BK, int WM, int WN, int NSPLIT, int KS>
+__global__ __launch_bounds__(64 * WM * WN * KS) void k_gemm(const GemmParams p) {
   extern __shared__ __attribute__((aligned(1024))) char smem[];
   // XCD-aware tile order (workgroup b runs on XCD b % 8; each XCD has its own L2, which starts cold): an XCD's workgroups
   // form a rectangle of the tile grid so that its L2 fetches (rows / xm) of A and (columns / xn) of W once.
@@ -68,7 +68,7 @@ __global__ __launch_bounds__(64 * WM * WN * KS + (BD ? 128 : 0)) void k_gemm(con
     }
     tm0 = (bid / n_tiles_n) * BM; tn0 = (bid % n_tiles_n) * BN;
   }
-  gemm_tile<BM, BN, BK, WM, WN, NSPLIT, KS, false, BD>(p, tm0, tn0, smem, ksel);
+  gemm_tile<BM, BN, BK, WM, WN, NSPLIT, KS, false>(p, tm0, tn0, smem, ksel);
 }
 
 template <int BM, int BN, int BK, int WM, int WN, int NSPLIT, int KS>
@@ -86,41 +86,6 @@ struct GemmCfg {
     return hipGetLastError();
   }
 };
-
-// BD tile (gemm_tile.h): weights fragment-major straight into registers, activations through per-chunk slab slots
-template <int NSPLIT>
-struct GemmCfgBD {
-  static constexpr int NPL = NSPLIT == 3 ? 2 : 1;
-  static constexpr int SMEM = ((DV_BD_AH + 1) * (64 * 128 * NPL + 2048)) > 65536 ? ((DV_BD_AH + 1) * (64 * 128 * NPL + 2048)) : 65536;   // BD_NSLOT slab slots (>= the 64 KiB k-group hand-over)
-  static hipError_t init() {
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm<64, 64, 64, 1, 2, NSPLIT, 4, true>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
-  }
-  static hipError_t launch(const GemmParams& p, hipStream_t st) {
-    const int tiles = (p.M / 64) * ((p.N + 63) / 64) * (p.sk_mode == 3 ? p.sk_split : 1);
-    hipLaunchKernelGGL((k_gemm<64, 64, 64, 1, 2, NSPLIT, 4, true>), dim3(tiles), dim3(640), SMEM, st, p);
-    return hipGetLastError();
-  }
-};
-// Can this GEMM run on the BD tile?  Fragment-major weights present, whole 64-channel chunks, 64-frame tiles inside one
-// utterance, plain row gather (stride 1, no upsample), k = 1 / 3 segments with 'same' padding, no GEGLU epilogue (its
-// [32 a | 32 gate] column blocks must sit in ONE wave; BD's waves own 32 columns).
-bool gemm_bd_supported(const GemmParams& p) {
-  if (!p.wf_hi || p.stride != 1 || p.up_mode != UP_NONE || p.T_in != p.T_out || p.T_out % 64 != 0 || p.M != p.B * p.T_out) return false;
-  if ((p.Tv_out > 0 && p.Tv_out != p.T_out) || (p.Tv_in > 0 && p.Tv_in != p.T_in)) return false;   // (no padded row spaces)
-  if (p.epi == EPI_GEGLU || p.sk_mode == 1 || p.sk_mode == 2 || p.Kp % 16 != 0 || p.N_pad % 64 != 0) return false;
-  int k_tot = 0;
-  for (int s2 = 0; s2 < p.nseg; ++s2) {
-    const GemmSeg& sg = p.seg[s2];
-    if (sg.c0 % 64 != 0 || sg.c1 % 64 != 0 || sg.c0 <= 0 || (sg.taps != 1 && sg.taps != 3) || sg.pad != (sg.taps - 1) / 2) return false;
-    if (!sg.a0_hi || (sg.c1 > 0 && !sg.a1_hi)) return false;
-    // the k = 3 run comes first and is walked two chunks per loop body (gemm_tile.h)
-    if (sg.taps == 3 && ((sg.c0 + sg.c1) / 64) % 2 != 0) return false;
-    if (s2 == 1 && sg.taps == 3 && p.seg[0].taps == 1) return false;
-    k_tot += sg.taps * (sg.c0 + sg.c1);
-  }
-  return k_tot == p.Kp;
-}
 
 template <int BM, int BN, int BK, int WM, int WN, int KS = 1>
 struct GemmTile {
@@ -190,8 +155,6 @@ hipError_t gemm_init() {
   hipError_t e = Tiles<32>::init();
   if (e != hipSuccess) return e;
   if ((e = Tiles<64>::init()) != hipSuccess) return e;
-  if ((e = GemmCfgBD<3>::init()) != hipSuccess) return e;
-  if ((e = GemmCfgBD<1>::init()) != hipSuccess) return e;
   return hipSuccess;
 }
 
@@ -253,10 +216,8 @@ int gemm_candidates(const GemmParams& p, int* out, int cap) {
 
 // environment knobs of launch_gemm that tests flip inside one process: re-read whenever an engine is prepared
 static int g_env_xn = [] { const char* e = getenv("DVITS_XCD_N"); return e ? atoi(e) : -1; }();
-static int g_env_bd = [] { const char* e = getenv("DVITS_GEMM_BD"); return e ? atoi(e) : 0; }();
 void gemm_env_refresh() {
   const char* e = getenv("DVITS_XCD_N"); g_env_xn = e ? atoi(e) : -1;
-  e = getenv("DVITS_GEMM_BD"); g_env_bd = e ? atoi(e) : 0;
 }
 
 // Tile (BM x BN) the shape heuristic of launch_gemm picks for a non-GEGLU GEMM (kept in step with
@@ -389,20 +350,6 @@ hipError_t launch_gemm(const GemmParams& pin, int precision, hipStream_t st) {
     p.seg[s].nkt = p.seg[s].taps * (p.seg[s].c0 + p.seg[s].c1) / bk;
   }
   if (ft != GT_AUTO) return bk == 64 ? Tiles<64>::launch_forced(p, x3, ft, st) : Tiles<32>::launch_forced(p, x3, ft, st);
-  {   // 64x64x64 tiles with fragment-major weights at hand: the BD tile (DVITS_GEMM_BD=0 keeps the plain tile: A/B runs)
-    int bm, bn;
-    gemm_pick_tile(p, bm, bn);
-    // OFF by default (DVITS_GEMM_BD unset / 0): measured in the forward it only wins for single-segment k = 3 convs with
-    // K >= 1920 (-5..7 % per launch) and loses below (start-up of the producer waves, 4-way k-group hand-over, an epilogue
-    // squeezed into 168 VGPRs): +-0 end to end - DESIGN.md section 4.  DVITS_GEMM_BD=1: those convs; =<n> > 2: single-segment
-    // k = 3 convs with packed K >= n; =2: every GEMM the tile can run (the parity tests).
-    const int k3 = p.seg[0].taps == 3 ? 3 * (p.seg[0].c0 + p.seg[0].c1) : 0;
-    const bool pays = g_env_bd == 2 || (g_env_bd == 1 ? (p.nseg == 1 && k3 >= 1920) : (p.nseg == 1 && k3 >= g_env_bd));
-    if (g_env_bd && pays && !big && bk == 64 && bm == 64 && bn == 64 && tune.ksplit && (!x3 || p.wf_lo) && gemm_bd_supported(p)) {
-      for (int s2 = 0; s2 < p.nseg; ++s2) p.seg[s2].nkt = p.seg[s2].taps * (p.seg[s2].c0 + p.seg[s2].c1) / 64;
-      return x3 ? GemmCfgBD<3>::launch(p, st) : GemmCfgBD<1>::launch(p, st);
-    }
-  }
   if (big) return tune.ksplit ? Tiles<32>::T0::launch(p, x3, st) : Tiles<32>::T0S::launch(p, x3, st);
   if (bk == 64) return Tiles<64>::launch(p, x3, tune.min_wg, tune.ksplit != 0, st);
   return Tiles<32>::launch(p, x3, tune.min_wg > 0 ? tune.min_wg : 1, false, st);

@@ -58,38 +58,6 @@ def test_conv1d(B, Cin, T, Cout, k, stride, up_T, prec):
     assert err < (1e-4 if prec == 0 else 2e-2), err
 
 
-def test_conv1d_bd_tile():
-    """The BD tile (gemm_tile.h: fragment-major weights straight into registers, activations through per-chunk slab slots
-    whose three taps read shifted rows, two producer waves; 1 x 2 waves x 4 k-groups).  Opt-in (DVITS_GEMM_BD, read once per
-    process: run in a child with =2, every GEMM the tile can take): stride-1 convs / linears with 64-multiples of channels and
-    64-frame tiles inside one utterance.  Against torch fp32 conv1d, incl. the utterance-edge halo rows (zero padding), N not
-    a multiple of the tile, k = 1, long K (every slab slot recycled several times) and the bf16 mode."""
-    import subprocess
-    import sys
-    code = r"""
-import numpy as np, torch, torch.nn.functional as F
-import diff_vits_amd
-from diff_vits_amd import _lib as L, synth
-cases = ((8, 384, 256, 384, 3, 0), (2, 128, 1024, 256, 3, 0), (4, 256, 128, 128, 3, 1), (1, 128, 64, 64, 3, 0), (8, 128, 1024, 128, 3, 0),
-         (2, 1024, 128, 512, 3, 0), (4, 1920, 256, 384, 1, 0), (2, 128, 64, 80, 3, 0), (3, 192, 192, 320, 1, 0), (1, 512, 64, 80, 3, 1))
-for (B, Cin, T, Cout, k, prec) in cases:
-    x = synth.normal(3, "x", (B, Cin, T)); w = synth.normal(3, "w", (Cout, Cin, k), 1.0 / np.sqrt(k * Cin)); b = synth.normal(3, "b", (Cout,), 0.1)
-    x, w, b = (a.astype(np.float32) for a in (x, w, b))
-    ref = F.conv1d(torch.from_numpy(x), torch.from_numpy(w), torch.from_numpy(b), padding=(k - 1) // 2)
-    y = torch.empty(ref.shape, device="cuda")
-    dx, dw, db = (torch.from_numpy(a).cuda() for a in (x, w, b))
-    L.check(L.lib().dv_op_conv1d(L.ptr(dx), L.ptr(dw), L.ptr(db), L.ptr(y), B, Cin, T, Cout, k, 1, 0, prec, None), "dv_op_conv1d")
-    torch.cuda.synchronize()
-    err = float(np.linalg.norm(y.cpu().numpy() - ref.numpy()) / np.linalg.norm(ref.numpy()))
-    assert err < (1e-4 if prec == 0 else 2e-2), (B, Cin, T, Cout, k, prec, err)
-print("ok")
-"""
-    env = dict(os.environ, DVITS_GEMM_BD="2")
-    r = subprocess.run([sys.executable, "-c", code], env=env, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
-                       capture_output=True, text=True, timeout=600)
-    assert r.returncode == 0 and "ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
-
-
 @pytest.mark.parametrize("M,K,N", [(100, 128, 384), (8192, 128, 1024), (1024, 2048, 512), (33, 32, 17)])
 def test_linear(M, K, N):
     L = _lib()

@@ -22,7 +22,7 @@ lib.dv_debug_gemm_trace.argtypes = [C.c_void_p, C.c_int]
 
 shapes = [(8192, 128, 128), (4096, 256, 2048), (1024, 3072, 512), (2048, 384, 3072), (2048, 1536, 384),
           (4096, 256, 256), (2048, 384, 384)]
-# "conv:BxTxCinxCoutxk" traces a conv1d (dv_op_conv1d; with DVITS_GEMM_BD=2 a stride-1 conv with 64-multiples of channels runs on the BD tile)
+# "conv:BxTxCinxCoutxk" traces a conv1d (dv_op_conv1d)
 conv_shapes = [tuple(int(v) for v in a[5:].split("x")) for a in sys.argv[1:] if a.startswith("conv:")]
 plain = [a for a in sys.argv[1:] if not a.startswith("conv:")]
 if plain:

@@ -49,7 +49,7 @@ def kloops(asm_path, sym_prefix="_Z6k_gemm"):
             seg = ins[lo:k + 1]
             mfma = sum(1 for s in seg if s.startswith("v_mfma"))
             dma = sum(1 for s in seg if s.startswith("global_load_lds"))
-            if mfma and dma:           # (one-wave tiles have no s_barrier; the BD tile's DMAs live in its producer waves' loops)
+            if mfma and dma:           # (one-wave tiles have no s_barrier)
                 cand.append((lo, k, m.group(1), len(seg), mfma, dma, sum(1 for s in seg if s.startswith("s_waitcnt") and "vmcnt(0)" in s)))
         # the steady-state k-loop = an innermost range (layout ranges of outer / unrelated back edges contain it)
         loops = [c[2:] for c in cand if not any(o is not c and c[0] <= o[0] and o[1] <= c[1] for o in cand)]
