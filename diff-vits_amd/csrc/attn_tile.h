@@ -211,6 +211,13 @@ __device__ __forceinline__ void attn_tile(const AttnParams& p, const int qblk, c
         const float ve0[4] = {a.x, a.y, a.z, a.w}, ve1[4] = {c.x, c.y, c.z, c.w};
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
+          if (SPLIT && DV_ATTN_PF16) {               // V as split fp16 (P enters P V as one fp16 plane: dv_device.h)
+            unsigned hw, lw;
+            dv_split_pk_f16(ve0[e], ve1[e], hw, lw);
+            *reinterpret_cast<unsigned*>(v_hi + (c4 + e) * VP + slot * 2) = hw;
+            *reinterpret_cast<unsigned*>(v_lo + (c4 + e) * VP + slot * 2) = lw;
+            continue;
+          }
           const unsigned hw = apk(ve0[e], ve1[e]);
           *reinterpret_cast<unsigned*>(v_hi + (c4 + e) * VP + slot * 2) = hw;
           if (SPLIT) *reinterpret_cast<unsigned*>(v_lo + (c4 + e) * VP + slot * 2) = apk(ve0[e] - bf_lo(hw), ve1[e] - bf_hi(hw));
@@ -324,6 +331,20 @@ __device__ __forceinline__ void attn_tile(const AttnParams& p, const int qblk, c
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb) {
         u32x4 hw, lw;
+        if (SPLIT && DV_ATTN_PF16) {
+          hw.x = dv_cvt_pk_f16(s[u][kb * 8 + 0], s[u][kb * 8 + 1]); hw.y = dv_cvt_pk_f16(s[u][kb * 8 + 2], s[u][kb * 8 + 3]);
+          hw.z = dv_cvt_pk_f16(s[u][kb * 8 + 4], s[u][kb * 8 + 5]); hw.w = dv_cvt_pk_f16(s[u][kb * 8 + 6], s[u][kb * 8 + 7]);
+          const dv_f16x8 ph16 = __builtin_bit_cast(dv_f16x8, hw);
+#pragma unroll
+          for (int nb = 0; nb < NB; ++nb) {
+            const int off = (nb * 32 + l31) * VP + (kb * 2 + lh) * 16;
+            const dv_f16x8 vh = *reinterpret_cast<const dv_f16x8*>(v_hi + off);
+            const dv_f16x8 vl = *reinterpret_cast<const dv_f16x8*>(v_lo + off);
+            o[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl, ph16, o[nb], 0, 0, 0);
+            o[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, ph16, o[nb], 0, 0, 0);
+          }
+          continue;
+        }
         hw.x = apk(s[u][kb * 8 + 0], s[u][kb * 8 + 1]); hw.y = apk(s[u][kb * 8 + 2], s[u][kb * 8 + 3]);
         hw.z = apk(s[u][kb * 8 + 4], s[u][kb * 8 + 5]); hw.w = apk(s[u][kb * 8 + 6], s[u][kb * 8 + 7]);
         const bf16x8 ph = __builtin_bit_cast(bf16x8, hw);

@@ -139,6 +139,31 @@ __device__ __forceinline__ unsigned dv_cvt_pk_bf16(float lo, float hi) {
   return __builtin_bit_cast(unsigned, __builtin_convertvector(v, dv_bf16x2));
 }
 
+// P V of the attention kernels (parity mode).  DV_ATTN_PF16 = 1 (default since round 4): the probabilities enter as ONE fp16
+// plane (11 significant bits, round to nearest even: v_cvt_pk_f16_f32) and V as split fp16 (hi + lo): two products
+// P Vhi + P Vlo on v_mfma_f32_32x32x16_f16.  [Rounds 1-3: P and V both split bf16, three products; the softmax loop is bound
+// by vector-ALU issue and a third of its work was splitting P.  P as ONE bf16 plane (8 bits) was measured in round 3: +1.9 %
+// end to end but 1e-4 of error per forward - rejected; fp16 keeps 8x the precision for the same instruction count.]
+// 0: the three-product split-bf16 form.  Writers of V^T fragments (kernels_chain.hip) and the kernels that multiply them agree
+// through this one macro.
+#ifndef DV_ATTN_PF16
+#define DV_ATTN_PF16 1
+#endif
+typedef _Float16 dv_f16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 dv_f16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ unsigned dv_cvt_pk_f16(float lo, float hi) {
+  const dv_f32x2 v = {lo, hi};
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, dv_f16x2));
+}
+// two floats -> packed fp16 pair `h` (round to nearest even) and the packed fp16 pair `l` of what the rounding left
+__device__ __forceinline__ void dv_split_pk_f16(float x0, float x1, unsigned& h, unsigned& l) {
+  const dv_f32x2 v = {x0, x1};
+  const dv_f16x2 hh = __builtin_convertvector(v, dv_f16x2);
+  const dv_f32x2 back = __builtin_convertvector(hh, dv_f32x2);
+  h = __builtin_bit_cast(unsigned, hh);
+  l = __builtin_bit_cast(unsigned, __builtin_convertvector(v - back, dv_f16x2));
+}
+
 // ---- cross-lane helpers ----
 // Sum over the 64 lanes of a wave, the same value in every lane, fixed order (deterministic): four DPP adds inside each row of 16
 // lanes, then the four row sums through scalar registers - instead of six dependent ds_bpermute round trips through the LDS

@@ -279,6 +279,20 @@ __global__ __launch_bounds__(64 * NW) void k_attention_frag(const AttnFragParams
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb) {
         u32x4 hw, lw;
+        if (SPLIT && DV_ATTN_PF16) {
+          // P as ONE fp16 plane, V as split fp16: O^T += Vlo^T P^T + Vhi^T P^T (dv_device.h DV_ATTN_PF16)
+          hw.x = dv_cvt_pk_f16(s[u][kb * 8 + 0], s[u][kb * 8 + 1]); hw.y = dv_cvt_pk_f16(s[u][kb * 8 + 2], s[u][kb * 8 + 3]);
+          hw.z = dv_cvt_pk_f16(s[u][kb * 8 + 4], s[u][kb * 8 + 5]); hw.w = dv_cvt_pk_f16(s[u][kb * 8 + 6], s[u][kb * 8 + 7]);
+          const dv_f16x8 ph = __builtin_bit_cast(dv_f16x8, hw);
+#pragma unroll
+          for (int nb = 0; nb < NB; ++nb) {
+            const dv_f16x8 vh = *reinterpret_cast<const dv_f16x8*>(vbase + (kb * NB + nb) * 1024 + lane * 16);
+            const dv_f16x8 vl = *reinterpret_cast<const dv_f16x8*>(vbase + (2 * NB + kb * NB + nb) * 1024 + lane * 16);
+            o[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl, ph, o[nb], 0, 0, 0);
+            o[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, ph, o[nb], 0, 0, 0);
+          }
+          continue;
+        }
         hw.x = apk(s[u][kb * 8 + 0], s[u][kb * 8 + 1]); hw.y = apk(s[u][kb * 8 + 2], s[u][kb * 8 + 3]);
         hw.z = apk(s[u][kb * 8 + 4], s[u][kb * 8 + 5]); hw.w = apk(s[u][kb * 8 + 6], s[u][kb * 8 + 7]);
         const bf16x8 ph = __builtin_bit_cast(bf16x8, hw);

@@ -439,10 +439,15 @@ __global__ __launch_bounds__((chain_pf_wave<NS, AMODE, XA, SA, CS>() ? NT_LAUNCH
               const float4 s23 = *reinterpret_cast<const float4*>(&s_ln[8 * g + 4 * lh + 2]);
               const float x0 = s01.y * (acc[ns][4 * g] - s01.x * uv) + bv, x1 = s01.w * (acc[ns][4 * g + 1] - s01.z * uv) + bv;
               const float x2 = s23.y * (acc[ns][4 * g + 2] - s23.x * uv) + bv, x3 = s23.w * (acc[ns][4 * g + 3] - s23.z * uv) + bv;
-              const unsigned h01 = pk(x0, x1), h23 = pk(x2, x3);
-              hp[2 * gg] = h01; hp[2 * gg + 1] = h23;
-              lp[2 * gg] = pk(x0 - __uint_as_float(h01 << 16), x1 - __uint_as_float(h01 & 0xffff0000u));
-              lp[2 * gg + 1] = pk(x2 - __uint_as_float(h23 << 16), x3 - __uint_as_float(h23 & 0xffff0000u));
+              if (DV_ATTN_PF16) {                    // V as split fp16 (dv_device.h)
+                dv_split_pk_f16(x0, x1, hp[2 * gg], lp[2 * gg]);
+                dv_split_pk_f16(x2, x3, hp[2 * gg + 1], lp[2 * gg + 1]);
+              } else {
+                const unsigned h01 = pk(x0, x1), h23 = pk(x2, x3);
+                hp[2 * gg] = h01; hp[2 * gg + 1] = h23;
+                lp[2 * gg] = pk(x0 - __uint_as_float(h01 << 16), x1 - __uint_as_float(h01 & 0xffff0000u));
+                lp[2 * gg + 1] = pk(x2 - __uint_as_float(h23 << 16), x3 - __uint_as_float(h23 & 0xffff0000u));
+              }
             }
             const size_t eo = ((((size_t)rb * (C / 32) + ns * 4 + wn) * 2 + kb) * 64 + lane) * 8;
             dv_st16(p.sa_vf_hi + eo, hw);
@@ -591,6 +596,17 @@ __global__ __launch_bounds__((chain_pf_wave<NS, AMODE, XA, SA, CS>() ? NT_LAUNCH
       for (int kb = 0; kb < 2; ++kb) {
         typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
         u32x4 hw, lw;
+        if (DV_ATTN_PF16) {                            // P as one fp16 plane, V as split fp16: two products (dv_device.h)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) hw[e] = dv_cvt_pk_f16(sc[kb * 8 + 2 * e], sc[kb * 8 + 2 * e + 1]);
+          const dv_f16x8 ph16 = __builtin_bit_cast(dv_f16x8, hw);
+#pragma unroll
+          for (int nb = 0; nb < NBv; ++nb) {
+            o[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(dv_f16x8, cur.vl[kb][nb]), ph16, o[nb], 0, 0, 0);
+            o[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(dv_f16x8, cur.vh[kb][nb]), ph16, o[nb], 0, 0, 0);
+          }
+          continue;
+        }
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const float x0 = sc[kb * 8 + 2 * e], x1 = sc[kb * 8 + 2 * e + 1];
@@ -952,7 +968,13 @@ __global__ __launch_bounds__(64) void k_kv_frag(const float* __restrict__ kv, bf
         v[j] = (key < L && ch < d) ? kv[((size_t)b * L + key) * 2 * C + C + h * d + ch] : 0.f;
       }
       const size_t e = (((bh * nT + t) * 2 + kb) * NBv + nb) * 64 + lane;
-      split8(v, vf_hi + e * 8, vf_lo + e * 8);
+      if (DV_ATTN_PF16) {                              // V as split fp16 (dv_device.h)
+        uint4 hw, lw;
+        dv_split_pk_f16(v[0], v[1], hw.x, lw.x); dv_split_pk_f16(v[2], v[3], hw.y, lw.y);
+        dv_split_pk_f16(v[4], v[5], hw.z, lw.z); dv_split_pk_f16(v[6], v[7], hw.w, lw.w);
+        *reinterpret_cast<uint4*>(vf_hi + e * 8) = hw;
+        *reinterpret_cast<uint4*>(vf_lo + e * 8) = lw;
+      } else split8(v, vf_hi + e * 8, vf_lo + e * 8);
     }
 }
 __global__ void k_xbias(const float* __restrict__ mb, float* __restrict__ out, int B, int L, int Lp) {

@@ -186,4 +186,10 @@ def test_attention(B, H, Tq, Tk, d, masked):
     L.check(L.lib().dv_op_attention(L.ptr(dq), L.ptr(dk), L.ptr(dv), L.ptr(dbias), L.ptr(o), B, H, Tq, Tk, d, None),
             "dv_op_attention")
     torch.cuda.synchronize()
-    assert rel_l2(o.cpu().numpy(), ref.numpy()) < 1e-5
+    # Round 4: the probabilities enter P V as ONE fp16 plane (11 significant bits, round to nearest even; V and both Q K^T
+    # operands stay split).  With zero-mean random V the rounding errors of P do not average out against the result (both are
+    # random-walk sums over the keys): a single attention sits at the rounding's own rms, 2^-12 / sqrt(3) = 1.4e-4 (measured
+    # 1.6-1.7e-4 on every shape here; 3e-6 with split-bf16 P).  Inside the denoiser the effect is 1.3e-5 -> 1.8e-5 of the
+    # reference output (profiles/r04_err_vs_goldens_p_fp16.txt; budget 1e-3).  DV_ATTN_PF16=0 builds restore the old form.
+    err = rel_l2(o.cpu().numpy(), ref.numpy())
+    assert err < 3e-4, err

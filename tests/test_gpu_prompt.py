@@ -88,7 +88,7 @@ def test_diffusion_encoder_native_sampler_loop(gold):
         a = dpm_solver.DPM_Solver(fn_native, ns, algorithm_type="dpmsolver++").sample(dx, steps=8, order=2, method="multistep")
         fn_calls = dpm_solver.model_wrapper(lambda xx, tt: m(xx, data, tt), ns, model_type="x_start")
         b = dpm_solver.DPM_Solver(fn_calls, ns, algorithm_type="dpmsolver++").sample(dx, steps=8, order=2, method="multistep")
-    assert torch.isfinite(a).all() and rel_l2(a.cpu().numpy(), b.cpu().numpy()) < 1e-5
+    assert torch.isfinite(a).all() and rel_l2(a.cpu().numpy(), b.cpu().numpy()) < 3e-5   # (graph vs call-by-call: same kernels, another order of the solver arithmetic; the fp16 P plane of round 4 turns a last-bit difference of x into ~1e-5 of the mel)
 
 
 # ---- NaturalSpeech2.sample orchestration on the HIP backend ------------------------------------

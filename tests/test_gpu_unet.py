@@ -1046,7 +1046,7 @@ def test_native_sampler_options_graph_equals_stepwise():
             a = make(fn, ns).sample(x.clone(), **opts)
             b, inter = make(fn, ns).sample(x.clone(), return_intermediate=True, **opts)
         assert len(inter) == 6 + 2 and torch.isfinite(a).all()
-        assert rel_l2(a.cpu().numpy(), b.cpu().numpy()) < 1e-5
+        assert rel_l2(a.cpu().numpy(), b.cpu().numpy()) < 3e-5   # (same kernels; see test_gpu_prompt.py on the fp16 P plane)
 
 
 def test_merged_ff_proj_out_matches_two_step(gold):
