@@ -524,22 +524,26 @@ def main():
         # these are the figures of the committed rocprofv3 --pmc passes over this same command (tools/pmc_roofline.py)
         traffic = traffic_src = hbm_gbps = mfma_util = None
         pmc_families = None
-        tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r03_pmc_roofline.json")
+        # (the newest committed evidence file: profiles/rNN_pmc_roofline.json)
+        import glob
+        cands = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r[0-9][0-9]_pmc_roofline.json")))
+        tpath = cands[-1] if cands else ""
+        tname = "profiles/" + os.path.basename(tpath)
         pj = None
-        if os.path.exists(tpath) and args.precision == "bf16x3" and (B, T, L) == (8, 1024, 256):
+        if tpath and args.precision == "bf16x3" and (B, T, L) == (8, 1024, 256):
             with open(tpath) as f:
                 pj = json.load(f)
         if pj is not None and not pmc_identity_ok(pj):
             from diff_vits_amd import _lib
-            traffic_src = ("stale: profiles/r03_pmc_roofline.json was collected on build %r, the loaded library is %r - PMC "
-                           "fields withheld" % (pj.get("build", {}).get("dv_version"), _lib.lib().dv_version().decode()))
+            traffic_src = ("stale: %s was collected on build %r, the loaded library is %r - PMC "
+                           "fields withheld" % (tname, pj.get("build", {}).get("dv_version"), _lib.lib().dv_version().decode()))
         elif pj is not None:
             traffic, hbm_gbps, mfma_util = (pj["gemm"][k] for k in ("hbm_bytes_per_launch", "hbm_gbps", "mfma_util"))
             pmc_families = {k: {kk: v[kk] for kk in ("launches", "avg_us_kernel_trace", "hbm_bytes_per_launch", "hbm_gbps", "mfma_util")}
                             for k, v in pj.items() if isinstance(v, dict) and "launches" in v}
-            traffic_src = ("profiles/r03_pmc_roofline.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, KiB; SQ_VALU_MFMA_BUSY_CYCLES / "
+            traffic_src = ("%s (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, KiB; SQ_VALU_MFMA_BUSY_CYCLES / "
                            "(1024 SIMDs x kernel duration x 2.4 GHz); separate passes, eager launches; build %s, git %s)"
-                           % (pj["build"].get("dv_version"), pj["build"].get("git_head")))
+                           % (tname, pj["build"].get("dv_version"), pj["build"].get("git_head")))
         result["roofline"] = {
             "bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
             "traffic": traffic, "traffic_source": traffic_src, "hbm_gbps": hbm_gbps, "mfma_util": mfma_util,

@@ -91,7 +91,7 @@ __device__ __forceinline__ void glds4_sc1(const void* gsrc, unsigned lds_dst) {
 }
 #ifndef DV_ATTN_PLO
 // 1: the probabilities P of an attention tile enter P V as split bf16 (hi + lo: three products); 0: as one bf16 (two products:
-// P_hi V_hi + P_hi V_lo) - experiment knob, see DESIGN.md
+// P_hi V_hi + P_hi V_lo) - experiment knob, see docs/HISTORY.md
 #define DV_ATTN_PLO 1
 #endif
 // Bulk result stores (activations, planes, fragments) of the epilogues: one place for their cache policy.  DV_WT_STORES=1
@@ -276,7 +276,7 @@ __device__ __forceinline__ void store_planes8(unsigned short* hi, unsigned short
 // GELU with the exact-erf definition (reference unet1d/activations / F.gelu default), erf by Abramowitz-Stegun 7.1.26
 // (|error| <= 1.5e-7): branch-free, one v_exp_f32 and one v_rcp_f32, ~20 issue slots instead of erff()'s two divergent
 // polynomial branches.  1 + erf is formed without cancellation on the negative side: measured max |error| of the GELU
-// 4.2e-7 over [-12, 12] (tools check in DESIGN.md), two orders below the split-bf16 product error.
+// 4.2e-7 over [-12, 12] (docs/HISTORY.md), two orders below the split-bf16 product error.
 __device__ __forceinline__ float gelu_erf(float v) {
   const float z = fabsf(v) * 0.70710678118654752440f;
   const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));

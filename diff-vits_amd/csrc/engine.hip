@@ -299,7 +299,7 @@ static bool autotune_on() {
 }
 
 // Prepare-time tile tuner.  The denoiser's GEMMs sit where per-workgroup fixed cost, rounds of workgroups and k-loop
-// efficiency trade against each other shape by shape, so every GEMM of the schedule is timed on its real
+// efficiency trade against each other shape by shape (docs/HISTORY.md §4), so every GEMM of the schedule is timed on its real
 // operands with each tile of the menu that can run it (and, where scratch was offered, with and without the split-K
 // pair), behind an L2 flush as in the real sequence (its inputs were written by the previous kernel and the L2 does
 // not survive a kernel boundary), and keeps the fastest.  ~0.1 s per prepare.  Off by default (DVITS_GEMM_AUTOTUNE=1):
@@ -508,7 +508,7 @@ struct Builder {
   // GroupNorm statistics of a GEMM output for its consumer are written by the GEMM's epilogue (k_gn_apply / the chain kernels /
   // the in-epilogue GroupNorm reduce them).  [Round 2 also had the CONSUMER conv normalise its own operand ("AF" tiles,
   // DVITS_FUSE_GN=1): parity-green but slower - an N-tiled conv repeats the elementwise GroupNorm + SiLU + hi/lo split of its
-  // rows in every 64-column tile - and removed in round 3; DESIGN.md section 4 keeps the measurements.]
+  // rows in every 64-column tile - and removed in round 3; docs/HISTORY.md section 4 keeps the measurements.]
   void alloc_stat(Act& a, bool want16 = false) {
     // 32-row blocks of the flat [B*Tp] row space must not span utterances: Tp % 32 == 0 (the padded row space of pitch()
     // makes that so for any T), or ONE utterance whose last block is partial (rows beyond M contribute zeros: the per-column

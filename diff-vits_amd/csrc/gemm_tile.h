@@ -49,7 +49,7 @@ __device__ __forceinline__ unsigned cvt_pk_bf16(float lo, float hi) { return dv_
 // Mode 3 (p.sk_ticket given, two slices) does both in ONE launch: each workgroup dumps its half with write-through
 // stores and takes a ticket from the tile's agent-scope counter; the first to arrive leaves, the second adds the
 // partner's dump (system-scope loads, after the atomic) and runs the epilogue.  No workgroup ever waits for another.
-// Measured: worth ~25 % on the K >= 1536 GEMMs of the 128-frame level, ~1 % of a forward.
+// Measured (docs/HISTORY.md §4): worth ~25 % on the K >= 1536 GEMMs of the 128-frame level, ~1 % of a forward.
 template <int BM, int BN, int BK, int WM, int WN, int NSPLIT, int KS, bool SC1>
 __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int m0, const int n0, char* smem, const int ksel = 0) {
   constexpr int FM = BM / (WM * 32), FN = BN / (WN * 32);

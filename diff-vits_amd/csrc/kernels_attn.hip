@@ -20,7 +20,7 @@
 // tiles are in flight, not by bandwidth.  Two 32-key sub-tiles are processed per iteration (one barrier).  Each pair is
 // converted fp32 -> split bf16 (K rows; V^T with the permuted key axis) once per workgroup, one iteration ahead of
 // the MFMAs, by ONE wave of each SIMD pair, and shared by the NW waves (32*NW queries).  The key loop is bound by
-// vector-ALU work (softmax, P -> hi + lo, the conversion), not by MFMA: see DESIGN.md and tools/attn_trace.py.
+// vector-ALU work (softmax, P -> hi + lo, the conversion), not by MFMA: see docs/HISTORY.md and tools/attn_trace.py.
 #include "dv_common.h"
 #define DV_ATTN_TRACE_OWNER   // the trace build's stamp buffer lives in this translation unit
 #include "attn_tile.h"

@@ -2,7 +2,7 @@
 // packing and conv_out) as ONE launch of 256 workgroups, one per CU.
 //
 // Why: with ~280 dependent launches per forward, each kernel boundary costs ~4 us of launch / drain / L2 write-back and
-// leaves the next kernel a cold L2 (profiles/r01_gemm_phase_trace.txt) - more than most of the
+// leaves the next kernel a cold L2 (docs/HISTORY.md §4, profiles/r01_gemm_phase_trace.txt) - more than most of the
 // contractions themselves.  The batch maps one-to-one onto the chip: utterance b is processed by XCD b % 8 (32 CUs,
 // its own 4 MB L2); utterances never exchange data (no BatchNorm, attention / norms are per utterance), so the only
 // synchronisation between consecutive operations is an XCD-LOCAL barrier (agent-scope atomic counter, ~1.2 us:

@@ -10,7 +10,7 @@
 // uni_pc.py:368-588; loops dpm_solver.py:1171-1213 and uni_pc.py:606-658), and executed as
 // steps x (UNet schedule + one fused lincomb kernel), captured into a hipGraph.
 //
-// Deviation from the reference, documented in DESIGN.md: the x0 -> noise -> x0 round trip of
+// Deviation from the reference, documented in DESIGN.md section 5: the x0 -> noise -> x0 round trip of
 // model_wrapper/data_prediction_fn (dpm_solver.py:290-292, 433-442) is algebraically the
 // identity and is not replayed.
 #include "../../include/dvits_hip.h"

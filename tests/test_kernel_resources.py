@@ -1,7 +1,7 @@
 """No kernel of the shipped library may use scratch (private-segment) memory: a spill inside a k-loop is a
 round trip through the slowest memory path of the chip for every lane.  Parsed from the code objects' metadata
 (`.private_segment_fixed_size`, tools/kernel_resources.py) - no GPU needed.  The only exceptions are named below: code
-paths that are off by default and measured slower, kept for their parity tests."""
+paths that are off by default and measured slower (docs/HISTORY.md section 4), kept for their parity tests."""
 import os
 import sys
 
