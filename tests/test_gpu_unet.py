@@ -424,6 +424,39 @@ def test_config2_full_size_sampler_steps_vs_oracle():
     assert err < 5e-4, err
 
 
+@pytest.mark.parametrize("solver,B,T,L,steps", [("dpm", 3, 300, 77, 8), ("unipc", 1, 300, 150, 8), ("dpm", 2, 75, 33, 10)])
+def test_native_sampler_odd_lengths_vs_oracle(solver, B, T, L, steps):
+    """The hipGraph-replayed loops on the padded row space (T = 300: 300 / 150 / 75 / 38 frames per level in row spaces of
+    320 / 160 / 96 / 64; the reference's own entry point, tts_infer.py, is exactly such a call) against the oracle's sampler
+    over the oracle's denoiser on the same inputs - ragged prompt masks, every evaluation's time-embedding rows taken from
+    the batched table; replayed twice, bit-equal."""
+    from diff_vits_amd import synth
+    from diff_vits_amd.sampler import dpm_solver, uni_pc
+    from oracle import sampler_ref, unet_ref
+    m, kw, sd = _bench_model()
+    x, cond, enc, mask = synth.make_inputs(B, 80, T, L, seed=4242, ragged_mask=B > 1)
+    betas = torch.from_numpy(synth.make_betas())
+    xt, ct, et, mt = (torch.from_numpy(a) for a in (x, cond, enc, mask))
+    mod = dpm_solver if solver == "dpm" else uni_pc
+    ns = mod.NoiseScheduleVP("discrete", betas=betas)
+    native = mod.NativeUNetModel(m, ct.cuda(), et.cuda(), mt.cuda())
+    fn = mod.model_wrapper(native, ns, model_type="x_start")
+    with torch.no_grad():
+        if solver == "dpm":
+            run = lambda: dpm_solver.DPM_Solver(fn, ns, algorithm_type="dpmsolver++").sample(   # noqa: E731
+                xt.cuda(), steps=steps, order=2, skip_type="time_uniform", method="multistep")
+        else:
+            run = lambda: uni_pc.UniPC(fn, ns, variant="bh2").sample(xt.cuda(), steps=steps, order=2)   # noqa: E731
+        out1, out2 = run(), run()
+        model = unet_ref.diffusion_model_fn({k: torch.from_numpy(v) for k, v in sd.items()}, oracle_cfg(kw), ct, et, mt)
+        ref = (sampler_ref.dpm_solver_pp_sample(model, betas, xt, steps, 2) if solver == "dpm"
+               else sampler_ref.unipc_sample(model, betas, xt, steps, 2))
+    assert torch.equal(out1, out2)
+    assert m.hip_engine().stats()[0] <= 170 and m.hip_engine().handover_status()[1] == 0
+    err = rel_l2(out1.cpu().numpy(), ref.numpy())
+    assert err < 5e-4, err
+
+
 def test_config4_longform_unipc_T2048():
     """BASELINE config 4: UniPC bh2, 20 steps, B=1, C=80, T=2048, L=256.  (a) one forward at T=2048
     against the oracle; (b) the hipGraph-replayed native loop equals the same compiled plan driven from
