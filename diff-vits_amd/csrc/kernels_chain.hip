@@ -257,7 +257,7 @@ __global__ __launch_bounds__((chain_pf_wave<NS, AMODE, XA, SA, CS>() ? NT_LAUNCH
   }
   BFrag bq[DEPTH];
   stage_prologue(p.w1_hi, p.w1_lo, 0, bq, std::integral_constant<int, NS>{});   // the first weight fragments fly under the A operand's arrival / conversion
-  if (!PFW && !XA && DV_CHAIN_PFMODE == 2) l2_prefetch(wave, NWV);
+  if (!PFW && !XA && DV_CHAIN_PFMODE == 2) l2_prefetch(wave, NWV);   // (XA kernels: measured +-0 with it, round 4)
   if (AMODE == 1) {
     // GroupNorm of the fp32 rows, once per row-block: table of this utterance, then convert
     const int T = p.T, b_item = m0 / T, Tv = p.Tv > 0 ? p.Tv : T;   // row pitch / frames that exist (padded row spaces)
@@ -564,17 +564,14 @@ __global__ __launch_bounds__((chain_pf_wave<NS, AMODE, XA, SA, CS>() ? NT_LAUNCH
       KVT nxt = load_kv(t + 1);
       __builtin_amdgcn_sched_barrier(0);
       f32x16 sc;
+      // (the key bias IS the initial accumulator: no add behind the MFMAs, 12 VGPRs fewer)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) sc[r] = 0.f;
+      for (int g = 0; g < 4; ++g) { sc[4 * g] = cur.bv[g].x; sc[4 * g + 1] = cur.bv[g].y; sc[4 * g + 2] = cur.bv[g].z; sc[4 * g + 3] = cur.bv[g].w; }
 #pragma unroll
       for (int ks = 0; ks < KSq; ++ks) {
         sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cur.kl[ks], qh[ks], sc, 0, 0, 0);
         sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cur.kh[ks], ql[ks], sc, 0, 0, 0);
         sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cur.kh[ks], qh[ks], sc, 0, 0, 0);
-      }
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        sc[4 * g] += cur.bv[g].x; sc[4 * g + 1] += cur.bv[g].y; sc[4 * g + 2] += cur.bv[g].z; sc[4 * g + 3] += cur.bv[g].w;
       }
       float tmax = m_run;
 #pragma unroll
