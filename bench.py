@@ -588,7 +588,7 @@ def main():
             print(json.dumps(result))
             raise SystemExit("bench: UNet output differs from the oracle by %.3e (rel-L2) / %.3e (max-abs-rel) > %.0e"
                              % (par["unet_rel_l2"], par["unet_max_abs_rel"], PARITY_TOL))
-    if world == 1 and not dry and not args.no_other_configs and (B, T, L) == (8, 1024, 256):
+    if world == 1 and not dry and not args.no_other_configs and not args.no_roofline and (B, T, L) == (8, 1024, 256):
         y_ref_ = locals().get("y_ref")
         result.setdefault("extra", {}).update(other_configs(dev, model, sd, args.precision, S, y_ref_))
     print(json.dumps(result))

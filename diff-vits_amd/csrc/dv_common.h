@@ -162,6 +162,10 @@ struct ChainParams {
   //      key(kb, lh, j) = kb*16 + (j < 4 ? 4 lh + j : 8 + 4 lh + j - 4) - the order of a score accumulator's registers
   // out2 then receives the query columns only (ldo2 >= C).
   bf16_t* sa_kf_hi; bf16_t* sa_kf_lo; bf16_t* sa_vf_hi; bf16_t* sa_vf_lo;
+  // Cross-attention tail on TWO workgroups per row block (nsplit = 2 with xa_kf_hi, C = 256): heads 0-3 / 4-7, two waves per
+  // head (key tiles of either parity), stage 3 as a 2-way K split handed over like the fused split-K pair of k_gemm:
+  // xs_buf >= (M / 32) * 2 * C * 32 floats of scratch, xs_ticket = M / 32 arrival counters (zero between launches)
+  float* xs_buf; unsigned* xs_ticket;
   // amode 1: workgroups per row block (0 / 1: one).  2 or 3: the stage-2 passes are shared out between them, each
   // repeating stage 1 - for launches with fewer row blocks than CUs (every workgroup streams the weights it multiplies)
   int nsplit;

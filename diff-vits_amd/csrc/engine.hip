@@ -1041,7 +1041,18 @@ struct Builder {
           cp.xa_qscale = (1.0f / sqrtf((float)cp.xa_d)) * 1.44269504088896340736f;
           cp.w3_hi = w_o2->fhi; cp.w3_lo = w_o2->flo; cp.b3 = w_o2->bias;
           cp.out3 = h3; cp.out3_hi = l3.pl.hi; cp.out3_lo = l3.pl.lo; cp.rowstat3 = l3.stat;
-          chain(ops, cp, "to_out+res+LN+to_q+xattn+to_out+res");
+          {   // C = 256 with few row blocks (M = 4096 at the bench shape: 128 for 256 CUs): two workgroups per row block, heads
+              // 0-3 / 4-7, two waves per head, stage 3 handed over like a fused split-K pair (DVITS_CHAIN_XSPLIT=0: one)
+            const char* es = getenv("DVITS_CHAIN_XSPLIT");
+            const int rbs = M / 32, cus = n_cu > 0 ? n_cu : 256;
+            if (!(es && es[0] == '0') && C == 256 && rbs * 2 <= cus && rbs <= 4096 && (dry || u->sk_tickets)) {
+              cp.nsplit = 2;
+              cp.xs_buf = alloc((size_t)rbs * 2 * C * 32);
+              cp.xs_ticket = dry ? reinterpret_cast<unsigned*>(0x1000) : u->sk_tickets;
+            }
+          }
+          chain(ops, cp, cp.nsplit == 2 ? "to_out+res+LN+to_q+xattn(2 wg)+to_out+res" : "to_out+res+LN+to_q+xattn+to_out+res");
+          if (cp.xs_buf) release(cp.xs_buf);
           if (!dry) { u->flops += 4.0 * B * u->cfg.num_heads * (double)Tp * L * cp.xa_d + 2.0 * (double)M * C * C; }
         }
         release(ao); release(h);

@@ -153,30 +153,34 @@ __global__ __launch_bounds__((chain_pf_wave<NS, AMODE, XA, SA, CS>() ? NT_LAUNCH
   // load per lane each from the fragment-major weights
   constexpr int KSTEPS = C / 16, KH = KSTEPS / 2, U = NS * KH;
   struct BFrag { bf16x8 h, l; };
-  auto load_unit = [&](const bf16_t* wf_hi, const bf16_t* wf_lo, int frag0, int u, auto nsx_tag) {
+  // (kh_tag / ks0: the stage's k-range is k-steps [ks0, ks0 + 2 * KHX), KHX per k-group - the whole K (KHX = KH, ks0 = 0)
+  // except in stage 3 of a head-split cross-attention launch, where a workgroup multiplies its own heads' half of K)
+  using KHfull = std::integral_constant<int, KH>;
+  auto load_unit = [&](const bf16_t* wf_hi, const bf16_t* wf_lo, int frag0, int u, auto nsx_tag, auto kh_tag, int ks0) {
     constexpr int NSX = decltype(nsx_tag)::value;   // fragments per wave in this stage (NS, or 1 in a column-split stage)
-    const int ks = kg * KH + u / NSX, nf = frag0 + (u % NSX) * 4 + wn;
+    constexpr int KHX = decltype(kh_tag)::value;
+    const int ks = ks0 + kg * KHX + u / NSX, nf = frag0 + (u % NSX) * 4 + wn;
     const size_t e = ((size_t)(nf * KSTEPS + ks) * 64 + lane) * 8;
     BFrag f;
     f.h = *reinterpret_cast<const bf16x8*>(wf_hi + e);
     f.l = *reinterpret_cast<const bf16x8*>(wf_lo + e);
     return f;
   };
-  auto stage_prologue = [&](const bf16_t* wf_hi, const bf16_t* wf_lo, int frag0, BFrag (&bq)[DEPTH], auto nsx_tag) __attribute__((always_inline)) {
-    constexpr int NSX = decltype(nsx_tag)::value;
+  auto stage_prologue = [&](const bf16_t* wf_hi, const bf16_t* wf_lo, int frag0, BFrag (&bq)[DEPTH], auto nsx_tag, auto kh_tag, int ks0) __attribute__((always_inline)) {
+    constexpr int NSX = decltype(nsx_tag)::value, KHX = decltype(kh_tag)::value;
 #pragma unroll
     for (int j = 0; j < DEPTH; ++j)
-      if (j < NSX * KH) bq[j] = load_unit(wf_hi, wf_lo, frag0, j, nsx_tag);
+      if (j < NSX * KHX) bq[j] = load_unit(wf_hi, wf_lo, frag0, j, nsx_tag, kh_tag, ks0);
     __builtin_amdgcn_sched_barrier(0);
   };
   // swap_tag: the activations are the FIRST MFMA operand - the accumulator is then the tile itself, lane = output column,
   // registers = rows 8g + 4lh + e (used for V: that register image IS the V^T operand fragment of the attention kernel)
-  auto stage_loop = [&](const bf16_t* wf_hi, const bf16_t* wf_lo, int frag0, BFrag (&bq)[DEPTH], f32x16 (&acc)[NS], auto swap_tag, auto nsx_tag) __attribute__((always_inline)) {
+  auto stage_loop = [&](const bf16_t* wf_hi, const bf16_t* wf_lo, int frag0, BFrag (&bq)[DEPTH], f32x16 (&acc)[NS], auto swap_tag, auto nsx_tag, auto kh_tag, int ks0) __attribute__((always_inline)) {
     constexpr bool SWAP = decltype(swap_tag)::value;
-    constexpr int NSX = decltype(nsx_tag)::value, UX = NSX * KH;
+    constexpr int NSX = decltype(nsx_tag)::value, KHX = decltype(kh_tag)::value, UX = NSX * KHX;
     // A fragment of k-step ksl (this wave's k-half): read one k-step ahead of its MFMAs (LDS latency off the chain)
     auto read_a = [&](int ksl, bf16x8& h, bf16x8& l) {
-      const int c16 = (kg * KH + ksl) * 2 + lh;                    // 16-byte chunk of the row: k-step * 2 + half
+      const int c16 = (ks0 + kg * KHX + ksl) * 2 + lh;             // 16-byte chunk of the row: k-step * 2 + half
       const int off = (c16 >> 3) * CHUNK_PL + l31 * 128 + (((c16 & 7) ^ swz(l31)) << 4);
       h = *reinterpret_cast<const bf16x8*>(a_reg + off);
       l = *reinterpret_cast<const bf16x8*>(a_reg + A_PL + off);
@@ -186,7 +190,7 @@ __global__ __launch_bounds__((chain_pf_wave<NS, AMODE, XA, SA, CS>() ? NT_LAUNCH
 #pragma unroll
     for (int u = 0; u < UX; ++u) {
       const int ksl = u / NSX, cur = ksl & 1;
-      if (u % NSX == 0 && ksl + 1 < KH) read_a(ksl + 1, ah[cur ^ 1], al[cur ^ 1]);
+      if (u % NSX == 0 && ksl + 1 < KHX) read_a(ksl + 1, ah[cur ^ 1], al[cur ^ 1]);
       const BFrag f = bq[u % DEPTH];
       if (SWAP) {
         acc[u % NSX] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[cur], f.h, acc[u % NSX], 0, 0, 0);
@@ -199,7 +203,7 @@ __global__ __launch_bounds__((chain_pf_wave<NS, AMODE, XA, SA, CS>() ? NT_LAUNCH
       }
       // pinned: without the scheduling barriers hipcc sinks every prefetch down to its use (load -> vmcnt(0) -> MFMA)
       __builtin_amdgcn_sched_barrier(0);
-      if (u + DEPTH < UX) bq[u % DEPTH] = load_unit(wf_hi, wf_lo, frag0, u + DEPTH, nsx_tag);
+      if (u + DEPTH < UX) bq[u % DEPTH] = load_unit(wf_hi, wf_lo, frag0, u + DEPTH, nsx_tag, kh_tag, ks0);
       __builtin_amdgcn_sched_barrier(0);
     }
   };
@@ -256,7 +260,7 @@ __global__ __launch_bounds__((chain_pf_wave<NS, AMODE, XA, SA, CS>() ? NT_LAUNCH
     }
   }
   BFrag bq[DEPTH];
-  stage_prologue(p.w1_hi, p.w1_lo, 0, bq, std::integral_constant<int, NS>{});   // the first weight fragments fly under the A operand's arrival / conversion
+  stage_prologue(p.w1_hi, p.w1_lo, 0, bq, std::integral_constant<int, NS>{}, KHfull{}, 0);   // the first weight fragments fly under the A operand's arrival / conversion
   if (!PFW && !XA && DV_CHAIN_PFMODE == 2) l2_prefetch(wave, NWV);   // (XA kernels: measured +-0 with it, round 4)
   if (AMODE == 1) {
     // GroupNorm of the fp32 rows, once per row-block: table of this utterance, then convert
@@ -340,12 +344,12 @@ __global__ __launch_bounds__((chain_pf_wave<NS, AMODE, XA, SA, CS>() ? NT_LAUNCH
   for (int ns = 0; ns < NS; ++ns)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[ns][r] = 0.f;
-  stage_loop(p.w1_hi, p.w1_lo, 0, bq, acc, std::false_type{}, std::integral_constant<int, NS>{});
+  stage_loop(p.w1_hi, p.w1_lo, 0, bq, acc, std::false_type{}, std::integral_constant<int, NS>{}, KHfull{}, 0);
   DV_CTRACE(3);
   // the second GEMM's first fragments fly during the hand-over and the epilogue
   using Ns2 = std::integral_constant<int, CS ? 1 : NS>;
   const int cs_frag0 = CS ? part * 4 : 0;          // column split: this part's fragment group
-  stage_prologue(p.w2_hi, p.w2_lo, ps_lo * (C / 32) + cs_frag0, bq, Ns2{});
+  stage_prologue(p.w2_hi, p.w2_lo, ps_lo * (C / 32) + cs_frag0, bq, Ns2{}, KHfull{}, 0);
   kgroup_reduce(acc, red_reg);                     // (its leading barrier: every wave is done reading the A operand)
   DV_CTRACE(4);
   // epilogue 1 (k-group 0): x1 = acc + b1 (+ res) -> out1 fp32, raw split planes into the A region, row partials
@@ -366,7 +370,9 @@ __global__ __launch_bounds__((chain_pf_wave<NS, AMODE, XA, SA, CS>() ? NT_LAUNCH
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const int n = nf + 8 * g;
-        if (part == 0) dv_st16(p.out1 + (size_t)m * C + n, make_float4(vv[4 * g], vv[4 * g + 1], vv[4 * g + 2], vv[4 * g + 3]));
+        // (XA with two workgroups per row block: BOTH write x1 - identical bits - because whichever finishes reads it back as
+        // the stage-3 residual)
+        if (part == 0 || (XA && CS)) dv_st16(p.out1 + (size_t)m * C + n, make_float4(vv[4 * g], vv[4 * g + 1], vv[4 * g + 2], vv[4 * g + 3]));
         uint2 hw, lw;
         hw.x = pk(vv[4 * g], vv[4 * g + 1]); hw.y = pk(vv[4 * g + 2], vv[4 * g + 3]);
         lw.x = pk(vv[4 * g] - __uint_as_float(hw.x << 16), vv[4 * g + 1] - __uint_as_float(hw.x & 0xffff0000u));
@@ -413,9 +419,9 @@ __global__ __launch_bounds__((chain_pf_wave<NS, AMODE, XA, SA, CS>() ? NT_LAUNCH
     for (int ns = 0; ns < NS; ++ns)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[ns][r] = 0.f;
-    stage_loop(p.w2_hi, p.w2_lo, ps * (C / 32) + cs_frag0, bq, acc, std::integral_constant<bool, MODE == 2>{}, Ns2{});
+    stage_loop(p.w2_hi, p.w2_lo, ps * (C / 32) + cs_frag0, bq, acc, std::integral_constant<bool, MODE == 2>{}, Ns2{}, KHfull{}, 0);
     if (ps == 0) DV_CTRACE(6);
-    if (ps + 1 < npass) stage_prologue(p.w2_hi, p.w2_lo, (ps + 1) * (C / 32) + cs_frag0, bq, Ns2{});
+    if (ps + 1 < npass) stage_prologue(p.w2_hi, p.w2_lo, (ps + 1) * (C / 32) + cs_frag0, bq, Ns2{}, KHfull{}, 0);
     kgroup_reduce(acc, red_reg);
     if (ps == 0) DV_CTRACE(7);
     if (MODE == 2) {
@@ -512,11 +518,19 @@ __global__ __launch_bounds__((chain_pf_wave<NS, AMODE, XA, SA, CS>() ? NT_LAUNCH
     // ================= cross attention: wave h = head h, 32 queries, keys / values as MFMA fragments from global =================
     // Same arithmetic as k_attention (attn_tile.h): S^T = K Q^T and O^T += V^T P^T with split-bf16 operands (3 products),
     // scores in the log2 domain, online softmax lane-local (lane = query, registers = keys), P never leaves registers.
-    stage_prologue(p.w3_hi, p.w3_lo, 0, bq, std::integral_constant<int, NS>{});   // the output projection's first weight fragments fly under the attention
+    // XS (XA with CS: two workgroups per row block, `part` = 0 / 1): this workgroup runs heads 4 part .. 4 part + 3 - the columns
+    // its stage 2 produced - with TWO waves per head (wave w: head w & 3, key tiles of parity w >> 2; merged through LDS
+    // behind the loop), then multiplies ITS heads' half of K in stage 3 and hands the partial sums over to its partner (or
+    // takes the partner's and finishes): the launch fills 256 CUs at M = 4096 and every workgroup streams 2/3 of the weights
+    constexpr bool XS = CS;
+    using KH3 = std::integral_constant<int, XS ? KH / 2 : KH>;
+    const int ks3 = XS ? part * KH : 0;              // first k-step of this workgroup's stage-3 range
+    stage_prologue(p.w3_hi, p.w3_lo, 0, bq, std::integral_constant<int, NS>{}, KH3{}, ks3);   // the output projection's first weight fragments fly under the attention
     __syncthreads();                               // query planes complete
     constexpr int d = 16 * NS, KSq = NS, NBv = NS == 3 ? 2 : 1;     // 8 heads: d = C / 8
     const int nT = p.xa_nT;
-    const int h = wave, b_item = m0 / p.T;
+    const int h = XS ? part * 4 + (wave & 3) : wave, b_item = m0 / p.T;
+    const int kh = XS ? wave >> 2 : 0, tstep = XS ? 2 : 1;           // key-tile parity of this wave / tile stride
     bf16x8 qh[KSq], ql[KSq];
 #pragma unroll
     for (int ks = 0; ks < KSq; ++ks) {
@@ -558,10 +572,10 @@ __global__ __launch_bounds__((chain_pf_wave<NS, AMODE, XA, SA, CS>() ? NT_LAUNCH
       for (int g = 0; g < 4; ++g) f.bv[g] = *reinterpret_cast<const float4*>(bias + tc * 32 + 8 * g);
       return f;
     };
-    KVT cur = load_kv(0);
-    for (int t = 0; t < nT; ++t) {
+    KVT cur = load_kv(kh);
+    for (int t = kh; t < nT; t += tstep) {
       __builtin_amdgcn_sched_barrier(0);
-      KVT nxt = load_kv(t + 1);
+      KVT nxt = load_kv(t + tstep);
       __builtin_amdgcn_sched_barrier(0);
       f32x16 sc;
       // (the key bias IS the initial accumulator: no add behind the MFMAs, 12 VGPRs fewer)
@@ -621,7 +635,32 @@ __global__ __launch_bounds__((chain_pf_wave<NS, AMODE, XA, SA, CS>() ? NT_LAUNCH
       }
       cur = nxt;
     }
-    {
+    if (XS) {
+      // merge the two key halves of every head: wave w + 4 hands (m, l, O) over, wave w combines (log2 domain)
+      float* mg = reinterpret_cast<float*>(red_reg);               // [4 heads][2 + 16 NBv][64 lanes]
+      constexpr int MW = 2 + 16 * NBv;
+      if (kh == 1) {
+        float* q = mg + (size_t)(wave & 3) * MW * 64 + lane;
+        q[0] = m_run; q[64] = l_run;
+#pragma unroll
+        for (int nb = 0; nb < NBv; ++nb)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) q[(2 + nb * 16 + r) * 64] = o[nb][r];
+      }
+      __syncthreads();
+      if (kh == 0) {
+        const float* q = mg + (size_t)(wave & 3) * MW * 64 + lane;
+        const float m1 = q[0], l1 = q[64];
+        const float mm = fmaxf(m_run, m1);
+        const float a0 = __builtin_amdgcn_exp2f(m_run - mm), a1 = __builtin_amdgcn_exp2f(m1 - mm);
+        l_run = l_run * a0 + l1 * a1;
+#pragma unroll
+        for (int nb = 0; nb < NBv; ++nb)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) o[nb][r] = o[nb][r] * a0 + q[(2 + nb * 16 + r) * 64] * a1;
+      }
+    }
+    if (!XS || kh == 0) {
       const float inv = 1.0f / pair_sum32(l_run);
       // O (lane = query row, registers = channels 8g + 4lh + e of block nb) -> split planes in the A region, columns of head h
 #pragma unroll
@@ -650,10 +689,43 @@ __global__ __launch_bounds__((chain_pf_wave<NS, AMODE, XA, SA, CS>() ? NT_LAUNCH
     for (int ns = 0; ns < NS; ++ns)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[ns][r] = 0.f;
-    stage_loop(p.w3_hi, p.w3_lo, 0, bq, acc, std::false_type{}, std::integral_constant<int, NS>{});
+    stage_loop(p.w3_hi, p.w3_lo, 0, bq, acc, std::false_type{}, std::integral_constant<int, NS>{}, KH3{}, ks3);
     DV_CTRACE(13);
     kgroup_reduce(acc, red_reg);
     DV_CTRACE(14);
+    if (XS) {
+      // hand-over between the two workgroups of the row block (the fused split-K pair's protocol, gemm_tile.h): dump the
+      // partial sums written through, take a ticket; the first to arrive leaves, the second adds the partner's dump and
+      // runs the epilogue.  Nobody waits for anybody.  [NS fragments][4 column owners][4 float4][64 lanes] per part.
+      float4* dump = reinterpret_cast<float4*>(p.xs_buf) + ((size_t)rb * 2 + part) * (NS * 4 * 4 * 64);
+      if (kg == 0) {
+#pragma unroll
+        for (int ns = 0; ns < NS; ++ns)
+#pragma unroll
+          for (int g = 0; g < 4; ++g)
+            st_handover16(dump + ((ns * 4 + wn) * 4 + g) * 64 + lane, make_float4(acc[ns][4 * g], acc[ns][4 * g + 1], acc[ns][4 * g + 2], acc[ns][4 * g + 3]));
+        wait_vmcnt<0>();
+      }
+      __shared__ unsigned s_arrival;
+      __syncthreads();
+      if (tid == 0) s_arrival = __hip_atomic_fetch_add(p.xs_ticket + rb, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __syncthreads();
+      if (s_arrival == 0) return;                    // the partner finishes this row block
+      if (tid == 0) __hip_atomic_store(p.xs_ticket + rb, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
+      if (kg == 0) {
+        const float4* other = reinterpret_cast<const float4*>(p.xs_buf) + ((size_t)rb * 2 + (part ^ 1)) * (NS * 4 * 4 * 64);
+#pragma unroll
+        for (int ns = 0; ns < NS; ++ns) {
+          float4 v[4];
+#pragma unroll
+          for (int g = 0; g < 4; ++g) v[g] = ld_handover16(other + ((ns * 4 + wn) * 4 + g) * 64 + lane);
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            acc[ns][4 * g] += v[g].x; acc[ns][4 * g + 1] += v[g].y; acc[ns][4 * g + 2] += v[g].z; acc[ns][4 * g + 3] += v[g].w;
+          }
+        }
+      }
+    }
     if (kg == 0) {
       const int m = m0 + l31;
 #pragma unroll
@@ -1033,6 +1105,7 @@ hipError_t chain_init() {
   if ((e = init_one<2, 0, false, false, true>()) != hipSuccess) return e;
   if ((e = init_one<3, 0, false, false, true>()) != hipSuccess) return e;
   if ((e = init_one<1, 0, true>()) != hipSuccess) return e;
+  if ((e = init_one<2, 0, true, false, true>()) != hipSuccess) return e;
   return init_one<2, 0, true>();   // (C = 384 with the attention inside needs > 256 VGPRs: it keeps the separate launches)
 }
 
@@ -1072,7 +1145,10 @@ bool chain2_supported(const ChainParams& p, int precision) {
   if (p.nsplit < 0 || p.nsplit > 3) return false;
   if (p.nsplit > 1 && p.amode == 1 && p.nsplit > p.passes) return false;
   // amode 0: the parts share out the 128-column groups of the one stage-2 pass
-  if (p.nsplit > 1 && p.amode == 0 && (p.xa_kf_hi || p.passes != 1 || p.nsplit != p.C / 128 || p.C > 384)) return false;
+  if (p.nsplit > 1 && p.amode == 0 && p.xa_kf_hi) {                    // cross-attention tail on two workgroups per row block
+    if (p.C != 256 || p.nsplit != 2 || p.passes != 1 || !p.xs_buf || !p.xs_ticket) return false;
+  } else
+  if (p.nsplit > 1 && p.amode == 0 && (p.passes != 1 || p.nsplit != p.C / 128 || p.C > 384)) return false;
   if (p.sa_kf_hi) {                                                    // q | k | v with K / V as attention fragments
     if (p.amode != 1 || p.passes != 3 || p.C > 384 || !p.sa_kf_lo || !p.sa_vf_hi || !p.sa_vf_lo) return false;
   }
@@ -1089,6 +1165,7 @@ hipError_t launch_chain2(const ChainParams& p, int precision, hipStream_t st) {
   if (!p.w1_hi || !p.w1_lo || !p.w2_hi || !p.w2_lo || !p.b1 || !p.b2 || !p.u2 || !p.out1 || (!p.out2 && !p.xa_kf_hi)) return hipErrorInvalidValue;
   if (p.amode == 0 ? (!p.a_hi || !p.a_lo) : (!p.x || !p.stat16 || !p.gamma || !p.beta)) return hipErrorInvalidValue;
   const int ns = p.C / 128;
+  if (p.xa_kf_hi && p.nsplit == 2) return launch_one<2, 0, true, false, true>(p, st);   // (two workgroups per row block: heads 0-3 / 4-7)
   if (p.xa_kf_hi) return ns == 1 ? launch_one<1, 0, true>(p, st) : launch_one<2, 0, true>(p, st);
   if (p.sa_kf_hi) return ns == 1 ? launch_one<1, 1, false, true>(p, st) : (ns == 2 ? launch_one<2, 1, false, true>(p, st) : launch_one<3, 1, false, true>(p, st));
   if (p.amode == 0 && p.nsplit > 1) return ns == 2 ? launch_one<2, 0, false, false, true>(p, st) : launch_one<3, 0, false, false, true>(p, st);

@@ -8,7 +8,7 @@ GIT_HEAD=${2:-$(git -C ${GRAFT_REPO_ROOT:-$PWD} rev-parse --short HEAD 2>/dev/nu
 R=${GRAFT_REPO_ROOT:-$PWD}
 mkdir -p $R/gpurun_out
 cd /tmp && export TMPDIR=/tmp DVITS_NO_GRAPH=1
-CMD="python3 $R/bench.py --steps 1 --warmup 1 --solver-steps 6 --no-cpu-baseline --no-roofline"
+CMD="python3 $R/bench.py --steps 1 --warmup 1 --solver-steps 6 --no-cpu-baseline --no-roofline --no-other-configs"
 rm -rf $R/gpurun_out/p_stats $R/gpurun_out/p_fetch $R/gpurun_out/p_write $R/gpurun_out/p_mfma
 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/p_stats -- $CMD > $R/gpurun_out/p_stats.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $R/gpurun_out/p_fetch -- $CMD > $R/gpurun_out/p_fetch.log 2>&1
