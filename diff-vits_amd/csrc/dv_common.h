@@ -41,6 +41,12 @@ struct GnxParams {
   int groups; float eps; int silu;
   int spin_max;                  // polls before a wait gives up (default 1 << 18, ~0.4 s; tests force time-outs with 1)
   bf16_t* y_hi; bf16_t* y_lo;    // normalised split planes [M, N]
+  // Concatenated consumer (norm1 of an up-path resnet over [this GEMM's output | skip], reference unet_1d_blocks.py:2085,2187):
+  // sk_c > 0 skip channels; gamma / beta then hold N + sk_c entries and `groups` are those of the concatenation.  The skip's
+  // fp32 rows [M, sk_c] and 32x16 block statistics [M / 32, sk_c / 16, 2] are read, its normalised planes sk_y and (optional)
+  // raw planes sk_raw [M, sk_c] are written - a slice per workgroup (gemm_tile.h).
+  const float* sk_x; const float* sk_stat16; int sk_c;
+  bf16_t* sk_y_hi; bf16_t* sk_y_lo; bf16_t* sk_raw_hi; bf16_t* sk_raw_lo;
 };
 
 struct GemmParams {

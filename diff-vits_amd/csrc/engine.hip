@@ -146,6 +146,9 @@ struct Act {   // channels-last fp32 [B*Tp, C] (+ GN statistics) (+ split planes
   // GroupNorm + SiLU of this tensor for ONE consumer (`n_pre` = its norm's weight prefix), written by the producer GEMM's
   // own epilogue (GnxParams); the consumer releases them
   bf16_t* n_hi = nullptr; bf16_t* n_lo = nullptr; std::string n_pre;
+  // ... of [this tensor | a skip tensor] when that consumer is an up-path resnet block (GnxParams sk_*): the skip's share of
+  // the normalised planes and of the raw planes (the folded 1x1 shortcut's operand), [B*Tp, skip channels]
+  bf16_t* sn_hi = nullptr; bf16_t* sn_lo = nullptr; bf16_t* sr_hi = nullptr; bf16_t* sr_lo = nullptr;
 };
 
 typedef std::function<hipError_t(hipStream_t)> OpFn;
@@ -575,25 +578,30 @@ struct Builder {
   // Call after g's segments, epilogue and statistics slab are set.
   // (a CU mask - HSA_CU_MASK / ROC_GLOBAL_CU_MASK - takes CUs away without hipDeviceAttributeMultiprocessorCount knowing:
   // the residency bound of the in-launch hand-over would be wrong, so it is not planned at all then)
+  bool sk_fused = [] { const char* e = getenv("DVITS_SPLITK_FUSED"); return !(e && e[0] == '0'); }();   // 0: split-K as two launches
   bool gnx_on = [] { const char* e = getenv("DVITS_GNX"); return !(e && e[0] == '0') && !getenv("HSA_CU_MASK") && !getenv("ROC_GLOBAL_CU_MASK"); }();
   size_t gnx_used = 0;
   // polls before an in-launch wait gives up; DVITS_GNX_SPIN=<n> is a test hook (1: every wait that is not satisfied at once
   // times out - exercises the fallback path of engine.py deterministically)
   int gnx_spin = [] { const char* e = getenv("DVITS_GNX_SPIN"); const int v = e ? atoi(e) : 0; return v != 0 ? v : (1 << 18); }();   // (-1: give up at the first unsatisfied poll)
   int n_cu = [] { int d = 0, n = 0; if (hipGetDevice(&d) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, d) != hipSuccess) n = 0; return n; }();
+  // `skip`: the consumer normalises [g's output | skip] (an up-path resnet block's norm1); the skip's share of the planes goes
+  // to *sk_y (and *sk_raw, if the consumer's shortcut wants the raw tensor as planes).  DVITS_GNX_CONCAT=0: not planned.
+  bool gnx_cat_on = [] { const char* e = getenv("DVITS_GNX_CONCAT"); return !(e && e[0] == '0'); }();
   bool gnx_setup(GemmParams& g, const std::string& pre, float eps, const float* tscale, const float* tshift, int ld_t, bool silu,
-                 Planes* y) {
+                 Planes* y, const Act* skip = nullptr, Planes* sk_y = nullptr, Planes* sk_raw = nullptr) {
     if (!gnx_on || !u->exclusive || arena.exact || autotune_on() || !g.stats16 || n_cu <= 0) return false;
+    if (skip && (!gnx_cat_on || !skip->p || !skip->stat16 || skip->Tp != g.T_out || tscale)) return false;
     GemmParams t = g;
     t.B = B;
     t.gnx = GnxParams{};
     t.gnx.groups = u->cfg.norm_num_groups;
+    t.gnx.sk_c = skip ? skip->C : 0;
     int k_pad = 0;
     for (int s2 = 0; s2 < t.nseg; ++s2) k_pad += t.seg[s2].taps * (t.seg[s2].c0 + t.seg[s2].c1);
     t.sk_split = gemm_splitk_plan(t.M, t.N, k_pad, t.epi);
     if (t.sk_split >= 2) {
-      const char* fe = getenv("DVITS_SPLITK_FUSED");
-      if ((fe && fe[0] == '0') || ((t.M + 31) / 32) * ((t.N + 31) / 32) > 4096) return false;   // (two launches: see gemm())
+      if (!sk_fused || ((t.M + 31) / 32) * ((t.N + 31) / 32) > 4096) return false;   // (two launches: see gemm())
       t.sk_buf = reinterpret_cast<float*>(0x1000); t.sk_ticket = reinterpret_cast<unsigned*>(0x1000);
     }
     const int nw = gemm_gnx_plan(t, n_cu);
@@ -608,26 +616,49 @@ struct Builder {
     if (!dry) u->gnx_words = gnx_used;
     *y = alloc_planes((size_t)g.M * g.N);
     g.gnx.y_hi = y->hi; g.gnx.y_lo = y->lo;
+    if (skip) {
+      g.gnx.sk_x = skip->p; g.gnx.sk_stat16 = skip->stat16;
+      *sk_y = alloc_planes((size_t)g.M * skip->C);
+      g.gnx.sk_y_hi = sk_y->hi; g.gnx.sk_y_lo = sk_y->lo;
+      if (sk_raw) { *sk_raw = alloc_planes((size_t)g.M * skip->C); g.gnx.sk_raw_hi = sk_raw->hi; g.gnx.sk_raw_lo = sk_raw->lo; }
+    }
     if (!dry) u->gnx_ops++;
     return true;
   }
 
   // The build loop announces the single GroupNorm consumer of the next producer's output (a resnet block's norm1, or
   // conv_norm_out); the producer's last GEMM takes the offer if it can finish that GroupNorm itself.
-  struct NextNorm { std::string pre; bool raw = false; bool set = false; } next_norm;
-  void announce_norm(const std::string& pre, bool raw_planes) { next_norm.pre = pre; next_norm.raw = raw_planes; next_norm.set = true; }
+  // (`skip`: that consumer normalises [the output | skip] - the up path's concatenation)
+  struct NextNorm { std::string pre; bool raw = false; bool set = false; Act skip; float eps = 0.f; bool silu = true; } next_norm;
+  void announce_norm(const std::string& pre, bool raw_planes, const Act& skip = Act{}) {
+    next_norm.pre = pre; next_norm.raw = raw_planes; next_norm.skip = skip; next_norm.set = true;
+    next_norm.eps = u->cfg.norm_eps; next_norm.silu = true;
+  }
+  // ... a Transformer2DModel's own GroupNorm (eps 1e-6, no activation; reference transformer_1d.py:262) when its first GEMM runs
+  // as a launch of its own (channel counts the row-block chain does not take)
+  void announce_transformer_norm(const std::string& tp, int Tp, int C) {
+    if (chain_ok(Tp, C)) return;
+    announce_norm(tp + "norm", false);
+    next_norm.eps = 1e-6f; next_norm.silu = false;
+  }
   void offer_next(GemmParams& g, Act& out) {
     if (!next_norm.set) return;
     const NextNorm nn = next_norm;
     next_norm.set = false;
-    Planes y;
-    if (!gnx_setup(g, nn.pre, u->cfg.norm_eps, nullptr, nullptr, 0, true, &y)) return;
+    Planes y, sy, sr;
+    const bool cat = nn.skip.C > 0;
+    if (!gnx_setup(g, nn.pre, nn.eps, nullptr, nullptr, 0, nn.silu, &y, cat ? &nn.skip : nullptr, &sy, nn.raw ? &sr : nullptr)) return;
     out.n_hi = y.hi; out.n_lo = y.lo; out.n_pre = nn.pre;
+    if (cat) { out.sn_hi = sy.hi; out.sn_lo = sy.lo; out.sr_hi = sr.hi; out.sr_lo = sr.lo; }
+    // (an up-path tensor has this one consumer, which reads it through the planes alone when its shortcut is a convolution)
+    const bool fp32_unread = cat && nn.raw && !u->keep_intermediates;
     if (nn.raw && !g.out_hi) {   // the consumer's folded 1x1 shortcut reads the raw tensor as split planes
       Planes pl = alloc_planes((size_t)g.M * g.N);
       out.pl_hi = pl.hi; out.pl_lo = pl.lo; g.out_hi = pl.hi; g.out_lo = pl.lo;
     }
+    if (fp32_unread && cat_drop_fp32) g.out = nullptr;
   }
+  bool cat_drop_fp32 = [] { const char* e = getenv("DVITS_GNX_CONCAT_KEEP_FP32"); return !(e && e[0] == '1'); }();
 
   void gemm(std::vector<OpFn>& ops, GemmParams g, const PackedW* pw, int k_real) {
     g.w_hi = pw->hi; g.w_lo = pw->lo; g.Kp = pw->Kp; g.N_pad = pw->N_pad;
@@ -654,7 +685,7 @@ struct Builder {
     if (g.sk_split >= 2 || offer) {
       g.sk_buf = alloc(gemm_splitk_bytes(g.M, g.N, g.sk_split > 2 ? g.sk_split : 2) / sizeof(float));
       // null: two launches (DVITS_SPLITK_FUSED=0); the counters are indexed by tile id of any tile shape >= 32x32
-      g.sk_ticket = ((g.M + 31) / 32) * ((g.N + 31) / 32) <= 4096 ? u->sk_tickets : nullptr;
+      g.sk_ticket = (sk_fused && ((g.M + 31) / 32) * ((g.N + 31) / 32) <= 4096) ? u->sk_tickets : nullptr;
     }
     PersistOp po;
     const bool pok = !dry && persist_gemm(g, po);
@@ -796,7 +827,7 @@ struct Builder {
     if (!w1) return Act{};
     Act h{};
     h.p = alloc((size_t)M * cout); h.C = cout; h.T = Tn; h.Tp = Tp; alloc_stat(h);
-    Planes raw;
+    Planes raw, raw1;             // the raw operand of the folded 1x1 shortcut: one tensor, or [x0 | x1] as two
     bool raw_made = false;
     const int toff = tproj_off[p];
     Planes n2x;                   // norm2(h) planes written by conv1's own epilogue (gnx_setup), if it can
@@ -805,20 +836,29 @@ struct Builder {
       GemmParams g = gp_base(Tn, M, cout);
       g.out = h.p; stat_out(g, h);
       {
-        Planes n1;
-        if (x1.C == 0 && x0.n_hi && x0.n_pre == p + "norm1" && (!shortcut || x0.pl_hi)) {   // normalised by its producer
+        Planes n1, n1b;
+        if (x0.n_hi && x0.n_pre == p + "norm1" && (!shortcut || x0.pl_hi) && (x1.C == 0 || (x0.sn_hi && (!shortcut || x0.sr_hi)))) {
+          // normalised by its producer: x0 alone, or [x0 | x1] as two tensors of planes
           n1.hi = x0.n_hi; n1.lo = x0.n_lo;
           if (shortcut) { raw.hi = x0.pl_hi; raw.lo = x0.pl_lo; }
+          if (x1.C) {
+            n1b.hi = x0.sn_hi; n1b.lo = x0.sn_lo;
+            if (shortcut) { raw1.hi = x0.sr_hi; raw1.lo = x0.sr_lo; }
+          }
+          g.seg[0] = x1.C ? seg(n1, x0.C, n1b, x1.C, 3, 1) : seg(n1, cin, Planes{}, 0, 3, 1);
         } else {
           if (x0.n_hi) { Planes stale; stale.hi = x0.n_hi; stale.lo = x0.n_lo; release(stale); }
+          if (x0.sn_hi) { Planes stale; stale.hi = x0.sn_hi; stale.lo = x0.sn_lo; release(stale); }
+          if (x0.sr_hi) { Planes stale; stale.hi = x0.sr_hi; stale.lo = x0.sr_lo; release(stale); }
           n1 = norm_apply(ops, x0, x1, p + "norm1", eps, nullptr, nullptr, 0, true, shortcut ? &raw : nullptr);
+          g.seg[0] = seg(n1, cin, Planes{}, 0, 3, 1);
         }
         raw_made = shortcut;
-        g.seg[0] = seg(n1, cin, Planes{}, 0, 3, 1);
         gnx1 = gnx_setup(g, p + "norm2", eps, tproj + toff, tproj + toff + cout, tproj_total, true, &n2x);
         if (gnx1 && !u->keep_intermediates) g.out = nullptr;   // h is only ever read through norm2
         gemm(ops, g, w1, 3 * cin);
         release(n1);
+        if (n1b.hi) release(n1b);
       }
     }
     probe(p + "conv1", h.p, Tn, cout);
@@ -844,7 +884,7 @@ struct Builder {
         Planes n2 = gnx1 ? n2x : norm_apply(ops, h, Act{}, p + "norm2", eps, tproj + toff, tproj + toff + cout, tproj_total, true, nullptr);
         g.seg[0] = seg(n2, cout, Planes{}, 0, 3, 1);
         g.nseg = 1;
-        if (shortcut) { g.seg[1] = seg(raw, cin, Planes{}, 0, 1, 0); g.nseg = 2; }
+        if (shortcut) { g.seg[1] = raw1.hi ? seg(raw, x0.C, raw1, x1.C, 1, 0) : seg(raw, cin, Planes{}, 0, 1, 0); g.nseg = 2; }
         if (offered) offer_next(g, out);
         gemm(ops, g, w2, K2);
         release(n2);
@@ -852,6 +892,7 @@ struct Builder {
     }
     release_act(h);
     if (raw_made) release(raw);
+    if (raw1.hi) release(raw1);
     probe(p.substr(0, p.size() - 1), out.p, Tn, cout);
     return out;
   }
@@ -1101,7 +1142,9 @@ struct Builder {
       GemmParams g = gp_base(Tn, M, C);
       g.out = h; l1 = ln_produce(g);
       {
-        Planes gn = norm_apply(ops, x, Act{}, p + "norm", 1e-6f, nullptr, nullptr, 0, false, nullptr);
+        Planes gn;
+        if (x.n_hi && x.n_pre == p + "norm") { gn.hi = x.n_hi; gn.lo = x.n_lo; }    // normalised by its producer's epilogue
+        else gn = norm_apply(ops, x, Act{}, p + "norm", 1e-6f, nullptr, nullptr, 0, false, nullptr);
         g.seg[0] = seg(gn, C, Planes{}, 0, 1, 0);
         gemm(ops, g, w_in, C);
         release(gn);
@@ -1352,8 +1395,7 @@ struct Builder {
         if (hipHostMalloc((void**)&u->gnx_status, 64, hipHostMallocMapped) != hipSuccess) return dv_fail(DV_ERR_HIP, "hipHostMalloc(status word) failed");
         *u->gnx_status = 0;
       }
-      const char* fe = getenv("DVITS_SPLITK_FUSED");
-      if (!u->sk_tickets && !(fe && fe[0] == '0')) {
+      if (!u->sk_tickets) {      // (fused split-K pairs and the two-workgroup cross-attention chain share them: both leave zeros behind)
         void* z = nullptr;
         if (hipMalloc(&z, 4096 * sizeof(unsigned)) != hipSuccess) return dv_fail(DV_ERR_HIP, "hipMalloc(split-K tickets) failed");
         (void)hipMemsetAsync(z, 0, 4096 * sizeof(unsigned), pack_stream);
@@ -1527,10 +1569,15 @@ struct Builder {
     probe("conv_in", h.p, T, C0);
 
     // a tensor kept for the up path's concat: without the planes that belong to its immediate consumer
-    auto skip_of = [](Act a) { a.pl_hi = a.pl_lo = a.n_hi = a.n_lo = nullptr; a.n_pre.clear(); return a; };
+    auto skip_of = [](Act a) { a.pl_hi = a.pl_lo = a.n_hi = a.n_lo = a.sn_hi = a.sn_lo = a.sr_hi = a.sr_lo = nullptr; a.n_pre.clear(); return a; };
     // the resnet block that consumes a down-path tensor alone: its norm1 can be finished by the tensor's producer
     auto announce_resnet = [&](const std::string& rp) { announce_norm(rp + "norm1", has(rp + "conv_shortcut.weight")); };
     std::vector<Act> skips{skip_of(h)};
+    // the up-path resnet block (i, j) normalises [h | the skip on top of the stack]: announced to h's producer
+    auto announce_up = [&](int i, int j) {
+      const std::string rp = "up_blocks." + std::to_string(i) + ".resnets." + std::to_string(j) + ".";
+      if (!skips.empty()) announce_norm(rp + "norm1", has(rp + "conv_shortcut.weight"), skips.back());
+    };
     for (int i = 0; i < n; ++i) {
       const std::string bp = "down_blocks." + std::to_string(i) + ".";
       const bool attn = i < n - 1;
@@ -1539,6 +1586,7 @@ struct Builder {
         // consumer of this (resnet [+ transformer]) pair's output: the block's next resnet, the downsampler, or the mid block
         const std::string next_rp = j + 1 < lpb ? bp + "resnets." + std::to_string(j + 1) + "." : (i == n - 1 ? std::string("mid_block.resnets.0.") : std::string());
         if (!attn && !next_rp.empty()) announce_resnet(next_rp);
+        if (attn) announce_transformer_norm(bp + "attentions." + std::to_string(j) + ".", h.Tp, c.block_out_channels[i]);
         Act r = resnet(S, bp + "resnets." + std::to_string(j) + ".", h, Act{}, c.block_out_channels[i], feeds_resampler && !attn,
                        attn && chain_ok(h.Tp, c.block_out_channels[i]));
         next_norm.set = false;
@@ -1563,14 +1611,18 @@ struct Builder {
       }
     }
     {
+      announce_transformer_norm("mid_block.attentions.0.", h.Tp, h.C);
       Act r0 = resnet(S, "mid_block.resnets.0.", h, Act{}, h.C, false, chain_ok(h.Tp, h.C));
+      next_norm.set = false;
       if (!r0.p) return dv_fail(DV_ERR_MISSING_WEIGHT, "%s", err.c_str());
       announce_resnet("mid_block.resnets.1.");
       Act a = transformer(S, "mid_block.attentions.0.", r0);
       next_norm.set = false;
       if (!a.p) return dv_fail(DV_ERR_MISSING_WEIGHT, "%s", err.c_str());
       release_act(r0);
+      announce_up(0, 0);
       h = resnet(S, "mid_block.resnets.1.", a, Act{}, a.C);
+      next_norm.set = false;
       if (!h.p) return dv_fail(DV_ERR_MISSING_WEIGHT, "%s", err.c_str());
       release_act(a);
     }
@@ -1584,6 +1636,8 @@ struct Builder {
         const bool feeds_resampler = !last && j == lpb;              // its output is the upsampler's input
         const bool final_op = last && j == lpb;                      // its output goes to conv_norm_out alone
         if (final_op && !attn) announce_norm("conv_norm_out", false);
+        if (j < lpb && !attn) announce_up(i, j + 1);
+        if (attn) announce_transformer_norm(bp + "attentions." + std::to_string(j) + ".", h.Tp, cout);
         Act r = resnet(S, bp + "resnets." + std::to_string(j) + ".", h, sk, cout, feeds_resampler && !attn, attn && chain_ok(h.Tp, cout));
         next_norm.set = false;
         if (!r.p) return dv_fail(DV_ERR_MISSING_WEIGHT, "%s", err.c_str());
@@ -1591,6 +1645,7 @@ struct Builder {
         release_act(sk);
         if (attn) {
           if (final_op) announce_norm("conv_norm_out", false);
+          if (j < lpb) announce_up(i, j + 1);
           Act a = transformer(S, bp + "attentions." + std::to_string(j) + ".", r, feeds_resampler);
           next_norm.set = false;
           if (!a.p) return dv_fail(DV_ERR_MISSING_WEIGHT, "%s", err.c_str());
@@ -1600,7 +1655,9 @@ struct Builder {
         h = r;
       }
       if (!last) {
+        announce_up(i + 1, 0);
         Act up = resample(S, bp + "upsamplers.0.", h, false, skips.back().T);
+        next_norm.set = false;
         if (!up.p) return dv_fail(DV_ERR_MISSING_WEIGHT, "%s", err.c_str());
         release_act(h);
         h = up;

@@ -130,7 +130,7 @@ template <int BK> struct Tiles {
       if (cnt(64, 64) >= min_wg) return T2G::launch(p, x3, st);
       return T4G::launch(p, x3, st);
     }
-    static const int t1_min = [] { const char* e = getenv("DVITS_GEMM_T1"); return e ? atoi(e) : 256; }();   // 128x64 tiles from 256 of them (>= 512 64x64 tiles: two rounds otherwise) - B >= 16 shapes
+    static const int t1_min = [] { const char* e = getenv("DVITS_GEMM_T1"); return e ? atoi(e) : 192; }();   // 128x64 tiles from 192 of them: 384+ 64x64 tiles would run as two rounds, and would not fit the in-launch GroupNorm hand-over (round 4: 256 -> 192, +0.4 % same box)
     if (BK == 64 && cnt(128, 64) >= t1_min) return T1::launch(p, x3, st);
     if (cnt(64, 64) >= min_wg) return ksplit ? T2::launch(p, x3, st) : T2S::launch(p, x3, st);
     if (cnt(64, 32) >= min_wg) return T3::launch(p, x3, st);
@@ -234,7 +234,7 @@ static void gemm_pick_tile(const GemmParams& p, int& bm, int& bn) {
     if (cnt(64, 64) >= min_wg) { bm = 64; bn = 64; return; }
     bm = 32; bn = 64; return;
   }
-  static const int t1_min = [] { const char* e = getenv("DVITS_GEMM_T1"); return e ? atoi(e) : 256; }();
+  static const int t1_min = [] { const char* e = getenv("DVITS_GEMM_T1"); return e ? atoi(e) : 192; }();
   if (k64 && cnt(128, 64) >= t1_min) { bm = 128; bn = 64; return; }
   if (cnt(64, 64) >= min_wg) { bm = 64; bn = 64; return; }
   if (cnt(64, 32) >= min_wg) { bm = 64; bn = 32; return; }
@@ -243,12 +243,14 @@ static void gemm_pick_tile(const GemmParams& p, int& bm, int& bn) {
 
 int gemm_gnx_plan(const GemmParams& p, int n_cu) {
   if (p.force_tile != GT_AUTO || (p.epi != EPI_STORE && p.epi != EPI_RESIDUAL) || !p.stats16 || p.rowmask || p.relu) return 0;
-  if (p.M != p.B * p.T_out || p.gnx.groups <= 0 || p.N % p.gnx.groups != 0) return 0;
-  const int cpg = p.N / p.gnx.groups;
-  if (cpg % 16 != 0 || p.N % 16 != 0) return 0;
+  const int skc = p.gnx.sk_c;                          // concatenated consumer: groups of [output | skip]
+  if (p.M != p.B * p.T_out || p.gnx.groups <= 0 || p.gnx.groups > 64 || skc < 0 || (p.N + skc) % p.gnx.groups != 0) return 0;
+  const int cpg = (p.N + skc) / p.gnx.groups;
+  if (cpg % 16 != 0 || p.N % 16 != 0 || skc % 16 != 0) return 0;
   int bm, bn;
   gemm_pick_tile(p, bm, bn);
   if (p.T_out % bm != 0 || p.N % bn != 0) return 0;
+  if (skc > 0 && ((skc / 16 + p.N / bn - 1) / (p.N / bn)) * 16 > 128) return 0;   // skip slice per workgroup (gemm_tile.h GSK)
   if ((p.T_out / 32) * (cpg / 16) > 256) return 0;     // entries of one group: four per lane of the reducing wave
   // Every workgroup of the launch must be resident at once - INCLUDING both halves of a fused split-K pair, although the
   // first arriver of a pair leaves without waiting: workgroups are bound to XCD id % 8, so a second round could only
@@ -298,6 +300,7 @@ hipError_t launch_gemm(const GemmParams& pin, int precision, hipStream_t st) {
   if (p.gnx.xchg && p.sk_mode == 0) {            // (checked once, before the split-K recursion)
     static const int n_cu = [] { int d = 0, n = 0; (void)hipGetDevice(&d); (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, d); return n; }();
     if (!p.gnx.status || !p.gnx.y_hi || !p.gnx.gamma || !p.gnx.beta || gemm_gnx_plan(p, n_cu) <= 0) return hipErrorInvalidValue;
+    if (p.gnx.sk_c > 0 && (!p.gnx.sk_x || !p.gnx.sk_stat16 || !p.gnx.sk_y_hi || (x3 && !p.gnx.sk_y_lo) || p.gnx.tscale)) return hipErrorInvalidValue;
   }
   if (p.sk_buf && p.sk_split == 2 && p.sk_ticket && p.sk_mode == 0) {
     p.sk_mode = 3;                                     // both k-halves and the epilogue in one launch

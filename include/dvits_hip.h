@@ -92,7 +92,8 @@ void dv_unet_destroy(dv_unet* u);
 int dv_unet_set_weight(dv_unet* u, const char* name, const void* dev_ptr, const int64_t* shape, int32_t ndim);
 
 /* Pack weights for `precision`, build the kernel schedule for (B, T, L) and allocate the
- * workspace arena.  Must be called after all weights are set and again whenever B/T/L,
+ * workspace arena (T is arbitrary: levels whose frame count is no multiple of 32 are laid out in a padded row space
+ * inside the engine).  Must be called after all weights are set and again whenever B/T/L,
  * the precision or the weights change.  `force_upsample_size` = the reference's
  * forward_upsample_size flag (unet_1d_condition.py:789-797), computed by the caller from
  * the shape of `sample`. */

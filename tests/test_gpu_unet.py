@@ -741,6 +741,48 @@ def test_groupnorm_finished_in_producer_epilogue_matches_separate_launch():
     assert rel_l2(outs[1], outs[0]) < 2e-5
 
 
+@pytest.mark.parametrize("B,T,L", [(1, 256, 128), (3, 300, 77), (8, 1024, 64)])
+def test_concat_groupnorm_finished_by_the_producer_of_h(B, T, L):
+    """Up path (reference unet_1d_blocks.py:2085,2187 -> resnet.py:594): norm1 of a resnet block runs over [h | skip].  Default
+    schedule: the GEMM that produces h finishes that GroupNorm too - its workgroups exchange h's block statistics, load the
+    skip's (stored since the down path), normalise their own tile and a slice of the skip's columns each (gemm_tile.h
+    gnx_table; groups that straddle the h / skip boundary included) - and conv1 / the folded shortcut read [h | skip] as two
+    tensors of planes.  DVITS_GNX_CONCAT=0 restores one k_gn_apply launch per block: same statistics, same fp64 combination ->
+    float32-rounding agreement, fewer launches, bit-repeatable, no hand-over timed out; at a padded length and at the bench
+    shape (where every GEMM but two fits the in-launch hand-over) as well."""
+    from diff_vits_amd import synth
+    from diff_vits_amd.unet1d.unet_1d_condition import UNet1DConditionModel
+    kw = UNET_CASES["cfg1"][0]
+    with torch.device("meta"):
+        shapes = {k: tuple(v.shape) for k, v in UNet1DConditionModel(**kw).state_dict().items()}
+    sd = {k: torch.from_numpy(v) for k, v in synth.make_state_dict(shapes, seed=777).items()}
+    x = torch.from_numpy(synth.normal(12, "x", (B, 80, T))).cuda()
+    cond = torch.from_numpy(synth.normal(12, "c", (B, 128, T))).cuda()
+    enc = torch.from_numpy(synth.normal(12, "e", (B, L, 128))).cuda()
+    t = torch.linspace(900.0, 20.0, B, device="cuda")
+    outs, launches = [], []
+    for cat in ("0", "1"):
+        os.environ["DVITS_GNX_CONCAT"] = cat
+        try:
+            m = UNet1DConditionModel(**kw).eval()
+            m.load_state_dict(sd)
+            eng = m.cuda().hip_engine()
+            eng.sync_weights()
+            eng.prepare(B, T, L)
+            eng.set_cond(enc, None)
+            y = eng.eval(x, cond, t).clone()
+            assert torch.equal(eng.eval(x, cond, t), y)
+            n_ops, bad = eng.handover_status()
+            assert bad == 0 and n_ops > 0, (n_ops, bad)
+            outs.append(y.cpu().numpy())
+            launches.append(eng.stats()[0])
+        finally:
+            os.environ.pop("DVITS_GNX_CONCAT", None)
+    assert launches[1] <= launches[0] - 6, launches          # 12 concatenations per forward; most producers qualify
+    assert np.isfinite(outs[1]).all()
+    assert rel_l2(outs[1], outs[0]) < 2e-5
+
+
 @pytest.mark.parametrize("B,T,L", [(16, 128, 40), (3, 256, 77), (1, 64, 10), (2, 2048, 300), (5, 512, 256), (1, 320, 150)])
 def test_fused_schedule_matches_plain_schedule_across_shapes(B, T, L):
     """The round-2 schedule (GroupNorm in the producer's epilogue, fragment attention, row-block chains shared out over
