@@ -188,10 +188,13 @@ struct ChainFFParams {
   const bf16_t* wg_hi; const bf16_t* wg_lo; const float* bg; const float* ug;   // GEGLU [8C][Kp = C] fragment-major (gamma folded), bias', u
   const bf16_t* wm_hi; const bf16_t* wm_lo; const float* bm;                    // merged [C][Kp = 5C] fragment-major, bias
   const float* res;                               // block input [M, C] fp32
-  float* out; float* stats16;                     // [M, C] fp32; [M/32, C/16, 2] or null
+  float* out; float* stats16;                     // [M, C] fp32 (null: nobody reads it); [M/32, C/16, 2] or null
   bf16_t* out_hi; bf16_t* out_lo;                 // optional split planes of the output
+  GnxParams gnx;                                  // xchg != null: the consumer's GroupNorm is finished by this launch (gnx_device.h)
 };
 bool chain_ff_supported(const ChainFFParams& p, int precision);
+// exchange words the in-launch GroupNorm of k_chain_ff needs (gnx.groups / gnx.sk_c set), 0: not possible (see gemm_gnx_plan)
+int chain_ff_gnx_plan(const ChainFFParams& p, int n_cu);
 hipError_t launch_chain_ff(const ChainFFParams& p, int precision, hipStream_t st);
 
 // cross-attention K/V of one block, fp32 [B*L, 2C] (k | v) -> MFMA-fragment-major split planes (ChainParams xa_*)

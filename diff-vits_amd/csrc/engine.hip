@@ -544,9 +544,16 @@ struct Builder {
   // Row-block chains of a transformer block (kernels_chain.hip; DVITS_CHAIN=0 restores one launch per GEMM):
   // norm -> proj_in -> LN -> to_q/k/v, and attention -> to_out + residual -> LN -> to_q of the next attention
   bool chain_on = [] { const char* e = getenv("DVITS_CHAIN"); return !(e && e[0] == '0'); }();
+  // Levels with fewer than four 32-row blocks in the whole batch run one launch per GEMM instead: a chain kernel there is three
+  // workgroups (x the column split) streaming whole weight matrices through one CU each, while 32x32 GEMM tiles spread the
+  // same weights over 36-108 CUs.  One utterance of 300 frames, level 2 (96 rows, C = 384): the two chains take 35.6 + 24.7 us,
+  // the five launches they replace ~45 us but the 30-step run drops 58.8 -> 55.2 ms; at 160 rows (level 1) the chains still
+  // win (56.4 ms with both levels unchained).  DVITS_CHAIN_MIN_ROWS=<rows> moves the limit (0: always chain).
+  int chain_min_rows = [] { const char* e = getenv("DVITS_CHAIN_MIN_ROWS"); return e ? atoi(e) : 128; }();
   bool chain_ok(int Tn, int C) const {
     const int G = u->cfg.norm_num_groups;
     return chain_on && fuse_ln && !arena.exact && prec == DV_PREC_BF16X3 && (C == 128 || C == 256 || C == 384) && Tn % 32 == 0 &&
+           B * Tn >= chain_min_rows &&
            G > 0 && G <= 64 && (G & (G - 1)) == 0 && C % G == 0 && (C / G) % 16 == 0 && (Tn / 32) * (C / 16) <= (C / 128) * 2048;
   }
   // fragment-major copies of a packed weight (kernels_chain.hip k_relayout_frag), made once per prepare
@@ -607,23 +614,28 @@ struct Builder {
     const int nw = gemm_gnx_plan(t, n_cu);
     if (nw <= 0 || gnx_used + (size_t)nw > dv_unet::GNX_POOL) return false;
     g.gnx = t.gnx;
-    g.gnx.gamma = W(pre + ".weight"); g.gnx.beta = W(pre + ".bias"); g.gnx.eps = eps;
-    g.gnx.tscale = tscale; g.gnx.tshift = tshift; g.gnx.ld_t = ld_t; g.gnx.silu = silu ? 1 : 0;
-    g.gnx.spin_max = gnx_spin;
-    g.gnx.xchg = dry ? reinterpret_cast<unsigned long long*>(0x1000) : u->gnx_pool + gnx_used;
-    g.gnx.status = dry ? reinterpret_cast<unsigned*>(0x1000) : u->gnx_status;
+    gnx_fill(g.gnx, nw, g.M, g.N, pre, eps, tscale, tshift, ld_t, silu, y, skip, sk_y, sk_raw);
+    return true;
+  }
+  // the part every producer kernel shares: `nw` exchange words of the pool, the norm's affine parameters, the planes it writes
+  void gnx_fill(GnxParams& gx, int nw, int M, int N, const std::string& pre, float eps, const float* tscale, const float* tshift, int ld_t,
+                bool silu, Planes* y, const Act* skip, Planes* sk_y, Planes* sk_raw) {
+    gx.gamma = W(pre + ".weight"); gx.beta = W(pre + ".bias"); gx.eps = eps;
+    gx.tscale = tscale; gx.tshift = tshift; gx.ld_t = ld_t; gx.silu = silu ? 1 : 0;
+    gx.spin_max = gnx_spin;
+    gx.xchg = dry ? reinterpret_cast<unsigned long long*>(0x1000) : u->gnx_pool + gnx_used;
+    gx.status = dry ? reinterpret_cast<unsigned*>(0x1000) : u->gnx_status;
     gnx_used += ((size_t)nw + 1) & ~(size_t)1;
     if (!dry) u->gnx_words = gnx_used;
-    *y = alloc_planes((size_t)g.M * g.N);
-    g.gnx.y_hi = y->hi; g.gnx.y_lo = y->lo;
+    *y = alloc_planes((size_t)M * N);
+    gx.y_hi = y->hi; gx.y_lo = y->lo;
     if (skip) {
-      g.gnx.sk_x = skip->p; g.gnx.sk_stat16 = skip->stat16;
-      *sk_y = alloc_planes((size_t)g.M * skip->C);
-      g.gnx.sk_y_hi = sk_y->hi; g.gnx.sk_y_lo = sk_y->lo;
-      if (sk_raw) { *sk_raw = alloc_planes((size_t)g.M * skip->C); g.gnx.sk_raw_hi = sk_raw->hi; g.gnx.sk_raw_lo = sk_raw->lo; }
+      gx.sk_x = skip->p; gx.sk_stat16 = skip->stat16;
+      *sk_y = alloc_planes((size_t)M * skip->C);
+      gx.sk_y_hi = sk_y->hi; gx.sk_y_lo = sk_y->lo;
+      if (sk_raw) { *sk_raw = alloc_planes((size_t)M * skip->C); gx.sk_raw_hi = sk_raw->hi; gx.sk_raw_lo = sk_raw->lo; }
     }
     if (!dry) u->gnx_ops++;
-    return true;
   }
 
   // The build loop announces the single GroupNorm consumer of the next producer's output (a resnet block's norm1, or
@@ -658,6 +670,30 @@ struct Builder {
     }
     if (fp32_unread && cat_drop_fp32) g.out = nullptr;
   }
+  // ... when the producer is the C = 128 feed-forward chain (k_chain_ff: one workgroup per row block)
+  void offer_next(ChainFFParams& fp, Act& out) {
+    if (!next_norm.set) return;
+    const NextNorm nn = next_norm;
+    next_norm.set = false;
+    const bool cat = nn.skip.C > 0;
+    if (!gnx_on || !gnx_ff_on || !u->exclusive || arena.exact || !fp.stats16 || n_cu <= 0) return;
+    if (cat && (!gnx_cat_on || !nn.skip.p || !nn.skip.stat16 || nn.skip.Tp != fp.T)) return;
+    fp.gnx = GnxParams{};
+    fp.gnx.groups = u->cfg.norm_num_groups;
+    fp.gnx.sk_c = cat ? nn.skip.C : 0;
+    const int nw = chain_ff_gnx_plan(fp, n_cu);
+    if (nw <= 0 || gnx_used + (size_t)nw > dv_unet::GNX_POOL) { fp.gnx = GnxParams{}; return; }
+    Planes y, sy, sr;
+    gnx_fill(fp.gnx, nw, fp.M, fp.C, nn.pre, nn.eps, nullptr, nullptr, 0, nn.silu, &y, cat ? &nn.skip : nullptr, &sy, nn.raw ? &sr : nullptr);
+    out.n_hi = y.hi; out.n_lo = y.lo; out.n_pre = nn.pre;
+    if (cat) { out.sn_hi = sy.hi; out.sn_lo = sy.lo; out.sr_hi = sr.hi; out.sr_lo = sr.lo; }
+    if (nn.raw && !fp.out_hi) {
+      Planes pl = alloc_planes((size_t)fp.M * fp.C);
+      out.pl_hi = pl.hi; out.pl_lo = pl.lo; fp.out_hi = pl.hi; fp.out_lo = pl.lo;
+    }
+    if (cat && nn.raw && !u->keep_intermediates && cat_drop_fp32) fp.out = nullptr;
+  }
+  bool gnx_ff_on = [] { const char* e = getenv("DVITS_GNX_FF"); return !(e && e[0] == '0'); }();
   bool cat_drop_fp32 = [] { const char* e = getenv("DVITS_GNX_CONCAT_KEEP_FP32"); return !(e && e[0] == '1'); }();
 
   void gemm(std::vector<OpFn>& ops, GemmParams g, const PackedW* pw, int k_real) {
@@ -1223,11 +1259,12 @@ struct Builder {
           Planes pl = alloc_planes((size_t)M * C);
           out.pl_hi = pl.hi; out.pl_lo = pl.lo; fp.out_hi = pl.hi; fp.out_lo = pl.lo;
         }
+        offer_next(fp, out);
         cur_kind = "chain";
         cur_flops = 2.0 * (double)M * C * (8.0 * C + 5.0 * C);
         {
           char buf[96];
-          snprintf(buf, sizeof(buf), "LN+GEGLU+ffproj+res M=%d C=%d", M, C);
+          snprintf(buf, sizeof(buf), "LN+GEGLU+ffproj+res%s M=%d C=%d", fp.gnx.xchg ? "+gnx" : "", M, C);
           cur_desc = buf;
         }
         if (!dry) u->flops += cur_flops;

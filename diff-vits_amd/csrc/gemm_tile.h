@@ -8,6 +8,7 @@
 #endif
 #include "dv_common.h"
 #include "dv_device.h"
+#include "gnx_device.h"
 
 #include <type_traits>
 
@@ -510,148 +511,13 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int m0, con
 
   // ---- in-epilogue GroupNorm, first half (GnxParams, dv_common.h): wait for the statistics of the groups this tile's columns
   // belong to and build the tile's per-column affine in LDS (s_gA, s_gB); `nwa` = waves of the workgroup that are still here ----
-  // Concatenated consumer (GnxParams sk_*; reference unet_1d_blocks.py:2085,2187 -> resnet.py:594: norm1 of an up-path resnet
-  // runs over [h | skip]): this GEMM produces h, the skip tensor and ITS block statistics have been in memory since the down
-  // path.  Groups are those of the concatenation ((N + sk_c) / groups channels each, h first): a group's entries come from the
-  // exchange words (h's blocks, polled) and / or from the skip's stored statistics (loaded), so a group that straddles the
-  // boundary needs no special case.  Besides its own tile every workgroup normalises a SLICE of the skip's columns for its rows
-  // (and writes the raw planes the folded 1x1 shortcut reads): the k_gn_apply launch of the concatenation disappears.
-  constexpr int GSK = 128;                           // widest skip slice per workgroup (gemm_gnx_plan checks)
-  __shared__ float2 s_gst[65];                       // (mean, rstd) by group index - g_lo (at most 64 groups)
-  __shared__ __attribute__((aligned(16))) float s_gA[BN < 64 ? 64 : BN], s_gB[BN < 64 ? 64 : BN];
-  __shared__ __attribute__((aligned(16))) float s_gA2[GSK], s_gB2[GSK];
+  // (GroupNorm of this GEMM's own output - GnxParams - and of a concatenated consumer's skip slice: gnx_device.h)
+  __shared__ GnxShared<BN> s_gnx;
+  float* const s_gA = s_gnx.gA; float* const s_gB = s_gnx.gB;
   auto gnx_table = [&](const int nwa) __attribute__((always_inline)) {
-    const int skc = p.gnx.sk_c;                      // 0: no concatenated consumer
-    const int cpg = (p.N + skc) / p.gnx.groups, bq = utt_of(m0);
-    // this workgroup's slice of the skip's 16-channel blocks: [sb0, sb1)
-    int sb0 = 0, sb1 = 0;
-    if (skc > 0) {
-      const int nbs = skc >> 4, tn = (p.N + BN - 1) / BN, per = (nbs + tn - 1) / tn, j = n0 / BN;
-      sb0 = min(j * per, nbs); sb1 = min(sb0 + per, nbs);
-    }
-    const int sw = (sb1 - sb0) * 16;                 // slice width in channels
-    float pg = 0.f, pb = 0.f, pts = 1.f, ptb = 0.f;  // this thread's column: affine + temb scale / shift (independent of the statistics)
-    if (tid < BN) {
-      const int c = min(n0 + tid, p.N - 1);
-      pg = p.gnx.gamma[c]; pb = p.gnx.beta[c];
-      if (p.gnx.tscale) pts = 1.0f + p.gnx.tscale[(size_t)bq * p.gnx.ld_t + c];
-      if (p.gnx.tshift) ptb = p.gnx.tshift[(size_t)bq * p.gnx.ld_t + c];
-    }
-    float pg2 = 0.f, pb2 = 0.f;                      // ... and its column of the skip slice (concatenated channel N + ...)
-    if (tid < sw) { pg2 = p.gnx.gamma[p.N + sb0 * 16 + tid]; pb2 = p.gnx.beta[p.N + sb0 * 16 + tid]; }
-    // statistics of the groups this tile's columns (and the skip slice's) belong to: one wave per group, fp64, fixed order
-    const int g_lo = n0 / cpg, g_hi = (min(n0 + BN, p.N) - 1) / cpg;
-    const int n1 = g_hi - g_lo + 1;
-    const int g2_lo = sw > 0 ? max((p.N + sb0 * 16) / cpg, g_hi + 1) : 0, g2_hi = sw > 0 ? (p.N + sb1 * 16 - 1) / cpg : -1;
-    const int ng = n1 + max(g2_hi - g2_lo + 1, 0);
-    const int RB = p.T_out >> 5, nvb = cpg >> 4, ncb = p.N >> 4, ncs = skc >> 4;
-    DV_TRACE(19);
-    for (int gi = wave; gi < ng; gi += nwa) {
-      const int g = gi < n1 ? g_lo + gi : g2_lo + (gi - n1);
-      // poll the group's entries until none is EMPTY (all ones: the forward's first kernel resets the exchange words;
-      // a published (sum, M2) is finite).  All tiles of the utterance are resident and arrive within the spread of the
-      // workgroups' k-loops; a lane re-reads only what it has not seen yet; bounded and flagged, never a hang
-      constexpr int EPL = 4;                         // entries per lane: up to 256 per group (gemm_gnx_plan checks)
-      unsigned long long w[EPL];
-#pragma unroll
-      for (int k = 0; k < EPL; ++k) w[k] = ~0ull;
-      const int ne = RB * nvb;
-      for (int spins = 0;; ++spins) {
-        bool ok = true;
-#pragma unroll
-        for (int k = 0; k < EPL; ++k) {
-          const int e = lane + 64 * k;
-          if (e < ne && w[k] == ~0ull) {
-            const int rb = e / nvb, cb = g * nvb + (e - rb * nvb);     // 16-channel block of the concatenation
-            if (cb < ncb)
-              w[k] = __hip_atomic_load(p.gnx.xchg + (size_t)(bq * RB + rb) * ncb + cb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            else {                                   // the skip's block: in memory since an earlier launch
-              const float2 sv = reinterpret_cast<const float2*>(p.gnx.sk_stat16)[(size_t)(bq * RB + rb) * ncs + (cb - ncb)];
-              w[k] = (unsigned long long)__float_as_uint(sv.x) | ((unsigned long long)__float_as_uint(sv.y) << 32);
-            }
-            ok = ok && w[k] != ~0ull;
-          }
-        }
-        if (__all(ok)) break;
-        // (another launch has already given up: the run is lost and will be repeated on the fallback schedule - do not
-        // spend ~0.4 s per GEMM waiting for partners that a foreign kernel keeps off the CUs)
-        const bool lost = (spins & 63) == 63 && __hip_atomic_load(p.gnx.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u;
-        if (lost) break;
-        if (spins > p.gnx.spin_max) {
-          if (lane == 0) {               // which GEMM, which workgroup, which group: reported by the next host call
-            p.gnx.status[1] = (unsigned)(size_t)p.gnx.xchg; p.gnx.status[2] = blockIdx.x; p.gnx.status[3] = (unsigned)g;
-            p.gnx.status[4] = (unsigned)__builtin_popcountll(__ballot(!ok));
-            __hip_atomic_store(p.gnx.status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-          }
-          break;
-        }
-        __builtin_amdgcn_s_sleep(1);
-      }
-      double s1 = 0.0, q = 0.0;
-#pragma unroll
-      for (int k = 0; k < EPL; ++k) {
-        if (lane + 64 * k < ne) {
-          const double sx = (double)__uint_as_float((unsigned)w[k]), m2 = (double)__uint_as_float((unsigned)(w[k] >> 32));
-          s1 += sx;
-          const int e = lane + 64 * k, cnt = min(32, p.Tv_out - 32 * (e / nvb));   // frames of row block e / nvb that exist
-          q += m2 + sx * sx / (double)(16 * cnt);    // = the block's sum of squares
-        }
-      }
-      s1 = wave_sum64(s1); q = wave_sum64(q);
-      if (lane == 0) {
-        const double n = (double)cpg * (double)p.Tv_out, mean = s1 / n;
-        double var = q / n - mean * mean;
-        var = var > 0 ? var : 0;
-        s_gst[g - g_lo] = make_float2((float)mean, (float)(1.0 / sqrt(var + (double)p.gnx.eps)));
-      }
-    }
-    DV_TRACE(20);                                    // this wave's groups are reduced
-    __syncthreads();
-    DV_TRACE(21);                                    // ... every wave's
-    if (tid < BN) {
-      const float2 st = s_gst[min(n0 + tid, p.N - 1) / cpg - g_lo];
-      const float a = st.y * pg;
-      s_gA[tid] = a * pts;
-      s_gB[tid] = fmaf(pb - st.x * a, pts, ptb);
-    }
-    if (tid < sw) {
-      const float2 st = s_gst[(p.N + sb0 * 16 + tid) / cpg - g_lo];
-      const float a = st.y * pg2;
-      s_gA2[tid] = a;
-      s_gB2[tid] = pb2 - st.x * a;
-    }
-    __syncthreads();
-    if (sw > 0) {
-      // the skip slice of this tile's rows: 8 channels per item (two 16-byte loads, one 16-byte store per plane)
-      const int sw8 = sw >> 3, total = BM * sw8, nthr = nwa * 64;
-      for (int i = tid; i < total; i += nthr) {
-        const int r = i / sw8, cl = (i - r * sw8) * 8, m = m0 + r;
-        if (m >= p.M) continue;
-        const size_t o = (size_t)m * skc + sb0 * 16 + cl;
-        const float4 v0 = *reinterpret_cast<const float4*>(p.gnx.sk_x + o), v1 = *reinterpret_cast<const float4*>(p.gnx.sk_x + o + 4);
-        const float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
-        float y[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          y[e] = fmaf(v[e], s_gA2[cl + e], s_gB2[cl + e]);
-          if (p.gnx.silu) y[e] = y[e] * __builtin_amdgcn_rcpf(1.0f + __expf(-y[e]));
-        }
-        auto put8 = [&](bf16_t* hi, bf16_t* lo, const float* x) {
-          uint4 h, l;
-          h.x = cvt_pk_bf16(x[0], x[1]); h.y = cvt_pk_bf16(x[2], x[3]); h.z = cvt_pk_bf16(x[4], x[5]); h.w = cvt_pk_bf16(x[6], x[7]);
-          dv_st16(hi + o, h);
-          if (lo) {
-            l.x = cvt_pk_bf16(x[0] - __uint_as_float(h.x << 16), x[1] - __uint_as_float(h.x & 0xffff0000u));
-            l.y = cvt_pk_bf16(x[2] - __uint_as_float(h.y << 16), x[3] - __uint_as_float(h.y & 0xffff0000u));
-            l.z = cvt_pk_bf16(x[4] - __uint_as_float(h.z << 16), x[5] - __uint_as_float(h.z & 0xffff0000u));
-            l.w = cvt_pk_bf16(x[6] - __uint_as_float(h.w << 16), x[7] - __uint_as_float(h.w & 0xffff0000u));
-            dv_st16(lo + o, l);
-          }
-        };
-        put8(p.gnx.sk_y_hi, p.gnx.sk_y_lo, y);
-        if (p.gnx.sk_raw_hi) put8(p.gnx.sk_raw_hi, p.gnx.sk_raw_lo, v);
-      }
-    }
+    GnxTile t;
+    t.M = p.M; t.N = p.N; t.T_out = p.T_out; t.Tv_out = p.Tv_out; t.m0 = m0; t.n0 = n0; t.bm = BM; t.bn = BN; t.bq = utt_of(m0);
+    gnx_finish_table<BN>(p.gnx, t, s_gnx, tid, lane, wave, nwa, [&](int k) { DV_TRACE(k); });
   };
 
   if (nk == 0) { wait_vmcnt<0>(); __syncthreads(); }   // epilogue-only launch: the bias DMA has landed

@@ -19,6 +19,7 @@
 //                weight fragments are already in flight
 #include "dv_common.h"
 #include "dv_device.h"
+#include "gnx_device.h"
 
 #include <cstdlib>
 #include <type_traits>
@@ -974,10 +975,7 @@ __global__ __launch_bounds__(NT_LAUNCH) void k_chain_ff(const ChainFFParams p) {
       vv[4 * g] = acc[4 * g] + bv.x + rr.x; vv[4 * g + 1] = acc[4 * g + 1] + bv.y + rr.y;
       vv[4 * g + 2] = acc[4 * g + 2] + bv.z + rr.z; vv[4 * g + 3] = acc[4 * g + 3] + bv.w + rr.w;
     }
-#pragma unroll
-    for (int g = 0; g < 4; ++g)
-      dv_st16(p.out + (size_t)m * C + nf + 8 * g, make_float4(vv[4 * g], vv[4 * g + 1], vv[4 * g + 2], vv[4 * g + 3]));
-    if (p.out_hi) store_planes16(p.out_hi, p.out_lo, (size_t)m * C + nf - 4 * lh, lh, vv);   // 16-byte plane stores (dv_device.h)
+    const bool gnx = p.gnx.xchg != nullptr;
     if (p.stats16) {
       // (padded row spaces: the utterance's last row block holds cnt < 32 frames that exist - the others stay out)
       const int Tv = p.Tv > 0 ? p.Tv : p.T, cnt = min(32, Tv - (m0 - (m0 / p.T) * p.T));
@@ -991,9 +989,42 @@ __global__ __launch_bounds__(NT_LAUNCH) void k_chain_ff(const ChainFFParams p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) { const float dv = r_ok ? vv[r] - mb[r >> 3] : 0.f; a2[r >> 3] = fmaf(dv, dv, a2[r >> 3]); }
       a2[0] = wave_sum64(a2[0]); a2[1] = wave_sum64(a2[1]);
-      if (lane < 2)
-        reinterpret_cast<float2*>(p.stats16)[(size_t)blockIdx.x * (C / 16) + wn * 2 + lane] =
-            make_float2(lane ? a1[1] : a1[0], lane ? a2[1] : a2[0]);
+      if (lane < 2) {
+        const float2 val = make_float2(lane ? a1[1] : a1[0], lane ? a2[1] : a2[0]);
+        reinterpret_cast<float2*>(p.stats16)[(size_t)blockIdx.x * (C / 16) + wn * 2 + lane] = val;
+        if (gnx)       // for the other row blocks of the utterance: one 8-byte word (sum, M2), written through
+          __hip_atomic_store(p.gnx.xchg + (size_t)blockIdx.x * (C / 16) + wn * 2 + lane,
+                             (unsigned long long)__float_as_uint(val.x) | ((unsigned long long)__float_as_uint(val.y) << 32),
+                             __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
+    }
+    // (the statistics go out FIRST: the other row blocks of the utterance wait for them, nobody waits for these stores)
+    if (p.out) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+        dv_st16(p.out + (size_t)m * C + nf + 8 * g, make_float4(vv[4 * g], vv[4 * g + 1], vv[4 * g + 2], vv[4 * g + 3]));
+    }
+    if (p.out_hi) store_planes16(p.out_hi, p.out_lo, (size_t)m * C + nf - 4 * lh, lh, vv);   // 16-byte plane stores (dv_device.h)
+    if (gnx) {
+      // ---- the consumer's GroupNorm (+ SiLU) of this block's output, a concatenated skip tensor included (gnx_device.h):
+      //      the four waves that are left reduce the groups, then normalise their own fragment ----
+      __shared__ GnxShared<C> s_gnx;
+      GnxTile t;
+      t.M = p.M; t.N = C; t.T_out = p.T; t.Tv_out = p.Tv > 0 ? p.Tv : p.T; t.m0 = m0; t.n0 = 0; t.bm = BM; t.bn = C; t.bq = m0 / p.T;
+      gnx_finish_table<C>(p.gnx, t, s_gnx, tid, lane, wave, 4, [](int) {});
+      float y[16];
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const float4 sa = *reinterpret_cast<const float4*>(s_gnx.gA + nf + 8 * g);
+        const float4 sb = *reinterpret_cast<const float4*>(s_gnx.gB + nf + 8 * g);
+        y[4 * g] = fmaf(vv[4 * g], sa.x, sb.x); y[4 * g + 1] = fmaf(vv[4 * g + 1], sa.y, sb.y);
+        y[4 * g + 2] = fmaf(vv[4 * g + 2], sa.z, sb.z); y[4 * g + 3] = fmaf(vv[4 * g + 3], sa.w, sb.w);
+      }
+      if (p.gnx.silu) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) y[r] = y[r] * __builtin_amdgcn_rcpf(1.0f + __expf(-y[r]));
+      }
+      store_planes16(p.gnx.y_hi, p.gnx.y_lo, (size_t)m * C + nf - 4 * lh, lh, y);
     }
   }
 }
@@ -1081,11 +1112,26 @@ static constexpr int FF_SMEM = 2 * 2 * CHUNK_PL + 2 * 8 * CHUNK_PL + 16384;
 bool chain_ff_supported(const ChainFFParams& p, int precision) {
   return precision == 0 && p.C == 128 && p.M % 32 == 0 && p.T % 32 == 0 && p.M % p.T == 0 && p.Tv >= 0 && p.Tv <= p.T && (p.Tv == 0 || p.Tv > p.T - 32);
 }
+// In-launch GroupNorm of k_chain_ff's output: one workgroup per row block and all of them resident (the conditions of
+// gemm_gnx_plan, kernels_gemm.hip, for a launch whose tiles are whole rows)
+int chain_ff_gnx_plan(const ChainFFParams& p, int n_cu) {
+  const GnxParams& gx = p.gnx;
+  if (!p.stats16 || gx.groups <= 0 || gx.groups > 64 || gx.sk_c < 0 || gx.sk_c > DV_GSK || gx.sk_c % 16 != 0 || gx.tscale) return 0;
+  if ((p.C + gx.sk_c) % gx.groups != 0) return 0;
+  const int cpg = (p.C + gx.sk_c) / gx.groups;
+  if (cpg % 16 != 0 || (p.T / 32) * (cpg / 16) > 256 || p.M / 32 > n_cu) return 0;
+  return (p.M / 32) * (p.C / 16);
+}
 hipError_t launch_chain_ff(const ChainFFParams& p, int precision, hipStream_t st) {
   if (!chain_ff_supported(p, precision)) return hipErrorInvalidValue;
-  if (!p.a_hi || !p.a_lo || !p.rowstat || !p.wg_hi || !p.wg_lo || !p.bg || !p.ug || !p.wm_hi || !p.wm_lo || !p.bm || !p.res || !p.out ||
+  if (!p.a_hi || !p.a_lo || !p.rowstat || !p.wg_hi || !p.wg_lo || !p.bg || !p.ug || !p.wm_hi || !p.wm_lo || !p.bm || !p.res ||
       (p.out_hi && !p.out_lo))
     return hipErrorInvalidValue;
+  if (p.gnx.xchg) {
+    static const int n_cu = [] { int d = 0, n = 0; (void)hipGetDevice(&d); (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, d); return n; }();
+    if (!p.gnx.status || !p.gnx.y_hi || !p.gnx.y_lo || !p.gnx.gamma || !p.gnx.beta || chain_ff_gnx_plan(p, n_cu) <= 0) return hipErrorInvalidValue;
+    if (p.gnx.sk_c > 0 && (!p.gnx.sk_x || !p.gnx.sk_stat16 || !p.gnx.sk_y_hi || !p.gnx.sk_y_lo)) return hipErrorInvalidValue;
+  } else if (!p.out) return hipErrorInvalidValue;
   hipLaunchKernelGGL(k_chain_ff, dim3(p.M / BM), dim3(NT_LAUNCH), FF_SMEM, st, p);
   return hipGetLastError();
 }

@@ -156,7 +156,9 @@ def test_unet_single_utterance_odd_length(gold):
     n2 = m.hip_engine().stats()[0]
     assert rel_l2(y1.cpu().numpy(), gold("unet_oddT.npz")["y"][:1]) < 2e-4
     assert rel_l2(y2.cpu().numpy(), gold("unet_oddT.npz")["y"]) < 2e-4
-    assert n1 <= 170 and n2 <= 170, (n1, n2)
+    # (levels with fewer than 128 rows in the whole batch - here 64 and 32 of the single utterance - run one launch per GEMM
+    # instead of the row-block chains: measured faster, engine.hip chain_min_rows; 146 launches otherwise)
+    assert n1 <= 180 and n2 <= 160, (n1, n2)
     assert m.hip_engine().handover_status()[1] == 0
 
 
@@ -241,7 +243,9 @@ def test_odd_lengths_run_the_fused_schedule_and_match_the_oracle(B, T, L):
     assert rel_l2(outs[0], y_ref) < 2e-4, rel_l2(outs[0], y_ref)
     assert rel_l2(outs[1], y_ref) < 2e-4
     assert rel_l2(outs[0], outs[1]) < 5e-5
-    assert launches[0] <= 170 < launches[1], launches
+    # (<= 156 launches, + 10 per level that has fewer than 128 rows in the whole batch and so runs one launch per GEMM instead of
+    # the row-block chains - engine.hip chain_min_rows; B = 2, T = 37: levels of 64 / 64 / 64 / 64 rows)
+    assert launches[0] <= (170 if B * T >= 256 else 200) < launches[1], launches
 
 
 def test_unet_bf16_fast_mode(gold):
