@@ -99,11 +99,15 @@ struct GemmTile {
 };
 
 // tile menu, largest first; *G variants keep a 64-column block inside one wave (FN == 2) for GEGLU
+#ifndef DV_T2_WM
+#define DV_T2_WM 2   // wave grid of the 64x64 tile (experiment builds: 1x2 / 2x1 - 64x32 / 32x64 per wave, fewer LDS operand reads)
+#define DV_T2_WN 2
+#endif
 template <int BK> struct Tiles {
   using T0 = GemmTile<128, 128, 32, 2, 2, 2>;
   using T0S = GemmTile<128, 128, 32, 2, 2, 1>;
   using T1 = GemmTile<128, 64, BK, 4, 1, (BK == 64 ? 2 : 1)>;
-  using T2 = GemmTile<64, 64, BK, 2, 2, (BK == 64 ? 2 : 1)>;   // 8 waves at BK = 64 (k-split pairs)
+  using T2 = GemmTile<64, 64, BK, DV_T2_WM, DV_T2_WN, (BK == 64 ? 2 : 1)>;   // 8 waves at BK = 64 (k-split pairs)
   using T2S = GemmTile<64, 64, BK, 2, 2, 1>;
   using T2G = GemmTile<64, 64, BK, 2, 1>;
   // (small tiles with ONE k-group - 2 / 1 waves - measured 1500 cycles per k-tile against 1030 for the 8-wave 64x64 tile
