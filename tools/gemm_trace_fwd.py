@@ -42,7 +42,8 @@ torch.cuda.synchronize()
 dbuf = C.create_string_buffer(256)
 n_gemm = lib.dv_debug_gemm_trace_desc(dbuf, 256)
 print("%d GEMM launches per forward (B=%d, T=%d); cycles = s_memtime ticks, medians over the launch's workgroups" % (n_gemm, B, T))
-print("  n  wgs | prologue  lands  k-loop  kgrp-add  pair | bias+res  stores  stats  gnx-wait  gnx-sync  rest | whole  span | what")
+# (differences are taken inside one workgroup only: s_memtime counters of different XCDs are not aligned)
+print("  n  wgs | prologue  lands  k-loop  kgrp-add  pair | bias+res  stores  stats  gnx-wait  gnx-sync  rest | whole | what")
 buf = np.zeros((NWG, W), dtype=np.uint64)
 tot = np.zeros(12)
 for n in range(n_gemm):
@@ -74,9 +75,15 @@ for n in range(n_gemm):
     last = 21 if has(21) else (18 if has(18) else 4)
     rest = d(5, last)
     whole = d(5, 0)
-    span = int(f[:, 5].max() - a[:, 0].min())
+    if "--prologue" in sys.argv:       # where the prologue goes: arguments arrive | row geometry | side DMAs issued | first tile issued
+        ok = lambda k: (a[:, k] > 0).all()
+        parts = [d(8, 0, a) if ok(8) else 0, d(9, 8, a) if ok(9) and ok(8) else 0, d(10, 9, a) if ok(10) and ok(9) else 0,
+                 d(1, 10, a) if ok(10) else 0]
+        print("%3d %4d | args %6d  rows %6d  side %6d  first-tile %6d | prologue %6d | whole %6d | %s"
+              % ((n, len(a)) + tuple(parts) + (pro, whole, dbuf.value.decode())))
+        continue
     row = [pro, lands, kloop, kadd, pair, e16, e17, e18, gw, gs, rest, whole]
     tot += np.array(row, dtype=np.float64)
-    print("%3d %4d | %7d %6d %7d %8d %6d | %7d %7d %6d %8d %8d %6d | %6d %6d | %s"
-          % ((n, len(a)) + tuple(row) + (span, dbuf.value.decode())))
+    print("%3d %4d | %7d %6d %7d %8d %6d | %7d %7d %6d %8d %8d %6d | %6d | %s"
+          % ((n, len(a)) + tuple(row) + (dbuf.value.decode(),)))
 print("sum      | %7d %6d %7d %8d %6d | %7d %7d %6d %8d %8d %6d | %6d" % tuple(int(v) for v in tot))
