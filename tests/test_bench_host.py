@@ -36,5 +36,6 @@ def test_committed_pmc_json_is_stamped():
     for p in files:
         d = json.load(open(p))
         assert d["build"]["dv_version"].startswith("dvits_hip") and d["build"]["git_head"]
-        for fam in ("gemm", "chain", "attention", "gn_apply"):
+        # (the schedule of round 4's final build has no k_gn_apply launch left: that family is present up to round 3 only)
+        for fam in ("gemm", "chain", "attention") + (("gn_apply",) if "gn_apply" in d else ()):
             assert d[fam]["launches"] > 0 and d[fam]["hbm_bytes_per_launch"] > 0
