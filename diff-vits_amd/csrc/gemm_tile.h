@@ -423,16 +423,24 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int m0, con
       const int m = min(m0 + r, p.M - 1);
       const float2* src = reinterpret_cast<const float2*>(p.ln_stat) + (size_t)m * p.ln_nblk;
       // partials per 32-column block: (sum, sum of squared deviations from the block's own mean); combined with the
-      // parallel-variance formula, so no E[x^2] - mean^2 cancellation for rows whose mean is large against their spread
+      // parallel-variance formula, so no E[x^2] - mean^2 cancellation for rows whose mean is large against their spread.
+      // All of a row's partials are requested at once (launch_gemm: at most 16 blocks): ONE memory round trip at the head of
+      // the workgroup instead of two dependent ones (round 4: 5000-9000 of these GEMMs' prologue cycles were here; +1.5 % end
+      // to end.  Reducing them BEHIND the first k-tiles' DMAs instead - no barrier, the round trip under the issue phase - was
+      // -1.6 %: the compiler's wait for these loads then also waits for every DMA behind them.)
+      float2 v[16];
+#pragma unroll
+      for (int k = 0; k < 16; ++k) v[k] = k < p.ln_nblk ? ld_mut2<SC1>(src + k) : make_float2(0.f, 0.f);
       float s1 = 0.f;
-      for (int k = 0; k < p.ln_nblk; ++k) s1 += ld_mut2<SC1>(src + k).x;
+#pragma unroll
+      for (int k = 0; k < 16; ++k) s1 += v[k].x;
       const float inv_c = 1.0f / (float)(p.ln_nblk * 32);
       const float mean = s1 * inv_c;
       float m2 = 0.f;
-      for (int k = 0; k < p.ln_nblk; ++k) {
-        const float2 v = ld_mut2<SC1>(src + k);
-        const float dm = v.x * (1.0f / 32.0f) - mean;
-        m2 += v.y + 32.0f * dm * dm;
+#pragma unroll
+      for (int k = 0; k < 16; ++k) {
+        const float dm = v[k].x * (1.0f / 32.0f) - mean;
+        m2 += k < p.ln_nblk ? v[k].y + 32.0f * dm * dm : 0.f;
       }
       s_ln[r] = make_float2(mean, 1.0f / sqrtf(m2 * inv_c + p.ln_eps));
     }

@@ -299,6 +299,7 @@ hipError_t launch_gemm(const GemmParams& pin, int precision, hipStream_t st) {
   if (p.Tv_out > p.T_out || p.Tv_in > p.T_in || ((p.stats16 || p.gnx.xchg) && p.Tv_out <= p.T_out - 32)) return hipErrorInvalidValue;
   if (p.T_out < 1 || (unsigned long long)(p.M > 0 ? p.M : 1) * (unsigned long long)p.T_out >= (1ull << 32)) return hipErrorInvalidValue;
   p.tout_magic = gemm_tout_magic(p.T_out);
+  if (p.ln_stat && (p.ln_nblk < 1 || p.ln_nblk > 16)) return hipErrorInvalidValue;   // (a row's LayerNorm partials are held in registers: gemm_tile.h)
   for (int s2 = 0; s2 < p.nseg; ++s2)     // (a lane on the zero page walks a row's k-tiles inside it: gemm_tile.h prep_a_next)
     if (2 * (size_t)p.seg[s2].c0 + 256 > DV_ZERO_PAGE_BYTES || 2 * (size_t)p.seg[s2].c1 + 256 > DV_ZERO_PAGE_BYTES) return hipErrorInvalidValue;
   if (p.gnx.xchg && p.sk_mode == 0) {            // (checked once, before the split-K recursion)
