@@ -146,6 +146,11 @@ __device__ __forceinline__ unsigned dv_cvt_pk_bf16(float lo, float hi) {
 // end to end but 1e-4 of error per forward - rejected; fp16 keeps 8x the precision for the same instruction count.]
 // 0: the three-product split-bf16 form.  Writers of V^T fragments (kernels_chain.hip) and the kernels that multiply them agree
 // through this one macro.
+// Row-block chains: with NS >= 2 output fragments per wave the two k-groups of a stage each OWN half of the fragments (hand the
+// others over, run the epilogue on their own) instead of k-group 1 handing everything to k-group 0 (kernels_chain.hip).  0: off.
+#ifndef DV_CHAIN_OWN
+#define DV_CHAIN_OWN 1
+#endif
 #ifndef DV_ATTN_PF16
 #define DV_ATTN_PF16 1
 #endif

@@ -208,46 +208,52 @@ __global__ __launch_bounds__((chain_pf_wave<NS, AMODE, XA, SA, CS>() ? NT_LAUNCH
       __builtin_amdgcn_sched_barrier(0);
     }
   };
-  // k-group 1 hands its accumulators to k-group 0 through `buf` (NS * 16 KiB)
-  auto kgroup_reduce = [&](f32x16 (&acc)[NS], char* buf) __attribute__((always_inline)) {
+  // The two k-groups add their accumulators through `buf` (NS * 16 KiB).  own_tag false: k-group 1 hands everything to k-group
+  // 0, which runs the epilogue alone.  own_tag true (stages with NS >= 2 fragments per wave - round 4): fragment ns BELONGS to
+  // k-group ns & 1 - each group hands over the fragments of the other and keeps its own, so both directions cross the LDS at
+  // once and both groups run the epilogue, on half the fragments each (same two addends per sum: the same bits).
+  auto owns = [&](int ns, auto own_tag) { return decltype(own_tag)::value ? (ns & 1) == kg : kg == 0; };
+  auto kgroup_reduce = [&](f32x16 (&acc)[NS], char* buf, auto own_tag) __attribute__((always_inline)) {
     float* red = reinterpret_cast<float*>(buf);
     __syncthreads();                               // the buffer's previous readers are done; every wave has left its k-loop
     if constexpr (PFW) {                           // (nine-wave instantiations sit at the 168-VGPR cap: dword form, no temporaries)
-      if (kg == 1) {
 #pragma unroll
-        for (int ns = 0; ns < NS; ++ns)
+      for (int ns = 0; ns < NS; ++ns)
+        if (!owns(ns, own_tag)) {
 #pragma unroll
           for (int r = 0; r < 16; ++r) red[((ns * 4 + wn) * 16 + r) * 64 + lane] = acc[ns][r];
-      }
+        }
       __syncthreads();
-      if (kg == 0) {
 #pragma unroll
-        for (int ns = 0; ns < NS; ++ns)
+      for (int ns = 0; ns < NS; ++ns)
+        if (owns(ns, own_tag)) {
 #pragma unroll
           for (int r = 0; r < 16; ++r) acc[ns][r] += red[((ns * 4 + wn) * 16 + r) * 64 + lane];
-      }
+        }
       return;
     }
     // (16-byte LDS accesses, lane-linear: a quarter of the instructions of the dword form)
     float4* red4 = reinterpret_cast<float4*>(red);
-    if (kg == 1) {
 #pragma unroll
-      for (int ns = 0; ns < NS; ++ns)
+    for (int ns = 0; ns < NS; ++ns)
+      if (!owns(ns, own_tag)) {
 #pragma unroll
         for (int g = 0; g < 4; ++g)
           red4[((ns * 4 + wn) * 4 + g) * 64 + lane] = make_float4(acc[ns][4 * g], acc[ns][4 * g + 1], acc[ns][4 * g + 2], acc[ns][4 * g + 3]);
-    }
+      }
     __syncthreads();
-    if (kg == 0) {
 #pragma unroll
-      for (int ns = 0; ns < NS; ++ns)
+    for (int ns = 0; ns < NS; ++ns)
+      if (owns(ns, own_tag)) {
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
           const float4 v = red4[((ns * 4 + wn) * 4 + g) * 64 + lane];
           acc[ns][4 * g] += v.x; acc[ns][4 * g + 1] += v.y; acc[ns][4 * g + 2] += v.z; acc[ns][4 * g + 3] += v.w;
         }
-    }
+      }
   };
+  using OwnSplit = std::integral_constant<bool, (NS >= 2) && DV_CHAIN_OWN>;   // stage 1 and the whole-width stage-2 passes
+  using OwnNone = std::false_type;
 
   // ================= A operand of stage 1 =================
   if (AMODE == 0) {
@@ -351,13 +357,14 @@ __global__ __launch_bounds__((chain_pf_wave<NS, AMODE, XA, SA, CS>() ? NT_LAUNCH
   using Ns2 = std::integral_constant<int, CS ? 1 : NS>;
   const int cs_frag0 = CS ? part * 4 : 0;          // column split: this part's fragment group
   stage_prologue(p.w2_hi, p.w2_lo, ps_lo * (C / 32) + cs_frag0, bq, Ns2{}, KHfull{}, 0);
-  kgroup_reduce(acc, red_reg);                     // (its leading barrier: every wave is done reading the A operand)
+  kgroup_reduce(acc, red_reg, OwnSplit{});         // (its leading barrier: every wave is done reading the A operand)
   DV_CTRACE(4);
-  // epilogue 1 (k-group 0): x1 = acc + b1 (+ res) -> out1 fp32, raw split planes into the A region, row partials
-  if (kg == 0) {
+  // epilogue 1 (the fragment's owner): x1 = acc + b1 (+ res) -> out1 fp32, raw split planes into the A region, row partials
+  {
     const int m = m0 + l31;
 #pragma unroll
     for (int ns = 0; ns < NS; ++ns) {
+      if (!owns(ns, OwnSplit{})) continue;
       const int nf = ns * 128 + wn * 32 + 4 * lh;           // column of g = 0, e = 0
       float vv[16];
 #pragma unroll
@@ -423,15 +430,17 @@ __global__ __launch_bounds__((chain_pf_wave<NS, AMODE, XA, SA, CS>() ? NT_LAUNCH
     stage_loop(p.w2_hi, p.w2_lo, ps * (C / 32) + cs_frag0, bq, acc, std::integral_constant<bool, MODE == 2>{}, Ns2{}, KHfull{}, 0);
     if (ps == 0) DV_CTRACE(6);
     if (ps + 1 < npass) stage_prologue(p.w2_hi, p.w2_lo, (ps + 1) * (C / 32) + cs_frag0, bq, Ns2{}, KHfull{}, 0);
-    kgroup_reduce(acc, red_reg);
+    using OwnP = std::integral_constant<bool, OwnSplit::value && !CS>;   // (a column-split pass has one fragment per wave)
+    kgroup_reduce(acc, red_reg, OwnP{});
     if (ps == 0) DV_CTRACE(7);
     if (MODE == 2) {
-      if (kg == 0) {
+      {
         // V: lane = channel ns*128 + wn*32 + l31, registers = rows (keys) 8g + 4lh + e.  Registers 8kb .. 8kb+7 are the
         // 8 keys a lane of the S^T accumulator holds for k-block kb: written as they are, they form the V^T fragment
         // (channel block f = ns*4 + wn, k-block kb) of this 32-key tile
 #pragma unroll
         for (int ns = 0; ns < NS; ++ns) {
+          if (!owns(ns, OwnP{})) continue;
           const int n = 2 * C + ns * 128 + wn * 32 + l31;
           const float bv = p.b2[n], uv = p.u2[n];
 #pragma unroll
@@ -462,11 +471,12 @@ __global__ __launch_bounds__((chain_pf_wave<NS, AMODE, XA, SA, CS>() ? NT_LAUNCH
           }
         }
       }
-    } else if (kg == 0) {
+    } else {
       const int m = m0 + l31;
       const float2 st = s_ln[l31];
 #pragma unroll
       for (int ns = 0; ns < (CS ? 1 : NS); ++ns) {
+        if (!owns(ns, OwnP{})) continue;
         const int nf = ps * C + (CS ? part : ns) * 128 + wn * 32 + 4 * lh;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
@@ -692,7 +702,7 @@ __global__ __launch_bounds__((chain_pf_wave<NS, AMODE, XA, SA, CS>() ? NT_LAUNCH
       for (int r = 0; r < 16; ++r) acc[ns][r] = 0.f;
     stage_loop(p.w3_hi, p.w3_lo, 0, bq, acc, std::false_type{}, std::integral_constant<int, NS>{}, KH3{}, ks3);
     DV_CTRACE(13);
-    kgroup_reduce(acc, red_reg);
+    kgroup_reduce(acc, red_reg, OwnNone{});
     DV_CTRACE(14);
     if (XS) {
       // hand-over between the two workgroups of the row block (the fused split-K pair's protocol, gemm_tile.h): dump the
