@@ -1,3 +1,6 @@
+#!/usr/bin/env python3
+"""Hash of the denoiser output at three shapes (GPU box): two builds whose change is meant to be bit-neutral must print the same
+lines.  Usage: python tools/hash_fwd.py   |   DVITS_LIB_FILE=diff-vits_amd/libdvits_hip_<other>.so python tools/hash_fwd.py"""
 import sys, hashlib, torch
 sys.path.insert(0, '.')
 import bench
