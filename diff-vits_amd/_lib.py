@@ -15,6 +15,7 @@ CSRC = os.path.join(_HERE, "csrc")
 PREC_BF16X3, PREC_BF16 = 0, 1
 SOLVER_DPMPP, SOLVER_UNIPC_BH1, SOLVER_UNIPC_BH2, SOLVER_UNIPC_VARY = 0, 1, 2, 3
 SKIP = {"time_uniform": 0, "time_quadratic": 1, "logSNR": 2}
+SCHEDULE = {"discrete": 0, "linear": 1, "cosine": 2}
 
 
 class UNetCfg(C.Structure):
@@ -64,6 +65,8 @@ SIGNATURES = {
                                   C.POINTER(C.c_void_p)]),
     "dv_sampler_plan_ex": (C.c_int, [C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                      C.c_double, C.c_double, C.c_int32, C.POINTER(C.c_void_p)]),
+    "dv_sampler_plan_sched": (C.c_int, [C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_double, C.c_double, C.c_int32, C.c_int32,
+                                        C.c_int32, C.c_int32, C.c_double, C.c_double, C.c_int32, C.POINTER(C.c_void_p)]),
     "dv_plan_destroy": (None, [C.c_void_p]),
     "dv_plan_info": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.c_void_p, C.c_void_p]),
     "dv_plan_coefs": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.c_void_p]),

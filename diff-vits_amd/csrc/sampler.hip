@@ -41,9 +41,21 @@ namespace {
 
 // NoiseScheduleVP('discrete', betas) — dpm_solver.py:6-167 / uni_pc.py:6-152.  The arrays are
 // built in float32 exactly as the reference stores them, then evaluated in fp64.
+// kind 1 / 2: the continuous-time VP schedules 'linear' (dpm_solver.py:108-111,133-134,160-163; uni_pc.py the same) and
+// 'cosine' (uni_pc.py:73-100 only): closed forms, total_N = 1000, T = 1 / 0.9946; the model then sees t itself
+// (get_model_input_time, dpm_solver.py:271-280).
 struct Schedule {
   std::vector<double> t_arr, la_arr;   // keypoints (float32 values widened)
   int total_N = 0;
+  int kind = 0;                        // 0 discrete, 1 linear, 2 cosine
+  double beta0 = 0.1, beta1 = 20.0, T = 1.0;
+  static constexpr double COS_S = 0.008;
+  double cos_la0 = 0.0;
+  void init_continuous(int k, double b0, double b1) {
+    kind = k; beta0 = b0; beta1 = b1; total_N = 1000;
+    T = k == 2 ? 0.9946 : 1.0;
+    cos_la0 = log(cos(COS_S / (1.0 + COS_S) * M_PI / 2.0));
+  }
   void init(const float* betas, int n, bool clip) {
     std::vector<float> la(n);
     float acc = 0.f;
@@ -83,14 +95,24 @@ struct Schedule {
     if (i > K - 2) i = K - 2;
     return Y(i) + (x - X(i)) * (Y(i + 1) - Y(i)) / (X(i + 1) - X(i));
   }
-  double log_alpha(double t) const { return interp(t, t_arr, la_arr, false); }
+  double log_alpha(double t) const {
+    if (kind == 1) return -0.25 * t * t * (beta1 - beta0) - 0.5 * t * beta0;
+    if (kind == 2) return log(cos((t + COS_S) / (1.0 + COS_S) * M_PI / 2.0)) - cos_la0;
+    return interp(t, t_arr, la_arr, false);
+  }
   double alpha(double t) const { return exp(log_alpha(t)); }
   double sigma(double t) const { return sqrt(1.0 - exp(2.0 * log_alpha(t))); }
   double lambda(double t) const { const double la = log_alpha(t); return la - 0.5 * log(1.0 - exp(2.0 * la)); }
   double inverse_lambda(double lamb) const {
     // log_alpha = -0.5 * logaddexp(0, -2 lamb); interpolate t on the flipped arrays
     const double a = -2.0 * lamb;
-    const double lae = -0.5 * (a > 0 ? a + log1p(exp(-a)) : log1p(exp(a)));
+    const double lse = a > 0 ? a + log1p(exp(-a)) : log1p(exp(a));      // logaddexp(-2 lamb, 0)
+    if (kind == 1) {
+      const double tmp = 2.0 * (beta1 - beta0) * lse, delta = beta0 * beta0 + tmp;
+      return tmp / (sqrt(delta) + beta0) / (beta1 - beta0);
+    }
+    if (kind == 2) return acos(exp(-0.5 * lse + cos_la0)) * 2.0 * (1.0 + COS_S) / M_PI - COS_S;
+    const double lae = -0.5 * lse;
     return interp(lae, la_arr, t_arr, true);
   }
 };
@@ -161,7 +183,7 @@ static int build_plan(dv_plan* p) {
   const Schedule& ns = p->ns;
   const int N = p->steps, order = p->order;
   // dpm_solver.py:1157-1158 / uni_pc.py:596-597: t_0 = 1/N unless t_end is given, t_T = T unless t_start is given
-  const double t_0 = p->t_end > 0 ? p->t_end : 1.0 / ns.total_N, t_T = p->t_start > 0 ? p->t_start : 1.0;
+  const double t_0 = p->t_end > 0 ? p->t_end : 1.0 / ns.total_N, t_T = p->t_start > 0 ? p->t_start : ns.T;
   // ---- time grid (get_time_steps, dpm_solver.py:453-480), float32 as the reference stores it
   p->timesteps.resize(N + 1);
   auto linspace32 = [&](float a, float b, std::vector<double>& out) {
@@ -185,6 +207,7 @@ static int build_plan(dv_plan* p) {
 
   auto t_in = [&](double t) {   // get_model_input_time, float32 arithmetic (dpm_solver.py:271-280)
     const float tf = (float)t;
+    if (ns.kind != 0) return (double)tf;            // continuous-time schedules: the model's time is t
     return (double)((tf - (float)(1.0 / ns.total_N)) * (float)ns.total_N);
   };
   auto add_eval = [&](int src, double t, int slot) {
@@ -396,7 +419,20 @@ extern "C" int dv_sampler_plan(int32_t solver, const float* betas, int32_t n_bet
 extern "C" int dv_sampler_plan_ex(int32_t solver, const float* betas, int32_t n_betas, int32_t steps, int32_t order,
                                   int32_t skip_type, int32_t lower_order_final, double t_start, double t_end,
                                   int32_t denoise_to_zero, dv_plan** out) {
-  if (!betas || !out || n_betas < 2) return dv_fail(DV_ERR_INVALID, "dv_sampler_plan: bad argument");
+  return dv_sampler_plan_sched(solver, DV_SCHEDULE_DISCRETE, betas, n_betas, 0.0, 0.0, steps, order, skip_type, lower_order_final,
+                               t_start, t_end, denoise_to_zero, out);
+}
+
+extern "C" int dv_sampler_plan_sched(int32_t solver, int32_t schedule, const float* betas, int32_t n_betas, double beta_0,
+                                     double beta_1, int32_t steps, int32_t order, int32_t skip_type,
+                                     int32_t lower_order_final, double t_start, double t_end, int32_t denoise_to_zero,
+                                     dv_plan** out) {
+  if (!out) return dv_fail(DV_ERR_INVALID, "dv_sampler_plan: bad argument");
+  if (schedule < DV_SCHEDULE_DISCRETE || schedule > DV_SCHEDULE_COSINE) return dv_fail(DV_ERR_INVALID, "unknown noise schedule %d", schedule);
+  if (schedule == DV_SCHEDULE_DISCRETE && (!betas || n_betas < 2)) return dv_fail(DV_ERR_INVALID, "dv_sampler_plan: bad argument");
+  if (schedule == DV_SCHEDULE_COSINE && solver == DV_SOLVER_DPMPP)      // (dpm_solver.py:94: 'discrete' or 'linear')
+    return dv_fail(DV_ERR_INVALID, "the 'cosine' schedule exists for the UniPC solvers only");
+  if (schedule == DV_SCHEDULE_LINEAR && !(beta_1 > beta_0 && beta_0 >= 0.0)) return dv_fail(DV_ERR_INVALID, "linear schedule: need 0 <= beta_0 < beta_1");
   if (solver < DV_SOLVER_DPMPP || solver > DV_SOLVER_UNIPC_VARY) return dv_fail(DV_ERR_INVALID, "unknown solver %d", solver);
   if (solver == DV_SOLVER_DPMPP && (order < 1 || order > 3)) return dv_fail(DV_ERR_INVALID, "Solver order must be 1 or 2 or 3, got %d", order);
   if (order < 1 || order > MAXO) return dv_fail(DV_ERR_INVALID, "UniPC order must be 1..%d, got %d", MAXO, order);
@@ -404,7 +440,8 @@ extern "C" int dv_sampler_plan_ex(int32_t solver, const float* betas, int32_t n_
   dv_plan* p = new dv_plan();
   p->solver = solver; p->steps = steps; p->order = order; p->skip = skip_type; p->lof = lower_order_final;
   p->t_start = t_start; p->t_end = t_end; p->denoise_to_zero = denoise_to_zero ? 1 : 0;
-  p->ns.init(betas, n_betas, solver == DV_SOLVER_DPMPP);
+  if (schedule == DV_SCHEDULE_DISCRETE) p->ns.init(betas, n_betas, solver == DV_SOLVER_DPMPP);
+  else p->ns.init_continuous(schedule, beta_0, beta_1);
   int rc = build_plan(p);
   if (rc != DV_OK) { delete p; return rc; }
   *out = p;

@@ -18,16 +18,27 @@ def _lib():
 class NoiseScheduleBase:
     """`NoiseScheduleVP('discrete', betas=... | alphas_cumprod=...)` (reference
     sampler/dpm_solver.py:6-167, sampler/uni_pc.py:6-152).  Arrays are stored in float32 like
-    the reference; the look-ups interpolate them in float64 on the host."""
+    the reference; the look-ups interpolate them in float64 on the host.
+    `NoiseScheduleVP('linear', continuous_beta_0=, continuous_beta_1=)` / `('cosine')`: the continuous-time VP schedules
+    (dpm_solver.py:108-111,133-134,160-163; uni_pc.py:67-100) as closed forms; total_N = 1000, T = 1 (0.9946 for 'cosine')."""
 
     clip_lambda = None   # dpm_solver clips log-SNR at -5.1 (numerical_clip_alpha :114-125); uni_pc does not
+    schedules = ("discrete", "linear")   # (uni_pc adds 'cosine')
+    _COS_S = 0.008
 
     def __init__(self, schedule="discrete", betas=None, alphas_cumprod=None, continuous_beta_0=0.1,
                  continuous_beta_1=20.0, dtype=torch.float32):
-        if schedule != "discrete":
-            raise ValueError("Unsupported noise schedule {}. This build supports schedule='discrete' "
-                             "(the diffusion sampling path)".format(schedule))
+        if schedule not in self.schedules:
+            raise ValueError("Unsupported noise schedule {}. The schedule needs to be {}".format(
+                schedule, " or ".join("'%s'" % s for s in self.schedules)))
         self.schedule = schedule
+        self.beta_0, self.beta_1 = float(continuous_beta_0), float(continuous_beta_1)
+        if schedule != "discrete":
+            self.total_N = 1000
+            self.T = 0.9946 if schedule == "cosine" else 1.0
+            self._betas = np.zeros(2, dtype=np.float32)          # (unused by the native plan of a continuous schedule)
+            self._cos_la0 = float(np.log(np.cos(self._COS_S / (1.0 + self._COS_S) * np.pi / 2.0)))
+            return
         if betas is not None:
             b = torch.as_tensor(betas).detach().to("cpu", torch.float32)
             log_alphas = 0.5 * torch.log(1 - b).cumsum(dim=0)
@@ -56,7 +67,12 @@ class NoiseScheduleBase:
         return yp[i] + (x - xp[i]) * (yp[i + 1] - yp[i]) / (xp[i + 1] - xp[i])
 
     def _la(self, t):
-        return self._interp(np.asarray(torch.as_tensor(t).detach().cpu().double().reshape(-1)), self._xp, self._yp)
+        t = np.asarray(torch.as_tensor(t).detach().cpu().double().reshape(-1))
+        if self.schedule == "linear":
+            return -0.25 * t ** 2 * (self.beta_1 - self.beta_0) - 0.5 * t * self.beta_0
+        if self.schedule == "cosine":
+            return np.log(np.cos((t + self._COS_S) / (1.0 + self._COS_S) * np.pi / 2.0)) - self._cos_la0
+        return self._interp(t, self._xp, self._yp)
 
     @staticmethod
     def _like(v, t):
@@ -79,8 +95,18 @@ class NoiseScheduleBase:
 
     def inverse_lambda(self, lamb):
         lam = np.asarray(torch.as_tensor(lamb).detach().cpu().double().reshape(-1))
-        la = -0.5 * np.logaddexp(0.0, -2.0 * lam)
+        lse = np.logaddexp(0.0, -2.0 * lam)
+        if self.schedule == "linear":        # dpm_solver.py:160-163
+            tmp = 2.0 * (self.beta_1 - self.beta_0) * lse
+            return self._like(tmp / (np.sqrt(self.beta_0 ** 2 + tmp) + self.beta_0) / (self.beta_1 - self.beta_0), lamb)
+        if self.schedule == "cosine":        # uni_pc.py:145-149
+            return self._like(np.arccos(np.exp(-0.5 * lse + self._cos_la0)) * 2.0 * (1.0 + self._COS_S) / np.pi - self._COS_S, lamb)
+        la = -0.5 * lse
         return self._like(self._interp(la, self._yp[::-1], self._xp[::-1]), lamb)
+
+    def _plan_schedule(self):
+        """(kind, beta_0, beta_1) for the native plan (dv_sampler_plan_sched)."""
+        return (self.schedule, self.beta_0, self.beta_1)
 
 
 def wrap_model(model, noise_schedule, model_type="noise", model_kwargs={}, guidance_type="uncond", condition=None,
@@ -99,7 +125,9 @@ def wrap_model(model, noise_schedule, model_type="noise", model_kwargs={}, guida
     def expand(v, x):
         return v.reshape((-1,) + (1,) * (x.dim() - 1))
 
-    def t_input(t_continuous):
+    def t_input(t_continuous):       # get_model_input_time (dpm_solver.py:271-280)
+        if ns.schedule != "discrete":
+            return t_continuous
         return (t_continuous - 1.0 / ns.total_N) * ns.total_N
 
     def model_fn(x, t_continuous):
@@ -122,7 +150,7 @@ class Plan:
     """Compiled multistep loop: events + fp64-derived coefficient rows."""
 
     def __init__(self, solver, betas, steps, order, skip_type, lower_order_final, t_start=None, t_end=None,
-                 denoise_to_zero=False):
+                 denoise_to_zero=False, schedule=("discrete", 0.0, 0.0)):
         L = _lib()
         for name, v in (("t_start", t_start), ("t_end", t_end)):
             # reference dpm_solver.py:1159 / uni_pc.py:598
@@ -132,14 +160,15 @@ class Plan:
             raise ValueError("Unsupported skip_type {}, need to be 'logSNR' or 'time_uniform' or 'time_quadratic'"
                              .format(skip_type))
         betas = np.ascontiguousarray(betas, dtype=np.float32)
-        self._args = (solver, betas, steps, order, skip_type, lower_order_final, t_start, t_end, denoise_to_zero)
+        self._args = (solver, betas, steps, order, skip_type, lower_order_final, t_start, t_end, denoise_to_zero, schedule)
         self._per_shape = {}          # captured graphs live in the native plan, one per plan: a copy per input shape
         self._h = C.c_void_p()
-        L.check(L.lib().dv_sampler_plan_ex(solver, betas.ctypes.data_as(C.c_void_p), len(betas), steps, order,
-                                           L.SKIP[skip_type], int(bool(lower_order_final)),
-                                           -1.0 if t_start is None else float(t_start), -1.0 if t_end is None else float(t_end),
-                                           int(bool(denoise_to_zero)), C.byref(self._h)),
-                "dv_sampler_plan_ex")
+        L.check(L.lib().dv_sampler_plan_sched(solver, L.SCHEDULE[schedule[0]], betas.ctypes.data_as(C.c_void_p), len(betas),
+                                              float(schedule[1]), float(schedule[2]), steps, order,
+                                              L.SKIP[skip_type], int(bool(lower_order_final)),
+                                              -1.0 if t_start is None else float(t_start), -1.0 if t_end is None else float(t_end),
+                                              int(bool(denoise_to_zero)), C.byref(self._h)),
+                "dv_sampler_plan_sched")
         nfe = C.c_int32()
         L.check(L.lib().dv_plan_info(self._h, C.byref(nfe), None, None), "dv_plan_info")
         self.nfe = nfe.value

@@ -5,7 +5,7 @@
 libdvits_hip.so `dv_sampler_plan`) and then either replays it natively (hipGraph: UNet schedule
 + fused update kernels) when the wrapped model is a `NativeUNetModel`, or runs it with torch ops
 around an arbitrary Python callable.  Scope of this build: algorithm_type='dpmsolver++',
-method='multistep', orders 1-3 (reference :1171-1213, :547-580, :796-904).
+method='multistep', orders 1-3 (reference :1171-1213, :547-580, :796-904), schedules 'discrete' and 'linear'.
 """
 import torch
 
@@ -17,8 +17,9 @@ _SOLVER_DPMPP = 0
 
 
 class NoiseScheduleVP(NoiseScheduleBase):
-    """Discrete VP schedule with the log-SNR clip at -5.1 (reference dpm_solver.py:6-167)."""
+    """VP schedule: 'discrete' with the log-SNR clip at -5.1, or the continuous-time 'linear' (reference dpm_solver.py:6-167)."""
     clip_lambda = -5.1
+    schedules = ("discrete", "linear")
 
 
 model_wrapper = wrap_model
@@ -47,7 +48,8 @@ class DPM_Solver:
         key = (steps, order, skip_type, bool(lower_order_final), t_start, t_end, bool(denoise_to_zero))
         if key not in self._plans:
             self._plans[key] = Plan(_SOLVER_DPMPP, self.noise_schedule._betas, steps, order, skip_type,
-                                    lower_order_final, t_start, t_end, denoise_to_zero)
+                                    lower_order_final, t_start, t_end, denoise_to_zero,
+                                    schedule=self.noise_schedule._plan_schedule())
         return self._plans[key]
 
     def sample(self, x, steps=20, t_start=None, t_end=None, order=2, skip_type="time_uniform", method="multistep",

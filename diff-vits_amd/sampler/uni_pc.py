@@ -16,8 +16,9 @@ MAX_ORDER = 8
 
 
 class NoiseScheduleVP(NoiseScheduleBase):
-    """Discrete VP schedule without log-SNR clipping (reference uni_pc.py:6-152)."""
+    """VP schedule without log-SNR clipping: 'discrete', 'linear' or 'cosine' (reference uni_pc.py:6-152)."""
     clip_lambda = None
+    schedules = ("discrete", "linear", "cosine")
 
 
 model_wrapper = wrap_model
@@ -43,7 +44,8 @@ class UniPC:
         key = (steps, order, skip_type, bool(lower_order_final), t_start, t_end, bool(denoise_to_zero))
         if key not in self._plans:
             self._plans[key] = Plan(_SOLVERS[self.variant], self.noise_schedule._betas, steps, order, skip_type,
-                                    lower_order_final, t_start, t_end, denoise_to_zero)
+                                    lower_order_final, t_start, t_end, denoise_to_zero,
+                                    schedule=self.noise_schedule._plan_schedule())
         return self._plans[key]
 
     def sample(self, x, steps=20, t_start=None, t_end=None, order=2, skip_type="time_uniform", method="multistep",

@@ -177,6 +177,11 @@ int dv_unet_probe(dv_unet* u, const char* name, float* host_out, int64_t capacit
  * order x order systems numerically, uni_pc.py:545-560 / :410-420). */
 typedef enum { DV_SOLVER_DPMPP = 0, DV_SOLVER_UNIPC_BH1 = 1, DV_SOLVER_UNIPC_BH2 = 2, DV_SOLVER_UNIPC_VARY = 3 } dv_solver;
 typedef enum { DV_SKIP_TIME_UNIFORM = 0, DV_SKIP_TIME_QUADRATIC = 1, DV_SKIP_LOGSNR = 2 } dv_skip;
+/* NoiseScheduleVP(schedule=...): 'discrete' (betas; dpm_solver.py:98-107, uni_pc.py:59-66), or the continuous-time VP
+ * schedules 'linear' (beta_0, beta_1; dpm_solver.py:108-111,133-134,160-163) and 'cosine' (uni_pc.py:73-100; UniPC only -
+ * dpm_solver.py:94 knows 'discrete' and 'linear').  Continuous schedules: total_N = 1000, T = 1 (0.9946 for 'cosine'), and
+ * the network is called with t itself instead of (t - 1/N) * N (dpm_solver.py:271-280). */
+typedef enum { DV_SCHEDULE_DISCRETE = 0, DV_SCHEDULE_LINEAR = 1, DV_SCHEDULE_COSINE = 2 } dv_schedule;
 
 /* Host fp64 precompute of every schedule scalar of the loop
  * (NoiseScheduleVP + get_time_steps + the multistep coefficient algebra:
@@ -190,6 +195,11 @@ int dv_sampler_plan(int32_t solver, const float* betas, int32_t n_betas, int32_t
 int dv_sampler_plan_ex(int32_t solver, const float* betas, int32_t n_betas, int32_t steps, int32_t order,
                        int32_t skip_type, int32_t lower_order_final, double t_start, double t_end,
                        int32_t denoise_to_zero, dv_plan** out);
+/* ... for any schedule kind: betas / n_betas are read for DV_SCHEDULE_DISCRETE only, beta_0 / beta_1 for DV_SCHEDULE_LINEAR
+ * only (the reference's defaults: 0.1, 20). */
+int dv_sampler_plan_sched(int32_t solver, int32_t schedule, const float* betas, int32_t n_betas, double beta_0, double beta_1,
+                          int32_t steps, int32_t order, int32_t skip_type, int32_t lower_order_final, double t_start,
+                          double t_end, int32_t denoise_to_zero, dv_plan** out);
 void dv_plan_destroy(dv_plan* p);
 
 /* Introspection for tests: number of model evaluations, and the plan's tables.

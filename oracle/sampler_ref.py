@@ -62,6 +62,44 @@ class Schedule:
                                 torch.flip(self.t_array, [0]))
 
 
+class ContinuousSchedule(Schedule):
+    """NoiseScheduleVP('linear' | 'cosine'): the continuous-time VP schedules as the reference evaluates them - closed
+    forms in float32 torch arithmetic (dpm_solver.py:108-111,133-134,160-163; uni_pc.py:67-100,125-149).  total_N = 1000,
+    T = 1 (0.9946 for 'cosine'); the network is called with t itself (dpm_solver.py:271-280)."""
+
+    def __init__(self, kind, beta_0=0.1, beta_1=20.0):
+        import math
+        assert kind in ("linear", "cosine")
+        self.kind, self.beta_0, self.beta_1 = kind, beta_0, beta_1
+        self.total_N = 1000
+        self.cosine_s = 0.008
+        self.cosine_log_alpha_0 = math.log(math.cos(self.cosine_s / (1.0 + self.cosine_s) * math.pi / 2.0))
+        self.T = 0.9946 if kind == "cosine" else 1.0
+
+    def log_alpha(self, t):
+        import math
+        t = t.reshape(-1)
+        if self.kind == "linear":
+            return -0.25 * t ** 2 * (self.beta_1 - self.beta_0) - 0.5 * t * self.beta_0
+        return torch.log(torch.cos((t + self.cosine_s) / (1.0 + self.cosine_s) * math.pi / 2.0)) - self.cosine_log_alpha_0
+
+    def inverse_lambda(self, lamb):
+        import math
+        if self.kind == "linear":
+            tmp = 2.0 * (self.beta_1 - self.beta_0) * torch.logaddexp(-2.0 * lamb, torch.zeros((1,)).to(lamb))
+            delta = self.beta_0 ** 2 + tmp
+            return tmp / (torch.sqrt(delta) + self.beta_0) / (self.beta_1 - self.beta_0)
+        log_alpha = -0.5 * torch.logaddexp(-2.0 * lamb, torch.zeros((1,)).to(lamb))
+        return torch.arccos(torch.exp(log_alpha + self.cosine_log_alpha_0)) * 2.0 * (1.0 + self.cosine_s) / math.pi - self.cosine_s
+
+
+def _schedule(betas, clip, schedule):
+    """`schedule`: None (discrete, from betas) or ('linear' | 'cosine', beta_0, beta_1)."""
+    if schedule is None or schedule[0] == "discrete":
+        return Schedule(betas, clip=clip)
+    return ContinuousSchedule(*schedule)
+
+
 def _bcast(v, x):
     return v.reshape((-1,) + (1,) * (x.dim() - 1))
 
@@ -74,7 +112,7 @@ def wrap_x_start_model(model, ns):
     it and only runs at B=1 where both forms coincide."""
     def data_prediction(x, t):
         tb = t.expand(x.shape[0])
-        t_input = (tb - 1.0 / ns.total_N) * ns.total_N
+        t_input = tb if isinstance(ns, ContinuousSchedule) else (tb - 1.0 / ns.total_N) * ns.total_N
         out = model(x, t_input)
         a, s = ns.alpha(tb), ns.sigma(tb)
         noise = (x - _bcast(a, x) * out) / _bcast(s, x)
@@ -131,11 +169,11 @@ def _dpmpp_update(ns, x, m_list, t_list, t, order):
 
 def dpm_solver_pp_sample(model, betas, x, steps=20, order=2, skip_type="time_uniform",
                          lower_order_final=True, return_intermediate=False, t_start=None, t_end=None,
-                         denoise_to_zero=False):
+                         denoise_to_zero=False, schedule=None):
     """DPM_Solver(model_fn, ns, 'dpmsolver++').sample(x, steps, order, skip_type,
     method='multistep'), dpm_solver.py:1047-1245 (multistep branch :1171-1213).
     `model(x, t_input)` is the raw x0-prediction network."""
-    ns = Schedule(betas, clip=True)
+    ns = _schedule(betas, True, schedule)
     fn = wrap_x_start_model(model, ns)
     # dpm_solver.py:1157-1158: t_0 = 1/N unless t_end is given, t_T = T unless t_start is given
     t_0 = 1.0 / ns.total_N if t_end is None else t_end
@@ -276,10 +314,11 @@ def _unipc_update(ns, fn, x, m_list, t_list, t, order, variant, use_corrector):
 
 
 def unipc_sample(model, betas, x, steps=20, order=2, skip_type="time_uniform", variant="bh2",
-                 lower_order_final=True, return_intermediate=False, t_start=None, t_end=None, denoise_to_zero=False):
+                 lower_order_final=True, return_intermediate=False, t_start=None, t_end=None, denoise_to_zero=False,
+                 schedule=None):
     """UniPC(model_fn, ns, variant=...).sample(x, steps, order, skip_type, 'multistep'),
     uni_pc.py:590-672."""
-    ns = Schedule(betas, clip=False)
+    ns = _schedule(betas, False, schedule)
     fn = wrap_x_start_model(model, ns)
     t_0 = 1.0 / ns.total_N if t_end is None else t_end        # uni_pc.py:596-597
     t_T = ns.T if t_start is None else t_start

@@ -1115,9 +1115,12 @@ def test_native_sampler_options_graph_equals_stepwise():
     x, cond = torch.from_numpy(x).cuda(), torch.from_numpy(cond).cuda()
     enc_t, mask_t = torch.from_numpy(enc_np).cuda(), torch.from_numpy(mask_np).cuda()
     betas = torch.from_numpy(synth.make_betas())
-    for mod, make in ((dpm_solver, lambda fn, ns: dpm_solver.DPM_Solver(fn, ns, algorithm_type="dpmsolver++")),
-                      (uni_pc, lambda fn, ns: uni_pc.UniPC(fn, ns, variant="bh2"))):
-        ns = mod.NoiseScheduleVP("discrete", betas=betas)
+    for mod, make, sched in ((dpm_solver, lambda fn, ns: dpm_solver.DPM_Solver(fn, ns, algorithm_type="dpmsolver++"), "discrete"),
+                             (uni_pc, lambda fn, ns: uni_pc.UniPC(fn, ns, variant="bh2"), "discrete"),
+                             # a continuous-time schedule: the network is called with t itself (dpm_solver.py:271-280)
+                             (dpm_solver, lambda fn, ns: dpm_solver.DPM_Solver(fn, ns, algorithm_type="dpmsolver++"), "linear"),
+                             (uni_pc, lambda fn, ns: uni_pc.UniPC(fn, ns, variant="bh2"), "cosine")):
+        ns = mod.NoiseScheduleVP("discrete", betas=betas) if sched == "discrete" else mod.NoiseScheduleVP(sched)
         native = mod.NativeUNetModel(m, cond, enc_t, mask_t)
         fn = mod.model_wrapper(native, ns, model_type="x_start")
         opts = dict(steps=6, order=2, skip_type="time_uniform", t_start=0.7, t_end=0.1, denoise_to_zero=True)

@@ -158,7 +158,9 @@ def test_solver_error_behaviour():
     with pytest.raises(ValueError):
         dpm_solver.DPM_Solver(fn, ns).sample(x, steps=10, method="singlestep")
     with pytest.raises(ValueError):
-        dpm_solver.NoiseScheduleVP("linear")
+        dpm_solver.NoiseScheduleVP("cosine")       # (dpm_solver.py:94: 'discrete' or 'linear'; uni_pc.py:59 adds 'cosine')
+    with pytest.raises(ValueError):
+        uni_pc.NoiseScheduleVP("bogus")
     with pytest.raises(AssertionError):
         dpm_solver.model_wrapper(lambda xx, t: xx, ns, model_type="bogus")
 
@@ -174,6 +176,13 @@ OPTION_CASES = {
     "unipc_window_dtz": ("unipc", dict(steps=10, order=2, skip_type="time_uniform", t_start=0.9, t_end=0.02, denoise_to_zero=True,
                                         return_intermediate=True)),
     "unipc_o3_logsnr": ("unipc", dict(steps=7, order=3, skip_type="logSNR", t_end=0.004)),
+    # continuous-time schedules (NoiseScheduleVP('linear' | 'cosine'); dpm_solver.py knows 'linear' only)
+    "dpm_linear": ("dpm", dict(steps=10, order=2, skip_type="time_uniform", schedule=("linear", 0.1, 20.0))),
+    "dpm_linear_logsnr_dtz": ("dpm", dict(steps=8, order=3, skip_type="logSNR", denoise_to_zero=True, return_intermediate=True,
+                                          schedule=("linear", 0.1, 20.0))),
+    "unipc_linear_quad": ("unipc", dict(steps=9, order=2, skip_type="time_quadratic", t_end=0.01, schedule=("linear", 0.2, 15.0))),
+    "unipc_cosine": ("unipc", dict(steps=10, order=2, skip_type="time_uniform", return_intermediate=True, schedule=("cosine", 0.1, 20.0))),
+    "unipc_cosine_logsnr": ("unipc", dict(steps=8, order=3, skip_type="logSNR", schedule=("cosine", 0.1, 20.0))),
 }
 
 
@@ -181,11 +190,18 @@ OPTION_CASES = {
 def test_sampler_options_match_reference(gold, key):
     g = gold("sampler_options.npz")
     solver, kw = OPTION_CASES[key]
+    kw = dict(kw)
+    sched = kw.pop("schedule", None)
     B = 2 if solver == "dpm" else 1
     x = torch.from_numpy(synth.normal(1234, "opts." + key, (B, 5, 24)))
     betas = torch.from_numpy(synth.make_betas())
     mod = dpm_solver if solver == "dpm" else uni_pc
-    ns = mod.NoiseScheduleVP("discrete", betas=betas)
+    ns = (mod.NoiseScheduleVP("discrete", betas=betas) if sched is None else
+          mod.NoiseScheduleVP(sched[0], continuous_beta_0=sched[1], continuous_beta_1=sched[2]))
+    # the mirror compiles the loop in fp64; the reference evaluates the continuous schedules' closed forms in float32, where
+    # sigma = sqrt(1 - exp(2 log alpha)) loses ~4 digits near t_end (log alpha ~ -5e-5): the agreement is the reference's
+    # own rounding there (the float32 oracle below reproduces the reference exactly)
+    tol = 2e-5 if sched is None else 5e-4
     fn = mod.model_wrapper(lambda xx, t, **k: sampler_ref.standin_model(xx, t), ns, model_type="x_start")
     if solver == "dpm":
         r = mod.DPM_Solver(fn, ns, algorithm_type="dpmsolver++").sample(x.clone(), method="multistep", **kw)
@@ -196,18 +212,18 @@ def test_sampler_options_match_reference(gold, key):
         ref_inter = g[key + "_inter"]
         assert len(inter) == len(ref_inter)
         for a, b in zip(inter, ref_inter):
-            assert rel_l2(a.numpy(), b) < 2e-5
+            assert rel_l2(a.numpy(), b) < tol
     else:
         out = r
-    assert rel_l2(out.numpy(), g[key + "_x"]) < 2e-5
+    assert rel_l2(out.numpy(), g[key + "_x"]) < tol
     # oracle on the same case
     okw = dict(kw)
     args = (okw.pop("steps"), okw.pop("order"), okw.pop("skip_type"))
     okw.pop("return_intermediate", None)
     if solver == "dpm":
-        o = sampler_ref.dpm_solver_pp_sample(sampler_ref.standin_model, betas, x.clone(), *args, **okw)
+        o = sampler_ref.dpm_solver_pp_sample(sampler_ref.standin_model, betas, x.clone(), *args, schedule=sched, **okw)
     else:
-        o = sampler_ref.unipc_sample(sampler_ref.standin_model, betas, x.clone(), *args, "bh2", **okw)
+        o = sampler_ref.unipc_sample(sampler_ref.standin_model, betas, x.clone(), *args, "bh2", schedule=sched, **okw)
     assert rel_l2(o.numpy(), g[key + "_x"]) < 1e-6
 
 

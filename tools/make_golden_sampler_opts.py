@@ -26,7 +26,21 @@ CASES = {
     "unipc_window_dtz": ("unipc", dict(steps=10, order=2, skip_type="time_uniform", t_start=0.9, t_end=0.02, denoise_to_zero=True,
                                         return_intermediate=True)),
     "unipc_o3_logsnr": ("unipc", dict(steps=7, order=3, skip_type="logSNR", t_end=0.004)),
+    # continuous-time schedules (NoiseScheduleVP('linear' | 'cosine'); dpm_solver.py knows 'linear' only)
+    "dpm_linear": ("dpm", dict(steps=10, order=2, skip_type="time_uniform", schedule=("linear", 0.1, 20.0))),
+    "dpm_linear_logsnr_dtz": ("dpm", dict(steps=8, order=3, skip_type="logSNR", denoise_to_zero=True, return_intermediate=True,
+                                          schedule=("linear", 0.1, 20.0))),
+    "unipc_linear_quad": ("unipc", dict(steps=9, order=2, skip_type="time_quadratic", t_end=0.01, schedule=("linear", 0.2, 15.0))),
+    "unipc_cosine": ("unipc", dict(steps=10, order=2, skip_type="time_uniform", return_intermediate=True, schedule=("cosine", 0.1, 20.0))),
+    "unipc_cosine_logsnr": ("unipc", dict(steps=8, order=3, skip_type="logSNR", schedule=("cosine", 0.1, 20.0))),
 }
+
+
+def make_ns(mod, schedule, betas):
+    """NoiseScheduleVP of module `mod` (reference or mirror) for a case's `schedule` entry (None: discrete)."""
+    if schedule is None:
+        return mod.NoiseScheduleVP("discrete", betas=betas)
+    return mod.NoiseScheduleVP(schedule[0], continuous_beta_0=schedule[1], continuous_beta_1=schedule[2])
 
 
 def rel(a, b):
@@ -46,20 +60,22 @@ def main():
     for key, (solver, kw) in CASES.items():
         B = 2 if solver == "dpm" else 1                        # the reference's UniPC wrapper only broadcasts at B = 1
         x = torch.from_numpy(synth.normal(1234, "opts." + key, (B, 5, 24)))
+        kw = dict(kw)
+        sched = kw.pop("schedule", None)
         if solver == "dpm":
-            ns = ref_dpm.NoiseScheduleVP("discrete", betas=betas)
+            ns = make_ns(ref_dpm, sched, betas)
             fn = ref_dpm.model_wrapper(lambda xx, t, **k: sampler_ref.standin_model(xx, t), ns, model_type="x_start")
             r = ref_dpm.DPM_Solver(fn, ns, algorithm_type="dpmsolver++").sample(x.clone(), method="multistep", **kw)
             okw = {k: v for k, v in kw.items()}
             o = sampler_ref.dpm_solver_pp_sample(sampler_ref.standin_model, betas, x.clone(), okw.pop("steps"), okw.pop("order"),
-                                                 okw.pop("skip_type"), **okw)
+                                                 okw.pop("skip_type"), schedule=sched, **okw)
         else:
-            ns = ref_unipc.NoiseScheduleVP("discrete", betas=betas)
+            ns = make_ns(ref_unipc, sched, betas)
             fn = ref_unipc.model_wrapper(lambda xx, t, **k: sampler_ref.standin_model(xx, t), ns, model_type="x_start")
             r = ref_unipc.UniPC(fn, ns, variant="bh2").sample(x.clone(), method="multistep", **kw)
             okw = {k: v for k, v in kw.items()}
             o = sampler_ref.unipc_sample(sampler_ref.standin_model, betas, x.clone(), okw.pop("steps"), okw.pop("order"),
-                                         okw.pop("skip_type"), "bh2", **okw)
+                                         okw.pop("skip_type"), "bh2", schedule=sched, **okw)
         if kw.get("return_intermediate"):
             xr, inter = r
             xo, ointer = o
