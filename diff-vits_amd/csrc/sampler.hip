@@ -121,7 +121,7 @@ struct Event {
   int type;          // 0 EVAL, 1 COMB
   int src;           // EVAL: input, COMB: base of the c0 term; 0 = x, 1 = x_pred
   int eval_idx;      // EVAL: index into t_input
-  int dst;           // EVAL: history slot;  COMB: 0 = x, 1 = x_pred
+  int dst;           // EVAL: history slot;  COMB: 0 = x, 1 = x_pred, 2 + s = history slot s (in place: x0 -> noise, DV_SOLVER_DPM)
   int coef;          // COMB: row of the coefficient table
   int slots[4];      // COMB: history slots of the m terms (-1 = unused)
 };
@@ -236,7 +236,8 @@ static int build_plan(dv_plan* p) {
   const std::vector<double>& ts = p->timesteps;
   std::vector<int> hist;            // history slots, newest first
   std::vector<double> htime;        // their times
-  const bool unipc = p->solver != DV_SOLVER_DPMPP;
+  const bool unipc = p->solver != DV_SOLVER_DPMPP && p->solver != DV_SOLVER_DPM;
+  const bool noise = p->solver == DV_SOLVER_DPM;   // multistep updates on the noise prediction (algorithm_type='dpmsolver')
   p->n_slots = unipc ? order + 1 : order;
   auto free_slot = [&]() {
     for (int s = 0; s < p->n_slots; ++s) {
@@ -253,8 +254,41 @@ static int build_plan(dv_plan* p) {
   };
 
   if (!unipc) {
-    // ---------------- DPM-Solver++ multistep ----------------
+    // ---------------- DPM-Solver++ / DPM-Solver multistep ----------------
+    // (noise form: the network predicts x0; its output becomes eps = (x - alpha x0) / sigma in place, with the x it was
+    // evaluated on - model_wrapper's 'x_start' branch, dpm_solver.py:290-292)
+    auto add_eval_m = [&](double t, int slot) {
+      add_eval(0, t, slot);
+      if (!noise) return;
+      Event e{}; e.type = 1; e.src = 0; e.dst = 2 + slot; e.coef = (int)p->coefs.size();
+      std::array<float, 8> row{};
+      row[0] = (float)(1.0 / ns.sigma(t)); row[1] = (float)(-ns.alpha(t) / ns.sigma(t));
+      e.slots[0] = slot; e.slots[1] = e.slots[2] = e.slots[3] = -1;
+      p->coefs.push_back(row);
+      p->ev.push_back(e);
+    };
+    auto update_noise = [&](double t, int ord) {      // dpm_solver.py:581-592 (first), 841-847 (second), 895-904 (third)
+      const double t0 = htime[0];
+      const double lam0 = ns.lambda(t0), lam_t = ns.lambda(t);
+      const double h = lam_t - lam0, phi_1 = expm1(h);
+      const double c0 = exp(ns.log_alpha(t) - ns.log_alpha(t0)), s = ns.sigma(t);
+      if (ord == 1) { add_comb(0, c0, {{hist[0], -s * phi_1}}); return; }
+      if (ord == 2) {
+        const double r0 = (lam0 - ns.lambda(htime[1])) / h;
+        add_comb(0, c0, {{hist[0], -s * phi_1 * (1.0 + 0.5 / r0)}, {hist[1], 0.5 * s * phi_1 / r0}});
+        return;
+      }
+      const double lam1 = ns.lambda(htime[1]), lam2 = ns.lambda(htime[2]);
+      const double r0 = (lam0 - lam1) / h, r1 = (lam1 - lam2) / h;
+      const double a0 = 1.0 / r0, a1 = 1.0 / r1, g = r0 / (r0 + r1), e = 1.0 / (r0 + r1);
+      const double phi_2 = phi_1 / h - 1.0, phi_3 = phi_2 / h - 0.5;
+      const double S2 = s * phi_2, S3 = s * phi_3;
+      add_comb(0, c0, {{hist[0], -s * phi_1 - S2 * (1 + g) * a0 - S3 * e * a0},
+                       {hist[1], S2 * (1 + g) * a0 + S2 * g * a1 + S3 * e * a0 + S3 * e * a1},
+                       {hist[2], -S2 * g * a1 - S3 * e * a1}});
+    };
     auto update = [&](double t, int ord) {
+      if (noise) { update_noise(t, ord); return; }
       const double t0 = htime[0];
       const double lam0 = ns.lambda(t0), lam_t = ns.lambda(t);
       const double h = lam_t - lam0, phi_1 = expm1(-h);
@@ -274,12 +308,12 @@ static int build_plan(dv_plan* p) {
                        {hist[1], -P2 * (1 + g) * a0 - P2 * g * a1 + P3 * e * a0 + P3 * e * a1},
                        {hist[2], P2 * g * a1 - P3 * e * a1}});
     };
-    add_eval(0, ts[0], 0);
+    add_eval_m(ts[0], 0);
     push_hist(0, ts[0]);
     for (int step = 1; step < order; ++step) {
       update(ts[step], step);
       int s = free_slot();
-      add_eval(0, ts[step], s);
+      add_eval_m(ts[step], s);
       push_hist(s, ts[step]);
     }
     for (int step = order; step <= N; ++step) {
@@ -290,7 +324,7 @@ static int build_plan(dv_plan* p) {
         int s;
         if ((int)hist.size() == order) { s = hist.back(); hist.pop_back(); htime.pop_back(); }
         else s = free_slot();
-        add_eval(0, ts[step], s);
+        add_eval_m(ts[step], s);
         push_hist(s, ts[step]);
       }
     }
@@ -430,17 +464,17 @@ extern "C" int dv_sampler_plan_sched(int32_t solver, int32_t schedule, const flo
   if (!out) return dv_fail(DV_ERR_INVALID, "dv_sampler_plan: bad argument");
   if (schedule < DV_SCHEDULE_DISCRETE || schedule > DV_SCHEDULE_COSINE) return dv_fail(DV_ERR_INVALID, "unknown noise schedule %d", schedule);
   if (schedule == DV_SCHEDULE_DISCRETE && (!betas || n_betas < 2)) return dv_fail(DV_ERR_INVALID, "dv_sampler_plan: bad argument");
-  if (schedule == DV_SCHEDULE_COSINE && solver == DV_SOLVER_DPMPP)      // (dpm_solver.py:94: 'discrete' or 'linear')
+  if (schedule == DV_SCHEDULE_COSINE && (solver == DV_SOLVER_DPMPP || solver == DV_SOLVER_DPM))   // (dpm_solver.py:94: 'discrete' or 'linear')
     return dv_fail(DV_ERR_INVALID, "the 'cosine' schedule exists for the UniPC solvers only");
   if (schedule == DV_SCHEDULE_LINEAR && !(beta_1 > beta_0 && beta_0 >= 0.0)) return dv_fail(DV_ERR_INVALID, "linear schedule: need 0 <= beta_0 < beta_1");
-  if (solver < DV_SOLVER_DPMPP || solver > DV_SOLVER_UNIPC_VARY) return dv_fail(DV_ERR_INVALID, "unknown solver %d", solver);
-  if (solver == DV_SOLVER_DPMPP && (order < 1 || order > 3)) return dv_fail(DV_ERR_INVALID, "Solver order must be 1 or 2 or 3, got %d", order);
+  if (solver < DV_SOLVER_DPMPP || solver > DV_SOLVER_DPM) return dv_fail(DV_ERR_INVALID, "unknown solver %d", solver);
+  if ((solver == DV_SOLVER_DPMPP || solver == DV_SOLVER_DPM) && (order < 1 || order > 3)) return dv_fail(DV_ERR_INVALID, "Solver order must be 1 or 2 or 3, got %d", order);
   if (order < 1 || order > MAXO) return dv_fail(DV_ERR_INVALID, "UniPC order must be 1..%d, got %d", MAXO, order);
   if (steps < order) return dv_fail(DV_ERR_INVALID, "steps (%d) must be >= order (%d)", steps, order);
   dv_plan* p = new dv_plan();
   p->solver = solver; p->steps = steps; p->order = order; p->skip = skip_type; p->lof = lower_order_final;
   p->t_start = t_start; p->t_end = t_end; p->denoise_to_zero = denoise_to_zero ? 1 : 0;
-  if (schedule == DV_SCHEDULE_DISCRETE) p->ns.init(betas, n_betas, solver == DV_SOLVER_DPMPP);
+  if (schedule == DV_SCHEDULE_DISCRETE) p->ns.init(betas, n_betas, solver == DV_SOLVER_DPMPP || solver == DV_SOLVER_DPM);
   else p->ns.init_continuous(schedule, beta_0, beta_1);
   int rc = build_plan(p);
   if (rc != DV_OK) { delete p; return rc; }
@@ -540,7 +574,8 @@ static int run_events(dv_plan* p, float* x, int64_t numel, EvalFn eval, hipStrea
     } else {
       const float* ms[4];
       for (int k = 0; k < 4; ++k) ms[k] = e.slots[k] >= 0 ? p->m[e.slots[k]] : nullptr;
-      hipError_t he = launch_lincomb(e.dst == 0 ? x : p->xp, e.src == 0 ? x : p->xp, ms[0], ms[1], ms[2], ms[3], p->d_coefs + (size_t)e.coef * 8,
+      float* const dst = e.dst == 0 ? x : (e.dst == 1 ? p->xp : p->m[e.dst - 2]);   // (a history slot: in place, elementwise)
+      hipError_t he = launch_lincomb(dst, e.src == 0 ? x : p->xp, ms[0], ms[1], ms[2], ms[3], p->d_coefs + (size_t)e.coef * 8,
                                      numel, st);
       if (he != hipSuccess) return dv_fail(DV_ERR_HIP, "lincomb launch failed: %s", hipGetErrorString(he));
     }

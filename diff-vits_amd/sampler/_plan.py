@@ -233,8 +233,10 @@ class Plan:
                     x = out
                     if intermediates is not None:
                         intermediates.append(x)
-                else:
+                elif dst == 1:
                     xp = out
+                else:                      # a history slot in place (x0 -> noise prediction: algorithm_type='dpmsolver')
+                    hist[dst - 2] = out
         return x
 
 

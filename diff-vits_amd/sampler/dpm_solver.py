@@ -4,8 +4,8 @@
 `DPM_Solver.sample(..., method='multistep')` compiles the loop once on the host (fp64 tables,
 libdvits_hip.so `dv_sampler_plan`) and then either replays it natively (hipGraph: UNet schedule
 + fused update kernels) when the wrapped model is a `NativeUNetModel`, or runs it with torch ops
-around an arbitrary Python callable.  Scope of this build: algorithm_type='dpmsolver++',
-method='multistep', orders 1-3 (reference :1171-1213, :547-580, :796-904), schedules 'discrete' and 'linear'.
+around an arbitrary Python callable.  Scope of this build: algorithm_type='dpmsolver++' and 'dpmsolver',
+method='multistep', orders 1-3 (reference :1171-1213, :547-592, :796-904), schedules 'discrete' and 'linear'.
 """
 import torch
 
@@ -14,6 +14,7 @@ from ._plan import NativeUNetModel, NoiseScheduleBase, Plan, sample_with_plan, w
 __all__ = ["NoiseScheduleVP", "model_wrapper", "DPM_Solver", "NativeUNetModel"]
 
 _SOLVER_DPMPP = 0
+_SOLVER_DPM = 4          # algorithm_type='dpmsolver': multistep updates on the noise prediction (include/dvits_hip.h)
 
 
 class NoiseScheduleVP(NoiseScheduleBase):
@@ -29,9 +30,6 @@ class DPM_Solver:
     def __init__(self, model_fn, noise_schedule, algorithm_type="dpmsolver++", correcting_x0_fn=None,
                  correcting_xt_fn=None, thresholding_max_val=1.0, dynamic_thresholding_ratio=0.995):
         assert algorithm_type in ["dpmsolver", "dpmsolver++"]
-        if algorithm_type != "dpmsolver++":
-            raise ValueError("algorithm_type='dpmsolver' (noise-prediction updates) is outside this build's scope; "
-                             "the diffusion sampling path uses 'dpmsolver++'")
         if correcting_x0_fn is not None or correcting_xt_fn is not None:
             raise ValueError("correcting_x0_fn / correcting_xt_fn are not supported on this path")
         self.model_fn = model_fn
@@ -47,7 +45,7 @@ class DPM_Solver:
     def _plan(self, steps, order, skip_type, lower_order_final, t_start=None, t_end=None, denoise_to_zero=False):
         key = (steps, order, skip_type, bool(lower_order_final), t_start, t_end, bool(denoise_to_zero))
         if key not in self._plans:
-            self._plans[key] = Plan(_SOLVER_DPMPP, self.noise_schedule._betas, steps, order, skip_type,
+            self._plans[key] = Plan(_SOLVER_DPMPP if self.algorithm_type == "dpmsolver++" else _SOLVER_DPM, self.noise_schedule._betas, steps, order, skip_type,
                                     lower_order_final, t_start, t_end, denoise_to_zero,
                                     schedule=self.noise_schedule._plan_schedule())
         return self._plans[key]

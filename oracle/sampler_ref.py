@@ -167,14 +167,60 @@ def _dpmpp_update(ns, x, m_list, t_list, t, order):
     raise ValueError("Solver order must be 1 or 2 or 3, got %r" % (order,))
 
 
+def _dpm_noise_update(ns, x, m_list, t_list, t, order):
+    """multistep_dpm_solver_update for algorithm_type='dpmsolver' (updates on the noise prediction), solver_type='dpmsolver':
+    first (dpm_solver.py:581-592), second (:841-847), third (:895-904) order."""
+    t0 = t_list[-1]
+    lam0, lam_t = ns.lam(t0), ns.lam(t)
+    la0, la_t = ns.log_alpha(t0), ns.log_alpha(t)
+    sig_t = ns.sigma(t)
+    h = lam_t - lam0
+    phi_1 = torch.expm1(h)
+    if order == 1:
+        return torch.exp(la_t - la0) * x - (sig_t * phi_1) * m_list[-1]
+    if order == 2:
+        m1, m0 = m_list[-2], m_list[-1]
+        r0 = (lam0 - ns.lam(t_list[-2])) / h
+        D1_0 = (1.0 / r0) * (m0 - m1)
+        return torch.exp(la_t - la0) * x - (sig_t * phi_1) * m0 - 0.5 * (sig_t * phi_1) * D1_0
+    if order == 3:
+        m2, m1, m0 = m_list
+        lam1, lam2 = ns.lam(t_list[-2]), ns.lam(t_list[-3])
+        h_1, h_0 = lam1 - lam2, lam0 - lam1
+        r0, r1 = h_0 / h, h_1 / h
+        D1_0 = (1.0 / r0) * (m0 - m1)
+        D1_1 = (1.0 / r1) * (m1 - m2)
+        D1 = D1_0 + (r0 / (r0 + r1)) * (D1_0 - D1_1)
+        D2 = (1.0 / (r0 + r1)) * (D1_0 - D1_1)
+        phi_2 = phi_1 / h - 1.0
+        phi_3 = phi_2 / h - 0.5
+        return torch.exp(la_t - la0) * x - (sig_t * phi_1) * m0 - (sig_t * phi_2) * D1 - (sig_t * phi_3) * D2
+    raise ValueError("Solver order must be 1 or 2 or 3, got %r" % (order,))
+
+
+def wrap_x_start_noise(model, ns):
+    """model_wrapper(model, ns, model_type='x_start') alone: the NOISE prediction the algorithm_type='dpmsolver' updates
+    consume - noise = (x - alpha_t * x0) / sigma_t (dpm_solver.py:290-292)."""
+    def noise_prediction(x, t):
+        tb = t.expand(x.shape[0])
+        t_input = tb if isinstance(ns, ContinuousSchedule) else (tb - 1.0 / ns.total_N) * ns.total_N
+        out = model(x, t_input)
+        a, s = ns.alpha(tb), ns.sigma(tb)
+        return (x - _bcast(a, x) * out) / _bcast(s, x)
+    return noise_prediction
+
+
 def dpm_solver_pp_sample(model, betas, x, steps=20, order=2, skip_type="time_uniform",
                          lower_order_final=True, return_intermediate=False, t_start=None, t_end=None,
-                         denoise_to_zero=False, schedule=None):
-    """DPM_Solver(model_fn, ns, 'dpmsolver++').sample(x, steps, order, skip_type,
+                         denoise_to_zero=False, schedule=None, algorithm_type="dpmsolver++"):
+    """DPM_Solver(model_fn, ns, algorithm_type).sample(x, steps, order, skip_type,
     method='multistep'), dpm_solver.py:1047-1245 (multistep branch :1171-1213).
-    `model(x, t_input)` is the raw x0-prediction network."""
+    `model(x, t_input)` is the raw x0-prediction network.  algorithm_type='dpmsolver': the same loop on the noise
+    prediction (model_fn = noise_prediction_fn, dpm_solver.py:390-392)."""
     ns = _schedule(betas, True, schedule)
-    fn = wrap_x_start_model(model, ns)
+    data_fn = wrap_x_start_model(model, ns)
+    fn = data_fn if algorithm_type == "dpmsolver++" else wrap_x_start_noise(model, ns)
+    _dpmpp_update = globals()["_dpmpp_update"] if algorithm_type == "dpmsolver++" else _dpm_noise_update
     # dpm_solver.py:1157-1158: t_0 = 1/N unless t_end is given, t_T = T unless t_start is given
     t_0 = 1.0 / ns.total_N if t_end is None else t_end
     t_T = ns.T if t_start is None else t_start
@@ -198,8 +244,8 @@ def dpm_solver_pp_sample(model, betas, x, steps=20, order=2, skip_type="time_uni
         m_list = m_list[1:] + [None]
         if step < steps:
             m_list[-1] = fn(x, t)
-    if denoise_to_zero:            # dpm_solver.py:1234-1240: x0 prediction at t_0 (one more evaluation)
-        x = fn(x, torch.ones((1,)) * t_0)
+    if denoise_to_zero:            # dpm_solver.py:1234-1240, :541-545: x0 prediction at t_0 (one more evaluation)
+        x = data_fn(x, torch.ones((1,)) * t_0)
         inter.append(x)
     return (x, inter) if return_intermediate else x
 

@@ -1119,7 +1119,9 @@ def test_native_sampler_options_graph_equals_stepwise():
                              (uni_pc, lambda fn, ns: uni_pc.UniPC(fn, ns, variant="bh2"), "discrete"),
                              # a continuous-time schedule: the network is called with t itself (dpm_solver.py:271-280)
                              (dpm_solver, lambda fn, ns: dpm_solver.DPM_Solver(fn, ns, algorithm_type="dpmsolver++"), "linear"),
-                             (uni_pc, lambda fn, ns: uni_pc.UniPC(fn, ns, variant="bh2"), "cosine")):
+                             (uni_pc, lambda fn, ns: uni_pc.UniPC(fn, ns, variant="bh2"), "cosine"),
+                             # algorithm_type='dpmsolver': every evaluation is followed by x0 -> noise in place on its history slot
+                             (dpm_solver, lambda fn, ns: dpm_solver.DPM_Solver(fn, ns, algorithm_type="dpmsolver"), "discrete")):
         ns = mod.NoiseScheduleVP("discrete", betas=betas) if sched == "discrete" else mod.NoiseScheduleVP(sched)
         native = mod.NativeUNetModel(m, cond, enc_t, mask_t)
         fn = mod.model_wrapper(native, ns, model_type="x_start")

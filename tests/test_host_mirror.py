@@ -183,6 +183,13 @@ OPTION_CASES = {
     "unipc_linear_quad": ("unipc", dict(steps=9, order=2, skip_type="time_quadratic", t_end=0.01, schedule=("linear", 0.2, 15.0))),
     "unipc_cosine": ("unipc", dict(steps=10, order=2, skip_type="time_uniform", return_intermediate=True, schedule=("cosine", 0.1, 20.0))),
     "unipc_cosine_logsnr": ("unipc", dict(steps=8, order=3, skip_type="logSNR", schedule=("cosine", 0.1, 20.0))),
+    # algorithm_type='dpmsolver': the multistep updates on the noise prediction (dpm_solver.py:581-592, 841-847, 895-904)
+    "dpmn_o1": ("dpm", dict(steps=10, order=1, skip_type="time_uniform", algorithm_type="dpmsolver")),
+    "dpmn_o2_dtz": ("dpm", dict(steps=12, order=2, skip_type="time_quadratic", denoise_to_zero=True, return_intermediate=True,
+                                algorithm_type="dpmsolver")),
+    "dpmn_o3_logsnr": ("dpm", dict(steps=8, order=3, skip_type="logSNR", algorithm_type="dpmsolver")),
+    "dpmn_o3_window": ("dpm", dict(steps=20, order=3, skip_type="time_uniform", t_start=0.9, t_end=0.02, algorithm_type="dpmsolver")),
+    "dpmn_linear": ("dpm", dict(steps=9, order=2, skip_type="time_uniform", schedule=("linear", 0.1, 20.0), algorithm_type="dpmsolver")),
 }
 
 
@@ -192,6 +199,7 @@ def test_sampler_options_match_reference(gold, key):
     solver, kw = OPTION_CASES[key]
     kw = dict(kw)
     sched = kw.pop("schedule", None)
+    algo = kw.pop("algorithm_type", "dpmsolver++")
     B = 2 if solver == "dpm" else 1
     x = torch.from_numpy(synth.normal(1234, "opts." + key, (B, 5, 24)))
     betas = torch.from_numpy(synth.make_betas())
@@ -204,7 +212,7 @@ def test_sampler_options_match_reference(gold, key):
     tol = 2e-5 if sched is None else 5e-4
     fn = mod.model_wrapper(lambda xx, t, **k: sampler_ref.standin_model(xx, t), ns, model_type="x_start")
     if solver == "dpm":
-        r = mod.DPM_Solver(fn, ns, algorithm_type="dpmsolver++").sample(x.clone(), method="multistep", **kw)
+        r = mod.DPM_Solver(fn, ns, algorithm_type=algo).sample(x.clone(), method="multistep", **kw)
     else:
         r = mod.UniPC(fn, ns, variant="bh2").sample(x.clone(), method="multistep", **kw)
     if kw.get("return_intermediate"):
@@ -221,7 +229,7 @@ def test_sampler_options_match_reference(gold, key):
     args = (okw.pop("steps"), okw.pop("order"), okw.pop("skip_type"))
     okw.pop("return_intermediate", None)
     if solver == "dpm":
-        o = sampler_ref.dpm_solver_pp_sample(sampler_ref.standin_model, betas, x.clone(), *args, schedule=sched, **okw)
+        o = sampler_ref.dpm_solver_pp_sample(sampler_ref.standin_model, betas, x.clone(), *args, schedule=sched, algorithm_type=algo, **okw)
     else:
         o = sampler_ref.unipc_sample(sampler_ref.standin_model, betas, x.clone(), *args, "bh2", schedule=sched, **okw)
     assert rel_l2(o.numpy(), g[key + "_x"]) < 1e-6

@@ -33,6 +33,13 @@ CASES = {
     "unipc_linear_quad": ("unipc", dict(steps=9, order=2, skip_type="time_quadratic", t_end=0.01, schedule=("linear", 0.2, 15.0))),
     "unipc_cosine": ("unipc", dict(steps=10, order=2, skip_type="time_uniform", return_intermediate=True, schedule=("cosine", 0.1, 20.0))),
     "unipc_cosine_logsnr": ("unipc", dict(steps=8, order=3, skip_type="logSNR", schedule=("cosine", 0.1, 20.0))),
+    # algorithm_type='dpmsolver': the multistep updates on the noise prediction (dpm_solver.py:581-592, 841-847, 895-904)
+    "dpmn_o1": ("dpm", dict(steps=10, order=1, skip_type="time_uniform", algorithm_type="dpmsolver")),
+    "dpmn_o2_dtz": ("dpm", dict(steps=12, order=2, skip_type="time_quadratic", denoise_to_zero=True, return_intermediate=True,
+                                algorithm_type="dpmsolver")),
+    "dpmn_o3_logsnr": ("dpm", dict(steps=8, order=3, skip_type="logSNR", algorithm_type="dpmsolver")),
+    "dpmn_o3_window": ("dpm", dict(steps=20, order=3, skip_type="time_uniform", t_start=0.9, t_end=0.02, algorithm_type="dpmsolver")),
+    "dpmn_linear": ("dpm", dict(steps=9, order=2, skip_type="time_uniform", schedule=("linear", 0.1, 20.0), algorithm_type="dpmsolver")),
 }
 
 
@@ -62,13 +69,14 @@ def main():
         x = torch.from_numpy(synth.normal(1234, "opts." + key, (B, 5, 24)))
         kw = dict(kw)
         sched = kw.pop("schedule", None)
+        algo = kw.pop("algorithm_type", "dpmsolver++")
         if solver == "dpm":
             ns = make_ns(ref_dpm, sched, betas)
             fn = ref_dpm.model_wrapper(lambda xx, t, **k: sampler_ref.standin_model(xx, t), ns, model_type="x_start")
-            r = ref_dpm.DPM_Solver(fn, ns, algorithm_type="dpmsolver++").sample(x.clone(), method="multistep", **kw)
+            r = ref_dpm.DPM_Solver(fn, ns, algorithm_type=algo).sample(x.clone(), method="multistep", **kw)
             okw = {k: v for k, v in kw.items()}
             o = sampler_ref.dpm_solver_pp_sample(sampler_ref.standin_model, betas, x.clone(), okw.pop("steps"), okw.pop("order"),
-                                                 okw.pop("skip_type"), schedule=sched, **okw)
+                                                 okw.pop("skip_type"), schedule=sched, algorithm_type=algo, **okw)
         else:
             ns = make_ns(ref_unipc, sched, betas)
             fn = ref_unipc.model_wrapper(lambda xx, t, **k: sampler_ref.standin_model(xx, t), ns, model_type="x_start")
