@@ -210,19 +210,37 @@ class Plan:
     def handle(self):
         return self._h
 
-    def run_python(self, x, data_model, intermediates=None):
+    def run_python(self, x, data_model, intermediates=None, x0_hook=None, xt_hook=None):
         """Execute the loop with torch ops; `data_model(x, eval_idx)` returns the x0 prediction.  `intermediates`
         (a list) receives what the reference's return_intermediate collects: the start point, x after every step
-        and, with denoise_to_zero, the final data prediction (dpm_solver.py:1179-1240)."""
+        and, with denoise_to_zero, the final data prediction (dpm_solver.py:1179-1240).
+        `x0_hook(x0, eval_idx)` corrects a data prediction (correcting_x0_fn / dynamic thresholding, dpm_solver.py:433-445);
+        `xt_hook(x, t, step)` corrects the state after the first evaluation (step 0) and after every step
+        (correcting_xt_fn, dpm_solver.py:1180-1181, 1188-1189, 1203-1204, 1237-1238; uni_pc.py:615-647, 664-665)."""
         hist = [None] * self.n_slots
         xp = None
-        first = True
+        start_pending = False          # the start point: recorded (and corrected) once the first evaluation is complete
+        step = 0
+        t_of = lambda k: torch.tensor(float(self.timesteps[min(k, len(self.timesteps) - 1)]), dtype=torch.float32, device=x.device)
+
+        def finish_start(x):
+            if xt_hook is not None:
+                x = xt_hook(x, t_of(0), 0)
+            if intermediates is not None:
+                intermediates.append(x)
+            return x
+
+        seen_eval = False
         for typ, src, eidx, dst, coef, s0, s1, s2, s3 in self.events.tolist():
+            if start_pending and not (typ == 1 and dst >= 2):      # (an x0 -> noise conversion still reads the uncorrected x)
+                x = finish_start(x)
+                start_pending = False
             if typ == 0:
-                hist[dst] = data_model(x if src == 0 else xp, eidx)
-                if first and intermediates is not None:
-                    intermediates.append(x)
-                first = False
+                m = data_model(x if src == 0 else xp, eidx)
+                hist[dst] = m if x0_hook is None else x0_hook(m, eidx)
+                if not seen_eval:
+                    start_pending = True
+                seen_eval = True
             else:
                 c = self.coefs[coef]
                 out = float(c[0]) * (x if src == 0 else xp)      # src 1: continuation of a sum chained through x_pred
@@ -231,12 +249,17 @@ class Plan:
                         out = out + float(c[1 + k]) * hist[s]
                 if dst == 0:
                     x = out
+                    step += 1
+                    if xt_hook is not None:
+                        x = xt_hook(x, t_of(step), step)
                     if intermediates is not None:
                         intermediates.append(x)
                 elif dst == 1:
                     xp = out
                 else:                      # a history slot in place (x0 -> noise prediction: algorithm_type='dpmsolver')
                     hist[dst - 2] = out
+        if start_pending:
+            x = finish_start(x)
         return x
 
 
@@ -303,10 +326,18 @@ class NativeUNetModel:
         return xbuf.clone()
 
 
-def sample_with_plan(plan, model_fn, noise_schedule, x, intermediates=None):
+def dynamic_thresholding(x0, ratio, max_val):
+    """dynamic_thresholding_fn (dpm_solver.py:416-425, uni_pc.py:268-277): per sample, s = max(quantile(|x0|, ratio), max_val);
+    x0 <- clamp(x0, -s, s) / s."""
+    s = torch.quantile(torch.abs(x0).reshape((x0.shape[0], -1)), ratio, dim=1)
+    s = torch.maximum(s, max_val * torch.ones_like(s)).reshape((-1,) + (1,) * (x0.dim() - 1))
+    return torch.clamp(x0, -s, s) / s
+
+
+def sample_with_plan(plan, model_fn, noise_schedule, x, intermediates=None, x0_hook=None, xt_hook=None):
     """Run a compiled loop for a solver-level `model_fn` (noise prediction, as returned by
-    model_wrapper or supplied by the user).  With `intermediates` (a list to fill) the loop runs step by step from
-    Python (same kernels per evaluation) instead of as one graph replay."""
+    model_wrapper or supplied by the user).  With `intermediates` (a list to fill) or a correction hook the loop runs step
+    by step from Python (same kernels per evaluation) instead of as one graph replay."""
     info = getattr(model_fn, "_dv", None)
     ns = noise_schedule
     B = x.shape[0]
@@ -314,7 +345,7 @@ def sample_with_plan(plan, model_fn, noise_schedule, x, intermediates=None):
         if info is not None and info["model_type"] == "x_start":
             raw = info["model"]
             if (isinstance(raw, NativeUNetModel) and x.is_cuda and raw.unet.backend == "hip" and not info["model_kwargs"]
-                    and intermediates is None):
+                    and intermediates is None and x0_hook is None and xt_hook is None):
                 return raw.run_plan(plan, x)
             kwargs = info["model_kwargs"]
 
@@ -332,7 +363,7 @@ def sample_with_plan(plan, model_fn, noise_schedule, x, intermediates=None):
                 a = float(ns.marginal_alpha(torch.tensor([eval_t[eidx]], dtype=torch.float64))[0])
                 s = float(ns.marginal_std(torch.tensor([eval_t[eidx]], dtype=torch.float64))[0])
                 return (xx - s * noise) / a
-        return plan.run_python(x, data_model, intermediates)
+        return plan.run_python(x, data_model, intermediates, x0_hook, xt_hook)
 
 
 def _eval_times(plan):

@@ -9,7 +9,7 @@ method='multistep', orders 1-3 (reference :1171-1213, :547-592, :796-904), sched
 """
 import torch
 
-from ._plan import NativeUNetModel, NoiseScheduleBase, Plan, sample_with_plan, wrap_model
+from ._plan import NativeUNetModel, NoiseScheduleBase, Plan, _eval_times, dynamic_thresholding, sample_with_plan, wrap_model
 
 __all__ = ["NoiseScheduleVP", "model_wrapper", "DPM_Solver", "NativeUNetModel"]
 
@@ -30,8 +30,11 @@ class DPM_Solver:
     def __init__(self, model_fn, noise_schedule, algorithm_type="dpmsolver++", correcting_x0_fn=None,
                  correcting_xt_fn=None, thresholding_max_val=1.0, dynamic_thresholding_ratio=0.995):
         assert algorithm_type in ["dpmsolver", "dpmsolver++"]
-        if correcting_x0_fn is not None or correcting_xt_fn is not None:
-            raise ValueError("correcting_x0_fn / correcting_xt_fn are not supported on this path")
+        # correcting_x0_fn ("dynamic_thresholding" or fn(x0, t)) / correcting_xt_fn (fn(x, t, step)): reference :409-415.  With
+        # either the loop is stepped from Python (the hooks are arbitrary callables), never replayed as one graph.
+        if correcting_x0_fn == "dynamic_thresholding":
+            correcting_x0_fn = lambda x0, t: dynamic_thresholding(x0, dynamic_thresholding_ratio, thresholding_max_val)
+        self.correcting_x0_fn, self.correcting_xt_fn = correcting_x0_fn, correcting_xt_fn
         self.model_fn = model_fn
         self.noise_schedule = noise_schedule
         self.algorithm_type = algorithm_type
@@ -63,8 +66,21 @@ class DPM_Solver:
             raise ValueError("solver_type='taylor' is not supported on this path")
         assert steps >= order
         plan = self._plan(steps, order, skip_type, lower_order_final, t_start, t_end, denoise_to_zero)
+        x0_hook = None
+        if self.correcting_x0_fn is not None:
+            # data_prediction_fn applies it (:433-445): every evaluation of 'dpmsolver++'; with 'dpmsolver' only the final
+            # denoise_to_zero evaluation goes through data_prediction_fn (:541-545)
+            times, fn0, last = _eval_times(plan), self.correcting_x0_fn, plan.nfe - 1
+            only_last = self.algorithm_type != "dpmsolver++"
+
+            def x0_hook(x0, eidx):
+                if only_last and not (denoise_to_zero and eidx == last):
+                    return x0
+                t = torch.tensor(float(plan.timesteps[-1] if eidx >= len(times) else times[eidx]), dtype=torch.float32, device=x0.device)
+                return fn0(x0, t)
+        hooks = dict(x0_hook=x0_hook, xt_hook=self.correcting_xt_fn)
         if not return_intermediate:
-            return sample_with_plan(plan, self.model_fn, self.noise_schedule, x)
+            return sample_with_plan(plan, self.model_fn, self.noise_schedule, x, **hooks)
         inter = []
-        out = sample_with_plan(plan, self.model_fn, self.noise_schedule, x, inter)
+        out = sample_with_plan(plan, self.model_fn, self.noise_schedule, x, inter, **hooks)
         return out, inter

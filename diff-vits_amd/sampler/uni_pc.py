@@ -7,7 +7,7 @@ coefficients and replayed natively or around a Python callable.  Unlike the refe
 'x_start' wrapper (uni_pc.py:189-191, which only broadcasts correctly at B == 1) the batch
 broadcast here is the intended per-sample one; at B == 1 both coincide.
 """
-from ._plan import NativeUNetModel, NoiseScheduleBase, Plan, sample_with_plan, wrap_model
+from ._plan import NativeUNetModel, NoiseScheduleBase, Plan, dynamic_thresholding, sample_with_plan, wrap_model
 
 __all__ = ["NoiseScheduleVP", "model_wrapper", "UniPC", "NativeUNetModel"]
 
@@ -30,8 +30,11 @@ class UniPC:
         assert algorithm_type in ["data_prediction", "noise_prediction"]
         if algorithm_type != "data_prediction":
             raise ValueError("algorithm_type='noise_prediction' is outside this build's scope")
-        if correcting_x0_fn is not None or correcting_xt_fn is not None:
-            raise ValueError("correcting_x0_fn / correcting_xt_fn are not supported on this path")
+        # correcting_x0_fn ("dynamic_thresholding" or fn(x0)) / correcting_xt_fn (fn(x, t, step)): reference :256-261, 292-293.
+        # With either the loop is stepped from Python, never replayed as one graph.
+        if correcting_x0_fn == "dynamic_thresholding":
+            correcting_x0_fn = lambda x0: dynamic_thresholding(x0, dynamic_thresholding_ratio, thresholding_max_val)
+        self.correcting_x0_fn, self.correcting_xt_fn = correcting_x0_fn, correcting_xt_fn
         if variant not in _SOLVERS:
             raise NotImplementedError("variant %r (supported: 'bh1', 'bh2', 'vary_coeff')" % (variant,))
         self.model_fn = model_fn
@@ -58,8 +61,10 @@ class UniPC:
             raise ValueError("UniPC order must be an integer in 1..{} in this build, got {}".format(MAX_ORDER, order))
         assert steps >= order
         plan = self._plan(steps, order, skip_type, lower_order_final, t_start, t_end, denoise_to_zero)
+        fn0 = self.correcting_x0_fn
+        hooks = dict(x0_hook=None if fn0 is None else (lambda x0, eidx: fn0(x0)), xt_hook=self.correcting_xt_fn)
         if not return_intermediate:
-            return sample_with_plan(plan, self.model_fn, self.noise_schedule, x)
+            return sample_with_plan(plan, self.model_fn, self.noise_schedule, x, **hooks)
         inter = []
-        out = sample_with_plan(plan, self.model_fn, self.noise_schedule, x, inter)
+        out = sample_with_plan(plan, self.model_fn, self.noise_schedule, x, inter, **hooks)
         return out, inter

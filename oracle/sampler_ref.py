@@ -104,7 +104,14 @@ def _bcast(v, x):
     return v.reshape((-1,) + (1,) * (x.dim() - 1))
 
 
-def wrap_x_start_model(model, ns):
+def dynamic_thresholding(x0, ratio=0.995, max_val=1.0):
+    """dynamic_thresholding_fn, dpm_solver.py:416-425 / uni_pc.py:268-277."""
+    s = torch.quantile(torch.abs(x0).reshape((x0.shape[0], -1)), ratio, dim=1)
+    s = torch.maximum(s, max_val * torch.ones_like(s)).reshape((-1,) + (1,) * (x0.dim() - 1))
+    return torch.clamp(x0, -s, s) / s
+
+
+def wrap_x_start_model(model, ns, x0_fn=None):
     """model_wrapper(model, ns, model_type='x_start') followed by the solver's
     data_prediction_fn: t_input = (t - 1/N) * N (dpm_solver.py:271-280); noise =
     (x - alpha_t * x0) / sigma_t (:290-292); x0 = (x - sigma_t * noise) / alpha_t (:433-442).
@@ -117,7 +124,8 @@ def wrap_x_start_model(model, ns):
         a, s = ns.alpha(tb), ns.sigma(tb)
         noise = (x - _bcast(a, x) * out) / _bcast(s, x)
         a1, s1 = ns.alpha(t), ns.sigma(t)
-        return (x - s1 * noise) / a1
+        x0 = (x - s1 * noise) / a1
+        return x0 if x0_fn is None else x0_fn(x0, t)      # correcting_x0_fn (dpm_solver.py:443-444; uni_pc.py:292-293 passes x0 only)
     return data_prediction
 
 
@@ -212,13 +220,14 @@ def wrap_x_start_noise(model, ns):
 
 def dpm_solver_pp_sample(model, betas, x, steps=20, order=2, skip_type="time_uniform",
                          lower_order_final=True, return_intermediate=False, t_start=None, t_end=None,
-                         denoise_to_zero=False, schedule=None, algorithm_type="dpmsolver++"):
+                         denoise_to_zero=False, schedule=None, algorithm_type="dpmsolver++", x0_fn=None, xt_fn=None):
     """DPM_Solver(model_fn, ns, algorithm_type).sample(x, steps, order, skip_type,
     method='multistep'), dpm_solver.py:1047-1245 (multistep branch :1171-1213).
     `model(x, t_input)` is the raw x0-prediction network.  algorithm_type='dpmsolver': the same loop on the noise
     prediction (model_fn = noise_prediction_fn, dpm_solver.py:390-392)."""
     ns = _schedule(betas, True, schedule)
-    data_fn = wrap_x_start_model(model, ns)
+    data_fn = wrap_x_start_model(model, ns, x0_fn)
+    fix = (lambda x, t, step: x) if xt_fn is None else xt_fn       # correcting_xt_fn (:1180-1181, 1188-1189, 1203-1204, 1237-1238)
     fn = data_fn if algorithm_type == "dpmsolver++" else wrap_x_start_noise(model, ns)
     _dpmpp_update = globals()["_dpmpp_update"] if algorithm_type == "dpmsolver++" else _dpm_noise_update
     # dpm_solver.py:1157-1158: t_0 = 1/N unless t_end is given, t_T = T unless t_start is given
@@ -229,23 +238,24 @@ def dpm_solver_pp_sample(model, betas, x, steps=20, order=2, skip_type="time_uni
     inter = []
     t = ts[0]
     t_list, m_list = [t], [fn(x, t)]
+    x = fix(x, t, 0)
     for step in range(1, order):
         t = ts[step]
-        x = _dpmpp_update(ns, x, m_list, t_list, t, step)
+        x = fix(_dpmpp_update(ns, x, m_list, t_list, t, step), t, step)
         inter.append(x)
         t_list.append(t)
         m_list.append(fn(x, t))
     for step in range(order, steps + 1):
         t = ts[step]
         step_order = min(order, steps + 1 - step) if (lower_order_final and steps < 10) else order
-        x = _dpmpp_update(ns, x, m_list, t_list, t, step_order)
+        x = fix(_dpmpp_update(ns, x, m_list, t_list, t, step_order), t, step)
         inter.append(x)
         t_list = t_list[1:] + [t]
         m_list = m_list[1:] + [None]
         if step < steps:
             m_list[-1] = fn(x, t)
     if denoise_to_zero:            # dpm_solver.py:1234-1240, :541-545: x0 prediction at t_0 (one more evaluation)
-        x = data_fn(x, torch.ones((1,)) * t_0)
+        x = fix(data_fn(x, torch.ones((1,)) * t_0), torch.ones((1,)) * t_0, steps + 1)
         inter.append(x)
     return (x, inter) if return_intermediate else x
 
@@ -361,11 +371,12 @@ def _unipc_update(ns, fn, x, m_list, t_list, t, order, variant, use_corrector):
 
 def unipc_sample(model, betas, x, steps=20, order=2, skip_type="time_uniform", variant="bh2",
                  lower_order_final=True, return_intermediate=False, t_start=None, t_end=None, denoise_to_zero=False,
-                 schedule=None):
+                 schedule=None, x0_fn=None, xt_fn=None):
     """UniPC(model_fn, ns, variant=...).sample(x, steps, order, skip_type, 'multistep'),
     uni_pc.py:590-672."""
     ns = _schedule(betas, False, schedule)
-    fn = wrap_x_start_model(model, ns)
+    fn = wrap_x_start_model(model, ns, None if x0_fn is None else (lambda x0, t: x0_fn(x0)))
+    fix = (lambda x, t, step: x) if xt_fn is None else xt_fn       # correcting_xt_fn (uni_pc.py:615-616, 626-627, 646-647, 664-665)
     t_0 = 1.0 / ns.total_N if t_end is None else t_end        # uni_pc.py:596-597
     t_T = ns.T if t_start is None else t_start
     assert steps >= order
@@ -373,9 +384,11 @@ def unipc_sample(model, betas, x, steps=20, order=2, skip_type="time_uniform", v
     inter = []
     t = ts[0]
     t_list, m_list = [t], [fn(x, t)]
+    x = fix(x, t, 0)
     for step in range(1, order):
         t = ts[step]
         x, m_x = _unipc_update(ns, fn, x, m_list, t_list, t, step, variant, True)
+        x = fix(x, t, step)
         inter.append(x)
         t_list.append(t)
         m_list.append(m_x)
@@ -383,13 +396,14 @@ def unipc_sample(model, betas, x, steps=20, order=2, skip_type="time_uniform", v
         t = ts[step]
         step_order = min(order, steps + 1 - step) if lower_order_final else order
         x, m_x = _unipc_update(ns, fn, x, m_list, t_list, t, step_order, variant, step != steps)
+        x = fix(x, t, step)
         inter.append(x)
         t_list = t_list[1:] + [t]
         m_list = m_list[1:] + [None]
         if step < steps:
             m_list[-1] = m_x
     if denoise_to_zero:            # uni_pc.py:660-666
-        x = fn(x, torch.ones((1,)) * t_0)
+        x = fix(fn(x, torch.ones((1,)) * t_0), torch.ones((1,)) * t_0, steps + 1)
         inter.append(x)
     return (x, inter) if return_intermediate else x
 
@@ -398,3 +412,14 @@ def standin_model(x, t_input):
     """Analytic stand-in network for sampler known-answer tests:
     x0 = tanh(x/2) * (1 + 1e-6 * tau)."""
     return torch.tanh(x / 2) * (1 + 1e-6 * t_input.reshape((-1,) + (1,) * (x.dim() - 1)))
+
+
+def standin_x0_fix(x0, t=None):
+    """A correcting_x0_fn for the known-answer cases (dpm_solver passes (x0, t), uni_pc passes x0 only)."""
+    return 0.98 * x0 if t is None else 0.98 * x0 + 0.01 * t
+
+
+def standin_xt_fix(x, t, step):
+    """A correcting_xt_fn for the known-answer cases: depends on all three arguments."""
+    return x * (1.0 - 1e-3 * (step % 3)) + 1e-3 * t
+

@@ -1131,6 +1131,16 @@ def test_native_sampler_options_graph_equals_stepwise():
             b, inter = make(fn, ns).sample(x.clone(), return_intermediate=True, **opts)
         assert len(inter) == 6 + 2 and torch.isfinite(a).all()
         assert rel_l2(a.cpu().numpy(), b.cpu().numpy()) < 3e-5   # (same kernels; see test_gpu_prompt.py on the fp16 P plane)
+    # a correction hook (correcting_xt_fn, dpm_solver.py:1180-1238) forces the stepwise path around the native UNet: the identity
+    # hook reproduces the graph's result, and it is called for step 0 .. steps (+ 1 with denoise_to_zero)
+    ns = dpm_solver.NoiseScheduleVP("discrete", betas=betas)
+    fn = dpm_solver.model_wrapper(dpm_solver.NativeUNetModel(m, cond, enc_t, mask_t), ns, model_type="x_start")
+    seen = []
+    with torch.no_grad():
+        a = dpm_solver.DPM_Solver(fn, ns, algorithm_type="dpmsolver++").sample(x.clone(), **opts)
+        c = dpm_solver.DPM_Solver(fn, ns, algorithm_type="dpmsolver++",
+                                  correcting_xt_fn=lambda xx, tt, step: (seen.append(step), xx)[1]).sample(x.clone(), **opts)
+    assert seen == list(range(6 + 2)) and rel_l2(c.cpu().numpy(), a.cpu().numpy()) < 3e-5
 
 
 def test_merged_ff_proj_out_matches_two_step(gold):

@@ -190,7 +190,43 @@ OPTION_CASES = {
     "dpmn_o3_logsnr": ("dpm", dict(steps=8, order=3, skip_type="logSNR", algorithm_type="dpmsolver")),
     "dpmn_o3_window": ("dpm", dict(steps=20, order=3, skip_type="time_uniform", t_start=0.9, t_end=0.02, algorithm_type="dpmsolver")),
     "dpmn_linear": ("dpm", dict(steps=9, order=2, skip_type="time_uniform", schedule=("linear", 0.1, 20.0), algorithm_type="dpmsolver")),
+    # correcting_x0_fn ("thr": dynamic thresholding, ratio 0.9 / max 0.6; "fn": sampler_ref.standin_x0_fix) and correcting_xt_fn
+    # (sampler_ref.standin_xt_fix): dpm_solver.py:409-425, 443-444, 1180-1238; uni_pc.py:256-277, 292-293, 615-665
+    "dpm_thr_xt": ("dpm", dict(steps=10, order=2, skip_type="time_uniform", denoise_to_zero=True, return_intermediate=True,
+                               hooks=("thr", True))),
+    "dpm_x0fn": ("dpm", dict(steps=8, order=3, skip_type="logSNR", hooks=("fn", False))),
+    "dpmn_thr_xt_dtz": ("dpm", dict(steps=9, order=2, skip_type="time_uniform", denoise_to_zero=True, algorithm_type="dpmsolver",
+                                    hooks=("thr", True))),
+    "unipc_thr_xt": ("unipc", dict(steps=10, order=2, skip_type="time_uniform", denoise_to_zero=True, return_intermediate=True,
+                                   hooks=("thr", True))),
+    "unipc_x0fn_o3": ("unipc", dict(steps=8, order=3, skip_type="time_quadratic", hooks=("fn", True))),
 }
+
+
+def _hook_kwargs(hooks, unipc):
+    if hooks is None:
+        return {}
+    x0, xt = hooks
+    kw = {}
+    if x0 == "thr":
+        kw.update(correcting_x0_fn="dynamic_thresholding", dynamic_thresholding_ratio=0.9, thresholding_max_val=0.6)
+    elif x0 == "fn":
+        kw.update(correcting_x0_fn=(lambda v: sampler_ref.standin_x0_fix(v)) if unipc else sampler_ref.standin_x0_fix)
+    if xt:
+        kw.update(correcting_xt_fn=sampler_ref.standin_xt_fix)
+    return kw
+
+
+def _oracle_hooks(hooks):
+    if hooks is None:
+        return {}
+    x0, xt = hooks
+    x0_fn = None
+    if x0 == "thr":
+        x0_fn = lambda v, t=None: sampler_ref.dynamic_thresholding(v, 0.9, 0.6)
+    elif x0 == "fn":
+        x0_fn = sampler_ref.standin_x0_fix
+    return dict(x0_fn=x0_fn, xt_fn=sampler_ref.standin_xt_fix if xt else None)
 
 
 @pytest.mark.parametrize("key", sorted(OPTION_CASES))
@@ -200,6 +236,7 @@ def test_sampler_options_match_reference(gold, key):
     kw = dict(kw)
     sched = kw.pop("schedule", None)
     algo = kw.pop("algorithm_type", "dpmsolver++")
+    hooks = kw.pop("hooks", None)
     B = 2 if solver == "dpm" else 1
     x = torch.from_numpy(synth.normal(1234, "opts." + key, (B, 5, 24)))
     betas = torch.from_numpy(synth.make_betas())
@@ -212,9 +249,9 @@ def test_sampler_options_match_reference(gold, key):
     tol = 2e-5 if sched is None else 5e-4
     fn = mod.model_wrapper(lambda xx, t, **k: sampler_ref.standin_model(xx, t), ns, model_type="x_start")
     if solver == "dpm":
-        r = mod.DPM_Solver(fn, ns, algorithm_type=algo).sample(x.clone(), method="multistep", **kw)
+        r = mod.DPM_Solver(fn, ns, algorithm_type=algo, **_hook_kwargs(hooks, False)).sample(x.clone(), method="multistep", **kw)
     else:
-        r = mod.UniPC(fn, ns, variant="bh2").sample(x.clone(), method="multistep", **kw)
+        r = mod.UniPC(fn, ns, variant="bh2", **_hook_kwargs(hooks, True)).sample(x.clone(), method="multistep", **kw)
     if kw.get("return_intermediate"):
         out, inter = r
         ref_inter = g[key + "_inter"]
@@ -229,9 +266,9 @@ def test_sampler_options_match_reference(gold, key):
     args = (okw.pop("steps"), okw.pop("order"), okw.pop("skip_type"))
     okw.pop("return_intermediate", None)
     if solver == "dpm":
-        o = sampler_ref.dpm_solver_pp_sample(sampler_ref.standin_model, betas, x.clone(), *args, schedule=sched, algorithm_type=algo, **okw)
+        o = sampler_ref.dpm_solver_pp_sample(sampler_ref.standin_model, betas, x.clone(), *args, schedule=sched, algorithm_type=algo, **_oracle_hooks(hooks), **okw)
     else:
-        o = sampler_ref.unipc_sample(sampler_ref.standin_model, betas, x.clone(), *args, "bh2", schedule=sched, **okw)
+        o = sampler_ref.unipc_sample(sampler_ref.standin_model, betas, x.clone(), *args, "bh2", schedule=sched, **_oracle_hooks(hooks), **okw)
     assert rel_l2(o.numpy(), g[key + "_x"]) < 1e-6
 
 

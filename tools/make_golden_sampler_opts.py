@@ -40,7 +40,44 @@ CASES = {
     "dpmn_o3_logsnr": ("dpm", dict(steps=8, order=3, skip_type="logSNR", algorithm_type="dpmsolver")),
     "dpmn_o3_window": ("dpm", dict(steps=20, order=3, skip_type="time_uniform", t_start=0.9, t_end=0.02, algorithm_type="dpmsolver")),
     "dpmn_linear": ("dpm", dict(steps=9, order=2, skip_type="time_uniform", schedule=("linear", 0.1, 20.0), algorithm_type="dpmsolver")),
+    # correcting_x0_fn ("thr": dynamic thresholding with ratio 0.9 / max 0.6; "fn": sampler_ref.standin_x0_fix) and
+    # correcting_xt_fn (sampler_ref.standin_xt_fix): dpm_solver.py:409-425, 443-444, 1180-1238; uni_pc.py:256-277, 292-293, 615-665
+    "dpm_thr_xt": ("dpm", dict(steps=10, order=2, skip_type="time_uniform", denoise_to_zero=True, return_intermediate=True,
+                               hooks=("thr", True))),
+    "dpm_x0fn": ("dpm", dict(steps=8, order=3, skip_type="logSNR", hooks=("fn", False))),
+    "dpmn_thr_xt_dtz": ("dpm", dict(steps=9, order=2, skip_type="time_uniform", denoise_to_zero=True, algorithm_type="dpmsolver",
+                                    hooks=("thr", True))),
+    "unipc_thr_xt": ("unipc", dict(steps=10, order=2, skip_type="time_uniform", denoise_to_zero=True, return_intermediate=True,
+                                   hooks=("thr", True))),
+    "unipc_x0fn_o3": ("unipc", dict(steps=8, order=3, skip_type="time_quadratic", hooks=("fn", True))),
 }
+
+
+def hook_kwargs(hooks, unipc):
+    """Constructor keywords of DPM_Solver / UniPC (reference or mirror) for a case's `hooks` entry."""
+    if hooks is None:
+        return {}
+    x0, xt = hooks
+    kw = {}
+    if x0 == "thr":
+        kw.update(correcting_x0_fn="dynamic_thresholding", dynamic_thresholding_ratio=0.9, thresholding_max_val=0.6)
+    elif x0 == "fn":
+        kw.update(correcting_x0_fn=(lambda v: sampler_ref.standin_x0_fix(v)) if unipc else sampler_ref.standin_x0_fix)
+    if xt:
+        kw.update(correcting_xt_fn=sampler_ref.standin_xt_fix)
+    return kw
+
+
+def oracle_hooks(hooks):
+    if hooks is None:
+        return {}
+    x0, xt = hooks
+    x0_fn = None
+    if x0 == "thr":
+        x0_fn = lambda v, t=None: sampler_ref.dynamic_thresholding(v, 0.9, 0.6)
+    elif x0 == "fn":
+        x0_fn = sampler_ref.standin_x0_fix
+    return dict(x0_fn=x0_fn, xt_fn=sampler_ref.standin_xt_fix if xt else None)
 
 
 def make_ns(mod, schedule, betas):
@@ -70,20 +107,21 @@ def main():
         kw = dict(kw)
         sched = kw.pop("schedule", None)
         algo = kw.pop("algorithm_type", "dpmsolver++")
+        hooks = kw.pop("hooks", None)
         if solver == "dpm":
             ns = make_ns(ref_dpm, sched, betas)
             fn = ref_dpm.model_wrapper(lambda xx, t, **k: sampler_ref.standin_model(xx, t), ns, model_type="x_start")
-            r = ref_dpm.DPM_Solver(fn, ns, algorithm_type=algo).sample(x.clone(), method="multistep", **kw)
+            r = ref_dpm.DPM_Solver(fn, ns, algorithm_type=algo, **hook_kwargs(hooks, False)).sample(x.clone(), method="multistep", **kw)
             okw = {k: v for k, v in kw.items()}
             o = sampler_ref.dpm_solver_pp_sample(sampler_ref.standin_model, betas, x.clone(), okw.pop("steps"), okw.pop("order"),
-                                                 okw.pop("skip_type"), schedule=sched, algorithm_type=algo, **okw)
+                                                 okw.pop("skip_type"), schedule=sched, algorithm_type=algo, **oracle_hooks(hooks), **okw)
         else:
             ns = make_ns(ref_unipc, sched, betas)
             fn = ref_unipc.model_wrapper(lambda xx, t, **k: sampler_ref.standin_model(xx, t), ns, model_type="x_start")
-            r = ref_unipc.UniPC(fn, ns, variant="bh2").sample(x.clone(), method="multistep", **kw)
+            r = ref_unipc.UniPC(fn, ns, variant="bh2", **hook_kwargs(hooks, True)).sample(x.clone(), method="multistep", **kw)
             okw = {k: v for k, v in kw.items()}
             o = sampler_ref.unipc_sample(sampler_ref.standin_model, betas, x.clone(), okw.pop("steps"), okw.pop("order"),
-                                         okw.pop("skip_type"), "bh2", schedule=sched, **okw)
+                                         okw.pop("skip_type"), "bh2", schedule=sched, **oracle_hooks(hooks), **okw)
         if kw.get("return_intermediate"):
             xr, inter = r
             xo, ointer = o
