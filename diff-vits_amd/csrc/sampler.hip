@@ -236,8 +236,9 @@ static int build_plan(dv_plan* p) {
   const std::vector<double>& ts = p->timesteps;
   std::vector<int> hist;            // history slots, newest first
   std::vector<double> htime;        // their times
-  const bool unipc = p->solver != DV_SOLVER_DPMPP && p->solver != DV_SOLVER_DPM;
-  const bool noise = p->solver == DV_SOLVER_DPM;   // multistep updates on the noise prediction (algorithm_type='dpmsolver')
+  const bool taylor = p->solver == DV_SOLVER_DPMPP_TAYLOR || p->solver == DV_SOLVER_DPM_TAYLOR;   // solver_type='taylor' (second order only)
+  const bool noise = p->solver == DV_SOLVER_DPM || p->solver == DV_SOLVER_DPM_TAYLOR;   // multistep updates on the noise prediction (algorithm_type='dpmsolver')
+  const bool unipc = p->solver >= DV_SOLVER_UNIPC_BH1 && p->solver <= DV_SOLVER_UNIPC_VARY;
   p->n_slots = unipc ? order + 1 : order;
   auto free_slot = [&]() {
     for (int s = 0; s < p->n_slots; ++s) {
@@ -275,7 +276,8 @@ static int build_plan(dv_plan* p) {
       if (ord == 1) { add_comb(0, c0, {{hist[0], -s * phi_1}}); return; }
       if (ord == 2) {
         const double r0 = (lam0 - ns.lambda(htime[1])) / h;
-        add_comb(0, c0, {{hist[0], -s * phi_1 * (1.0 + 0.5 / r0)}, {hist[1], 0.5 * s * phi_1 / r0}});
+        const double d = taylor ? s * (phi_1 / h - 1.0) : 0.5 * s * phi_1;      // coefficient of D1_0 = (m0 - m1) / r0 (:841-851)
+        add_comb(0, c0, {{hist[0], -s * phi_1 - d / r0}, {hist[1], d / r0}});
         return;
       }
       const double lam1 = ns.lambda(htime[1]), lam2 = ns.lambda(htime[2]);
@@ -296,6 +298,11 @@ static int build_plan(dv_plan* p) {
       if (ord == 1) { add_comb(0, c0, {{hist[0], -a * phi_1}}); return; }
       if (ord == 2) {
         const double r0 = (lam0 - ns.lambda(htime[1])) / h;
+        if (taylor) {                                   // x_t = c0 x - a phi_1 m0 + a (phi_1 / h + 1) D1_0 (:825-829)
+          const double d = a * (phi_1 / h + 1.0);
+          add_comb(0, c0, {{hist[0], -a * phi_1 + d / r0}, {hist[1], -d / r0}});
+          return;
+        }
         add_comb(0, c0, {{hist[0], -a * phi_1 * (1.0 + 0.5 / r0)}, {hist[1], 0.5 * a * phi_1 / r0}});
         return;
       }
@@ -462,19 +469,20 @@ extern "C" int dv_sampler_plan_sched(int32_t solver, int32_t schedule, const flo
                                      int32_t lower_order_final, double t_start, double t_end, int32_t denoise_to_zero,
                                      dv_plan** out) {
   if (!out) return dv_fail(DV_ERR_INVALID, "dv_sampler_plan: bad argument");
+  const bool dpm_family = solver == DV_SOLVER_DPMPP || solver >= DV_SOLVER_DPM;   // DPM-Solver(++) (the others: UniPC variants)
   if (schedule < DV_SCHEDULE_DISCRETE || schedule > DV_SCHEDULE_COSINE) return dv_fail(DV_ERR_INVALID, "unknown noise schedule %d", schedule);
   if (schedule == DV_SCHEDULE_DISCRETE && (!betas || n_betas < 2)) return dv_fail(DV_ERR_INVALID, "dv_sampler_plan: bad argument");
-  if (schedule == DV_SCHEDULE_COSINE && (solver == DV_SOLVER_DPMPP || solver == DV_SOLVER_DPM))   // (dpm_solver.py:94: 'discrete' or 'linear')
+  if (schedule == DV_SCHEDULE_COSINE && dpm_family)   // (dpm_solver.py:94: 'discrete' or 'linear')
     return dv_fail(DV_ERR_INVALID, "the 'cosine' schedule exists for the UniPC solvers only");
   if (schedule == DV_SCHEDULE_LINEAR && !(beta_1 > beta_0 && beta_0 >= 0.0)) return dv_fail(DV_ERR_INVALID, "linear schedule: need 0 <= beta_0 < beta_1");
-  if (solver < DV_SOLVER_DPMPP || solver > DV_SOLVER_DPM) return dv_fail(DV_ERR_INVALID, "unknown solver %d", solver);
-  if ((solver == DV_SOLVER_DPMPP || solver == DV_SOLVER_DPM) && (order < 1 || order > 3)) return dv_fail(DV_ERR_INVALID, "Solver order must be 1 or 2 or 3, got %d", order);
+  if (solver < DV_SOLVER_DPMPP || solver > DV_SOLVER_DPM_TAYLOR) return dv_fail(DV_ERR_INVALID, "unknown solver %d", solver);
+  if (dpm_family && (order < 1 || order > 3)) return dv_fail(DV_ERR_INVALID, "Solver order must be 1 or 2 or 3, got %d", order);
   if (order < 1 || order > MAXO) return dv_fail(DV_ERR_INVALID, "UniPC order must be 1..%d, got %d", MAXO, order);
   if (steps < order) return dv_fail(DV_ERR_INVALID, "steps (%d) must be >= order (%d)", steps, order);
   dv_plan* p = new dv_plan();
   p->solver = solver; p->steps = steps; p->order = order; p->skip = skip_type; p->lof = lower_order_final;
   p->t_start = t_start; p->t_end = t_end; p->denoise_to_zero = denoise_to_zero ? 1 : 0;
-  if (schedule == DV_SCHEDULE_DISCRETE) p->ns.init(betas, n_betas, solver == DV_SOLVER_DPMPP || solver == DV_SOLVER_DPM);
+  if (schedule == DV_SCHEDULE_DISCRETE) p->ns.init(betas, n_betas, dpm_family);
   else p->ns.init_continuous(schedule, beta_0, beta_1);
   int rc = build_plan(p);
   if (rc != DV_OK) { delete p; return rc; }

@@ -117,9 +117,8 @@ def wrap_model(model, noise_schedule, model_type="noise", model_kwargs={}, guida
     directly instead of converting x0 -> noise -> x0."""
     if model_type not in ("noise", "x_start", "v", "score"):
         raise AssertionError("model_type must be one of noise / x_start / v / score")
-    if guidance_type != "uncond":
-        raise ValueError("guidance_type=%r is not supported on this path (the reference call sites use 'uncond')"
-                         % (guidance_type,))
+    if guidance_type not in ("uncond", "classifier", "classifier-free"):
+        raise AssertionError("guidance_type must be one of uncond / classifier / classifier-free")
     ns = noise_schedule
 
     def expand(v, x):
@@ -130,8 +129,11 @@ def wrap_model(model, noise_schedule, model_type="noise", model_kwargs={}, guida
             return t_continuous
         return (t_continuous - 1.0 / ns.total_N) * ns.total_N
 
-    def model_fn(x, t_continuous):
-        out = model(x, t_input(t_continuous), **model_kwargs)
+    def noise_pred_fn(x, t_continuous, cond=None):     # dpm_solver.py:282-298
+        if cond is None:
+            out = model(x, t_input(t_continuous), **model_kwargs)
+        else:
+            out = model(x, t_input(t_continuous), cond, **model_kwargs)
         if model_type == "noise":
             return out
         alpha_t = ns.marginal_alpha(t_continuous).to(x)
@@ -142,7 +144,32 @@ def wrap_model(model, noise_schedule, model_type="noise", model_kwargs={}, guida
             return expand(alpha_t, x) * out + expand(sigma_t, x) * x
         return -expand(sigma_t, x) * out
 
-    model_fn._dv = dict(model=model, model_type=model_type, model_kwargs=model_kwargs, noise_schedule=ns)
+    def cond_grad_fn(x, t_in):                         # grad_x log p_t(condition | x_t), dpm_solver.py:300-307
+        with torch.enable_grad():
+            x_in = x.detach().requires_grad_(True)
+            log_prob = classifier_fn(x_in, t_in, condition, **classifier_kwargs)
+            return torch.autograd.grad(log_prob.sum(), x_in)[0]
+
+    def model_fn(x, t_continuous):                     # dpm_solver.py:309-330
+        if guidance_type == "uncond":
+            return noise_pred_fn(x, t_continuous)
+        if guidance_type == "classifier":
+            assert classifier_fn is not None
+            cond_grad = cond_grad_fn(x, t_input(t_continuous))
+            sigma_t = ns.marginal_std(t_continuous).to(x)
+            return noise_pred_fn(x, t_continuous) - guidance_scale * expand(sigma_t, x) * cond_grad
+        if guidance_scale == 1.0 or unconditional_condition is None:
+            return noise_pred_fn(x, t_continuous, cond=condition)
+        x_in = torch.cat([x] * 2)
+        t_in = torch.cat([t_continuous] * 2)
+        c_in = torch.cat([unconditional_condition, condition])
+        noise_uncond, noise = noise_pred_fn(x_in, t_in, cond=c_in).chunk(2)
+        return noise_uncond + guidance_scale * (noise - noise_uncond)
+
+    # (the direct x0 route - and with it the native graph - is taken for the unguided wrapper only: a guided model_fn is an
+    # arbitrary noise prediction for the solvers)
+    if guidance_type == "uncond":
+        model_fn._dv = dict(model=model, model_type=model_type, model_kwargs=model_kwargs, noise_schedule=ns)
     return model_fn
 
 

@@ -15,6 +15,7 @@ __all__ = ["NoiseScheduleVP", "model_wrapper", "DPM_Solver", "NativeUNetModel"]
 
 _SOLVER_DPMPP = 0
 _SOLVER_DPM = 4          # algorithm_type='dpmsolver': multistep updates on the noise prediction (include/dvits_hip.h)
+_TAYLOR = {_SOLVER_DPMPP: 5, _SOLVER_DPM: 6}     # solver_type='taylor': the second-order update's Taylor form
 
 
 class NoiseScheduleVP(NoiseScheduleBase):
@@ -45,10 +46,14 @@ class DPM_Solver:
         plan = self._plan(N, min(2, N), skip_type, True, float(t_T), float(t_0))
         return torch.as_tensor(plan.timesteps, dtype=torch.float32, device=device)
 
-    def _plan(self, steps, order, skip_type, lower_order_final, t_start=None, t_end=None, denoise_to_zero=False):
-        key = (steps, order, skip_type, bool(lower_order_final), t_start, t_end, bool(denoise_to_zero))
+    def _plan(self, steps, order, skip_type, lower_order_final, t_start=None, t_end=None, denoise_to_zero=False,
+              solver_type="dpmsolver"):
+        key = (steps, order, skip_type, bool(lower_order_final), t_start, t_end, bool(denoise_to_zero), solver_type)
         if key not in self._plans:
-            self._plans[key] = Plan(_SOLVER_DPMPP if self.algorithm_type == "dpmsolver++" else _SOLVER_DPM, self.noise_schedule._betas, steps, order, skip_type,
+            solver = _SOLVER_DPMPP if self.algorithm_type == "dpmsolver++" else _SOLVER_DPM
+            if solver_type == "taylor":
+                solver = _TAYLOR[solver]
+            self._plans[key] = Plan(solver, self.noise_schedule._betas, steps, order, skip_type,
                                     lower_order_final, t_start, t_end, denoise_to_zero,
                                     schedule=self.noise_schedule._plan_schedule())
         return self._plans[key]
@@ -62,10 +67,10 @@ class DPM_Solver:
             raise ValueError("Got wrong method {} (this build implements method='multistep')".format(method))
         if order not in (1, 2, 3):
             raise ValueError("Solver order must be 1 or 2 or 3, got {}".format(order))
-        if solver_type != "dpmsolver":
-            raise ValueError("solver_type='taylor' is not supported on this path")
+        if solver_type not in ("dpmsolver", "taylor"):
+            raise ValueError("'solver_type' must be either 'dpmsolver' or 'taylor', got {}".format(solver_type))
         assert steps >= order
-        plan = self._plan(steps, order, skip_type, lower_order_final, t_start, t_end, denoise_to_zero)
+        plan = self._plan(steps, order, skip_type, lower_order_final, t_start, t_end, denoise_to_zero, solver_type)
         x0_hook = None
         if self.correcting_x0_fn is not None:
             # data_prediction_fn applies it (:433-445): every evaluation of 'dpmsolver++'; with 'dpmsolver' only the final

@@ -129,6 +129,29 @@ def wrap_x_start_model(model, ns, x0_fn=None):
     return data_prediction
 
 
+def guided_noise_fn(model, ns, guidance_type, condition=None, unconditional_condition=None, guidance_scale=1.0,
+                    classifier_fn=None):
+    """model_wrapper(model, ns, model_type='x_start', guidance_type='classifier' | 'classifier-free', ...) ->
+    model_fn(x, t): dpm_solver.py:282-330.  `model(x, t_input[, cond])` predicts x0."""
+    def noise_pred(x, t, cond=None):
+        t_input = t if isinstance(ns, ContinuousSchedule) else (t - 1.0 / ns.total_N) * ns.total_N
+        out = model(x, t_input) if cond is None else model(x, t_input, cond)
+        return (x - _bcast(ns.alpha(t), x) * out) / _bcast(ns.sigma(t), x)
+
+    def model_fn(x, t):
+        if guidance_type == "classifier":
+            t_input = t if isinstance(ns, ContinuousSchedule) else (t - 1.0 / ns.total_N) * ns.total_N
+            with torch.enable_grad():
+                x_in = x.detach().requires_grad_(True)
+                grad = torch.autograd.grad(classifier_fn(x_in, t_input, condition).sum(), x_in)[0]
+            return noise_pred(x, t) - guidance_scale * _bcast(ns.sigma(t), x) * grad
+        if guidance_scale == 1.0 or unconditional_condition is None:
+            return noise_pred(x, t, cond=condition)
+        nu, n = noise_pred(torch.cat([x] * 2), torch.cat([t] * 2), cond=torch.cat([unconditional_condition, condition])).chunk(2)
+        return nu + guidance_scale * (n - nu)
+    return model_fn
+
+
 def time_steps(ns, skip_type, t_T, t_0, N):
     """get_time_steps, dpm_solver.py:453-480."""
     if skip_type == "time_uniform":
@@ -143,7 +166,7 @@ def time_steps(ns, skip_type, t_T, t_0, N):
 
 
 # ----------------------------------------------------------------------------- DPM-Solver++
-def _dpmpp_update(ns, x, m_list, t_list, t, order):
+def _dpmpp_update(ns, x, m_list, t_list, t, order, taylor=False):
     """multistep_dpm_solver_update for algorithm_type='dpmsolver++', solver_type='dpmsolver':
     first (:547-580), second (:796-831), third (:854-889) order."""
     t0 = t_list[-1]
@@ -159,6 +182,8 @@ def _dpmpp_update(ns, x, m_list, t_list, t, order):
         h_0 = lam0 - ns.lam(t_list[-2])
         r0 = h_0 / h
         D1_0 = (1.0 / r0) * (m0 - m1)
+        if taylor:                 # solver_type='taylor', dpm_solver.py:825-829
+            return (sig_t / sig0) * x - (alpha_t * phi_1) * m0 + (alpha_t * (phi_1 / h + 1.0)) * D1_0
         return (sig_t / sig0) * x - (alpha_t * phi_1) * m0 - 0.5 * (alpha_t * phi_1) * D1_0
     if order == 3:
         m2, m1, m0 = m_list
@@ -175,7 +200,7 @@ def _dpmpp_update(ns, x, m_list, t_list, t, order):
     raise ValueError("Solver order must be 1 or 2 or 3, got %r" % (order,))
 
 
-def _dpm_noise_update(ns, x, m_list, t_list, t, order):
+def _dpm_noise_update(ns, x, m_list, t_list, t, order, taylor=False):
     """multistep_dpm_solver_update for algorithm_type='dpmsolver' (updates on the noise prediction), solver_type='dpmsolver':
     first (dpm_solver.py:581-592), second (:841-847), third (:895-904) order."""
     t0 = t_list[-1]
@@ -190,6 +215,8 @@ def _dpm_noise_update(ns, x, m_list, t_list, t, order):
         m1, m0 = m_list[-2], m_list[-1]
         r0 = (lam0 - ns.lam(t_list[-2])) / h
         D1_0 = (1.0 / r0) * (m0 - m1)
+        if taylor:                 # solver_type='taylor', dpm_solver.py:848-851
+            return torch.exp(la_t - la0) * x - (sig_t * phi_1) * m0 - (sig_t * (phi_1 / h - 1.0)) * D1_0
         return torch.exp(la_t - la0) * x - (sig_t * phi_1) * m0 - 0.5 * (sig_t * phi_1) * D1_0
     if order == 3:
         m2, m1, m0 = m_list
@@ -220,16 +247,25 @@ def wrap_x_start_noise(model, ns):
 
 def dpm_solver_pp_sample(model, betas, x, steps=20, order=2, skip_type="time_uniform",
                          lower_order_final=True, return_intermediate=False, t_start=None, t_end=None,
-                         denoise_to_zero=False, schedule=None, algorithm_type="dpmsolver++", x0_fn=None, xt_fn=None):
+                         denoise_to_zero=False, schedule=None, algorithm_type="dpmsolver++", x0_fn=None, xt_fn=None,
+                         guidance=None, solver_type="dpmsolver"):
     """DPM_Solver(model_fn, ns, algorithm_type).sample(x, steps, order, skip_type,
     method='multistep'), dpm_solver.py:1047-1245 (multistep branch :1171-1213).
     `model(x, t_input)` is the raw x0-prediction network.  algorithm_type='dpmsolver': the same loop on the noise
     prediction (model_fn = noise_prediction_fn, dpm_solver.py:390-392)."""
     ns = _schedule(betas, True, schedule)
     data_fn = wrap_x_start_model(model, ns, x0_fn)
+    if guidance is not None:       # a guided wrapper (dict of guided_noise_fn's keywords): model_fn is its noise prediction
+        g_noise = guided_noise_fn(model, ns, **guidance)
+
+        def data_fn(x, t):         # data_prediction_fn, dpm_solver.py:433-445
+            tb = t.expand(x.shape[0])
+            x0 = (x - ns.sigma(t) * g_noise(x, tb)) / ns.alpha(t)
+            return x0 if x0_fn is None else x0_fn(x0, t)
     fix = (lambda x, t, step: x) if xt_fn is None else xt_fn       # correcting_xt_fn (:1180-1181, 1188-1189, 1203-1204, 1237-1238)
     fn = data_fn if algorithm_type == "dpmsolver++" else wrap_x_start_noise(model, ns)
-    _dpmpp_update = globals()["_dpmpp_update"] if algorithm_type == "dpmsolver++" else _dpm_noise_update
+    _upd = globals()["_dpmpp_update"] if algorithm_type == "dpmsolver++" else _dpm_noise_update
+    _dpmpp_update = lambda *a: _upd(*a, taylor=solver_type == "taylor")
     # dpm_solver.py:1157-1158: t_0 = 1/N unless t_end is given, t_T = T unless t_start is given
     t_0 = 1.0 / ns.total_N if t_end is None else t_end
     t_T = ns.T if t_start is None else t_start
@@ -422,4 +458,15 @@ def standin_x0_fix(x0, t=None):
 def standin_xt_fix(x, t, step):
     """A correcting_xt_fn for the known-answer cases: depends on all three arguments."""
     return x * (1.0 - 1e-3 * (step % 3)) + 1e-3 * t
+
+
+def standin_cond_model(x, t_input, cond=None):
+    """The stand-in network with an optional condition (guidance known-answer cases)."""
+    out = standin_model(x, t_input)
+    return out if cond is None else out + 0.1 * torch.tanh(cond)
+
+
+def standin_classifier(x, t_input, cond):
+    """log p_t(cond | x) of the guidance known-answer cases (differentiable in x)."""
+    return -0.005 * ((x - cond) ** 2).reshape(x.shape[0], -1).sum(1)
 

@@ -200,7 +200,24 @@ OPTION_CASES = {
     "unipc_thr_xt": ("unipc", dict(steps=10, order=2, skip_type="time_uniform", denoise_to_zero=True, return_intermediate=True,
                                    hooks=("thr", True))),
     "unipc_x0fn_o3": ("unipc", dict(steps=8, order=3, skip_type="time_quadratic", hooks=("fn", True))),
+    # model_wrapper(guidance_type='classifier-free' | 'classifier', ...) (dpm_solver.py:282-330) on the conditional stand-in
+    "dpm_cfg": ("dpm", dict(steps=10, order=2, skip_type="time_uniform", guidance="cfg")),
+    "dpm_cfg_scale1": ("dpm", dict(steps=8, order=3, skip_type="logSNR", guidance="cfg1")),
+    "dpm_classifier": ("dpm", dict(steps=10, order=2, skip_type="time_quadratic", denoise_to_zero=True, guidance="clf")),
+    # solver_type='taylor' (the second-order update's Taylor form, dpm_solver.py:825-829, 848-851)
+    "dpm_taylor": ("dpm", dict(steps=10, order=2, skip_type="time_uniform", solver_type="taylor")),
+    "dpmn_taylor": ("dpm", dict(steps=12, order=2, skip_type="logSNR", solver_type="taylor", algorithm_type="dpmsolver")),
 }
+
+
+def _guidance_kwargs(name, key, B):
+    if name is None:
+        return None
+    cond = torch.from_numpy(synth.normal(4321, "cond." + key, (B, 5, 1)))
+    if name == "clf":
+        return dict(guidance_type="classifier", condition=cond, guidance_scale=1.5, classifier_fn=sampler_ref.standin_classifier)
+    return dict(guidance_type="classifier-free", condition=cond, unconditional_condition=torch.zeros_like(cond),
+                guidance_scale=2.5 if name == "cfg" else 1.0)
 
 
 def _hook_kwargs(hooks, unipc):
@@ -238,6 +255,8 @@ def test_sampler_options_match_reference(gold, key):
     algo = kw.pop("algorithm_type", "dpmsolver++")
     hooks = kw.pop("hooks", None)
     B = 2 if solver == "dpm" else 1
+    guid = _guidance_kwargs(kw.pop("guidance", None), key, B)
+    net = sampler_ref.standin_cond_model if guid else sampler_ref.standin_model
     x = torch.from_numpy(synth.normal(1234, "opts." + key, (B, 5, 24)))
     betas = torch.from_numpy(synth.make_betas())
     mod = dpm_solver if solver == "dpm" else uni_pc
@@ -247,7 +266,7 @@ def test_sampler_options_match_reference(gold, key):
     # sigma = sqrt(1 - exp(2 log alpha)) loses ~4 digits near t_end (log alpha ~ -5e-5): the agreement is the reference's
     # own rounding there (the float32 oracle below reproduces the reference exactly)
     tol = 2e-5 if sched is None else 5e-4
-    fn = mod.model_wrapper(lambda xx, t, **k: sampler_ref.standin_model(xx, t), ns, model_type="x_start")
+    fn = mod.model_wrapper(lambda xx, t, *c, **k: net(xx, t, *c), ns, model_type="x_start", **(guid or {}))
     if solver == "dpm":
         r = mod.DPM_Solver(fn, ns, algorithm_type=algo, **_hook_kwargs(hooks, False)).sample(x.clone(), method="multistep", **kw)
     else:
@@ -266,7 +285,8 @@ def test_sampler_options_match_reference(gold, key):
     args = (okw.pop("steps"), okw.pop("order"), okw.pop("skip_type"))
     okw.pop("return_intermediate", None)
     if solver == "dpm":
-        o = sampler_ref.dpm_solver_pp_sample(sampler_ref.standin_model, betas, x.clone(), *args, schedule=sched, algorithm_type=algo, **_oracle_hooks(hooks), **okw)
+        o = sampler_ref.dpm_solver_pp_sample(net, betas, x.clone(), *args, schedule=sched, algorithm_type=algo, guidance=guid,
+                                             **_oracle_hooks(hooks), **okw)
     else:
         o = sampler_ref.unipc_sample(sampler_ref.standin_model, betas, x.clone(), *args, "bh2", schedule=sched, **_oracle_hooks(hooks), **okw)
     assert rel_l2(o.numpy(), g[key + "_x"]) < 1e-6

@@ -50,7 +50,25 @@ CASES = {
     "unipc_thr_xt": ("unipc", dict(steps=10, order=2, skip_type="time_uniform", denoise_to_zero=True, return_intermediate=True,
                                    hooks=("thr", True))),
     "unipc_x0fn_o3": ("unipc", dict(steps=8, order=3, skip_type="time_quadratic", hooks=("fn", True))),
+    # model_wrapper(guidance_type='classifier-free' | 'classifier', ...) (dpm_solver.py:282-330) on the conditional stand-in
+    "dpm_cfg": ("dpm", dict(steps=10, order=2, skip_type="time_uniform", guidance="cfg")),
+    "dpm_cfg_scale1": ("dpm", dict(steps=8, order=3, skip_type="logSNR", guidance="cfg1")),
+    "dpm_classifier": ("dpm", dict(steps=10, order=2, skip_type="time_quadratic", denoise_to_zero=True, guidance="clf")),
+    # solver_type='taylor' (the second-order update's Taylor form, dpm_solver.py:825-829, 848-851)
+    "dpm_taylor": ("dpm", dict(steps=10, order=2, skip_type="time_uniform", solver_type="taylor")),
+    "dpmn_taylor": ("dpm", dict(steps=12, order=2, skip_type="logSNR", solver_type="taylor", algorithm_type="dpmsolver")),
 }
+
+
+def guidance_kwargs(name, key, B):
+    """model_wrapper keywords (reference and mirror) / guided_noise_fn keywords (oracle) of a case's `guidance` entry."""
+    if name is None:
+        return None
+    cond = torch.from_numpy(synth.normal(4321, "cond." + key, (B, 5, 1)))
+    if name == "clf":
+        return dict(guidance_type="classifier", condition=cond, guidance_scale=1.5, classifier_fn=sampler_ref.standin_classifier)
+    return dict(guidance_type="classifier-free", condition=cond, unconditional_condition=torch.zeros_like(cond),
+                guidance_scale=2.5 if name == "cfg" else 1.0)
 
 
 def hook_kwargs(hooks, unipc):
@@ -108,13 +126,15 @@ def main():
         sched = kw.pop("schedule", None)
         algo = kw.pop("algorithm_type", "dpmsolver++")
         hooks = kw.pop("hooks", None)
+        guid = guidance_kwargs(kw.pop("guidance", None), key, B)
+        net = sampler_ref.standin_cond_model if guid else sampler_ref.standin_model
         if solver == "dpm":
             ns = make_ns(ref_dpm, sched, betas)
-            fn = ref_dpm.model_wrapper(lambda xx, t, **k: sampler_ref.standin_model(xx, t), ns, model_type="x_start")
+            fn = ref_dpm.model_wrapper(lambda xx, t, *c, **k: net(xx, t, *c), ns, model_type="x_start", **(guid or {}))
             r = ref_dpm.DPM_Solver(fn, ns, algorithm_type=algo, **hook_kwargs(hooks, False)).sample(x.clone(), method="multistep", **kw)
             okw = {k: v for k, v in kw.items()}
-            o = sampler_ref.dpm_solver_pp_sample(sampler_ref.standin_model, betas, x.clone(), okw.pop("steps"), okw.pop("order"),
-                                                 okw.pop("skip_type"), schedule=sched, algorithm_type=algo, **oracle_hooks(hooks), **okw)
+            o = sampler_ref.dpm_solver_pp_sample(net, betas, x.clone(), okw.pop("steps"), okw.pop("order"),
+                                                 okw.pop("skip_type"), schedule=sched, algorithm_type=algo, guidance=guid, **oracle_hooks(hooks), **okw)
         else:
             ns = make_ns(ref_unipc, sched, betas)
             fn = ref_unipc.model_wrapper(lambda xx, t, **k: sampler_ref.standin_model(xx, t), ns, model_type="x_start")
