@@ -16,6 +16,7 @@ PREC_BF16X3, PREC_BF16 = 0, 1
 SOLVER_DPMPP, SOLVER_UNIPC_BH1, SOLVER_UNIPC_BH2, SOLVER_UNIPC_VARY = 0, 1, 2, 3
 SKIP = {"time_uniform": 0, "time_quadratic": 1, "logSNR": 2}
 SCHEDULE = {"discrete": 0, "linear": 1, "cosine": 2}
+METHOD = {"multistep": 0, "singlestep": 1, "singlestep_fixed": 2}
 
 
 class UNetCfg(C.Structure):
@@ -67,6 +68,9 @@ SIGNATURES = {
                                      C.c_double, C.c_double, C.c_int32, C.POINTER(C.c_void_p)]),
     "dv_sampler_plan_sched": (C.c_int, [C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_double, C.c_double, C.c_int32, C.c_int32,
                                         C.c_int32, C.c_int32, C.c_double, C.c_double, C.c_int32, C.POINTER(C.c_void_p)]),
+    "dv_sampler_plan_method": (C.c_int, [C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_double, C.c_double, C.c_int32, C.c_int32,
+                                         C.c_int32, C.c_int32, C.c_int32, C.c_double, C.c_double, C.c_int32, C.POINTER(C.c_void_p)]),
+    "dv_plan_times": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.c_void_p]),
     "dv_plan_destroy": (None, [C.c_void_p]),
     "dv_plan_info": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.c_void_p, C.c_void_p]),
     "dv_plan_coefs": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.c_void_p]),

@@ -167,6 +167,8 @@ struct dv_plan {
   Schedule ns;
   std::vector<double> timesteps;      // steps + 1
   std::vector<double> t_input;        // per EVAL
+  std::vector<double> eval_time;      // per EVAL: its continuous time
+  int method = 0;                     // 0 multistep, 1 singlestep ("DPM-Solver-fast"), 2 singlestep_fixed (DPM-Solver(++) only)
   std::vector<Event> ev;
   std::vector<std::array<float, 8>> coefs;
   int n_slots = 0;
@@ -185,25 +187,26 @@ static int build_plan(dv_plan* p) {
   // dpm_solver.py:1157-1158 / uni_pc.py:596-597: t_0 = 1/N unless t_end is given, t_T = T unless t_start is given
   const double t_0 = p->t_end > 0 ? p->t_end : 1.0 / ns.total_N, t_T = p->t_start > 0 ? p->t_start : ns.T;
   // ---- time grid (get_time_steps, dpm_solver.py:453-480), float32 as the reference stores it
-  p->timesteps.resize(N + 1);
-  auto linspace32 = [&](float a, float b, std::vector<double>& out) {
-    const int pts = N + 1;
-    const float step = (b - a) / (float)(pts - 1);
-    for (int i = 0; i < pts; ++i)   // ATen's vectorised fill rounds once per element (fma)
-      out[i] = (double)((i < pts / 2) ? fmaf(step, (float)i, a) : fmaf(-step, (float)(pts - i - 1), b));
+  auto time_grid = [&](double tT, double t0, int n, std::vector<double>& out) -> bool {   // n steps: n + 1 points from tT to t0
+    out.assign(n + 1, 0.0);
+    auto linspace32 = [&](float a, float b, std::vector<double>& o) {
+      const int pts = n + 1;
+      const float step = (b - a) / (float)(pts - 1);
+      for (int i = 0; i < pts; ++i)   // ATen's vectorised fill rounds once per element (fma)
+        o[i] = (double)((i < pts / 2) ? fmaf(step, (float)i, a) : fmaf(-step, (float)(pts - i - 1), b));
+    };
+    if (p->skip == DV_SKIP_TIME_UNIFORM) linspace32((float)tT, (float)t0, out);
+    else if (p->skip == DV_SKIP_TIME_QUADRATIC) {
+      linspace32((float)sqrt(tT), (float)sqrt(t0), out);
+      for (auto& v : out) { const float f = (float)v; v = (double)(f * f); }
+    } else if (p->skip == DV_SKIP_LOGSNR) {
+      std::vector<double> lam(n + 1);
+      linspace32((float)ns.lambda(tT), (float)ns.lambda(t0), lam);
+      for (int i = 0; i <= n; ++i) out[i] = (double)(float)ns.inverse_lambda(lam[i]);
+    } else return false;
+    return true;
   };
-  if (p->skip == DV_SKIP_TIME_UNIFORM) linspace32((float)t_T, (float)t_0, p->timesteps);
-  else if (p->skip == DV_SKIP_TIME_QUADRATIC) {
-    linspace32((float)sqrt(t_T), (float)sqrt(t_0), p->timesteps);
-    for (auto& v : p->timesteps) { const float f = (float)v; v = (double)(f * f); }
-  } else if (p->skip == DV_SKIP_LOGSNR) {
-    std::vector<double> lam(N + 1);
-    const float lT = (float)ns.lambda(t_T), l0 = (float)ns.lambda(t_0);
-    const int pts = N + 1;
-    const float step = (l0 - lT) / (float)(pts - 1);
-    for (int i = 0; i < pts; ++i) lam[i] = (double)((i < pts / 2) ? fmaf(step, (float)i, lT) : fmaf(-step, (float)(pts - i - 1), l0));
-    for (int i = 0; i <= N; ++i) p->timesteps[i] = (double)(float)ns.inverse_lambda(lam[i]);
-  } else return dv_fail(DV_ERR_INVALID, "Unsupported skip_type %d", p->skip);
+  if (!time_grid(t_T, t_0, N, p->timesteps)) return dv_fail(DV_ERR_INVALID, "Unsupported skip_type %d", p->skip);
 
   auto t_in = [&](double t) {   // get_model_input_time, float32 arithmetic (dpm_solver.py:271-280)
     const float tf = (float)t;
@@ -213,6 +216,7 @@ static int build_plan(dv_plan* p) {
   auto add_eval = [&](int src, double t, int slot) {
     Event e{}; e.type = 0; e.src = src; e.eval_idx = (int)p->t_input.size(); e.dst = slot;
     p->t_input.push_back(t_in(t));
+    p->eval_time.push_back(t);
     p->ev.push_back(e);
   };
   // COMB: dst = c0 * x + sum_k c_k * m[slot_k].  The update kernel takes four m terms: longer sums (orders >= 4) are
@@ -258,10 +262,10 @@ static int build_plan(dv_plan* p) {
     // ---------------- DPM-Solver++ / DPM-Solver multistep ----------------
     // (noise form: the network predicts x0; its output becomes eps = (x - alpha x0) / sigma in place, with the x it was
     // evaluated on - model_wrapper's 'x_start' branch, dpm_solver.py:290-292)
-    auto add_eval_m = [&](double t, int slot) {
-      add_eval(0, t, slot);
+    auto add_eval_m = [&](double t, int slot, int src = 0) {
+      add_eval(src, t, slot);
       if (!noise) return;
-      Event e{}; e.type = 1; e.src = 0; e.dst = 2 + slot; e.coef = (int)p->coefs.size();
+      Event e{}; e.type = 1; e.src = src; e.dst = 2 + slot; e.coef = (int)p->coefs.size();
       std::array<float, 8> row{};
       row[0] = (float)(1.0 / ns.sigma(t)); row[1] = (float)(-ns.alpha(t) / ns.sigma(t));
       e.slots[0] = slot; e.slots[1] = e.slots[2] = e.slots[3] = -1;
@@ -315,6 +319,102 @@ static int build_plan(dv_plan* p) {
                        {hist[1], -P2 * (1 + g) * a0 - P2 * g * a1 + P3 * e * a0 + P3 * e * a1},
                        {hist[2], P2 * g * a1 - P3 * e * a1}});
     };
+    if (p->method != 0) {
+      // ---------------- singlestep DPM-Solver(++) ("DPM-Solver-fast", dpm_solver.py:482-539, 594-794, 1214-1232) ----------------
+      // outer grid + the order of every outer step (NFE = steps); inside a step of order k the evaluations sit at
+      // lambda_s + r_i h with r_i from the step's own time grid of k pieces.  History slots: 0 model_s, 1 model_s1, 2 model_s2.
+      std::vector<int> orders;
+      int K = 0;
+      if (p->method == 2) { K = N / order; orders.assign(K, order); }
+      else if (order == 3) {
+        K = N / 3 + 1;
+        if (N % 3 == 0) { orders.assign(std::max(K - 2, 0), 3); orders.push_back(2); orders.push_back(1); }
+        else if (N % 3 == 1) { orders.assign(K - 1, 3); orders.push_back(1); }
+        else { orders.assign(K - 1, 3); orders.push_back(2); }
+      } else if (order == 2) {
+        if (N % 2 == 0) { K = N / 2; orders.assign(K, 2); } else { K = N / 2 + 1; orders.assign(K - 1, 2); orders.push_back(1); }
+      } else { K = 1; orders.assign(N, 1); }
+      std::vector<double> outer;
+      if (p->method == 2 || p->skip == DV_SKIP_LOGSNR) { if (!time_grid(t_T, t_0, K, outer)) return dv_fail(DV_ERR_INVALID, "Unsupported skip_type %d", p->skip); }
+      else {                                         // the multistep grid at the cumulative orders (:533-534)
+        outer.push_back(ts[0]);
+        int c = 0;
+        for (int o : orders) { c += o; outer.push_back(ts[c]); }
+      }
+      if (outer.size() != orders.size() + 1)         // (order 1 with skip_type 'logSNR': the reference indexes past its K = 1 grid)
+        return dv_fail(DV_ERR_INVALID, "singlestep: %d steps of order %d need %d grid points, the '%s' grid has %d (reference: IndexError)",
+                       N, order, (int)orders.size() + 1, "logSNR", (int)outer.size());
+      p->n_slots = 3;
+      p->timesteps = outer;
+      for (size_t st = 0; st < orders.size(); ++st) {
+        const int k = orders[st];
+        const double s_ = outer[st], t = outer[st + 1];
+        std::vector<double> inner;
+        time_grid(s_, t, k, inner);
+        const double lam_s = ns.lambda(s_), lam_t = ns.lambda(t), h = lam_t - lam_s;
+        // (r from the float32 lambdas of the inner grid, as the reference computes them: :1224-1227)
+        const double hi = (double)((float)ns.lambda(inner[k]) - (float)ns.lambda(inner[0]));
+        const double r1 = k >= 2 ? (double)(((float)ns.lambda(inner[1]) - (float)ns.lambda(inner[0])) / (float)hi) : 0.0;
+        const double r2 = k >= 3 ? (double)(((float)ns.lambda(inner[2]) - (float)ns.lambda(inner[0])) / (float)hi) : 0.0;
+        const double la_s = ns.log_alpha(s_), sg_s = ns.sigma(s_);
+        // x at time u from (x, model_s): first-order piece shared by every stage; pp: coefficient of x, of model_s
+        auto first = [&](double u, double hu, double& cx, double& cm) {
+          if (noise) { cx = exp(ns.log_alpha(u) - la_s); cm = -ns.sigma(u) * expm1(hu); }
+          else { cx = ns.sigma(u) / sg_s; cm = -ns.alpha(u) * expm1(-hu); }
+        };
+        double cx, cm;
+        add_eval_m(s_, 0);
+        if (k == 1) { first(t, h, cx, cm); add_comb(0, cx, {{0, cm}}); continue; }
+        const double s1 = (double)(float)ns.inverse_lambda(lam_s + r1 * h);
+        first(s1, r1 * h, cx, cm);
+        add_comb(1, cx, {{0, cm}});
+        add_eval_m(s1, 1, 1);
+        const double sgn = noise ? 1.0 : -1.0;                 // h enters the phi functions as -h in the data form
+        const double amp_t = noise ? -ns.sigma(t) : ns.alpha(t);   // x_t = cx x + amp_t * (...): alpha_t for x0, -sigma_t for noise
+        const double phi_1 = expm1(sgn * h);
+        first(t, h, cx, cm);
+        if (k == 2) {
+          // dpmsolver: x_t = cx x + cm m0 - (0.5 / r1) (a phi_1) (m1 - m0)   [noise: - (0.5 / r1) (sigma phi_1) (m1 - m0)]
+          // taylor   : x_t = cx x + cm m0 + (1 / r1) a (phi_1 / h + 1) (m1 - m0)   [noise: - (1 / r1) sigma (phi_1 / h - 1) (m1 - m0)]
+          double d;
+          if (!taylor) d = noise ? -(0.5 / r1) * ns.sigma(t) * phi_1 : -(0.5 / r1) * ns.alpha(t) * phi_1;
+          else d = noise ? -(1.0 / r1) * ns.sigma(t) * (phi_1 / h - 1.0) : (1.0 / r1) * ns.alpha(t) * (phi_1 / h + 1.0);
+          add_comb(0, cx, {{0, cm - d}, {1, d}});
+          continue;
+        }
+        // ---- third order ----
+        const double s2 = (double)(float)ns.inverse_lambda(lam_s + r2 * h);
+        const double phi_22 = noise ? expm1(r2 * h) / (r2 * h) - 1.0 : expm1(-r2 * h) / (r2 * h) + 1.0;
+        const double phi_2 = noise ? phi_1 / h - 1.0 : phi_1 / h + 1.0;
+        const double phi_3 = phi_2 / h - 0.5;
+        {   // x_s2 = cx x + cm m0 (+|-) (r2 / r1) (a_s2 | sigma_s2) phi_22 (m1 - m0)
+          double c2x, c2m;
+          first(s2, r2 * h, c2x, c2m);
+          const double d = noise ? -(r2 / r1) * ns.sigma(s2) * phi_22 : (r2 / r1) * ns.alpha(s2) * phi_22;
+          add_comb(1, c2x, {{0, c2m - d}, {1, d}});
+        }
+        add_eval_m(s2, 2, 1);
+        if (!taylor) {                                         // x_t = cx x + cm m0 (+|-) (1 / r2) (a | sigma) phi_2 (m2 - m0)
+          const double d = noise ? -(1.0 / r2) * ns.sigma(t) * phi_2 : (1.0 / r2) * ns.alpha(t) * phi_2;
+          add_comb(0, cx, {{0, cm - d}, {2, d}});
+        } else {
+          // D1_0 = (m1 - m0) / r1, D1_1 = (m2 - m0) / r2, D1 = (r2 D1_0 - r1 D1_1) / (r2 - r1), D2 = 2 (D1_1 - D1_0) / (r2 - r1)
+          // x_t = cx x + cm m0 + A2 D1 - A3 D2 with (A2, A3) = (a phi_2, a phi_3) [noise: (-sigma phi_2, +sigma phi_3)]
+          const double A2 = noise ? -ns.sigma(t) * phi_2 : ns.alpha(t) * phi_2;
+          const double A3 = noise ? ns.sigma(t) * phi_3 : ns.alpha(t) * phi_3;
+          const double q = 1.0 / (r2 - r1);
+          const double w1 = A2 * q * r2 / r1 + A3 * 2.0 * q / r1;          // coefficient of (m1 - m0)
+          const double w2 = -A2 * q * r1 / r2 - A3 * 2.0 * q / r2;         // coefficient of (m2 - m0)
+          add_comb(0, cx, {{0, cm - w1 - w2}, {1, w1}, {2, w2}});
+        }
+        (void)amp_t;
+      }
+      if (p->denoise_to_zero) {
+        add_eval(0, t_0, 0);
+        add_comb(0, 0.0, {{0, 1.0}});
+      }
+      return DV_OK;
+    }
     add_eval_m(ts[0], 0);
     push_hist(0, ts[0]);
     for (int step = 1; step < order; ++step) {
@@ -468,7 +568,16 @@ extern "C" int dv_sampler_plan_sched(int32_t solver, int32_t schedule, const flo
                                      double beta_1, int32_t steps, int32_t order, int32_t skip_type,
                                      int32_t lower_order_final, double t_start, double t_end, int32_t denoise_to_zero,
                                      dv_plan** out) {
+  return dv_sampler_plan_method(solver, schedule, betas, n_betas, beta_0, beta_1, DV_METHOD_MULTISTEP, steps, order, skip_type,
+                                lower_order_final, t_start, t_end, denoise_to_zero, out);
+}
+
+extern "C" int dv_sampler_plan_method(int32_t solver, int32_t schedule, const float* betas, int32_t n_betas, double beta_0,
+                                      double beta_1, int32_t method, int32_t steps, int32_t order, int32_t skip_type,
+                                      int32_t lower_order_final, double t_start, double t_end, int32_t denoise_to_zero,
+                                      dv_plan** out) {
   if (!out) return dv_fail(DV_ERR_INVALID, "dv_sampler_plan: bad argument");
+  if (method < DV_METHOD_MULTISTEP || method > DV_METHOD_SINGLESTEP_FIXED) return dv_fail(DV_ERR_INVALID, "unknown method %d", method);
   const bool dpm_family = solver == DV_SOLVER_DPMPP || solver >= DV_SOLVER_DPM;   // DPM-Solver(++) (the others: UniPC variants)
   if (schedule < DV_SCHEDULE_DISCRETE || schedule > DV_SCHEDULE_COSINE) return dv_fail(DV_ERR_INVALID, "unknown noise schedule %d", schedule);
   if (schedule == DV_SCHEDULE_DISCRETE && (!betas || n_betas < 2)) return dv_fail(DV_ERR_INVALID, "dv_sampler_plan: bad argument");
@@ -479,7 +588,9 @@ extern "C" int dv_sampler_plan_sched(int32_t solver, int32_t schedule, const flo
   if (dpm_family && (order < 1 || order > 3)) return dv_fail(DV_ERR_INVALID, "Solver order must be 1 or 2 or 3, got %d", order);
   if (order < 1 || order > MAXO) return dv_fail(DV_ERR_INVALID, "UniPC order must be 1..%d, got %d", MAXO, order);
   if (steps < order) return dv_fail(DV_ERR_INVALID, "steps (%d) must be >= order (%d)", steps, order);
+  if (method != DV_METHOD_MULTISTEP && !dpm_family) return dv_fail(DV_ERR_INVALID, "the singlestep methods exist for DPM-Solver(++) only");
   dv_plan* p = new dv_plan();
+  p->method = method;
   p->solver = solver; p->steps = steps; p->order = order; p->skip = skip_type; p->lof = lower_order_final;
   p->t_start = t_start; p->t_end = t_end; p->denoise_to_zero = denoise_to_zero ? 1 : 0;
   if (schedule == DV_SCHEDULE_DISCRETE) p->ns.init(betas, n_betas, dpm_family);
@@ -512,6 +623,15 @@ extern "C" int dv_plan_info(const dv_plan* p, int32_t* nfe, double* t_input, dou
   if (nfe) *nfe = (int32_t)p->t_input.size();
   if (t_input) memcpy(t_input, p->t_input.data(), p->t_input.size() * sizeof(double));
   if (timesteps) memcpy(timesteps, p->timesteps.data(), p->timesteps.size() * sizeof(double));
+  return DV_OK;
+}
+
+// ... and: the number of grid points (steps + 1 for the multistep loops; outer steps + 1 for the singlestep ones) and the
+// continuous time of every model evaluation (eval_times[nfe])
+extern "C" int dv_plan_times(const dv_plan* p, int32_t* n_timesteps, double* eval_times) {
+  if (!p) return dv_fail(DV_ERR_INVALID, "dv_plan_times: null plan");
+  if (n_timesteps) *n_timesteps = (int32_t)p->timesteps.size();
+  if (eval_times) memcpy(eval_times, p->eval_time.data(), p->eval_time.size() * sizeof(double));
   return DV_OK;
 }
 

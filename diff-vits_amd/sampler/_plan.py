@@ -177,8 +177,9 @@ class Plan:
     """Compiled multistep loop: events + fp64-derived coefficient rows."""
 
     def __init__(self, solver, betas, steps, order, skip_type, lower_order_final, t_start=None, t_end=None,
-                 denoise_to_zero=False, schedule=("discrete", 0.0, 0.0)):
+                 denoise_to_zero=False, schedule=("discrete", 0.0, 0.0), method="multistep"):
         L = _lib()
+        self.method = method
         for name, v in (("t_start", t_start), ("t_end", t_end)):
             # reference dpm_solver.py:1159 / uni_pc.py:598
             assert v is None or v > 0, ("Time range needs to be greater than 0. For discrete-time DPMs, it needs to be in "
@@ -187,22 +188,26 @@ class Plan:
             raise ValueError("Unsupported skip_type {}, need to be 'logSNR' or 'time_uniform' or 'time_quadratic'"
                              .format(skip_type))
         betas = np.ascontiguousarray(betas, dtype=np.float32)
-        self._args = (solver, betas, steps, order, skip_type, lower_order_final, t_start, t_end, denoise_to_zero, schedule)
+        self._args = (solver, betas, steps, order, skip_type, lower_order_final, t_start, t_end, denoise_to_zero, schedule, method)
         self._per_shape = {}          # captured graphs live in the native plan, one per plan: a copy per input shape
         self._h = C.c_void_p()
-        L.check(L.lib().dv_sampler_plan_sched(solver, L.SCHEDULE[schedule[0]], betas.ctypes.data_as(C.c_void_p), len(betas),
-                                              float(schedule[1]), float(schedule[2]), steps, order,
-                                              L.SKIP[skip_type], int(bool(lower_order_final)),
-                                              -1.0 if t_start is None else float(t_start), -1.0 if t_end is None else float(t_end),
-                                              int(bool(denoise_to_zero)), C.byref(self._h)),
-                "dv_sampler_plan_sched")
+        L.check(L.lib().dv_sampler_plan_method(solver, L.SCHEDULE[schedule[0]], betas.ctypes.data_as(C.c_void_p), len(betas),
+                                               float(schedule[1]), float(schedule[2]), L.METHOD[method], steps, order,
+                                               L.SKIP[skip_type], int(bool(lower_order_final)),
+                                               -1.0 if t_start is None else float(t_start), -1.0 if t_end is None else float(t_end),
+                                               int(bool(denoise_to_zero)), C.byref(self._h)),
+                "dv_sampler_plan_method")
         nfe = C.c_int32()
         L.check(L.lib().dv_plan_info(self._h, C.byref(nfe), None, None), "dv_plan_info")
         self.nfe = nfe.value
+        nts = C.c_int32()
+        L.check(L.lib().dv_plan_times(self._h, C.byref(nts), None), "dv_plan_times")
         self.t_input = np.zeros(self.nfe, dtype=np.float64)
-        self.timesteps = np.zeros(steps + 1, dtype=np.float64)
+        self.timesteps = np.zeros(nts.value, dtype=np.float64)     # steps + 1 points (singlestep methods: outer steps + 1)
+        self.eval_times = np.zeros(self.nfe, dtype=np.float64)     # continuous time of every evaluation
         L.check(L.lib().dv_plan_info(self._h, None, self.t_input.ctypes.data_as(C.c_void_p),
                                      self.timesteps.ctypes.data_as(C.c_void_p)), "dv_plan_info")
+        L.check(L.lib().dv_plan_times(self._h, None, self.eval_times.ctypes.data_as(C.c_void_p)), "dv_plan_times")
         n = C.c_int32()
         L.check(L.lib().dv_plan_coefs(self._h, C.byref(n), None), "dv_plan_coefs")
         self.coefs = np.zeros((n.value, 8), dtype=np.float32)
@@ -250,7 +255,13 @@ class Plan:
         step = 0
         t_of = lambda k: torch.tensor(float(self.timesteps[min(k, len(self.timesteps) - 1)]), dtype=torch.float32, device=x.device)
 
+        # the singlestep methods neither record nor correct the start point, and number their steps from 0
+        # (dpm_solver.py:1221-1232 against :1179-1183)
+        single = self.method != "multistep"
+
         def finish_start(x):
+            if single:
+                return x
             if xt_hook is not None:
                 x = xt_hook(x, t_of(0), 0)
             if intermediates is not None:
@@ -277,8 +288,8 @@ class Plan:
                 if dst == 0:
                     x = out
                     step += 1
-                    if xt_hook is not None:
-                        x = xt_hook(x, t_of(step), step)
+                    if xt_hook is not None:     # (singlestep: the steps - and the final denoise step behind them - count from 0)
+                        x = xt_hook(x, t_of(step), step - 1 if single else step)
                     if intermediates is not None:
                         intermediates.append(x)
                 elif dst == 1:
@@ -397,6 +408,5 @@ def _eval_times(plan):
     """Continuous time of each model evaluation (inverse of t_input = (t - 1/N) * N is not
     needed: evaluations happen at the grid points in order; UniPC evaluates at the step's
     end time, DPM-Solver++ at the step's start)."""
-    # EVAL k of both loops is at timesteps[k] (k-th grid point): DPM++ evaluates at ts[0..N-1],
-    # UniPC at ts[0] and then at ts[1..N-1] (the corrector's evaluation point).
-    return plan.timesteps[: plan.nfe]
+    # (multistep: EVAL k is at timesteps[k]; the singlestep methods evaluate inside their outer steps)
+    return plan.eval_times

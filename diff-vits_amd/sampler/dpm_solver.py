@@ -5,7 +5,8 @@
 libdvits_hip.so `dv_sampler_plan`) and then either replays it natively (hipGraph: UNet schedule
 + fused update kernels) when the wrapped model is a `NativeUNetModel`, or runs it with torch ops
 around an arbitrary Python callable.  Scope of this build: algorithm_type='dpmsolver++' and 'dpmsolver',
-method='multistep', orders 1-3 (reference :1171-1213, :547-592, :796-904), schedules 'discrete' and 'linear'.
+methods 'multistep' (reference :1171-1213, :547-592, :796-904), 'singlestep' and 'singlestep_fixed' (:482-539, :594-794,
+:1214-1232), orders 1-3, solver types 'dpmsolver' and 'taylor', schedules 'discrete' and 'linear'.
 """
 import torch
 
@@ -47,15 +48,15 @@ class DPM_Solver:
         return torch.as_tensor(plan.timesteps, dtype=torch.float32, device=device)
 
     def _plan(self, steps, order, skip_type, lower_order_final, t_start=None, t_end=None, denoise_to_zero=False,
-              solver_type="dpmsolver"):
-        key = (steps, order, skip_type, bool(lower_order_final), t_start, t_end, bool(denoise_to_zero), solver_type)
+              solver_type="dpmsolver", method="multistep"):
+        key = (steps, order, skip_type, bool(lower_order_final), t_start, t_end, bool(denoise_to_zero), solver_type, method)
         if key not in self._plans:
             solver = _SOLVER_DPMPP if self.algorithm_type == "dpmsolver++" else _SOLVER_DPM
             if solver_type == "taylor":
                 solver = _TAYLOR[solver]
             self._plans[key] = Plan(solver, self.noise_schedule._betas, steps, order, skip_type,
                                     lower_order_final, t_start, t_end, denoise_to_zero,
-                                    schedule=self.noise_schedule._plan_schedule())
+                                    schedule=self.noise_schedule._plan_schedule(), method=method)
         return self._plans[key]
 
     def sample(self, x, steps=20, t_start=None, t_end=None, order=2, skip_type="time_uniform", method="multistep",
@@ -63,14 +64,15 @@ class DPM_Solver:
                return_intermediate=False):
         """x at t_start (default T) -> x at t_end (default 1/N), reference dpm_solver.py:1047-1245.  NFE == steps
         (+1 with denoise_to_zero).  return_intermediate=True returns (x, [start point, x after every step, ...])."""
-        if method != "multistep":
-            raise ValueError("Got wrong method {} (this build implements method='multistep')".format(method))
+        if method not in ("multistep", "singlestep", "singlestep_fixed"):
+            # ('adaptive' chooses its step sizes from the data: not a loop that can be compiled ahead; reference :906-1010)
+            raise ValueError("Got wrong method {} (this build implements 'multistep', 'singlestep' and 'singlestep_fixed')".format(method))
         if order not in (1, 2, 3):
             raise ValueError("Solver order must be 1 or 2 or 3, got {}".format(order))
         if solver_type not in ("dpmsolver", "taylor"):
             raise ValueError("'solver_type' must be either 'dpmsolver' or 'taylor', got {}".format(solver_type))
         assert steps >= order
-        plan = self._plan(steps, order, skip_type, lower_order_final, t_start, t_end, denoise_to_zero, solver_type)
+        plan = self._plan(steps, order, skip_type, lower_order_final, t_start, t_end, denoise_to_zero, solver_type, method)
         x0_hook = None
         if self.correcting_x0_fn is not None:
             # data_prediction_fn applies it (:433-445): every evaluation of 'dpmsolver++'; with 'dpmsolver' only the final
@@ -81,7 +83,7 @@ class DPM_Solver:
             def x0_hook(x0, eidx):
                 if only_last and not (denoise_to_zero and eidx == last):
                     return x0
-                t = torch.tensor(float(plan.timesteps[-1] if eidx >= len(times) else times[eidx]), dtype=torch.float32, device=x0.device)
+                t = torch.tensor(float(times[eidx]), dtype=torch.float32, device=x0.device)
                 return fn0(x0, t)
         hooks = dict(x0_hook=x0_hook, xt_hook=self.correcting_xt_fn)
         if not return_intermediate:

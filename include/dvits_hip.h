@@ -206,12 +206,22 @@ int dv_sampler_plan_ex(int32_t solver, const float* betas, int32_t n_betas, int3
 int dv_sampler_plan_sched(int32_t solver, int32_t schedule, const float* betas, int32_t n_betas, double beta_0, double beta_1,
                           int32_t steps, int32_t order, int32_t skip_type, int32_t lower_order_final, double t_start,
                           double t_end, int32_t denoise_to_zero, dv_plan** out);
+/* ... and for the singlestep methods of DPM_Solver.sample ("DPM-Solver-fast", dpm_solver.py:482-539, 594-794, 1214-1232):
+ * `steps` model evaluations shared out over outer steps of order <= `order`; DV_METHOD_SINGLESTEP_FIXED: steps / order outer
+ * steps of exactly `order`.  DPM-Solver(++) solvers only. */
+typedef enum { DV_METHOD_MULTISTEP = 0, DV_METHOD_SINGLESTEP = 1, DV_METHOD_SINGLESTEP_FIXED = 2 } dv_method;
+int dv_sampler_plan_method(int32_t solver, int32_t schedule, const float* betas, int32_t n_betas, double beta_0, double beta_1,
+                           int32_t method, int32_t steps, int32_t order, int32_t skip_type, int32_t lower_order_final,
+                           double t_start, double t_end, int32_t denoise_to_zero, dv_plan** out);
 void dv_plan_destroy(dv_plan* p);
 
 /* Introspection for tests: number of model evaluations, and the plan's tables.
  * t_input[nfe] = timestep fed to the network at each evaluation;
  * timesteps[steps+1] = continuous-time grid. */
 int dv_plan_info(const dv_plan* p, int32_t* nfe, double* t_input, double* timesteps);
+/* n_timesteps = entries of `timesteps` (steps + 1 for the multistep loops, outer steps + 1 for the singlestep methods);
+ * eval_times[nfe] = continuous time of each evaluation. */
+int dv_plan_times(const dv_plan* p, int32_t* n_timesteps, double* eval_times);
 
 /* The compiled loop, for host-side execution with an arbitrary Python callable and for tests:
  * coefficient rows (8 floats each: c0 for x, c1..c4 for the history terms) and events

@@ -233,6 +233,73 @@ def _dpm_noise_update(ns, x, m_list, t_list, t, order, taylor=False):
     raise ValueError("Solver order must be 1 or 2 or 3, got %r" % (order,))
 
 
+def _singlestep_update(ns, fn, x, s, t, order, r1, r2, noise, taylor):
+    """singlestep_dpm_solver_update: first (dpm_solver.py:547-592), second (:594-676), third (:678-794) order from time s to
+    time t; fn = model_fn (data prediction for 'dpmsolver++', noise prediction for 'dpmsolver')."""
+    lam_s, lam_t = ns.lam(s), ns.lam(t)
+    h = lam_t - lam_s
+    la = ns.log_alpha
+    sg = ns.sigma
+
+    def first(u, hu, m):      # x at time u from (x, model_s)
+        if noise:
+            return torch.exp(la(u) - la(s)) * x - (sg(u) * torch.expm1(hu)) * m
+        return (sg(u) / sg(s)) * x - (torch.exp(la(u)) * torch.expm1(-hu)) * m
+    m_s = fn(x, s)
+    if order == 1:
+        return first(t, h, m_s)
+    s1 = ns.inverse_lambda(lam_s + r1 * h)
+    m_s1 = fn(first(s1, r1 * h, m_s), s1)
+    alpha_t, sig_t = torch.exp(la(t)), sg(t)
+    phi_1 = torch.expm1(h) if noise else torch.expm1(-h)
+    if order == 2:
+        if noise:
+            corr = -(0.5 / r1) * (sig_t * phi_1) * (m_s1 - m_s) if not taylor else -(1.0 / r1) * (sig_t * (phi_1 / h - 1.0)) * (m_s1 - m_s)
+        else:
+            corr = -(0.5 / r1) * (alpha_t * phi_1) * (m_s1 - m_s) if not taylor else (1.0 / r1) * (alpha_t * (phi_1 / h + 1.0)) * (m_s1 - m_s)
+        return first(t, h, m_s) + corr
+    s2 = ns.inverse_lambda(lam_s + r2 * h)
+    if noise:
+        phi_22 = torch.expm1(r2 * h) / (r2 * h) - 1.0
+        phi_2 = phi_1 / h - 1.0
+        x_s2 = first(s2, r2 * h, m_s) - r2 / r1 * (sg(s2) * phi_22) * (m_s1 - m_s)
+    else:
+        phi_22 = torch.expm1(-r2 * h) / (r2 * h) + 1.0
+        phi_2 = phi_1 / h + 1.0
+        x_s2 = first(s2, r2 * h, m_s) + r2 / r1 * (torch.exp(la(s2)) * phi_22) * (m_s1 - m_s)
+    phi_3 = phi_2 / h - 0.5
+    m_s2 = fn(x_s2, s2)
+    if not taylor:
+        if noise:
+            return first(t, h, m_s) - (1.0 / r2) * (sig_t * phi_2) * (m_s2 - m_s)
+        return first(t, h, m_s) + (1.0 / r2) * (alpha_t * phi_2) * (m_s2 - m_s)
+    D1_0 = (1.0 / r1) * (m_s1 - m_s)
+    D1_1 = (1.0 / r2) * (m_s2 - m_s)
+    D1 = (r2 * D1_0 - r1 * D1_1) / (r2 - r1)
+    D2 = 2.0 * (D1_1 - D1_0) / (r2 - r1)
+    if noise:
+        return first(t, h, m_s) - (sig_t * phi_2) * D1 - (sig_t * phi_3) * D2
+    return first(t, h, m_s) + (alpha_t * phi_2) * D1 - (alpha_t * phi_3) * D2
+
+
+def singlestep_orders(ns, steps, order, skip_type, t_T, t_0, fixed=False):
+    """get_orders_and_timesteps_for_singlestep_solver (dpm_solver.py:482-539) / the 'singlestep_fixed' grid (:1217-1220)."""
+    if fixed:
+        K = steps // order
+        return time_steps(ns, skip_type, t_T, t_0, K), [order] * K
+    if order == 3:
+        K = steps // 3 + 1
+        orders = [3] * (K - 2) + [2, 1] if steps % 3 == 0 else ([3] * (K - 1) + [1] if steps % 3 == 1 else [3] * (K - 1) + [2])
+    elif order == 2:
+        K = steps // 2 if steps % 2 == 0 else steps // 2 + 1
+        orders = [2] * K if steps % 2 == 0 else [2] * (K - 1) + [1]
+    else:
+        K, orders = 1, [1] * steps
+    if skip_type == "logSNR":
+        return time_steps(ns, skip_type, t_T, t_0, K), orders
+    return time_steps(ns, skip_type, t_T, t_0, steps)[torch.cumsum(torch.tensor([0] + orders), 0)], orders
+
+
 def wrap_x_start_noise(model, ns):
     """model_wrapper(model, ns, model_type='x_start') alone: the NOISE prediction the algorithm_type='dpmsolver' updates
     consume - noise = (x - alpha_t * x0) / sigma_t (dpm_solver.py:290-292)."""
@@ -248,7 +315,7 @@ def wrap_x_start_noise(model, ns):
 def dpm_solver_pp_sample(model, betas, x, steps=20, order=2, skip_type="time_uniform",
                          lower_order_final=True, return_intermediate=False, t_start=None, t_end=None,
                          denoise_to_zero=False, schedule=None, algorithm_type="dpmsolver++", x0_fn=None, xt_fn=None,
-                         guidance=None, solver_type="dpmsolver"):
+                         guidance=None, solver_type="dpmsolver", method="multistep"):
     """DPM_Solver(model_fn, ns, algorithm_type).sample(x, steps, order, skip_type,
     method='multistep'), dpm_solver.py:1047-1245 (multistep branch :1171-1213).
     `model(x, t_input)` is the raw x0-prediction network.  algorithm_type='dpmsolver': the same loop on the noise
@@ -270,6 +337,21 @@ def dpm_solver_pp_sample(model, betas, x, steps=20, order=2, skip_type="time_uni
     t_0 = 1.0 / ns.total_N if t_end is None else t_end
     t_T = ns.T if t_start is None else t_start
     assert steps >= order
+    if method != "multistep":      # 'singlestep' / 'singlestep_fixed', dpm_solver.py:1214-1232 (no start point in the intermediates)
+        outer, orders = singlestep_orders(ns, steps, order, skip_type, t_T, t_0, method == "singlestep_fixed")
+        inter = []
+        for step, k in enumerate(orders):
+            s_, t = outer[step], outer[step + 1]
+            lam_in = ns.lam(time_steps(ns, skip_type, s_.item(), t.item(), k))
+            h_in = lam_in[-1] - lam_in[0]
+            r1 = None if k <= 1 else (lam_in[1] - lam_in[0]) / h_in
+            r2 = None if k <= 2 else (lam_in[2] - lam_in[0]) / h_in
+            x = fix(_singlestep_update(ns, fn, x, s_, t, k, r1, r2, algorithm_type != "dpmsolver++", solver_type == "taylor"), t, step)
+            inter.append(x)
+        if denoise_to_zero:
+            x = fix(data_fn(x, torch.ones((1,)) * t_0), torch.ones((1,)) * t_0, len(orders))
+            inter.append(x)
+        return (x, inter) if return_intermediate else x
     ts = time_steps(ns, skip_type, t_T, t_0, steps)
     inter = []
     t = ts[0]

@@ -1141,6 +1141,14 @@ def test_native_sampler_options_graph_equals_stepwise():
         c = dpm_solver.DPM_Solver(fn, ns, algorithm_type="dpmsolver++",
                                   correcting_xt_fn=lambda xx, tt, step: (seen.append(step), xx)[1]).sample(x.clone(), **opts)
     assert seen == list(range(6 + 2)) and rel_l2(c.cpu().numpy(), a.cpu().numpy()) < 3e-5
+    # method='singlestep' (dpm_solver.py:1214-1232): evaluations on x_pred inside the outer steps, both algorithm types
+    for algo in ("dpmsolver++", "dpmsolver"):
+        sopts = dict(steps=7, order=3, skip_type="logSNR", method="singlestep", denoise_to_zero=True)
+        with torch.no_grad():
+            a = dpm_solver.DPM_Solver(fn, ns, algorithm_type=algo).sample(x.clone(), **sopts)
+            b, inter = dpm_solver.DPM_Solver(fn, ns, algorithm_type=algo).sample(x.clone(), return_intermediate=True, **sopts)
+        assert len(inter) == 3 + 1 and torch.isfinite(a).all()      # orders [3, 3, 1] + the final denoise step
+        assert rel_l2(a.cpu().numpy(), b.cpu().numpy()) < 3e-5
 
 
 def test_merged_ff_proj_out_matches_two_step(gold):

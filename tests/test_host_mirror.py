@@ -156,7 +156,11 @@ def test_solver_error_behaviour():
     with pytest.raises(AssertionError):
         dpm_solver.DPM_Solver(fn, ns).sample(x, steps=1, order=2)
     with pytest.raises(ValueError):
-        dpm_solver.DPM_Solver(fn, ns).sample(x, steps=10, method="singlestep")
+        dpm_solver.DPM_Solver(fn, ns).sample(x, steps=10, method="adaptive")      # (data-dependent step sizes: not compiled)
+    with pytest.raises(ValueError):
+        dpm_solver.DPM_Solver(fn, ns).sample(x, steps=10, solver_type="bogus")
+    with pytest.raises(RuntimeError):                                                # (the reference: IndexError past its K = 1 grid)
+        dpm_solver.DPM_Solver(fn, ns).sample(x, steps=10, order=1, method="singlestep", skip_type="logSNR")
     with pytest.raises(ValueError):
         dpm_solver.NoiseScheduleVP("cosine")       # (dpm_solver.py:94: 'discrete' or 'linear'; uni_pc.py:59 adds 'cosine')
     with pytest.raises(ValueError):
@@ -207,6 +211,15 @@ OPTION_CASES = {
     # solver_type='taylor' (the second-order update's Taylor form, dpm_solver.py:825-829, 848-851)
     "dpm_taylor": ("dpm", dict(steps=10, order=2, skip_type="time_uniform", solver_type="taylor")),
     "dpmn_taylor": ("dpm", dict(steps=12, order=2, skip_type="logSNR", solver_type="taylor", algorithm_type="dpmsolver")),
+    # method='singlestep' ("DPM-Solver-fast": the evaluations shared out over outer steps of order <= order) and
+    # 'singlestep_fixed' (dpm_solver.py:482-539, 594-794, 1214-1232)
+    "dpm_ss_o3": ("dpm", dict(steps=12, order=3, skip_type="time_uniform", method="singlestep")),
+    "dpm_ss_o2_logsnr_dtz": ("dpm", dict(steps=9, order=2, skip_type="logSNR", denoise_to_zero=True, return_intermediate=True,
+                                         method="singlestep", hooks=(None, True))),
+    "dpmn_ss_o3_quad": ("dpm", dict(steps=11, order=3, skip_type="time_quadratic", method="singlestep", algorithm_type="dpmsolver")),
+    "dpm_ssfixed_taylor": ("dpm", dict(steps=12, order=3, skip_type="time_uniform", method="singlestep_fixed", solver_type="taylor")),
+    "dpmn_ss_taylor_o2": ("dpm", dict(steps=10, order=2, skip_type="time_uniform", method="singlestep", solver_type="taylor",
+                                      algorithm_type="dpmsolver")),
 }
 
 
@@ -254,6 +267,7 @@ def test_sampler_options_match_reference(gold, key):
     sched = kw.pop("schedule", None)
     algo = kw.pop("algorithm_type", "dpmsolver++")
     hooks = kw.pop("hooks", None)
+    method = kw.pop("method", "multistep")
     B = 2 if solver == "dpm" else 1
     guid = _guidance_kwargs(kw.pop("guidance", None), key, B)
     net = sampler_ref.standin_cond_model if guid else sampler_ref.standin_model
@@ -266,9 +280,11 @@ def test_sampler_options_match_reference(gold, key):
     # sigma = sqrt(1 - exp(2 log alpha)) loses ~4 digits near t_end (log alpha ~ -5e-5): the agreement is the reference's
     # own rounding there (the float32 oracle below reproduces the reference exactly)
     tol = 2e-5 if sched is None else 5e-4
+    if algo == "dpmsolver":     # the noise form: eps = (x - alpha x0) / sigma in float32 amplifies rounding by 1 / sigma at the low-noise end
+        tol = max(tol, 1e-4)
     fn = mod.model_wrapper(lambda xx, t, *c, **k: net(xx, t, *c), ns, model_type="x_start", **(guid or {}))
     if solver == "dpm":
-        r = mod.DPM_Solver(fn, ns, algorithm_type=algo, **_hook_kwargs(hooks, False)).sample(x.clone(), method="multistep", **kw)
+        r = mod.DPM_Solver(fn, ns, algorithm_type=algo, **_hook_kwargs(hooks, False)).sample(x.clone(), method=method, **kw)
     else:
         r = mod.UniPC(fn, ns, variant="bh2", **_hook_kwargs(hooks, True)).sample(x.clone(), method="multistep", **kw)
     if kw.get("return_intermediate"):
@@ -285,7 +301,7 @@ def test_sampler_options_match_reference(gold, key):
     args = (okw.pop("steps"), okw.pop("order"), okw.pop("skip_type"))
     okw.pop("return_intermediate", None)
     if solver == "dpm":
-        o = sampler_ref.dpm_solver_pp_sample(net, betas, x.clone(), *args, schedule=sched, algorithm_type=algo, guidance=guid,
+        o = sampler_ref.dpm_solver_pp_sample(net, betas, x.clone(), *args, schedule=sched, algorithm_type=algo, guidance=guid, method=method,
                                              **_oracle_hooks(hooks), **okw)
     else:
         o = sampler_ref.unipc_sample(sampler_ref.standin_model, betas, x.clone(), *args, "bh2", schedule=sched, **_oracle_hooks(hooks), **okw)

@@ -57,6 +57,15 @@ CASES = {
     # solver_type='taylor' (the second-order update's Taylor form, dpm_solver.py:825-829, 848-851)
     "dpm_taylor": ("dpm", dict(steps=10, order=2, skip_type="time_uniform", solver_type="taylor")),
     "dpmn_taylor": ("dpm", dict(steps=12, order=2, skip_type="logSNR", solver_type="taylor", algorithm_type="dpmsolver")),
+    # method='singlestep' ("DPM-Solver-fast": the evaluations shared out over outer steps of order <= order) and
+    # 'singlestep_fixed' (dpm_solver.py:482-539, 594-794, 1214-1232)
+    "dpm_ss_o3": ("dpm", dict(steps=12, order=3, skip_type="time_uniform", method="singlestep")),
+    "dpm_ss_o2_logsnr_dtz": ("dpm", dict(steps=9, order=2, skip_type="logSNR", denoise_to_zero=True, return_intermediate=True,
+                                         method="singlestep", hooks=(None, True))),
+    "dpmn_ss_o3_quad": ("dpm", dict(steps=11, order=3, skip_type="time_quadratic", method="singlestep", algorithm_type="dpmsolver")),
+    "dpm_ssfixed_taylor": ("dpm", dict(steps=12, order=3, skip_type="time_uniform", method="singlestep_fixed", solver_type="taylor")),
+    "dpmn_ss_taylor_o2": ("dpm", dict(steps=10, order=2, skip_type="time_uniform", method="singlestep", solver_type="taylor",
+                                      algorithm_type="dpmsolver")),
 }
 
 
@@ -126,15 +135,16 @@ def main():
         sched = kw.pop("schedule", None)
         algo = kw.pop("algorithm_type", "dpmsolver++")
         hooks = kw.pop("hooks", None)
+        method = kw.pop("method", "multistep")
         guid = guidance_kwargs(kw.pop("guidance", None), key, B)
         net = sampler_ref.standin_cond_model if guid else sampler_ref.standin_model
         if solver == "dpm":
             ns = make_ns(ref_dpm, sched, betas)
             fn = ref_dpm.model_wrapper(lambda xx, t, *c, **k: net(xx, t, *c), ns, model_type="x_start", **(guid or {}))
-            r = ref_dpm.DPM_Solver(fn, ns, algorithm_type=algo, **hook_kwargs(hooks, False)).sample(x.clone(), method="multistep", **kw)
+            r = ref_dpm.DPM_Solver(fn, ns, algorithm_type=algo, **hook_kwargs(hooks, False)).sample(x.clone(), method=method, **kw)
             okw = {k: v for k, v in kw.items()}
             o = sampler_ref.dpm_solver_pp_sample(net, betas, x.clone(), okw.pop("steps"), okw.pop("order"),
-                                                 okw.pop("skip_type"), schedule=sched, algorithm_type=algo, guidance=guid, **oracle_hooks(hooks), **okw)
+                                                 okw.pop("skip_type"), schedule=sched, algorithm_type=algo, guidance=guid, method=method, **oracle_hooks(hooks), **okw)
         else:
             ns = make_ns(ref_unipc, sched, betas)
             fn = ref_unipc.model_wrapper(lambda xx, t, **k: sampler_ref.standin_model(xx, t), ns, model_type="x_start")
@@ -147,7 +157,9 @@ def main():
             xo, ointer = o
             inter = torch.stack([t for t in inter]).numpy()     # reference: start point, every step, (denoised)
             out[key + "_inter"] = inter
-            worst = max(rel(a.numpy(), b) for a, b in zip(ointer, inter[1:]))   # the oracle list omits the start point
+            ref_steps = inter if method != "multistep" else inter[1:]   # (multistep: the oracle list omits the start point)
+            assert len(ointer) == len(ref_steps)
+            worst = max(rel(a.numpy(), b) for a, b in zip(ointer, ref_steps))
         else:
             xr, xo, worst = r, o, 0.0
         out[key + "_x"] = xr.numpy()
