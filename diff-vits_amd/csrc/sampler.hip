@@ -242,7 +242,8 @@ static int build_plan(dv_plan* p) {
   std::vector<double> htime;        // their times
   const bool taylor = p->solver == DV_SOLVER_DPMPP_TAYLOR || p->solver == DV_SOLVER_DPM_TAYLOR;   // solver_type='taylor' (second order only)
   const bool noise = p->solver == DV_SOLVER_DPM || p->solver == DV_SOLVER_DPM_TAYLOR;   // multistep updates on the noise prediction (algorithm_type='dpmsolver')
-  const bool unipc = p->solver >= DV_SOLVER_UNIPC_BH1 && p->solver <= DV_SOLVER_UNIPC_VARY;
+  const bool unoise = p->solver >= DV_SOLVER_UNIPC_BH1_NOISE && p->solver <= DV_SOLVER_UNIPC_VARY_NOISE;   // UniPC on the noise prediction
+  const bool unipc = (p->solver >= DV_SOLVER_UNIPC_BH1 && p->solver <= DV_SOLVER_UNIPC_VARY) || unoise;
   p->n_slots = unipc ? order + 1 : order;
   auto free_slot = [&]() {
     for (int s = 0; s < p->n_slots; ++s) {
@@ -439,12 +440,27 @@ static int build_plan(dv_plan* p) {
     // ---------------- UniPC multistep, x0-prediction: B(h) variants (uni_pc.py:471-588) and 'vary_coeff'
     // (multistep_uni_pc_vary_update, uni_pc.py:368-469); any order <= MAXO (the reference solves the order x order
     // systems with torch.linalg.solve / inv, :545-560, :410-420) ----------------
-    const bool bh1 = p->solver == DV_SOLVER_UNIPC_BH1, vary = p->solver == DV_SOLVER_UNIPC_VARY;
+    const bool bh1 = p->solver == DV_SOLVER_UNIPC_BH1 || p->solver == DV_SOLVER_UNIPC_BH1_NOISE;
+    const bool vary = p->solver == DV_SOLVER_UNIPC_VARY || p->solver == DV_SOLVER_UNIPC_VARY_NOISE;
+    // (noise form: the network predicts x0; its output becomes eps = (x_in - alpha x0) / sigma in place - see DV_SOLVER_DPM)
+    auto add_eval_u = [&](int src, double t, int slot) {
+      add_eval(src, t, slot);
+      if (!unoise) return;
+      Event e{}; e.type = 1; e.src = src; e.dst = 2 + slot; e.coef = (int)p->coefs.size();
+      std::array<float, 8> row{};
+      row[0] = (float)(1.0 / ns.sigma(t)); row[1] = (float)(-ns.alpha(t) / ns.sigma(t));
+      e.slots[0] = slot; e.slots[1] = e.slots[2] = e.slots[3] = -1;
+      p->coefs.push_back(row);
+      p->ev.push_back(e);
+    };
     auto do_step = [&](double t, int ord, bool corr) -> int {
       const double t0 = htime[0];
       const double lam0 = ns.lambda(t0), lam_t = ns.lambda(t);
-      const double h = lam_t - lam0, hh = -h;
-      const double a = ns.alpha(t), c0 = ns.sigma(t) / ns.sigma(t0);
+      // data form: hh = -h, amplitude alpha_t, x coefficient sigma_t / sigma_0; noise form (uni_pc.py:448-468, 569-587): hh = h,
+      // amplitude sigma_t, x coefficient exp(log alpha_t - log alpha_0) - the same algebra otherwise
+      const double h = lam_t - lam0, hh = unoise ? h : -h;
+      const double a = unoise ? ns.sigma(t) : ns.alpha(t);
+      const double c0 = unoise ? exp(ns.log_alpha(t) - ns.log_alpha(t0)) : ns.sigma(t) / ns.sigma(t0);
       const double h_phi_1 = expm1(hh);
       double rks[MAXO];
       for (int i = 1; i < ord; ++i) rks[i - 1] = (ns.lambda(htime[i]) - lam0) / h;
@@ -521,7 +537,7 @@ static int build_plan(dv_plan* p) {
       }
       if (corr) {
         const int s = free_slot();
-        add_eval(1, t, s);
+        add_eval_u(1, t, s);
         std::vector<std::pair<int, double>> terms;
         double cm0 = -a * h_phi_1 + a * wt;
         for (int k = 1; k < ord; ++k) cm0 += a * wc[k - 1] / rks[k - 1];
@@ -533,7 +549,7 @@ static int build_plan(dv_plan* p) {
       }
       return DV_OK;
     };
-    add_eval(0, ts[0], 0);
+    add_eval_u(0, ts[0], 0);
     push_hist(0, ts[0]);
     for (int step = 1; step < order; ++step) {
       int rc = do_step(ts[step], step, true);
@@ -578,13 +594,13 @@ extern "C" int dv_sampler_plan_method(int32_t solver, int32_t schedule, const fl
                                       dv_plan** out) {
   if (!out) return dv_fail(DV_ERR_INVALID, "dv_sampler_plan: bad argument");
   if (method < DV_METHOD_MULTISTEP || method > DV_METHOD_SINGLESTEP_FIXED) return dv_fail(DV_ERR_INVALID, "unknown method %d", method);
-  const bool dpm_family = solver == DV_SOLVER_DPMPP || solver >= DV_SOLVER_DPM;   // DPM-Solver(++) (the others: UniPC variants)
+  const bool dpm_family = solver == DV_SOLVER_DPMPP || (solver >= DV_SOLVER_DPM && solver <= DV_SOLVER_DPM_TAYLOR);   // DPM-Solver(++) (the others: UniPC variants)
   if (schedule < DV_SCHEDULE_DISCRETE || schedule > DV_SCHEDULE_COSINE) return dv_fail(DV_ERR_INVALID, "unknown noise schedule %d", schedule);
   if (schedule == DV_SCHEDULE_DISCRETE && (!betas || n_betas < 2)) return dv_fail(DV_ERR_INVALID, "dv_sampler_plan: bad argument");
   if (schedule == DV_SCHEDULE_COSINE && dpm_family)   // (dpm_solver.py:94: 'discrete' or 'linear')
     return dv_fail(DV_ERR_INVALID, "the 'cosine' schedule exists for the UniPC solvers only");
   if (schedule == DV_SCHEDULE_LINEAR && !(beta_1 > beta_0 && beta_0 >= 0.0)) return dv_fail(DV_ERR_INVALID, "linear schedule: need 0 <= beta_0 < beta_1");
-  if (solver < DV_SOLVER_DPMPP || solver > DV_SOLVER_DPM_TAYLOR) return dv_fail(DV_ERR_INVALID, "unknown solver %d", solver);
+  if (solver < DV_SOLVER_DPMPP || solver > DV_SOLVER_UNIPC_VARY_NOISE) return dv_fail(DV_ERR_INVALID, "unknown solver %d", solver);
   if (dpm_family && (order < 1 || order > 3)) return dv_fail(DV_ERR_INVALID, "Solver order must be 1 or 2 or 3, got %d", order);
   if (order < 1 || order > MAXO) return dv_fail(DV_ERR_INVALID, "UniPC order must be 1..%d, got %d", MAXO, order);
   if (steps < order) return dv_fail(DV_ERR_INVALID, "steps (%d) must be >= order (%d)", steps, order);

@@ -28,8 +28,6 @@ class UniPC:
     def __init__(self, model_fn, noise_schedule, algorithm_type="data_prediction", correcting_x0_fn=None,
                  correcting_xt_fn=None, thresholding_max_val=1.0, dynamic_thresholding_ratio=0.995, variant="bh1"):
         assert algorithm_type in ["data_prediction", "noise_prediction"]
-        if algorithm_type != "data_prediction":
-            raise ValueError("algorithm_type='noise_prediction' is outside this build's scope")
         # correcting_x0_fn ("dynamic_thresholding" or fn(x0)) / correcting_xt_fn (fn(x, t, step)): reference :256-261, 292-293.
         # With either the loop is stepped from Python, never replayed as one graph.
         if correcting_x0_fn == "dynamic_thresholding":
@@ -40,13 +38,13 @@ class UniPC:
         self.model_fn = model_fn
         self.noise_schedule = noise_schedule
         self.variant = variant
-        self.predict_x0 = True
+        self.predict_x0 = algorithm_type == "data_prediction"    # (False: the same updates on the noise prediction, uni_pc.py:266)
         self._plans = {}
 
     def _plan(self, steps, order, skip_type, lower_order_final, t_start=None, t_end=None, denoise_to_zero=False):
         key = (steps, order, skip_type, bool(lower_order_final), t_start, t_end, bool(denoise_to_zero))
         if key not in self._plans:
-            self._plans[key] = Plan(_SOLVERS[self.variant], self.noise_schedule._betas, steps, order, skip_type,
+            self._plans[key] = Plan(_SOLVERS[self.variant] + (0 if self.predict_x0 else 6), self.noise_schedule._betas, steps, order, skip_type,
                                     lower_order_final, t_start, t_end, denoise_to_zero,
                                     schedule=self.noise_schedule._plan_schedule())
         return self._plans[key]
@@ -62,7 +60,11 @@ class UniPC:
         assert steps >= order
         plan = self._plan(steps, order, skip_type, lower_order_final, t_start, t_end, denoise_to_zero)
         fn0 = self.correcting_x0_fn
-        hooks = dict(x0_hook=None if fn0 is None else (lambda x0, eidx: fn0(x0)), xt_hook=self.correcting_xt_fn)
+        # (data_prediction_fn applies correcting_x0_fn, uni_pc.py:292-293: every evaluation of 'data_prediction'; with
+        # 'noise_prediction' only the final denoise_to_zero evaluation goes through it, :279-281)
+        last = plan.nfe - 1
+        keep = (lambda eidx: True) if self.predict_x0 else (lambda eidx: denoise_to_zero and eidx == last)
+        hooks = dict(x0_hook=None if fn0 is None else (lambda x0, eidx: fn0(x0) if keep(eidx) else x0), xt_hook=self.correcting_xt_fn)
         if not return_intermediate:
             return sample_with_plan(plan, self.model_fn, self.noise_schedule, x, **hooks)
         inter = []

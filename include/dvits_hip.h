@@ -179,9 +179,12 @@ int dv_unet_probe(dv_unet* u, const char* name, float* host_out, int64_t capacit
  * 895-904); the network still predicts x0: every evaluation is followed by eps = (x - alpha_t x0) / sigma_t on its history
  * slot (model_wrapper's 'x_start' branch, dpm_solver.py:290-292).
  * DV_SOLVER_*_TAYLOR: solver_type='taylor' - the second-order update's Taylor form (dpm_solver.py:825-829, 848-851); orders 1
- * and 3 are the same as without it. */
+ * and 3 are the same as without it.
+ * DV_SOLVER_UNIPC_*_NOISE: UniPC(algorithm_type='noise_prediction') - the same three variants on the noise prediction
+ * (uni_pc.py:448-468, 569-587), with the in-place x0 -> noise conversion of DV_SOLVER_DPM. */
 typedef enum { DV_SOLVER_DPMPP = 0, DV_SOLVER_UNIPC_BH1 = 1, DV_SOLVER_UNIPC_BH2 = 2, DV_SOLVER_UNIPC_VARY = 3, DV_SOLVER_DPM = 4,
-               DV_SOLVER_DPMPP_TAYLOR = 5, DV_SOLVER_DPM_TAYLOR = 6 } dv_solver;
+               DV_SOLVER_DPMPP_TAYLOR = 5, DV_SOLVER_DPM_TAYLOR = 6, DV_SOLVER_UNIPC_BH1_NOISE = 7, DV_SOLVER_UNIPC_BH2_NOISE = 8,
+               DV_SOLVER_UNIPC_VARY_NOISE = 9 } dv_solver;
 typedef enum { DV_SKIP_TIME_UNIFORM = 0, DV_SKIP_TIME_QUADRATIC = 1, DV_SKIP_LOGSNR = 2 } dv_skip;
 /* NoiseScheduleVP(schedule=...): 'discrete' (betas; dpm_solver.py:98-107, uni_pc.py:59-66), or the continuous-time VP
  * schedules 'linear' (beta_0, beta_1; dpm_solver.py:108-111,133-134,160-163) and 'cosine' (uni_pc.py:73-100; UniPC only -

@@ -379,8 +379,8 @@ def dpm_solver_pp_sample(model, betas, x, steps=20, order=2, skip_type="time_uni
 
 
 # ----------------------------------------------------------------------------- UniPC
-def _unipc_bh_update(ns, fn, x, m_list, t_list, t, order, variant, use_corrector):
-    """multistep_uni_pc_bh_update with predict_x0=True, uni_pc.py:471-588."""
+def _unipc_bh_update(ns, fn, x, m_list, t_list, t, order, variant, use_corrector, predict_x0=True):
+    """multistep_uni_pc_bh_update, uni_pc.py:471-588 (predict_x0=False: the noise form, :503, :569-587)."""
     t = t.reshape(-1)
     t0 = t_list[-1]
     lam0, lam_t = ns.lam(t0), ns.lam(t)
@@ -395,7 +395,7 @@ def _unipc_bh_update(ns, fn, x, m_list, t_list, t, order, variant, use_corrector
         D1s.append((m_list[-(i + 1)] - m0) / rk)
     rks.append(1.0)
     rks = torch.tensor([float(r) for r in rks])
-    hh = -h
+    hh = -h if predict_x0 else h
     h_phi_1 = torch.expm1(hh)
     h_phi_k = h_phi_1 / hh - 1
     B_h = hh if variant == "bh1" else torch.expm1(hh)
@@ -416,19 +416,23 @@ def _unipc_bh_update(ns, fn, x, m_list, t_list, t, order, variant, use_corrector
         D1s = None
     if use_corrector:
         rhos_c = torch.tensor([0.5]) if order == 1 else torch.linalg.solve(R, b)
-    x_t_ = sig_t / sig0 * x - alpha_t * h_phi_1 * m0
+    amp = alpha_t if predict_x0 else sig_t
+    if predict_x0:
+        x_t_ = sig_t / sig0 * x - alpha_t * h_phi_1 * m0
+    else:
+        x_t_ = torch.exp(ns.log_alpha(t) - ns.log_alpha(t0)) * x - sig_t * h_phi_1 * m0
     pred = torch.einsum("k,bkct->bct", rhos_p, D1s) if D1s is not None else 0
-    x_t = x_t_ - alpha_t * B_h * pred
+    x_t = x_t_ - amp * B_h * pred
     m_t = None
     if use_corrector:
         m_t = fn(x_t, t)
         corr = torch.einsum("k,bkct->bct", rhos_c[:-1], D1s) if D1s is not None else 0
-        x_t = x_t_ - alpha_t * B_h * (corr + rhos_c[-1] * (m_t - m0))
+        x_t = x_t_ - amp * B_h * (corr + rhos_c[-1] * (m_t - m0))
     return x_t, m_t
 
 
-def _unipc_vary_update(ns, fn, x, m_list, t_list, t, order, use_corrector):
-    """multistep_uni_pc_vary_update with predict_x0=True, uni_pc.py:368-469 (variant='vary_coeff'): residual weights
+def _unipc_vary_update(ns, fn, x, m_list, t_list, t, order, use_corrector, predict_x0=True):
+    """multistep_uni_pc_vary_update, uni_pc.py:368-469 (variant='vary_coeff'; predict_x0=False: :417, :448-468): residual weights
     from the inverse of C[i, k] = rks[i]^k / (k+1)! instead of the B(h) systems.  The corrector's last term indexes
     A_c with the loop variable `k` left over from the residual loop (:444-447), reproduced as written."""
     t = t.reshape(-1)
@@ -455,18 +459,22 @@ def _unipc_vary_update(ns, fn, x, m_list, t_list, t, order, use_corrector):
     if D1s:
         D1s = torch.stack(D1s, dim=1)
     A_c = torch.linalg.inv(Cm) if use_corrector else None
-    hh = -h
+    hh = -h if predict_x0 else h
     h_phi_1 = torch.expm1(hh)
     h_phi_ks, fact, h_phi_k = [], 1, h_phi_1
     for k in range(1, K + 2):
         h_phi_ks.append(h_phi_k)
         h_phi_k = h_phi_k / hh - 1 / fact
         fact *= (k + 1)
-    x_t_ = sig_t / sig0 * x - alpha_t * h_phi_1 * m0
+    amp = alpha_t if predict_x0 else sig_t
+    if predict_x0:
+        x_t_ = sig_t / sig0 * x - alpha_t * h_phi_1 * m0
+    else:
+        x_t_ = torch.exp(ns.log_alpha(t) - ns.log_alpha(t0)) * x - sig_t * h_phi_1 * m0
     x_t = x_t_
     if len(D1s) > 0:
         for k in range(K - 1):
-            x_t = x_t - alpha_t * h_phi_ks[k + 1] * torch.einsum("bkct,k->bct", D1s, A_p[k])
+            x_t = x_t - amp * h_phi_ks[k + 1] * torch.einsum("bkct,k->bct", D1s, A_p[k])
     m_t = None
     if use_corrector:
         m_t = fn(x_t, t)
@@ -474,26 +482,29 @@ def _unipc_vary_update(ns, fn, x, m_list, t_list, t, order, use_corrector):
         x_t = x_t_
         k = 0
         for k in range(K - 1):
-            x_t = x_t - alpha_t * h_phi_ks[k + 1] * torch.einsum("bkct,k->bct", D1s, A_c[k][:-1])
-        x_t = x_t - alpha_t * h_phi_ks[K] * (D1_t * A_c[k][-1])
+            x_t = x_t - amp * h_phi_ks[k + 1] * torch.einsum("bkct,k->bct", D1s, A_c[k][:-1])
+        x_t = x_t - amp * h_phi_ks[K] * (D1_t * A_c[k][-1])
     return x_t, m_t
 
 
-def _unipc_update(ns, fn, x, m_list, t_list, t, order, variant, use_corrector):
+def _unipc_update(ns, fn, x, m_list, t_list, t, order, variant, use_corrector, predict_x0=True):
     """multistep_uni_pc_update dispatch, uni_pc.py:357-366."""
     if "bh" in variant:
-        return _unipc_bh_update(ns, fn, x, m_list, t_list, t, order, variant, use_corrector)
+        return _unipc_bh_update(ns, fn, x, m_list, t_list, t, order, variant, use_corrector, predict_x0)
     assert variant == "vary_coeff"
-    return _unipc_vary_update(ns, fn, x, m_list, t_list, t, order, use_corrector)
+    return _unipc_vary_update(ns, fn, x, m_list, t_list, t, order, use_corrector, predict_x0)
 
 
 def unipc_sample(model, betas, x, steps=20, order=2, skip_type="time_uniform", variant="bh2",
                  lower_order_final=True, return_intermediate=False, t_start=None, t_end=None, denoise_to_zero=False,
-                 schedule=None, x0_fn=None, xt_fn=None):
-    """UniPC(model_fn, ns, variant=...).sample(x, steps, order, skip_type, 'multistep'),
-    uni_pc.py:590-672."""
+                 schedule=None, x0_fn=None, xt_fn=None, algorithm_type="data_prediction"):
+    """UniPC(model_fn, ns, algorithm_type, variant=...).sample(x, steps, order, skip_type, 'multistep'),
+    uni_pc.py:590-672.  algorithm_type='noise_prediction': the same loop on the noise prediction (:266, :296-303)."""
     ns = _schedule(betas, False, schedule)
-    fn = wrap_x_start_model(model, ns, None if x0_fn is None else (lambda x0, t: x0_fn(x0)))
+    data_fn = wrap_x_start_model(model, ns, None if x0_fn is None else (lambda x0, t: x0_fn(x0)))
+    px0 = algorithm_type == "data_prediction"
+    fn = data_fn if px0 else wrap_x_start_noise(model, ns)
+    _unipc_update = lambda *a: globals()["_unipc_update"](*a, predict_x0=px0)
     fix = (lambda x, t, step: x) if xt_fn is None else xt_fn       # correcting_xt_fn (uni_pc.py:615-616, 626-627, 646-647, 664-665)
     t_0 = 1.0 / ns.total_N if t_end is None else t_end        # uni_pc.py:596-597
     t_T = ns.T if t_start is None else t_start
@@ -521,7 +532,7 @@ def unipc_sample(model, betas, x, steps=20, order=2, skip_type="time_uniform", v
         if step < steps:
             m_list[-1] = m_x
     if denoise_to_zero:            # uni_pc.py:660-666
-        x = fix(fn(x, torch.ones((1,)) * t_0), torch.ones((1,)) * t_0, steps + 1)
+        x = fix(data_fn(x, torch.ones((1,)) * t_0), torch.ones((1,)) * t_0, steps + 1)
         inter.append(x)
     return (x, inter) if return_intermediate else x
 

@@ -220,6 +220,11 @@ OPTION_CASES = {
     "dpm_ssfixed_taylor": ("dpm", dict(steps=12, order=3, skip_type="time_uniform", method="singlestep_fixed", solver_type="taylor")),
     "dpmn_ss_taylor_o2": ("dpm", dict(steps=10, order=2, skip_type="time_uniform", method="singlestep", solver_type="taylor",
                                       algorithm_type="dpmsolver")),
+    # UniPC(algorithm_type='noise_prediction') (uni_pc.py:266, 448-468, 569-587)
+    "unipcn_bh2_o2": ("unipc", dict(steps=10, order=2, skip_type="time_uniform", unipc_algo="noise_prediction")),
+    "unipcn_bh1_o3_dtz": ("unipc", dict(steps=9, order=3, skip_type="time_quadratic", denoise_to_zero=True, return_intermediate=True,
+                                        unipc_algo="noise_prediction", variant="bh1", hooks=("fn", True))),
+    "unipcn_vary_o4": ("unipc", dict(steps=9, order=4, skip_type="time_uniform", unipc_algo="noise_prediction", variant="vary_coeff")),
 }
 
 
@@ -268,6 +273,7 @@ def test_sampler_options_match_reference(gold, key):
     algo = kw.pop("algorithm_type", "dpmsolver++")
     hooks = kw.pop("hooks", None)
     method = kw.pop("method", "multistep")
+    ualgo, variant = kw.pop("unipc_algo", "data_prediction"), kw.pop("variant", "bh2")
     B = 2 if solver == "dpm" else 1
     guid = _guidance_kwargs(kw.pop("guidance", None), key, B)
     net = sampler_ref.standin_cond_model if guid else sampler_ref.standin_model
@@ -280,13 +286,13 @@ def test_sampler_options_match_reference(gold, key):
     # sigma = sqrt(1 - exp(2 log alpha)) loses ~4 digits near t_end (log alpha ~ -5e-5): the agreement is the reference's
     # own rounding there (the float32 oracle below reproduces the reference exactly)
     tol = 2e-5 if sched is None else 5e-4
-    if algo == "dpmsolver":     # the noise form: eps = (x - alpha x0) / sigma in float32 amplifies rounding by 1 / sigma at the low-noise end
+    if algo == "dpmsolver" or ualgo == "noise_prediction":     # the noise form: eps = (x - alpha x0) / sigma in float32 amplifies rounding by 1 / sigma at the low-noise end
         tol = max(tol, 1e-4)
     fn = mod.model_wrapper(lambda xx, t, *c, **k: net(xx, t, *c), ns, model_type="x_start", **(guid or {}))
     if solver == "dpm":
         r = mod.DPM_Solver(fn, ns, algorithm_type=algo, **_hook_kwargs(hooks, False)).sample(x.clone(), method=method, **kw)
     else:
-        r = mod.UniPC(fn, ns, variant="bh2", **_hook_kwargs(hooks, True)).sample(x.clone(), method="multistep", **kw)
+        r = mod.UniPC(fn, ns, variant=variant, algorithm_type=ualgo, **_hook_kwargs(hooks, True)).sample(x.clone(), method="multistep", **kw)
     if kw.get("return_intermediate"):
         out, inter = r
         ref_inter = g[key + "_inter"]
@@ -304,7 +310,7 @@ def test_sampler_options_match_reference(gold, key):
         o = sampler_ref.dpm_solver_pp_sample(net, betas, x.clone(), *args, schedule=sched, algorithm_type=algo, guidance=guid, method=method,
                                              **_oracle_hooks(hooks), **okw)
     else:
-        o = sampler_ref.unipc_sample(sampler_ref.standin_model, betas, x.clone(), *args, "bh2", schedule=sched, **_oracle_hooks(hooks), **okw)
+        o = sampler_ref.unipc_sample(sampler_ref.standin_model, betas, x.clone(), *args, variant, schedule=sched, algorithm_type=ualgo, **_oracle_hooks(hooks), **okw)
     assert rel_l2(o.numpy(), g[key + "_x"]) < 1e-6
 
 

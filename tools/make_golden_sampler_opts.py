@@ -66,6 +66,11 @@ CASES = {
     "dpm_ssfixed_taylor": ("dpm", dict(steps=12, order=3, skip_type="time_uniform", method="singlestep_fixed", solver_type="taylor")),
     "dpmn_ss_taylor_o2": ("dpm", dict(steps=10, order=2, skip_type="time_uniform", method="singlestep", solver_type="taylor",
                                       algorithm_type="dpmsolver")),
+    # UniPC(algorithm_type='noise_prediction') (uni_pc.py:266, 448-468, 569-587)
+    "unipcn_bh2_o2": ("unipc", dict(steps=10, order=2, skip_type="time_uniform", unipc_algo="noise_prediction")),
+    "unipcn_bh1_o3_dtz": ("unipc", dict(steps=9, order=3, skip_type="time_quadratic", denoise_to_zero=True, return_intermediate=True,
+                                        unipc_algo="noise_prediction", variant="bh1", hooks=("fn", True))),
+    "unipcn_vary_o4": ("unipc", dict(steps=9, order=4, skip_type="time_uniform", unipc_algo="noise_prediction", variant="vary_coeff")),
 }
 
 
@@ -136,6 +141,7 @@ def main():
         algo = kw.pop("algorithm_type", "dpmsolver++")
         hooks = kw.pop("hooks", None)
         method = kw.pop("method", "multistep")
+        ualgo, variant = kw.pop("unipc_algo", "data_prediction"), kw.pop("variant", "bh2")
         guid = guidance_kwargs(kw.pop("guidance", None), key, B)
         net = sampler_ref.standin_cond_model if guid else sampler_ref.standin_model
         if solver == "dpm":
@@ -148,10 +154,10 @@ def main():
         else:
             ns = make_ns(ref_unipc, sched, betas)
             fn = ref_unipc.model_wrapper(lambda xx, t, **k: sampler_ref.standin_model(xx, t), ns, model_type="x_start")
-            r = ref_unipc.UniPC(fn, ns, variant="bh2", **hook_kwargs(hooks, True)).sample(x.clone(), method="multistep", **kw)
+            r = ref_unipc.UniPC(fn, ns, variant=variant, algorithm_type=ualgo, **hook_kwargs(hooks, True)).sample(x.clone(), method="multistep", **kw)
             okw = {k: v for k, v in kw.items()}
             o = sampler_ref.unipc_sample(sampler_ref.standin_model, betas, x.clone(), okw.pop("steps"), okw.pop("order"),
-                                         okw.pop("skip_type"), "bh2", schedule=sched, **oracle_hooks(hooks), **okw)
+                                         okw.pop("skip_type"), variant, schedule=sched, algorithm_type=ualgo, **oracle_hooks(hooks), **okw)
         if kw.get("return_intermediate"):
             xr, inter = r
             xo, ointer = o
