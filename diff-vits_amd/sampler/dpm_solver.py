@@ -6,10 +6,11 @@ libdvits_hip.so `dv_sampler_plan`) and then either replays it natively (hipGraph
 + fused update kernels) when the wrapped model is a `NativeUNetModel`, or runs it with torch ops
 around an arbitrary Python callable.  Scope of this build: algorithm_type='dpmsolver++' and 'dpmsolver',
 methods 'multistep' (reference :1171-1213, :547-592, :796-904), 'singlestep' and 'singlestep_fixed' (:482-539, :594-794,
-:1214-1232), orders 1-3, solver types 'dpmsolver' and 'taylor', schedules 'discrete' and 'linear'.
+:1214-1232) - compiled - and 'adaptive' (:906-1010, stepped from Python: sampler/_adaptive.py), orders 1-3, solver types 'dpmsolver' and 'taylor', schedules 'discrete' and 'linear'.
 """
 import torch
 
+from ._adaptive import adaptive_sample
 from ._plan import NativeUNetModel, NoiseScheduleBase, Plan, _eval_times, dynamic_thresholding, sample_with_plan, wrap_model
 
 __all__ = ["NoiseScheduleVP", "model_wrapper", "DPM_Solver", "NativeUNetModel"]
@@ -64,9 +65,26 @@ class DPM_Solver:
                return_intermediate=False):
         """x at t_start (default T) -> x at t_end (default 1/N), reference dpm_solver.py:1047-1245.  NFE == steps
         (+1 with denoise_to_zero).  return_intermediate=True returns (x, [start point, x after every step, ...])."""
-        if method not in ("multistep", "singlestep", "singlestep_fixed"):
-            # ('adaptive' chooses its step sizes from the data: not a loop that can be compiled ahead; reference :906-1010)
-            raise ValueError("Got wrong method {} (this build implements 'multistep', 'singlestep' and 'singlestep_fixed')".format(method))
+        if method not in ("multistep", "singlestep", "singlestep_fixed", "adaptive"):
+            raise ValueError("Got wrong method {}".format(method))
+        if method == "adaptive":
+            # data-dependent step sizes: stepped from Python (sampler/_adaptive.py; reference :906-1010, :1164-1170, :1234-1240)
+            assert self.correcting_xt_fn is None, "Cannot use adaptive solver when correcting_xt_fn is not None"
+            assert not return_intermediate, "Cannot use adaptive solver when saving intermediate values"      # (reference :1162-1163)
+            ns = self.noise_schedule
+            t_0 = 1.0 / ns.total_N if t_end is None else t_end
+            t_T = ns.T if t_start is None else t_start
+            assert t_0 > 0 and t_T > 0, "Time range needs to be greater than 0. For discrete-time DPMs, it needs to be in [1 / N, 1], where N is the length of betas array"
+            with torch.no_grad():
+                x, self.last_adaptive_nfe = adaptive_sample(self, x, order, t_T, t_0, atol=atol, rtol=rtol, solver_type=solver_type)
+                if denoise_to_zero:
+                    saved, self.algorithm_type = self.algorithm_type, "dpmsolver++"      # (denoise_to_zero_fn = data_prediction_fn, :541-545)
+                    try:
+                        from ._adaptive import _prediction_fn
+                        x = _prediction_fn(self)[0](x, torch.ones((1,), dtype=torch.float32, device=x.device) * t_0)
+                    finally:
+                        self.algorithm_type = saved
+            return x
         if order not in (1, 2, 3):
             raise ValueError("Solver order must be 1 or 2 or 3, got {}".format(order))
         if solver_type not in ("dpmsolver", "taylor"):

@@ -300,6 +300,33 @@ def singlestep_orders(ns, steps, order, skip_type, t_T, t_0, fixed=False):
     return time_steps(ns, skip_type, t_T, t_0, steps)[torch.cumsum(torch.tensor([0] + orders), 0)], orders
 
 
+def _adaptive(ns, fn, x, order, t_T, t_0, noise, taylor, h_init=0.05, atol=0.0078, rtol=0.05, theta=0.9, t_err=1e-5):
+    """dpm_solver_adaptive, dpm_solver.py:906-1010: the lower-order update (order - 1) estimates the error of the order-th
+    singlestep update; a step is accepted when the scaled error is <= 1, the next step size follows theta h E^(-1/order).
+    (The reference hands model_s / model_s1 from the lower to the higher update; re-evaluating them gives the same bits.)
+    Returns (x, nfe)."""
+    assert order in (2, 3)
+    s = t_T * torch.ones((1,))
+    lam_s = ns.lam(s)
+    lam_0 = ns.lam(t_0 * torch.ones_like(s))
+    h = h_init * torch.ones_like(s)
+    x_prev, nfe = x, 0
+    r1, r2 = (0.5, None) if order == 2 else (1.0 / 3.0, 2.0 / 3.0)
+    while torch.abs(s - t_0).mean() > t_err:
+        t = ns.inverse_lambda(lam_s + h)
+        x_lower = _singlestep_update(ns, fn, x, s, t, order - 1, r1, None, noise, taylor)
+        x_higher = _singlestep_update(ns, fn, x, s, t, order, r1, r2, noise, taylor)
+        delta = torch.max(torch.ones_like(x) * atol, rtol * torch.max(torch.abs(x_lower), torch.abs(x_prev)))
+        v = (x_higher - x_lower) / delta
+        E = torch.sqrt(torch.square(v.reshape((v.shape[0], -1))).mean(dim=-1, keepdim=True)).max()
+        if torch.all(E <= 1.0):
+            x, s, x_prev = x_higher, t, x_lower
+            lam_s = ns.lam(s)
+        h = torch.min(theta * h * torch.float_power(E, -1.0 / order).float(), lam_0 - lam_s)
+        nfe += order
+    return x, nfe
+
+
 def wrap_x_start_noise(model, ns):
     """model_wrapper(model, ns, model_type='x_start') alone: the NOISE prediction the algorithm_type='dpmsolver' updates
     consume - noise = (x - alpha_t * x0) / sigma_t (dpm_solver.py:290-292)."""
@@ -315,7 +342,7 @@ def wrap_x_start_noise(model, ns):
 def dpm_solver_pp_sample(model, betas, x, steps=20, order=2, skip_type="time_uniform",
                          lower_order_final=True, return_intermediate=False, t_start=None, t_end=None,
                          denoise_to_zero=False, schedule=None, algorithm_type="dpmsolver++", x0_fn=None, xt_fn=None,
-                         guidance=None, solver_type="dpmsolver", method="multistep"):
+                         guidance=None, solver_type="dpmsolver", method="multistep", atol=0.0078, rtol=0.05):
     """DPM_Solver(model_fn, ns, algorithm_type).sample(x, steps, order, skip_type,
     method='multistep'), dpm_solver.py:1047-1245 (multistep branch :1171-1213).
     `model(x, t_input)` is the raw x0-prediction network.  algorithm_type='dpmsolver': the same loop on the noise
@@ -337,6 +364,10 @@ def dpm_solver_pp_sample(model, betas, x, steps=20, order=2, skip_type="time_uni
     t_0 = 1.0 / ns.total_N if t_end is None else t_end
     t_T = ns.T if t_start is None else t_start
     assert steps >= order
+    if method == "adaptive":       # dpm_solver.py:1162-1170
+        assert not return_intermediate, "Cannot use adaptive solver when saving intermediate values"
+        x, _ = _adaptive(ns, fn, x, order, t_T, t_0, algorithm_type != "dpmsolver++", solver_type == "taylor", atol=atol, rtol=rtol)
+        return data_fn(x, torch.ones((1,)) * t_0) if denoise_to_zero else x
     if method != "multistep":      # 'singlestep' / 'singlestep_fixed', dpm_solver.py:1214-1232 (no start point in the intermediates)
         outer, orders = singlestep_orders(ns, steps, order, skip_type, t_T, t_0, method == "singlestep_fixed")
         inter = []
