@@ -129,16 +129,25 @@ def wrap_x_start_model(model, ns, x0_fn=None):
     return data_prediction
 
 
-def guided_noise_fn(model, ns, guidance_type, condition=None, unconditional_condition=None, guidance_scale=1.0,
-                    classifier_fn=None):
+def guided_noise_fn(model, ns, guidance_type="uncond", condition=None, unconditional_condition=None, guidance_scale=1.0,
+                    classifier_fn=None, model_type="x_start"):
     """model_wrapper(model, ns, model_type='x_start', guidance_type='classifier' | 'classifier-free', ...) ->
     model_fn(x, t): dpm_solver.py:282-330.  `model(x, t_input[, cond])` predicts x0."""
-    def noise_pred(x, t, cond=None):
+    def noise_pred(x, t, cond=None):      # dpm_solver.py:282-298, every model_type
         t_input = t if isinstance(ns, ContinuousSchedule) else (t - 1.0 / ns.total_N) * ns.total_N
         out = model(x, t_input) if cond is None else model(x, t_input, cond)
-        return (x - _bcast(ns.alpha(t), x) * out) / _bcast(ns.sigma(t), x)
+        if model_type == "noise":
+            return out
+        if model_type == "x_start":
+            return (x - _bcast(ns.alpha(t), x) * out) / _bcast(ns.sigma(t), x)
+        if model_type == "v":
+            return _bcast(ns.alpha(t), x) * out + _bcast(ns.sigma(t), x) * x
+        assert model_type == "score"
+        return -_bcast(ns.sigma(t), x) * out
 
     def model_fn(x, t):
+        if guidance_type == "uncond":
+            return noise_pred(x, t)
         if guidance_type == "classifier":
             t_input = t if isinstance(ns, ContinuousSchedule) else (t - 1.0 / ns.total_N) * ns.total_N
             with torch.enable_grad():
@@ -357,7 +366,12 @@ def dpm_solver_pp_sample(model, betas, x, steps=20, order=2, skip_type="time_uni
             x0 = (x - ns.sigma(t) * g_noise(x, tb)) / ns.alpha(t)
             return x0 if x0_fn is None else x0_fn(x0, t)
     fix = (lambda x, t, step: x) if xt_fn is None else xt_fn       # correcting_xt_fn (:1180-1181, 1188-1189, 1203-1204, 1237-1238)
-    fn = data_fn if algorithm_type == "dpmsolver++" else wrap_x_start_noise(model, ns)
+    if algorithm_type == "dpmsolver++":
+        fn = data_fn
+    elif guidance is not None:                       # model_fn = noise_prediction_fn (dpm_solver.py:427-431) of the guided / typed wrapper
+        fn = lambda x, t: g_noise(x, t.expand(x.shape[0]))
+    else:
+        fn = wrap_x_start_noise(model, ns)
     _upd = globals()["_dpmpp_update"] if algorithm_type == "dpmsolver++" else _dpm_noise_update
     _dpmpp_update = lambda *a: _upd(*a, taylor=solver_type == "taylor")
     # dpm_solver.py:1157-1158: t_0 = 1/N unless t_end is given, t_T = T unless t_start is given

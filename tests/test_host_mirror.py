@@ -239,12 +239,18 @@ OPTION_CASES = {
     "dpmn_adaptive_o2": ("dpm", dict(steps=20, order=2, skip_type="time_uniform", method="adaptive", algorithm_type="dpmsolver")),
     "dpmn_adaptive_o3_taylor": ("dpm", dict(steps=20, order=3, skip_type="time_uniform", method="adaptive", solver_type="taylor",
                                             algorithm_type="dpmsolver", t_end=0.01)),
+    # the other model types of model_wrapper (dpm_solver.py:288-298): the stand-in's output read as noise / v / score
+    "dpm_type_noise": ("dpm", dict(steps=10, order=2, skip_type="time_uniform", guidance="type:noise")),
+    "dpm_type_v": ("dpm", dict(steps=10, order=3, skip_type="logSNR", guidance="type:v")),
+    "dpmn_type_score": ("dpm", dict(steps=10, order=2, skip_type="time_quadratic", guidance="type:score", algorithm_type="dpmsolver")),
 }
 
 
 def _guidance_kwargs(name, key, B):
     if name is None:
         return None
+    if name.startswith("type:"):
+        return dict(model_type=name[5:])
     cond = torch.from_numpy(synth.normal(4321, "cond." + key, (B, 5, 1)))
     if name == "clf":
         return dict(guidance_type="classifier", condition=cond, guidance_scale=1.5, classifier_fn=sampler_ref.standin_classifier)
@@ -290,7 +296,9 @@ def test_sampler_options_match_reference(gold, key):
     ualgo, variant = kw.pop("unipc_algo", "data_prediction"), kw.pop("variant", "bh2")
     B = 2 if solver == "dpm" else 1
     guid = _guidance_kwargs(kw.pop("guidance", None), key, B)
-    net = sampler_ref.standin_cond_model if guid else sampler_ref.standin_model
+    net = sampler_ref.standin_cond_model if (guid and "model_type" not in guid) else sampler_ref.standin_model
+    mtype = (guid or {}).get("model_type", "x_start")
+    wkw = {k: v for k, v in (guid or {}).items() if k != "model_type"}
     x = torch.from_numpy(synth.normal(1234, "opts." + key, (B, 5, 24)))
     betas = torch.from_numpy(synth.make_betas())
     mod = dpm_solver if solver == "dpm" else uni_pc
@@ -304,7 +312,7 @@ def test_sampler_options_match_reference(gold, key):
         tol = max(tol, 2e-4)
     if algo == "dpmsolver" or ualgo == "noise_prediction":     # the noise form: eps = (x - alpha x0) / sigma in float32 amplifies rounding by 1 / sigma at the low-noise end
         tol = max(tol, 1e-4)
-    fn = mod.model_wrapper(lambda xx, t, *c, **k: net(xx, t, *c), ns, model_type="x_start", **(guid or {}))
+    fn = mod.model_wrapper(lambda xx, t, *c, **k: net(xx, t, *c), ns, model_type=mtype, **wkw)
     if solver == "dpm":
         r = mod.DPM_Solver(fn, ns, algorithm_type=algo, **_hook_kwargs(hooks, False)).sample(x.clone(), method=method, **kw)
     else:

@@ -81,6 +81,10 @@ CASES = {
     "dpmn_adaptive_o2": ("dpm", dict(steps=20, order=2, skip_type="time_uniform", method="adaptive", algorithm_type="dpmsolver")),
     "dpmn_adaptive_o3_taylor": ("dpm", dict(steps=20, order=3, skip_type="time_uniform", method="adaptive", solver_type="taylor",
                                             algorithm_type="dpmsolver", t_end=0.01)),
+    # the other model types of model_wrapper (dpm_solver.py:288-298): the stand-in's output read as noise / v / score
+    "dpm_type_noise": ("dpm", dict(steps=10, order=2, skip_type="time_uniform", guidance="type:noise")),
+    "dpm_type_v": ("dpm", dict(steps=10, order=3, skip_type="logSNR", guidance="type:v")),
+    "dpmn_type_score": ("dpm", dict(steps=10, order=2, skip_type="time_quadratic", guidance="type:score", algorithm_type="dpmsolver")),
 }
 
 
@@ -88,6 +92,8 @@ def guidance_kwargs(name, key, B):
     """model_wrapper keywords (reference and mirror) / guided_noise_fn keywords (oracle) of a case's `guidance` entry."""
     if name is None:
         return None
+    if name.startswith("type:"):
+        return dict(model_type=name[5:])
     cond = torch.from_numpy(synth.normal(4321, "cond." + key, (B, 5, 1)))
     if name == "clf":
         return dict(guidance_type="classifier", condition=cond, guidance_scale=1.5, classifier_fn=sampler_ref.standin_classifier)
@@ -153,10 +159,12 @@ def main():
         method = kw.pop("method", "multistep")
         ualgo, variant = kw.pop("unipc_algo", "data_prediction"), kw.pop("variant", "bh2")
         guid = guidance_kwargs(kw.pop("guidance", None), key, B)
-        net = sampler_ref.standin_cond_model if guid else sampler_ref.standin_model
+        net = sampler_ref.standin_cond_model if (guid and "model_type" not in guid) else sampler_ref.standin_model
+        mtype = (guid or {}).get("model_type", "x_start")
+        wkw = {k: v for k, v in (guid or {}).items() if k != "model_type"}
         if solver == "dpm":
             ns = make_ns(ref_dpm, sched, betas)
-            fn = ref_dpm.model_wrapper(lambda xx, t, *c, **k: net(xx, t, *c), ns, model_type="x_start", **(guid or {}))
+            fn = ref_dpm.model_wrapper(lambda xx, t, *c, **k: net(xx, t, *c), ns, model_type=mtype, **wkw)
             import contextlib, io
             with contextlib.redirect_stdout(io.StringIO()):      # (the adaptive solver prints its NFE)
                 r = ref_dpm.DPM_Solver(fn, ns, algorithm_type=algo, **hook_kwargs(hooks, False)).sample(x.clone(), method=method, **kw)
