@@ -197,6 +197,44 @@ bool chain_ff_supported(const ChainFFParams& p, int precision);
 int chain_ff_gnx_plan(const ChainFFParams& p, int n_cu);
 hipError_t launch_chain_ff(const ChainFFParams& p, int precision, hipStream_t st);
 
+// Feed-forward tail of a transformer block at C = 256 / 384 as ONE launch (k_ff_split, kernels_ffsplit.hip; reference
+// attention.py:189-203, 206-255, 280-301 + transformer_1d.py:300-326).  As two GEMMs the block costs 55-62 us at the bench
+// shape: a [M, 8C] GEGLU GEMM whose 4C-wide product makes an HBM round trip, then the K = 5C merged ff.net.2 + proj_out GEMM.
+// A row-block kernel of 32 rows (k_chain_ff) does not scale to these widths: every workgroup would stream 3.3 / 7.6 MB of
+// weights.  Here a workgroup owns 64 rows (two row fragments per weight fragment: half the weight bytes per MFMA) and ONE
+// SLICE of the product columns: `nspl` workgroups per row block, workgroup id = row block * nspl + slice, so that XCD x
+// (= id % 8) only ever touches slice x % nspl of the weights (its L2 holds 1 / nspl of them).
+//   stage A: LN3 (from the producer's row partials) -> GEGLU for the slice's 4C / nspl product columns, product as split
+//            planes in LDS
+//   stage B: partial ffproj over the slice's K range [C / nspl channels of h3 | its product columns] for ALL C output columns
+//   hand-over: every workgroup writes its partial sums through (8 x 16-column half fragments per 32-row fragment), publishes a
+//            flag word, waits for the flags of its row block (all workgroups of the launch are resident: the planner checks,
+//            the wait is bounded and flagged like the in-launch GroupNorm's) and FINISHES C / nspl output columns: partials
+//            summed in slice order (deterministic), + bias + block residual -> fp32, 32x16 block statistics, optional planes,
+//            optional GroupNorm of the consumer (GnxParams) - the tile [64 rows x C / nspl columns] behaves like a GEMM tile.
+struct FFSplitParams {
+  int M, C, T;                                    // rows (T % 64 == 0: row pitch per utterance), C = 256 or 384
+  int Tv;                                         // frames that exist per utterance (0: T)
+  int nspl;                                       // workgroups per 64-row block (4 at C = 256, 8 at C = 384)
+  const bf16_t* a_hi; const bf16_t* a_lo;         // raw split planes of h3 [M, C]
+  const float* rowstat; float ln_eps;             // LayerNorm row partials of h3 [M, C/32, 2]
+  const bf16_t* wg_hi; const bf16_t* wg_lo; const float* bg; const float* ug;   // GEGLU [8C][Kp = C] fragment-major (gamma folded), bias', u
+  const bf16_t* wm_hi; const bf16_t* wm_lo; const float* bm;                    // merged [C][Kp = 5C] fragment-major, bias
+  const float* res;                               // block input [M, C] fp32
+  float* out; float* stats16;                     // [M, C] fp32 (null: nobody reads it); [M/32, C/16, 2] or null
+  bf16_t* out_hi; bf16_t* out_lo;                 // optional split planes of the output
+  float* xbuf;                                    // partial sums: ff_split_xbuf_floats(M, C, nspl) floats of scratch
+  unsigned long long* flags;                      // (M / 64) * nspl exchange words, EMPTY (all ones) before the launch
+  unsigned* status; int spin_max;                 // time-out flag / bound of the waits (GnxParams)
+  GnxParams gnx;                                  // xchg != null: the consumer's GroupNorm is finished by this launch
+};
+bool ff_split_supported(const FFSplitParams& p, int precision);
+size_t ff_split_xbuf_floats(int M, int C, int nspl);
+// exchange words of the in-launch GroupNorm ((M / 32) * (C / 16); gnx.groups / gnx.sk_c set), 0: not possible
+int ff_split_gnx_plan(const FFSplitParams& p, int n_cu);
+hipError_t ff_split_init();
+hipError_t launch_ff_split(const FFSplitParams& p, int precision, hipStream_t st);
+
 // cross-attention K/V of one block, fp32 [B*L, 2C] (k | v) -> MFMA-fragment-major split planes (ChainParams xa_*)
 hipError_t launch_kv_frag(const float* kv, bf16_t* kf_hi, bf16_t* kf_lo, bf16_t* vf_hi, bf16_t* vf_lo, int B, int L, int C, int H,
                           hipStream_t st);

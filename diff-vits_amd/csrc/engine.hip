@@ -693,6 +693,31 @@ struct Builder {
     }
     if (cat && nn.raw && !u->keep_intermediates && cat_drop_fp32) fp.out = nullptr;
   }
+  // ... when the producer is the split feed-forward launch of the C = 256 / 384 blocks (k_ff_split: its finishing tiles are
+  // [64 rows x C / nspl columns], all resident)
+  void offer_next(FFSplitParams& fp, Act& out) {
+    if (!next_norm.set) return;
+    const NextNorm nn = next_norm;
+    next_norm.set = false;
+    const bool cat = nn.skip.C > 0;
+    if (!gnx_on || !gnx_ff_on || !u->exclusive || arena.exact || !fp.stats16 || n_cu <= 0) return;
+    if (cat && (!gnx_cat_on || !nn.skip.p || !nn.skip.stat16 || nn.skip.Tp != fp.T)) return;
+    fp.gnx = GnxParams{};
+    fp.gnx.groups = u->cfg.norm_num_groups;
+    fp.gnx.sk_c = cat ? nn.skip.C : 0;
+    const int nw = ff_split_gnx_plan(fp, n_cu);
+    if (nw <= 0 || gnx_used + (size_t)nw > dv_unet::GNX_POOL) { fp.gnx = GnxParams{}; return; }
+    Planes y, sy, sr;
+    gnx_fill(fp.gnx, nw, fp.M, fp.C, nn.pre, nn.eps, nullptr, nullptr, 0, nn.silu, &y, cat ? &nn.skip : nullptr, &sy, nn.raw ? &sr : nullptr);
+    out.n_hi = y.hi; out.n_lo = y.lo; out.n_pre = nn.pre;
+    if (cat) { out.sn_hi = sy.hi; out.sn_lo = sy.lo; out.sr_hi = sr.hi; out.sr_lo = sr.lo; }
+    if (nn.raw && !fp.out_hi) {
+      Planes pl = alloc_planes((size_t)fp.M * fp.C);
+      out.pl_hi = pl.hi; out.pl_lo = pl.lo; fp.out_hi = pl.hi; fp.out_lo = pl.lo;
+    }
+    if (cat && nn.raw && !u->keep_intermediates && cat_drop_fp32) fp.out = nullptr;
+  }
+  bool ff_split_on = [] { const char* e = getenv("DVITS_FF_SPLIT"); return !(e && e[0] == '0'); }();
   bool gnx_ff_on = [] { const char* e = getenv("DVITS_GNX_FF"); return !(e && e[0] == '0'); }();
   bool cat_drop_fp32 = [] { const char* e = getenv("DVITS_GNX_CONCAT_KEEP_FP32"); return !(e && e[0] == '1'); }();
 
@@ -1270,6 +1295,63 @@ struct Builder {
         if (!dry) u->flops += cur_flops;
         const int pr = prec;
         emit(ops, [fp, pr](hipStream_t st) { return launch_chain_ff(fp, pr, st); });
+        ln_release(l3);
+        release(h3);
+        probe(p.substr(0, p.size() - 1), out.p, Tn, C);
+        return out;
+      }
+    }
+    // C = 256 / 384 blocks: the same three steps as ONE launch of 64-row blocks whose product columns are split over 4 / 8
+    // workgroups (k_ff_split, kernels_ffsplit.hip: partial ffproj sums handed over inside the launch - every workgroup resident,
+    // like the in-launch GroupNorm; DVITS_FF_SPLIT=0 restores the two GEMMs)
+    {
+      FFSplitParams fp{};
+      fp.M = M; fp.C = C; fp.T = Tp; fp.Tv = Tn; fp.nspl = C == 256 ? 4 : 8;
+      const size_t n_flags = ((size_t)(M / 64) * fp.nspl + 1) & ~(size_t)1;
+      if (ff_split_on && merged_ffproj && chain_on && gnx_on && u->exclusive && !arena.exact && !autotune_on() && l3.stat && x.stat16 &&
+          n_cu > 0 && (C == 256 || C == 384) && ff_split_supported(fp, prec) && (M / 64) * fp.nspl <= n_cu &&
+          gnx_used + n_flags <= dv_unet::GNX_POOL) {
+        const std::string mw = tb + "__ffproj.weight", mb = tb + "__ffproj.bias";
+        if (!dry && !u->packed.count(p + "ffproj")) {
+          const float* Wo = W(p + "proj_out.weight"); const float* W2 = W(tb + "ff.net.2.weight");
+          const float* bo = W(p + "proj_out.bias"); const float* b2 = W(tb + "ff.net.2.bias");
+          float* dw = derived(mw, {C, 4 * C});
+          float* db = derived(mb, {C});
+          if (!Wo || !W2 || !bo || !b2 || !dw || !db) return Act{};
+          (void)launch_matmul_f32(Wo, W2, dw, C, C, 4 * C, pack_stream);
+          (void)launch_fold_bias(Wo, bo, b2, db, C, C, 0, 0, pack_stream);
+        }
+        const PackedW* w_m = pack(p + "ffproj", C, 5 * C, {{p + "proj_out.weight", 1, C, 1, C, 0, 0, "", 0}, {mw, 0, 4 * C, 1, 4 * C, C, 0, "", 0}},
+                                  {{mb, "", "", "", C, 0, 0, 0}});
+        if (!w_m || !frag(w_gg) || !frag(w_m)) return Act{};
+        Act out{};
+        out.p = alloc((size_t)M * C); out.C = C; out.T = Tn; out.Tp = Tp; alloc_stat(out, true);
+        fp.a_hi = l3.pl.hi; fp.a_lo = l3.pl.lo; fp.rowstat = l3.stat; fp.ln_eps = 1e-5f;
+        fp.wg_hi = w_gg->fhi; fp.wg_lo = w_gg->flo; fp.bg = w_gg->bias; fp.ug = w_gg->u;
+        fp.wm_hi = w_m->fhi; fp.wm_lo = w_m->flo; fp.bm = w_m->bias;
+        fp.res = x.p; fp.out = out.p; fp.stats16 = out.stat16;
+        fp.flags = dry ? reinterpret_cast<unsigned long long*>(0x1000) : u->gnx_pool + gnx_used;
+        fp.status = dry ? reinterpret_cast<unsigned*>(0x1000) : u->gnx_status;
+        fp.spin_max = gnx_spin;
+        gnx_used += n_flags;
+        if (!dry) { u->gnx_words = gnx_used; u->gnx_ops++; }
+        fp.xbuf = alloc(ff_split_xbuf_floats(M, C, fp.nspl));
+        if (want_planes) {
+          Planes pl = alloc_planes((size_t)M * C);
+          out.pl_hi = pl.hi; out.pl_lo = pl.lo; fp.out_hi = pl.hi; fp.out_lo = pl.lo;
+        }
+        offer_next(fp, out);
+        cur_kind = "chain";
+        cur_flops = 2.0 * (double)M * C * (8.0 * C + 5.0 * C);
+        {
+          char buf[96];
+          snprintf(buf, sizeof(buf), "LN+GEGLU+ffproj+res%s (%d wg / 64 rows) M=%d C=%d", fp.gnx.xchg ? "+gnx" : "", fp.nspl, M, C);
+          cur_desc = buf;
+        }
+        if (!dry) u->flops += cur_flops;
+        const int pr = prec;
+        emit(ops, [fp, pr](hipStream_t st) { return launch_ff_split(fp, pr, st); });
+        release(fp.xbuf);
         ln_release(l3);
         release(h3);
         probe(p.substr(0, p.size() - 1), out.p, Tn, C);
@@ -1910,6 +1992,7 @@ extern "C" int dv_unet_prepare(dv_unet* u, int32_t B, int32_t T, int32_t L, int3
   gemm_env_refresh();
   HIPCHK(attn_init());
   HIPCHK(chain_init());
+  HIPCHK(ff_split_init());
   // a new shape re-plans the schedule; the packed weights survive unless the weights or the precision changed
   unet_release_prepared(u, !u->weights_dirty && u->packed_prec == precision);
   u->packed_prec = precision;

@@ -1,0 +1,493 @@
+// Feed-forward tail of a transformer block at C = 256 / 384 for gfx950 (MI355X) as ONE launch: LN3 -> GEGLU -> merged
+// ff.net.2 + proj_out + block residual (-> the consumer's GroupNorm), FFSplitParams in dv_common.h.  Reference:
+// unet1d/attention.py:189-203 (norm3, ff, residual), :206-255 / :280-301 (FeedForward, GEGLU), transformer_1d.py:300-326.
+//
+// Why not two GEMMs (rounds 1-4): 31.9 + 25.0 us (C = 256, M = 4096) and 35.4 + 28.8 us (C = 384, M = 2048) at the bench
+// shape, 0.59 ms = 19 % of a forward, with the 4C-wide GEGLU product making an HBM round trip between them.  Why not the
+// 32-row row-block kernel of the C = 128 blocks (k_chain_ff): a workgroup there streams ALL weights of the block - 3.3 / 7.6 MB
+// at these widths - for 32 rows.  This kernel keeps what makes the row-block form fast (the A operand resident in LDS, the
+// weights fragment-major straight into registers, no barrier in a k-loop, the product never leaves the CU) and fixes its
+// weight traffic twice over:
+//   * 64 rows per workgroup - two row fragments per weight fragment, half the weight bytes per MFMA;
+//   * the product columns are SPLIT over `nspl` workgroups per row block (4 at C = 256, 8 at C = 384: 256 workgroups at the
+//     bench shape), and workgroup id = row block * nspl + slice puts slice s on the XCDs x = s (mod nspl) only: an XCD's L2
+//     holds 1 / nspl of the weights and every CU of the XCD walks the same 0.8-0.9 MB.
+// The price is a reduction over the slices: every workgroup writes its partial ffproj sums through, raises a flag word, and
+// finishes C / nspl of the output columns once its row block's flags are up (reduce-scatter; partials summed in slice order:
+// deterministic).  That wait needs every workgroup of the launch resident at once - the planner checks (engine.hip), the wait
+// is bounded and flagged exactly like the in-launch GroupNorm's (gnx_device.h), and the engine's recovery path is the same.
+#include "dv_common.h"
+#include "dv_device.h"
+#include "gnx_device.h"
+
+#include <cstdlib>
+#include <type_traits>
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+#ifdef DV_GEMM_TRACE
+// development build only (make trace): per-workgroup s_memtime stamps of the phases (tools/ffsplit_trace.py)
+__device__ unsigned long long g_ffs_trace[1024 * 16];
+#define DV_FTRACE(i) do { if (threadIdx.x == 0 && blockIdx.x < 1024) g_ffs_trace[blockIdx.x * 16 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+extern "C" int dv_debug_ffs_trace(unsigned long long* host, int n_wg) {
+  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_ffs_trace), (size_t)n_wg * 16 * sizeof(unsigned long long));
+}
+#else
+#define DV_FTRACE(i) do {} while (0)
+#endif
+
+namespace {
+
+constexpr int BM = 64, NWV = 8, NT = 64 * NWV;
+constexpr int CHP = BM * 128;                       // bytes of one 64-channel chunk of one plane of a resident operand
+__device__ __forceinline__ int swz(int row) { return (row >> 1) & 7; }
+__device__ __forceinline__ unsigned pk(float lo, float hi) { return dv_cvt_pk_bf16(lo, hi); }
+struct BFrag { bf16x8 h, l; };
+
+template <int C, int NSPL>
+struct FFGeom {
+  static constexpr int KSA = C / 16;                               // k-steps of stage A (K = C)
+  static constexpr int PS = 4 * C / NSPL, UNITS = PS / 32;          // product columns of a slice; 32-column units ([32 a | 32 gate] packed blocks)
+  static constexpr int HS = C / NSPL, HKS = HS / 16, PKS = PS / 16; // the slice's share of h3's channels / k-steps of either part of stage B
+  static constexpr int KSB = HKS + PKS;                             // k-steps of stage B per workgroup
+  static constexpr int NF = C / 32, KSBW = 5 * C / 16;              // output column fragments; k-steps per row of the merged weights
+  static constexpr int KGB = NF > NWV ? 2 : 1;                      // k-groups of stage B (C = 384: 4 column groups x 2 k-groups)
+  static constexpr int NFW = NF / (NWV / KGB);                      // column fragments per wave in stage B
+  static constexpr int NSRC = NSPL * KGB;                           // partial sums per output element
+  static constexpr int BNF = C / NSPL, HFT = BNF / 16;              // finishing tile: columns / 16-column blocks
+  static constexpr int A_CH = C / 64, A_PL = A_CH * CHP, G_CH = PS / 64, G_PL = G_CH * CHP;
+  static constexpr int SMEM = 2 * A_PL + 2 * G_PL;
+  static constexpr int DA = 8, DB = NFW == 1 ? 8 : 6;               // weight units (hi + lo fragment: 8 VGPRs) in flight per wave
+  static_assert(UNITS <= NWV && PS % 64 == 0 && HS % 16 == 0 && NF % (NWV / KGB) == 0 && BNF % 16 == 0 && HFT * 2 <= NWV, "geometry");
+};
+
+template <int C, int NSPL>
+__global__ __launch_bounds__(NT) void k_ff_split(const FFSplitParams p) {
+  using G = FFGeom<C, NSPL>;
+  extern __shared__ __attribute__((aligned(1024))) char smem[];
+  char* const a_reg = smem;                                  // h3:      [2 planes][C / 64 chunks][64 rows][128 B]
+  char* const g_reg = smem + 2 * G::A_PL;                    // product: [2 planes][PS / 64 chunks][64 rows][128 B]
+  __shared__ __attribute__((aligned(16))) float2 s_ln[BM];
+  __shared__ __attribute__((aligned(16))) float s_ug[G::UNITS * 64], s_bg[G::UNITS * 64];
+  __shared__ GnxShared<64> s_gnx;
+  __shared__ __attribute__((aligned(256))) unsigned s_pf[64];
+  // (every 64-byte line of the argument block is requested at once: see k_gemm)
+  asm volatile("" ::"s"(p.M), "s"(p.rowstat), "s"(p.wg_lo), "s"(p.wm_hi), "s"(p.res), "s"(p.out_lo), "s"(p.flags), "s"(p.gnx.xchg),
+               "s"(p.gnx.y_hi), "s"(p.gnx.sk_x), "s"(p.gnx.sk_raw_lo));
+  DV_FTRACE(0);
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, lh = lane >> 5;
+  const int rb = (int)blockIdx.x / NSPL, s = (int)blockIdx.x - rb * NSPL;
+  const int m0 = rb * BM;
+  const unsigned a_base = (unsigned)(size_t)a_reg;
+
+  // ---- h3 planes -> LDS by LDS-DMA: instruction = (64-channel chunk, 8 rows) of one plane ----
+  {
+    const int d_row = lane >> 3, d_slot = lane & 7;
+    for (int idx = wave; idx < G::A_CH * 8; idx += NWV) {
+      const int c = idx >> 3, r8 = idx & 7, row = r8 * 8 + d_row;
+      const size_t e = (size_t)(m0 + row) * C + c * 64 + ((d_slot ^ swz(row)) << 3);
+      const unsigned dst = a_base + (unsigned)(c * CHP + r8 * 1024);
+      glds16(p.a_hi + e, dst);
+      glds16(p.a_lo + e, dst + G::A_PL);
+    }
+  }
+  // ---- stage A weights: unit U = k-step * 2 + f (f: 0 = the `a` fragment, 1 = the gate fragment of this wave's 32 product columns) ----
+  constexpr int UA = 2 * G::KSA;
+  const bool a_wave = wave < G::UNITS;
+  const int unit = s * G::UNITS + (a_wave ? wave : 0);       // packed 64-column block of the GEGLU weights
+  auto load_a_unit = [&](int U) __attribute__((always_inline)) {
+    const int nf = 2 * unit + (U & 1), ks = U >> 1;
+    const size_t e = ((size_t)(nf * G::KSA + ks) * 64 + lane) * 8;
+    BFrag f;
+    f.h = *reinterpret_cast<const bf16x8*>(p.wg_hi + e);
+    f.l = *reinterpret_cast<const bf16x8*>(p.wg_lo + e);
+    return f;
+  };
+  BFrag bq[G::DA > G::DB ? G::DA : G::DB];
+  if (a_wave) {
+#pragma unroll
+    for (int j = 0; j < G::DA; ++j) bq[j] = load_a_unit(j);
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  // LayerNorm finish vectors of the slice's packed columns, the rows' (mean, rstd) from the producer's partials
+  for (int i = tid; i < G::UNITS * 64; i += NT) {
+    s_ug[i] = p.ug[(size_t)s * G::UNITS * 64 + i];
+    s_bg[i] = p.bg[(size_t)s * G::UNITS * 64 + i];
+  }
+  if (tid < BM) {
+    constexpr int NB = C / 32;
+    const float2* src = reinterpret_cast<const float2*>(p.rowstat) + (size_t)(m0 + tid) * NB;
+    float2 v[NB];
+#pragma unroll
+    for (int k = 0; k < NB; ++k) v[k] = src[k];
+    float s1 = 0.f;
+#pragma unroll
+    for (int k = 0; k < NB; ++k) s1 += v[k].x;
+    const float inv_c = 1.0f / (float)C, mean = s1 * inv_c;
+    float m2 = 0.f;
+#pragma unroll
+    for (int k = 0; k < NB; ++k) { const float dm = v[k].x * (1.0f / 32.0f) - mean; m2 += v[k].y + 32.0f * dm * dm; }
+    s_ln[tid] = make_float2(mean, 1.0f / sqrtf(m2 * inv_c + p.ln_eps));
+  }
+  // ---- L2 prefetch: the workgroups of an XCD (id % 8 - a speed assumption only) all read slice s of both weight matrices;
+  //      each touches a share of its lines at launch (one 128-byte line per lane, LDS-DMA into a scratch word), so the L2
+  //      fills with thousands of requests in flight while the compute waves start on their first fragments (see k_chain2) ----
+  {
+    constexpr int LG = G::UNITS * 2 * G::KSA * 8, LM = G::NF * G::KSB * 8;    // 128-byte lines per plane of this slice
+    const int xw = (int)blockIdx.x >> 3, nxw = ((int)gridDim.x + 7) >> 3;
+    const int total = 2 * (LG + LM), per = (total + nxw - 1) / nxw, end = min(total, (xw + 1) * per);
+    for (int ln = xw * per + tid; ln < end; ln += NT) {
+      const char* src;
+      if (ln < 2 * LG) {
+        const int pl = ln >= LG, r = ln - pl * LG;
+        src = reinterpret_cast<const char*>(pl ? p.wg_lo : p.wg_hi) + ((size_t)s * LG + r) * 128;
+      } else {
+        const int l2 = ln - 2 * LG, pl = l2 >= LM, r = l2 - pl * LM;
+        const int nf = r / (G::KSB * 8), q = r - nf * (G::KSB * 8), kk = q >> 3, sub = q & 7;
+        const int ksw = kk < G::HKS ? s * G::HKS + kk : G::KSA + s * G::PKS + (kk - G::HKS);
+        src = reinterpret_cast<const char*>(pl ? p.wm_lo : p.wm_hi) + ((size_t)(nf * G::KSBW + ksw) * 8 + sub) * 128;
+      }
+      glds4(src, (unsigned)(size_t)s_pf);
+    }
+  }
+  DV_FTRACE(1);
+  wait_vmcnt<0>();
+  __syncthreads();
+  DV_FTRACE(2);
+
+  // A fragments (both row fragments, both planes) of k-step `ks` of a resident operand
+  auto read_frag = [&](const char* reg, int pl_bytes, int ks, bf16x8 (&h)[2], bf16x8 (&l)[2]) __attribute__((always_inline)) {
+    const int c16 = ks * 2 + lh;
+#pragma unroll
+    for (int rf = 0; rf < 2; ++rf) {
+      const int row = rf * 32 + l31;
+      const int off = (c16 >> 3) * CHP + row * 128 + (((c16 & 7) ^ swz(row)) << 4);
+      h[rf] = *reinterpret_cast<const bf16x8*>(reg + off);
+      l[rf] = *reinterpret_cast<const bf16x8*>(reg + pl_bytes + off);
+    }
+  };
+  auto mfma3 = [&](f32x16& acc, const BFrag& f, const bf16x8& ah, const bf16x8& al) __attribute__((always_inline)) {
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.h, al, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.l, ah, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.h, ah, acc, 0, 0, 0);
+  };
+
+  // ================= stage A: GEGLU of this wave's 32 product columns, both row fragments =================
+  if (a_wave) {
+    f32x16 acc[2][2];                                        // [a | gate][row fragment]
+#pragma unroll
+    for (int f = 0; f < 2; ++f)
+#pragma unroll
+      for (int rf = 0; rf < 2; ++rf)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[f][rf][r] = 0.f;
+    bf16x8 ah[2][2], al[2][2];
+    read_frag(a_reg, G::A_PL, 0, ah[0], al[0]);
+#pragma unroll
+    for (int U = 0; U < UA; ++U) {
+      const int ks = U >> 1, f = U & 1, cur = ks & 1;
+      if (f == 0 && ks + 1 < G::KSA) read_frag(a_reg, G::A_PL, ks + 1, ah[cur ^ 1], al[cur ^ 1]);
+      const BFrag w = bq[U % G::DA];
+      // (the two row fragments alternate: consecutive MFMAs write different accumulators)
+      acc[f][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.h, al[cur][0], acc[f][0], 0, 0, 0);
+      acc[f][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.h, al[cur][1], acc[f][1], 0, 0, 0);
+      acc[f][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.l, ah[cur][0], acc[f][0], 0, 0, 0);
+      acc[f][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.l, ah[cur][1], acc[f][1], 0, 0, 0);
+      acc[f][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.h, ah[cur][0], acc[f][0], 0, 0, 0);
+      acc[f][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.h, ah[cur][1], acc[f][1], 0, 0, 0);
+      // pinned: without the scheduling barriers hipcc sinks every prefetch down to its use (load -> vmcnt(0) -> MFMA)
+      __builtin_amdgcn_sched_barrier(0);
+      if (U + G::DA < UA) bq[U % G::DA] = load_a_unit(U + G::DA);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    DV_FTRACE(3);
+    // LayerNorm finish + bias, a * gelu(gate) -> product columns wave * 32 + (8g + 4lh + e) of the slice as split planes in LDS
+#pragma unroll
+    for (int rf = 0; rf < 2; ++rf) {
+      const int row = rf * 32 + l31;
+      const float2 st = s_ln[row];
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int cl = 8 * g + 4 * lh;
+        const float4 ua = *reinterpret_cast<const float4*>(s_ug + wave * 64 + cl), ugt = *reinterpret_cast<const float4*>(s_ug + wave * 64 + 32 + cl);
+        const float4 ba = *reinterpret_cast<const float4*>(s_bg + wave * 64 + cl), bgt = *reinterpret_cast<const float4*>(s_bg + wave * 64 + 32 + cl);
+        const float ua_[4] = {ua.x, ua.y, ua.z, ua.w}, ug_[4] = {ugt.x, ugt.y, ugt.z, ugt.w};
+        const float ba_[4] = {ba.x, ba.y, ba.z, ba.w}, bg_[4] = {bgt.x, bgt.y, bgt.z, bgt.w};
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float a = st.y * (acc[0][rf][4 * g + e] - st.x * ua_[e]) + ba_[e];
+          const float gt = st.y * (acc[1][rf][4 * g + e] - st.x * ug_[e]) + bg_[e];
+          v[e] = a * gelu_erf(gt);
+        }
+        uint2 hw, lw;
+        hw.x = pk(v[0], v[1]); hw.y = pk(v[2], v[3]);
+        lw.x = pk(v[0] - __uint_as_float(hw.x << 16), v[1] - __uint_as_float(hw.x & 0xffff0000u));
+        lw.y = pk(v[2] - __uint_as_float(hw.y << 16), v[3] - __uint_as_float(hw.y & 0xffff0000u));
+        const int n = wave * 32 + cl, c = n >> 6, s16 = (n & 63) >> 3;
+        const int off = c * CHP + row * 128 + ((s16 ^ swz(row)) << 4) + ((n & 7) >> 2) * 8;
+        *reinterpret_cast<uint2*>(g_reg + off) = hw;
+        *reinterpret_cast<uint2*>(g_reg + G::G_PL + off) = lw;
+      }
+    }
+  }
+  DV_FTRACE(4);
+
+  // ================= stage B: partial ffproj over [this slice's channels of h3 | its product columns], all C output columns ==========
+  // wave -> NFW column fragments from cf0 and k-group kg (KGB = 2: 4 column groups x 2 halves of the k-steps)
+  const int kg = G::KGB == 1 ? 0 : wave >> 2;
+  const int cf0 = G::KGB == 1 ? wave : (wave & 3) * G::NFW;
+  f32x16 accb[G::NFW][2];
+#pragma unroll
+  for (int i = 0; i < G::NFW; ++i)
+#pragma unroll
+    for (int rf = 0; rf < 2; ++rf)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) accb[i][rf][r] = 0.f;
+  auto load_b_unit = [&](int j, int i) __attribute__((always_inline)) {        // k-step j of the workgroup's range, fragment cf0 + i
+    const int ksw = j < G::HKS ? s * G::HKS + j : G::KSA + s * G::PKS + (j - G::HKS);
+    const size_t e = ((size_t)((cf0 + i) * G::KSBW + ksw) * 64 + lane) * 8;
+    BFrag f;
+    f.h = *reinterpret_cast<const bf16x8*>(p.wm_hi + e);
+    f.l = *reinterpret_cast<const bf16x8*>(p.wm_lo + e);
+    return f;
+  };
+  auto b_prologue = [&](auto kg_tag) __attribute__((always_inline)) {
+    constexpr int KG = decltype(kg_tag)::value;
+    constexpr int J0 = KG == 0 ? 0 : (G::KSB + 1) / 2;
+    constexpr int JN = G::KGB == 1 ? G::KSB : (KG == 0 ? (G::KSB + 1) / 2 : G::KSB / 2);
+#pragma unroll
+    for (int u = 0; u < G::DB; ++u)
+      if (u < JN * G::NFW) bq[u] = load_b_unit(J0 + u / G::NFW, u % G::NFW);
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  auto b_loop = [&](auto kg_tag) __attribute__((always_inline)) {
+    constexpr int KG = decltype(kg_tag)::value;
+    constexpr int J0 = KG == 0 ? 0 : (G::KSB + 1) / 2;
+    constexpr int JN = G::KGB == 1 ? G::KSB : (KG == 0 ? (G::KSB + 1) / 2 : G::KSB / 2);
+    constexpr int UB = JN * G::NFW;
+    auto read_b = [&](int j, bf16x8 (&h)[2], bf16x8 (&l)[2]) __attribute__((always_inline)) {
+      if (j < G::HKS) read_frag(a_reg, G::A_PL, s * G::HKS + j, h, l);
+      else read_frag(g_reg, G::G_PL, j - G::HKS, h, l);
+    };
+    bf16x8 ah[2][2], al[2][2];
+    read_b(J0, ah[0], al[0]);
+#pragma unroll
+    for (int u = 0; u < UB; ++u) {
+      const int jj = u / G::NFW, i = u % G::NFW, cur = jj & 1;
+      if (i == 0 && jj + 1 < JN) read_b(J0 + jj + 1, ah[cur ^ 1], al[cur ^ 1]);
+      const BFrag w = bq[u % G::DB];
+      accb[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.h, al[cur][0], accb[i][0], 0, 0, 0);
+      accb[i][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.h, al[cur][1], accb[i][1], 0, 0, 0);
+      accb[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.l, ah[cur][0], accb[i][0], 0, 0, 0);
+      accb[i][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.l, ah[cur][1], accb[i][1], 0, 0, 0);
+      accb[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.h, ah[cur][0], accb[i][0], 0, 0, 0);
+      accb[i][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.h, ah[cur][1], accb[i][1], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      if (u + G::DB < UB) bq[u % G::DB] = load_b_unit(J0 + (u + G::DB) / G::NFW, (u + G::DB) % G::NFW);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+  if (kg == 0) b_prologue(std::integral_constant<int, 0>{});
+  else b_prologue(std::integral_constant<int, 1>{});
+  // the finishing waves' bias / residual (cold rows) are requested under stage B
+  const bool fin = wave < G::HFT * 2;
+  const int f_rf = wave & 1, f_hf = s * G::HFT + (wave >> 1);       // finishing unit: row fragment, 16-column block of the output
+  const int f_m = m0 + f_rf * 32 + l31;
+  float4 rres[2], rbias[2];
+  if (fin) {
+    const float* rp = p.res + (size_t)f_m * C + f_hf * 16 + 4 * lh;
+    rres[0] = *reinterpret_cast<const float4*>(rp); rres[1] = *reinterpret_cast<const float4*>(rp + 8);
+    rbias[0] = *reinterpret_cast<const float4*>(p.bm + f_hf * 16 + 4 * lh); rbias[1] = *reinterpret_cast<const float4*>(p.bm + f_hf * 16 + 4 * lh + 8);
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  __syncthreads();                                           // product planes complete
+  DV_FTRACE(5);
+  if (kg == 0) b_loop(std::integral_constant<int, 0>{});
+  else b_loop(std::integral_constant<int, 1>{});
+  DV_FTRACE(6);
+
+  // ================= hand-over: partial sums written through, flag, wait for the row block, finish C / nspl columns =================
+  // xbuf (float4 units): [row block][16-column block hf][source][row fragment][gg][64 lanes]; register group g of column fragment cf
+  // is 16-column block 2 cf + (g >> 1), half gg = g & 1 (columns 8 gg + 4 lh + e of the block)
+  float4* const xb = reinterpret_cast<float4*>(p.xbuf) + (size_t)rb * (2 * G::NF) * G::NSRC * 4 * 64 + lane;
+  {
+    const int src = s * G::KGB + kg;
+#pragma unroll
+    for (int i = 0; i < G::NFW; ++i)
+#pragma unroll
+      for (int rf = 0; rf < 2; ++rf)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int hf = 2 * (cf0 + i) + (g >> 1);
+          st_handover16(xb + ((size_t)((hf * G::NSRC + src) * 2 + rf) * 2 + (g & 1)) * 64,
+                        make_float4(accb[i][rf][4 * g], accb[i][rf][4 * g + 1], accb[i][rf][4 * g + 2], accb[i][rf][4 * g + 3]));
+        }
+    wait_vmcnt<0>();                                         // this thread's partial sums have been written through
+  }
+  __syncthreads();
+  if (tid == 0) __hip_atomic_store(p.flags + (size_t)rb * NSPL + s, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  DV_FTRACE(7);
+  const int b_item = m0 / p.T, Tv = p.Tv > 0 ? p.Tv : p.T;
+  const int t_row = f_m - b_item * p.T;
+  const bool m_ok = t_row < Tv;                              // a frame that exists (padded row spaces: dv_common.h)
+  float vv[8];
+#pragma unroll
+  for (int r = 0; r < 8; ++r) vv[r] = 0.f;
+  if (fin) {
+    // wait for the flags of this row block (every wave polls for itself: no barrier behind the wait); bounded and flagged
+    {
+      const unsigned long long* fl = p.flags + (size_t)rb * NSPL;
+      for (int spins = 0;; ++spins) {
+        bool ok = true;
+        if (lane < NSPL) ok = __hip_atomic_load(fl + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != ~0ull;
+        if (__all(ok)) break;
+        const bool lost = (spins & 63) == 63 && __hip_atomic_load(p.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u;
+        if (lost) break;
+        if (spins > p.spin_max) {
+          if (lane == 0) {
+            p.status[1] = (unsigned)(size_t)p.flags; p.status[2] = blockIdx.x; p.status[3] = 0xff5u; p.status[4] = (unsigned)__builtin_popcountll(__ballot(!ok));
+            __hip_atomic_store(p.status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+          }
+          break;
+        }
+        __builtin_amdgcn_s_sleep(1);
+      }
+      asm volatile("" ::: "memory");
+    }
+    DV_FTRACE(8);
+    // partial sums of this unit's 32 x 16 block, in source order (slice, k-group): the same bits on every run
+    const float4* src0 = xb + (size_t)(f_hf * G::NSRC * 2 + f_rf) * 2 * 64;
+    constexpr int BATCH = G::NSRC < 8 ? G::NSRC : 8;
+#pragma unroll
+    for (int s0 = 0; s0 < G::NSRC; s0 += BATCH) {
+      float4 t[BATCH][2];
+#pragma unroll
+      for (int k = 0; k < BATCH; ++k)
+#pragma unroll
+        for (int gg = 0; gg < 2; ++gg) t[k][gg] = ld_handover16(src0 + ((size_t)(s0 + k) * 4 + gg) * 64);
+#pragma unroll
+      for (int k = 0; k < BATCH; ++k)
+#pragma unroll
+        for (int gg = 0; gg < 2; ++gg) {
+          vv[4 * gg] += t[k][gg].x; vv[4 * gg + 1] += t[k][gg].y; vv[4 * gg + 2] += t[k][gg].z; vv[4 * gg + 3] += t[k][gg].w;
+        }
+    }
+#pragma unroll
+    for (int gg = 0; gg < 2; ++gg) {
+      vv[4 * gg] += rbias[gg].x + rres[gg].x; vv[4 * gg + 1] += rbias[gg].y + rres[gg].y;
+      vv[4 * gg + 2] += rbias[gg].z + rres[gg].z; vv[4 * gg + 3] += rbias[gg].w + rres[gg].w;
+    }
+#pragma unroll
+    for (int r = 0; r < 8; ++r) vv[r] = m_ok ? vv[r] : 0.f;     // (padding rows are stored as zeros)
+    DV_FTRACE(9);
+    if (p.stats16) {   // this unit's 32 x 16 block: (sum, squared deviations about its own mean) over the frames that exist
+      const int cnt = min(32, Tv - (m0 + f_rf * 32 - b_item * p.T));
+      float a1 = 0.f, a2 = 0.f;
+#pragma unroll
+      for (int r = 0; r < 8; ++r) a1 += vv[r];
+      a1 = wave_sum64(a1);
+      const float mb = cnt == 32 ? a1 * (1.0f / 512.0f) : a1 / (float)(16 * cnt);
+#pragma unroll
+      for (int r = 0; r < 8; ++r) { const float dv = m_ok ? vv[r] - mb : 0.f; a2 = fmaf(dv, dv, a2); }
+      a2 = wave_sum64(a2);
+      if (lane == 0) {
+        const size_t e = (size_t)((m0 >> 5) + f_rf) * (C >> 4) + f_hf;
+        reinterpret_cast<float2*>(p.stats16)[e] = make_float2(a1, a2);
+        if (p.gnx.xchg)    // for the other workgroups of the launch: one 8-byte word (sum, M2), written through
+          __hip_atomic_store(p.gnx.xchg + e, (unsigned long long)__float_as_uint(a1) | ((unsigned long long)__float_as_uint(a2) << 32),
+                             __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
+    }
+    // (the statistics go out FIRST: other workgroups wait for them, nobody waits for these stores)
+    const size_t ob = (size_t)f_m * C + f_hf * 16;
+    if (p.out) {
+#pragma unroll
+      for (int gg = 0; gg < 2; ++gg)
+        dv_st16(p.out + ob + 4 * lh + 8 * gg, make_float4(vv[4 * gg], vv[4 * gg + 1], vv[4 * gg + 2], vv[4 * gg + 3]));
+    }
+    if (p.out_hi) store_planes8(p.out_hi, p.out_lo, ob, lh, vv);
+  }
+  DV_FTRACE(10);
+  if (p.gnx.xchg) {
+    // ---- the consumer's GroupNorm (+ SiLU) of this block's output, a concatenated skip tensor included (gnx_device.h): the
+    //      workgroup's finishing tile [64 rows x C / nspl columns] is treated exactly like a GEMM tile ----
+    GnxTile t;
+    t.M = p.M; t.N = C; t.T_out = p.T; t.Tv_out = Tv; t.m0 = m0; t.n0 = s * G::BNF; t.bm = BM; t.bn = G::BNF; t.bq = b_item;
+    gnx_finish_table<64>(p.gnx, t, s_gnx, tid, lane, wave, NWV, [](int) {});
+    if (fin) {
+      const int cl0 = (wave >> 1) * 16 + 4 * lh;             // tile-local column of gg = 0, e = 0
+      float y[8];
+#pragma unroll
+      for (int gg = 0; gg < 2; ++gg) {
+        const float4 sa = *reinterpret_cast<const float4*>(s_gnx.gA + cl0 + 8 * gg);
+        const float4 sb = *reinterpret_cast<const float4*>(s_gnx.gB + cl0 + 8 * gg);
+        y[4 * gg] = fmaf(vv[4 * gg], sa.x, sb.x); y[4 * gg + 1] = fmaf(vv[4 * gg + 1], sa.y, sb.y);
+        y[4 * gg + 2] = fmaf(vv[4 * gg + 2], sa.z, sb.z); y[4 * gg + 3] = fmaf(vv[4 * gg + 3], sa.w, sb.w);
+      }
+      if (p.gnx.silu) {
+#pragma unroll
+        for (int r = 0; r < 8; ++r) y[r] = y[r] * __builtin_amdgcn_rcpf(1.0f + __expf(-y[r]));
+      }
+      store_planes8(p.gnx.y_hi, p.gnx.y_lo, (size_t)f_m * C + f_hf * 16, lh, y);
+    }
+  }
+  DV_FTRACE(11);
+}
+
+template <int C, int NSPL>
+hipError_t ffs_init_one() {
+  return hipFuncSetAttribute(reinterpret_cast<const void*>(k_ff_split<C, NSPL>), hipFuncAttributeMaxDynamicSharedMemorySize, FFGeom<C, NSPL>::SMEM);
+}
+template <int C, int NSPL>
+hipError_t ffs_launch_one(const FFSplitParams& p, hipStream_t st) {
+  constexpr int smem = FFGeom<C, NSPL>::SMEM;
+  hipLaunchKernelGGL((k_ff_split<C, NSPL>), dim3((p.M / BM) * NSPL), dim3(NT), smem, st, p);
+  return hipGetLastError();
+}
+
+}  // namespace
+
+hipError_t ff_split_init() {
+  hipError_t e = ffs_init_one<256, 4>();
+  return e != hipSuccess ? e : ffs_init_one<384, 8>();
+}
+
+bool ff_split_supported(const FFSplitParams& p, int precision) {
+  if (precision != 0) return false;                                  // split-bf16 mode only
+  if (!((p.C == 256 && p.nspl == 4) || (p.C == 384 && p.nspl == 8))) return false;
+  if (p.M % BM != 0 || p.T % BM != 0 || p.M % p.T != 0) return false;   // (a 64-row block never spans two utterances)
+  if (p.Tv < 0 || p.Tv > p.T || (p.Tv > 0 && p.Tv <= p.T - 32)) return false;
+  return true;
+}
+size_t ff_split_xbuf_floats(int M, int C, int nspl) {
+  const int nsrc = nspl * (C / 32 > NWV ? 2 : 1);
+  return (size_t)(M / BM) * (2 * (C / 32)) * nsrc * 4 * 64 * 4;
+}
+// In-launch GroupNorm of the output: the finishing tiles ([64 rows x C / nspl columns], all resident) behave like GEMM tiles
+// (the conditions of gemm_gnx_plan, kernels_gemm.hip)
+int ff_split_gnx_plan(const FFSplitParams& p, int n_cu) {
+  const GnxParams& gx = p.gnx;
+  if (!p.stats16 || gx.groups <= 0 || gx.groups > 64 || gx.sk_c < 0 || gx.sk_c % 16 != 0 || gx.tscale) return 0;
+  if ((p.C + gx.sk_c) % gx.groups != 0) return 0;
+  const int cpg = (p.C + gx.sk_c) / gx.groups;
+  if (cpg % 16 != 0 || (p.T / 32) * (cpg / 16) > 256 || (p.M / BM) * p.nspl > n_cu) return 0;
+  if (gx.sk_c > 0 && ((gx.sk_c / 16 + p.nspl - 1) / p.nspl) * 16 > DV_GSK) return 0;   // skip slice per workgroup
+  return (p.M / 32) * (p.C / 16);
+}
+
+hipError_t launch_ff_split(const FFSplitParams& p, int precision, hipStream_t st) {
+  if (!ff_split_supported(p, precision)) return hipErrorInvalidValue;
+  if (!p.a_hi || !p.a_lo || !p.rowstat || !p.wg_hi || !p.wg_lo || !p.bg || !p.ug || !p.wm_hi || !p.wm_lo || !p.bm || !p.res || !p.xbuf ||
+      !p.flags || !p.status || (p.out_hi && !p.out_lo))
+    return hipErrorInvalidValue;
+  static const int n_cu = [] { int d = 0, n = 0; (void)hipGetDevice(&d); (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, d); return n; }();
+  if ((p.M / BM) * p.nspl > n_cu) return hipErrorInvalidValue;       // (every workgroup of the launch resident at once)
+  if (p.gnx.xchg) {
+    if (!p.gnx.status || !p.gnx.y_hi || !p.gnx.y_lo || !p.gnx.gamma || !p.gnx.beta || ff_split_gnx_plan(p, n_cu) <= 0) return hipErrorInvalidValue;
+    if (p.gnx.sk_c > 0 && (!p.gnx.sk_x || !p.gnx.sk_stat16 || !p.gnx.sk_y_hi || !p.gnx.sk_y_lo)) return hipErrorInvalidValue;
+  } else if (!p.out) return hipErrorInvalidValue;
+  return p.C == 256 ? ffs_launch_one<256, 4>(p, st) : ffs_launch_one<384, 8>(p, st);
+}

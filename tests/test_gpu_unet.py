@@ -787,6 +787,48 @@ def test_concat_groupnorm_finished_by_the_producer_of_h(B, T, L):
     assert rel_l2(outs[1], outs[0]) < 2e-5
 
 
+@pytest.mark.parametrize("B,T,L", [(8, 1024, 64), (2, 512, 40), (2, 500, 33), (4, 256, 20)])
+def test_split_feed_forward_launch_matches_two_gemms(B, T, L):
+    """C = 256 / 384 transformer blocks (reference attention.py:189-203, 206-255): LN3 -> GEGLU -> merged ff.net.2 + proj_out +
+    residual runs as ONE launch of 64-row blocks whose product columns are split over 4 / 8 workgroups (k_ff_split,
+    kernels_ffsplit.hip: partial sums handed over inside the launch, summed in slice order).  DVITS_FF_SPLIT=0 restores the two
+    GEMMs: same weights, same split-bf16 products, another summation order - float32-rounding agreement, fewer launches,
+    bit-repeatable, no hand-over timed out; at the bench shape (256 workgroups = every CU), at small grids and at a padded
+    length (T = 500: 250 / 125 frames at the two levels, row pitch 256 / 128)."""
+    from diff_vits_amd import synth
+    from diff_vits_amd.unet1d.unet_1d_condition import UNet1DConditionModel
+    kw = UNET_CASES["cfg1"][0]
+    with torch.device("meta"):
+        shapes = {k: tuple(v.shape) for k, v in UNet1DConditionModel(**kw).state_dict().items()}
+    sd = {k: torch.from_numpy(v) for k, v in synth.make_state_dict(shapes, seed=515).items()}
+    x = torch.from_numpy(synth.normal(15, "x", (B, 80, T))).cuda()
+    cond = torch.from_numpy(synth.normal(15, "c", (B, 128, T))).cuda()
+    enc = torch.from_numpy(synth.normal(15, "e", (B, L, 128))).cuda()
+    t = torch.linspace(900.0, 20.0, B, device="cuda")
+    outs, launches = [], []
+    for on in ("0", "1"):
+        os.environ["DVITS_FF_SPLIT"] = on
+        try:
+            m = UNet1DConditionModel(**kw).eval()
+            m.load_state_dict(sd)
+            eng = m.cuda().hip_engine()
+            eng.sync_weights()
+            eng.prepare(B, T, L)
+            eng.set_cond(enc, None)
+            y = eng.eval(x, cond, t).clone()
+            assert torch.equal(eng.eval(x, cond, t), y)
+            torch.cuda.synchronize()
+            n_ops, bad = eng.handover_status()
+            assert bad == 0 and n_ops > 0, (n_ops, bad)
+            outs.append(y.cpu().numpy())
+            launches.append(eng.stats()[0])
+        finally:
+            os.environ.pop("DVITS_FF_SPLIT", None)
+    assert launches[1] == launches[0] - 10, launches          # ten blocks at C = 256 / 384: two launches -> one
+    assert np.isfinite(outs[1]).all()
+    assert rel_l2(outs[1], outs[0]) < 2e-5, rel_l2(outs[1], outs[0])
+
+
 @pytest.mark.parametrize("B,T,L", [(16, 128, 40), (3, 256, 77), (1, 64, 10), (2, 2048, 300), (5, 512, 256), (1, 320, 150)])
 def test_fused_schedule_matches_plain_schedule_across_shapes(B, T, L):
     """The round-2 schedule (GroupNorm in the producer's epilogue, fragment attention, row-block chains shared out over
