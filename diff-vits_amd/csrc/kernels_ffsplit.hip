@@ -29,7 +29,14 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 #ifdef DV_GEMM_TRACE
 // development build only (make trace): per-workgroup s_memtime stamps of the phases (tools/ffsplit_trace.py)
 __device__ unsigned long long g_ffs_trace[1024 * 16];
-#define DV_FTRACE(i) do { if (threadIdx.x == 0 && blockIdx.x < 1024) g_ffs_trace[blockIdx.x * 16 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+__device__ int g_ffs_sel = 0;                      // which launches stamp: C (0 = any) - set by the tool
+#define DV_FTRACE(i) do { if (threadIdx.x == 0 && blockIdx.x < 1024 && (g_ffs_sel == 0 || g_ffs_sel == p.C)) g_ffs_trace[blockIdx.x * 16 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+extern "C" int dv_debug_ffs_trace_select(int C) {
+  hipError_t e = hipMemcpyToSymbol(HIP_SYMBOL(g_ffs_sel), &C, sizeof(C));
+  void* d = nullptr;
+  if (e == hipSuccess) e = hipGetSymbolAddress(&d, HIP_SYMBOL(g_ffs_trace));
+  return (int)(e != hipSuccess ? e : hipMemset(d, 0, sizeof(g_ffs_trace)));
+}
 extern "C" int dv_debug_ffs_trace(unsigned long long* host, int n_wg) {
   return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_ffs_trace), (size_t)n_wg * 16 * sizeof(unsigned long long));
 }
@@ -54,10 +61,11 @@ struct FFGeom {
   static constexpr int NF = C / 32, KSBW = 5 * C / 16;              // output column fragments; k-steps per row of the merged weights
   static constexpr int KGB = NF > NWV ? 2 : 1;                      // k-groups of stage B (C = 384: 4 column groups x 2 k-groups)
   static constexpr int NFW = NF / (NWV / KGB);                      // column fragments per wave in stage B
-  static constexpr int NSRC = NSPL * KGB;                           // partial sums per output element
+  static constexpr int NSRC = NSPL;                                 // partial sums per output element (the k-groups of stage B are added through LDS first)
   static constexpr int BNF = C / NSPL, HFT = BNF / 16;              // finishing tile: columns / 16-column blocks
   static constexpr int A_CH = C / 64, A_PL = A_CH * CHP, G_CH = PS / 64, G_PL = G_CH * CHP;
   static constexpr int SMEM = 2 * A_PL + 2 * G_PL;
+  static_assert(KGB == 1 || 2 * 4 * NFW * 4 * 64 * 16 <= 2 * A_PL, "k-group exchange of stage B fits the h3 region");
   static constexpr int DA = 8, DB = NFW == 1 ? 8 : 6;               // weight units (hi + lo fragment: 8 VGPRs) in flight per wave
   static_assert(UNITS <= NWV && PS % 64 == 0 && HS % 16 == 0 && NF % (NWV / KGB) == 0 && BNF % 16 == 0 && HFT * 2 <= NWV, "geometry");
 };
@@ -68,8 +76,9 @@ __global__ __launch_bounds__(NT) void k_ff_split(const FFSplitParams p) {
   extern __shared__ __attribute__((aligned(1024))) char smem[];
   char* const a_reg = smem;                                  // h3:      [2 planes][C / 64 chunks][64 rows][128 B]
   char* const g_reg = smem + 2 * G::A_PL;                    // product: [2 planes][PS / 64 chunks][64 rows][128 B]
-  __shared__ __attribute__((aligned(16))) float2 s_ln[BM];
-  __shared__ __attribute__((aligned(16))) float s_ug[G::UNITS * 64], s_bg[G::UNITS * 64];
+  constexpr int NB = C / 32;                                 // LayerNorm row partials per row
+  __shared__ __attribute__((aligned(1024))) float2 s_rs[BM * NB];           // the rows' raw partials (sum, M2 about the block mean)
+  __shared__ __attribute__((aligned(256))) float s_ug[G::UNITS * 64], s_bg[G::UNITS * 64];
   __shared__ GnxShared<64> s_gnx;
   __shared__ __attribute__((aligned(256))) unsigned s_pf[64];
   // (every 64-byte line of the argument block is requested at once: see k_gemm)
@@ -82,21 +91,19 @@ __global__ __launch_bounds__(NT) void k_ff_split(const FFSplitParams p) {
   const int m0 = rb * BM;
   const unsigned a_base = (unsigned)(size_t)a_reg;
 
-  // ---- h3 planes -> LDS by LDS-DMA: instruction = (64-channel chunk, 8 rows) of one plane ----
-  {
-    const int d_row = lane >> 3, d_slot = lane & 7;
-    for (int idx = wave; idx < G::A_CH * 8; idx += NWV) {
-      const int c = idx >> 3, r8 = idx & 7, row = r8 * 8 + d_row;
-      const size_t e = (size_t)(m0 + row) * C + c * 64 + ((d_slot ^ swz(row)) << 3);
-      const unsigned dst = a_base + (unsigned)(c * CHP + r8 * 1024);
-      glds16(p.a_hi + e, dst);
-      glds16(p.a_lo + e, dst + G::A_PL);
-    }
-  }
-  // ---- stage A weights: unit U = k-step * 2 + f (f: 0 = the `a` fragment, 1 = the gate fragment of this wave's 32 product columns) ----
+  // ---- prologue: everything the kernel reads before its first hand-over is REQUESTED here, and only the first 64 channels of h3
+  //      are WAITED for.  Issue order = queue order (a wave's vector-memory operations return in order):
+  //        1. the small LDS-DMAs (LayerNorm vectors, the rows' partials) and this workgroup's share of the L2 prefetch
+  //        2. chunk 0 of h3 (two instructions per wave)      <- the first barrier waits for these
+  //        3. weight units 0-3 of stage A
+  //        4. chunks 1.. of h3                               <- waited for inside the k-loop, before k-step 4 is read
+  //        5. weight units 4-7
+  //      [v1 waited for all of h3 and sixteen weight fragments per wave - 192 KiB per CU through a path that delivers ~20 B/clk
+  //      while every CU of the chip starts cold: 10.6 k of 62 k cycles before the first MFMA.] ----
   constexpr int UA = 2 * G::KSA;
   const bool a_wave = wave < G::UNITS;
   const int unit = s * G::UNITS + (a_wave ? wave : 0);       // packed 64-column block of the GEGLU weights
+  // stage A weights: unit U = k-step * 2 + f (f: 0 = the `a` fragment, 1 = the gate fragment of this wave's 32 product columns)
   auto load_a_unit = [&](int U) __attribute__((always_inline)) {
     const int nf = 2 * unit + (U & 1), ks = U >> 1;
     const size_t e = ((size_t)(nf * G::KSA + ks) * 64 + lane) * 8;
@@ -106,34 +113,21 @@ __global__ __launch_bounds__(NT) void k_ff_split(const FFSplitParams p) {
     return f;
   };
   BFrag bq[G::DA > G::DB ? G::DA : G::DB];
+  static_assert(G::DA == 8, "the counted waits below assume eight weight units in flight");
+  // 1. LayerNorm finish vectors of the slice's packed columns and the rows' raw LayerNorm partials: by LDS-DMA as well.  [First
+  // version: plain loads -> registers -> LDS, (mean, rstd) per row computed here: two dependent cold round trips at the head of
+  // every workgroup, and the compiler's wait for the first also drains every DMA issued before it
+  // (profiles/r05_ffsplit_phase_trace_v1.txt).  Nothing in the prologue has a register destination now; the rows' statistics
+  // are formed from the LDS copy in the GEGLU epilogue.]
   if (a_wave) {
-#pragma unroll
-    for (int j = 0; j < G::DA; ++j) bq[j] = load_a_unit(j);
+    glds4(p.ug + (size_t)(s * G::UNITS + wave) * 64 + lane, (unsigned)(size_t)s_ug + wave * 256);
+    glds4(p.bg + (size_t)(s * G::UNITS + wave) * 64 + lane, (unsigned)(size_t)s_bg + wave * 256);
   }
-  __builtin_amdgcn_sched_barrier(0);
-  // LayerNorm finish vectors of the slice's packed columns, the rows' (mean, rstd) from the producer's partials
-  for (int i = tid; i < G::UNITS * 64; i += NT) {
-    s_ug[i] = p.ug[(size_t)s * G::UNITS * 64 + i];
-    s_bg[i] = p.bg[(size_t)s * G::UNITS * 64 + i];
-  }
-  if (tid < BM) {
-    constexpr int NB = C / 32;
-    const float2* src = reinterpret_cast<const float2*>(p.rowstat) + (size_t)(m0 + tid) * NB;
-    float2 v[NB];
-#pragma unroll
-    for (int k = 0; k < NB; ++k) v[k] = src[k];
-    float s1 = 0.f;
-#pragma unroll
-    for (int k = 0; k < NB; ++k) s1 += v[k].x;
-    const float inv_c = 1.0f / (float)C, mean = s1 * inv_c;
-    float m2 = 0.f;
-#pragma unroll
-    for (int k = 0; k < NB; ++k) { const float dm = v[k].x * (1.0f / 32.0f) - mean; m2 += v[k].y + 32.0f * dm * dm; }
-    s_ln[tid] = make_float2(mean, 1.0f / sqrtf(m2 * inv_c + p.ln_eps));
-  }
-  // ---- L2 prefetch: the workgroups of an XCD (id % 8 - a speed assumption only) all read slice s of both weight matrices;
-  //      each touches a share of its lines at launch (one 128-byte line per lane, LDS-DMA into a scratch word), so the L2
-  //      fills with thousands of requests in flight while the compute waves start on their first fragments (see k_chain2) ----
+  if (wave < BM * NB * 8 / 1024)                              // 64 rows x NB float2, contiguous: 1 KiB per instruction
+    glds16(reinterpret_cast<const char*>(p.rowstat) + ((size_t)m0 * NB * 8 + wave * 1024 + lane * 16), (unsigned)(size_t)s_rs + wave * 1024);
+  // L2 prefetch: the workgroups of an XCD (id % 8 - a speed assumption only) all read slice s of both weight matrices; each
+  // touches a share of its lines at launch (one 128-byte line per lane, LDS-DMA into a scratch word), so the L2 fills with
+  // thousands of requests in flight while the compute waves start on their first fragments (see k_chain2)
   {
     constexpr int LG = G::UNITS * 2 * G::KSA * 8, LM = G::NF * G::KSB * 8;    // 128-byte lines per plane of this slice
     const int xw = (int)blockIdx.x >> 3, nxw = ((int)gridDim.x + 7) >> 3;
@@ -152,9 +146,35 @@ __global__ __launch_bounds__(NT) void k_ff_split(const FFSplitParams p) {
       glds4(src, (unsigned)(size_t)s_pf);
     }
   }
+  // h3 planes -> LDS: instruction = (64-channel chunk c, 8 rows r8) of one plane; wave w sends rows 8 w .. 8 w + 7 of every chunk
+  auto h3_chunk = [&](int c) __attribute__((always_inline)) {
+    const int d_row = lane >> 3, d_slot = lane & 7, row = wave * 8 + d_row;
+    const size_t e = (size_t)(m0 + row) * C + c * 64 + ((d_slot ^ swz(row)) << 3);
+    const unsigned dst = a_base + (unsigned)(c * CHP + wave * 1024);
+    glds16(p.a_hi + e, dst);
+    glds16(p.a_lo + e, dst + G::A_PL);
+  };
+  h3_chunk(0);                                               // 2.
+  if (a_wave) {                                              // 3.
+#pragma unroll
+    for (int j = 0; j < 4; ++j) bq[j] = load_a_unit(j);
+  }
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int c = 1; c < G::A_CH; ++c) h3_chunk(c);             // 4.
+  constexpr int NC = (G::A_CH - 1) * 2;                      // ... LDS-DMA instructions per wave
+  if (a_wave) {                                              // 5.
+#pragma unroll
+    for (int j = 4; j < 8; ++j) bq[j] = load_a_unit(j);
+  }
+  __builtin_amdgcn_sched_barrier(0);
   DV_FTRACE(1);
-  wait_vmcnt<0>();
-  __syncthreads();
+  // [v4 put steps 3b-5 BEHIND the barrier (two weight units ahead of it): first MFMA at 8.0 k instead of 9.0 k cycles, but the
+  // k-loop then waits for what it had not asked for in time: 13.7 k instead of 12.3 k cycles, nothing gained - the start-up is
+  // bound by how fast a cold chip delivers the first ~200 KiB per CU, not by the order of the requests.]
+  if (a_wave) wait_vmcnt<8 + NC + 8>();                       // chunk 0 (and everything older) has landed
+  else wait_vmcnt<NC>();
+  __builtin_amdgcn_s_barrier();
   DV_FTRACE(2);
 
   // A fragments (both row fragments, both planes) of k-step `ks` of a resident operand
@@ -174,78 +194,12 @@ __global__ __launch_bounds__(NT) void k_ff_split(const FFSplitParams p) {
     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.h, ah, acc, 0, 0, 0);
   };
 
-  // ================= stage A: GEGLU of this wave's 32 product columns, both row fragments =================
-  if (a_wave) {
-    f32x16 acc[2][2];                                        // [a | gate][row fragment]
-#pragma unroll
-    for (int f = 0; f < 2; ++f)
-#pragma unroll
-      for (int rf = 0; rf < 2; ++rf)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[f][rf][r] = 0.f;
-    bf16x8 ah[2][2], al[2][2];
-    read_frag(a_reg, G::A_PL, 0, ah[0], al[0]);
-#pragma unroll
-    for (int U = 0; U < UA; ++U) {
-      const int ks = U >> 1, f = U & 1, cur = ks & 1;
-      if (f == 0 && ks + 1 < G::KSA) read_frag(a_reg, G::A_PL, ks + 1, ah[cur ^ 1], al[cur ^ 1]);
-      const BFrag w = bq[U % G::DA];
-      // (the two row fragments alternate: consecutive MFMAs write different accumulators)
-      acc[f][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.h, al[cur][0], acc[f][0], 0, 0, 0);
-      acc[f][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.h, al[cur][1], acc[f][1], 0, 0, 0);
-      acc[f][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.l, ah[cur][0], acc[f][0], 0, 0, 0);
-      acc[f][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.l, ah[cur][1], acc[f][1], 0, 0, 0);
-      acc[f][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.h, ah[cur][0], acc[f][0], 0, 0, 0);
-      acc[f][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.h, ah[cur][1], acc[f][1], 0, 0, 0);
-      // pinned: without the scheduling barriers hipcc sinks every prefetch down to its use (load -> vmcnt(0) -> MFMA)
-      __builtin_amdgcn_sched_barrier(0);
-      if (U + G::DA < UA) bq[U % G::DA] = load_a_unit(U + G::DA);
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    DV_FTRACE(3);
-    // LayerNorm finish + bias, a * gelu(gate) -> product columns wave * 32 + (8g + 4lh + e) of the slice as split planes in LDS
-#pragma unroll
-    for (int rf = 0; rf < 2; ++rf) {
-      const int row = rf * 32 + l31;
-      const float2 st = s_ln[row];
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int cl = 8 * g + 4 * lh;
-        const float4 ua = *reinterpret_cast<const float4*>(s_ug + wave * 64 + cl), ugt = *reinterpret_cast<const float4*>(s_ug + wave * 64 + 32 + cl);
-        const float4 ba = *reinterpret_cast<const float4*>(s_bg + wave * 64 + cl), bgt = *reinterpret_cast<const float4*>(s_bg + wave * 64 + 32 + cl);
-        const float ua_[4] = {ua.x, ua.y, ua.z, ua.w}, ug_[4] = {ugt.x, ugt.y, ugt.z, ugt.w};
-        const float ba_[4] = {ba.x, ba.y, ba.z, ba.w}, bg_[4] = {bgt.x, bgt.y, bgt.z, bgt.w};
-        float v[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const float a = st.y * (acc[0][rf][4 * g + e] - st.x * ua_[e]) + ba_[e];
-          const float gt = st.y * (acc[1][rf][4 * g + e] - st.x * ug_[e]) + bg_[e];
-          v[e] = a * gelu_erf(gt);
-        }
-        uint2 hw, lw;
-        hw.x = pk(v[0], v[1]); hw.y = pk(v[2], v[3]);
-        lw.x = pk(v[0] - __uint_as_float(hw.x << 16), v[1] - __uint_as_float(hw.x & 0xffff0000u));
-        lw.y = pk(v[2] - __uint_as_float(hw.y << 16), v[3] - __uint_as_float(hw.y & 0xffff0000u));
-        const int n = wave * 32 + cl, c = n >> 6, s16 = (n & 63) >> 3;
-        const int off = c * CHP + row * 128 + ((s16 ^ swz(row)) << 4) + ((n & 7) >> 2) * 8;
-        *reinterpret_cast<uint2*>(g_reg + off) = hw;
-        *reinterpret_cast<uint2*>(g_reg + G::G_PL + off) = lw;
-      }
-    }
-  }
-  DV_FTRACE(4);
 
   // ================= stage B: partial ffproj over [this slice's channels of h3 | its product columns], all C output columns ==========
   // wave -> NFW column fragments from cf0 and k-group kg (KGB = 2: 4 column groups x 2 halves of the k-steps)
   const int kg = G::KGB == 1 ? 0 : wave >> 2;
   const int cf0 = G::KGB == 1 ? wave : (wave & 3) * G::NFW;
   f32x16 accb[G::NFW][2];
-#pragma unroll
-  for (int i = 0; i < G::NFW; ++i)
-#pragma unroll
-    for (int rf = 0; rf < 2; ++rf)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) accb[i][rf][r] = 0.f;
   auto load_b_unit = [&](int j, int i) __attribute__((always_inline)) {        // k-step j of the workgroup's range, fragment cf0 + i
     const int ksw = j < G::HKS ? s * G::HKS + j : G::KSA + s * G::PKS + (j - G::HKS);
     const size_t e = ((size_t)((cf0 + i) * G::KSBW + ksw) * 64 + lane) * 8;
@@ -290,18 +244,118 @@ __global__ __launch_bounds__(NT) void k_ff_split(const FFSplitParams p) {
       __builtin_amdgcn_sched_barrier(0);
     }
   };
-  if (kg == 0) b_prologue(std::integral_constant<int, 0>{});
-  else b_prologue(std::integral_constant<int, 1>{});
-  // the finishing waves' bias / residual (cold rows) are requested under stage B
   const bool fin = wave < G::HFT * 2;
   const int f_rf = wave & 1, f_hf = s * G::HFT + (wave >> 1);       // finishing unit: row fragment, 16-column block of the output
   const int f_m = m0 + f_rf * 32 + l31;
   float4 rres[2], rbias[2];
-  if (fin) {
-    const float* rp = p.res + (size_t)f_m * C + f_hf * 16 + 4 * lh;
-    rres[0] = *reinterpret_cast<const float4*>(rp); rres[1] = *reinterpret_cast<const float4*>(rp + 8);
-    rbias[0] = *reinterpret_cast<const float4*>(p.bm + f_hf * 16 + 4 * lh); rbias[1] = *reinterpret_cast<const float4*>(p.bm + f_hf * 16 + 4 * lh + 8);
+  // The first weight fragments of stage B and the finishing waves' bias / residual rows (cold: written a whole transformer block
+  // ago): requested behind a wave's GEGLU epilogue, ahead of the barrier that waits for everybody's
+  auto early_requests = [&]() __attribute__((always_inline)) {
+    if (kg == 0) b_prologue(std::integral_constant<int, 0>{});
+    else b_prologue(std::integral_constant<int, 1>{});
+    if (fin) {
+      const float* rp = p.res + (size_t)f_m * C + f_hf * 16 + 4 * lh;
+      rres[0] = *reinterpret_cast<const float4*>(rp); rres[1] = *reinterpret_cast<const float4*>(rp + 8);
+      rbias[0] = *reinterpret_cast<const float4*>(p.bm + f_hf * 16 + 4 * lh); rbias[1] = *reinterpret_cast<const float4*>(p.bm + f_hf * 16 + 4 * lh + 8);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  // [Requested BEFORE the GEGLU epilogue (C = 256, v2): the epilogue grew by 2.5 k cycles - 249 VGPRs - and the barrier behind it is
+  // the wait for the slowest wave either way: nothing gained.]
+  if (!a_wave) {       // (C = 384: waves 6 and 7 have no stage-A unit; they meet the others at the in-loop barrier)
+    wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+    early_requests();
   }
+
+  // ================= stage A: GEGLU of this wave's 32 product columns, both row fragments =================
+  if (a_wave) {
+    f32x16 acc[2][2];                                        // [a | gate][row fragment]
+#pragma unroll
+    for (int f = 0; f < 2; ++f)
+#pragma unroll
+      for (int rf = 0; rf < 2; ++rf)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[f][rf][r] = 0.f;
+    bf16x8 ah[2][2], al[2][2];
+    read_frag(a_reg, G::A_PL, 0, ah[0], al[0]);
+#pragma unroll
+    for (int U = 0; U < UA; ++U) {
+      const int ks = U >> 1, f = U & 1, cur = ks & 1;
+      if (U == 6) {        // k-step 4 (read ahead below) is the first of chunk 1: the rest of h3 has landed - here and in every wave
+        wait_vmcnt<12>();  // (younger than the DMAs: the refills of units 8-13 only)
+        __builtin_amdgcn_s_barrier();
+      }
+      if (f == 0 && ks + 1 < G::KSA) read_frag(a_reg, G::A_PL, ks + 1, ah[cur ^ 1], al[cur ^ 1]);
+      const BFrag w = bq[U % G::DA];
+      // (the two row fragments alternate: consecutive MFMAs write different accumulators)
+      acc[f][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.h, al[cur][0], acc[f][0], 0, 0, 0);
+      acc[f][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.h, al[cur][1], acc[f][1], 0, 0, 0);
+      acc[f][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.l, ah[cur][0], acc[f][0], 0, 0, 0);
+      acc[f][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.l, ah[cur][1], acc[f][1], 0, 0, 0);
+      acc[f][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.h, ah[cur][0], acc[f][0], 0, 0, 0);
+      acc[f][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.h, ah[cur][1], acc[f][1], 0, 0, 0);
+      // pinned: without the scheduling barriers hipcc sinks every prefetch down to its use (load -> vmcnt(0) -> MFMA)
+      __builtin_amdgcn_sched_barrier(0);
+      if (U + G::DA < UA) bq[U % G::DA] = load_a_unit(U + G::DA);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    DV_FTRACE(3);
+    // LayerNorm finish + bias, a * gelu(gate) -> product columns wave * 32 + (8g + 4lh + e) of the slice as split planes in LDS
+#pragma unroll
+    for (int rf = 0; rf < 2; ++rf) {
+      const int row = rf * 32 + l31;
+      float2 st;
+      {   // (mean, rstd) of this lane's row from the producer's partials per 32-column block, parallel-variance form (gemm_tile.h)
+        float4 v[NB / 2];
+#pragma unroll
+        for (int k = 0; k < NB / 2; ++k) v[k] = *reinterpret_cast<const float4*>(s_rs + row * NB + 2 * k);
+        float s1 = 0.f;
+#pragma unroll
+        for (int k = 0; k < NB / 2; ++k) { s1 += v[k].x; s1 += v[k].z; }
+        const float inv_c = 1.0f / (float)C, mean = s1 * inv_c;
+        float m2 = 0.f;
+#pragma unroll
+        for (int k = 0; k < NB / 2; ++k) {
+          const float d0 = v[k].x * (1.0f / 32.0f) - mean, d1 = v[k].z * (1.0f / 32.0f) - mean;
+          m2 += v[k].y + 32.0f * d0 * d0;
+          m2 += v[k].w + 32.0f * d1 * d1;
+        }
+        st = make_float2(mean, 1.0f / sqrtf(m2 * inv_c + p.ln_eps));
+      }
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int cl = 8 * g + 4 * lh;
+        const float4 ua = *reinterpret_cast<const float4*>(s_ug + wave * 64 + cl), ugt = *reinterpret_cast<const float4*>(s_ug + wave * 64 + 32 + cl);
+        const float4 ba = *reinterpret_cast<const float4*>(s_bg + wave * 64 + cl), bgt = *reinterpret_cast<const float4*>(s_bg + wave * 64 + 32 + cl);
+        const float ua_[4] = {ua.x, ua.y, ua.z, ua.w}, ug_[4] = {ugt.x, ugt.y, ugt.z, ugt.w};
+        const float ba_[4] = {ba.x, ba.y, ba.z, ba.w}, bg_[4] = {bgt.x, bgt.y, bgt.z, bgt.w};
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float a = st.y * (acc[0][rf][4 * g + e] - st.x * ua_[e]) + ba_[e];
+          const float gt = st.y * (acc[1][rf][4 * g + e] - st.x * ug_[e]) + bg_[e];
+          v[e] = a * gelu_erf(gt);
+        }
+        uint2 hw, lw;
+        hw.x = pk(v[0], v[1]); hw.y = pk(v[2], v[3]);
+        lw.x = pk(v[0] - __uint_as_float(hw.x << 16), v[1] - __uint_as_float(hw.x & 0xffff0000u));
+        lw.y = pk(v[2] - __uint_as_float(hw.y << 16), v[3] - __uint_as_float(hw.y & 0xffff0000u));
+        const int n = wave * 32 + cl, c = n >> 6, s16 = (n & 63) >> 3;
+        const int off = c * CHP + row * 128 + ((s16 ^ swz(row)) << 4) + ((n & 7) >> 2) * 8;
+        *reinterpret_cast<uint2*>(g_reg + off) = hw;
+        *reinterpret_cast<uint2*>(g_reg + G::G_PL + off) = lw;
+      }
+    }
+  }
+  if (a_wave) early_requests();
+  DV_FTRACE(4);
+#pragma unroll
+  for (int i = 0; i < G::NFW; ++i)
+#pragma unroll
+    for (int rf = 0; rf < 2; ++rf)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) accb[i][rf][r] = 0.f;
   __builtin_amdgcn_sched_barrier(0);
   __syncthreads();                                           // product planes complete
   DV_FTRACE(5);
@@ -313,8 +367,35 @@ __global__ __launch_bounds__(NT) void k_ff_split(const FFSplitParams p) {
   // xbuf (float4 units): [row block][16-column block hf][source][row fragment][gg][64 lanes]; register group g of column fragment cf
   // is 16-column block 2 cf + (g >> 1), half gg = g & 1 (columns 8 gg + 4 lh + e of the block)
   float4* const xb = reinterpret_cast<float4*>(p.xbuf) + (size_t)rb * (2 * G::NF) * G::NSRC * 4 * 64 + lane;
-  {
-    const int src = s * G::KGB + kg;
+  if constexpr (G::KGB == 2) {
+    // two k-groups (C = 384): added through LDS first - row fragment rf BELONGS to k-group rf: each group hands the other's
+    // fragments over and keeps its own, so both directions cross the LDS at once and every wave writes half of the partial sums
+    // (first version: both groups wrote everything through and the finishing waves summed 16 sources - 25 k of 88 k cycles)
+    __syncthreads();                                         // every wave is done reading the resident operands
+    float4* red4 = reinterpret_cast<float4*>(a_reg) + (size_t)(wave & 3) * (G::NFW * 4 * 64) + lane;   // [column group][fragment][g][64 lanes]
+#pragma unroll
+    for (int i = 0; i < G::NFW; ++i)
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+        // (the half the OTHER group owns; selects, not a run-time index: an indexed register array lives in scratch memory)
+        red4[(size_t)(kg * 4 * G::NFW + i) * 4 * 64 + g * 64] =
+            kg ? make_float4(accb[i][0][4 * g], accb[i][0][4 * g + 1], accb[i][0][4 * g + 2], accb[i][0][4 * g + 3])
+               : make_float4(accb[i][1][4 * g], accb[i][1][4 * g + 1], accb[i][1][4 * g + 2], accb[i][1][4 * g + 3]);
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < G::NFW; ++i)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const float4 v = red4[(size_t)((kg ^ 1) * 4 * G::NFW + i) * 4 * 64 + g * 64];
+        // (k-group 0's sums first, whichever group adds)
+        float4 a = kg ? make_float4(accb[i][1][4 * g], accb[i][1][4 * g + 1], accb[i][1][4 * g + 2], accb[i][1][4 * g + 3])
+                      : make_float4(accb[i][0][4 * g], accb[i][0][4 * g + 1], accb[i][0][4 * g + 2], accb[i][0][4 * g + 3]);
+        a = kg == 0 ? make_float4(a.x + v.x, a.y + v.y, a.z + v.z, a.w + v.w) : make_float4(v.x + a.x, v.y + a.y, v.z + a.z, v.w + a.w);
+        const int hf = 2 * (cf0 + i) + (g >> 1);
+        st_handover16(xb + ((size_t)((hf * G::NSRC + s) * 2 + kg) * 2 + (g & 1)) * 64, a);
+      }
+    wait_vmcnt<0>();
+  } else {
 #pragma unroll
     for (int i = 0; i < G::NFW; ++i)
 #pragma unroll
@@ -322,7 +403,7 @@ __global__ __launch_bounds__(NT) void k_ff_split(const FFSplitParams p) {
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
           const int hf = 2 * (cf0 + i) + (g >> 1);
-          st_handover16(xb + ((size_t)((hf * G::NSRC + src) * 2 + rf) * 2 + (g & 1)) * 64,
+          st_handover16(xb + ((size_t)((hf * G::NSRC + s) * 2 + rf) * 2 + (g & 1)) * 64,
                         make_float4(accb[i][rf][4 * g], accb[i][rf][4 * g + 1], accb[i][rf][4 * g + 2], accb[i][rf][4 * g + 3]));
         }
     wait_vmcnt<0>();                                         // this thread's partial sums have been written through
@@ -463,8 +544,7 @@ bool ff_split_supported(const FFSplitParams& p, int precision) {
   return true;
 }
 size_t ff_split_xbuf_floats(int M, int C, int nspl) {
-  const int nsrc = nspl * (C / 32 > NWV ? 2 : 1);
-  return (size_t)(M / BM) * (2 * (C / 32)) * nsrc * 4 * 64 * 4;
+  return (size_t)(M / BM) * (2 * (C / 32)) * nspl * 4 * 64 * 4;
 }
 // In-launch GroupNorm of the output: the finishing tiles ([64 rows x C / nspl columns], all resident) behave like GEMM tiles
 // (the conditions of gemm_gnx_plan, kernels_gemm.hip)
