@@ -162,6 +162,9 @@ __device__ __forceinline__ unsigned dv_cvt_pk_f16(float lo, float hi) {
 }
 // two floats -> packed fp16 pair `h` (round to nearest even) and the packed fp16 pair `l` of what the rounding left
 __device__ __forceinline__ void dv_split_pk_f16(float x0, float x1, unsigned& h, unsigned& l) {
+  // (clamped to the fp16 range: a |V| beyond 65504 - no checkpoint seen has one - saturates instead of becoming inf / NaN in the
+  // P V product; v_med3_f32, two instructions per pair in the kernels that WRITE V fragments, none in the attention loops)
+  x0 = __builtin_amdgcn_fmed3f(x0, -65504.0f, 65504.0f); x1 = __builtin_amdgcn_fmed3f(x1, -65504.0f, 65504.0f);
   const dv_f32x2 v = {x0, x1};
   const dv_f16x2 hh = __builtin_convertvector(v, dv_f16x2);
   const dv_f32x2 back = __builtin_convertvector(hh, dv_f32x2);

@@ -420,6 +420,7 @@ struct Builder {
       if (big || !k64) { cfg = 0; bm = 128; bk = 32; } else { cfg = 2; bm = 64; bk = 64; }
     }
     if (gin.T_out % bm != 0 || gin.M != B * gin.T_out) return false;
+    if (gin.T_out < 1 || (unsigned long long)(gin.M > 0 ? gin.M : 1) * (unsigned long long)gin.T_out >= (1ull << 32)) return false;   // (tout_magic: launch_gemm's guard)
     po = PersistOp{};
     po.type = POP_GEMM; po.cfg = cfg; po.g = gin;
     po.g.tout_magic = gemm_tout_magic(gin.T_out);      // (launch_gemm's normalisations: the persistent launch runs the tile routine directly)

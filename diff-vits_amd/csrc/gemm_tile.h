@@ -1,6 +1,10 @@
 // Implicit-GEMM tile routine shared by the per-launch kernel (kernels_gemm.hip) and the persistent per-XCD schedule
 // (persist.hip).  See kernels_gemm.hip for the design notes.
 #pragma once
+#ifndef DV_GNX_STATS_FIRST
+// 1: a fragment's 32x16 block statistics are computed and published before its result stores are issued (0: round-4 order)
+#define DV_GNX_STATS_FIRST 1
+#endif
 #ifndef DV_GEMM_EXP
 // development knob (trace experiments on the plain tile's k-loop, WRONG results): 1 = B fragments read from LDS once, not per
 // k-tile; 2 = 1 + no B DMA; 3 = 2 + A fragments read once; 4 = no DMA inside the loop at all.  0 in every shipped build
@@ -590,16 +594,9 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int m0, con
 #pragma unroll
       for (int r = 0; r < 8; ++r) vv[r] = m_ok ? vv[r] : 0.f;
       DV_TRACE(16);
-      if (m_in) {                                    // (padding rows are stored as zeros)
-        const size_t ob = (size_t)m * p.ldo + ncol;
-        if (p.out) {
-#pragma unroll
-          for (int g = 0; g < 2; ++g)
-            dv_st16(p.out + ob + 4 * lh + 8 * g, make_float4(vv[4 * g], vv[4 * g + 1], vv[4 * g + 2], vv[4 * g + 3]));
-        }
-        if (p.out_hi) store_planes8(p.out_hi, p.out_lo, ob, lh, vv);
-      }
-      DV_TRACE(17);
+#if DV_GNX_STATS_FIRST
+      // (round 5: the block statistics are published BEFORE this wave's result stores are issued - the other workgroups of the
+      // launch wait for the words, nobody waits for the stores; k_chain_ff has had this order since round 4)
       if (p.stats16) {                               // this wave's 32 x 16 block: (sum, squared deviations about its own mean)
         float a1 = 0.f, a2 = 0.f;
 #pragma unroll
@@ -617,6 +614,36 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int m0, con
                                __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         }
       }
+#endif
+      if (m_in) {                                    // (padding rows are stored as zeros)
+        const size_t ob = (size_t)m * p.ldo + ncol;
+        if (p.out) {
+#pragma unroll
+          for (int g = 0; g < 2; ++g)
+            dv_st16(p.out + ob + 4 * lh + 8 * g, make_float4(vv[4 * g], vv[4 * g + 1], vv[4 * g + 2], vv[4 * g + 3]));
+        }
+        if (p.out_hi) store_planes8(p.out_hi, p.out_lo, ob, lh, vv);
+      }
+      DV_TRACE(17);
+#if !DV_GNX_STATS_FIRST
+      if (p.stats16) {                               // this wave's 32 x 16 block: (sum, squared deviations about its own mean)
+        float a1 = 0.f, a2 = 0.f;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) a1 += vv[r];
+        a1 = wave_sum64(a1);
+        const float mb = padded ? a1 / (float)(16 * blk_cnt(mrow0)) : a1 * (1.0f / 512.0f);
+#pragma unroll
+        for (int r = 0; r < 8; ++r) { const float dv = (!padded || m_ok) ? vv[r] - mb : 0.f; a2 = fmaf(dv, dv, a2); }
+        a2 = wave_sum64(a2);
+        if (lane == 0 && mrow0 < p.M) {
+          const size_t e = (size_t)(mrow0 >> 5) * (p.N >> 4) + (ncol >> 4);
+          reinterpret_cast<float2*>(p.stats16)[e] = make_float2(a1, a2);
+          if (gnx_h)
+            __hip_atomic_store(p.gnx.xchg + e, (unsigned long long)__float_as_uint(a1) | ((unsigned long long)__float_as_uint(a2) << 32),
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+      }
+#endif
       DV_TRACE(18);
       if (gnx_h) {
         gnx_table(NWV);
@@ -890,6 +917,36 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int m0, con
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][j][r] = vv[r];
       }
+#if DV_GNX_STATS_FIRST
+      // (the 32x16 block statistics - published to the other workgroups of the launch when a GroupNorm is finished here - go out
+      // BEFORE this fragment's result stores are issued: the words are what the launch waits for)
+      if (p.stats16) {
+        // per (32-row, 16-column) block: (sum, squared deviations from the block's OWN mean) - no E[x^2] - mean^2
+        // cancellation when |mean| >> spread; the consumer combines blocks with the parallel-variance formula in fp64.
+        // Registers 0-7 / 8-15 are the fragment's first / second 16 columns (column = 8g + 4lh + e, r = 4g + e);
+        // every lane holds columns of both halves, so both sums run over all 64 lanes.
+        float a1[2] = {0.f, 0.f}, a2[2] = {0.f, 0.f};
+#pragma unroll
+        for (int r = 0; r < 16; ++r) a1[r >> 3] += vv[r];
+        auto wsum = [&](float v) { return wave_sum64(v); };   // (DPP + scalar registers: dv_device.h)
+        a1[0] = wsum(a1[0]); a1[1] = wsum(a1[1]);
+        const float inv_n = padded ? 1.0f / (float)(16 * blk_cnt(mrow0)) : 1.0f / 512.0f;
+        const float mb[2] = {a1[0] * inv_n, a1[1] * inv_n};
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { const float dv = (!padded || m_ok) ? vv[r] - mb[r >> 3] : 0.f; a2[r >> 3] = fmaf(dv, dv, a2[r >> 3]); }
+        a2[0] = wsum(a2[0]); a2[1] = wsum(a2[1]);
+        const int cb0 = (n0 + (wn * FN + j) * 32) >> 4;
+        if (lane < 2 && mrow0 < p.M && (cb0 + lane) * 16 < p.N) {
+          float2* const dst = reinterpret_cast<float2*>(p.stats16) + (size_t)(mrow0 >> 5) * (p.N >> 4) + cb0 + lane;
+          const float2 val = make_float2(lane ? a1[1] : a1[0], lane ? a2[1] : a2[0]);
+          *dst = val;
+          if (gnx)     // for the other workgroups of this launch: one 8-byte word (sum, M2), written through
+            __hip_atomic_store(p.gnx.xchg + (size_t)(mrow0 >> 5) * (p.N >> 4) + cb0 + lane,
+                               (unsigned long long)__float_as_uint(val.x) | ((unsigned long long)__float_as_uint(val.y) << 32),
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+      }
+#endif
       if (p.epi == EPI_STORE_NCT) {
         // [B, N, T_out]: the 32 lanes of a half-wave write 32 consecutive frames of one channel
         if (m_ok) {
@@ -953,6 +1010,7 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int m0, con
         if ((l31 & 1) == 0 && n < p.N && mrow0 < p.M)
           reinterpret_cast<float2*>(p.stats)[(size_t)(mrow0 >> 5) * p.N + n] = make_float2(s1[0], s2[0]);
       }
+#if !DV_GNX_STATS_FIRST
       if (p.stats16) {
         // per (32-row, 16-column) block: (sum, squared deviations from the block's OWN mean) - no E[x^2] - mean^2
         // cancellation when |mean| >> spread; the consumer combines blocks with the parallel-variance formula in fp64.
@@ -979,6 +1037,7 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int m0, con
                                __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         }
       }
+#endif
     }
     }
   DV_TRACE(18);                                      // statistics of every fragment written

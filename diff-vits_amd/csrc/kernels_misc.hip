@@ -812,6 +812,14 @@ hipError_t launch_fill_f32(float* dst, float v, int64_t n, hipStream_t st) {
 __global__ void k_lincomb(float* out, const float* x, const float* m0, const float* m1, const float* m2,
                           const float* m3, const float* __restrict__ coef, int64_t n4) {
   const float c0 = coef[0], c1 = coef[1], c2 = coef[2], c3 = coef[3], c4 = coef[4];
+  if (coef[7] != 0.f) {     // x0 -> noise prediction: (x - alpha m0) / sigma, every step rounded as torch rounds it (sampler.hip)
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+      const float4 v = reinterpret_cast<const float4*>(x)[i], a = reinterpret_cast<const float4*>(m0)[i];
+      reinterpret_cast<float4*>(out)[i] = make_float4(__fdiv_rn(__fsub_rn(v.x, __fmul_rn(c1, a.x)), c0), __fdiv_rn(__fsub_rn(v.y, __fmul_rn(c1, a.y)), c0),
+                                                      __fdiv_rn(__fsub_rn(v.z, __fmul_rn(c1, a.z)), c0), __fdiv_rn(__fsub_rn(v.w, __fmul_rn(c1, a.w)), c0));
+    }
+    return;
+  }
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
     float4 v = reinterpret_cast<const float4*>(x)[i];
     v.x *= c0; v.y *= c0; v.z *= c0; v.w *= c0;
@@ -829,6 +837,7 @@ __global__ void k_lincomb_tail(float* out, const float* x, const float* m0, cons
                                const float* m3, const float* __restrict__ coef, int64_t start, int64_t n) {
   const int64_t i = start + threadIdx.x;
   if (i >= n) return;
+  if (coef[7] != 0.f) { out[i] = __fdiv_rn(__fsub_rn(x[i], __fmul_rn(coef[1], m0[i])), coef[0]); return; }
   float v = coef[0] * x[i];
   if (m0) v = fmaf(coef[1], m0[i], v);
   if (m1) v = fmaf(coef[2], m1[i], v);

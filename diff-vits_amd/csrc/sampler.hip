@@ -268,7 +268,11 @@ static int build_plan(dv_plan* p) {
       if (!noise) return;
       Event e{}; e.type = 1; e.src = src; e.dst = 2 + slot; e.coef = (int)p->coefs.size();
       std::array<float, 8> row{};
-      row[0] = (float)(1.0 / ns.sigma(t)); row[1] = (float)(-ns.alpha(t) / ns.sigma(t));
+      // (x - alpha m) / sigma with the subtraction BEFORE the scaling, as the reference computes it (dpm_solver.py:290-292) -
+      // as c0 x + c1 m with two float32-rounded coefficients 1 / sigma and -alpha / sigma the cancellation is amplified by
+      // 1 / sigma at the low-noise end (singlestep order 3 with 3-4 steps: 7e-4 from the reference).  row[7] = 1
+      // marks the form for k_lincomb / Plan.run_python: row[0] = sigma, row[1] = alpha.
+      row[0] = (float)ns.sigma(t); row[1] = (float)ns.alpha(t); row[7] = 1.0f;
       e.slots[0] = slot; e.slots[1] = e.slots[2] = e.slots[3] = -1;
       p->coefs.push_back(row);
       p->ev.push_back(e);
@@ -448,7 +452,11 @@ static int build_plan(dv_plan* p) {
       if (!unoise) return;
       Event e{}; e.type = 1; e.src = src; e.dst = 2 + slot; e.coef = (int)p->coefs.size();
       std::array<float, 8> row{};
-      row[0] = (float)(1.0 / ns.sigma(t)); row[1] = (float)(-ns.alpha(t) / ns.sigma(t));
+      // (x - alpha m) / sigma with the subtraction BEFORE the scaling, as the reference computes it (dpm_solver.py:290-292) -
+      // as c0 x + c1 m with two float32-rounded coefficients 1 / sigma and -alpha / sigma the cancellation is amplified by
+      // 1 / sigma at the low-noise end (singlestep order 3 with 3-4 steps: 7e-4 from the reference).  row[7] = 1
+      // marks the form for k_lincomb / Plan.run_python: row[0] = sigma, row[1] = alpha.
+      row[0] = (float)ns.sigma(t); row[1] = (float)ns.alpha(t); row[7] = 1.0f;
       e.slots[0] = slot; e.slots[1] = e.slots[2] = e.slots[3] = -1;
       p->coefs.push_back(row);
       p->ev.push_back(e);

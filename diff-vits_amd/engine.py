@@ -19,10 +19,19 @@ def default_precision():
 
 
 def verify_handover_default():
-    """DVITS_HANDOVER_VERIFY=0: results leave the engine without waiting for the stream to drain and checking the in-launch
-    GroupNorm hand-overs (a time-out is then only noticed - loudly - by the NEXT call on the engine, and the lost run is not
-    repeated): measurement aid / callers that overlap host work with the replay and accept that."""
-    return os.environ.get("DVITS_HANDOVER_VERIFY", "1") != "0"
+    """How results of a schedule with in-launch hand-overs (GroupNorm exchange, split feed-forward, split-K) are verified before
+    they leave the engine (DVITS_HANDOVER_VERIFY):
+      "lazy"  (default) - no host synchronisation in the steady state.  The first result of a freshly planned schedule is checked
+                the old way (wait for the stream, read the flag, repeat on the fallback schedule if a wait timed out: a GPU that
+                is shared from the start never hands out a wrong tensor); after that a time-out - flagged in host-mapped memory by
+                the kernel that gave up - is noticed by the NEXT call on the engine, which recovers and raises ("repeat the run"),
+                or by an explicit `engine.wait()`, which returns False.  This package's own loops (model3.NaturalSpeech2.sample,
+                tts_infer.synthesize) call wait() once per utterance and repeat it themselves.
+      "eager" / "1"    - every forward / sampler run waits for the stream and is repeated transparently (round 4's behaviour:
+                one host synchronisation per denoiser evaluation in a Python-driven solver loop).
+      "off" / "0"      - never waits, never repeats (measurements)."""
+    v = os.environ.get("DVITS_HANDOVER_VERIFY", "lazy").lower()
+    return {"0": "off", "off": "off", "false": "off", "1": "eager", "eager": "eager", "true": "eager"}.get(v, "lazy")
 
 
 class UNetEngine:
@@ -59,8 +68,16 @@ class UNetEngine:
         self.prepare_serial = 0         # bumped whenever another schedule becomes current (the caller must set_cond again)
         self.plan_builds = 0            # native prepares really run (a cached shape does not count)
         self._fwd_cond = None           # forward(): the (enc, mask) tensors the engine is currently conditioned on
-        self.handover_downgraded = False  # an in-launch GroupNorm hand-over timed out once: this engine runs the k_gn_apply schedule now
-        self.verify_handover = verify_handover_default()   # wait + check the hand-overs before a result leaves the engine
+        self.handover_downgraded = False  # an in-launch hand-over timed out: this engine runs the fallback schedule (until it is retried)
+        self.verify_handover = verify_handover_default()   # "lazy" | "eager" | "off" (True / False are accepted: eager / off)
+        self._probation = 1             # results still verified eagerly in lazy mode (reset whenever a schedule is planned)
+        self.unverified_results = 0     # results handed out since the last verification point (lazy mode)
+        self.host_syncs = 0             # host synchronisations this engine has issued for verification (tests, bench)
+        # a downgraded engine tries the fused schedule again after this many clean results (doubled after every failed retry;
+        # DVITS_HANDOVER_RETRY=0: never - round 4's permanent downgrade)
+        self._retry_after = max(0, int(os.environ.get("DVITS_HANDOVER_RETRY", "64")))
+        self._clean_since_downgrade = 0
+        self.handover_retries = 0
 
     class _Slot:
         __slots__ = ("h", "weight_sig", "prepared", "cond_keepalive")
@@ -176,6 +193,7 @@ class UNetEngine:
                                                   int(bool(force_upsample_size))), "dv_unet_prepare")
             slot.prepared = key
             self.plan_builds += 1
+            self._probation = 1          # (lazy verification: the first result of a new schedule is checked before it leaves)
         self._plans[key] = slot
         self._plans.move_to_end(key)
         self._cur = slot
@@ -244,21 +262,78 @@ class UNetEngine:
         t = timesteps.detach().to(device=sample.device, dtype=torch.float32).contiguous()
         y = self.eval(x, None, t)
         # The result leaves the engine here (an unmodified reference caller, a Python-driven solver loop, the bench's parity
-        # forward): while the schedule finishes GroupNorms inside producer GEMMs, wait for the forward to drain and check its
-        # hand-overs - a time-out (shared GPU) downgrades the engine and the forward is REPEATED on the fallback schedule, the
-        # caller never sees the invalid tensor.  One host synchronisation per call (the graph-replayed sampler pays one per
-        # run instead: sampler/_plan.py); DVITS_HANDOVER_VERIFY=0 or `engine.verify_handover = False` opts out.
-        if self.verify_handover and self.handover_active():
-            torch.cuda.current_stream().synchronize()
-            if self.recover_handover():
-                self.prepare(B, T, enc.shape[1])
-                self.set_cond(enc.to(sample.device), None if bias is None else bias.to(sample.device))
-                self._fwd_cond = None
-                y = self.eval(x, None, t)
-                torch.cuda.current_stream().synchronize()
-                if self.handover_status()[1]:
-                    raise RuntimeError("in-kernel hand-over timed out on the fallback schedule (it has none): internal error")
+        # forward).  Verification policy: verify_handover_default() - in the steady state of the default ("lazy") no host
+        # synchronisation happens here; a timed-out hand-over is noticed by the next call / by wait().
+        def again():
+            self.prepare(B, T, enc.shape[1])
+            self.set_cond(enc.to(sample.device), None if bias is None else bias.to(sample.device))
+            self._fwd_cond = None
+            return self.eval(x, None, t)
+        y2 = self.result_leaves(again)
+        if y2 is not None:
+            y = y2
         return y if sample.dtype == torch.float32 else y.to(sample.dtype)
+
+    # ------------------------------------------------------------------ verification of in-launch hand-overs
+    def _verify_mode(self):
+        v = self.verify_handover
+        if v is True:
+            return "eager"
+        if v is False or v is None:
+            return "off"
+        return v
+
+    def result_leaves(self, again):
+        """Called by forward() / NativeUNetModel.run_plan once a result has been enqueued and before it is returned.
+        `again()` re-enqueues the same work on the re-prepared engine and returns its result.  Returns None if the result
+        stands (verified, or handed out unverified: lazy mode in the steady state), else the repeated result."""
+        if not self.handover_active():
+            self._note_clean()
+            return None
+        mode = self._verify_mode()
+        if mode == "off" or torch.cuda.is_current_stream_capturing():   # (a host wait would invalidate a capture in progress)
+            self.unverified_results += 1
+            return None
+        if mode == "lazy" and self._probation <= 0:
+            self.unverified_results += 1
+            return None
+        self.host_syncs += 1
+        torch.cuda.current_stream().synchronize()
+        self.unverified_results = 0
+        if self.recover_handover():
+            out = again()
+            self.host_syncs += 1
+            torch.cuda.current_stream().synchronize()
+            if self.handover_status()[1]:
+                raise RuntimeError("in-kernel hand-over timed out on the fallback schedule (it has none): internal error")
+            return out
+        self._probation -= 1
+        self._note_clean()
+        return None
+
+    def wait(self):
+        """Wait for everything enqueued on the current stream and verify the in-launch hand-overs of the results handed out since
+        the last verification point.  True: they are valid.  False: a hand-over timed out somewhere among them (a foreign
+        kernel shared the GPU); the engine has recovered - it is on the fallback schedule and needs prepare + set_cond, which
+        forward() / a sampler run do by themselves - and the caller repeats what it computed since the last wait()."""
+        self.host_syncs += 1
+        torch.cuda.current_stream().synchronize()
+        self.unverified_results = 0
+        if self._cur.prepared is not None and self.recover_handover():
+            return False
+        return True
+
+    def _note_clean(self):
+        """One more result without a time-out.  A downgraded engine goes back to the fused schedule after `_retry_after` of them
+        (the next prepare plans it; its first result is verified eagerly; a second failure doubles the distance)."""
+        if not self.handover_downgraded or self._retry_after <= 0:
+            return
+        self._clean_since_downgrade += 1
+        if self._clean_since_downgrade >= self._retry_after:
+            self._clean_since_downgrade = 0
+            self.handover_downgraded = False
+            self.handover_retries += 1
+            self.set_exclusive(True)
 
     def stats(self):
         n, f = C.c_int64(), C.c_double()
@@ -304,19 +379,22 @@ class UNetEngine:
     def recover_handover(self):
         """Deal with a timed-out in-launch hand-over (a foreign kernel - another stream, another process - kept workgroups
         of a GroupNorm-finishing GEMM off the CUs past the bounded wait; the results of that run are invalid).  Clears the
-        native flag, switches this engine to the fallback schedule for good (GroupNorm by k_gn_apply launches: no in-launch
-        waits), and reports it once.  Returns True if a time-out had happened: the caller repeats the lost run (the sampler
+        native flag, switches this engine to the fallback schedule (GroupNorm by k_gn_apply launches, the feed-forward blocks as
+        two GEMMs: no in-launch waits; the fused schedule is tried again after DVITS_HANDOVER_RETRY clean results), and reports it once.  Returns True if a time-out had happened: the caller repeats the lost run (the sampler
         path does: sampler/_plan.py) - the engine must be prepared and conditioned again first."""
         n, bad = self.handover_status()
         if not bad:
             return False
         import warnings
         _lib.check(_lib.lib().dv_unet_handover_reset(self._h), "dv_unet_handover_reset")
-        if not self.handover_downgraded:
+        if self.handover_retries == 0:
             warnings.warn("diff_vits_amd: an in-kernel GroupNorm hand-over timed out (the GPU is shared with other kernels); "
                           "this engine now runs GroupNorm as separate launches (DVITS_GNX=0 schedule) and the lost run is repeated",
                           RuntimeWarning, stacklevel=3)
+        else:                                       # a retry of the fused schedule failed as well: try again later
+            self._retry_after = min(self._retry_after * 2, 1 << 20)
         self.handover_downgraded = True
+        self._clean_since_downgrade = 0
         self.set_exclusive(False)
         return True
 

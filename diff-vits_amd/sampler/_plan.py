@@ -281,10 +281,13 @@ class Plan:
                 seen_eval = True
             else:
                 c = self.coefs[coef]
-                out = float(c[0]) * (x if src == 0 else xp)      # src 1: continuation of a sum chained through x_pred
-                for k, s in enumerate((s0, s1, s2, s3)):
-                    if s >= 0:
-                        out = out + float(c[1 + k]) * hist[s]
+                if float(c[7]) != 0.0:     # x0 -> noise prediction: (x - alpha m) / sigma, the reference's order of operations (sampler.hip)
+                    out = ((x if src == 0 else xp) - float(c[1]) * hist[s0]) / float(c[0])
+                else:
+                    out = float(c[0]) * (x if src == 0 else xp)      # src 1: continuation of a sum chained through x_pred
+                    for k, s in enumerate((s0, s1, s2, s3)):
+                        if s >= 0:
+                            out = out + float(c[1 + k]) * hist[s]
                 if dst == 0:
                     x = out
                     step += 1
@@ -319,25 +322,19 @@ class NativeUNetModel:
     def run_plan(self, plan, x):
         """hipGraph replay of the whole loop (dv_sampler_run).  Returns a new tensor.
 
-        Blocks the host until the run has drained while the engine's schedule uses in-launch GroupNorm hand-overs (the
-        default on a GPU the process has to itself): the hand-overs are verified before the result is returned and a lost
-        run is repeated.  Callers that overlap host work / another stream with the replay set
-        `unet.hip_engine().verify_handover = False` (or DVITS_HANDOVER_VERIFY=0): the run is then asynchronous, a time-out
-        is reported by the next call on the engine and the lost run is not repeated."""
+        Does not block the host in the steady state (engine.verify_handover_default(): "lazy").  While the engine's schedule
+        uses in-launch hand-overs (the default on a GPU the process has to itself) the first run of a newly planned schedule is
+        verified before its result is returned - wait for the stream, read the flag, repeat on the fallback schedule if a wait
+        timed out; later runs are asynchronous: a time-out is reported by the next call on the engine (RuntimeError: repeat the
+        run) or by `unet.hip_engine().wait()` (False).  DVITS_HANDOVER_VERIFY=eager restores one host wait per run."""
         L = _lib()
         eng = self.unet.hip_engine()
         out = self._run_plan_once(plan, x, eng, L)
-        # In-launch GroupNorm hand-overs need the device to themselves; on a shared GPU one may time out (bounded wait, flag in
-        # host memory).  Checked once per RUN, after it has drained: the engine then drops to the separate-GroupNorm schedule
-        # for good and the run is repeated on it - degraded, not dead (VERDICT r2 #6).
-        if eng.verify_handover and eng.handover_active():
-            torch.cuda.current_stream().synchronize()
-            if eng.recover_handover():
-                out = self._run_plan_once(plan, x, eng, L)
-                torch.cuda.current_stream().synchronize()
-                if eng.handover_status()[1]:
-                    raise RuntimeError("in-kernel hand-over timed out on the fallback schedule (it has none): internal error")
-        return out
+        # In-launch hand-overs need the device to themselves; on a shared GPU one may time out (bounded wait, flag in host
+        # memory): the engine then drops to the fallback schedule and the run is repeated on it - degraded, not dead
+        # (VERDICT r2 #6); when that check happens: UNetEngine.result_leaves
+        out2 = eng.result_leaves(lambda: self._run_plan_once(plan, x, eng, L))
+        return out if out2 is None else out2
 
     def _run_plan_once(self, plan, x, eng, L):
         B, C_, T = x.shape

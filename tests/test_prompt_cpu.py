@@ -273,3 +273,47 @@ def test_full_chain_ids_to_mel_torch_backend(gold):
     audio, mel = ns2.sample(*[torch.from_numpy(a) for a in args], PassThroughVocoder(), sample_method="unipc",
                             noise=torch.from_numpy(x_T), prior_noise=torch.from_numpy(pn))
     assert mel.shape == gf["mel"].shape and rel_l2(mel.numpy(), gf["mel"]) < 2e-5 and rel_l2(audio.numpy(), gf["audio"]) < 2e-5
+
+
+# ---- BASELINE.json configuration 5 (B = 16, C = 100, prior -> prompt encoder -> 20-step DPM-Solver++) at reduced length ---------
+def config5_case(gold):
+    """Inputs of tests/golden/config5_b16.npz (tools/make_golden_config5.py: the stub-imported reference's own chain)."""
+    g5 = gold("config5_b16.npz")
+    B, L, T = int(g5["B"]), int(g5["L"]), int(g5["T"])
+    dcfg = ast.literal_eval(str(g5["diffusion_encoder"]))
+    y = synth.normal(1234, "cfg5.refer", (B, 100, L))
+    x_T = synth.normal(1234, "cfg5.x_T", (B, dcfg["in_channels"], T))
+    pn = synth.normal(1234, "cfg5.prior_noise", (B, 128, T))
+    x_lengths = np.full((B,), int(g5["TX"]), np.int64)
+    y_lengths = np.full((B,), L, np.int64)
+    return g5, dcfg, y, x_T, pn, x_lengths, y_lengths
+
+
+def test_oracle_config5_b16_chain_matches_reference(gold):
+    """The oracle's restatement of the whole configuration-5 chain - text encoder, duration predictor, alignment, o_proj
+    (oracle/text_enc_ref.py, prior_ref.py), prompt encoder inside every denoiser call (prompt_ref.py), 20-step DPM-Solver++
+    (sampler_ref.py) - on sixteen utterances against the mel the imported reference produced for the same ids and seeds."""
+    from oracle import prior_ref, prompt_ref, sampler_ref, text_enc_ref, unet_ref
+    g5, dcfg, y, x_T, pn, x_lengths, y_lengths = config5_case(gold)
+    g, sd, _ = prior_case(gold)
+    kw = ast.literal_eval(str(g["vits_kwargs"]))
+    tsd = {k: torch.from_numpy(v) for k, v in sd.items()}
+    ty, tl, yl = torch.from_numpy(y), torch.from_numpy(x_lengths), torch.from_numpy(y_lengths)
+    with torch.no_grad():
+        g_ref = prior_ref.ref_enc(tsd, ty).unsqueeze(-1)
+        ex, em, el, emask = text_enc_ref.text_encoder(tsd, torch.from_numpy(g5["text"]), tl, torch.from_numpy(g5["tone"]),
+                                                      torch.from_numpy(g5["language"]), g_ref, kw["n_heads"], kw["n_layers"], kw["kernel_size"])
+        z, _, ylen, _ = prior_ref.infer_from_encoder(tsd, ex, em, el, emask, tl, ty, yl, lambda shp: torch.from_numpy(pn))
+        assert np.array_equal(ylen.numpy(), g5["frames"]) and z.shape[2] == int(g5["T"])
+        H = dcfg["hidden_channels"]
+        ucfg = unet_ref.default_config(dcfg["in_channels"] + H, dcfg["out_channels"], (128, 256, 384, 512), H, dcfg["n_heads"], 8, 2, 64)
+        dsd = {k: torch.from_numpy(v) for k, v in diffusion_state_dict(dcfg).items()}
+        betas = torch.from_numpy(np.asarray(sampler_ref_betas(int(g5["timesteps"]))))
+        mel = sampler_ref.dpm_solver_pp_sample(lambda xx, t_in: prompt_ref.diffusion_encoder_forward(dsd, ucfg, xx, z, ty, yl, t_in),
+                                               betas, torch.from_numpy(x_T), int(g5["steps"]), 2, "time_uniform")
+    assert rel_l2(mel.numpy(), g5["mel"]) < 1e-6
+
+
+def sampler_ref_betas(timesteps):
+    from oracle import sample_ref
+    return sample_ref.schedule_buffers(timesteps)["betas"].numpy()
