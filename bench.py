@@ -525,6 +525,15 @@ def main():
         # the per-launch event pairs above (~+2.5 us each) give the per-family split and are reported beside it
         gemm_us, gemm_n = eng.time_family("gemm", reps=10)
         flops_gemm_fwd = g[1] / reps
+        fam = {}
+        for kind in ("gemm", "chain", "attn"):
+            if kind not in agg:
+                continue
+            us_k, n_k = (gemm_us, gemm_n) if kind == "gemm" else eng.time_family(kind, reps=10)
+            fl_k = agg[kind][1] / reps
+            fam[kind] = {"launches_per_forward": n_k, "avg_launch_us": us_k, "gflop_per_forward": fl_k / 1e9,
+                         "ms_per_forward_back_to_back": us_k * n_k * 1e-3,
+                         "achieved": fl_k / (us_k * 1e-6 * n_k) / 1e12, "frac": fl_k / (us_k * 1e-6 * n_k) / 1e12 / peak}
         achieved = flops_gemm_fwd / (gemm_us * 1e-6 * gemm_n) / 1e12
         achieved_evpair = g[1] / (g[2] * 1e-3) / 1e12
         fwd_ms = 1e3 * dt / args.steps / S
@@ -566,6 +575,11 @@ def main():
             "kernel": "k_gemm<*> (implicit-GEMM conv1d/linear, all tile instantiations)",
             "flops_per_launch": flops_gemm_fwd / gemm_n, "avg_launch_us": gemm_us, "launches_per_forward": gemm_n,
             "avg_op_us_event_pair_per_operation": 1e3 * g[2] / g[0], "achieved_event_pair_per_launch": achieved_evpair,
+            # every MFMA kernel family the same way (live back-to-back replay of the family's launches between one event pair):
+            # round 5 moved the GEGLU / ffproj GEMMs of the C = 256 / 384 blocks - the family's most efficient launches - into
+            # k_ff_split, which is counted under "chain"; family averages are not comparable across that change, the whole-forward
+            # fraction below is
+            "families": fam,
             "per_kind_ms_per_forward": {k: v[2] / reps for k, v in agg.items()},
             "per_kind_operations": {k: v[0] // reps for k, v in agg.items()},   # a split-K GEMM pair is one operation
             "forward": {"launches": n_launch,

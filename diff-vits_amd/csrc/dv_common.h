@@ -224,7 +224,7 @@ struct FFSplitParams {
   float* out; float* stats16;                     // [M, C] fp32 (null: nobody reads it); [M/32, C/16, 2] or null
   bf16_t* out_hi; bf16_t* out_lo;                 // optional split planes of the output
   float* xbuf;                                    // partial sums: ff_split_xbuf_floats(M, C, nspl) floats of scratch
-  unsigned long long* flags;                      // (M / 64) * nspl exchange words, EMPTY (all ones) before the launch
+  unsigned long long* flags;                      // (M / 64) * nspl * 8 exchange words (one per wave), EMPTY (all ones) before the launch
   unsigned* status; int spin_max;                 // time-out flag / bound of the waits (GnxParams)
   GnxParams gnx;                                  // xchg != null: the consumer's GroupNorm is finished by this launch
 };

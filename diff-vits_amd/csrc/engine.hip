@@ -1308,7 +1308,7 @@ struct Builder {
     {
       FFSplitParams fp{};
       fp.M = M; fp.C = C; fp.T = Tp; fp.Tv = Tn; fp.nspl = C == 256 ? 4 : 8;
-      const size_t n_flags = ((size_t)(M / 64) * fp.nspl + 1) & ~(size_t)1;
+      const size_t n_flags = (size_t)(M / 64) * fp.nspl * 8;          // one word per wave (kernels_ffsplit.hip)
       if (ff_split_on && merged_ffproj && chain_on && gnx_on && u->exclusive && !arena.exact && !autotune_on() && l3.stat && x.stat16 &&
           n_cu > 0 && (C == 256 || C == 384) && ff_split_supported(fp, prec) && (M / 64) * fp.nspl <= n_cu &&
           gnx_used + n_flags <= dv_unet::GNX_POOL) {
@@ -1665,7 +1665,9 @@ struct Builder {
       release(tsin); release(h1);
       probe("emb", emb, 1, E);
     }
-    const int cin = c.in_channels, cpad = rup(cin, 32);
+    // (input channels padded to whole 64-deep k-tiles: 208 -> 256 instead of 224 - conv_in then runs the 64-deep tile menu,
+    // 12 k-tiles instead of 21 half-depth ones: 20.7 k -> ~13 k cycles of k-loop at the bench shape, profiles/r05_gemm_per_launch_trace.txt)
+    const int cin = c.in_channels, cpad = cin > 64 ? rup(cin, 64) : rup(cin, 32);
     const int Tp0 = pitch(T);                            // row pitch of the first level (padding rows: zeros)
     Planes xin = alloc_planes((size_t)B * Tp0 * cpad);
     emit(S, [=](hipStream_t st) {

@@ -2,8 +2,10 @@
 // (persist.hip).  See kernels_gemm.hip for the design notes.
 #pragma once
 #ifndef DV_GNX_STATS_FIRST
-// 1: a fragment's 32x16 block statistics are computed and published before its result stores are issued (0: round-4 order)
-#define DV_GNX_STATS_FIRST 1
+// 1: a fragment's 32x16 block statistics are computed and published before its result stores are issued; 0 (default): behind them.
+// Round 5, same-box A/B (profiles/r05_ab_stats_first.txt): 62.29 k vs 62.42 k mel-frames/s - the publishing workgroup is rarely the
+// one the launch waits for; not adopted
+#define DV_GNX_STATS_FIRST 0
 #endif
 #ifndef DV_GEMM_EXP
 // development knob (trace experiments on the plain tile's k-loop, WRONG results): 1 = B fragments read from LDS once, not per

@@ -408,8 +408,10 @@ __global__ __launch_bounds__(NT) void k_ff_split(const FFSplitParams p) {
         }
     wait_vmcnt<0>();                                         // this thread's partial sums have been written through
   }
-  __syncthreads();
-  if (tid == 0) __hip_atomic_store(p.flags + (size_t)rb * NSPL + s, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  // one flag word per WAVE: a finishing wave needs the partial sums of exactly one wave of every workgroup of its row block (the one
+  // that multiplied its column fragment) - it waits for those four / eight words, not for whole workgroups, and no barrier sits
+  // between a wave's last store and its flag [v3: one flag per workgroup behind a __syncthreads]
+  if (lane == 0) __hip_atomic_store(p.flags + ((size_t)rb * NSPL + s) * NWV + wave, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   DV_FTRACE(7);
   const int b_item = m0 / p.T, Tv = p.Tv > 0 ? p.Tv : p.T;
   const int t_row = f_m - b_item * p.T;
@@ -420,10 +422,13 @@ __global__ __launch_bounds__(NT) void k_ff_split(const FFSplitParams p) {
   if (fin) {
     // wait for the flags of this row block (every wave polls for itself: no barrier behind the wait); bounded and flagged
     {
-      const unsigned long long* fl = p.flags + (size_t)rb * NSPL;
+      // (the wave of workgroup `lane` that wrote this unit's block: column fragment f_hf / 2 - and, with two k-groups, the group
+      // that owns row fragment f_rf)
+      const int cfw = f_hf >> 1, ww = G::KGB == 1 ? cfw : f_rf * 4 + cfw / G::NFW;
+      const unsigned long long* fl = p.flags + (size_t)rb * NSPL * NWV + ww;
       for (int spins = 0;; ++spins) {
         bool ok = true;
-        if (lane < NSPL) ok = __hip_atomic_load(fl + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != ~0ull;
+        if (lane < NSPL) ok = __hip_atomic_load(fl + lane * NWV, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != ~0ull;
         if (__all(ok)) break;
         const bool lost = (spins & 63) == 63 && __hip_atomic_load(p.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u;
         if (lost) break;
