@@ -1308,9 +1308,10 @@ struct Builder {
     {
       FFSplitParams fp{};
       fp.M = M; fp.C = C; fp.T = Tp; fp.Tv = Tn; fp.nspl = C == 256 ? 4 : 8;
-      const size_t n_flags = (size_t)(M / 64) * fp.nspl * 8;          // one word per wave (kernels_ffsplit.hip)
+      const int ff_rows = ff_split_rows(C);                            // 64 rows per workgroup, 32 at C = 512
+      const size_t n_flags = (size_t)(M / ff_rows) * fp.nspl * 8;       // one word per wave (kernels_ffsplit.hip)
       if (ff_split_on && merged_ffproj && chain_on && gnx_on && u->exclusive && !arena.exact && !autotune_on() && l3.stat && x.stat16 &&
-          n_cu > 0 && (C == 256 || C == 384) && ff_split_supported(fp, prec) && (M / 64) * fp.nspl <= n_cu &&
+          n_cu > 0 && (C == 256 || C == 384 || C == 512) && ff_split_supported(fp, prec) && (M / ff_rows) * fp.nspl <= n_cu &&
           gnx_used + n_flags <= dv_unet::GNX_POOL) {
         const std::string mw = tb + "__ffproj.weight", mb = tb + "__ffproj.bias";
         if (!dry && !u->packed.count(p + "ffproj")) {
@@ -1346,7 +1347,7 @@ struct Builder {
         cur_flops = 2.0 * (double)M * C * (8.0 * C + 5.0 * C);
         {
           char buf[96];
-          snprintf(buf, sizeof(buf), "LN+GEGLU+ffproj+res%s (%d wg / 64 rows) M=%d C=%d", fp.gnx.xchg ? "+gnx" : "", fp.nspl, M, C);
+          snprintf(buf, sizeof(buf), "LN+GEGLU+ffproj+res%s (%d wg / %d rows) M=%d C=%d", fp.gnx.xchg ? "+gnx" : "", fp.nspl, ff_rows, M, C);
           cur_desc = buf;
         }
         if (!dry) u->flops += cur_flops;

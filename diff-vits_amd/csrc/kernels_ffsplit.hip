@@ -46,14 +46,16 @@ extern "C" int dv_debug_ffs_trace(unsigned long long* host, int n_wg) {
 
 namespace {
 
-constexpr int BM = 64, NWV = 8, NT = 64 * NWV;
-constexpr int CHP = BM * 128;                       // bytes of one 64-channel chunk of one plane of a resident operand
+constexpr int NWV = 8, NT = 64 * NWV;
 __device__ __forceinline__ int swz(int row) { return (row >> 1) & 7; }
 __device__ __forceinline__ unsigned pk(float lo, float hi) { return dv_cvt_pk_bf16(lo, hi); }
 struct BFrag { bf16x8 h, l; };
 
-template <int C, int NSPL>
+// RF = row fragments per workgroup: 2 (64 rows: C = 256 / 384) or 1 (32 rows: C = 512, where 64 rows of h3 alone would fill the LDS)
+template <int C, int NSPL, int RF>
 struct FFGeom {
+  static constexpr int BM = 32 * RF;
+  static constexpr int CHP = BM * 128;                              // bytes of one 64-channel chunk of one plane of a resident operand
   static constexpr int KSA = C / 16;                               // k-steps of stage A (K = C)
   static constexpr int PS = 4 * C / NSPL, UNITS = PS / 32;          // product columns of a slice; 32-column units ([32 a | 32 gate] packed blocks)
   static constexpr int HS = C / NSPL, HKS = HS / 16, PKS = PS / 16; // the slice's share of h3's channels / k-steps of either part of stage B
@@ -65,17 +67,21 @@ struct FFGeom {
   static constexpr int BNF = C / NSPL, HFT = BNF / 16;              // finishing tile: columns / 16-column blocks
   static constexpr int A_CH = C / 64, A_PL = A_CH * CHP, G_CH = PS / 64, G_PL = G_CH * CHP;
   static constexpr int SMEM = 2 * A_PL + 2 * G_PL;
-  static_assert(KGB == 1 || 2 * 4 * NFW * 4 * 64 * 16 <= 2 * A_PL, "k-group exchange of stage B fits the h3 region");
-  static constexpr int DA = 8, DB = NFW == 1 ? 8 : 6;               // weight units (hi + lo fragment: 8 VGPRs) in flight per wave
-  static_assert(UNITS <= NWV && PS % 64 == 0 && HS % 16 == 0 && NF % (NWV / KGB) == 0 && BNF % 16 == 0 && HFT * 2 <= NWV, "geometry");
+  static constexpr int NIT = NFW * RF;                              // (fragment, row fragment) items a wave accumulates in stage B
+  static_assert(KGB == 1 || (NIT % 2 == 0 && 2 * 4 * (NIT / 2) * 4 * 64 * 16 <= 2 * A_PL), "k-group exchange of stage B fits the h3 region");
+  static constexpr int DA = 8, DB = NFW == 3 ? 6 : 8;               // weight units (hi + lo fragment: 8 VGPRs) in flight per wave
+  static constexpr int CPG = 8 / (BM / 8);                          // chunks of h3 one round of LDS-DMAs (one instruction per wave and plane) covers
+  static constexpr int KS_G1 = CPG * 4;                             // first k-step that reads h3 beyond the first round
+  static_assert(UNITS <= NWV && PS % 64 == 0 && HS % 16 == 0 && NF % (NWV / KGB) == 0 && BNF % 16 == 0 && HFT * RF <= NWV && A_CH % CPG == 0 && A_CH > CPG, "geometry");
 };
 
-template <int C, int NSPL>
+template <int C, int NSPL, int RF>
 __global__ __launch_bounds__(NT) void k_ff_split(const FFSplitParams p) {
-  using G = FFGeom<C, NSPL>;
+  using G = FFGeom<C, NSPL, RF>;
+  constexpr int BM = G::BM, CHP = G::CHP;
   extern __shared__ __attribute__((aligned(1024))) char smem[];
-  char* const a_reg = smem;                                  // h3:      [2 planes][C / 64 chunks][64 rows][128 B]
-  char* const g_reg = smem + 2 * G::A_PL;                    // product: [2 planes][PS / 64 chunks][64 rows][128 B]
+  char* const a_reg = smem;                                  // h3:      [2 planes][C / 64 chunks][BM rows][128 B]
+  char* const g_reg = smem + 2 * G::A_PL;                    // product: [2 planes][PS / 64 chunks][BM rows][128 B]
   constexpr int NB = C / 32;                                 // LayerNorm row partials per row
   __shared__ __attribute__((aligned(1024))) float2 s_rs[BM * NB];           // the rows' raw partials (sum, M2 about the block mean)
   __shared__ __attribute__((aligned(256))) float s_ug[G::UNITS * 64], s_bg[G::UNITS * 64];
@@ -146,11 +152,12 @@ __global__ __launch_bounds__(NT) void k_ff_split(const FFSplitParams p) {
       glds4(src, (unsigned)(size_t)s_pf);
     }
   }
-  // h3 planes -> LDS: instruction = (64-channel chunk c, 8 rows r8) of one plane; wave w sends rows 8 w .. 8 w + 7 of every chunk
-  auto h3_chunk = [&](int c) __attribute__((always_inline)) {
-    const int d_row = lane >> 3, d_slot = lane & 7, row = wave * 8 + d_row;
+  // h3 planes -> LDS: instruction = (64-channel chunk, 8 rows) of one plane; one round = one instruction per wave and plane =
+  // CPG chunks (64 rows: wave w sends rows 8 w .. 8 w + 7 of one chunk; 32 rows: waves 0-3 / 4-7 send two chunks)
+  auto h3_chunk = [&](int cg) __attribute__((always_inline)) {
+    const int d_row = lane >> 3, d_slot = lane & 7, r8 = wave % (BM / 8), c = cg * G::CPG + wave / (BM / 8), row = r8 * 8 + d_row;
     const size_t e = (size_t)(m0 + row) * C + c * 64 + ((d_slot ^ swz(row)) << 3);
-    const unsigned dst = a_base + (unsigned)(c * CHP + wave * 1024);
+    const unsigned dst = a_base + (unsigned)(c * CHP + r8 * 1024);
     glds16(p.a_hi + e, dst);
     glds16(p.a_lo + e, dst + G::A_PL);
   };
@@ -161,8 +168,8 @@ __global__ __launch_bounds__(NT) void k_ff_split(const FFSplitParams p) {
   }
   __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-  for (int c = 1; c < G::A_CH; ++c) h3_chunk(c);             // 4.
-  constexpr int NC = (G::A_CH - 1) * 2;                      // ... LDS-DMA instructions per wave
+  for (int c = 1; c < G::A_CH / G::CPG; ++c) h3_chunk(c);    // 4.
+  constexpr int NC = (G::A_CH / G::CPG - 1) * 2;             // ... LDS-DMA instructions per wave
   if (a_wave) {                                              // 5.
 #pragma unroll
     for (int j = 4; j < 8; ++j) bq[j] = load_a_unit(j);
@@ -178,10 +185,10 @@ __global__ __launch_bounds__(NT) void k_ff_split(const FFSplitParams p) {
   DV_FTRACE(2);
 
   // A fragments (both row fragments, both planes) of k-step `ks` of a resident operand
-  auto read_frag = [&](const char* reg, int pl_bytes, int ks, bf16x8 (&h)[2], bf16x8 (&l)[2]) __attribute__((always_inline)) {
+  auto read_frag = [&](const char* reg, int pl_bytes, int ks, bf16x8 (&h)[RF], bf16x8 (&l)[RF]) __attribute__((always_inline)) {
     const int c16 = ks * 2 + lh;
 #pragma unroll
-    for (int rf = 0; rf < 2; ++rf) {
+    for (int rf = 0; rf < RF; ++rf) {
       const int row = rf * 32 + l31;
       const int off = (c16 >> 3) * CHP + row * 128 + (((c16 & 7) ^ swz(row)) << 4);
       h[rf] = *reinterpret_cast<const bf16x8*>(reg + off);
@@ -199,7 +206,7 @@ __global__ __launch_bounds__(NT) void k_ff_split(const FFSplitParams p) {
   // wave -> NFW column fragments from cf0 and k-group kg (KGB = 2: 4 column groups x 2 halves of the k-steps)
   const int kg = G::KGB == 1 ? 0 : wave >> 2;
   const int cf0 = G::KGB == 1 ? wave : (wave & 3) * G::NFW;
-  f32x16 accb[G::NFW][2];
+  f32x16 accb[G::NFW][RF];
   auto load_b_unit = [&](int j, int i) __attribute__((always_inline)) {        // k-step j of the workgroup's range, fragment cf0 + i
     const int ksw = j < G::HKS ? s * G::HKS + j : G::KSA + s * G::PKS + (j - G::HKS);
     const size_t e = ((size_t)((cf0 + i) * G::KSBW + ksw) * 64 + lane) * 8;
@@ -222,30 +229,31 @@ __global__ __launch_bounds__(NT) void k_ff_split(const FFSplitParams p) {
     constexpr int J0 = KG == 0 ? 0 : (G::KSB + 1) / 2;
     constexpr int JN = G::KGB == 1 ? G::KSB : (KG == 0 ? (G::KSB + 1) / 2 : G::KSB / 2);
     constexpr int UB = JN * G::NFW;
-    auto read_b = [&](int j, bf16x8 (&h)[2], bf16x8 (&l)[2]) __attribute__((always_inline)) {
+    auto read_b = [&](int j, bf16x8 (&h)[RF], bf16x8 (&l)[RF]) __attribute__((always_inline)) {
       if (j < G::HKS) read_frag(a_reg, G::A_PL, s * G::HKS + j, h, l);
       else read_frag(g_reg, G::G_PL, j - G::HKS, h, l);
     };
-    bf16x8 ah[2][2], al[2][2];
+    bf16x8 ah[2][RF], al[2][RF];
     read_b(J0, ah[0], al[0]);
 #pragma unroll
     for (int u = 0; u < UB; ++u) {
       const int jj = u / G::NFW, i = u % G::NFW, cur = jj & 1;
       if (i == 0 && jj + 1 < JN) read_b(J0 + jj + 1, ah[cur ^ 1], al[cur ^ 1]);
       const BFrag w = bq[u % G::DB];
-      accb[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.h, al[cur][0], accb[i][0], 0, 0, 0);
-      accb[i][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.h, al[cur][1], accb[i][1], 0, 0, 0);
-      accb[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.l, ah[cur][0], accb[i][0], 0, 0, 0);
-      accb[i][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.l, ah[cur][1], accb[i][1], 0, 0, 0);
-      accb[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.h, ah[cur][0], accb[i][0], 0, 0, 0);
-      accb[i][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.h, ah[cur][1], accb[i][1], 0, 0, 0);
+      // (the row fragments alternate: consecutive MFMAs write different accumulators)
+#pragma unroll
+      for (int rf = 0; rf < RF; ++rf) accb[i][rf] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.h, al[cur][rf], accb[i][rf], 0, 0, 0);
+#pragma unroll
+      for (int rf = 0; rf < RF; ++rf) accb[i][rf] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.l, ah[cur][rf], accb[i][rf], 0, 0, 0);
+#pragma unroll
+      for (int rf = 0; rf < RF; ++rf) accb[i][rf] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.h, ah[cur][rf], accb[i][rf], 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
       if (u + G::DB < UB) bq[u % G::DB] = load_b_unit(J0 + (u + G::DB) / G::NFW, (u + G::DB) % G::NFW);
       __builtin_amdgcn_sched_barrier(0);
     }
   };
-  const bool fin = wave < G::HFT * 2;
-  const int f_rf = wave & 1, f_hf = s * G::HFT + (wave >> 1);       // finishing unit: row fragment, 16-column block of the output
+  const bool fin = wave < G::HFT * RF;
+  const int f_rf = wave % RF, f_hfl = wave / RF, f_hf = s * G::HFT + f_hfl;   // finishing unit: row fragment, 16-column block of the output (tile-local / global)
   const int f_m = m0 + f_rf * 32 + l31;
   float4 rres[2], rbias[2];
   // The first weight fragments of stage B and the finishing waves' bias / residual rows (cold: written a whole transformer block
@@ -270,31 +278,31 @@ __global__ __launch_bounds__(NT) void k_ff_split(const FFSplitParams p) {
 
   // ================= stage A: GEGLU of this wave's 32 product columns, both row fragments =================
   if (a_wave) {
-    f32x16 acc[2][2];                                        // [a | gate][row fragment]
+    f32x16 acc[2][RF];                                       // [a | gate][row fragment]
 #pragma unroll
     for (int f = 0; f < 2; ++f)
 #pragma unroll
-      for (int rf = 0; rf < 2; ++rf)
+      for (int rf = 0; rf < RF; ++rf)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[f][rf][r] = 0.f;
-    bf16x8 ah[2][2], al[2][2];
+    bf16x8 ah[2][RF], al[2][RF];
     read_frag(a_reg, G::A_PL, 0, ah[0], al[0]);
 #pragma unroll
     for (int U = 0; U < UA; ++U) {
       const int ks = U >> 1, f = U & 1, cur = ks & 1;
-      if (U == 6) {        // k-step 4 (read ahead below) is the first of chunk 1: the rest of h3 has landed - here and in every wave
-        wait_vmcnt<12>();  // (younger than the DMAs: the refills of units 8-13 only)
+      if (U == 2 * (G::KS_G1 - 1) && G::A_CH > G::CPG) {   // the k-step read ahead below is the first beyond the first round of h3 DMAs: the rest has landed - here and in every wave
+        wait_vmcnt<16>();  // (younger than the DMAs: the eight weight units in flight, U .. U + 7)
         __builtin_amdgcn_s_barrier();
       }
       if (f == 0 && ks + 1 < G::KSA) read_frag(a_reg, G::A_PL, ks + 1, ah[cur ^ 1], al[cur ^ 1]);
       const BFrag w = bq[U % G::DA];
-      // (the two row fragments alternate: consecutive MFMAs write different accumulators)
-      acc[f][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.h, al[cur][0], acc[f][0], 0, 0, 0);
-      acc[f][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.h, al[cur][1], acc[f][1], 0, 0, 0);
-      acc[f][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.l, ah[cur][0], acc[f][0], 0, 0, 0);
-      acc[f][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.l, ah[cur][1], acc[f][1], 0, 0, 0);
-      acc[f][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.h, ah[cur][0], acc[f][0], 0, 0, 0);
-      acc[f][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.h, ah[cur][1], acc[f][1], 0, 0, 0);
+      // (the row fragments alternate: consecutive MFMAs write different accumulators)
+#pragma unroll
+      for (int rf = 0; rf < RF; ++rf) acc[f][rf] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.h, al[cur][rf], acc[f][rf], 0, 0, 0);
+#pragma unroll
+      for (int rf = 0; rf < RF; ++rf) acc[f][rf] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.l, ah[cur][rf], acc[f][rf], 0, 0, 0);
+#pragma unroll
+      for (int rf = 0; rf < RF; ++rf) acc[f][rf] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.h, ah[cur][rf], acc[f][rf], 0, 0, 0);
       // pinned: without the scheduling barriers hipcc sinks every prefetch down to its use (load -> vmcnt(0) -> MFMA)
       __builtin_amdgcn_sched_barrier(0);
       if (U + G::DA < UA) bq[U % G::DA] = load_a_unit(U + G::DA);
@@ -303,7 +311,7 @@ __global__ __launch_bounds__(NT) void k_ff_split(const FFSplitParams p) {
     DV_FTRACE(3);
     // LayerNorm finish + bias, a * gelu(gate) -> product columns wave * 32 + (8g + 4lh + e) of the slice as split planes in LDS
 #pragma unroll
-    for (int rf = 0; rf < 2; ++rf) {
+    for (int rf = 0; rf < RF; ++rf) {
       const int row = rf * 32 + l31;
       float2 st;
       {   // (mean, rstd) of this lane's row from the producer's partials per 32-column block, parallel-variance form (gemm_tile.h)
@@ -353,7 +361,7 @@ __global__ __launch_bounds__(NT) void k_ff_split(const FFSplitParams p) {
 #pragma unroll
   for (int i = 0; i < G::NFW; ++i)
 #pragma unroll
-    for (int rf = 0; rf < 2; ++rf)
+    for (int rf = 0; rf < RF; ++rf)
 #pragma unroll
       for (int r = 0; r < 16; ++r) accb[i][rf][r] = 0.f;
   __builtin_amdgcn_sched_barrier(0);
@@ -366,46 +374,55 @@ __global__ __launch_bounds__(NT) void k_ff_split(const FFSplitParams p) {
   // ================= hand-over: partial sums written through, flag, wait for the row block, finish C / nspl columns =================
   // xbuf (float4 units): [row block][16-column block hf][source][row fragment][gg][64 lanes]; register group g of column fragment cf
   // is 16-column block 2 cf + (g >> 1), half gg = g & 1 (columns 8 gg + 4 lh + e of the block)
-  float4* const xb = reinterpret_cast<float4*>(p.xbuf) + (size_t)rb * (2 * G::NF) * G::NSRC * 4 * 64 + lane;
+  float4* const xb = reinterpret_cast<float4*>(p.xbuf) + (size_t)rb * (2 * G::NF) * G::NSRC * RF * 2 * 64 + lane;
+  auto xslot = [&](int hf, int rf, int gg) { return xb + ((size_t)((hf * G::NSRC + s) * RF + rf) * 2 + gg) * 64; };
   if constexpr (G::KGB == 2) {
-    // two k-groups (C = 384): added through LDS first - row fragment rf BELONGS to k-group rf: each group hands the other's
-    // fragments over and keeps its own, so both directions cross the LDS at once and every wave writes half of the partial sums
-    // (first version: both groups wrote everything through and the finishing waves summed 16 sources - 25 k of 88 k cycles)
+    // two k-groups (C = 384, 512): added through LDS first.  Item q = fragment * RF + row fragment BELONGS to k-group q & 1: each group
+    // hands the other's items over and keeps its own, so both directions cross the LDS at once and every wave writes half of
+    // the partial sums (first version: both groups wrote everything through and the finishing waves summed 16 sources - 25 k of 88 k cycles)
     __syncthreads();                                         // every wave is done reading the resident operands
-    float4* red4 = reinterpret_cast<float4*>(a_reg) + (size_t)(wave & 3) * (G::NFW * 4 * 64) + lane;   // [column group][fragment][g][64 lanes]
+    constexpr int HO = G::NIT / 2;                           // items handed over per wave
+    float4* red4 = reinterpret_cast<float4*>(a_reg) + lane;  // [writer's k-group][column group][item slot q >> 1][g][64 lanes]
 #pragma unroll
     for (int i = 0; i < G::NFW; ++i)
 #pragma unroll
-      for (int g = 0; g < 4; ++g)
-        // (the half the OTHER group owns; selects, not a run-time index: an indexed register array lives in scratch memory)
-        red4[(size_t)(kg * 4 * G::NFW + i) * 4 * 64 + g * 64] =
-            kg ? make_float4(accb[i][0][4 * g], accb[i][0][4 * g + 1], accb[i][0][4 * g + 2], accb[i][0][4 * g + 3])
-               : make_float4(accb[i][1][4 * g], accb[i][1][4 * g + 1], accb[i][1][4 * g + 2], accb[i][1][4 * g + 3]);
+      for (int rf = 0; rf < RF; ++rf) {
+        const int q = i * RF + rf;
+        // (a wave-uniform branch per item, not a run-time index: an indexed register array lives in scratch memory)
+        if ((q & 1) != kg) {
+#pragma unroll
+          for (int g = 0; g < 4; ++g)
+            red4[(size_t)(((kg * 4 + (wave & 3)) * HO + (q >> 1)) * 4 + g) * 64] =
+                make_float4(accb[i][rf][4 * g], accb[i][rf][4 * g + 1], accb[i][rf][4 * g + 2], accb[i][rf][4 * g + 3]);
+        }
+      }
     __syncthreads();
 #pragma unroll
     for (int i = 0; i < G::NFW; ++i)
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const float4 v = red4[(size_t)((kg ^ 1) * 4 * G::NFW + i) * 4 * 64 + g * 64];
-        // (k-group 0's sums first, whichever group adds)
-        float4 a = kg ? make_float4(accb[i][1][4 * g], accb[i][1][4 * g + 1], accb[i][1][4 * g + 2], accb[i][1][4 * g + 3])
-                      : make_float4(accb[i][0][4 * g], accb[i][0][4 * g + 1], accb[i][0][4 * g + 2], accb[i][0][4 * g + 3]);
-        a = kg == 0 ? make_float4(a.x + v.x, a.y + v.y, a.z + v.z, a.w + v.w) : make_float4(v.x + a.x, v.y + a.y, v.z + a.z, v.w + a.w);
-        const int hf = 2 * (cf0 + i) + (g >> 1);
-        st_handover16(xb + ((size_t)((hf * G::NSRC + s) * 2 + kg) * 2 + (g & 1)) * 64, a);
+      for (int rf = 0; rf < RF; ++rf) {
+        const int q = i * RF + rf;
+        if ((q & 1) == kg) {
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const float4 v = red4[(size_t)((((kg ^ 1) * 4 + (wave & 3)) * HO + (q >> 1)) * 4 + g) * 64];
+            float4 a = make_float4(accb[i][rf][4 * g], accb[i][rf][4 * g + 1], accb[i][rf][4 * g + 2], accb[i][rf][4 * g + 3]);
+            // (k-group 0's sums first, whichever group adds)
+            a = kg == 0 ? make_float4(a.x + v.x, a.y + v.y, a.z + v.z, a.w + v.w) : make_float4(v.x + a.x, v.y + a.y, v.z + a.z, v.w + a.w);
+            st_handover16(xslot(2 * (cf0 + i) + (g >> 1), rf, g & 1), a);
+          }
+        }
       }
     wait_vmcnt<0>();
   } else {
 #pragma unroll
     for (int i = 0; i < G::NFW; ++i)
 #pragma unroll
-      for (int rf = 0; rf < 2; ++rf)
+      for (int rf = 0; rf < RF; ++rf)
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const int hf = 2 * (cf0 + i) + (g >> 1);
-          st_handover16(xb + ((size_t)((hf * G::NSRC + s) * 2 + rf) * 2 + (g & 1)) * 64,
+        for (int g = 0; g < 4; ++g)
+          st_handover16(xslot(2 * (cf0 + i) + (g >> 1), rf, g & 1),
                         make_float4(accb[i][rf][4 * g], accb[i][rf][4 * g + 1], accb[i][rf][4 * g + 2], accb[i][rf][4 * g + 3]));
-        }
     wait_vmcnt<0>();                                         // this thread's partial sums have been written through
   }
   // one flag word per WAVE: a finishing wave needs the partial sums of exactly one wave of every workgroup of its row block (the one
@@ -423,8 +440,8 @@ __global__ __launch_bounds__(NT) void k_ff_split(const FFSplitParams p) {
     // wait for the flags of this row block (every wave polls for itself: no barrier behind the wait); bounded and flagged
     {
       // (the wave of workgroup `lane` that wrote this unit's block: column fragment f_hf / 2 - and, with two k-groups, the group
-      // that owns row fragment f_rf)
-      const int cfw = f_hf >> 1, ww = G::KGB == 1 ? cfw : f_rf * 4 + cfw / G::NFW;
+      // that owns the item (fragment, row fragment))
+      const int cfw = f_hf >> 1, ww = G::KGB == 1 ? cfw : ((((cfw % G::NFW) * RF + f_rf) & 1) * 4 + cfw / G::NFW);
       const unsigned long long* fl = p.flags + (size_t)rb * NSPL * NWV + ww;
       for (int spins = 0;; ++spins) {
         bool ok = true;
@@ -445,7 +462,7 @@ __global__ __launch_bounds__(NT) void k_ff_split(const FFSplitParams p) {
     }
     DV_FTRACE(8);
     // partial sums of this unit's 32 x 16 block, in source order (slice, k-group): the same bits on every run
-    const float4* src0 = xb + (size_t)(f_hf * G::NSRC * 2 + f_rf) * 2 * 64;
+    const float4* src0 = xb + (size_t)(f_hf * G::NSRC * RF + f_rf) * 2 * 64;
     constexpr int BATCH = G::NSRC < 8 ? G::NSRC : 8;
 #pragma unroll
     for (int s0 = 0; s0 < G::NSRC; s0 += BATCH) {
@@ -453,7 +470,7 @@ __global__ __launch_bounds__(NT) void k_ff_split(const FFSplitParams p) {
 #pragma unroll
       for (int k = 0; k < BATCH; ++k)
 #pragma unroll
-        for (int gg = 0; gg < 2; ++gg) t[k][gg] = ld_handover16(src0 + ((size_t)(s0 + k) * 4 + gg) * 64);
+        for (int gg = 0; gg < 2; ++gg) t[k][gg] = ld_handover16(src0 + ((size_t)(s0 + k) * RF * 2 + gg) * 64);
 #pragma unroll
       for (int k = 0; k < BATCH; ++k)
 #pragma unroll
@@ -504,7 +521,7 @@ __global__ __launch_bounds__(NT) void k_ff_split(const FFSplitParams p) {
     t.M = p.M; t.N = C; t.T_out = p.T; t.Tv_out = Tv; t.m0 = m0; t.n0 = s * G::BNF; t.bm = BM; t.bn = G::BNF; t.bq = b_item;
     gnx_finish_table<64>(p.gnx, t, s_gnx, tid, lane, wave, NWV, [](int) {});
     if (fin) {
-      const int cl0 = (wave >> 1) * 16 + 4 * lh;             // tile-local column of gg = 0, e = 0
+      const int cl0 = f_hfl * 16 + 4 * lh;                   // tile-local column of gg = 0, e = 0
       float y[8];
 #pragma unroll
       for (int gg = 0; gg < 2; ++gg) {
@@ -523,42 +540,48 @@ __global__ __launch_bounds__(NT) void k_ff_split(const FFSplitParams p) {
   DV_FTRACE(11);
 }
 
-template <int C, int NSPL>
+template <int C, int NSPL, int RF>
 hipError_t ffs_init_one() {
-  return hipFuncSetAttribute(reinterpret_cast<const void*>(k_ff_split<C, NSPL>), hipFuncAttributeMaxDynamicSharedMemorySize, FFGeom<C, NSPL>::SMEM);
+  return hipFuncSetAttribute(reinterpret_cast<const void*>(k_ff_split<C, NSPL, RF>), hipFuncAttributeMaxDynamicSharedMemorySize, FFGeom<C, NSPL, RF>::SMEM);
 }
-template <int C, int NSPL>
+template <int C, int NSPL, int RF>
 hipError_t ffs_launch_one(const FFSplitParams& p, hipStream_t st) {
-  constexpr int smem = FFGeom<C, NSPL>::SMEM;
-  hipLaunchKernelGGL((k_ff_split<C, NSPL>), dim3((p.M / BM) * NSPL), dim3(NT), smem, st, p);
+  constexpr int smem = FFGeom<C, NSPL, RF>::SMEM;
+  hipLaunchKernelGGL((k_ff_split<C, NSPL, RF>), dim3((p.M / (32 * RF)) * NSPL), dim3(NT), smem, st, p);
   return hipGetLastError();
 }
 
 }  // namespace
 
 hipError_t ff_split_init() {
-  hipError_t e = ffs_init_one<256, 4>();
-  return e != hipSuccess ? e : ffs_init_one<384, 8>();
+  hipError_t e = ffs_init_one<256, 4, 2>();
+  if (e == hipSuccess) e = ffs_init_one<384, 8, 2>();
+  return e != hipSuccess ? e : ffs_init_one<512, 8, 1>();
 }
+
+// rows per workgroup: 64, or 32 at C = 512 (64 rows of h3 alone - 128 KiB of split planes - would leave no room for the product)
+int ff_split_rows(int C) { return C == 512 ? 32 : 64; }
 
 bool ff_split_supported(const FFSplitParams& p, int precision) {
   if (precision != 0) return false;                                  // split-bf16 mode only
-  if (!((p.C == 256 && p.nspl == 4) || (p.C == 384 && p.nspl == 8))) return false;
-  if (p.M % BM != 0 || p.T % BM != 0 || p.M % p.T != 0) return false;   // (a 64-row block never spans two utterances)
+  if (!((p.C == 256 && p.nspl == 4) || (p.C == 384 && p.nspl == 8) || (p.C == 512 && p.nspl == 8))) return false;
+  const int bm = ff_split_rows(p.C);
+  if (p.M % bm != 0 || p.T % bm != 0 || p.M % p.T != 0) return false;   // (a row block never spans two utterances)
   if (p.Tv < 0 || p.Tv > p.T || (p.Tv > 0 && p.Tv <= p.T - 32)) return false;
   return true;
 }
 size_t ff_split_xbuf_floats(int M, int C, int nspl) {
-  return (size_t)(M / BM) * (2 * (C / 32)) * nspl * 4 * 64 * 4;
+  const int bm = ff_split_rows(C);
+  return (size_t)(M / bm) * (2 * (C / 32)) * nspl * (bm / 32) * 2 * 64 * 4;
 }
-// In-launch GroupNorm of the output: the finishing tiles ([64 rows x C / nspl columns], all resident) behave like GEMM tiles
+// In-launch GroupNorm of the output: the finishing tiles ([rows x C / nspl columns], all resident) behave like GEMM tiles
 // (the conditions of gemm_gnx_plan, kernels_gemm.hip)
 int ff_split_gnx_plan(const FFSplitParams& p, int n_cu) {
   const GnxParams& gx = p.gnx;
   if (!p.stats16 || gx.groups <= 0 || gx.groups > 64 || gx.sk_c < 0 || gx.sk_c % 16 != 0 || gx.tscale) return 0;
   if ((p.C + gx.sk_c) % gx.groups != 0) return 0;
   const int cpg = (p.C + gx.sk_c) / gx.groups;
-  if (cpg % 16 != 0 || (p.T / 32) * (cpg / 16) > 256 || (p.M / BM) * p.nspl > n_cu) return 0;
+  if (cpg % 16 != 0 || (p.T / 32) * (cpg / 16) > 256 || (p.M / ff_split_rows(p.C)) * p.nspl > n_cu) return 0;
   if (gx.sk_c > 0 && ((gx.sk_c / 16 + p.nspl - 1) / p.nspl) * 16 > DV_GSK) return 0;   // skip slice per workgroup
   return (p.M / 32) * (p.C / 16);
 }
@@ -569,10 +592,11 @@ hipError_t launch_ff_split(const FFSplitParams& p, int precision, hipStream_t st
       !p.flags || !p.status || (p.out_hi && !p.out_lo))
     return hipErrorInvalidValue;
   static const int n_cu = [] { int d = 0, n = 0; (void)hipGetDevice(&d); (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, d); return n; }();
-  if ((p.M / BM) * p.nspl > n_cu) return hipErrorInvalidValue;       // (every workgroup of the launch resident at once)
+  if ((p.M / ff_split_rows(p.C)) * p.nspl > n_cu) return hipErrorInvalidValue;       // (every workgroup of the launch resident at once)
   if (p.gnx.xchg) {
     if (!p.gnx.status || !p.gnx.y_hi || !p.gnx.y_lo || !p.gnx.gamma || !p.gnx.beta || ff_split_gnx_plan(p, n_cu) <= 0) return hipErrorInvalidValue;
     if (p.gnx.sk_c > 0 && (!p.gnx.sk_x || !p.gnx.sk_stat16 || !p.gnx.sk_y_hi || !p.gnx.sk_y_lo)) return hipErrorInvalidValue;
   } else if (!p.out) return hipErrorInvalidValue;
-  return p.C == 256 ? ffs_launch_one<256, 4>(p, st) : ffs_launch_one<384, 8>(p, st);
+  if (p.C == 256) return ffs_launch_one<256, 4, 2>(p, st);
+  return p.C == 384 ? ffs_launch_one<384, 8, 2>(p, st) : ffs_launch_one<512, 8, 1>(p, st);
 }

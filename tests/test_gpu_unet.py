@@ -789,8 +789,8 @@ def test_concat_groupnorm_finished_by_the_producer_of_h(B, T, L):
 
 @pytest.mark.parametrize("B,T,L", [(8, 1024, 64), (2, 512, 40), (2, 500, 33), (4, 256, 20)])
 def test_split_feed_forward_launch_matches_two_gemms(B, T, L):
-    """C = 256 / 384 transformer blocks (reference attention.py:189-203, 206-255): LN3 -> GEGLU -> merged ff.net.2 + proj_out +
-    residual runs as ONE launch of 64-row blocks whose product columns are split over 4 / 8 workgroups (k_ff_split,
+    """C = 256 / 384 / 512 transformer blocks (reference attention.py:189-203, 206-255): LN3 -> GEGLU -> merged ff.net.2 + proj_out +
+    residual runs as ONE launch of 64-row (C = 512: 32-row) blocks whose product columns are split over 4 / 8 workgroups (k_ff_split,
     kernels_ffsplit.hip: partial sums handed over inside the launch, summed in slice order).  DVITS_FF_SPLIT=0 restores the two
     GEMMs: same weights, same split-bf16 products, another summation order - float32-rounding agreement, fewer launches,
     bit-repeatable, no hand-over timed out; at the bench shape (256 workgroups = every CU), at small grids and at a padded
@@ -824,7 +824,7 @@ def test_split_feed_forward_launch_matches_two_gemms(B, T, L):
             launches.append(eng.stats()[0])
         finally:
             os.environ.pop("DVITS_FF_SPLIT", None)
-    assert launches[1] == launches[0] - 10, launches          # ten blocks at C = 256 / 384: two launches -> one
+    assert launches[1] == launches[0] - 11, launches          # eleven blocks at C = 256 / 384 / 512: two launches -> one
     assert np.isfinite(outs[1]).all()
     assert rel_l2(outs[1], outs[0]) < 2e-5, rel_l2(outs[1], outs[0])
 

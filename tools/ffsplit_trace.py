@@ -19,7 +19,7 @@ import bench  # noqa: E402
 from diff_vits_amd import synth  # noqa: E402
 
 B, T = int(sys.argv[1]) if len(sys.argv) > 1 else 8, int(sys.argv[2]) if len(sys.argv) > 2 else 1024
-CS = [int(sys.argv[3])] if len(sys.argv) > 3 else [256, 384]
+CS = [int(sys.argv[3])] if len(sys.argv) > 3 else [256, 384, 512]
 dev = torch.device("cuda", 0)
 model, _ = bench.build_model(dev, "bf16x3")
 x, cond, enc, mask = (torch.from_numpy(v).to(dev) for v in synth.make_inputs(B, 80, T, 256))
