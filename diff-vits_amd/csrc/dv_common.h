@@ -213,7 +213,8 @@ hipError_t launch_chain_ff(const ChainFFParams& p, int precision, hipStream_t st
 //            summed in slice order (deterministic), + bias + block residual -> fp32, 32x16 block statistics, optional planes,
 //            optional GroupNorm of the consumer (GnxParams) - the tile [64 rows x C / nspl columns] behaves like a GEMM tile.
 struct FFSplitParams {
-  int M, C, T;                                    // rows (T % ff_split_rows(C) == 0: row pitch per utterance), C = 256, 384 or 512
+  int M, C, T;                                    // rows (T % rows == 0: row pitch per utterance), C = 256, 384 or 512
+  int rows;                                       // rows per workgroup: 64 or 32 (ff_split_rows; C = 512: 32)
   int Tv;                                         // frames that exist per utterance (0: T)
   int nspl;                                       // workgroups per row block (4 at C = 256, 8 at C = 384 / 512)
   const bf16_t* a_hi; const bf16_t* a_lo;         // raw split planes of h3 [M, C]
@@ -224,13 +225,13 @@ struct FFSplitParams {
   float* out; float* stats16;                     // [M, C] fp32 (null: nobody reads it); [M/32, C/16, 2] or null
   bf16_t* out_hi; bf16_t* out_lo;                 // optional split planes of the output
   float* xbuf;                                    // partial sums: ff_split_xbuf_floats(M, C, nspl) floats of scratch
-  unsigned long long* flags;                      // (M / ff_split_rows(C)) * nspl * 8 exchange words (one per wave), EMPTY (all ones) before the launch
+  unsigned long long* flags;                      // (M / rows) * nspl * 8 exchange words (one per wave), EMPTY (all ones) before the launch
   unsigned* status; int spin_max;                 // time-out flag / bound of the waits (GnxParams)
   GnxParams gnx;                                  // xchg != null: the consumer's GroupNorm is finished by this launch
 };
 bool ff_split_supported(const FFSplitParams& p, int precision);
-size_t ff_split_xbuf_floats(int M, int C, int nspl);
-int ff_split_rows(int C);                       // rows per workgroup: 64 (C = 256 / 384) or 32 (C = 512)
+size_t ff_split_xbuf_floats(int M, int C, int nspl, int rows);
+int ff_split_rows(int C, int M, int T, int nspl, int n_cu);   // rows per workgroup the planner should ask for: 64 or 32 (kernels_ffsplit.hip)
 // exchange words of the in-launch GroupNorm ((M / 32) * (C / 16); gnx.groups / gnx.sk_c set), 0: not possible
 int ff_split_gnx_plan(const FFSplitParams& p, int n_cu);
 hipError_t ff_split_init();

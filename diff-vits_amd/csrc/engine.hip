@@ -719,6 +719,10 @@ struct Builder {
     if (cat && nn.raw && !u->keep_intermediates && cat_drop_fp32) fp.out = nullptr;
   }
   bool ff_split_on = [] { const char* e = getenv("DVITS_FF_SPLIT"); return !(e && e[0] == '0'); }();
+  // ... from this many workgroups: one utterance (B = 1, T = 300 or 1024: 16-64 workgroups per launch) is bound by the chain of
+  // dependent launches, and a launch with two in-launch hand-overs costs there what the two GEMM launches did (54.4 vs 53.6 ms per
+  // 30-step run, 58.5 vs 57.6 at T = 1024: measured, round 5); from 128 workgroups (B = 4) the launch wins (+4.9 %)
+  int ff_split_min_wg = [] { const char* e = getenv("DVITS_FF_SPLIT_MIN_WG"); return e ? atoi(e) : 96; }();
   bool gnx_ff_on = [] { const char* e = getenv("DVITS_GNX_FF"); return !(e && e[0] == '0'); }();
   bool cat_drop_fp32 = [] { const char* e = getenv("DVITS_GNX_CONCAT_KEEP_FP32"); return !(e && e[0] == '1'); }();
 
@@ -1308,10 +1312,11 @@ struct Builder {
     {
       FFSplitParams fp{};
       fp.M = M; fp.C = C; fp.T = Tp; fp.Tv = Tn; fp.nspl = C == 256 ? 4 : 8;
-      const int ff_rows = ff_split_rows(C);                            // 64 rows per workgroup, 32 at C = 512
+      const int ff_rows = fp.rows = ff_split_rows(C, M, Tp, fp.nspl, n_cu);   // 64 rows per workgroup; 32 at C = 512, odd pitches, small inputs
       const size_t n_flags = (size_t)(M / ff_rows) * fp.nspl * 8;       // one word per wave (kernels_ffsplit.hip)
       if (ff_split_on && merged_ffproj && chain_on && gnx_on && u->exclusive && !arena.exact && !autotune_on() && l3.stat && x.stat16 &&
           n_cu > 0 && (C == 256 || C == 384 || C == 512) && ff_split_supported(fp, prec) && (M / ff_rows) * fp.nspl <= n_cu &&
+          (M / ff_rows) * fp.nspl >= ff_split_min_wg &&
           gnx_used + n_flags <= dv_unet::GNX_POOL) {
         const std::string mw = tb + "__ffproj.weight", mb = tb + "__ffproj.bias";
         if (!dry && !u->packed.count(p + "ffproj")) {
@@ -1337,7 +1342,7 @@ struct Builder {
         fp.spin_max = gnx_spin;
         gnx_used += n_flags;
         if (!dry) { u->gnx_words = gnx_used; u->gnx_ops++; }
-        fp.xbuf = alloc(ff_split_xbuf_floats(M, C, fp.nspl));
+        fp.xbuf = alloc(ff_split_xbuf_floats(M, C, fp.nspl, fp.rows));
         if (want_planes) {
           Planes pl = alloc_planes((size_t)M * C);
           out.pl_hi = pl.hi; out.pl_lo = pl.lo; fp.out_hi = pl.hi; fp.out_lo = pl.lo;

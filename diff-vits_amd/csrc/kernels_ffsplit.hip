@@ -556,23 +556,30 @@ hipError_t ffs_launch_one(const FFSplitParams& p, hipStream_t st) {
 hipError_t ff_split_init() {
   hipError_t e = ffs_init_one<256, 4, 2>();
   if (e == hipSuccess) e = ffs_init_one<384, 8, 2>();
+  if (e == hipSuccess) e = ffs_init_one<256, 4, 1>();
   return e != hipSuccess ? e : ffs_init_one<512, 8, 1>();
 }
 
-// rows per workgroup: 64, or 32 at C = 512 (64 rows of h3 alone - 128 KiB of split planes - would leave no room for the product)
-int ff_split_rows(int C) { return C == 512 ? 32 : 64; }
+// Rows per workgroup.  64 (two row fragments per weight fragment) wherever that fills the chip; 32 at C = 512 (64 rows of h3 alone
+// - 128 KiB of split planes - would leave no room for the product), for row pitches that are no multiple of 64 (utterances of any
+// length: 32-frame padding), and for small inputs, where twice the workgroups matter more than half the weight bytes per MFMA
+// (one utterance of 300 frames: 5 / 3 / 2 row blocks of 32 at the three levels)
+int ff_split_rows(int C, int M, int T, int nspl, int n_cu) {
+  if (C == 384) return 64;            // (three column fragments per wave and k-group in stage B: no even split of the items at 32 rows)
+  if (C == 512 || T % 64 != 0) return 32;
+  return (M / 32) * nspl * 2 <= n_cu ? 32 : 64;
+}
 
 bool ff_split_supported(const FFSplitParams& p, int precision) {
   if (precision != 0) return false;                                  // split-bf16 mode only
   if (!((p.C == 256 && p.nspl == 4) || (p.C == 384 && p.nspl == 8) || (p.C == 512 && p.nspl == 8))) return false;
-  const int bm = ff_split_rows(p.C);
-  if (p.M % bm != 0 || p.T % bm != 0 || p.M % p.T != 0) return false;   // (a row block never spans two utterances)
+  if (!(p.rows == 32 && p.C != 384) && !(p.rows == 64 && p.C != 512)) return false;
+  if (p.M % p.rows != 0 || p.T % p.rows != 0 || p.M % p.T != 0) return false;   // (a row block never spans two utterances)
   if (p.Tv < 0 || p.Tv > p.T || (p.Tv > 0 && p.Tv <= p.T - 32)) return false;
   return true;
 }
-size_t ff_split_xbuf_floats(int M, int C, int nspl) {
-  const int bm = ff_split_rows(C);
-  return (size_t)(M / bm) * (2 * (C / 32)) * nspl * (bm / 32) * 2 * 64 * 4;
+size_t ff_split_xbuf_floats(int M, int C, int nspl, int rows) {
+  return (size_t)(M / rows) * (2 * (C / 32)) * nspl * (rows / 32) * 2 * 64 * 4;
 }
 // In-launch GroupNorm of the output: the finishing tiles ([rows x C / nspl columns], all resident) behave like GEMM tiles
 // (the conditions of gemm_gnx_plan, kernels_gemm.hip)
@@ -581,7 +588,7 @@ int ff_split_gnx_plan(const FFSplitParams& p, int n_cu) {
   if (!p.stats16 || gx.groups <= 0 || gx.groups > 64 || gx.sk_c < 0 || gx.sk_c % 16 != 0 || gx.tscale) return 0;
   if ((p.C + gx.sk_c) % gx.groups != 0) return 0;
   const int cpg = (p.C + gx.sk_c) / gx.groups;
-  if (cpg % 16 != 0 || (p.T / 32) * (cpg / 16) > 256 || (p.M / ff_split_rows(p.C)) * p.nspl > n_cu) return 0;
+  if (cpg % 16 != 0 || (p.T / 32) * (cpg / 16) > 256 || (p.M / p.rows) * p.nspl > n_cu) return 0;
   if (gx.sk_c > 0 && ((gx.sk_c / 16 + p.nspl - 1) / p.nspl) * 16 > DV_GSK) return 0;   // skip slice per workgroup
   return (p.M / 32) * (p.C / 16);
 }
@@ -592,11 +599,12 @@ hipError_t launch_ff_split(const FFSplitParams& p, int precision, hipStream_t st
       !p.flags || !p.status || (p.out_hi && !p.out_lo))
     return hipErrorInvalidValue;
   static const int n_cu = [] { int d = 0, n = 0; (void)hipGetDevice(&d); (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, d); return n; }();
-  if ((p.M / ff_split_rows(p.C)) * p.nspl > n_cu) return hipErrorInvalidValue;       // (every workgroup of the launch resident at once)
+  if ((p.M / p.rows) * p.nspl > n_cu) return hipErrorInvalidValue;       // (every workgroup of the launch resident at once)
   if (p.gnx.xchg) {
     if (!p.gnx.status || !p.gnx.y_hi || !p.gnx.y_lo || !p.gnx.gamma || !p.gnx.beta || ff_split_gnx_plan(p, n_cu) <= 0) return hipErrorInvalidValue;
     if (p.gnx.sk_c > 0 && (!p.gnx.sk_x || !p.gnx.sk_stat16 || !p.gnx.sk_y_hi || !p.gnx.sk_y_lo)) return hipErrorInvalidValue;
   } else if (!p.out) return hipErrorInvalidValue;
-  if (p.C == 256) return ffs_launch_one<256, 4, 2>(p, st);
-  return p.C == 384 ? ffs_launch_one<384, 8, 2>(p, st) : ffs_launch_one<512, 8, 1>(p, st);
+  if (p.C == 256) return p.rows == 64 ? ffs_launch_one<256, 4, 2>(p, st) : ffs_launch_one<256, 4, 1>(p, st);
+  if (p.C == 384) return ffs_launch_one<384, 8, 2>(p, st);
+  return ffs_launch_one<512, 8, 1>(p, st);
 }
