@@ -808,6 +808,7 @@ def test_split_feed_forward_launch_matches_two_gemms(B, T, L):
     outs, launches = [], []
     for on in ("0", "1"):
         os.environ["DVITS_FF_SPLIT"] = on
+        os.environ["DVITS_FF_SPLIT_MIN_WG"] = "1"      # (default 96: small inputs keep the two GEMMs - here every shape takes the launch)
         try:
             m = UNet1DConditionModel(**kw).eval()
             m.load_state_dict(sd)
@@ -824,6 +825,7 @@ def test_split_feed_forward_launch_matches_two_gemms(B, T, L):
             launches.append(eng.stats()[0])
         finally:
             os.environ.pop("DVITS_FF_SPLIT", None)
+            os.environ.pop("DVITS_FF_SPLIT_MIN_WG", None)
     assert launches[1] == launches[0] - 11, launches          # eleven blocks at C = 256 / 384 / 512: two launches -> one
     assert np.isfinite(outs[1]).all()
     assert rel_l2(outs[1], outs[0]) < 2e-5, rel_l2(outs[1], outs[0])

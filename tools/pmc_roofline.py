@@ -24,7 +24,7 @@ import json
 import sys
 from collections import defaultdict
 
-FAMILIES = (("gemm", "k_gemm"), ("chain", "k_chain"), ("attention", "k_attention"), ("gn_apply", "k_gn_apply"))
+FAMILIES = (("gemm", "k_gemm"), ("chain", "k_chain"), ("ff_split", "k_ff_split"), ("attention", "k_attention"), ("gn_apply", "k_gn_apply"))
 
 
 def counters(d):
