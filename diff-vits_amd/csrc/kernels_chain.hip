@@ -536,34 +536,16 @@ __global__ __launch_bounds__((chain_pf_wave<NS, AMODE, XA, SA, CS>() ? NT_LAUNCH
     constexpr bool XS = CS;
     using KH3 = std::integral_constant<int, XS ? KH / 2 : KH>;
     const int ks3 = XS ? part * KH : 0;              // first k-step of this workgroup's stage-3 range
-    stage_prologue(p.w3_hi, p.w3_lo, 0, bq, std::integral_constant<int, NS>{}, KH3{}, ks3);   // the output projection's first weight fragments fly under the attention
-    __syncthreads();                               // query planes complete
     constexpr int d = 16 * NS, KSq = NS, NBv = NS == 3 ? 2 : 1;     // 8 heads: d = C / 8
     const int nT = p.xa_nT;
     const int h = XS ? part * 4 + (wave & 3) : wave, b_item = m0 / p.T;
     const int kh = XS ? wave >> 2 : 0, tstep = XS ? 2 : 1;           // key-tile parity of this wave / tile stride
-    bf16x8 qh[KSq], ql[KSq];
-#pragma unroll
-    for (int ks = 0; ks < KSq; ++ks) {
-      const int c16 = ((h * d + ks * 16) >> 3) + lh;
-      const int off = (c16 >> 3) * CHUNK_PL + l31 * 128 + (((c16 & 7) ^ swz(l31)) << 4);
-      qh[ks] = *reinterpret_cast<const bf16x8*>(a_reg + off);
-      ql[ks] = *reinterpret_cast<const bf16x8*>(a_reg + A_PL + off);
-    }
-    f32x16 o[NBv];
-#pragma unroll
-    for (int nb = 0; nb < NBv; ++nb)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) o[nb][r] = 0.f;
-    float m_run = -1e30f, l_run = 0.f;
     const size_t bh = (size_t)b_item * NWV + h;
     const bf16x8* kfh = reinterpret_cast<const bf16x8*>(p.xa_kf_hi) + bh * nT * KSq * 64 + lane;
     const bf16x8* kfl = reinterpret_cast<const bf16x8*>(p.xa_kf_lo) + bh * nT * KSq * 64 + lane;
     const bf16x8* vfh = reinterpret_cast<const bf16x8*>(p.xa_vf_hi) + bh * nT * 2 * NBv * 64 + lane;
     const bf16x8* vfl = reinterpret_cast<const bf16x8*>(p.xa_vf_lo) + bh * nT * 2 * NBv * 64 + lane;
     const float* bias = p.xa_bias + (size_t)b_item * nT * 32 + 4 * lh;
-    __syncthreads();                               // every wave holds its query fragments: the A region may be rewritten
-    DV_CTRACE(10);
     // K / V fragments and the key bias of tile t + 1 are requested before tile t is multiplied (pinned like the weight
     // prefetch: the loads have no consumer in the current iteration and would otherwise sink to their use)
     struct KVT { bf16x8 kh[KSq], kl[KSq], vh[2][NBv], vl[2][NBv]; float4 bv[4]; };
@@ -583,7 +565,29 @@ __global__ __launch_bounds__((chain_pf_wave<NS, AMODE, XA, SA, CS>() ? NT_LAUNCH
       for (int g = 0; g < 4; ++g) f.bv[g] = *reinterpret_cast<const float4*>(bias + tc * 32 + 8 * g);
       return f;
     };
+    // The FIRST key tile is requested here - the prompt's fragments depend on nothing this launch computes - so that its
+    // round trip (the fragments were written a whole sampler run ago: L2 misses) runs under the two barriers and the query
+    // fragment reads below instead of at the head of the key loop [round 4: requested behind the second barrier]
     KVT cur = load_kv(kh);
+    __builtin_amdgcn_sched_barrier(0);
+    stage_prologue(p.w3_hi, p.w3_lo, 0, bq, std::integral_constant<int, NS>{}, KH3{}, ks3);   // the output projection's first weight fragments fly under the attention
+    __syncthreads();                               // query planes complete
+    bf16x8 qh[KSq], ql[KSq];
+#pragma unroll
+    for (int ks = 0; ks < KSq; ++ks) {
+      const int c16 = ((h * d + ks * 16) >> 3) + lh;
+      const int off = (c16 >> 3) * CHUNK_PL + l31 * 128 + (((c16 & 7) ^ swz(l31)) << 4);
+      qh[ks] = *reinterpret_cast<const bf16x8*>(a_reg + off);
+      ql[ks] = *reinterpret_cast<const bf16x8*>(a_reg + A_PL + off);
+    }
+    f32x16 o[NBv];
+#pragma unroll
+    for (int nb = 0; nb < NBv; ++nb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[nb][r] = 0.f;
+    float m_run = -1e30f, l_run = 0.f;
+    __syncthreads();                               // every wave holds its query fragments: the A region may be rewritten
+    DV_CTRACE(10);
     for (int t = kh; t < nT; t += tstep) {
       __builtin_amdgcn_sched_barrier(0);
       KVT nxt = load_kv(t + tstep);
