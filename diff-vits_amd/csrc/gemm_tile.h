@@ -237,6 +237,16 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int m0, con
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
   constexpr bool SPLIT_EPI = KS == 2 && FM % 2 == 0;
+#ifndef DV_T1_COLSPLIT
+#define DV_T1_COLSPLIT 1
+#endif
+  // ... and tiles with ONE row fragment and two column fragments per wave (128x64: four row waves x two k-groups): k-group g keeps
+  // column fragment j = g.  [Until round 5 the second k-group of such a tile handed both fragments over and left: the epilogue of the
+  // two most expensive launches of the forward - the up-path resamplers, 65 k and 53 k cycles - ran on four waves, one per SIMD:
+  // statistics 6.8 k + in-launch GroupNorm pass 10.7 k cycles against 0.7 k + 1.5 k in the 64x64 tiles, r05_gemm_per_launch_trace.txt.]
+  // Wave-uniform run-time flag: GEGLU needs both fragments of a 64-column block in one wave, the split-K forms keep their layout.
+  const bool own_col = DV_T1_COLSPLIT && !SC1 && KS == 2 && !SPLIT_EPI && FN % 2 == 0 && p.epi != EPI_GEGLU && p.sk_mode == 0;
+  auto own = [&](int i, int j) { return SPLIT_EPI ? ((i & 1) == kgrp) : (own_col ? ((j & 1) == kgrp) : (kgrp == 0)); };
   const int l31 = lane & 31, lh = lane >> 5;
   // split-K dump: [slice][tile][fragment][4 column groups][64 * NWQ lanes] float4
   const size_t sk_tile = ((size_t)(m0 / BM) * ((p.N + BN - 1) / BN) + n0 / BN) * (FM * FN * 4) * (64 * NWQ);
@@ -401,10 +411,11 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int m0, con
     for (int i = 0; i < FM; ++i) {
       // (only the waves that will run this fragment's epilogue: with two k-groups and one row fragment the second group hands
       // its sums over and leaves - its prefetch was 16 KiB of loads per workgroup for nothing)
-      if (KS == 2 && ((FM % 2 == 0) ? ((i & 1) != kgrp) : (kgrp != 0))) continue;
+      if (KS == 2 && !own_col && ((FM % 2 == 0) ? ((i & 1) != kgrp) : (kgrp != 0))) continue;
       const size_t ro = (size_t)min(m0 + (wm * FM + i) * 32 + l31, p.M - 1) * p.ldres;
 #pragma unroll
       for (int j = 0; j < FN; ++j) {
+        if (KS == 2 && own_col && (j & 1) != kgrp) continue;
         const int nfj = n0 + (wn * FN + j) * 32;
         float* dst = &rpre[(j * FM + i) * 16];
         if (!SC1 && vec4 && nfj + 32 <= p.N) {       // (wave-uniform) whole fragment inside N: four unguarded 16-byte loads
@@ -678,33 +689,36 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int m0, con
     float4* red4 = reinterpret_cast<float4*>(smem);  // (16-byte LDS accesses, lane-linear: a quarter of the instructions of the dword form)
 #pragma unroll
     for (int i = 0; i < FM; ++i) {
-      const bool mine = SPLIT_EPI ? ((i & 1) == kgrp) : (kgrp == 0);
-      if (!mine) {
 #pragma unroll
-        for (int j = 0; j < FN; ++j)
+      for (int j = 0; j < FN; ++j) {
+        if (!own(i, j)) {
 #pragma unroll
           for (int g = 0; g < 4; ++g)
             red4[((i * FN + j) * 4 + g) * (64 * NWQ) + wq * 64 + lane] =
                 make_float4(acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]);
+        }
       }
     }
     __syncthreads();
-    if (!SPLIT_EPI && kgrp == 1) return;
+    if (!SPLIT_EPI && !own_col && kgrp == 1) return;
 #pragma unroll
     for (int i = 0; i < FM; ++i) {
-      const bool mine = SPLIT_EPI ? ((i & 1) == kgrp) : true;
-      if (mine) {
 #pragma unroll
-        for (int j = 0; j < FN; ++j)
+      for (int j = 0; j < FN; ++j) {
+        if (own(i, j)) {
 #pragma unroll
           for (int g = 0; g < 4; ++g) {
             const float4 v = red4[((i * FN + j) * 4 + g) * (64 * NWQ) + wq * 64 + lane];
-            acc[i][j][4 * g] += v.x; acc[i][j][4 * g + 1] += v.y; acc[i][j][4 * g + 2] += v.z; acc[i][j][4 * g + 3] += v.w;
+            // (k-group 0's sums first, whichever group adds: the same bits as the one-finisher form)
+            if (kgrp == 0) { acc[i][j][4 * g] += v.x; acc[i][j][4 * g + 1] += v.y; acc[i][j][4 * g + 2] += v.z; acc[i][j][4 * g + 3] += v.w; }
+            else { acc[i][j][4 * g] = v.x + acc[i][j][4 * g]; acc[i][j][4 * g + 1] = v.y + acc[i][j][4 * g + 1]; acc[i][j][4 * g + 2] = v.z + acc[i][j][4 * g + 2]; acc[i][j][4 * g + 3] = v.w + acc[i][j][4 * g + 3]; }
           }
+        }
       }
     }
   }
   auto my_frag_row = [&](int i) { return !SPLIT_EPI || ((i & 1) == kgrp); };
+  auto my_frag = [&](int i, int j) { return KS != 2 || own(i, j); };
   DV_TRACE(22);                                      // k-groups added up
   if (p.sk_mode == 3) {                              // fused split-K pair: hand over, or finish
     float4* d0 = reinterpret_cast<float4*>(p.sk_buf) + (size_t)ksel * sk_slice + sk_tile + wq * 64 + lane;
@@ -860,7 +874,7 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int m0, con
     }
 #pragma unroll
     for (int i = 0; i < FM; ++i) {
-      if (!my_frag_row(i)) continue;
+      if (!my_frag(i, j)) continue;
       const int mrow0 = m0 + (wm * FM + i) * 32;
       const int rl = (wm * FM + i) * 32 + l31;
       const int m = m0 + rl;
@@ -1045,13 +1059,13 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int m0, con
   DV_TRACE(18);                                      // statistics of every fragment written
   if (gnx) {
     // ---- GroupNorm of this GEMM's own output (GnxParams, dv_common.h) ----
-    gnx_table((KS == 2 && !SPLIT_EPI) ? NWQ : NWV);   // (waves still here)
+    gnx_table((KS == 2 && !SPLIT_EPI && !own_col) ? NWQ : NWV);   // (waves still here)
 #pragma unroll
     for (int j = 0; j < FN; ++j) {
       const int cl = (wn * FN + j) * 32 + 4 * lh;    // tile-local column of g = 0, e = 0
 #pragma unroll
       for (int i = 0; i < FM; ++i) {
-        if (!my_frag_row(i)) continue;
+        if (!my_frag(i, j)) continue;
         const int m = m0 + (wm * FM + i) * 32 + l31;
         if (m >= p.M) continue;
         const int nfr = n0 + (wn * FN + j) * 32;
