@@ -197,11 +197,11 @@ bool chain_ff_supported(const ChainFFParams& p, int precision);
 int chain_ff_gnx_plan(const ChainFFParams& p, int n_cu);
 hipError_t launch_chain_ff(const ChainFFParams& p, int precision, hipStream_t st);
 
-// Feed-forward tail of a transformer block at C = 256 / 384 as ONE launch (k_ff_split, kernels_ffsplit.hip; reference
+// Feed-forward tail of a transformer block at C = 256 / 384 / 512 as ONE launch (k_ff_split, kernels_ffsplit.hip; reference
 // attention.py:189-203, 206-255, 280-301 + transformer_1d.py:300-326).  As two GEMMs the block costs 55-62 us at the bench
 // shape: a [M, 8C] GEGLU GEMM whose 4C-wide product makes an HBM round trip, then the K = 5C merged ff.net.2 + proj_out GEMM.
 // A row-block kernel of 32 rows (k_chain_ff) does not scale to these widths: every workgroup would stream 3.3 / 7.6 MB of
-// weights.  Here a workgroup owns 64 rows (two row fragments per weight fragment: half the weight bytes per MFMA) and ONE
+// weights.  Here a workgroup owns 64 (or 32: `rows`) rows (two row fragments per weight fragment: half the weight bytes per MFMA) and ONE
 // SLICE of the product columns: `nspl` workgroups per row block, workgroup id = row block * nspl + slice, so that XCD x
 // (= id % 8) only ever touches slice x % nspl of the weights (its L2 holds 1 / nspl of them).
 //   stage A: LN3 (from the producer's row partials) -> GEGLU for the slice's 4C / nspl product columns, product as split
@@ -211,7 +211,7 @@ hipError_t launch_chain_ff(const ChainFFParams& p, int precision, hipStream_t st
 //            flag word, waits for the flags of its row block (all workgroups of the launch are resident: the planner checks,
 //            the wait is bounded and flagged like the in-launch GroupNorm's) and FINISHES C / nspl output columns: partials
 //            summed in slice order (deterministic), + bias + block residual -> fp32, 32x16 block statistics, optional planes,
-//            optional GroupNorm of the consumer (GnxParams) - the tile [64 rows x C / nspl columns] behaves like a GEMM tile.
+//            optional GroupNorm of the consumer (GnxParams) - the tile [rows x C / nspl columns] behaves like a GEMM tile.
 struct FFSplitParams {
   int M, C, T;                                    // rows (T % rows == 0: row pitch per utterance), C = 256, 384 or 512
   int rows;                                       // rows per workgroup: 64 or 32 (ff_split_rows; C = 512: 32)

@@ -1,4 +1,4 @@
-// Feed-forward tail of a transformer block at C = 256 / 384 for gfx950 (MI355X) as ONE launch: LN3 -> GEGLU -> merged
+// Feed-forward tail of a transformer block at C = 256 / 384 / 512 for gfx950 (MI355X) as ONE launch: LN3 -> GEGLU -> merged
 // ff.net.2 + proj_out + block residual (-> the consumer's GroupNorm), FFSplitParams in dv_common.h.  Reference:
 // unet1d/attention.py:189-203 (norm3, ff, residual), :206-255 / :280-301 (FeedForward, GEGLU), transformer_1d.py:300-326.
 //
@@ -8,14 +8,18 @@
 // at these widths - for 32 rows.  This kernel keeps what makes the row-block form fast (the A operand resident in LDS, the
 // weights fragment-major straight into registers, no barrier in a k-loop, the product never leaves the CU) and fixes its
 // weight traffic twice over:
-//   * 64 rows per workgroup - two row fragments per weight fragment, half the weight bytes per MFMA;
-//   * the product columns are SPLIT over `nspl` workgroups per row block (4 at C = 256, 8 at C = 384: 256 workgroups at the
+//   * 64 rows per workgroup - two row fragments per weight fragment, half the weight bytes per MFMA (32 rows at C = 512, where
+//     64 rows of h3 alone would fill the LDS, for row pitches that are no multiple of 64, and for mid-size inputs: RF below);
+//   * the product columns are SPLIT over `nspl` workgroups per row block (4 at C = 256, 8 at C = 384 / 512: 256 workgroups at the
 //     bench shape), and workgroup id = row block * nspl + slice puts slice s on the XCDs x = s (mod nspl) only: an XCD's L2
-//     holds 1 / nspl of the weights and every CU of the XCD walks the same 0.8-0.9 MB.
-// The price is a reduction over the slices: every workgroup writes its partial ffproj sums through, raises a flag word, and
-// finishes C / nspl of the output columns once its row block's flags are up (reduce-scatter; partials summed in slice order:
+//     holds 1 / nspl of the weights and every CU of the XCD walks the same 0.8-0.9 MB (1.7 MB at C = 512).
+// The price is a reduction over the slices: every workgroup writes its partial ffproj sums through, raises a flag word per wave,
+// and finishes C / nspl of the output columns once the flags of the waves that wrote its blocks are up (reduce-scatter; partials summed in slice order:
 // deterministic).  That wait needs every workgroup of the launch resident at once - the planner checks (engine.hip), the wait
 // is bounded and flagged exactly like the in-launch GroupNorm's (gnx_device.h), and the engine's recovery path is the same.
+// Measured (profiles/r05_*): both k-loops run at the MFMA rate (192 + 120 MFMAs x 32 cycles x two waves per SIMD at C = 256);
+// per launch 32.5-44 us against 53-64 us for the two GEMMs, +7.8 % on the 50-step run; planned from 96 workgroups (one utterance
+// keeps the two GEMMs: there a launch with two in-launch hand-overs costs what the two launches did).
 #include "dv_common.h"
 #include "dv_device.h"
 #include "gnx_device.h"
