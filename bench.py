@@ -407,7 +407,15 @@ def main():
             fn = dpm_solver.model_wrapper(native, ns, model_type="x_start")
             state[("solver", i)] = dpm_solver.DPM_Solver(fn, ns, algorithm_type="dpmsolver++")
         native.cond, native.enc, native.mask = c, enc, mask
-        return state[("solver", i)].sample(x, steps=S, order=2, skip_type="time_uniform", method="multistep")
+        try:
+            return state[("solver", i)].sample(x, steps=S, order=2, skip_type="time_uniform", method="multistep")
+        except RuntimeError as e:
+            # lazy hand-over verification (diff_vits_amd/engine.py): an EARLIER run's timed-out in-launch hand-over is noticed by
+            # this call - the engine has recovered (fallback schedule); repeat, the line below reports the downgrade and the bench
+            # refuses the number
+            if "repeat the run" not in str(e):
+                raise
+            return state[("solver", i)].sample(x, steps=S, order=2, skip_type="time_uniform", method="multistep")
 
     def run_local(x, c, enc, mask):
         if NS == 1:
@@ -458,6 +466,7 @@ def main():
     ho_ranks = None
     if not dry:
         eng0 = model.hip_engine()
+        eng0.wait()                                  # (the stream has drained above: verifies the last runs, recovers if one was lost)
         n_ho_r, bad_r = eng0.handover_status()
         mine = [int(n_ho_r), int(bool(bad_r)), int(bool(eng0.handover_downgraded))]
         if world > 1:

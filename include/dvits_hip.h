@@ -140,16 +140,20 @@ int dv_unet_time_family(dv_unet* u, const char* kind, int32_t reps, void* stream
  * *error_flag = 0 ok, 1 = an in-launch barrier timed out, 2 = the workgroups were not spread evenly over the XCDs
  * (synchronises the device). */
 int dv_unet_persist_status(dv_unet* u, int32_t* n_ops, int32_t* error_flag);
-/* GroupNorm finished inside the producer GEMM (default; environment DVITS_GNX=0 at prepare time restores the separate
- * k_gn_apply launches): the workgroups of such a GEMM exchange their tile statistics inside the launch and wait for one
- * another (bounded).  *n_ops = schedule operations that do so; *timed_out = 1 if any of them ever gave up waiting - the
+/* In-launch hand-overs (default; environment DVITS_GNX=0 at prepare time restores the separate k_gn_apply launches and the
+ * two-GEMM feed-forward).  GroupNorm finished inside the producer GEMM: the workgroups of such a GEMM exchange their tile
+ * statistics inside the launch and wait for one another (bounded).  Feed-forward block of the C = 256 / 384 / 512 transformer
+ * blocks as one launch (round 5, csrc/kernels_ffsplit.hip; reference unet1d/attention.py:189-203, 206-255; DVITS_FF_SPLIT=0
+ * restores the two GEMMs): the 4 / 8 workgroups of a row block hand their partial sums over the same way.  *n_ops = schedule
+ * operations that wait inside their launch; *timed_out = 1 if any of them ever gave up waiting - the
  * results of that launch are invalid and every later dv_unet_forward / dv_sampler_run on this handle fails with
  * DV_ERR_HIP.  Does not synchronise: meaningful once the stream has drained. */
 int dv_unet_handover_status(dv_unet* u, int32_t* n_ops, int32_t* timed_out);
 /* Recovery from such a time-out (a foreign kernel kept some workgroups off the CUs past the bounded wait): synchronises the
  * device and clears the flag, so that the handle works again.  The caller then re-plans it with dv_unet_set_exclusive(u, 0) -
  * GroupNorm as separate launches, no in-launch waits - and repeats the lost run; diff_vits_amd/engine.py does exactly that
- * for a sampler run (UNetEngine.recover_handover) and reports the downgrade once. */
+ * (UNetEngine.recover_handover; WHEN it checks - lazily since round 5, UNetEngine.wait() being the explicit point - is
+ * described in INTEGRATION.md section 4) and reports the downgrade once. */
 int dv_unet_handover_reset(dv_unet* u);
 /* The in-launch waits above assume that the launch has the device to itself (every workgroup resident at once): true
  * for one stream, or for several streams that never run kernels of such handles side by side.  A host that drives
