@@ -34,6 +34,11 @@ def verify_handover_default():
     return {"0": "off", "off": "off", "false": "off", "1": "eager", "eager": "eager", "true": "eager"}.get(v, "lazy")
 
 
+class HandoverLost(RuntimeError):
+    """Raised by the call that NOTICES an earlier run's timed-out in-launch hand-over (lazy verification): that earlier result
+    was invalid; the engine has already recovered (fallback schedule) - repeat what was computed since the last verified point."""
+
+
 class UNetEngine:
     def __init__(self, module):
         self.module = module
@@ -217,7 +222,7 @@ class UNetEngine:
         downgraded to the separate-GroupNorm schedule, it needs prepare + set_cond again - and the caller is told to repeat."""
         if rc != 0 and getattr(self, "_exclusive", True) and self._cur.prepared is not None and self.handover_status()[1]:
             self.recover_handover()
-            raise RuntimeError("diff_vits_amd: the previous denoiser run was invalid (in-kernel GroupNorm hand-over timed out "
+            raise HandoverLost("diff_vits_amd: the previous denoiser run was invalid (in-kernel GroupNorm hand-over timed out "
                                "on a shared GPU); the engine has switched to the separate-GroupNorm schedule - repeat the run")
         _lib.check(rc, what)
 

@@ -358,13 +358,12 @@ class NaturalSpeech2(nn.Module):
             # the mel leaves this package here (vocoder, caller): ONE host wait per utterance verifies the in-launch hand-overs
             # of the whole run (engine.UNetEngine.wait; the solver loop itself never blocks the host), and a lost run - a foreign
             # kernel shared the GPU - is repeated on the fallback schedule
+            from .engine import HandoverLost
             eng = self.diff_model.unet.hip_engine()
             try:
                 mel = run()
                 ok = eng.unverified_results == 0 or eng.wait()
-            except RuntimeError as e:                # an EARLIER run's time-out, noticed by this call: the engine has recovered
-                if "repeat the run" not in str(e):
-                    raise
+            except HandoverLost:                      # an EARLIER run's time-out, noticed by this call: the engine has recovered
                 ok = False
             if not ok:
                 mel = run()
