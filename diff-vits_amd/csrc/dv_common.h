@@ -104,6 +104,9 @@ struct GemmParams {
   GnxParams gnx;                // GroupNorm of the output in the epilogue (needs stats16)
   int xcd_n;                    // internal (launch_gemm): XCDs the columns are split over (0: row bands of the tile grid)
   int xcd_sh_n, xcd_sh_mn, xcd_tn, xcd_tm, xcd_inv_tn;   // internal: log2 xn, log2 (xm xn), rectangle width / height in tiles, ceil(2^16 / width)
+  // the same weights FRAGMENT-MAJOR (launch_relayout_frag of w_hi / w_lo), or null: with them a stride-1 three-tap convolution whose
+  // input channels fit the LDS runs on k_conv3 (kernels_conv.hip, gemm_conv3_shape_ok) instead of k_gemm
+  const bf16_t* wf_hi; const bf16_t* wf_lo;
 #ifdef DV_GEMM_TRACE
   int trace;                    // development build (make trace): this launch stamps its phases (gemm_tile.h DV_TRACE)
 #endif
@@ -297,6 +300,11 @@ struct PersistSync {
 // launchers (each enqueues on `st` and returns hipGetLastError())
 hipError_t launch_gemm(const GemmParams& p, int precision, hipStream_t st);
 hipError_t gemm_init();   // one-time kernel attribute setup (call outside stream capture)
+// k_conv3 (kernels_conv.hip): the resident-operand kernel of the stride-1 three-tap convolutions; launch_gemm dispatches to it
+bool gemm_conv3_shape_ok(const GemmParams& p);   // shape / epilogue test only (weights and precision are the caller's)
+hipError_t conv3_init();
+void conv3_env_refresh();                        // DVITS_CONV3=0: off
+hipError_t launch_conv3(const GemmParams& p, hipStream_t st);
 void gemm_env_refresh();  // re-read launch_gemm's environment knobs (called by every prepare)
 hipError_t attn_init();
 hipError_t launch_attention(const AttnParams& p, hipStream_t st);

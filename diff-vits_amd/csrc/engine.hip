@@ -607,7 +607,7 @@ struct Builder {
     t.gnx.sk_c = skip ? skip->C : 0;
     int k_pad = 0;
     for (int s2 = 0; s2 < t.nseg; ++s2) k_pad += t.seg[s2].taps * (t.seg[s2].c0 + t.seg[s2].c1);
-    t.sk_split = gemm_splitk_plan(t.M, t.N, k_pad, t.epi);
+    t.sk_split = conv3_takes(t) ? 0 : gemm_splitk_plan(t.M, t.N, k_pad, t.epi);
     if (t.sk_split >= 2) {
       if (!sk_fused || ((t.M + 31) / 32) * ((t.N + 31) / 32) > 4096) return false;   // (two launches: see gemm())
       t.sk_buf = reinterpret_cast<float*>(0x1000); t.sk_ticket = reinterpret_cast<unsigned*>(0x1000);
@@ -726,17 +726,32 @@ struct Builder {
   bool gnx_ff_on = [] { const char* e = getenv("DVITS_GNX_FF"); return !(e && e[0] == '0'); }();
   bool cat_drop_fp32 = [] { const char* e = getenv("DVITS_GNX_CONCAT_KEEP_FP32"); return !(e && e[0] == '1'); }();
 
+  // Stride-1 three-tap convolutions over 128-512 input channels run on the resident-operand kernel (k_conv3, kernels_conv.hip;
+  // DVITS_CONV3=0: k_gemm): launch_gemm dispatches there when the fragment-major weights are given.  Such a launch is never split
+  // over K (64 rows x all input channels are resident: the k-loop runs at the MFMA rate on the tiles there are).
+  bool conv3_takes(const GemmParams& g) const {
+    if (arena.exact || autotune_on() || prec != DV_PREC_BF16X3) return false;
+    GemmParams t = g;
+    t.B = B;
+    if (!gemm_conv3_shape_ok(t)) return false;
+    // (the tile the heuristic picks must be the 64x64 one - launch_gemm checks the same - and with an in-launch GroupNorm its tiles
+    // must all be resident: both hold when there are at most 256 of them and fewer than 192 128x64 tiles)
+    const int t64 = (t.M / 64) * (t.N / 64), t128 = ((t.M + 127) / 128) * (t.N / 64);
+    return t64 >= 128 && t128 < 192 && (n_cu <= 0 || t64 <= n_cu || !gnx_on);
+  }
   void gemm(std::vector<OpFn>& ops, GemmParams g, const PackedW* pw, int k_real) {
     g.w_hi = pw->hi; g.w_lo = pw->lo; g.Kp = pw->Kp; g.N_pad = pw->N_pad;
     if (!g.bias) g.bias = pw->bias;
     g.B = B;
     g.zero_page = u->zero_page;
     const int p = prec;
+    const bool c3 = conv3_takes(g) && g.Kp == 3 * (g.seg[0].c0 + g.seg[0].c1) && frag(pw);
+    if (c3) { g.wf_hi = dry ? reinterpret_cast<const bf16_t*>(0x1000) : pw->fhi; g.wf_lo = dry ? reinterpret_cast<const bf16_t*>(0x1000) : pw->flo; }
     cur_kind = "gemm"; cur_flops = 2.0 * (double)g.M * (double)g.N * (double)k_real;
     {
       char buf[128];
       snprintf(buf, sizeof(buf), "M=%d N=%d K=%d taps=%d nseg=%d epi=%d stride=%d up=%d%s%s%s", g.M, g.N, k_real, g.seg[0].taps,
-               g.nseg, g.epi, g.stride, g.up_mode, (g.stats || g.stats16) ? " +stats" : "", "",
+               g.nseg, g.epi, g.stride, g.up_mode, (g.stats || g.stats16) ? " +stats" : "", c3 ? " resident" : "",
                g.gnx.xchg ? " +gnx" : "");
       cur_desc = buf;
     }
@@ -744,7 +759,7 @@ struct Builder {
     // long K on few tiles: offer scratch for a two-launch split-K (kernels_gemm.hip decides with the same predicate)
     int k_pad = 0;
     for (int s2 = 0; s2 < g.nseg; ++s2) k_pad += g.seg[s2].taps * (g.seg[s2].c0 + g.seg[s2].c1);
-    g.sk_split = arena.exact ? 0 : gemm_splitk_plan(g.M, g.N, k_pad, g.epi);
+    g.sk_split = (arena.exact || c3) ? 0 : gemm_splitk_plan(g.M, g.N, k_pad, g.epi);
     // with the tuner on, scratch is also offered to GEMMs the heuristic would not split (the tuner times both ways)
     const bool offer = !arena.exact && autotune_on() && gemm_splitk_plan(64, 64, 1 << 20, EPI_STORE) != 0 && k_pad >= 768 && (g.epi == EPI_STORE || g.epi == EPI_RESIDUAL) &&
                        ((g.M + 63) / 64) * ((g.N + 63) / 64) <= 256;

@@ -1,0 +1,352 @@
+// Stride-1, three-tap convolution with the A operand RESIDENT in LDS for gfx950 (MI355X): the ResnetBlock2D convolutions
+// (reference unet1d/resnet.py:591-641: conv1 / conv2 over [B, C, T], kernel 3, padding 1) whose input channels fit a CU's LDS
+// beside nothing else - C_in = 128 / 256 / 384 / 512 (one tensor of planes, or the channel concatenation of two).
+//
+// Why a second contraction kernel.  k_gemm (kernels_gemm.hip) stages BOTH operands of every 64-deep k-tile through an LDS ring
+// with one barrier per k-tile; its k-loop sits on three per-CU bounds at once - instruction issue, LDS bytes and the
+// vector-memory path - at 1050-1170 cycles per 64x64x64 k-tile against 384 cycles of MFMA (docs/HISTORY.md, round 3).  A 3-tap
+// convolution reads every activation row three times (once per tap), and at these channel counts the 64 + 2 rows a 64-row tile
+// touches are 34-135 KiB as split planes: they fit.  So, exactly like k_ff_split (kernels_ffsplit.hip):
+//   * the tile's rows [m0 - 1, m0 + 64] x all C_in channels are DMA'd into LDS ONCE (the three taps read them at row offsets
+//     -1 / 0 / +1; the two halo rows are zeros at an utterance's ends);
+//   * the weights never touch LDS: fragment-major (launch_relayout_frag of the packed [N][3 C_in] planes), each wave loads the
+//     fragments it multiplies with coalesced 16-byte loads, 8 ahead in registers;
+//   * 8 waves = 2 column fragments x 4 k-quarters, each wave multiplies BOTH row fragments with every weight fragment it loads
+//     (half the weight bytes per MFMA of a one-fragment wave); no barrier inside the k-loop;
+//   * the four k-quarters are added through LDS and every wave finishes a 32-row x 16-column half fragment - the layout of
+//     k_gemm's half-fragment epilogue, whose steps follow unchanged: bias, residual, fp32 / split-plane stores, 32x16 block
+//     statistics, the consumer's GroupNorm finished in the launch (gnx_device.h).
+// The tile grid, the XCD rectangle and the exchange-word layout are those of k_gemm's 64x64 tile: launch_gemm (kernels_gemm.hip)
+// dispatches here when gemm_conv3_ok() holds and the fragment-major weights are given (GemmParams wf_hi / wf_lo).
+#include "dv_common.h"
+#include "dv_device.h"
+#include "gnx_device.h"
+
+#include <cstdlib>
+#include <type_traits>
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+#ifdef DV_GEMM_TRACE
+// development build only (make trace): per-workgroup s_memtime stamps of the phases (tools/conv3_trace.py)
+__device__ unsigned long long g_c3_trace[1024 * 16];
+__device__ int g_c3_sel = 0;                       // which launches stamp: C_in (0 = any) - set by the tool
+#define DV_C3TRACE(i) do { if (threadIdx.x == 0 && blockIdx.x < 1024 && (g_c3_sel == 0 || g_c3_sel == CIN)) g_c3_trace[blockIdx.x * 16 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+extern "C" int dv_debug_c3_trace_select(int cin) {
+  hipError_t e = hipMemcpyToSymbol(HIP_SYMBOL(g_c3_sel), &cin, sizeof(cin));
+  void* d = nullptr;
+  if (e == hipSuccess) e = hipGetSymbolAddress(&d, HIP_SYMBOL(g_c3_trace));
+  return (int)(e != hipSuccess ? e : hipMemset(d, 0, sizeof(g_c3_trace)));
+}
+extern "C" int dv_debug_c3_trace(unsigned long long* host, int n_wg) {
+  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_c3_trace), (size_t)n_wg * 16 * sizeof(unsigned long long));
+}
+#else
+#define DV_C3TRACE(i) do {} while (0)
+#endif
+
+namespace {
+
+constexpr int BM = 64, BN = 64, NWV = 8, NT = 64 * NWV;
+constexpr int ROWS = BM + 2;                         // LDS rows of a chunk: the tile's 64, then row m0 + 64 (index 64), then row m0 - 1 (index 65)
+constexpr int CHP = ROWS * 128;                      // bytes of one 64-channel chunk of one plane
+__device__ __forceinline__ int swz(int row) { return (row >> 1) & 7; }
+struct BFrag { bf16x8 h, l; };
+
+template <int CIN>
+struct ConvGeom {
+  static constexpr int NCH = CIN / 64;               // 64-channel chunks
+  static constexpr int KPT = CIN / 16;               // 16-deep k-steps per tap
+  static constexpr int KS = 3 * KPT;                 // ... of the whole contraction (K order: tap, channel - the packed weights' order)
+  static constexpr int U = KS / 4;                   // ... per k-quarter (wave)
+  static constexpr int DEPTH = U < 8 ? U : 8;        // weight units (hi + lo fragment: 8 VGPRs) in flight per wave
+  static constexpr int A_PL = NCH * CHP;             // bytes per plane of the resident operand
+  static constexpr int RED = 2 * 4 * 2 * 4 * 64 * 16;   // k-quarter exchange: [column fragment][quarter][row fragment][4 column groups][64 lanes] float4
+  static constexpr int SMEM = 2 * A_PL > RED ? 2 * A_PL : RED;
+  static_assert(CIN % 64 == 0 && KS % 4 == 0 && SMEM + 4096 <= 160 * 1024, "geometry");
+};
+
+}  // namespace
+
+template <int CIN>
+__global__ __launch_bounds__(NT) void k_conv3(const GemmParams p) {
+  using G = ConvGeom<CIN>;
+  extern __shared__ __attribute__((aligned(1024))) char smem[];
+  __shared__ __attribute__((aligned(16))) float s_bias[BN];
+  __shared__ GnxShared<BN> s_gnx;
+  // (every 64-byte line of the argument block is requested at once: see k_gemm)
+  asm volatile("" ::"s"(p.seg[0].a0_hi), "s"(p.seg[1].a0_hi), "s"(p.seg[1].pad), "s"(p.T_in), "s"(p.w_hi), "s"(p.M), "s"(p.res),
+               "s"(p.out_hi), "s"(p.zero_page), "s"(p.ln_u), "s"(p.gnx.xchg), "s"(p.gnx.y_hi), "s"(p.xcd_n), "s"(p.xcd_inv_tn), "s"(p.wf_lo));
+  DV_C3TRACE(0);
+  // ---- tile of this workgroup: k_gemm's XCD-aware order (workgroup b runs on XCD b % 8) ----
+  int m0, n0;
+  {
+    const int n_tiles_n = p.N / BN, nwg = gridDim.x;
+    int bid = blockIdx.x;
+    if (p.xcd_n > 0) {
+      const int x = bid & 7, i = bid >> 3;
+      const int r = x & ((1 << p.xcd_sh_mn) - 1), xm_i = r >> p.xcd_sh_n, xn_i = r & (p.xcd_n - 1);
+      const int lm = (i * p.xcd_inv_tn) >> 16, ln = i - lm * p.xcd_tn;
+      m0 = (xm_i * p.xcd_tm + lm) * BM; n0 = (xn_i * p.xcd_tn + ln) * BN;
+    } else {
+      const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+      bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+      m0 = (bid / n_tiles_n) * BM; n0 = (bid % n_tiles_n) * BN;
+    }
+  }
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, lh = lane >> 5;
+  const int cf = wave & 1, kq = wave >> 1;           // k-loop role: column fragment, k-quarter
+  const int e_wn = cf, e_wm = (wave >> 1) & 1, e_half = wave >> 2;   // epilogue role: fragment (e_wm, e_wn), its columns [16 e_half, +16)
+  const unsigned a_base = (unsigned)(size_t)smem;
+  const GemmSeg& sg = p.seg[0];
+  const int c0 = sg.c0, c1 = sg.c1;
+  const int t0 = m0 - (int)__umulhi((unsigned)m0, p.tout_magic) * p.T_out;   // frame of the tile's first row inside its utterance
+
+  // ---- requests, oldest first: residual rows of this wave's half fragment, halo rows, bias, the tile's rows, first weights ----
+  float rpre[8];
+  if (p.epi == EPI_RESIDUAL) {
+    const float* rp = p.res + (size_t)(m0 + e_wm * 32 + l31) * p.ldres + n0 + e_wn * 32 + e_half * 16 + 4 * lh;
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+      const float4 a = *reinterpret_cast<const float4*>(rp + 8 * g);
+      rpre[4 * g] = a.x; rpre[4 * g + 1] = a.y; rpre[4 * g + 2] = a.z; rpre[4 * g + 3] = a.w;
+    }
+  }
+  // halo rows: 2 rows x 2 planes x CIN / 8 pieces of 16 bytes, one per thread (register round trip: 4 KiB at most)
+  constexpr int HITEMS = CIN / 2;
+  uint4 hv = make_uint4(0u, 0u, 0u, 0u);
+  int h_dst = -1;
+  if (tid < HITEMS) {
+    const int pl = tid / (CIN / 4), rem = tid - pl * (CIN / 4), which = rem / (CIN / 8), piece = rem - which * (CIN / 8);
+    const int ch = piece * 8, c = piece >> 3, slot = piece & 7;
+    const bool ok = which == 0 ? (t0 + BM < p.T_out) : (t0 > 0);                 // which 0: row m0 + 64 (LDS row 64), 1: row m0 - 1 (LDS row 65)
+    const long srow = which == 0 ? (long)m0 + BM : (long)m0 - 1;
+    const bool first = ch < c0;
+    const bf16_t* src = first ? (pl ? sg.a0_lo : sg.a0_hi) : (pl ? sg.a1_lo : sg.a1_hi);
+    if (ok) hv = *reinterpret_cast<const uint4*>(src + (size_t)srow * (first ? c0 : c1) + (first ? ch : ch - c0));
+    h_dst = pl * G::A_PL + c * CHP + (BM + which) * 128 + ((slot ^ swz(BM + which)) << 4);
+  }
+  if (wave == 0) glds4(p.bias ? (const void*)(p.bias + n0 + lane) : (const void*)p.zero_page, (unsigned)(size_t)s_bias);
+  {
+    // wave w brings rows 8w .. 8w + 7 of every chunk, both planes: lane = (row, 16-byte slot), the source chunk is swizzled
+    const int row = wave * 8 + (lane >> 3), slot = lane & 7;
+    const int sc8 = (slot ^ swz(row)) << 3;
+#pragma unroll
+    for (int c = 0; c < G::NCH; ++c) {
+      const int cb = c * 64;
+      const bool first = cb < c0;
+      const size_t e = (size_t)(m0 + row) * (first ? c0 : c1) + (first ? cb : cb - c0) + sc8;
+      const unsigned dst = a_base + (unsigned)(c * CHP + wave * 1024);
+      glds16((first ? sg.a0_hi : sg.a1_hi) + e, dst);
+      glds16((first ? sg.a0_lo : sg.a1_lo) + e, dst + G::A_PL);
+    }
+  }
+  // weights of this wave: fragment nf = n0 / 32 + cf, k-steps [kq U, kq U + U); unit j = k-step kq U + j (1 KiB per plane)
+  const size_t w_e0 = ((size_t)((n0 >> 5) + cf) * G::KS + (size_t)kq * G::U) * 512 + (size_t)lane * 8;
+  const bf16_t* const wh = p.wf_hi + w_e0;
+  const bf16_t* const wl = p.wf_lo + w_e0;
+  auto load_unit = [&](int j) {
+    BFrag f;
+    f.h = *reinterpret_cast<const bf16x8*>(wh + (size_t)j * 512);
+    f.l = *reinterpret_cast<const bf16x8*>(wl + (size_t)j * 512);
+    return f;
+  };
+  BFrag bq[G::DEPTH];
+#pragma unroll
+  for (int j = 0; j < G::DEPTH; ++j) bq[j] = load_unit(j);
+  __builtin_amdgcn_sched_barrier(0);
+  if (h_dst >= 0) *reinterpret_cast<uint4*>(smem + h_dst) = hv;
+  DV_C3TRACE(1);
+  wait_vmcnt<2 * G::DEPTH>();                        // everything older than the weight units: the tile's rows have landed
+  __syncthreads();
+  DV_C3TRACE(2);
+
+  // ---- k-loop: acc[rf] += W[fragment][k-step] x A^T[row fragment rf][k-step], no barrier ----
+  // LDS row of (row fragment rf, tap): frame rf * 32 + l31 + tap - 1 of the tile; -1 is LDS row 65, 64 is LDS row 64
+  int rowb[2][3], swl[2][3];
+#pragma unroll
+  for (int rf = 0; rf < 2; ++rf)
+#pragma unroll
+    for (int tap = 0; tap < 3; ++tap) {
+      const int idx = rf * 32 + l31 + tap - 1, row = idx < 0 ? BM + 1 : idx;
+      rowb[rf][tap] = row * 128;
+      swl[rf][tap] = swz(row) ^ lh;                  // (the 16-byte slot of k-step cs, half lh, is ((cs & 3) * 2 + lh) ^ swz(row))
+    }
+  f32x16 acc[2];
+#pragma unroll
+  for (int rf = 0; rf < 2; ++rf)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[rf][r] = 0.f;
+  auto run = [&](auto kq_tag) __attribute__((always_inline)) {
+    constexpr int KQ = decltype(kq_tag)::value;
+    auto read_a = [&](int u, bf16x8 (&h)[2], bf16x8 (&l)[2]) {
+      const int ks = KQ * G::U + u, tap = ks / G::KPT, cs = ks - tap * G::KPT;
+#pragma unroll
+      for (int rf = 0; rf < 2; ++rf) {
+        const int off = (cs >> 2) * CHP + rowb[rf][tap] + ((((cs & 3) << 1) ^ swl[rf][tap]) << 4);
+        h[rf] = *reinterpret_cast<const bf16x8*>(smem + off);
+        l[rf] = *reinterpret_cast<const bf16x8*>(smem + G::A_PL + off);
+      }
+    };
+    bf16x8 ah[2][2], al[2][2];
+    read_a(0, ah[0], al[0]);
+#pragma unroll
+    for (int u = 0; u < G::U; ++u) {
+      const int cur = u & 1;
+      if (u + 1 < G::U) read_a(u + 1, ah[cur ^ 1], al[cur ^ 1]);
+      const BFrag f = bq[u % G::DEPTH];
+      // (consecutive MFMAs alternate accumulators)
+      acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.h, al[cur][0], acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.h, al[cur][1], acc[1], 0, 0, 0);
+      acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.l, ah[cur][0], acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.l, ah[cur][1], acc[1], 0, 0, 0);
+      acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.h, ah[cur][0], acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.h, ah[cur][1], acc[1], 0, 0, 0);
+      // pinned: without the scheduling barriers hipcc sinks every prefetch down to its use (load -> vmcnt(0) -> MFMA)
+      __builtin_amdgcn_sched_barrier(0);
+      if (u + G::DEPTH < G::U) bq[u % G::DEPTH] = load_unit(u + G::DEPTH);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+  if (kq == 0) run(std::integral_constant<int, 0>{});
+  else if (kq == 1) run(std::integral_constant<int, 1>{});
+  else if (kq == 2) run(std::integral_constant<int, 2>{});
+  else run(std::integral_constant<int, 3>{});
+  DV_C3TRACE(3);
+
+  // ---- the four k-quarters are added through LDS; this wave keeps a 32-row x 16-column half fragment ----
+  __syncthreads();                                   // every wave is done reading the resident operand
+  float4* const red4 = reinterpret_cast<float4*>(smem);
+#pragma unroll
+  for (int rf = 0; rf < 2; ++rf)
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+      red4[((((cf * 4 + kq) * 2 + rf) * 4 + g) << 6) + lane] = make_float4(acc[rf][4 * g], acc[rf][4 * g + 1], acc[rf][4 * g + 2], acc[rf][4 * g + 3]);
+  __syncthreads();
+  float vv[8];
+#pragma unroll
+  for (int g = 0; g < 2; ++g) {
+    float4 s = red4[((((e_wn * 4 + 0) * 2 + e_wm) * 4 + e_half * 2 + g) << 6) + lane];
+#pragma unroll
+    for (int k = 1; k < 4; ++k) {                    // (quarters in order: deterministic)
+      const float4 v = red4[((((e_wn * 4 + k) * 2 + e_wm) * 4 + e_half * 2 + g) << 6) + lane];
+      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+    vv[4 * g] = s.x; vv[4 * g + 1] = s.y; vv[4 * g + 2] = s.z; vv[4 * g + 3] = s.w;
+  }
+  DV_C3TRACE(4);
+
+  // ---- epilogue of the half fragment (the steps of gemm_tile.h's half-fragment epilogue) ----
+  const bool gnx_h = p.gnx.xchg != nullptr;
+  const int coff = e_half * 16;                      // this wave's columns inside the fragment
+  const int ncol = n0 + e_wn * 32 + coff;            // first of them
+  const int m = m0 + e_wm * 32 + l31, mrow0 = m0 + e_wm * 32;
+#pragma unroll
+  for (int g = 0; g < 2; ++g) {
+    const float4 b4 = *reinterpret_cast<const float4*>(s_bias + e_wn * 32 + coff + 4 * lh + 8 * g);
+    vv[4 * g] += b4.x; vv[4 * g + 1] += b4.y; vv[4 * g + 2] += b4.z; vv[4 * g + 3] += b4.w;
+  }
+  if (p.epi == EPI_RESIDUAL) {
+#pragma unroll
+    for (int r = 0; r < 8; ++r) vv[r] += rpre[r];
+  }
+  {
+    const size_t ob = (size_t)m * p.ldo + ncol;
+    if (p.out) {
+#pragma unroll
+      for (int g = 0; g < 2; ++g)
+        dv_st16(p.out + ob + 4 * lh + 8 * g, make_float4(vv[4 * g], vv[4 * g + 1], vv[4 * g + 2], vv[4 * g + 3]));
+    }
+    if (p.out_hi) store_planes8(p.out_hi, p.out_lo, ob, lh, vv);
+  }
+  DV_C3TRACE(5);
+  if (p.stats16) {                                   // this wave's 32 x 16 block: (sum, squared deviations about its own mean)
+    float a1 = 0.f, a2 = 0.f;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) a1 += vv[r];
+    a1 = wave_sum64(a1);
+    const float mb = a1 * (1.0f / 512.0f);
+#pragma unroll
+    for (int r = 0; r < 8; ++r) { const float dv = vv[r] - mb; a2 = fmaf(dv, dv, a2); }
+    a2 = wave_sum64(a2);
+    if (lane == 0) {
+      const size_t e = (size_t)(mrow0 >> 5) * (p.N >> 4) + (ncol >> 4);
+      reinterpret_cast<float2*>(p.stats16)[e] = make_float2(a1, a2);
+      if (gnx_h)
+        __hip_atomic_store(p.gnx.xchg + e, (unsigned long long)__float_as_uint(a1) | ((unsigned long long)__float_as_uint(a2) << 32),
+                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+  }
+  DV_C3TRACE(6);
+  if (gnx_h) {
+    GnxTile t;
+    t.M = p.M; t.N = p.N; t.T_out = p.T_out; t.Tv_out = p.Tv_out; t.m0 = m0; t.n0 = n0; t.bm = BM; t.bn = BN;
+    t.bq = (int)__umulhi((unsigned)m0, p.tout_magic);
+    gnx_finish_table<BN>(p.gnx, t, s_gnx, tid, lane, wave, NWV, [&](int) {});
+    DV_C3TRACE(7);
+    float y[8];
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+      const int cl = e_wn * 32 + coff + 4 * lh + 8 * g;
+      const float4 sa = *reinterpret_cast<const float4*>(s_gnx.gA + cl);
+      const float4 sb = *reinterpret_cast<const float4*>(s_gnx.gB + cl);
+      y[4 * g] = fmaf(vv[4 * g], sa.x, sb.x); y[4 * g + 1] = fmaf(vv[4 * g + 1], sa.y, sb.y);
+      y[4 * g + 2] = fmaf(vv[4 * g + 2], sa.z, sb.z); y[4 * g + 3] = fmaf(vv[4 * g + 3], sa.w, sb.w);
+    }
+    if (p.gnx.silu) {
+#pragma unroll
+      for (int r = 0; r < 8; ++r) y[r] = y[r] * __builtin_amdgcn_rcpf(1.0f + __expf(-y[r]));
+    }
+    store_planes8(p.gnx.y_hi, p.gnx.y_lo, (size_t)m * p.N + ncol, lh, y);
+  }
+  DV_C3TRACE(8);
+}
+
+// ---- host side ----
+static bool g_conv3_on = [] { const char* e = getenv("DVITS_CONV3"); return !(e && e[0] == '0'); }();
+void conv3_env_refresh() { const char* e = getenv("DVITS_CONV3"); g_conv3_on = !(e && e[0] == '0'); }
+
+// Shapes this kernel takes (everything else stays with k_gemm): one 3-tap segment over 128 / 256 / 384 / 512 input channels (one
+// tensor or the concatenation of two, each a multiple of 64 channels), stride 1, no resampling, no padded row space, whole 64 x 64
+// tiles that never span two utterances, the plain / residual epilogue without LayerNorm, column-slab statistics, ReLU or row mask.
+bool gemm_conv3_shape_ok(const GemmParams& p) {
+  if (!g_conv3_on || p.nseg != 1 || p.seg[0].taps != 3 || p.seg[0].pad != 1 || p.stride != 1 || p.up_mode != UP_NONE) return false;
+  const int cin = p.seg[0].c0 + p.seg[0].c1;
+  if (cin != 128 && cin != 256 && cin != 384 && cin != 512) return false;
+  if (p.seg[0].c0 % 64 != 0 || p.seg[0].c1 % 64 != 0 || (p.seg[0].c1 > 0 && !p.seg[0].a1_hi)) return false;
+  if (p.T_in != p.T_out || p.T_virt != p.T_out || (p.Tv_out > 0 && p.Tv_out != p.T_out) || (p.Tv_in > 0 && p.Tv_in != p.T_in)) return false;
+  if (p.T_out % BM != 0 || p.M % BM != 0 || p.N % BN != 0 || p.B <= 0 || p.M != p.B * p.T_out) return false;
+  if ((p.epi != EPI_STORE && p.epi != EPI_RESIDUAL) || p.stats || p.rowstat_out || p.ln_stat || p.relu || p.rowmask) return false;
+  if ((p.ldo & 7) != 0 || (p.epi == EPI_RESIDUAL && (p.ldres & 3) != 0) || p.force_tile != GT_AUTO) return false;
+  return true;
+}
+
+template <int CIN>
+static hipError_t conv3_launch(const GemmParams& p, hipStream_t st) {
+  constexpr int smem = ConvGeom<CIN>::SMEM;
+  hipLaunchKernelGGL((k_conv3<CIN>), dim3((p.M / BM) * (p.N / BN)), dim3(NT), smem, st, p);
+  return hipGetLastError();
+}
+template <int CIN>
+static hipError_t conv3_attr() {
+  return hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv3<CIN>), hipFuncAttributeMaxDynamicSharedMemorySize, ConvGeom<CIN>::SMEM);
+}
+hipError_t conv3_init() {
+  hipError_t e;
+  if ((e = conv3_attr<128>()) != hipSuccess) return e;
+  if ((e = conv3_attr<256>()) != hipSuccess) return e;
+  if ((e = conv3_attr<384>()) != hipSuccess) return e;
+  return conv3_attr<512>();
+}
+// (called by launch_gemm with p validated, tout_magic and the XCD rectangle of the 64x64 tile grid set)
+hipError_t launch_conv3(const GemmParams& p, hipStream_t st) {
+  if (!p.wf_hi || !p.wf_lo || !gemm_conv3_shape_ok(p) || p.Kp != 3 * (p.seg[0].c0 + p.seg[0].c1) || p.sk_mode != 0) return hipErrorInvalidValue;
+  switch (p.seg[0].c0 + p.seg[0].c1) {
+    case 128: return conv3_launch<128>(p, st);
+    case 256: return conv3_launch<256>(p, st);
+    case 384: return conv3_launch<384>(p, st);
+    default: return conv3_launch<512>(p, st);
+  }
+}

@@ -159,7 +159,7 @@ hipError_t gemm_init() {
   hipError_t e = Tiles<32>::init();
   if (e != hipSuccess) return e;
   if ((e = Tiles<64>::init()) != hipSuccess) return e;
-  return hipSuccess;
+  return conv3_init();
 }
 
 // Tunables (env DVITS_GEMM_CFG="big,min_wg,bk64"): workgroup-count threshold for the 128x128x32 tile,
@@ -222,6 +222,7 @@ int gemm_candidates(const GemmParams& p, int* out, int cap) {
 static int g_env_xn = [] { const char* e = getenv("DVITS_XCD_N"); return e ? atoi(e) : -1; }();
 void gemm_env_refresh() {
   const char* e = getenv("DVITS_XCD_N"); g_env_xn = e ? atoi(e) : -1;
+  conv3_env_refresh();
 }
 
 // Tile (BM x BN) the shape heuristic of launch_gemm picks for a non-GEGLU GEMM (kept in step with
@@ -344,6 +345,13 @@ hipError_t launch_gemm(const GemmParams& pin, int precision, hipStream_t st) {
       p.xcd_n = best_xn; p.xcd_sh_n = lg2(best_xn); p.xcd_sh_mn = lg2(xm * best_xn);
       p.xcd_tn = tn / best_xn; p.xcd_tm = tm / xm; p.xcd_inv_tn = (65536 + p.xcd_tn - 1) / p.xcd_tn;
     }
+  }
+  // stride-1 three-tap convolutions whose input channels fit the LDS: the resident-operand kernel (kernels_conv.hip), on the tile
+  // grid / XCD rectangle / exchange-word layout of the 64x64 tile the heuristic would have picked
+  if (x3 && p.wf_hi && p.wf_lo && p.sk_mode == 0 && p.Kp == 3 * (p.seg[0].c0 + p.seg[0].c1) && gemm_conv3_shape_ok(p)) {
+    int bm, bn;
+    gemm_pick_tile(p, bm, bn);
+    if (bm == 64 && bn == 64) return launch_conv3(p, st);
   }
   const GemmTune& tune = gemm_tune();
   const int big_tiles = ((p.M + 127) / 128) * ((p.N + 127) / 128);

@@ -831,6 +831,50 @@ def test_split_feed_forward_launch_matches_two_gemms(B, T, L):
     assert rel_l2(outs[1], outs[0]) < 2e-5, rel_l2(outs[1], outs[0])
 
 
+@pytest.mark.parametrize("B,T,L", [(8, 1024, 64), (16, 512, 40), (4, 2048, 33), (32, 256, 20)])
+def test_resident_operand_convolution_matches_the_ring_kernel(B, T, L):
+    """ResnetBlock2D convolutions (reference resnet.py:591-641: kernel 3, padding 1, stride 1) over 128 / 256 / 384 / 512 input
+    channels run on k_conv3 (kernels_conv.hip: the tile's 64 + 2 rows of every input channel resident in LDS, fragment-major
+    weights straight into registers, four k-quarters added through LDS) where the 64x64 tile grid has 128-256 tiles;
+    DVITS_CONV3=0 keeps them on k_gemm's LDS ring.  Same operands, same split-bf16 products, another summation order:
+    float32-rounding agreement, the same number of launches, bit-repeatable, no hand-over timed out.  Shapes: the bench shape, 64-frame
+    levels whose tiles are whole utterances (both halo rows are zeros), and long utterances (interior tiles: both halo rows exist)."""
+    from diff_vits_amd import synth
+    from diff_vits_amd.unet1d.unet_1d_condition import UNet1DConditionModel
+    kw = UNET_CASES["cfg1"][0]
+    with torch.device("meta"):
+        shapes = {k: tuple(v.shape) for k, v in UNet1DConditionModel(**kw).state_dict().items()}
+    sd = {k: torch.from_numpy(v) for k, v in synth.make_state_dict(shapes, seed=616).items()}
+    x = torch.from_numpy(synth.normal(16, "x", (B, 80, T))).cuda()
+    cond = torch.from_numpy(synth.normal(16, "c", (B, 128, T))).cuda()
+    enc = torch.from_numpy(synth.normal(16, "e", (B, L, 128))).cuda()
+    t = torch.linspace(900.0, 20.0, B, device="cuda")
+    outs, launches, resident = [], [], []
+    for on in ("0", "1"):
+        os.environ["DVITS_CONV3"] = on
+        try:
+            m = UNet1DConditionModel(**kw).eval()
+            m.load_state_dict(sd)
+            eng = m.cuda().hip_engine()
+            eng.sync_weights()
+            eng.prepare(B, T, L)
+            eng.set_cond(enc, None)
+            y = eng.eval(x, cond, t).clone()
+            assert torch.equal(eng.eval(x, cond, t), y)
+            torch.cuda.synchronize()
+            n_ops, bad = eng.handover_status()
+            assert bad == 0 and n_ops > 0, (n_ops, bad)
+            outs.append(y.cpu().numpy())
+            launches.append(eng.stats()[0])
+            resident.append(sum(1 for r in eng.profile_forward(x, cond, t) if r[0] == "gemm" and " resident" in r[3]))
+        finally:
+            os.environ.pop("DVITS_CONV3", None)
+    assert resident[0] == 0 and resident[1] >= 12, resident
+    assert launches[1] == launches[0], launches
+    assert np.isfinite(outs[1]).all()
+    assert rel_l2(outs[1], outs[0]) < 2e-5, rel_l2(outs[1], outs[0])
+
+
 @pytest.mark.parametrize("B,T,L", [(16, 128, 40), (3, 256, 77), (1, 64, 10), (2, 2048, 300), (5, 512, 256), (1, 320, 150)])
 def test_fused_schedule_matches_plain_schedule_across_shapes(B, T, L):
     """The round-2 schedule (GroupNorm in the producer's epilogue, fragment attention, row-block chains shared out over
