@@ -53,6 +53,7 @@ constexpr int ROWS = BM + 2;                         // LDS rows of a chunk: the
 constexpr int CHP = ROWS * 128;                      // bytes of one 64-channel chunk of one plane
 __device__ __forceinline__ int swz(int row) { return (row >> 1) & 7; }
 struct BFrag { bf16x8 h, l; };
+constexpr int RED_BYTES = 2 * 4 * 2 * 4 * 64 * 16;      // k-quarter exchange: [column fragment][quarter][row fragment][4 column groups][64 lanes] float4
 
 template <int CIN>
 struct ConvGeom {
@@ -62,12 +63,126 @@ struct ConvGeom {
   static constexpr int U = KS / 4;                   // ... per k-quarter (wave)
   static constexpr int DEPTH = U < 8 ? U : 8;        // weight units (hi + lo fragment: 8 VGPRs) in flight per wave
   static constexpr int A_PL = NCH * CHP;             // bytes per plane of the resident operand
-  static constexpr int RED = 2 * 4 * 2 * 4 * 64 * 16;   // k-quarter exchange: [column fragment][quarter][row fragment][4 column groups][64 lanes] float4
+  static constexpr int RED = RED_BYTES;   // k-quarter exchange: [column fragment][quarter][row fragment][4 column groups][64 lanes] float4
   static constexpr int SMEM = 2 * A_PL > RED ? 2 * A_PL : RED;
   static_assert(CIN % 64 == 0 && KS % 4 == 0 && SMEM + 4096 <= 160 * 1024, "geometry");
 };
 
 }  // namespace
+
+// tile of this workgroup: k_gemm's XCD-aware order (workgroup b runs on XCD b % 8)
+__device__ __forceinline__ void conv3_tile(const GemmParams& p, int& m0, int& n0) {
+  const int n_tiles_n = p.N / BN, nwg = gridDim.x;
+  int bid = blockIdx.x;
+  if (p.xcd_n > 0) {
+    const int x = bid & 7, i = bid >> 3;
+    const int r = x & ((1 << p.xcd_sh_mn) - 1), xm_i = r >> p.xcd_sh_n, xn_i = r & (p.xcd_n - 1);
+    const int lm = (i * p.xcd_inv_tn) >> 16, ln = i - lm * p.xcd_tn;
+    m0 = (xm_i * p.xcd_tm + lm) * BM; n0 = (xn_i * p.xcd_tn + ln) * BN;
+  } else {
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    m0 = (bid / n_tiles_n) * BM; n0 = (bid % n_tiles_n) * BN;
+  }
+}
+
+// The part both kernels share: the four k-quarters' accumulators (wave = column fragment cf = wave & 1, quarter kq = wave >> 1, both
+// row fragments) are added through LDS - `smem` is free: the caller's waves are past their last operand read only after the barrier
+// here - and every wave finishes a 32-row x 16-column half fragment: the steps of gemm_tile.h's half-fragment epilogue.
+__device__ __forceinline__ void conv3_finish(const GemmParams& p, char* smem, const float* s_bias, GnxShared<BN>& s_gnx, f32x16 (&acc)[2],
+                                             const float (&rpre)[8], const int m0, const int n0, const int tid, const int lane, const int wave,
+                                             const int CIN) {
+  (void)CIN;                                         // (trace builds select launches by it)
+  const int l31 = lane & 31, lh = lane >> 5;
+  const int cf = wave & 1, kq = wave >> 1;
+  const int e_wn = cf, e_wm = (wave >> 1) & 1, e_half = wave >> 2;   // epilogue role: fragment (e_wm, e_wn), its columns [16 e_half, +16)
+  // ---- the four k-quarters are added through LDS; this wave keeps a 32-row x 16-column half fragment ----
+  __syncthreads();                                   // every wave is done reading the resident operand
+  float4* const red4 = reinterpret_cast<float4*>(smem);
+#pragma unroll
+  for (int rf = 0; rf < 2; ++rf)
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+      red4[((((cf * 4 + kq) * 2 + rf) * 4 + g) << 6) + lane] = make_float4(acc[rf][4 * g], acc[rf][4 * g + 1], acc[rf][4 * g + 2], acc[rf][4 * g + 3]);
+  __syncthreads();
+  float vv[8];
+#pragma unroll
+  for (int g = 0; g < 2; ++g) {
+    float4 s = red4[((((e_wn * 4 + 0) * 2 + e_wm) * 4 + e_half * 2 + g) << 6) + lane];
+#pragma unroll
+    for (int k = 1; k < 4; ++k) {                    // (quarters in order: deterministic)
+      const float4 v = red4[((((e_wn * 4 + k) * 2 + e_wm) * 4 + e_half * 2 + g) << 6) + lane];
+      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+    vv[4 * g] = s.x; vv[4 * g + 1] = s.y; vv[4 * g + 2] = s.z; vv[4 * g + 3] = s.w;
+  }
+  DV_C3TRACE(4);
+
+  // ---- epilogue of the half fragment (the steps of gemm_tile.h's half-fragment epilogue) ----
+  const bool gnx_h = p.gnx.xchg != nullptr;
+  const int coff = e_half * 16;                      // this wave's columns inside the fragment
+  const int ncol = n0 + e_wn * 32 + coff;            // first of them
+  const int m = m0 + e_wm * 32 + l31, mrow0 = m0 + e_wm * 32;
+#pragma unroll
+  for (int g = 0; g < 2; ++g) {
+    const float4 b4 = *reinterpret_cast<const float4*>(s_bias + e_wn * 32 + coff + 4 * lh + 8 * g);
+    vv[4 * g] += b4.x; vv[4 * g + 1] += b4.y; vv[4 * g + 2] += b4.z; vv[4 * g + 3] += b4.w;
+  }
+  if (p.epi == EPI_RESIDUAL) {
+#pragma unroll
+    for (int r = 0; r < 8; ++r) vv[r] += rpre[r];
+  }
+  {
+    const size_t ob = (size_t)m * p.ldo + ncol;
+    if (p.out) {
+#pragma unroll
+      for (int g = 0; g < 2; ++g)
+        dv_st16(p.out + ob + 4 * lh + 8 * g, make_float4(vv[4 * g], vv[4 * g + 1], vv[4 * g + 2], vv[4 * g + 3]));
+    }
+    if (p.out_hi) store_planes8(p.out_hi, p.out_lo, ob, lh, vv);
+  }
+  DV_C3TRACE(5);
+  if (p.stats16) {                                   // this wave's 32 x 16 block: (sum, squared deviations about its own mean)
+    float a1 = 0.f, a2 = 0.f;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) a1 += vv[r];
+    a1 = wave_sum64(a1);
+    const float mb = a1 * (1.0f / 512.0f);
+#pragma unroll
+    for (int r = 0; r < 8; ++r) { const float dv = vv[r] - mb; a2 = fmaf(dv, dv, a2); }
+    a2 = wave_sum64(a2);
+    if (lane == 0) {
+      const size_t e = (size_t)(mrow0 >> 5) * (p.N >> 4) + (ncol >> 4);
+      reinterpret_cast<float2*>(p.stats16)[e] = make_float2(a1, a2);
+      if (gnx_h)
+        __hip_atomic_store(p.gnx.xchg + e, (unsigned long long)__float_as_uint(a1) | ((unsigned long long)__float_as_uint(a2) << 32),
+                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+  }
+  DV_C3TRACE(6);
+  if (gnx_h) {
+    GnxTile t;
+    t.M = p.M; t.N = p.N; t.T_out = p.T_out; t.Tv_out = p.Tv_out; t.m0 = m0; t.n0 = n0; t.bm = BM; t.bn = BN;
+    t.bq = (int)__umulhi((unsigned)m0, p.tout_magic);
+    gnx_finish_table<BN>(p.gnx, t, s_gnx, tid, lane, wave, NWV, [&](int) {});
+    DV_C3TRACE(7);
+    float y[8];
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+      const int cl = e_wn * 32 + coff + 4 * lh + 8 * g;
+      const float4 sa = *reinterpret_cast<const float4*>(s_gnx.gA + cl);
+      const float4 sb = *reinterpret_cast<const float4*>(s_gnx.gB + cl);
+      y[4 * g] = fmaf(vv[4 * g], sa.x, sb.x); y[4 * g + 1] = fmaf(vv[4 * g + 1], sa.y, sb.y);
+      y[4 * g + 2] = fmaf(vv[4 * g + 2], sa.z, sb.z); y[4 * g + 3] = fmaf(vv[4 * g + 3], sa.w, sb.w);
+    }
+    if (p.gnx.silu) {
+#pragma unroll
+      for (int r = 0; r < 8; ++r) y[r] = y[r] * __builtin_amdgcn_rcpf(1.0f + __expf(-y[r]));
+    }
+    store_planes8(p.gnx.y_hi, p.gnx.y_lo, (size_t)m * p.N + ncol, lh, y);
+  }
+  DV_C3TRACE(8);
+}
 
 template <int CIN>
 __global__ __launch_bounds__(NT) void k_conv3(const GemmParams p) {
@@ -79,26 +194,12 @@ __global__ __launch_bounds__(NT) void k_conv3(const GemmParams p) {
   asm volatile("" ::"s"(p.seg[0].a0_hi), "s"(p.seg[1].a0_hi), "s"(p.seg[1].pad), "s"(p.T_in), "s"(p.w_hi), "s"(p.M), "s"(p.res),
                "s"(p.out_hi), "s"(p.zero_page), "s"(p.ln_u), "s"(p.gnx.xchg), "s"(p.gnx.y_hi), "s"(p.xcd_n), "s"(p.xcd_inv_tn), "s"(p.wf_lo));
   DV_C3TRACE(0);
-  // ---- tile of this workgroup: k_gemm's XCD-aware order (workgroup b runs on XCD b % 8) ----
   int m0, n0;
-  {
-    const int n_tiles_n = p.N / BN, nwg = gridDim.x;
-    int bid = blockIdx.x;
-    if (p.xcd_n > 0) {
-      const int x = bid & 7, i = bid >> 3;
-      const int r = x & ((1 << p.xcd_sh_mn) - 1), xm_i = r >> p.xcd_sh_n, xn_i = r & (p.xcd_n - 1);
-      const int lm = (i * p.xcd_inv_tn) >> 16, ln = i - lm * p.xcd_tn;
-      m0 = (xm_i * p.xcd_tm + lm) * BM; n0 = (xn_i * p.xcd_tn + ln) * BN;
-    } else {
-      const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
-      bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-      m0 = (bid / n_tiles_n) * BM; n0 = (bid % n_tiles_n) * BN;
-    }
-  }
+  conv3_tile(p, m0, n0);
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l31 = lane & 31, lh = lane >> 5;
   const int cf = wave & 1, kq = wave >> 1;           // k-loop role: column fragment, k-quarter
-  const int e_wn = cf, e_wm = (wave >> 1) & 1, e_half = wave >> 2;   // epilogue role: fragment (e_wm, e_wn), its columns [16 e_half, +16)
+  const int e_wn = cf, e_wm = (wave >> 1) & 1, e_half = wave >> 2;   // epilogue role (conv3_finish): this wave's residual rows
   const unsigned a_base = (unsigned)(size_t)smem;
   const GemmSeg& sg = p.seg[0];
   const int c0 = sg.c0, c1 = sg.c1;
@@ -216,105 +317,209 @@ __global__ __launch_bounds__(NT) void k_conv3(const GemmParams p) {
   else run(std::integral_constant<int, 3>{});
   DV_C3TRACE(3);
 
-  // ---- the four k-quarters are added through LDS; this wave keeps a 32-row x 16-column half fragment ----
-  __syncthreads();                                   // every wave is done reading the resident operand
-  float4* const red4 = reinterpret_cast<float4*>(smem);
+  conv3_finish(p, smem, s_bias, s_gnx, acc, rpre, m0, n0, tid, lane, wave, CIN);
+}
+
+// ---------------------------------------------------------------------------------------
+// Any input width (a multiple of 128 channels, up to 1024): the same tile with the rows STREAMED through a ring of 64-channel
+// chunks.  K runs chunk-major (chunk -> tap -> the chunk's four 16-deep k-steps); within a chunk wave quarter q multiplies
+// k-step q of every tap - three weight units per chunk and wave, the same 16 channels of the rows at offsets -1 / 0 / +1 - so a
+// chunk is 18 MFMAs per wave between two barriers, its operand reads are per-lane constants plus the ring slot, and the first
+// MFMA needs the first chunk only.  Ring: RS slots of [2 planes][64 rows][128 B]; the DMAs of chunk c + RS - 1 go out right
+// behind chunk c's barrier (the slot of chunk c - 1 is free then).  The two halo rows of EVERY chunk are DMA'd once, at the head,
+// into their own 4 KiB per plane.  The waits are counted by hand: every wave issues exactly two LDS-DMAs and six weight loads per
+// chunk (past the last chunk: two DMAs of the zero page into a sink, and the last weight unit again), so "chunk c has landed" is
+// one constant in the steady state (XS below) and 24 + 6 c for the RS - 1 chunks requested before the loop.
+// ---------------------------------------------------------------------------------------
+#ifndef DV_C3_EXP
+// development knob (trace experiments on the streaming k-loop, WRONG results): bit 0 = no operand DMA inside the loop, bit 1 = no
+// weight loads inside the loop.  0 in every shipped build
+#define DV_C3_EXP 0
+#endif
+namespace {
+constexpr int RS = 8;                                // ring slots
+constexpr int SLOT_PL = BM * 128, SLOT = 2 * SLOT_PL;   // one plane / both planes of a 64-channel chunk: 16 KiB per slot
+constexpr int S_HALO = RS * SLOT;                    // halo rows: [16 chunks][row m0 + 64 | row m0 - 1][128 B], the lo plane SLOT_PL further on
+constexpr int S_SINK = S_HALO + 4096;                // 1 KiB nobody reads (DMAs past the last chunk)
+constexpr int S_TOTAL = S_HALO + SLOT_PL + 4096;
+constexpr int DWS = 6;                               // weight units in flight per wave: two chunks
+constexpr int XS = 6 + (RS - 2) * 8;                 // VM operations a wave has issued behind a chunk's DMAs when that chunk is due (steady state)
+static_assert(XS <= 63 && 22 + 6 * (RS - 3) <= 63 && RS == 8 && S_TOTAL + 4096 <= 160 * 1024 && RED_BYTES <= RS * SLOT, "ring geometry");
+}  // namespace
+
+__global__ __launch_bounds__(NT) void k_conv3s(const GemmParams p) {
+  extern __shared__ __attribute__((aligned(1024))) char smem[];
+  __shared__ __attribute__((aligned(16))) float s_bias[BN];
+  __shared__ GnxShared<BN> s_gnx;
+  asm volatile("" ::"s"(p.seg[0].a0_hi), "s"(p.seg[1].a0_hi), "s"(p.seg[1].pad), "s"(p.T_in), "s"(p.w_hi), "s"(p.M), "s"(p.res),
+               "s"(p.out_hi), "s"(p.zero_page), "s"(p.ln_u), "s"(p.gnx.xchg), "s"(p.gnx.y_hi), "s"(p.xcd_n), "s"(p.xcd_inv_tn), "s"(p.wf_lo));
+  const GemmSeg& sg = p.seg[0];
+  const int c0 = sg.c0, c1 = sg.c1, CIN = c0 + c1;
+  DV_C3TRACE(0);
+  int m0, n0;
+  conv3_tile(p, m0, n0);
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, lh = lane >> 5;
+  const int cf = wave & 1, kq = wave >> 1;           // k-loop role: column fragment, k-quarter (k-step kq of every 64-channel chunk and tap)
+  const int e_wn = cf, e_wm = (wave >> 1) & 1, e_half = wave >> 2;   // epilogue role (conv3_finish): this wave's residual rows
+  const unsigned a_base = (unsigned)(size_t)smem;
+  const int NCH = CIN >> 6, KPT = CIN >> 4;          // chunks; 16-deep k-steps per tap
+  const int t0 = m0 - (int)__umulhi((unsigned)m0, p.tout_magic) * p.T_out;   // frame of the tile's first row inside its utterance
+
+  // ---- requests, oldest first: residual rows, bias, halo rows of every chunk, chunks 0 .. RS - 2, weight units 0 .. 5 ----
+  float rpre[8];
+  if (p.epi == EPI_RESIDUAL) {
+    const float* rp = p.res + (size_t)(m0 + e_wm * 32 + l31) * p.ldres + n0 + e_wn * 32 + e_half * 16 + 4 * lh;
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+      const float4 a = *reinterpret_cast<const float4*>(rp + 8 * g);
+      rpre[4 * g] = a.x; rpre[4 * g + 1] = a.y; rpre[4 * g + 2] = a.z; rpre[4 * g + 3] = a.w;
+    }
+  }
+  if (wave == 0) glds4(p.bias ? (const void*)(p.bias + n0 + lane) : (const void*)p.zero_page, (unsigned)(size_t)s_bias);
+  {
+    // halo rows: one instruction per wave = one plane of four chunks, lane = (chunk, row m0 + 64 | row m0 - 1, 16-byte slot);
+    // rows beyond the utterance's ends and chunks beyond the last come from the zero page
+    const int pl = wave & 1, c = (wave >> 1) * 4 + (lane >> 4), which = (lane >> 3) & 1, slot = lane & 7;
+    const bool ok = c < NCH && (which == 0 ? (t0 + BM < p.T_out) : (t0 > 0));
+    const long srow = which == 0 ? (long)m0 + BM : (long)m0 - 1;
+    const int ch = c * 64 + slot * 8;
+    const bool first = ch < c0;
+    const bf16_t* src = first ? (pl ? sg.a0_lo : sg.a0_hi) : (pl ? sg.a1_lo : sg.a1_hi);
+    const void* g = ok ? (const void*)(src + (size_t)srow * (first ? c0 : c1) + (first ? ch : ch - c0)) : (const void*)p.zero_page;
+    glds16(g, a_base + (unsigned)(S_HALO + pl * SLOT_PL + (wave >> 1) * 1024));
+  }
+  // a chunk's rows: wave w brings rows 8w .. 8w + 7, both planes (lane = (row, slot); the source chunk is swizzled)
+  const int d_row = wave * 8 + (lane >> 3);
+  const unsigned d_sc = (unsigned)(((lane & 7) ^ swz(d_row)) << 4);
+  const unsigned voff0 = (unsigned)((size_t)(m0 + d_row) * c0 * 2) + d_sc, voff1 = (unsigned)((size_t)(m0 + d_row) * c1 * 2) + d_sc;
+  auto issue_chunk = [&](int cc) __attribute__((always_inline)) {
+    if (cc < NCH) {
+      const int cb = cc * 64;
+      const bool first = cb < c0;
+      const unsigned dst = a_base + (unsigned)((cc & (RS - 1)) * SLOT + wave * 1024);
+      const unsigned vo = first ? voff0 : voff1;
+      glds16_s((first ? sg.a0_hi : sg.a1_hi) + (first ? cb : cb - c0), vo, dst);
+      glds16_s((first ? sg.a0_lo : sg.a1_lo) + (first ? cb : cb - c0), vo, dst + SLOT_PL);
+    } else {
+      glds16_s(p.zero_page, (unsigned)lane * 16u, a_base + S_SINK);
+      glds16_s(p.zero_page, (unsigned)lane * 16u, a_base + S_SINK);
+    }
+  };
+#pragma unroll
+  for (int cc = 0; cc < RS - 1; ++cc) issue_chunk(cc);
+  // weights of this wave: fragment nf = n0 / 32 + cf; unit (chunk c, tap t) = k-step t KPT + 4 c + kq of the packed order
+  const bf16_t* const wh = p.wf_hi + ((size_t)((n0 >> 5) + cf) * (3 * KPT) + kq) * 512;
+  const bf16_t* const wl = p.wf_lo + ((size_t)((n0 >> 5) + cf) * (3 * KPT) + kq) * 512;
+  auto load_unit = [&](int c, int t) {
+    const size_t e = (size_t)(t * KPT + 4 * min(c, NCH - 1)) * 512 + (size_t)lane * 8;
+    BFrag f;
+    f.h = *reinterpret_cast<const bf16x8*>(wh + e);
+    f.l = *reinterpret_cast<const bf16x8*>(wl + e);
+    return f;
+  };
+  BFrag bq[DWS];
+#pragma unroll
+  for (int j = 0; j < DWS; ++j) bq[j] = load_unit(j / 3, j % 3);
+  __builtin_amdgcn_sched_barrier(0);
+  DV_C3TRACE(1);
+
+  // operand reads: LDS byte offset of (row fragment rf, tap) inside a slot for this lane - frame rf * 32 + l31 + tap - 1, k-step kq
+  // of the chunk, half lh - or, for the one lane pair whose frame is the row before / behind the tile, inside the halo area
+  int rb[2][3];
+  bool hs[2][3];
 #pragma unroll
   for (int rf = 0; rf < 2; ++rf)
 #pragma unroll
-    for (int g = 0; g < 4; ++g)
-      red4[((((cf * 4 + kq) * 2 + rf) * 4 + g) << 6) + lane] = make_float4(acc[rf][4 * g], acc[rf][4 * g + 1], acc[rf][4 * g + 2], acc[rf][4 * g + 3]);
-  __syncthreads();
-  float vv[8];
-#pragma unroll
-  for (int g = 0; g < 2; ++g) {
-    float4 s = red4[((((e_wn * 4 + 0) * 2 + e_wm) * 4 + e_half * 2 + g) << 6) + lane];
-#pragma unroll
-    for (int k = 1; k < 4; ++k) {                    // (quarters in order: deterministic)
-      const float4 v = red4[((((e_wn * 4 + k) * 2 + e_wm) * 4 + e_half * 2 + g) << 6) + lane];
-      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    for (int tap = 0; tap < 3; ++tap) {
+      const int idx = rf * 32 + l31 + tap - 1, c16 = kq * 2 + lh;
+      hs[rf][tap] = idx < 0 || idx >= BM;
+      rb[rf][tap] = hs[rf][tap] ? S_HALO + (idx < 0 ? 128 : 0) + (c16 << 4) : idx * 128 + ((c16 ^ swz(idx)) << 4);
     }
-    vv[4 * g] = s.x; vv[4 * g + 1] = s.y; vv[4 * g + 2] = s.z; vv[4 * g + 3] = s.w;
-  }
-  DV_C3TRACE(4);
+  f32x16 acc[2];
+#pragma unroll
+  for (int rf = 0; rf < 2; ++rf)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[rf][r] = 0.f;
 
-  // ---- epilogue of the half fragment (the steps of gemm_tile.h's half-fragment epilogue) ----
-  const bool gnx_h = p.gnx.xchg != nullptr;
-  const int coff = e_half * 16;                      // this wave's columns inside the fragment
-  const int ncol = n0 + e_wn * 32 + coff;            // first of them
-  const int m = m0 + e_wm * 32 + l31, mrow0 = m0 + e_wm * 32;
+  // operand fragments (both row fragments, both planes) of tap t of chunk c
+  auto read_a = [&](int c, int t, bf16x8 (&h)[2], bf16x8 (&l)[2]) __attribute__((always_inline)) {
+    const int s_slot = (c & (RS - 1)) * SLOT, s_halo = c * 256;
 #pragma unroll
-  for (int g = 0; g < 2; ++g) {
-    const float4 b4 = *reinterpret_cast<const float4*>(s_bias + e_wn * 32 + coff + 4 * lh + 8 * g);
-    vv[4 * g] += b4.x; vv[4 * g + 1] += b4.y; vv[4 * g + 2] += b4.z; vv[4 * g + 3] += b4.w;
-  }
-  if (p.epi == EPI_RESIDUAL) {
-#pragma unroll
-    for (int r = 0; r < 8; ++r) vv[r] += rpre[r];
-  }
-  {
-    const size_t ob = (size_t)m * p.ldo + ncol;
-    if (p.out) {
-#pragma unroll
-      for (int g = 0; g < 2; ++g)
-        dv_st16(p.out + ob + 4 * lh + 8 * g, make_float4(vv[4 * g], vv[4 * g + 1], vv[4 * g + 2], vv[4 * g + 3]));
+    for (int rf = 0; rf < 2; ++rf) {
+      // (only (rf 0, tap 0) and (rf 1, tap 2) have a halo lane pair: the select folds away elsewhere)
+      const bool any_halo = (rf == 0 && t == 0) || (rf == 1 && t == 2);
+      const int off = rb[rf][t] + ((any_halo && hs[rf][t]) ? s_halo : s_slot);
+      h[rf] = *reinterpret_cast<const bf16x8*>(smem + off);
+      l[rf] = *reinterpret_cast<const bf16x8*>(smem + off + SLOT_PL);
     }
-    if (p.out_hi) store_planes8(p.out_hi, p.out_lo, ob, lh, vv);
-  }
-  DV_C3TRACE(5);
-  if (p.stats16) {                                   // this wave's 32 x 16 block: (sum, squared deviations about its own mean)
-    float a1 = 0.f, a2 = 0.f;
+  };
+  bf16x8 ahb[2][2], alb[2][2];                       // fragments of unit 3c + t sit in buffer (c + t) & 1
+  wait_vmcnt<24>();                                  // chunk 0 (and everything older): behind its DMAs this wave has issued chunks 1 - 6 and the weights
+  __builtin_amdgcn_s_barrier();
+  DV_C3TRACE(2);
+  read_a(0, 0, ahb[0], alb[0]);
+  // Iteration c: its barrier makes chunk c + 1 visible (every wave has waited for ITS part: the constants below) and says that
+  // every wave is done with chunk c - 1, whose slot the DMAs of chunk c + RS - 1 then overwrite.  The fragments of a unit are read
+  // one unit ahead - those of chunk c + 1's first tap under chunk c's last MFMAs - so no wave arrives behind a barrier with
+  // nothing to multiply.  [First version: barrier c made chunk c visible and the reads started behind it - both waves of every
+  // SIMD waited out the LDS latency at once, 1950 cycles per chunk against 1152 of MFMA: profiles/r05_conv3_phase_trace_*.txt]
+  auto chunk = [&](const int c, auto par_tag) __attribute__((always_inline)) {
+    constexpr int PAR = decltype(par_tag)::value;    // c & 1: units 3c .. 3c + 2 sit in bq[3 PAR ..]
+    if (c >= RS - 2) wait_vmcnt<XS - 8>();           // chunk c + 1 has landed - this wave's part
+    else if (c == 0) wait_vmcnt<22>();
+    else if (c == 1) wait_vmcnt<28>();
+    else if (c == 2) wait_vmcnt<34>();
+    else if (c == 3) wait_vmcnt<40>();
+    else if (c == 4) wait_vmcnt<46>();
+    else wait_vmcnt<52>();
+    __builtin_amdgcn_s_barrier();
+    if (!(DV_C3_EXP & 1)) issue_chunk(c + RS - 1);   // into the slot chunk c - 1 was read from
 #pragma unroll
-    for (int r = 0; r < 8; ++r) a1 += vv[r];
-    a1 = wave_sum64(a1);
-    const float mb = a1 * (1.0f / 512.0f);
-#pragma unroll
-    for (int r = 0; r < 8; ++r) { const float dv = vv[r] - mb; a2 = fmaf(dv, dv, a2); }
-    a2 = wave_sum64(a2);
-    if (lane == 0) {
-      const size_t e = (size_t)(mrow0 >> 5) * (p.N >> 4) + (ncol >> 4);
-      reinterpret_cast<float2*>(p.stats16)[e] = make_float2(a1, a2);
-      if (gnx_h)
-        __hip_atomic_store(p.gnx.xchg + e, (unsigned long long)__float_as_uint(a1) | ((unsigned long long)__float_as_uint(a2) << 32),
-                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    for (int t = 0; t < 3; ++t) {
+      const int cur = (PAR + t) & 1;
+      if (t + 1 < 3) read_a(c, t + 1, ahb[cur ^ 1], alb[cur ^ 1]);
+      else read_a(c + 1, 0, ahb[cur ^ 1], alb[cur ^ 1]);            // (behind the last chunk: a slot nobody waits for - never multiplied)
+      bf16x8 (&ah)[2] = ahb[cur];
+      bf16x8 (&al)[2] = alb[cur];
+      const BFrag f = bq[3 * PAR + t];
+      acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.h, al[0], acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.h, al[1], acc[1], 0, 0, 0);
+      acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.l, ah[0], acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.l, ah[1], acc[1], 0, 0, 0);
+      acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.h, ah[0], acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.h, ah[1], acc[1], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      if (!(DV_C3_EXP & 2)) bq[3 * PAR + t] = load_unit(c + 2, t);   // (unconditional: past the end the last chunk's unit again - the counts stay constant)
+      __builtin_amdgcn_sched_barrier(0);
     }
+  };
+  for (int c = 0; c < NCH; c += 2) {                 // (NCH is even: C_in is a multiple of 128)
+    chunk(c, std::integral_constant<int, 0>{});
+    chunk(c + 1, std::integral_constant<int, 1>{});
   }
-  DV_C3TRACE(6);
-  if (gnx_h) {
-    GnxTile t;
-    t.M = p.M; t.N = p.N; t.T_out = p.T_out; t.Tv_out = p.Tv_out; t.m0 = m0; t.n0 = n0; t.bm = BM; t.bn = BN;
-    t.bq = (int)__umulhi((unsigned)m0, p.tout_magic);
-    gnx_finish_table<BN>(p.gnx, t, s_gnx, tid, lane, wave, NWV, [&](int) {});
-    DV_C3TRACE(7);
-    float y[8];
-#pragma unroll
-    for (int g = 0; g < 2; ++g) {
-      const int cl = e_wn * 32 + coff + 4 * lh + 8 * g;
-      const float4 sa = *reinterpret_cast<const float4*>(s_gnx.gA + cl);
-      const float4 sb = *reinterpret_cast<const float4*>(s_gnx.gB + cl);
-      y[4 * g] = fmaf(vv[4 * g], sa.x, sb.x); y[4 * g + 1] = fmaf(vv[4 * g + 1], sa.y, sb.y);
-      y[4 * g + 2] = fmaf(vv[4 * g + 2], sa.z, sb.z); y[4 * g + 3] = fmaf(vv[4 * g + 3], sa.w, sb.w);
-    }
-    if (p.gnx.silu) {
-#pragma unroll
-      for (int r = 0; r < 8; ++r) y[r] = y[r] * __builtin_amdgcn_rcpf(1.0f + __expf(-y[r]));
-    }
-    store_planes8(p.gnx.y_hi, p.gnx.y_lo, (size_t)m * p.N + ncol, lh, y);
-  }
-  DV_C3TRACE(8);
+  DV_C3TRACE(3);
+  wait_vmcnt<0>();                                   // (the sink's DMAs: nothing may still be writing LDS when it becomes the exchange buffer)
+  conv3_finish(p, smem, s_bias, s_gnx, acc, rpre, m0, n0, tid, lane, wave, CIN);
 }
 
 // ---- host side ----
-static bool g_conv3_on = [] { const char* e = getenv("DVITS_CONV3"); return !(e && e[0] == '0'); }();
-void conv3_env_refresh() { const char* e = getenv("DVITS_CONV3"); g_conv3_on = !(e && e[0] == '0'); }
+static bool g_conv3_on = true;
+static int g_conv3_stream = 512;                     // widths above this run the streaming kernel (DVITS_CONV3_STREAM=<channels>; 0: every width)
+void conv3_env_refresh() {
+  const char* e = getenv("DVITS_CONV3"); g_conv3_on = !(e && e[0] == '0');
+  const char* e2 = getenv("DVITS_CONV3_STREAM"); g_conv3_stream = e2 ? atoi(e2) : 512;
+}
+static const bool g_conv3_env_once = [] { conv3_env_refresh(); return true; }();
 
-// Shapes this kernel takes (everything else stays with k_gemm): one 3-tap segment over 128 / 256 / 384 / 512 input channels (one
-// tensor or the concatenation of two, each a multiple of 64 channels), stride 1, no resampling, no padded row space, whole 64 x 64
-// tiles that never span two utterances, the plain / residual epilogue without LayerNorm, column-slab statistics, ReLU or row mask.
+// Shapes these kernels take (everything else stays with k_gemm): one 3-tap segment over 128 .. 1024 input channels in steps of 128
+// (one tensor or the concatenation of two, each a multiple of 64 channels), stride 1, no resampling, no padded row space, whole
+// 64 x 64 tiles that never span two utterances, the plain / residual epilogue without LayerNorm, column-slab statistics, ReLU or
+// row mask.
 bool gemm_conv3_shape_ok(const GemmParams& p) {
   if (!g_conv3_on || p.nseg != 1 || p.seg[0].taps != 3 || p.seg[0].pad != 1 || p.stride != 1 || p.up_mode != UP_NONE) return false;
   const int cin = p.seg[0].c0 + p.seg[0].c1;
-  if (cin != 128 && cin != 256 && cin != 384 && cin != 512) return false;
+  if (cin < 128 || cin > 1024 || cin % 128 != 0) return false;
   if (p.seg[0].c0 % 64 != 0 || p.seg[0].c1 % 64 != 0 || (p.seg[0].c1 > 0 && !p.seg[0].a1_hi)) return false;
   if (p.T_in != p.T_out || p.T_virt != p.T_out || (p.Tv_out > 0 && p.Tv_out != p.T_out) || (p.Tv_in > 0 && p.Tv_in != p.T_in)) return false;
   if (p.T_out % BM != 0 || p.M % BM != 0 || p.N % BN != 0 || p.B <= 0 || p.M != p.B * p.T_out) return false;
@@ -335,6 +540,7 @@ static hipError_t conv3_attr() {
 }
 hipError_t conv3_init() {
   hipError_t e;
+  if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv3s), hipFuncAttributeMaxDynamicSharedMemorySize, S_TOTAL)) != hipSuccess) return e;
   if ((e = conv3_attr<128>()) != hipSuccess) return e;
   if ((e = conv3_attr<256>()) != hipSuccess) return e;
   if ((e = conv3_attr<384>()) != hipSuccess) return e;
@@ -343,7 +549,12 @@ hipError_t conv3_init() {
 // (called by launch_gemm with p validated, tout_magic and the XCD rectangle of the 64x64 tile grid set)
 hipError_t launch_conv3(const GemmParams& p, hipStream_t st) {
   if (!p.wf_hi || !p.wf_lo || !gemm_conv3_shape_ok(p) || p.Kp != 3 * (p.seg[0].c0 + p.seg[0].c1) || p.sk_mode != 0) return hipErrorInvalidValue;
-  switch (p.seg[0].c0 + p.seg[0].c1) {
+  const int cin = p.seg[0].c0 + p.seg[0].c1;
+  if (cin > 512 || cin > g_conv3_stream) {
+    hipLaunchKernelGGL(k_conv3s, dim3((p.M / BM) * (p.N / BN)), dim3(NT), S_TOTAL, st, p);
+    return hipGetLastError();
+  }
+  switch (cin) {
     case 128: return conv3_launch<128>(p, st);
     case 256: return conv3_launch<256>(p, st);
     case 384: return conv3_launch<384>(p, st);

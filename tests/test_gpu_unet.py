@@ -835,7 +835,8 @@ def test_split_feed_forward_launch_matches_two_gemms(B, T, L):
 def test_resident_operand_convolution_matches_the_ring_kernel(B, T, L):
     """ResnetBlock2D convolutions (reference resnet.py:591-641: kernel 3, padding 1, stride 1) over 128 / 256 / 384 / 512 input
     channels run on k_conv3 (kernels_conv.hip: the tile's 64 + 2 rows of every input channel resident in LDS, fragment-major
-    weights straight into registers, four k-quarters added through LDS) where the 64x64 tile grid has 128-256 tiles;
+    weights straight into registers, four k-quarters added through LDS) and over 640 - 1024 on k_conv3s (the same tile, the rows
+    streamed through a ring of 64-channel chunks; DVITS_CONV3_STREAM=0: at every width) where the 64x64 tile grid has 128-256 tiles;
     DVITS_CONV3=0 keeps them on k_gemm's LDS ring.  Same operands, same split-bf16 products, another summation order:
     float32-rounding agreement, the same number of launches, bit-repeatable, no hand-over timed out.  Shapes: the bench shape, 64-frame
     levels whose tiles are whole utterances (both halo rows are zeros), and long utterances (interior tiles: both halo rows exist)."""
@@ -850,8 +851,10 @@ def test_resident_operand_convolution_matches_the_ring_kernel(B, T, L):
     enc = torch.from_numpy(synth.normal(16, "e", (B, L, 128))).cuda()
     t = torch.linspace(900.0, 20.0, B, device="cuda")
     outs, launches, resident = [], [], []
-    for on in ("0", "1"):
+    for on, stream in (("0", None), ("1", None), ("1", "0")):      # the LDS ring; resident up to 512 channels + streamed above; streamed at every width
         os.environ["DVITS_CONV3"] = on
+        if stream is not None:
+            os.environ["DVITS_CONV3_STREAM"] = stream
         try:
             m = UNet1DConditionModel(**kw).eval()
             m.load_state_dict(sd)
@@ -869,10 +872,12 @@ def test_resident_operand_convolution_matches_the_ring_kernel(B, T, L):
             resident.append(sum(1 for r in eng.profile_forward(x, cond, t) if r[0] == "gemm" and " resident" in r[3]))
         finally:
             os.environ.pop("DVITS_CONV3", None)
-    assert resident[0] == 0 and resident[1] >= 12, resident
-    assert launches[1] == launches[0], launches
-    assert np.isfinite(outs[1]).all()
-    assert rel_l2(outs[1], outs[0]) < 2e-5, rel_l2(outs[1], outs[0])
+            os.environ.pop("DVITS_CONV3_STREAM", None)
+    assert resident[0] == 0 and resident[1] >= 12 and resident[2] == resident[1], resident
+    assert launches[1] == launches[0] and launches[2] == launches[0], launches
+    for k in (1, 2):
+        assert np.isfinite(outs[k]).all()
+        assert rel_l2(outs[k], outs[0]) < 2e-5, (k, rel_l2(outs[k], outs[0]))
 
 
 @pytest.mark.parametrize("B,T,L", [(16, 128, 40), (3, 256, 77), (1, 64, 10), (2, 2048, 300), (5, 512, 256), (1, 320, 150)])

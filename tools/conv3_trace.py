@@ -1,0 +1,56 @@
+#!/usr/bin/env python3
+"""Phase timeline of the resident-operand convolution k_conv3 (GPU box, `make -C diff-vits_amd/csrc trace`): runs forwards of
+the bench model with libdvits_hip_trace.so and prints, for the LAST launch of the selected input width, the median s_memtime
+deltas between the kernel's phase stamps (thread 0 of every workgroup).   python tools/conv3_trace.py [B T [C_in]]"""
+import ctypes as C
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+import torch
+import diff_vits_amd  # noqa
+from diff_vits_amd import _lib as L
+
+L.LIB_PATH = os.environ.get("DVITS_TRACE_LIB") or os.path.join(os.path.dirname(L.LIB_PATH), "libdvits_hip_trace.so")
+lib = L.lib()
+import bench  # noqa: E402
+from diff_vits_amd import synth  # noqa: E402
+
+B, T = int(sys.argv[1]) if len(sys.argv) > 1 else 8, int(sys.argv[2]) if len(sys.argv) > 2 else 1024
+CS = [int(sys.argv[3])] if len(sys.argv) > 3 else [128, 256, 384, 512, 640, 768, 896, 1024]
+dev = torch.device("cuda", 0)
+model, _ = bench.build_model(dev, "bf16x3")
+x, cond, enc, mask = (torch.from_numpy(v).to(dev) for v in synth.make_inputs(B, 80, T, 256))
+eng = model.hip_engine()
+eng.prepare(B, T, 256)
+eng.set_cond(enc, None)
+t = torch.full((B,), 500.0, device=dev)
+lib.dv_debug_c3_trace_select.restype = C.c_int
+lib.dv_debug_c3_trace_select.argtypes = [C.c_int]
+lib.dv_debug_c3_trace.restype = C.c_int
+lib.dv_debug_c3_trace.argtypes = [C.c_void_p, C.c_int]
+names = ["args, tile, residual / halo / bias / rows / first weights requested", "rows landed (wait + barrier)", "k-loop",
+         "k-quarters added through LDS", "bias, residual, stores", "block statistics (+ exchange words)",
+         "in-launch GroupNorm: table (+ skip slice)", "normalised planes stored"]
+for Csel in CS:
+    assert lib.dv_debug_c3_trace_select(Csel) == 0
+    for _ in range(3):
+        eng.eval(x, cond, t)
+    torch.cuda.synchronize()
+    NWG = 1024
+    buf = np.zeros((NWG, 16), dtype=np.uint64)
+    assert lib.dv_debug_c3_trace(buf.ctypes.data_as(C.c_void_p), NWG) == 0
+    tt = buf.astype(np.int64)
+    live = tt[:, 8] > 0
+    tt = tt[live]
+    if not len(tt):
+        print("k_conv3, C_in = %d: no launch" % Csel)
+        continue
+    print("k_conv3, C_in = %d: last launch of the forward, %d workgroups (cycles of s_memtime, thread 0)" % (Csel, int(live.sum())))
+    for i, nm in enumerate(names):
+        d = tt[:, i + 1] - tt[:, i]
+        print("   %-66s median %6d  p10 %6d  p90 %6d" % (nm, np.median(d), np.percentile(d, 10), np.percentile(d, 90)))
+    print("   %-66s median %6d  max %6d" % ("whole workgroup", np.median(tt[:, 8] - tt[:, 0]), np.max(tt[:, 8] - tt[:, 0])))
+    print("   %-66s %6d" % ("first start -> last end over the launch", int(tt[:, 8].max() - tt[:, 0].min())))
