@@ -302,6 +302,7 @@ hipError_t launch_gemm(const GemmParams& p, int precision, hipStream_t st);
 hipError_t gemm_init();   // one-time kernel attribute setup (call outside stream capture)
 // k_conv3 (kernels_conv.hip): the resident-operand kernel of the stride-1 three-tap convolutions; launch_gemm dispatches to it
 bool gemm_conv3_shape_ok(const GemmParams& p);   // shape / epilogue test only (weights and precision are the caller's)
+int gemm_conv3_k(const GemmParams& p);           // the packed K such a launch expects
 hipError_t conv3_init();
 void conv3_env_refresh();                        // DVITS_CONV3=0: off
 hipError_t launch_conv3(const GemmParams& p, hipStream_t st);

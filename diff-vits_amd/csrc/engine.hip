@@ -745,7 +745,7 @@ struct Builder {
     g.B = B;
     g.zero_page = u->zero_page;
     const int p = prec;
-    const bool c3 = conv3_takes(g) && g.Kp == 3 * (g.seg[0].c0 + g.seg[0].c1) && frag(pw);
+    const bool c3 = conv3_takes(g) && g.Kp == gemm_conv3_k(g) && frag(pw);
     if (c3) { g.wf_hi = dry ? reinterpret_cast<const bf16_t*>(0x1000) : pw->fhi; g.wf_lo = dry ? reinterpret_cast<const bf16_t*>(0x1000) : pw->flo; }
     cur_kind = "gemm"; cur_flops = 2.0 * (double)g.M * (double)g.N * (double)k_real;
     {

@@ -321,15 +321,25 @@ __global__ __launch_bounds__(NT) void k_conv3(const GemmParams p) {
 }
 
 // ---------------------------------------------------------------------------------------
-// Any input width (a multiple of 128 channels, up to 1024): the same tile with the rows STREAMED through a ring of 64-channel
-// chunks.  K runs chunk-major (chunk -> tap -> the chunk's four 16-deep k-steps); within a chunk wave quarter q multiplies
-// k-step q of every tap - three weight units per chunk and wave, the same 16 channels of the rows at offsets -1 / 0 / +1 - so a
-// chunk is 18 MFMAs per wave between two barriers, its operand reads are per-lane constants plus the ring slot, and the first
-// MFMA needs the first chunk only.  Ring: RS slots of [2 planes][64 rows][128 B]; the DMAs of chunk c + RS - 1 go out right
-// behind chunk c's barrier (the slot of chunk c - 1 is free then).  The two halo rows of EVERY chunk are DMA'd once, at the head,
-// into their own 4 KiB per plane.  The waits are counted by hand: every wave issues exactly two LDS-DMAs and six weight loads per
-// chunk (past the last chunk: two DMAs of the zero page into a sink, and the last weight unit again), so "chunk c has landed" is
-// one constant in the steady state (XS below) and 24 + 6 c for the RS - 1 chunks requested before the loop.
+// Any input width (multiples of 128 channels up to 1024), and the ResnetBlock2D's second convolution WITH its folded 1x1 shortcut
+// (a second, one-tap K-segment over the block's raw input - reference resnet.py:627-641): the same tile with the rows STREAMED
+// through a ring of 64-channel chunks.
+//   K order  : chunk-major.  Three-tap segment: chunk -> tap -> the chunk's four 16-deep k-steps, wave quarter q multiplies
+//              k-step q of every tap (three weight units per chunk and wave: the same 16 channels of the rows at offsets
+//              -1 / 0 / +1).  One-tap segment: two chunks per step, k-step q of each (two units).
+//   ring     : RS slots of [2 planes][64 rows][128 B]; the two halo rows of every three-tap chunk are brought once, at the head,
+//              into their own 4 KiB per plane.
+//   producer : a NINTH wave issues every LDS-DMA (16 per chunk) and nothing else: its vector-memory queue holds DMAs only, so
+//              "all but the two youngest chunks have landed" is vmcnt(32) whatever the segment mix, and the compute waves' queues
+//              hold nothing but compiler-visible weight loads (hipcc counts those exactly; it cannot see a DMA).  [First version:
+//              every compute wave issued two DMAs per chunk with hand-counted waits - the same speed for one segment, and no
+//              constant that fits two.]
+//   barriers : one per step.  Barrier s says: the chunks of step s + 1 are in LDS (the producer waited), and every wave is done
+//              with step s - 1 (the producer refills its slots).  Operand fragments are read one unit ahead - those of step
+//              s + 1's first unit under step s's last MFMAs - so nobody arrives behind a barrier with nothing to multiply.
+// Measured (profiles/r05_conv3_*): ~1850 cycles per three-tap chunk against 1152 of MFMA and ~3500 on k_gemm's ring - the per-CU
+// vector-memory path carries 48 KiB of weights AND 17 KiB of rows per chunk here (ablation: 1230 cycles with neither, 1510 / 1400
+// with one of them); the resident kernel above streams the weights only and runs at the MFMA rate, so it keeps the widths it fits.
 // ---------------------------------------------------------------------------------------
 #ifndef DV_C3_EXP
 // development knob (trace experiments on the streaming k-loop, WRONG results): bit 0 = no operand DMA inside the loop, bit 1 = no
@@ -340,33 +350,91 @@ namespace {
 constexpr int RS = 8;                                // ring slots
 constexpr int SLOT_PL = BM * 128, SLOT = 2 * SLOT_PL;   // one plane / both planes of a 64-channel chunk: 16 KiB per slot
 constexpr int S_HALO = RS * SLOT;                    // halo rows: [16 chunks][row m0 + 64 | row m0 - 1][128 B], the lo plane SLOT_PL further on
-constexpr int S_SINK = S_HALO + 4096;                // 1 KiB nobody reads (DMAs past the last chunk)
 constexpr int S_TOTAL = S_HALO + SLOT_PL + 4096;
-constexpr int DWS = 6;                               // weight units in flight per wave: two chunks
-constexpr int XS = 6 + (RS - 2) * 8;                 // VM operations a wave has issued behind a chunk's DMAs when that chunk is due (steady state)
-static_assert(XS <= 63 && 22 + 6 * (RS - 3) <= 63 && RS == 8 && S_TOTAL + 4096 <= 160 * 1024 && RED_BYTES <= RS * SLOT, "ring geometry");
+constexpr int DWS = 6;                               // weight units in flight per wave
+constexpr int NT_S = NT + 64;                        // + the producer wave
+static_assert(S_TOTAL + 4096 <= 160 * 1024 && RED_BYTES <= RS * SLOT && RS == 8, "ring geometry");
 }  // namespace
 
-__global__ __launch_bounds__(NT) void k_conv3s(const GemmParams p) {
+__global__ __launch_bounds__(NT_S) void k_conv3s(const GemmParams p) {
   extern __shared__ __attribute__((aligned(1024))) char smem[];
   __shared__ __attribute__((aligned(16))) float s_bias[BN];
   __shared__ GnxShared<BN> s_gnx;
   asm volatile("" ::"s"(p.seg[0].a0_hi), "s"(p.seg[1].a0_hi), "s"(p.seg[1].pad), "s"(p.T_in), "s"(p.w_hi), "s"(p.M), "s"(p.res),
                "s"(p.out_hi), "s"(p.zero_page), "s"(p.ln_u), "s"(p.gnx.xchg), "s"(p.gnx.y_hi), "s"(p.xcd_n), "s"(p.xcd_inv_tn), "s"(p.wf_lo));
   const GemmSeg& sg = p.seg[0];
+  const GemmSeg& sh = p.seg[1];
   const int c0 = sg.c0, c1 = sg.c1, CIN = c0 + c1;
+  const int d0 = p.nseg > 1 ? sh.c0 : 0, d1 = p.nseg > 1 ? sh.c1 : 0;   // the one-tap segment's channels (0: none)
   DV_C3TRACE(0);
   int m0, n0;
   conv3_tile(p, m0, n0);
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const unsigned a_base = (unsigned)(size_t)smem;
+  const int NCH = CIN >> 6, KPT = CIN >> 4;          // three-tap chunks (even); 16-deep k-steps per tap
+  const int NC2 = (d0 + d1) >> 6;                    // one-tap chunks
+  const int NS2 = (NC2 + 1) >> 1;                    // ... steps (two chunks each; the last may hold one)
+  const int NCT = NCH + NC2, NSTEP = NCH + NS2;
+
+  if (wave == NWV) {
+    // ================= producer =================
+    glds4(p.bias ? (const void*)(p.bias + n0 + lane) : (const void*)p.zero_page, (unsigned)(size_t)s_bias);
+    // a chunk: 8 instructions per plane, instruction r8 = rows 8 r8 .. 8 r8 + 7 (lane = (row, 16-byte slot); the source chunk is swizzled)
+    const int lr = lane >> 3;
+    const unsigned sw_e = (unsigned)(((lane & 7) ^ swz(lr)) << 4), sw_o = (unsigned)(((lane & 7) ^ swz(8 + lr)) << 4);
+    auto issue_chunk = [&](int cc) {
+      // chunk cc of the list [three-tap segment's chunks | one-tap segment's chunks] -> slot cc % RS
+      const bool seg0 = cc < NCH;
+      const int cb = (seg0 ? cc : cc - NCH) * 64;
+      const int e0 = seg0 ? c0 : d0;
+      const bool first = cb < e0;
+      const int ld = first ? e0 : (seg0 ? c1 : d1);
+      const bf16_t* bh = seg0 ? (first ? sg.a0_hi : sg.a1_hi) : (first ? sh.a0_hi : sh.a1_hi);
+      const bf16_t* bl = seg0 ? (first ? sg.a0_lo : sg.a1_lo) : (first ? sh.a0_lo : sh.a1_lo);
+      const size_t col = (size_t)(first ? cb : cb - e0);
+      const unsigned dst = a_base + (unsigned)((cc & (RS - 1)) * SLOT);
+      const unsigned v0 = (unsigned)((size_t)(m0 + lr) * ld * 2);
+#pragma unroll
+      for (int r8 = 0; r8 < 8; ++r8) {
+        const unsigned vo = v0 + (unsigned)(r8 * 8 * ld * 2) + ((r8 & 1) ? sw_o : sw_e);
+        glds16_s(bh + col, vo, dst + r8 * 1024);
+        glds16_s(bl + col, vo, dst + SLOT_PL + r8 * 1024);
+      }
+    };
+    // (chunks 0 and 1 - steps 0 and 1 - and the halo rows are brought by the eight compute waves together, 5 instructions each:
+    // one wave issuing the first 73 instructions held barrier 0 back by ~4 k cycles)
+    int next = 2;
+    for (; next < min(4, NCT); ++next) issue_chunk(next);
+    wait_vmcnt<32>();                                // (the bias; chunks 2 and 3 are not needed before barrier 1)
+    __builtin_amdgcn_s_barrier();                    // barrier 0
+    int done = 0;                                    // chunks of the steps every wave is through
+    for (int s2 = 1; s2 < NSTEP; ++s2) {
+      // (at most two chunks per step: the ring fills over the first steps instead of holding barrier 1 back)
+      if (!(DV_C3_EXP & 1)) {
+        const int lim = min(min(NCT, done + RS), next + 2);
+        for (; next < lim; ++next) issue_chunk(next);
+      }
+      // the chunks of step s2 + 1 must be in LDS: everything but the chunks issued behind its last one (at most three: the queue
+      // holds 63 operations) may still be under way
+      {
+        const int s3 = s2 + 1;
+        const int need = s3 < NCH ? s3 : min(NCH + 2 * (s3 - NCH) + 1, NCT - 1);
+        const int k = next - 1 - need;
+        if (k >= 3) wait_vmcnt<48>();
+        else if (k == 2) wait_vmcnt<32>();
+        else if (k == 1) wait_vmcnt<16>();
+        else wait_vmcnt<0>();
+      }
+      __builtin_amdgcn_s_barrier();                  // barrier s2: everybody is through step s2 - 1
+      done += (s2 - 1) < NCH ? 1 : 2;
+    }
+    return;
+  }
+
+  // ================= compute waves =================
   const int l31 = lane & 31, lh = lane >> 5;
   const int cf = wave & 1, kq = wave >> 1;           // k-loop role: column fragment, k-quarter (k-step kq of every 64-channel chunk and tap)
   const int e_wn = cf, e_wm = (wave >> 1) & 1, e_half = wave >> 2;   // epilogue role (conv3_finish): this wave's residual rows
-  const unsigned a_base = (unsigned)(size_t)smem;
-  const int NCH = CIN >> 6, KPT = CIN >> 4;          // chunks; 16-deep k-steps per tap
-  const int t0 = m0 - (int)__umulhi((unsigned)m0, p.tout_magic) * p.T_out;   // frame of the tile's first row inside its utterance
-
-  // ---- requests, oldest first: residual rows, bias, halo rows of every chunk, chunks 0 .. RS - 2, weight units 0 .. 5 ----
   float rpre[8];
   if (p.epi == EPI_RESIDUAL) {
     const float* rp = p.res + (size_t)(m0 + e_wm * 32 + l31) * p.ldres + n0 + e_wn * 32 + e_half * 16 + 4 * lh;
@@ -376,10 +444,10 @@ __global__ __launch_bounds__(NT) void k_conv3s(const GemmParams p) {
       rpre[4 * g] = a.x; rpre[4 * g + 1] = a.y; rpre[4 * g + 2] = a.z; rpre[4 * g + 3] = a.w;
     }
   }
-  if (wave == 0) glds4(p.bias ? (const void*)(p.bias + n0 + lane) : (const void*)p.zero_page, (unsigned)(size_t)s_bias);
   {
-    // halo rows: one instruction per wave = one plane of four chunks, lane = (chunk, row m0 + 64 | row m0 - 1, 16-byte slot);
-    // rows beyond the utterance's ends and chunks beyond the last come from the zero page
+    // halo rows: one instruction per wave = one plane of four chunks, lane = (chunk, row m0 + 64 | row m0 - 1, 16-byte slot); rows
+    // beyond the utterance's ends and chunks beyond the last come from the zero page
+    const int t0 = m0 - (int)__umulhi((unsigned)m0, p.tout_magic) * p.T_out;   // frame of the tile's first row inside its utterance
     const int pl = wave & 1, c = (wave >> 1) * 4 + (lane >> 4), which = (lane >> 3) & 1, slot = lane & 7;
     const bool ok = c < NCH && (which == 0 ? (t0 + BM < p.T_out) : (t0 > 0));
     const long srow = which == 0 ? (long)m0 + BM : (long)m0 - 1;
@@ -388,39 +456,41 @@ __global__ __launch_bounds__(NT) void k_conv3s(const GemmParams p) {
     const bf16_t* src = first ? (pl ? sg.a0_lo : sg.a0_hi) : (pl ? sg.a1_lo : sg.a1_hi);
     const void* g = ok ? (const void*)(src + (size_t)srow * (first ? c0 : c1) + (first ? ch : ch - c0)) : (const void*)p.zero_page;
     glds16(g, a_base + (unsigned)(S_HALO + pl * SLOT_PL + (wave >> 1) * 1024));
-  }
-  // a chunk's rows: wave w brings rows 8w .. 8w + 7, both planes (lane = (row, slot); the source chunk is swizzled)
-  const int d_row = wave * 8 + (lane >> 3);
-  const unsigned d_sc = (unsigned)(((lane & 7) ^ swz(d_row)) << 4);
-  const unsigned voff0 = (unsigned)((size_t)(m0 + d_row) * c0 * 2) + d_sc, voff1 = (unsigned)((size_t)(m0 + d_row) * c1 * 2) + d_sc;
-  auto issue_chunk = [&](int cc) __attribute__((always_inline)) {
-    if (cc < NCH) {
-      const int cb = cc * 64;
-      const bool first = cb < c0;
-      const unsigned dst = a_base + (unsigned)((cc & (RS - 1)) * SLOT + wave * 1024);
-      const unsigned vo = first ? voff0 : voff1;
-      glds16_s((first ? sg.a0_hi : sg.a1_hi) + (first ? cb : cb - c0), vo, dst);
-      glds16_s((first ? sg.a0_lo : sg.a1_lo) + (first ? cb : cb - c0), vo, dst + SLOT_PL);
-    } else {
-      glds16_s(p.zero_page, (unsigned)lane * 16u, a_base + S_SINK);
-      glds16_s(p.zero_page, (unsigned)lane * 16u, a_base + S_SINK);
-    }
-  };
+    // chunks 0 and 1 (both of the three-tap segment: NCH >= 2): wave w brings rows 8w .. 8w + 7, both planes
+    const int d_row = wave * 8 + (lane >> 3);
+    const unsigned d_sc = (unsigned)(((lane & 7) ^ swz(d_row)) << 4);
 #pragma unroll
-  for (int cc = 0; cc < RS - 1; ++cc) issue_chunk(cc);
-  // weights of this wave: fragment nf = n0 / 32 + cf; unit (chunk c, tap t) = k-step t KPT + 4 c + kq of the packed order
-  const bf16_t* const wh = p.wf_hi + ((size_t)((n0 >> 5) + cf) * (3 * KPT) + kq) * 512;
-  const bf16_t* const wl = p.wf_lo + ((size_t)((n0 >> 5) + cf) * (3 * KPT) + kq) * 512;
-  auto load_unit = [&](int c, int t) {
-    const size_t e = (size_t)(t * KPT + 4 * min(c, NCH - 1)) * 512 + (size_t)lane * 8;
+    for (int cc = 0; cc < 2; ++cc) {
+      const int cb = cc * 64;
+      const bool f0 = cb < c0;
+      const unsigned vo = (unsigned)((size_t)(m0 + d_row) * (f0 ? c0 : c1) * 2) + d_sc;
+      const unsigned dst = a_base + (unsigned)(cc * SLOT + wave * 1024);
+      glds16_s((f0 ? sg.a0_hi : sg.a1_hi) + (f0 ? cb : cb - c0), vo, dst);
+      glds16_s((f0 ? sg.a0_lo : sg.a1_lo) + (f0 ? cb : cb - c0), vo, dst + SLOT_PL);
+    }
+  }
+  // weights of this wave: fragment nf = n0 / 32 + cf of the packed [N][3 C_in | one-tap channels] rows, k-steps of quarter kq.
+  // Unit list: (chunk c, tap t) = k-step t KPT + 4 c + kq for the three-tap chunks (three per chunk), then k-step 3 KPT + 4 j + kq
+  // for one-tap chunk j (one per chunk).
+  const int KSW = 3 * KPT + 4 * NC2;                 // k-steps per weight row
+  const bf16_t* const wh = p.wf_hi + ((size_t)((n0 >> 5) + cf) * KSW + kq) * 512 + (size_t)lane * 8;
+  const bf16_t* const wl = p.wf_lo + ((size_t)((n0 >> 5) + cf) * KSW + kq) * 512 + (size_t)lane * 8;
+  auto load_ks = [&](int ks) {
     BFrag f;
-    f.h = *reinterpret_cast<const bf16x8*>(wh + e);
-    f.l = *reinterpret_cast<const bf16x8*>(wl + e);
+    f.h = *reinterpret_cast<const bf16x8*>(wh + (size_t)ks * 512);
+    f.l = *reinterpret_cast<const bf16x8*>(wl + (size_t)ks * 512);
     return f;
+  };
+  // unit (c, t) of the three-tap list, continued into the one-tap list behind its end (past the very end: the last unit again -
+  // every refill is unconditional, hipcc's wait counts stay exact)
+  auto unit_ks = [&](int c, int t) {
+    if (c < NCH) return t * KPT + 4 * c;
+    const int j = 3 * (c - NCH) + t;
+    return NC2 > 0 ? 3 * KPT + 4 * min(j, NC2 - 1) : 2 * KPT + 4 * (NCH - 1);
   };
   BFrag bq[DWS];
 #pragma unroll
-  for (int j = 0; j < DWS; ++j) bq[j] = load_unit(j / 3, j % 3);
+  for (int j = 0; j < DWS; ++j) bq[j] = load_ks(unit_ks(j / 3, j % 3));
   __builtin_amdgcn_sched_barrier(0);
   DV_C3TRACE(1);
 
@@ -441,8 +511,7 @@ __global__ __launch_bounds__(NT) void k_conv3s(const GemmParams p) {
   for (int rf = 0; rf < 2; ++rf)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[rf][r] = 0.f;
-
-  // operand fragments (both row fragments, both planes) of tap t of chunk c
+  // operand fragments (both row fragments, both planes) of tap t of three-tap chunk c / of one-tap chunk j (list position NCH + j)
   auto read_a = [&](int c, int t, bf16x8 (&h)[2], bf16x8 (&l)[2]) __attribute__((always_inline)) {
     const int s_slot = (c & (RS - 1)) * SLOT, s_halo = c * 256;
 #pragma unroll
@@ -454,43 +523,34 @@ __global__ __launch_bounds__(NT) void k_conv3s(const GemmParams p) {
       l[rf] = *reinterpret_cast<const bf16x8*>(smem + off + SLOT_PL);
     }
   };
-  bf16x8 ahb[2][2], alb[2][2];                       // fragments of unit 3c + t sit in buffer (c + t) & 1
-  wait_vmcnt<24>();                                  // chunk 0 (and everything older): behind its DMAs this wave has issued chunks 1 - 6 and the weights
-  __builtin_amdgcn_s_barrier();
+  auto mma = [&](const BFrag& f, bf16x8 (&ah)[2], bf16x8 (&al)[2]) __attribute__((always_inline)) {
+    acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.h, al[0], acc[0], 0, 0, 0);
+    acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.h, al[1], acc[1], 0, 0, 0);
+    acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.l, ah[0], acc[0], 0, 0, 0);
+    acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.l, ah[1], acc[1], 0, 0, 0);
+    acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.h, ah[0], acc[0], 0, 0, 0);
+    acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.h, ah[1], acc[1], 0, 0, 0);
+  };
+  bf16x8 ahb[2][2], alb[2][2];                       // fragments of the unit at list position i sit in buffer i & 1
+  wait_vmcnt<2 * DWS>();                             // this wave's part of chunks 0 / 1 and of the halo rows (everything older than the weight units)
+  __builtin_amdgcn_s_barrier();                      // barrier 0: chunks 0 and 1, halo rows, bias are in LDS
   DV_C3TRACE(2);
   read_a(0, 0, ahb[0], alb[0]);
-  // Iteration c: its barrier makes chunk c + 1 visible (every wave has waited for ITS part: the constants below) and says that
-  // every wave is done with chunk c - 1, whose slot the DMAs of chunk c + RS - 1 then overwrite.  The fragments of a unit are read
-  // one unit ahead - those of chunk c + 1's first tap under chunk c's last MFMAs - so no wave arrives behind a barrier with
-  // nothing to multiply.  [First version: barrier c made chunk c visible and the reads started behind it - both waves of every
-  // SIMD waited out the LDS latency at once, 1950 cycles per chunk against 1152 of MFMA: profiles/r05_conv3_phase_trace_*.txt]
+
+  // ---- three-tap chunks: step c = chunk c ----
   auto chunk = [&](const int c, auto par_tag) __attribute__((always_inline)) {
     constexpr int PAR = decltype(par_tag)::value;    // c & 1: units 3c .. 3c + 2 sit in bq[3 PAR ..]
-    if (c >= RS - 2) wait_vmcnt<XS - 8>();           // chunk c + 1 has landed - this wave's part
-    else if (c == 0) wait_vmcnt<22>();
-    else if (c == 1) wait_vmcnt<28>();
-    else if (c == 2) wait_vmcnt<34>();
-    else if (c == 3) wait_vmcnt<40>();
-    else if (c == 4) wait_vmcnt<46>();
-    else wait_vmcnt<52>();
-    __builtin_amdgcn_s_barrier();
-    if (!(DV_C3_EXP & 1)) issue_chunk(c + RS - 1);   // into the slot chunk c - 1 was read from
+    if (c > 0) __builtin_amdgcn_s_barrier();         // barrier c
 #pragma unroll
     for (int t = 0; t < 3; ++t) {
       const int cur = (PAR + t) & 1;
       if (t + 1 < 3) read_a(c, t + 1, ahb[cur ^ 1], alb[cur ^ 1]);
-      else read_a(c + 1, 0, ahb[cur ^ 1], alb[cur ^ 1]);            // (behind the last chunk: a slot nobody waits for - never multiplied)
-      bf16x8 (&ah)[2] = ahb[cur];
-      bf16x8 (&al)[2] = alb[cur];
-      const BFrag f = bq[3 * PAR + t];
-      acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.h, al[0], acc[0], 0, 0, 0);
-      acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.h, al[1], acc[1], 0, 0, 0);
-      acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.l, ah[0], acc[0], 0, 0, 0);
-      acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.l, ah[1], acc[1], 0, 0, 0);
-      acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.h, ah[0], acc[0], 0, 0, 0);
-      acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.h, ah[1], acc[1], 0, 0, 0);
+      else if (c + 1 < NCH) read_a(c + 1, 0, ahb[cur ^ 1], alb[cur ^ 1]);
+      else read_a(c + 1, 1, ahb[cur ^ 1], alb[cur ^ 1]);           // the first one-tap chunk: list position NCH, centre tap (none: a slot nobody multiplies)
+      mma(bq[3 * PAR + t], ahb[cur], alb[cur]);
+      // pinned: without the scheduling barriers hipcc sinks every prefetch down to its use (load -> vmcnt(0) -> MFMA)
       __builtin_amdgcn_sched_barrier(0);
-      if (!(DV_C3_EXP & 2)) bq[3 * PAR + t] = load_unit(c + 2, t);   // (unconditional: past the end the last chunk's unit again - the counts stay constant)
+      if (!(DV_C3_EXP & 2)) bq[3 * PAR + t] = load_ks(unit_ks(c + 2, t));
       __builtin_amdgcn_sched_barrier(0);
     }
   };
@@ -498,8 +558,29 @@ __global__ __launch_bounds__(NT) void k_conv3s(const GemmParams p) {
     chunk(c, std::integral_constant<int, 0>{});
     chunk(c + 1, std::integral_constant<int, 1>{});
   }
+  // ---- one-tap chunks: step = chunks 2 j2, 2 j2 + 1 (list positions NCH + ...: even NCH keeps the buffer / weight-ring parities) ----
+  // (unit j sits in bq[j % 6]: three steps per round of the ring)
+  auto pair = [&](const int j2, auto pos_tag) __attribute__((always_inline)) {
+    constexpr int POS = decltype(pos_tag)::value;    // j2 % 3
+    __builtin_amdgcn_s_barrier();                    // barrier NCH + j2
+    const int j = 2 * j2;
+    read_a(NCH + j + 1, 1, ahb[1], alb[1]);
+    mma(bq[2 * POS], ahb[0], alb[0]);
+    __builtin_amdgcn_sched_barrier(0);
+    if (!(DV_C3_EXP & 2)) bq[2 * POS] = load_ks(3 * KPT + 4 * min(j + 6, NC2 - 1));
+    __builtin_amdgcn_sched_barrier(0);
+    read_a(NCH + j + 2, 1, ahb[0], alb[0]);          // the next step's first chunk (behind the last: a slot nobody multiplies)
+    if (j + 1 < NC2) mma(bq[2 * POS + 1], ahb[1], alb[1]);
+    __builtin_amdgcn_sched_barrier(0);
+    if (!(DV_C3_EXP & 2)) bq[2 * POS + 1] = load_ks(3 * KPT + 4 * min(j + 7, NC2 - 1));
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  for (int j2 = 0; j2 < NS2; j2 += 3) {
+    pair(j2, std::integral_constant<int, 0>{});
+    if (j2 + 1 < NS2) pair(j2 + 1, std::integral_constant<int, 1>{});
+    if (j2 + 2 < NS2) pair(j2 + 2, std::integral_constant<int, 2>{});
+  }
   DV_C3TRACE(3);
-  wait_vmcnt<0>();                                   // (the sink's DMAs: nothing may still be writing LDS when it becomes the exchange buffer)
   conv3_finish(p, smem, s_bias, s_gnx, acc, rpre, m0, n0, tid, lane, wave, CIN);
 }
 
@@ -517,15 +598,23 @@ static const bool g_conv3_env_once = [] { conv3_env_refresh(); return true; }();
 // 64 x 64 tiles that never span two utterances, the plain / residual epilogue without LayerNorm, column-slab statistics, ReLU or
 // row mask.
 bool gemm_conv3_shape_ok(const GemmParams& p) {
-  if (!g_conv3_on || p.nseg != 1 || p.seg[0].taps != 3 || p.seg[0].pad != 1 || p.stride != 1 || p.up_mode != UP_NONE) return false;
+  if (!g_conv3_on || p.nseg < 1 || p.nseg > 2 || p.seg[0].taps != 3 || p.seg[0].pad != 1 || p.stride != 1 || p.up_mode != UP_NONE) return false;
   const int cin = p.seg[0].c0 + p.seg[0].c1;
   if (cin < 128 || cin > 1024 || cin % 128 != 0) return false;
   if (p.seg[0].c0 % 64 != 0 || p.seg[0].c1 % 64 != 0 || (p.seg[0].c1 > 0 && !p.seg[0].a1_hi)) return false;
+  if (p.nseg == 2) {   // the folded 1x1 shortcut: one tap over the block's raw input (one tensor or two), any multiple of 64 channels
+    const GemmSeg& s1 = p.seg[1];
+    if (s1.taps != 1 || s1.pad != 0 || s1.c0 <= 0 || s1.c0 % 64 != 0 || s1.c1 % 64 != 0 || (s1.c1 > 0 && !s1.a1_hi) || s1.c0 + s1.c1 > 2048) return false;
+  }
   if (p.T_in != p.T_out || p.T_virt != p.T_out || (p.Tv_out > 0 && p.Tv_out != p.T_out) || (p.Tv_in > 0 && p.Tv_in != p.T_in)) return false;
   if (p.T_out % BM != 0 || p.M % BM != 0 || p.N % BN != 0 || p.B <= 0 || p.M != p.B * p.T_out) return false;
   if ((p.epi != EPI_STORE && p.epi != EPI_RESIDUAL) || p.stats || p.rowstat_out || p.ln_stat || p.relu || p.rowmask) return false;
   if ((p.ldo & 7) != 0 || (p.epi == EPI_RESIDUAL && (p.ldres & 3) != 0) || p.force_tile != GT_AUTO) return false;
   return true;
+}
+// packed K (weight row length) such a launch expects: 3 C_in (+ the one-tap segment's channels)
+int gemm_conv3_k(const GemmParams& p) {
+  return 3 * (p.seg[0].c0 + p.seg[0].c1) + (p.nseg > 1 ? p.seg[1].c0 + p.seg[1].c1 : 0);
 }
 
 template <int CIN>
@@ -548,10 +637,10 @@ hipError_t conv3_init() {
 }
 // (called by launch_gemm with p validated, tout_magic and the XCD rectangle of the 64x64 tile grid set)
 hipError_t launch_conv3(const GemmParams& p, hipStream_t st) {
-  if (!p.wf_hi || !p.wf_lo || !gemm_conv3_shape_ok(p) || p.Kp != 3 * (p.seg[0].c0 + p.seg[0].c1) || p.sk_mode != 0) return hipErrorInvalidValue;
+  if (!p.wf_hi || !p.wf_lo || !gemm_conv3_shape_ok(p) || p.Kp != gemm_conv3_k(p) || p.sk_mode != 0) return hipErrorInvalidValue;
   const int cin = p.seg[0].c0 + p.seg[0].c1;
-  if (cin > 512 || cin > g_conv3_stream) {
-    hipLaunchKernelGGL(k_conv3s, dim3((p.M / BM) * (p.N / BN)), dim3(NT), S_TOTAL, st, p);
+  if (cin > 512 || cin > g_conv3_stream || p.nseg > 1) {
+    hipLaunchKernelGGL(k_conv3s, dim3((p.M / BM) * (p.N / BN)), dim3(NT_S), S_TOTAL, st, p);
     return hipGetLastError();
   }
   switch (cin) {
