@@ -303,6 +303,7 @@ hipError_t gemm_init();   // one-time kernel attribute setup (call outside strea
 // k_conv3 (kernels_conv.hip): the resident-operand kernel of the stride-1 three-tap convolutions; launch_gemm dispatches to it
 bool gemm_conv3_shape_ok(const GemmParams& p);   // shape / epilogue test only (weights and precision are the caller's)
 int gemm_conv3_k(const GemmParams& p);           // the packed K such a launch expects
+int gemm_conv3_split(const GemmParams& p, int n_cu);   // 2: run it as a fused split-K pair (sk_buf / sk_ticket needed), 0: one workgroup per tile
 hipError_t conv3_init();
 void conv3_env_refresh();                        // DVITS_CONV3=0: off
 hipError_t launch_conv3(const GemmParams& p, hipStream_t st);

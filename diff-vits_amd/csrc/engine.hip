@@ -607,7 +607,7 @@ struct Builder {
     t.gnx.sk_c = skip ? skip->C : 0;
     int k_pad = 0;
     for (int s2 = 0; s2 < t.nseg; ++s2) k_pad += t.seg[s2].taps * (t.seg[s2].c0 + t.seg[s2].c1);
-    t.sk_split = conv3_takes(t) ? 0 : gemm_splitk_plan(t.M, t.N, k_pad, t.epi);
+    t.sk_split = conv3_takes(t) ? gemm_conv3_split(t, n_cu) : gemm_splitk_plan(t.M, t.N, k_pad, t.epi);
     if (t.sk_split >= 2) {
       if (!sk_fused || ((t.M + 31) / 32) * ((t.N + 31) / 32) > 4096) return false;   // (two launches: see gemm())
       t.sk_buf = reinterpret_cast<float*>(0x1000); t.sk_ticket = reinterpret_cast<unsigned*>(0x1000);
@@ -759,7 +759,7 @@ struct Builder {
     // long K on few tiles: offer scratch for a two-launch split-K (kernels_gemm.hip decides with the same predicate)
     int k_pad = 0;
     for (int s2 = 0; s2 < g.nseg; ++s2) k_pad += g.seg[s2].taps * (g.seg[s2].c0 + g.seg[s2].c1);
-    g.sk_split = (arena.exact || c3) ? 0 : gemm_splitk_plan(g.M, g.N, k_pad, g.epi);
+    g.sk_split = arena.exact ? 0 : (c3 ? gemm_conv3_split(g, n_cu) : gemm_splitk_plan(g.M, g.N, k_pad, g.epi));
     // with the tuner on, scratch is also offered to GEMMs the heuristic would not split (the tuner times both ways)
     const bool offer = !arena.exact && autotune_on() && gemm_splitk_plan(64, 64, 1 << 20, EPI_STORE) != 0 && k_pad >= 768 && (g.epi == EPI_STORE || g.epi == EPI_RESIDUAL) &&
                        ((g.M + 63) / 64) * ((g.N + 63) / 64) <= 256;

@@ -71,17 +71,24 @@ struct ConvGeom {
 }  // namespace
 
 // tile of this workgroup: k_gemm's XCD-aware order (workgroup b runs on XCD b % 8)
-__device__ __forceinline__ void conv3_tile(const GemmParams& p, int& m0, int& n0) {
+// (ksel: the k-half of a fused split-K pair - GemmParams sk_mode 3 - else 0)
+__device__ __forceinline__ void conv3_tile(const GemmParams& p, int& m0, int& n0, int& ksel) {
   const int n_tiles_n = p.N / BN, nwg = gridDim.x;
   int bid = blockIdx.x;
+  ksel = 0;
   if (p.xcd_n > 0) {
     const int x = bid & 7, i = bid >> 3;
     const int r = x & ((1 << p.xcd_sh_mn) - 1), xm_i = r >> p.xcd_sh_n, xn_i = r & (p.xcd_n - 1);
     const int lm = (i * p.xcd_inv_tn) >> 16, ln = i - lm * p.xcd_tn;
-    m0 = (xm_i * p.xcd_tm + lm) * BM; n0 = (xn_i * p.xcd_tn + ln) * BN;
+    m0 = (xm_i * p.xcd_tm + lm) * BM; n0 = (xn_i * p.xcd_tn + ln) * BN; ksel = x >> p.xcd_sh_mn;
   } else {
     const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
     bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    if (p.sk_mode == 3) {                            // XCD-contiguous ids share a k-half
+      const int tiles = nwg >> 1;
+      ksel = bid / tiles;
+      bid -= ksel * tiles;
+    }
     m0 = (bid / n_tiles_n) * BM; n0 = (bid % n_tiles_n) * BN;
   }
 }
@@ -91,7 +98,7 @@ __device__ __forceinline__ void conv3_tile(const GemmParams& p, int& m0, int& n0
 // here - and every wave finishes a 32-row x 16-column half fragment: the steps of gemm_tile.h's half-fragment epilogue.
 __device__ __forceinline__ void conv3_finish(const GemmParams& p, char* smem, const float* s_bias, GnxShared<BN>& s_gnx, f32x16 (&acc)[2],
                                              const float (&rpre)[8], const int m0, const int n0, const int tid, const int lane, const int wave,
-                                             const int CIN) {
+                                             const int CIN, const int ksel) {
   (void)CIN;                                         // (trace builds select launches by it)
   const int l31 = lane & 31, lh = lane >> 5;
   const int cf = wave & 1, kq = wave >> 1;
@@ -117,6 +124,27 @@ __device__ __forceinline__ void conv3_finish(const GemmParams& p, char* smem, co
     vv[4 * g] = s.x; vv[4 * g + 1] = s.y; vv[4 * g + 2] = s.z; vv[4 * g + 3] = s.w;
   }
   DV_C3TRACE(4);
+  if (p.sk_mode == 3) {
+    // fused split-K pair (the protocol of gemm_tile.h's sk_mode 3): this workgroup multiplied one half of the chunks.  It writes
+    // its half-fragment sums through and takes a ticket; the first of the pair to arrive leaves, the second adds the partner's
+    // sums (a + b = b + a: the same bits whoever finishes) and runs the epilogue.  Nobody waits for anybody.
+    const int tile = (m0 / BM) * (p.N / BN) + n0 / BN, tiles = (p.M / BM) * (p.N / BN);
+    float4* const d0 = reinterpret_cast<float4*>(p.sk_buf) + ((size_t)(ksel * tiles + tile) * NWV + wave) * 128 + lane;
+    st_handover16(d0, make_float4(vv[0], vv[1], vv[2], vv[3]));
+    st_handover16(d0 + 64, make_float4(vv[4], vv[5], vv[6], vv[7]));
+    wait_vmcnt<0>();                                 // this thread's sums have been written through
+    __shared__ unsigned s_arrival;
+    __syncthreads();
+    unsigned* const ticket = p.sk_ticket + tile;
+    if (tid == 0) s_arrival = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    if (s_arrival == 0) return;                      // the partner finishes this tile
+    if (tid == 0) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
+    const float4* const s0 = reinterpret_cast<const float4*>(p.sk_buf) + ((size_t)((ksel ^ 1) * tiles + tile) * NWV + wave) * 128 + lane;
+    const float4 v0 = ld_handover16(s0), v1 = ld_handover16(s0 + 64);
+    vv[0] += v0.x; vv[1] += v0.y; vv[2] += v0.z; vv[3] += v0.w;
+    vv[4] += v1.x; vv[5] += v1.y; vv[6] += v1.z; vv[7] += v1.w;
+  }
 
   // ---- epilogue of the half fragment (the steps of gemm_tile.h's half-fragment epilogue) ----
   const bool gnx_h = p.gnx.xchg != nullptr;
@@ -194,8 +222,8 @@ __global__ __launch_bounds__(NT) void k_conv3(const GemmParams p) {
   asm volatile("" ::"s"(p.seg[0].a0_hi), "s"(p.seg[1].a0_hi), "s"(p.seg[1].pad), "s"(p.T_in), "s"(p.w_hi), "s"(p.M), "s"(p.res),
                "s"(p.out_hi), "s"(p.zero_page), "s"(p.ln_u), "s"(p.gnx.xchg), "s"(p.gnx.y_hi), "s"(p.xcd_n), "s"(p.xcd_inv_tn), "s"(p.wf_lo));
   DV_C3TRACE(0);
-  int m0, n0;
-  conv3_tile(p, m0, n0);
+  int m0, n0, ksel;
+  conv3_tile(p, m0, n0, ksel);
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l31 = lane & 31, lh = lane >> 5;
   const int cf = wave & 1, kq = wave >> 1;           // k-loop role: column fragment, k-quarter
@@ -317,7 +345,7 @@ __global__ __launch_bounds__(NT) void k_conv3(const GemmParams p) {
   else run(std::integral_constant<int, 3>{});
   DV_C3TRACE(3);
 
-  conv3_finish(p, smem, s_bias, s_gnx, acc, rpre, m0, n0, tid, lane, wave, CIN);
+  conv3_finish(p, smem, s_bias, s_gnx, acc, rpre, m0, n0, tid, lane, wave, CIN, 0);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -367,13 +395,19 @@ __global__ __launch_bounds__(NT_S) void k_conv3s(const GemmParams p) {
   const int c0 = sg.c0, c1 = sg.c1, CIN = c0 + c1;
   const int d0 = p.nseg > 1 ? sh.c0 : 0, d1 = p.nseg > 1 ? sh.c1 : 0;   // the one-tap segment's channels (0: none)
   DV_C3TRACE(0);
-  int m0, n0;
-  conv3_tile(p, m0, n0);
+  int m0, n0, ksel;
+  conv3_tile(p, m0, n0, ksel);
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const unsigned a_base = (unsigned)(size_t)smem;
-  const int NCH = CIN >> 6, KPT = CIN >> 4;          // three-tap chunks (even); 16-deep k-steps per tap
-  const int NC2 = (d0 + d1) >> 6;                    // one-tap chunks
-  const int NS2 = (NC2 + 1) >> 1;                    // ... steps (two chunks each; the last may hold one)
+  const int NCH_ALL = CIN >> 6, KPT = CIN >> 4;      // three-tap chunks of the whole contraction (even); 16-deep k-steps per tap
+  const int NC2_ALL = (d0 + d1) >> 6;                // one-tap chunks
+  // this workgroup's chunks: all of them, or - fused split-K pair - one half of either list (three-tap halves stay even: the
+  // parities of the weight ring and of the fragment buffers below rely on it)
+  const bool half = p.sk_mode == 3;
+  const int h1 = half ? (((NCH_ALL >> 1) + 1) & ~1) : NCH_ALL, h2 = half ? ((NC2_ALL + 1) >> 1) : NC2_ALL;
+  const int CA = ksel ? h1 : 0, NCH = ksel ? NCH_ALL - h1 : h1;      // three-tap chunks CA .. CA + NCH - 1 (list positions 0 .. NCH - 1)
+  const int JA = ksel ? h2 : 0, NC2 = ksel ? NC2_ALL - h2 : h2;      // one-tap chunks JA .. JA + NC2 - 1 (list positions NCH ..)
+  const int NS2 = (NC2 + 1) >> 1;                    // one-tap steps (two chunks each; the last may hold one)
   const int NCT = NCH + NC2, NSTEP = NCH + NS2;
 
   if (wave == NWV) {
@@ -385,7 +419,7 @@ __global__ __launch_bounds__(NT_S) void k_conv3s(const GemmParams p) {
     auto issue_chunk = [&](int cc) {
       // chunk cc of the list [three-tap segment's chunks | one-tap segment's chunks] -> slot cc % RS
       const bool seg0 = cc < NCH;
-      const int cb = (seg0 ? cc : cc - NCH) * 64;
+      const int cb = (seg0 ? CA + cc : JA + cc - NCH) * 64;
       const int e0 = seg0 ? c0 : d0;
       const bool first = cb < e0;
       const int ld = first ? e0 : (seg0 ? c1 : d1);
@@ -449,7 +483,7 @@ __global__ __launch_bounds__(NT_S) void k_conv3s(const GemmParams p) {
     // beyond the utterance's ends and chunks beyond the last come from the zero page
     const int t0 = m0 - (int)__umulhi((unsigned)m0, p.tout_magic) * p.T_out;   // frame of the tile's first row inside its utterance
     const int pl = wave & 1, c = (wave >> 1) * 4 + (lane >> 4), which = (lane >> 3) & 1, slot = lane & 7;
-    const bool ok = c < NCH && (which == 0 ? (t0 + BM < p.T_out) : (t0 > 0));
+    const bool ok = c < NCH_ALL && (which == 0 ? (t0 + BM < p.T_out) : (t0 > 0));
     const long srow = which == 0 ? (long)m0 + BM : (long)m0 - 1;
     const int ch = c * 64 + slot * 8;
     const bool first = ch < c0;
@@ -461,7 +495,7 @@ __global__ __launch_bounds__(NT_S) void k_conv3s(const GemmParams p) {
     const unsigned d_sc = (unsigned)(((lane & 7) ^ swz(d_row)) << 4);
 #pragma unroll
     for (int cc = 0; cc < 2; ++cc) {
-      const int cb = cc * 64;
+      const int cb = (CA + cc) * 64;
       const bool f0 = cb < c0;
       const unsigned vo = (unsigned)((size_t)(m0 + d_row) * (f0 ? c0 : c1) * 2) + d_sc;
       const unsigned dst = a_base + (unsigned)(cc * SLOT + wave * 1024);
@@ -472,7 +506,7 @@ __global__ __launch_bounds__(NT_S) void k_conv3s(const GemmParams p) {
   // weights of this wave: fragment nf = n0 / 32 + cf of the packed [N][3 C_in | one-tap channels] rows, k-steps of quarter kq.
   // Unit list: (chunk c, tap t) = k-step t KPT + 4 c + kq for the three-tap chunks (three per chunk), then k-step 3 KPT + 4 j + kq
   // for one-tap chunk j (one per chunk).
-  const int KSW = 3 * KPT + 4 * NC2;                 // k-steps per weight row
+  const int KSW = 3 * KPT + 4 * NC2_ALL;             // k-steps per weight row
   const bf16_t* const wh = p.wf_hi + ((size_t)((n0 >> 5) + cf) * KSW + kq) * 512 + (size_t)lane * 8;
   const bf16_t* const wl = p.wf_lo + ((size_t)((n0 >> 5) + cf) * KSW + kq) * 512 + (size_t)lane * 8;
   auto load_ks = [&](int ks) {
@@ -484,9 +518,9 @@ __global__ __launch_bounds__(NT_S) void k_conv3s(const GemmParams p) {
   // unit (c, t) of the three-tap list, continued into the one-tap list behind its end (past the very end: the last unit again -
   // every refill is unconditional, hipcc's wait counts stay exact)
   auto unit_ks = [&](int c, int t) {
-    if (c < NCH) return t * KPT + 4 * c;
+    if (c < NCH) return t * KPT + 4 * (CA + c);
     const int j = 3 * (c - NCH) + t;
-    return NC2 > 0 ? 3 * KPT + 4 * min(j, NC2 - 1) : 2 * KPT + 4 * (NCH - 1);
+    return NC2 > 0 ? 3 * KPT + 4 * (JA + min(j, NC2 - 1)) : 2 * KPT + 4 * (CA + NCH - 1);
   };
   BFrag bq[DWS];
 #pragma unroll
@@ -513,7 +547,7 @@ __global__ __launch_bounds__(NT_S) void k_conv3s(const GemmParams p) {
     for (int r = 0; r < 16; ++r) acc[rf][r] = 0.f;
   // operand fragments (both row fragments, both planes) of tap t of three-tap chunk c / of one-tap chunk j (list position NCH + j)
   auto read_a = [&](int c, int t, bf16x8 (&h)[2], bf16x8 (&l)[2]) __attribute__((always_inline)) {
-    const int s_slot = (c & (RS - 1)) * SLOT, s_halo = c * 256;
+    const int s_slot = (c & (RS - 1)) * SLOT, s_halo = (CA + c) * 256;   // (c: list position)
 #pragma unroll
     for (int rf = 0; rf < 2; ++rf) {
       // (only (rf 0, tap 0) and (rf 1, tap 2) have a halo lane pair: the select folds away elsewhere)
@@ -567,12 +601,12 @@ __global__ __launch_bounds__(NT_S) void k_conv3s(const GemmParams p) {
     read_a(NCH + j + 1, 1, ahb[1], alb[1]);
     mma(bq[2 * POS], ahb[0], alb[0]);
     __builtin_amdgcn_sched_barrier(0);
-    if (!(DV_C3_EXP & 2)) bq[2 * POS] = load_ks(3 * KPT + 4 * min(j + 6, NC2 - 1));
+    if (!(DV_C3_EXP & 2)) bq[2 * POS] = load_ks(3 * KPT + 4 * (JA + min(j + 6, NC2 - 1)));
     __builtin_amdgcn_sched_barrier(0);
     read_a(NCH + j + 2, 1, ahb[0], alb[0]);          // the next step's first chunk (behind the last: a slot nobody multiplies)
     if (j + 1 < NC2) mma(bq[2 * POS + 1], ahb[1], alb[1]);
     __builtin_amdgcn_sched_barrier(0);
-    if (!(DV_C3_EXP & 2)) bq[2 * POS + 1] = load_ks(3 * KPT + 4 * min(j + 7, NC2 - 1));
+    if (!(DV_C3_EXP & 2)) bq[2 * POS + 1] = load_ks(3 * KPT + 4 * (JA + min(j + 7, NC2 - 1)));
     __builtin_amdgcn_sched_barrier(0);
   };
   for (int j2 = 0; j2 < NS2; j2 += 3) {
@@ -581,7 +615,7 @@ __global__ __launch_bounds__(NT_S) void k_conv3s(const GemmParams p) {
     if (j2 + 2 < NS2) pair(j2 + 2, std::integral_constant<int, 2>{});
   }
   DV_C3TRACE(3);
-  conv3_finish(p, smem, s_bias, s_gnx, acc, rpre, m0, n0, tid, lane, wave, CIN);
+  conv3_finish(p, smem, s_bias, s_gnx, acc, rpre, m0, n0, tid, lane, wave, CIN, ksel);
 }
 
 // ---- host side ----
@@ -612,6 +646,17 @@ bool gemm_conv3_shape_ok(const GemmParams& p) {
   if ((p.ldo & 7) != 0 || (p.epi == EPI_RESIDUAL && (p.ldres & 3) != 0) || p.force_tile != GT_AUTO) return false;
   return true;
 }
+// Fused split-K pair on the streaming kernel (GemmParams sk_buf / sk_ticket, sk_split 2): 2 when the launch should run as two
+// workgroups per tile - at most half the CUs' worth of tiles and a k-loop of at least eight steps (the 128-frame level's
+// K >= 1920 convolutions: 128 tiles) - else 0.  The three-tap list must split into two even halves.
+int gemm_conv3_split(const GemmParams& p, int n_cu) {
+  static const bool on = [] { const char* e = getenv("DVITS_CONV3_SPLIT"); return !(e && e[0] == '0'); }();
+  if (!on || n_cu <= 0 || !gemm_conv3_shape_ok(p)) return 0;
+  const int cin = p.seg[0].c0 + p.seg[0].c1, nch = cin >> 6, nc2 = p.nseg > 1 ? (p.seg[1].c0 + p.seg[1].c1) >> 6 : 0;
+  if (cin <= 512 && cin <= g_conv3_stream && p.nseg == 1) return 0;       // (the resident kernel has no split form)
+  if (2 * (p.M / BM) * (p.N / BN) > n_cu || nch < 4 || nch + ((nc2 + 1) >> 1) < 8) return 0;
+  return 2;
+}
 // packed K (weight row length) such a launch expects: 3 C_in (+ the one-tap segment's channels)
 int gemm_conv3_k(const GemmParams& p) {
   return 3 * (p.seg[0].c0 + p.seg[0].c1) + (p.nseg > 1 ? p.seg[1].c0 + p.seg[1].c1 : 0);
@@ -637,7 +682,12 @@ hipError_t conv3_init() {
 }
 // (called by launch_gemm with p validated, tout_magic and the XCD rectangle of the 64x64 tile grid set)
 hipError_t launch_conv3(const GemmParams& p, hipStream_t st) {
-  if (!p.wf_hi || !p.wf_lo || !gemm_conv3_shape_ok(p) || p.Kp != gemm_conv3_k(p) || p.sk_mode != 0) return hipErrorInvalidValue;
+  if (!p.wf_hi || !p.wf_lo || !gemm_conv3_shape_ok(p) || p.Kp != gemm_conv3_k(p) || (p.sk_mode != 0 && p.sk_mode != 3)) return hipErrorInvalidValue;
+  if (p.sk_mode == 3) {
+    if (!p.sk_buf || !p.sk_ticket || p.sk_split != 2 || p.seg[0].c0 + p.seg[0].c1 < 256) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_conv3s, dim3(2 * (p.M / BM) * (p.N / BN)), dim3(NT_S), S_TOTAL, st, p);
+    return hipGetLastError();
+  }
   const int cin = p.seg[0].c0 + p.seg[0].c1;
   if (cin > 512 || cin > g_conv3_stream || p.nseg > 1) {
     hipLaunchKernelGGL(k_conv3s, dim3((p.M / BM) * (p.N / BN)), dim3(NT_S), S_TOTAL, st, p);

@@ -348,7 +348,7 @@ hipError_t launch_gemm(const GemmParams& pin, int precision, hipStream_t st) {
   }
   // stride-1 three-tap convolutions whose input channels fit the LDS: the resident-operand kernel (kernels_conv.hip), on the tile
   // grid / XCD rectangle / exchange-word layout of the 64x64 tile the heuristic would have picked
-  if (x3 && p.wf_hi && p.wf_lo && p.sk_mode == 0 && gemm_conv3_shape_ok(p) && p.Kp == gemm_conv3_k(p)) {
+  if (x3 && p.wf_hi && p.wf_lo && (p.sk_mode == 0 || p.sk_mode == 3) && gemm_conv3_shape_ok(p) && p.Kp == gemm_conv3_k(p)) {
     int bm, bn;
     gemm_pick_tile(p, bm, bn);
     if (bm == 64 && bn == 64) return launch_conv3(p, st);
