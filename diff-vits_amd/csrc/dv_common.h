@@ -307,6 +307,8 @@ int gemm_conv3_split(const GemmParams& p, int n_cu);   // 2: run it as a fused s
 hipError_t conv3_init();
 void conv3_env_refresh();                        // DVITS_CONV3=0: off
 hipError_t launch_conv3(const GemmParams& p, hipStream_t st);
+bool gemm_conv3_up_ok(const GemmParams& p);      // the nearest-x2 upsampling convolutions (k_conv3u: 128-row tiles)
+hipError_t launch_conv3_up(const GemmParams& p, hipStream_t st);
 void gemm_env_refresh();  // re-read launch_gemm's environment knobs (called by every prepare)
 hipError_t attn_init();
 hipError_t launch_attention(const AttnParams& p, hipStream_t st);

@@ -733,6 +733,10 @@ struct Builder {
     if (arena.exact || autotune_on() || prec != DV_PREC_BF16X3) return false;
     GemmParams t = g;
     t.B = B;
+    if (gemm_conv3_up_ok(t)) {   // the upsampling form: 128 x 64 tiles, all resident when a GroupNorm is finished in the launch
+      const int tu = (t.M / 128) * (t.N / 64);
+      return tu >= 96 && (n_cu <= 0 || tu <= n_cu || !gnx_on);
+    }
     if (!gemm_conv3_shape_ok(t)) return false;
     // (the tile the heuristic picks must be the 64x64 one - launch_gemm checks the same - and with an in-launch GroupNorm its tiles
     // must all be resident: both hold when there are at most 256 of them and fewer than 192 128x64 tiles)
@@ -745,7 +749,7 @@ struct Builder {
     g.B = B;
     g.zero_page = u->zero_page;
     const int p = prec;
-    const bool c3 = conv3_takes(g) && g.Kp == gemm_conv3_k(g) && frag(pw);
+    const bool c3 = conv3_takes(g) && g.Kp == gemm_conv3_k(g) && frag(pw);   // (the upsampling form has one segment too: the same K)
     if (c3) { g.wf_hi = dry ? reinterpret_cast<const bf16_t*>(0x1000) : pw->fhi; g.wf_lo = dry ? reinterpret_cast<const bf16_t*>(0x1000) : pw->flo; }
     cur_kind = "gemm"; cur_flops = 2.0 * (double)g.M * (double)g.N * (double)k_real;
     {

@@ -349,6 +349,247 @@ __global__ __launch_bounds__(NT) void k_conv3(const GemmParams p) {
 }
 
 // ---------------------------------------------------------------------------------------
+// Upsample2D (reference resnet.py:138-187: nearest x2, then a 3-tap convolution): the same resident-operand scheme on a tile of
+// 128 OUTPUT rows.  Output frame t reads source frames (t + tap - 1) >> 1, so 128 output rows touch 64 + 2 source rows - the LDS
+// image of k_conv3 exactly - and every weight fragment a wave loads is multiplied with FOUR row fragments: the k-loop needs
+// 21 B/clk of weights per CU and runs at the MFMA rate.  8 waves = 2 column fragments x 4 k-quarters as above; after the exchange
+// every wave finishes one whole 32 x 32 fragment (the steps of gemm_tile.h's full-fragment epilogue).  These were the two most
+// expensive launches of the forward on k_gemm (128 x 64 tiles whose row gather reads every source row twice).
+// ---------------------------------------------------------------------------------------
+namespace {
+constexpr int BMU = 128, RFU = 4;
+template <int CIN>
+struct ConvGeomU {
+  static constexpr int NCH = CIN / 64, KPT = CIN / 16, KS = 3 * KPT, U = KS / 4;
+  static constexpr int DEPTH = U < 6 ? U : 6;        // weight units in flight per wave (four row fragments of operands are live too)
+  static constexpr int A_PL = NCH * CHP;
+  static constexpr int RED = 2 * 4 * RFU * 4 * 64 * 16;   // k-quarter exchange: [column fragment][quarter][row fragment][4 column groups][64 lanes] float4
+  static constexpr int SMEM = 2 * A_PL > RED ? 2 * A_PL : RED;
+  static_assert(CIN % 64 == 0 && KS % 4 == 0 && SMEM + 4096 <= 160 * 1024, "geometry");
+};
+}  // namespace
+
+template <int CIN>
+__global__ __launch_bounds__(NT) void k_conv3u(const GemmParams p) {
+  using G = ConvGeomU<CIN>;
+  extern __shared__ __attribute__((aligned(1024))) char smem[];
+  __shared__ __attribute__((aligned(16))) float s_bias[BN];
+  __shared__ GnxShared<BN> s_gnx;
+  asm volatile("" ::"s"(p.seg[0].a0_hi), "s"(p.seg[1].a0_hi), "s"(p.seg[1].pad), "s"(p.T_in), "s"(p.w_hi), "s"(p.M), "s"(p.res),
+               "s"(p.out_hi), "s"(p.zero_page), "s"(p.ln_u), "s"(p.gnx.xchg), "s"(p.gnx.y_hi), "s"(p.xcd_n), "s"(p.xcd_inv_tn), "s"(p.wf_lo));
+  DV_C3TRACE(0);
+  // tile: XCD x takes a band of row tiles (all their column tiles: an L2 fetches its rows of the source once)
+  int m0, n0;
+  {
+    const int n_tiles_n = p.N / BN, nwg = gridDim.x;
+    int bid = blockIdx.x;
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    m0 = (bid / n_tiles_n) * BMU; n0 = (bid % n_tiles_n) * BN;
+  }
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, lh = lane >> 5;
+  const int cf = wave & 1, kq = wave >> 1;           // k-loop role: column fragment, k-quarter; epilogue role: fragment (row kq, column cf)
+  const unsigned a_base = (unsigned)(size_t)smem;
+  const GemmSeg& sg = p.seg[0];
+  const int c0 = sg.c0, c1 = sg.c1;
+  const int t0 = m0 - (int)__umulhi((unsigned)m0, p.tout_magic) * p.T_out;   // output frame of the tile's first row inside its utterance
+  const int ms0 = m0 >> 1;                           // source row of output row m0 (row pitches: T_out = 2 T_in)
+
+  // ---- requests, oldest first: halo rows, bias, the tile's 64 source rows, first weights ----
+  constexpr int HITEMS = CIN / 2;
+  uint4 hv = make_uint4(0u, 0u, 0u, 0u);
+  int h_dst = -1;
+  if (tid < HITEMS) {
+    const int pl = tid / (CIN / 4), rem = tid - pl * (CIN / 4), which = rem / (CIN / 8), piece = rem - which * (CIN / 8);
+    const int ch = piece * 8, c = piece >> 3, slot = piece & 7;
+    const bool ok = which == 0 ? (t0 + BMU < p.T_out) : (t0 > 0);               // which 0: source row ms0 + 64 (LDS row 64), 1: row ms0 - 1 (LDS row 65)
+    const long srow = which == 0 ? (long)ms0 + 64 : (long)ms0 - 1;
+    const bool first = ch < c0;
+    const bf16_t* src = first ? (pl ? sg.a0_lo : sg.a0_hi) : (pl ? sg.a1_lo : sg.a1_hi);
+    if (ok) hv = *reinterpret_cast<const uint4*>(src + (size_t)srow * (first ? c0 : c1) + (first ? ch : ch - c0));
+    h_dst = pl * G::A_PL + c * CHP + (64 + which) * 128 + ((slot ^ swz(64 + which)) << 4);
+  }
+  if (wave == 0) glds4(p.bias ? (const void*)(p.bias + n0 + lane) : (const void*)p.zero_page, (unsigned)(size_t)s_bias);
+  {
+    const int row = wave * 8 + (lane >> 3), slot = lane & 7;
+    const int sc8 = (slot ^ swz(row)) << 3;
+#pragma unroll
+    for (int c = 0; c < G::NCH; ++c) {
+      const int cb = c * 64;
+      const bool first = cb < c0;
+      const size_t e = (size_t)(ms0 + row) * (first ? c0 : c1) + (first ? cb : cb - c0) + sc8;
+      const unsigned dst = a_base + (unsigned)(c * CHP + wave * 1024);
+      glds16((first ? sg.a0_hi : sg.a1_hi) + e, dst);
+      glds16((first ? sg.a0_lo : sg.a1_lo) + e, dst + G::A_PL);
+    }
+  }
+  const size_t w_e0 = ((size_t)((n0 >> 5) + cf) * G::KS + (size_t)kq * G::U) * 512 + (size_t)lane * 8;
+  const bf16_t* const wh = p.wf_hi + w_e0;
+  const bf16_t* const wl = p.wf_lo + w_e0;
+  auto load_unit = [&](int j) {
+    BFrag f;
+    f.h = *reinterpret_cast<const bf16x8*>(wh + (size_t)j * 512);
+    f.l = *reinterpret_cast<const bf16x8*>(wl + (size_t)j * 512);
+    return f;
+  };
+  BFrag bq[G::DEPTH];
+#pragma unroll
+  for (int j = 0; j < G::DEPTH; ++j) bq[j] = load_unit(j);
+  __builtin_amdgcn_sched_barrier(0);
+  if (h_dst >= 0) *reinterpret_cast<uint4*>(smem + h_dst) = hv;
+  DV_C3TRACE(1);
+  wait_vmcnt<2 * G::DEPTH>();                        // everything older than the weight units: the source rows have landed
+  __syncthreads();
+  DV_C3TRACE(2);
+
+  // ---- k-loop: acc[rf] += W[fragment][k-step] x A^T[row fragment rf][k-step], no barrier ----
+  // LDS row of (row fragment rf, tap): source frame (rf * 32 + l31 + tap - 1) >> 1 of the tile; -1 is LDS row 65, 64 is LDS row 64
+  int rowb[RFU][3], swl[RFU][3];
+#pragma unroll
+  for (int rf = 0; rf < RFU; ++rf)
+#pragma unroll
+    for (int tap = 0; tap < 3; ++tap) {
+      const int idx = (rf * 32 + l31 + tap - 1) >> 1, row = idx < 0 ? 65 : idx;
+      rowb[rf][tap] = row * 128;
+      swl[rf][tap] = swz(row) ^ lh;
+    }
+  f32x16 acc[RFU];
+#pragma unroll
+  for (int rf = 0; rf < RFU; ++rf)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[rf][r] = 0.f;
+  auto run = [&](auto kq_tag) __attribute__((always_inline)) {
+    constexpr int KQ = decltype(kq_tag)::value;
+    auto read_a = [&](int u, bf16x8 (&h)[RFU], bf16x8 (&l)[RFU]) {
+      const int ks = KQ * G::U + u, tap = ks / G::KPT, cs = ks - tap * G::KPT;
+#pragma unroll
+      for (int rf = 0; rf < RFU; ++rf) {
+        const int off = (cs >> 2) * CHP + rowb[rf][tap] + ((((cs & 3) << 1) ^ swl[rf][tap]) << 4);
+        h[rf] = *reinterpret_cast<const bf16x8*>(smem + off);
+        l[rf] = *reinterpret_cast<const bf16x8*>(smem + G::A_PL + off);
+      }
+    };
+    bf16x8 ah[2][RFU], al[2][RFU];
+    read_a(0, ah[0], al[0]);
+#pragma unroll
+    for (int u = 0; u < G::U; ++u) {
+      const int cur = u & 1;
+      if (u + 1 < G::U) read_a(u + 1, ah[cur ^ 1], al[cur ^ 1]);
+      const BFrag f = bq[u % G::DEPTH];
+#pragma unroll
+      for (int rf = 0; rf < RFU; ++rf) acc[rf] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.h, al[cur][rf], acc[rf], 0, 0, 0);
+#pragma unroll
+      for (int rf = 0; rf < RFU; ++rf) acc[rf] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.l, ah[cur][rf], acc[rf], 0, 0, 0);
+#pragma unroll
+      for (int rf = 0; rf < RFU; ++rf) acc[rf] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.h, ah[cur][rf], acc[rf], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      if (u + G::DEPTH < G::U) bq[u % G::DEPTH] = load_unit(u + G::DEPTH);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+  if (kq == 0) run(std::integral_constant<int, 0>{});
+  else if (kq == 1) run(std::integral_constant<int, 1>{});
+  else if (kq == 2) run(std::integral_constant<int, 2>{});
+  else run(std::integral_constant<int, 3>{});
+  DV_C3TRACE(3);
+
+  // ---- the four k-quarters are added through LDS; wave (kq, cf) keeps the whole fragment (row fragment kq, column fragment cf) ----
+  __syncthreads();                                   // every wave is done reading the resident operand
+  float4* const red4 = reinterpret_cast<float4*>(smem);
+#pragma unroll
+  for (int rf = 0; rf < RFU; ++rf)
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+      red4[((((cf * 4 + kq) * RFU + rf) * 4 + g) << 6) + lane] = make_float4(acc[rf][4 * g], acc[rf][4 * g + 1], acc[rf][4 * g + 2], acc[rf][4 * g + 3]);
+  __syncthreads();
+  const int e_wm = kq, e_wn = cf;
+  float vv[16];
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    float4 s = red4[((((e_wn * 4 + 0) * RFU + e_wm) * 4 + g) << 6) + lane];
+#pragma unroll
+    for (int k = 1; k < 4; ++k) {                    // (quarters in order: deterministic)
+      const float4 v = red4[((((e_wn * 4 + k) * RFU + e_wm) * 4 + g) << 6) + lane];
+      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+    vv[4 * g] = s.x; vv[4 * g + 1] = s.y; vv[4 * g + 2] = s.z; vv[4 * g + 3] = s.w;
+  }
+  DV_C3TRACE(4);
+
+  // ---- epilogue of the fragment: vv[4g + e] = column n0 + 32 e_wn + 8g + 4lh + e of row m0 + 32 e_wm + l31 ----
+  const bool gnx_h = p.gnx.xchg != nullptr;
+  const int ncol0 = n0 + e_wn * 32;
+  const int m = m0 + e_wm * 32 + l31, mrow0 = m0 + e_wm * 32;
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    const float4 b4 = *reinterpret_cast<const float4*>(s_bias + e_wn * 32 + 4 * lh + 8 * g);
+    vv[4 * g] += b4.x; vv[4 * g + 1] += b4.y; vv[4 * g + 2] += b4.z; vv[4 * g + 3] += b4.w;
+  }
+  if (p.epi == EPI_RESIDUAL) {
+    const float* rp = p.res + (size_t)m * p.ldres + ncol0 + 4 * lh;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const float4 a = *reinterpret_cast<const float4*>(rp + 8 * g);
+      vv[4 * g] += a.x; vv[4 * g + 1] += a.y; vv[4 * g + 2] += a.z; vv[4 * g + 3] += a.w;
+    }
+  }
+  {
+    const size_t ob = (size_t)m * p.ldo + ncol0;
+    if (p.out) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+        dv_st16(p.out + ob + 4 * lh + 8 * g, make_float4(vv[4 * g], vv[4 * g + 1], vv[4 * g + 2], vv[4 * g + 3]));
+    }
+    if (p.out_hi) store_planes16(p.out_hi, p.out_lo, ob, lh, vv);
+  }
+  DV_C3TRACE(5);
+  if (p.stats16) {
+    // per (32-row, 16-column) block: (sum, squared deviations from the block's own mean); registers 0-7 / 8-15 are the fragment's
+    // first / second 16 columns
+    float a1[2] = {0.f, 0.f}, a2[2] = {0.f, 0.f};
+#pragma unroll
+    for (int r = 0; r < 16; ++r) a1[r >> 3] += vv[r];
+    a1[0] = wave_sum64(a1[0]); a1[1] = wave_sum64(a1[1]);
+    const float mb[2] = {a1[0] * (1.0f / 512.0f), a1[1] * (1.0f / 512.0f)};
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { const float dv = vv[r] - mb[r >> 3]; a2[r >> 3] = fmaf(dv, dv, a2[r >> 3]); }
+    a2[0] = wave_sum64(a2[0]); a2[1] = wave_sum64(a2[1]);
+    if (lane < 2) {
+      const size_t e = (size_t)(mrow0 >> 5) * (p.N >> 4) + (ncol0 >> 4) + lane;
+      const float2 val = make_float2(lane ? a1[1] : a1[0], lane ? a2[1] : a2[0]);
+      reinterpret_cast<float2*>(p.stats16)[e] = val;
+      if (gnx_h)
+        __hip_atomic_store(p.gnx.xchg + e, (unsigned long long)__float_as_uint(val.x) | ((unsigned long long)__float_as_uint(val.y) << 32),
+                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+  }
+  DV_C3TRACE(6);
+  if (gnx_h) {
+    GnxTile t;
+    t.M = p.M; t.N = p.N; t.T_out = p.T_out; t.Tv_out = p.Tv_out; t.m0 = m0; t.n0 = n0; t.bm = BMU; t.bn = BN;
+    t.bq = (int)__umulhi((unsigned)m0, p.tout_magic);
+    gnx_finish_table<BN>(p.gnx, t, s_gnx, tid, lane, wave, NWV, [&](int) {});
+    DV_C3TRACE(7);
+    float y[16];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int cl = e_wn * 32 + 4 * lh + 8 * g;
+      const float4 sa = *reinterpret_cast<const float4*>(s_gnx.gA + cl);
+      const float4 sb = *reinterpret_cast<const float4*>(s_gnx.gB + cl);
+      y[4 * g] = fmaf(vv[4 * g], sa.x, sb.x); y[4 * g + 1] = fmaf(vv[4 * g + 1], sa.y, sb.y);
+      y[4 * g + 2] = fmaf(vv[4 * g + 2], sa.z, sb.z); y[4 * g + 3] = fmaf(vv[4 * g + 3], sa.w, sb.w);
+    }
+    if (p.gnx.silu) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) y[r] = y[r] * __builtin_amdgcn_rcpf(1.0f + __expf(-y[r]));
+    }
+    store_planes16(p.gnx.y_hi, p.gnx.y_lo, (size_t)m * p.N + ncol0, lh, y);
+  }
+  DV_C3TRACE(8);
+}
+
+// ---------------------------------------------------------------------------------------
 // Any input width (multiples of 128 channels up to 1024), and the ResnetBlock2D's second convolution WITH its folded 1x1 shortcut
 // (a second, one-tap K-segment over the block's raw input - reference resnet.py:627-641): the same tile with the rows STREAMED
 // through a ring of 64-channel chunks.
@@ -657,6 +898,18 @@ int gemm_conv3_split(const GemmParams& p, int n_cu) {
   if (2 * (p.M / BM) * (p.N / BN) > n_cu || nch < 4 || nch + ((nc2 + 1) >> 1) < 8) return 0;
   return 2;
 }
+// ... and the upsampling form (k_conv3u): nearest x2 folded into the row gather, 128 x 64 tiles, the widths the resident image fits
+bool gemm_conv3_up_ok(const GemmParams& p) {
+  if (!g_conv3_on || p.nseg != 1 || p.seg[0].taps != 3 || p.seg[0].pad != 1 || p.stride != 1 || p.up_mode != UP_X2) return false;
+  const int cin = p.seg[0].c0 + p.seg[0].c1;
+  if (cin != 128 && cin != 256 && cin != 384 && cin != 512) return false;
+  if (p.seg[0].c0 % 64 != 0 || p.seg[0].c1 % 64 != 0 || (p.seg[0].c1 > 0 && !p.seg[0].a1_hi)) return false;
+  if (p.T_out != 2 * p.T_in || p.T_virt != p.T_out || (p.Tv_out > 0 && p.Tv_out != p.T_out) || (p.Tv_in > 0 && p.Tv_in != p.T_in)) return false;
+  if (p.T_out % BMU != 0 || p.M % BMU != 0 || p.N % BN != 0 || p.B <= 0 || p.M != p.B * p.T_out) return false;
+  if ((p.epi != EPI_STORE && p.epi != EPI_RESIDUAL) || p.stats || p.rowstat_out || p.ln_stat || p.relu || p.rowmask) return false;
+  if ((p.ldo & 7) != 0 || (p.epi == EPI_RESIDUAL && (p.ldres & 3) != 0) || p.force_tile != GT_AUTO || p.sk_buf) return false;
+  return true;
+}
 // packed K (weight row length) such a launch expects: 3 C_in (+ the one-tap segment's channels)
 int gemm_conv3_k(const GemmParams& p) {
   return 3 * (p.seg[0].c0 + p.seg[0].c1) + (p.nseg > 1 ? p.seg[1].c0 + p.seg[1].c1 : 0);
@@ -672,8 +925,31 @@ template <int CIN>
 static hipError_t conv3_attr() {
   return hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv3<CIN>), hipFuncAttributeMaxDynamicSharedMemorySize, ConvGeom<CIN>::SMEM);
 }
+template <int CIN>
+static hipError_t conv3u_attr() {
+  return hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv3u<CIN>), hipFuncAttributeMaxDynamicSharedMemorySize, ConvGeomU<CIN>::SMEM);
+}
+template <int CIN>
+static hipError_t conv3u_launch(const GemmParams& p, hipStream_t st) {
+  constexpr int smem = ConvGeomU<CIN>::SMEM;
+  hipLaunchKernelGGL((k_conv3u<CIN>), dim3((p.M / BMU) * (p.N / BN)), dim3(NT), smem, st, p);
+  return hipGetLastError();
+}
+hipError_t launch_conv3_up(const GemmParams& p, hipStream_t st) {
+  if (!p.wf_hi || !p.wf_lo || !gemm_conv3_up_ok(p) || p.Kp != 3 * (p.seg[0].c0 + p.seg[0].c1) || p.sk_mode != 0) return hipErrorInvalidValue;
+  switch (p.seg[0].c0 + p.seg[0].c1) {
+    case 128: return conv3u_launch<128>(p, st);
+    case 256: return conv3u_launch<256>(p, st);
+    case 384: return conv3u_launch<384>(p, st);
+    default: return conv3u_launch<512>(p, st);
+  }
+}
 hipError_t conv3_init() {
   hipError_t e;
+  if ((e = conv3u_attr<128>()) != hipSuccess) return e;
+  if ((e = conv3u_attr<256>()) != hipSuccess) return e;
+  if ((e = conv3u_attr<384>()) != hipSuccess) return e;
+  if ((e = conv3u_attr<512>()) != hipSuccess) return e;
   if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv3s), hipFuncAttributeMaxDynamicSharedMemorySize, S_TOTAL)) != hipSuccess) return e;
   if ((e = conv3_attr<128>()) != hipSuccess) return e;
   if ((e = conv3_attr<256>()) != hipSuccess) return e;

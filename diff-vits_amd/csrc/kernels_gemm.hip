@@ -353,6 +353,7 @@ hipError_t launch_gemm(const GemmParams& pin, int precision, hipStream_t st) {
     gemm_pick_tile(p, bm, bn);
     if (bm == 64 && bn == 64) return launch_conv3(p, st);
   }
+  if (x3 && p.wf_hi && p.wf_lo && p.sk_mode == 0 && gemm_conv3_up_ok(p) && p.Kp == 3 * (p.seg[0].c0 + p.seg[0].c1)) return launch_conv3_up(p, st);
   const GemmTune& tune = gemm_tune();
   const int big_tiles = ((p.M + 127) / 128) * ((p.N + 127) / 128);
   bool k64 = tune.bk64 != 0;
