@@ -580,7 +580,7 @@ def main():
             "frac_rocprofv3": None if frac_rocprof is None else frac_rocprof["frac"], "rocprofv3": frac_rocprof,
             "traffic": traffic, "traffic_source": traffic_src, "hbm_gbps": hbm_gbps, "mfma_util": mfma_util,
             "pmc_per_kernel_family": pmc_families,
-            "kernel": "k_gemm<*> (implicit-GEMM conv1d/linear, all tile instantiations)",
+            "kernel": "k_gemm<*> + k_conv3 / k_conv3s / k_conv3u (implicit-GEMM conv1d / linear: every launch of the engine's GEMM kind)",
             "flops_per_launch": flops_gemm_fwd / gemm_n, "avg_launch_us": gemm_us, "launches_per_forward": gemm_n,
             "avg_op_us_event_pair_per_operation": 1e3 * g[2] / g[0], "achieved_event_pair_per_launch": achieved_evpair,
             # every MFMA kernel family the same way (live back-to-back replay of the family's launches between one event pair):

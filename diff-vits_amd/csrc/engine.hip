@@ -729,6 +729,7 @@ struct Builder {
   // Stride-1 three-tap convolutions over 128-512 input channels run on the resident-operand kernel (k_conv3, kernels_conv.hip;
   // DVITS_CONV3=0: k_gemm): launch_gemm dispatches there when the fragment-major weights are given.  Such a launch is never split
   // over K (64 rows x all input channels are resident: the k-loop runs at the MFMA rate on the tiles there are).
+  int conv3_min_tiles = [] { const char* e = getenv("DVITS_CONV3_MIN_TILES"); return e ? atoi(e) : 64; }();   // (below: k_gemm's 64x32 / 32x32 tiles spread the launch over more CUs; B = 4 / 2: 2.34 / 2.09 -> 2.24 / 2.06 ms per forward with 64 instead of 128, 32: the same)
   bool conv3_takes(const GemmParams& g) const {
     if (arena.exact || autotune_on() || prec != DV_PREC_BF16X3) return false;
     GemmParams t = g;
@@ -741,7 +742,7 @@ struct Builder {
     // (the tile the heuristic picks must be the 64x64 one - launch_gemm checks the same - and with an in-launch GroupNorm its tiles
     // must all be resident: both hold when there are at most 256 of them and fewer than 192 128x64 tiles)
     const int t64 = (t.M / 64) * (t.N / 64), t128 = ((t.M + 127) / 128) * (t.N / 64);
-    return t64 >= 128 && t128 < 192 && (n_cu <= 0 || t64 <= n_cu || !gnx_on);
+    return t64 >= conv3_min_tiles && t128 < 192 && (n_cu <= 0 || t64 <= n_cu || !gnx_on);
   }
   void gemm(std::vector<OpFn>& ops, GemmParams g, const PackedW* pw, int k_real) {
     g.w_hi = pw->hi; g.w_lo = pw->lo; g.Kp = pw->Kp; g.N_pad = pw->N_pad;

@@ -348,10 +348,13 @@ hipError_t launch_gemm(const GemmParams& pin, int precision, hipStream_t st) {
   }
   // stride-1 three-tap convolutions whose input channels fit the LDS: the resident-operand kernel (kernels_conv.hip), on the tile
   // grid / XCD rectangle / exchange-word layout of the 64x64 tile the heuristic would have picked
+  // (the caller - engine.hip conv3_takes - gives the fragment-major weights only where this kernel's 64x64 grid is the better
+  // one: 128-256 tiles by default)
   if (x3 && p.wf_hi && p.wf_lo && (p.sk_mode == 0 || p.sk_mode == 3) && gemm_conv3_shape_ok(p) && p.Kp == gemm_conv3_k(p)) {
     int bm, bn;
     gemm_pick_tile(p, bm, bn);
-    if (bm == 64 && bn == 64) return launch_conv3(p, st);
+    if (bm != 64 || bn != 64) p.xcd_n = 0;           // (the rectangle above was laid out for another tile: plain row bands)
+    return launch_conv3(p, st);
   }
   if (x3 && p.wf_hi && p.wf_lo && p.sk_mode == 0 && gemm_conv3_up_ok(p) && p.Kp == 3 * (p.seg[0].c0 + p.seg[0].c1)) return launch_conv3_up(p, st);
   const GemmTune& tune = gemm_tune();

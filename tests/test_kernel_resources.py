@@ -37,7 +37,7 @@ def test_config2_schedule_kernels_are_present_and_spill_free(kernels):
     want = ["k_gemm<64, 64, 64, 2, 2, 3, 2>", "k_gemm<128, 128, 32, 2, 2, 3, 2>", "k_attention_frag<16, 8, 3, 1>",
             "k_attention_frag<32, 4, 3, 1>", "k_attention_frag<48, 4, 3, 2>", "k_attention_frag<64, 4, 3, 2>",
             "k_ff_split<256, 4, 2>", "k_ff_split<384, 8, 2>", "k_ff_split<512, 8, 1>",             # (round 5)
-            "k_conv3<128>", "k_conv3<256>", "k_conv3<384>", "k_conv3<512>",
+            "k_conv3<128>", "k_conv3<256>", "k_conv3<384>", "k_conv3<512>", "k_conv3s(", "k_conv3u<256>", "k_conv3u<384>", "k_conv3u<512>",
             "k_chain2<1, 0, true, false, false>", "k_chain2<2, 0, true, false, false>", "k_chain2<1, 1, false, true, false>",
             "k_chain2<2, 1, false, true, false>", "k_chain2<3, 1, false, true, false>", "k_chain2<3, 0, false, false, true>",
             "k_chain_ff(", "k_gn_apply(", "k_pack_input(", "k_lincomb("]

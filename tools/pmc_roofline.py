@@ -24,15 +24,17 @@ import json
 import sys
 from collections import defaultdict
 
-FAMILIES = (("gemm", "k_gemm"), ("chain", "k_chain"), ("ff_split", "k_ff_split"), ("attention", "k_attention"), ("gn_apply", "k_gn_apply"))
+# (the GEMM family = every launch of the engine's kind "gemm": k_gemm and, since round 5, the resident / streamed convolution kernels)
+FAMILIES = (("gemm", ("k_gemm", "k_conv3")), ("chain", ("k_chain",)), ("ff_split", ("k_ff_split",)), ("attention", ("k_attention",)), ("gn_apply", ("k_gn_apply",)),
+            ("conv3", ("k_conv3",)))
 
 
 def counters(d):
     acc = defaultdict(lambda: defaultdict(lambda: [0.0, 0]))
     for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
         for r in csv.DictReader(open(f)):
-            for fam, pat in FAMILIES:
-                if pat in r["Kernel_Name"]:
+            for fam, pats in FAMILIES:
+                if any(pat in r["Kernel_Name"] for pat in pats):
                     a = acc[fam][r["Counter_Name"]]
                     a[0] += float(r["Counter_Value"])
                     a[1] += 1
@@ -43,8 +45,8 @@ def durations(d):
     acc = defaultdict(lambda: [0.0, 0])
     for f in glob.glob(d + "/**/*kernel_trace.csv", recursive=True):
         for r in csv.DictReader(open(f)):
-            for fam, pat in FAMILIES:
-                if pat in r["Kernel_Name"]:
+            for fam, pats in FAMILIES:
+                if any(pat in r["Kernel_Name"] for pat in pats):
                     acc[fam][0] += (float(r["End_Timestamp"]) - float(r["Start_Timestamp"])) * 1e-3
                     acc[fam][1] += 1
     return {fam: (v[0] / v[1], v[1]) for fam, v in acc.items()}
