@@ -736,7 +736,7 @@ struct Builder {
     t.B = B;
     if (gemm_conv3_up_ok(t)) {   // the upsampling form: 128 x 64 tiles, all resident when a GroupNorm is finished in the launch
       const int tu = (t.M / 128) * (t.N / 64);
-      return tu >= 96 && (n_cu <= 0 || tu <= n_cu || !gnx_on);
+      return tu >= (conv3_min_tiles < 64 ? conv3_min_tiles : 96) && (n_cu <= 0 || tu <= n_cu || !gnx_on);   // (a lowered DVITS_CONV3_MIN_TILES - tests - lowers this bound too)
     }
     if (!gemm_conv3_shape_ok(t)) return false;
     // (the tile the heuristic picks must be the 64x64 one - launch_gemm checks the same - and with an in-launch GroupNorm its tiles

@@ -1,23 +1,30 @@
-// Stride-1, three-tap convolution with the A operand RESIDENT in LDS for gfx950 (MI355X): the ResnetBlock2D convolutions
-// (reference unet1d/resnet.py:591-641: conv1 / conv2 over [B, C, T], kernel 3, padding 1) whose input channels fit a CU's LDS
-// beside nothing else - C_in = 128 / 256 / 384 / 512 (one tensor of planes, or the channel concatenation of two).
+// The ResnetBlock2D / Upsample2D convolutions of the denoiser on gfx950 (MI355X) with the A operand RESIDENT in LDS (reference
+// unet1d/resnet.py:591-641: conv1 / conv2 over [B, C, T], kernel 3, padding 1, stride 1, conv2 with its 1x1 shortcut; resnet.py:138-187:
+// nearest x2 + the same convolution).  Three kernels, one tile scheme:
+//   k_conv3<CIN>  - all C_in = 128 / 256 / 384 / 512 channels of the tile's rows resident (one tensor of planes, or the concatenation of two)
+//   k_conv3s      - any width up to 1024 channels and / or a second, one-tap K-segment (the folded shortcut): the rows streamed through
+//                   a ring of 64-channel chunks by a producer wave; fused split-K pairs on 128-tile grids
+//   k_conv3u<CIN> - the upsampling form: 128 output rows per tile over the same 64 + 2 source rows
 //
-// Why a second contraction kernel.  k_gemm (kernels_gemm.hip) stages BOTH operands of every 64-deep k-tile through an LDS ring
-// with one barrier per k-tile; its k-loop sits on three per-CU bounds at once - instruction issue, LDS bytes and the
-// vector-memory path - at 1050-1170 cycles per 64x64x64 k-tile against 384 cycles of MFMA (docs/HISTORY.md, round 3).  A 3-tap
-// convolution reads every activation row three times (once per tap), and at these channel counts the 64 + 2 rows a 64-row tile
-// touches are 34-135 KiB as split planes: they fit.  So, exactly like k_ff_split (kernels_ffsplit.hip):
+// Why not k_gemm (kernels_gemm.hip).  It stages BOTH operands of every 64-deep k-tile through an LDS ring with one barrier per
+// k-tile; its k-loop sits on three per-CU bounds at once - instruction issue, LDS bytes and the vector-memory path - at 1050-1170
+// cycles per 64x64x64 k-tile against 384 cycles of MFMA (docs/HISTORY.md, round 3).  A 3-tap convolution reads every activation row
+// three times (once per tap), and the 64 + 2 rows a 64-row tile touches are 34-135 KiB as split planes at up to 512 channels: they
+// fit.  So, exactly like k_ff_split (kernels_ffsplit.hip):
 //   * the tile's rows [m0 - 1, m0 + 64] x all C_in channels are DMA'd into LDS ONCE (the three taps read them at row offsets
 //     -1 / 0 / +1; the two halo rows are zeros at an utterance's ends);
 //   * the weights never touch LDS: fragment-major (launch_relayout_frag of the packed [N][3 C_in] planes), each wave loads the
-//     fragments it multiplies with coalesced 16-byte loads, 8 ahead in registers;
+//     fragments it multiplies with coalesced 16-byte loads, 6-8 ahead in registers;
 //   * 8 waves = 2 column fragments x 4 k-quarters, each wave multiplies BOTH row fragments with every weight fragment it loads
-//     (half the weight bytes per MFMA of a one-fragment wave); no barrier inside the k-loop;
+//     (half the weight bytes per MFMA of a one-fragment wave); no barrier inside the resident k-loop;
 //   * the four k-quarters are added through LDS and every wave finishes a 32-row x 16-column half fragment - the layout of
 //     k_gemm's half-fragment epilogue, whose steps follow unchanged: bias, residual, fp32 / split-plane stores, 32x16 block
 //     statistics, the consumer's GroupNorm finished in the launch (gnx_device.h).
 // The tile grid, the XCD rectangle and the exchange-word layout are those of k_gemm's 64x64 tile: launch_gemm (kernels_gemm.hip)
-// dispatches here when gemm_conv3_ok() holds and the fragment-major weights are given (GemmParams wf_hi / wf_lo).
+// dispatches here when gemm_conv3_shape_ok() / gemm_conv3_up_ok() hold and the caller gives the fragment-major weights (GemmParams
+// wf_hi / wf_lo; engine.hip conv3_takes: grids of 64-256 tiles).  Measured (profiles/r05_*conv3*): the resident k-loops run AT the
+// MFMA rate, the streamed one at ~1900 cycles per 64-channel chunk (1152 of MFMA: the per-CU vector-memory path carries the rows AND
+// the weights); 48 of the forward's 62 GEMM launches, family 1.24 -> 1.06 ms per forward, +4.9 % on the 50-step run.
 #include "dv_common.h"
 #include "dv_device.h"
 #include "gnx_device.h"

@@ -141,9 +141,10 @@ def test_unet_vs_golden(name, gold):
 
 def test_unet_cfg1_golden_on_the_convolution_kernels(gold):
     """The reference's own output of config 1 (B = 1, T = 256: levels of 256 / 128 / 64 / 32 frames) with the resnet convolutions
-    forced onto k_conv3 / k_conv3s at this small size (DVITS_CONV3_MIN_TILES=1; by default they are planned from 64 tiles, and the
+    forced onto k_conv3 / k_conv3s / k_conv3u at this small size (DVITS_CONV3_MIN_TILES=1; by default they are planned from 64 tiles, and the
     golden cases would all stay on k_gemm): the resident form (C_in <= 512), the streamed form (wider, and conv2 with its folded
-    1x1 shortcut), tiles at an utterance's first / last frames (zero halo rows) and tiles that are a whole utterance (64 frames)."""
+    1x1 shortcut), the upsampling form (128-row tiles), tiles at an utterance's first / last frames (zero halo rows) and tiles that
+    are a whole utterance (64 frames)."""
     os.environ["DVITS_CONV3_MIN_TILES"] = "1"
     try:
         m, kw, sd, sample, t, enc, mask = _build("cfg1")
@@ -158,7 +159,7 @@ def test_unet_cfg1_golden_on_the_convolution_kernels(gold):
         resident = [r[3] for r in rows if r[0] == "gemm" and " resident" in r[3]]
     finally:
         os.environ.pop("DVITS_CONV3_MIN_TILES", None)
-    assert len(resident) >= 20 and any("nseg=2" in d for d in resident), resident
+    assert len(resident) >= 20 and any("nseg=2" in d for d in resident) and any("up=1" in d for d in resident), resident
     err = rel_l2(y.cpu().numpy(), gold("unet_cfg1.npz")["y"])
     assert err < 2e-4, err
 
