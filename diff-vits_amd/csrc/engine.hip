@@ -571,9 +571,11 @@ struct Builder {
         launch_relayout_frag(w->lo, w->flo, w->N_pad, w->Kp, pack_stream) != hipSuccess) { err = "relayout launch failed"; return false; }
     return true;
   }
-  void chain(std::vector<OpFn>& ops, const ChainParams& cp, const char* what) {
+  // `extra_flops`: work of the launch beyond its two K = C contractions (the in-chain cross attention and its to_out GEMM) - part
+  // of the operation's own count, so that the per-operation table and the family sums agree with dv_unet_stats
+  void chain(std::vector<OpFn>& ops, const ChainParams& cp, const char* what, double extra_flops = 0.0) {
     cur_kind = "chain";
-    cur_flops = 2.0 * (double)cp.M * cp.C * cp.C * (1 + cp.passes);
+    cur_flops = 2.0 * (double)cp.M * cp.C * cp.C * (1 + cp.passes) + extra_flops;
     char buf[96];
     snprintf(buf, sizeof(buf), "%s M=%d C=%d N2=%d", what, cp.M, cp.C, cp.passes * cp.C);
     cur_desc = buf;
@@ -1178,9 +1180,9 @@ struct Builder {
               cp.xs_ticket = dry ? reinterpret_cast<unsigned*>(0x1000) : u->sk_tickets;
             }
           }
-          chain(ops, cp, cp.nsplit == 2 ? "to_out+res+LN+to_q+xattn(2 wg)+to_out+res" : "to_out+res+LN+to_q+xattn+to_out+res");
+          chain(ops, cp, cp.nsplit == 2 ? "to_out+res+LN+to_q+xattn(2 wg)+to_out+res" : "to_out+res+LN+to_q+xattn+to_out+res",
+                4.0 * B * u->cfg.num_heads * (double)Tp * L * cp.xa_d + 2.0 * (double)M * C * C);
           if (cp.xs_buf) release(cp.xs_buf);
-          if (!dry) { u->flops += 4.0 * B * u->cfg.num_heads * (double)Tp * L * cp.xa_d + 2.0 * (double)M * C * C; }
         }
         release(ao); release(h);
         probe(tb + "attn1", h2, Tn, C);

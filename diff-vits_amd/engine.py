@@ -3,9 +3,14 @@
 prepares the kernel schedule for the current (B, T, L) and runs forwards on the current
 HIP stream.  torch is used only for device memory and streams.
 """
+import atexit
 import collections
 import ctypes as C
 import os
+import sys
+import time
+import warnings
+import weakref
 
 import torch
 
@@ -37,6 +42,22 @@ def verify_handover_default():
 class HandoverLost(RuntimeError):
     """Raised by the call that NOTICES an earlier run's timed-out in-launch hand-over (lazy verification): that earlier result
     was invalid; the engine has already recovered (fallback schedule) - repeat what was computed since the last verified point."""
+
+
+_LIVE_ENGINES = weakref.WeakSet()      # engines with results that may still be unverified at interpreter exit
+
+
+def _verify_at_exit():
+    """Interpreter exit: the LAST results of a process (an unmodified reference loop never calls wait()) are verified here -
+    nothing can be repeated any more, but a timed-out hand-over is reported on stderr instead of passing silently."""
+    for eng in list(_LIVE_ENGINES):
+        try:
+            eng._verify_final("at interpreter exit")
+        except Exception:
+            pass
+
+
+atexit.register(_verify_at_exit)
 
 
 class UNetEngine:
@@ -82,7 +103,19 @@ class UNetEngine:
         # DVITS_HANDOVER_RETRY=0: never - round 4's permanent downgrade)
         self._retry_after = max(0, int(os.environ.get("DVITS_HANDOVER_RETRY", "64")))
         self._clean_since_downgrade = 0
+        self._retry_pending = False     # the clean results are in: the fused schedule is planned again at the next utterance boundary
         self.handover_retries = 0
+        # lazy verification, the windows nobody's next call closes:
+        #   * unverified results + a host that was idle for DVITS_VERIFY_IDLE_MS: the stream has drained long ago - the next call
+        #     verifies (one wait that returns at once) before it enqueues anything;
+        #   * more unverified results than DVITS_UNVERIFIED_WARN (a few utterances' evaluations): warn once, naming wait();
+        #   * the engine is destroyed / the interpreter exits with unverified results: verified there, reported on stderr.
+        self._idle_ms = float(os.environ.get("DVITS_VERIFY_IDLE_MS", "50"))
+        self._warn_unverified = int(os.environ.get("DVITS_UNVERIFIED_WARN", "512"))
+        self._warned_unverified = False
+        self._last_call = time.monotonic()
+        self.final_check_failed = False  # set by the destruction / exit check when it found a timed-out hand-over
+        _LIVE_ENGINES.add(self)
 
     class _Slot:
         __slots__ = ("h", "weight_sig", "prepared", "cond_keepalive")
@@ -127,7 +160,33 @@ class UNetEngine:
                     sl.h = C.c_void_p()
             self._plans.clear()
 
+    def _slots(self):
+        """Every live native handle of this engine (the current schedule and the cached ones)."""
+        seen = {}
+        for sl in list(self._plans.values()) + [self._cur]:
+            if sl is not None and sl.h and sl.h.value:
+                seen[id(sl)] = sl
+        return list(seen.values())
+
+    def _verify_final(self, when):
+        """Last chance: results were handed out unverified and nobody will call the engine again."""
+        if getattr(self, "unverified_results", 0) <= 0 or not torch.cuda.is_initialized():
+            return
+        torch.cuda.synchronize()
+        self.unverified_results = 0
+        if any(self._slot_status(sl)[1] for sl in self._slots()):
+            self.final_check_failed = True
+            msg = ("diff_vits_amd: an in-kernel hand-over timed out in one of the LAST denoiser runs of this engine (noticed %s: "
+                   "the GPU was shared with other kernels) - results returned since the last verified point are INVALID; "
+                   "call engine.wait() after each utterance and repeat the run when it returns False" % when)
+            sys.stderr.write(msg + "\n")
+            warnings.warn(msg, RuntimeWarning, stacklevel=2)
+
     def __del__(self):
+        try:
+            self._verify_final("when the engine was destroyed")
+        except Exception:
+            pass
         try:
             slots = {id(sl): sl for sl in list(getattr(self, "_plans", {}).values()) + [getattr(self, "_cur", None)] if sl is not None}
             for sl in slots.values():
@@ -211,6 +270,11 @@ class UNetEngine:
         enc = enc.detach().to(torch.float32).contiguous()
         if bias is not None:
             bias = bias.detach().to(torch.float32).reshape(enc.shape[0], enc.shape[1]).contiguous()
+        if self._retry_pending and self._cur.prepared is not None:
+            # a new conditioning = a new utterance: the safe place to go back to the fused schedule (re-plan, same shape)
+            B, T, L, _, fu = self._cur.prepared
+            self._apply_retry()
+            self.prepare(B, T, L, fu)
         self._cur.cond_keepalive = (enc, bias)
         self.cond_serial += 1
         self.check_or_recover(_lib.lib().dv_unet_set_cond(self._h, _lib.ptr(enc), _lib.ptr(bias), _lib.stream_ptr()),
@@ -220,7 +284,7 @@ class UNetEngine:
         """`_lib.check` for the calls that start with the native health check (set_cond, forward, dv_sampler_run): if the
         failure is an EARLIER run's timed-out in-launch hand-over (noticed now: runs are asynchronous), the engine recovers -
         downgraded to the separate-GroupNorm schedule, it needs prepare + set_cond again - and the caller is told to repeat."""
-        if rc != 0 and getattr(self, "_exclusive", True) and self._cur.prepared is not None and self.handover_status()[1]:
+        if rc != 0 and getattr(self, "_exclusive", True) and self._cur.prepared is not None and self._any_timed_out():
             self.recover_handover()
             raise HandoverLost("diff_vits_amd: the previous denoiser run was invalid (in-kernel GroupNorm hand-over timed out "
                                "on a shared GPU); the engine has switched to the separate-GroupNorm schedule - repeat the run")
@@ -232,6 +296,7 @@ class UNetEngine:
         B, cx, T = x.shape
         if out is None:
             out = torch.empty((B, self.out_channels, T), device=x.device, dtype=torch.float32)
+        self.before_enqueue()
         rc = _lib.lib().dv_unet_forward(self._h, _lib.ptr(x), cx, _lib.ptr(cond), _lib.ptr(t), _lib.ptr(out), _lib.stream_ptr())
         self.check_or_recover(rc, "dv_unet_forward")
         return out
@@ -288,6 +353,29 @@ class UNetEngine:
             return "off"
         return v
 
+    def before_enqueue(self):
+        """Called before a forward / sampler run is enqueued.  Lazy verification leaves results unverified until "the next
+        call"; if that call comes after the host was idle for a while (the mel went to the vocoder, the process waited for the
+        next request) the stream has drained long ago: verify NOW - a wait that returns at once - so the time-out of the run
+        before the pause is reported here ("repeat the run") whichever schedule slot it ran on."""
+        now = time.monotonic()
+        idle = 1e3 * (now - self._last_call)
+        self._last_call = now
+        if (self.unverified_results > 0 and idle >= self._idle_ms and self._verify_mode() == "lazy"
+                and not torch.cuda.is_current_stream_capturing()):
+            if not self.wait(_boundary=False):
+                raise HandoverLost("diff_vits_amd: a denoiser run before the last pause was invalid (in-kernel hand-over timed "
+                                   "out on a shared GPU); the engine has switched to the fallback schedule - repeat the run")
+
+    def _count_unverified(self):
+        self.unverified_results += 1
+        if self.unverified_results > self._warn_unverified and not self._warned_unverified and self._verify_mode() == "lazy":
+            self._warned_unverified = True
+            warnings.warn("diff_vits_amd: %d denoiser results have left the engine without a verification point; call "
+                          "`unet.hip_engine().wait()` once per utterance (True: the results since the last call are valid; "
+                          "False: repeat them) or set DVITS_HANDOVER_VERIFY=eager" % self.unverified_results,
+                          RuntimeWarning, stacklevel=4)
+
     def result_leaves(self, again):
         """Called by forward() / NativeUNetModel.run_plan once a result has been enqueued and before it is returned.
         `again()` re-enqueues the same work on the re-prepared engine and returns its result.  Returns None if the result
@@ -297,10 +385,10 @@ class UNetEngine:
             return None
         mode = self._verify_mode()
         if mode == "off" or torch.cuda.is_current_stream_capturing():   # (a host wait would invalidate a capture in progress)
-            self.unverified_results += 1
+            self._count_unverified()
             return None
         if mode == "lazy" and self._probation <= 0:
-            self.unverified_results += 1
+            self._count_unverified()
             return None
         self.host_syncs += 1
         torch.cuda.current_stream().synchronize()
@@ -309,14 +397,14 @@ class UNetEngine:
             out = again()
             self.host_syncs += 1
             torch.cuda.current_stream().synchronize()
-            if self.handover_status()[1]:
+            if self._any_timed_out():
                 raise RuntimeError("in-kernel hand-over timed out on the fallback schedule (it has none): internal error")
             return out
         self._probation -= 1
         self._note_clean()
         return None
 
-    def wait(self):
+    def wait(self, _boundary=True):
         """Wait for everything enqueued on the current stream and verify the in-launch hand-overs of the results handed out since
         the last verification point.  True: they are valid.  False: a hand-over timed out somewhere among them (a foreign
         kernel shared the GPU); the engine has recovered - it is on the fallback schedule and needs prepare + set_cond, which
@@ -324,21 +412,30 @@ class UNetEngine:
         self.host_syncs += 1
         torch.cuda.current_stream().synchronize()
         self.unverified_results = 0
-        if self._cur.prepared is not None and self.recover_handover():
+        self._last_call = time.monotonic()
+        if self.recover_handover():      # (looks at EVERY cached schedule: the flag lives in the handle the run used)
             return False
+        if self._retry_pending and _boundary:          # an utterance boundary: the safe place to plan the fused schedule again
+            self._apply_retry()
         return True
 
     def _note_clean(self):
-        """One more result without a time-out.  A downgraded engine goes back to the fused schedule after `_retry_after` of them
-        (the next prepare plans it; its first result is verified eagerly; a second failure doubles the distance)."""
-        if not self.handover_downgraded or self._retry_after <= 0:
+        """One more result without a time-out.  A downgraded engine goes back to the fused schedule after `_retry_after` of them -
+        not here, in the middle of somebody's solver loop (re-planning destroys the cached schedules and their graphs), but at the
+        next utterance boundary: `wait()` or the next `set_cond` (its first result is verified eagerly; a second failure doubles
+        the distance)."""
+        if not self.handover_downgraded or self._retry_after <= 0 or self._retry_pending:
             return
         self._clean_since_downgrade += 1
         if self._clean_since_downgrade >= self._retry_after:
             self._clean_since_downgrade = 0
-            self.handover_downgraded = False
-            self.handover_retries += 1
-            self.set_exclusive(True)
+            self._retry_pending = True
+
+    def _apply_retry(self):
+        self._retry_pending = False
+        self.handover_downgraded = False
+        self.handover_retries += 1
+        self.set_exclusive(True)
 
     def stats(self):
         n, f = C.c_int64(), C.c_double()
@@ -370,11 +467,21 @@ class UNetEngine:
         return n.value, err.value
 
     def handover_status(self):
-        """(GEMMs that finish their consumer's GroupNorm in the epilogue, timed-out flag) - see dv_unet_handover_status.
-        Meaningful after the stream has drained; a set flag also fails every later forward / sampler run."""
+        """(GEMMs that finish their consumer's GroupNorm in the epilogue, timed-out flag) of the CURRENT schedule - see
+        dv_unet_handover_status.  Meaningful after the stream has drained; a set flag also fails every later forward / sampler
+        run on that schedule."""
+        return self._slot_status(self._cur)
+
+    @staticmethod
+    def _slot_status(slot):
         n, bad = C.c_int32(), C.c_int32()
-        _lib.check(_lib.lib().dv_unet_handover_status(self._h, C.byref(n), C.byref(bad)), "dv_unet_handover_status")
+        _lib.check(_lib.lib().dv_unet_handover_status(slot.h, C.byref(n), C.byref(bad)), "dv_unet_handover_status")
         return n.value, bad.value
+
+    def _any_timed_out(self):
+        """The time-out flag lives in the native handle a run used, and the engine keeps several (one per cached shape): a
+        time-out on shape A must not be missed because shape B is current now."""
+        return any(self._slot_status(sl)[1] for sl in self._slots())
 
     def handover_active(self):
         """True while the current schedule finishes GroupNorms inside producer GEMMs (in-launch hand-over: needs the device
@@ -387,11 +494,12 @@ class UNetEngine:
         native flag, switches this engine to the fallback schedule (GroupNorm by k_gn_apply launches, the feed-forward blocks as
         two GEMMs: no in-launch waits; the fused schedule is tried again after DVITS_HANDOVER_RETRY clean results), and reports it once.  Returns True if a time-out had happened: the caller repeats the lost run (the sampler
         path does: sampler/_plan.py) - the engine must be prepared and conditioned again first."""
-        n, bad = self.handover_status()
+        bad = [sl for sl in self._slots() if self._slot_status(sl)[1]]
         if not bad:
             return False
-        import warnings
-        _lib.check(_lib.lib().dv_unet_handover_reset(self._h), "dv_unet_handover_reset")
+        for sl in bad:
+            _lib.check(_lib.lib().dv_unet_handover_reset(sl.h), "dv_unet_handover_reset")
+        self._retry_pending = False
         if self.handover_retries == 0:
             warnings.warn("diff_vits_amd: an in-kernel GroupNorm hand-over timed out (the GPU is shared with other kernels); "
                           "this engine now runs GroupNorm as separate launches (DVITS_GNX=0 schedule) and the lost run is repeated",

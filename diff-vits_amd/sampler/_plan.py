@@ -338,6 +338,7 @@ class NativeUNetModel:
 
     def _run_plan_once(self, plan, x, eng, L):
         B, C_, T = x.shape
+        eng.before_enqueue()             # (lazy verification: a run before a long host pause is verified here - engine.py)
         eng.prepare(B, T, self.enc.shape[1])
         bias = self.unet._bias_from_mask(self.mask, torch.float32)
         eng.set_cond(self.enc, bias)

@@ -208,3 +208,69 @@ def test_config5_b16_prior_prompt_encoder_sampler_vs_reference(gold):
     assert eng.wait() and torch.equal(mel, mel2)
     assert mel.shape == g5["mel"].shape and rel_l2(mel.cpu().numpy(), g5["mel"]) < 5e-4, rel_l2(mel.cpu().numpy(), g5["mel"])
     assert eng.handover_status()[1] == 0
+
+
+def test_diffusion_encoder_forward_survives_a_replan_of_the_same_shape(gold):
+    """`Diffusion_Encoder.forward` cached "the engine is conditioned" on (cond_serial, shape key).  A re-plan
+    of the SAME shape - the fused schedule retried after a downgrade, the documented `wait() is False: repeat` recovery - left
+    the native handle unconditioned while the key still matched: 'forward before dv_unet_set_cond'.  Both paths, through the
+    reference's own plumbing (a Python loop around `diff_model(x, data, t)`)."""
+    import subprocess
+    import sys
+    code = r"""
+import os, sys, warnings
+sys.path.insert(0, "tests")
+import numpy as np, torch
+import conftest
+from test_prompt_cpu import diffusion_state_dict, prompt_case
+from diff_vits_amd.model3 import Diffusion_Encoder
+gold = lambda name: np.load(os.path.join(conftest.GOLD, name))
+g, kw, x, cond, prompt, lengths, t = prompt_case(gold, "cfg")
+def model():
+    m = Diffusion_Encoder(backend="hip", **kw).eval()
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in diffusion_state_dict(kw).items()})
+    return m.cuda()
+dx, dc, dp = torch.from_numpy(x).cuda(), torch.from_numpy(cond).cuda(), torch.from_numpy(prompt).cuda()
+dl, dt = torch.from_numpy(lengths).cuda(), torch.from_numpy(t).cuda()
+data = (dc, dp, None, dl)
+ref_m = model()
+ref_m.unet.hip_engine().set_exclusive(False)
+with torch.no_grad():
+    ref = ref_m(dx, data, dt)
+# (1) forced time-out on the first schedule -> downgrade; DVITS_HANDOVER_RETRY = 3 clean results; wait() = the boundary that
+#     re-plans the fused schedule; the NEXT forward of the same shape must condition the new plan by itself
+os.environ["DVITS_GNX_SPIN"] = "-1"
+m = model()
+eng = m.unet.hip_engine()
+with warnings.catch_warnings(record=True) as w, torch.no_grad():
+    warnings.simplefilter("always")
+    y = m(dx, data, dt)
+    assert eng.handover_downgraded and torch.equal(y, ref)
+    os.environ.pop("DVITS_GNX_SPIN")
+    for _ in range(4):
+        assert torch.equal(m(dx, data, dt), ref)
+    assert eng._retry_pending
+    assert eng.wait() and not eng.handover_downgraded and eng.handover_retries == 1
+    y2 = m(dx, data, dt)                                    # same shape, same prompt objects: re-planned AND re-conditioned
+    torch.cuda.synchronize()
+    assert eng.handover_status()[0] > 0 and eng.handover_status()[1] == 0
+    assert float((y2 - ref).norm() / ref.norm()) < 2e-5
+# (2) wait() is False -> "repeat": the repeat goes through forward() again and must not raise
+os.environ["DVITS_GNX_SPIN"] = "-1"
+m = model()
+eng = m.unet.hip_engine()
+eng.prepare(dx.shape[0], dx.shape[2], dp.shape[2])
+os.environ.pop("DVITS_GNX_SPIN")
+eng._probation = 0
+with warnings.catch_warnings(record=True) as w, torch.no_grad():
+    warnings.simplefilter("always")
+    y = m(dx, data, dt)                                     # times out, leaves unverified
+    assert eng.wait() is False
+    y = m(dx, data, dt)                                     # the documented recovery
+    assert eng.wait() and torch.equal(y, ref)
+print("ok")
+"""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, DVITS_HANDOVER_RETRY="3"), cwd=root,
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]

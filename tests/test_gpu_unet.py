@@ -1600,8 +1600,12 @@ with warnings.catch_warnings(record=True) as w, torch.no_grad():
     y = m(inp, t, enc, encoder_attention_mask=mask).sample           # time-out -> repeated on the fallback schedule
     assert eng.handover_downgraded and torch.equal(y, ref)
     os.environ.pop("DVITS_GNX_SPIN")
-    ys = [m(inp, t, enc, encoder_attention_mask=mask).sample for _ in range(3)]     # DVITS_HANDOVER_RETRY = 3 clean results
+    builds = eng.plan_builds
+    ys = [m(inp, t, enc, encoder_attention_mask=mask).sample for _ in range(5)]     # DVITS_HANDOVER_RETRY = 3 clean results
     assert all(torch.equal(v, ref) for v in ys)
+    # ADVICE r5: the retry waits for an utterance boundary - nothing is re-planned in the middle of the caller's loop
+    assert eng.handover_downgraded and eng._retry_pending and eng.handover_retries == 0 and eng.plan_builds == builds
+    assert eng.wait()                                                # ... such as wait() (or the next set_cond)
     assert not eng.handover_downgraded and eng.handover_retries == 1
     y2 = m(inp, t, enc, encoder_attention_mask=mask).sample          # re-planned: the fused schedule again, verified
     torch.cuda.synchronize()
@@ -1612,4 +1616,103 @@ msgs = [str(i.message) for i in w if "hand-over timed out" in str(i.message)]
 assert len(msgs) == 1, msgs
 print("ok")
 """, DVITS_HANDOVER_RETRY="3")
+    assert "ok" in out
+
+
+def test_timeout_on_another_cached_schedule_is_seen_by_wait():
+    """the time-out flag lives in the native handle a run used and the engine keeps one handle per cached
+    shape.  A time-out in an (unverified) run on shape A followed by a run on shape B used to be missed by wait() - it read the
+    current handle only, returned True and A's invalid tensor stood as verified.  Forced: A's schedule is planned with
+    DVITS_GNX_SPIN=-1 and its probation skipped, B's normally."""
+    out = _handover_child(_HANDOVER_SETUP + r"""
+import os
+m = build()
+eng = m.hip_engine()
+t = torch.full((B,), 500.0, device="cuda")
+xb, cb, eb, kb = (torch.from_numpy(a).cuda() for a in synth.make_inputs(1, 80, 128, 40, seed=3))
+tb = torch.full((1,), 300.0, device="cuda")
+with warnings.catch_warnings(record=True) as w, torch.no_grad():
+    warnings.simplefilter("always")
+    yb = m(torch.cat([xb, cb], 1), tb, eb, encoder_attention_mask=kb).sample     # shape B: planned, verified
+    assert eng.wait()
+    os.environ["DVITS_GNX_SPIN"] = "-1"
+    eng.sync_weights(); eng.prepare(B, T, L)                                     # shape A planned with waits that give up
+    os.environ.pop("DVITS_GNX_SPIN")
+    eng._probation = 0                                                           # (as if A had run cleanly before)
+    ya = m(torch.cat([x, cond], 1), t, enc, encoder_attention_mask=mask).sample  # times out, leaves unverified
+    assert eng.unverified_results == 1
+    yb2 = m(torch.cat([xb, cb], 1), tb, eb, encoder_attention_mask=kb).sample    # B is current again
+    torch.cuda.synchronize()
+    assert eng.handover_status()[1] == 0                                         # ... and ITS flag is clean
+    assert eng.wait() is False                                                   # A's time-out is reported all the same
+    assert eng.handover_downgraded
+    ya2 = m(torch.cat([x, cond], 1), t, enc, encoder_attention_mask=mask).sample # repeated on the fallback schedule
+    assert eng.wait()
+ref_m = build(exclusive=False)
+with torch.no_grad():
+    ref = ref_m(torch.cat([x, cond], 1), t, enc, encoder_attention_mask=mask).sample
+assert torch.equal(ya2, ref)
+print("ok")
+""")
+    assert "ok" in out
+
+
+def test_timeout_in_the_last_forward_of_a_loop_without_wait_still_surfaces():
+    """an unmodified reference loop never calls wait(); the LAST result of a process (or the last before a
+    long pause) had no "next call" to report its time-out.  Now: (a) the engine verifies when it is destroyed / at interpreter
+    exit and reports on stderr + RuntimeWarning, (b) the first call after DVITS_VERIFY_IDLE_MS of host idle verifies before it
+    enqueues, (c) DVITS_UNVERIFIED_WARN results without a verification point warn, naming wait()."""
+    out = _handover_child(_HANDOVER_SETUP + r"""
+import gc, os, time
+t = torch.full((B,), 500.0, device="cuda")
+inp = torch.cat([x, cond], 1)
+# (a) destruction
+os.environ["DVITS_GNX_SPIN"] = "-1"
+m = build()
+eng = m.hip_engine()
+eng.sync_weights(); eng.prepare(B, T, L)
+os.environ.pop("DVITS_GNX_SPIN")
+eng._probation = 0
+with warnings.catch_warnings(record=True) as w, torch.no_grad():
+    warnings.simplefilter("always")
+    for k in range(3):
+        y = m(inp, t - k, enc, encoder_attention_mask=mask).sample     # every one of them times out; nobody looks
+        eng._last_call = time.monotonic()                              # (no pause between the calls)
+    assert eng.unverified_results == 3
+    del m, eng
+    gc.collect()
+msgs = [str(i.message) for i in w if "INVALID" in str(i.message)]
+assert len(msgs) == 1 and "wait()" in msgs[0], [str(i.message) for i in w]
+# (b) a pause
+os.environ["DVITS_GNX_SPIN"] = "-1"
+m = build()
+eng = m.hip_engine()
+eng.sync_weights(); eng.prepare(B, T, L)
+os.environ.pop("DVITS_GNX_SPIN")
+eng._probation = 0
+with warnings.catch_warnings(record=True) as w, torch.no_grad():
+    warnings.simplefilter("always")
+    y = m(inp, t, enc, encoder_attention_mask=mask).sample
+    time.sleep(0.2)
+    try:
+        m(inp, t, enc, encoder_attention_mask=mask)
+        raise AssertionError("the call after the pause did not report the lost run")
+    except HandoverLost as e:
+        assert "repeat the run" in str(e)
+    y = m(inp, t, enc, encoder_attention_mask=mask).sample             # repeated: fallback schedule
+    assert eng.wait() and eng.handover_downgraded
+# (c) the reminder
+os.environ["DVITS_UNVERIFIED_WARN"] = "4"
+m3 = build()
+e3 = m3.hip_engine()
+with warnings.catch_warnings(record=True) as w, torch.no_grad():
+    warnings.simplefilter("always")
+    for k in range(8):
+        m3(inp, t - k, enc, encoder_attention_mask=mask)
+        e3._last_call = time.monotonic()
+msgs = [str(i.message) for i in w if "without a verification point" in str(i.message)]
+assert len(msgs) == 1 and "wait()" in msgs[0], [str(i.message) for i in w]
+assert e3.wait()
+print("ok")
+""")
     assert "ok" in out
