@@ -135,6 +135,52 @@ def enc_dim_of(dry):
     return DRY_KW["cross_attention_dim"] if dry else UNET_KW["cross_attention_dim"]
 
 
+FAMILY_KERNELS = {
+    "gemm": "k_gemm<*> + k_conv3 / k_conv3s / k_conv3u (implicit-GEMM conv1d / linear: every launch of the engine's GEMM kind)",
+    "chain": "k_chain2<*> + k_chain_ff + k_ff_split<*> (row-block chains of the transformer blocks: every launch of the engine's chain kind)",
+    "attn": "k_attention_frag<*> + k_attention<*> (flash attention: every launch of the engine's attention kind)",
+}
+# engine kind -> the families of tools/pmc_roofline.py's JSON that make it up
+PMC_FAMILIES = {"gemm": ("gemm",), "chain": ("chain", "ff_split"), "attn": ("attention",)}
+
+
+def roofline_families(live, pmc, peak, engine_counted_gflop):
+    """The MFMA kernel families of one forward side by side, and which of them the headline `roofline` fields describe.
+
+    live: {kind: (launches_per_forward, avg_launch_us, gflop_per_forward)} - launch durations measured live (the family's
+          launches of the schedule replayed back to back between one HIP event pair on the launch stream)
+    pmc:  the committed rocprofv3 JSON of this build (tools/pmc_roofline.py) or None
+    Returns (families, dominant): every family carries its achieved TFLOP/s and fraction of `peak` live AND by rocprofv3's
+    per-kernel average of the committed kernel trace, its share of the forward's kernel time and of its FLOPs; `dominant` is the
+    family with the most kernel time - the one `roofline.kernel / achieved / frac / frac_rocprofv3` describe.
+    The families' FLOPs sum to the engine's own count (dv_unet_stats): asserted."""
+    fam = {}
+    t_all = sum(n * us for n, us, _ in live.values())
+    for kind, (n, us, gf) in live.items():
+        ach = gf * 1e9 / (us * 1e-6 * n) / 1e12 if n and us > 0 else 0.0
+        f = {"kernel": FAMILY_KERNELS.get(kind, kind), "launches_per_forward": n, "avg_launch_us": us, "gflop_per_forward": gf,
+             "ms_per_forward_back_to_back": us * n * 1e-3, "time_share": (n * us / t_all) if t_all > 0 else 0.0,
+             "flop_share": gf / engine_counted_gflop if engine_counted_gflop > 0 else 0.0,
+             "achieved": ach, "frac": ach / peak, "rocprofv3": None, "frac_rocprofv3": None}
+        parts = [pmc[k] for k in PMC_FAMILIES.get(kind, ()) if pmc and k in pmc and pmc[k].get("launches")]
+        if parts:
+            ln = sum(q["launches"] for q in parts)
+            rp_us = sum(q["launches"] * q["avg_us_kernel_trace"] for q in parts) / ln
+            # (the trace holds several forwards: its launch count is a multiple of the family's launches per forward)
+            ach_rp = gf * 1e9 / (rp_us * 1e-6 * n) / 1e12 if n else 0.0
+            f["rocprofv3"] = {"avg_launch_us": rp_us, "launches_in_trace": ln, "achieved": ach_rp,
+                              "hbm_gbps": sum(q["launches"] * q["avg_us_kernel_trace"] * q["hbm_gbps"] for q in parts) / (ln * rp_us),
+                              "hbm_bytes_per_launch": sum(q["launches"] * q["hbm_bytes_per_launch"] for q in parts) / ln,
+                              "mfma_util": sum(q["launches"] * q["avg_us_kernel_trace"] * q["mfma_util"] for q in parts) / (ln * rp_us)}
+            f["frac_rocprofv3"] = ach_rp / peak
+        fam[kind] = f
+    total = sum(f["gflop_per_forward"] for f in fam.values())
+    assert abs(total - engine_counted_gflop) <= 1e-6 * max(engine_counted_gflop, 1.0), \
+        "family FLOPs %.3f GF do not sum to the engine's count %.3f GF" % (total, engine_counted_gflop)
+    dominant = max(fam, key=lambda k: fam[k]["ms_per_forward_back_to_back"])
+    return fam, dominant
+
+
 def pmc_identity_ok(pj):
     """The committed PMC figures belong to ONE build of the kernels: tools/pmc_roofline.py stamps them with the library's
     dv_version() (which carries a hash of csrc/).  They are reported only while that still is the loaded library."""
@@ -327,6 +373,8 @@ def main():
     ap.add_argument("--precision", default=os.environ.get("DVITS_PRECISION", "bf16x3"), choices=["bf16x3", "bf16"])
     ap.add_argument("--streams", type=int, default=int(os.environ.get("DVITS_BENCH_STREAMS", "1")),
                     help="split the per-GPU batch into this many concurrent sub-batches (own engine + HIP stream each)")
+    ap.add_argument("--keep-handover", action="store_true", default=os.environ.get("DVITS_BENCH_KEEP_HANDOVER") == "1",
+                    help="with --streams k: the engines keep their in-launch hand-overs (plan each with DVITS_CU_BUDGET = CUs / k)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-other-configs", action="store_true",
@@ -378,7 +426,7 @@ def main():
     model, sd = build_model(dev, args.precision, dry)
     replicas = [model] + [build_model(dev, args.precision)[0] for _ in range(NS - 1)]
     streams = [torch.cuda.Stream(device=dev) for _ in range(NS)] if NS > 1 else [None]
-    if NS > 1:      # engines driven side by side on one device: no in-launch GroupNorm hand-over (dv_unet_set_exclusive)
+    if NS > 1 and not args.keep_handover:   # engines driven side by side on one device: no in-launch GroupNorm hand-over (dv_unet_set_exclusive)
         for r in replicas:
             r.hip_engine(args.precision).set_exclusive(False)
 
@@ -465,9 +513,12 @@ def main():
     ho_ranks = None
     if not dry:
         eng0 = model.hip_engine()
-        eng0.wait()                                  # (the stream has drained above: verifies the last runs, recovers if one was lost)
-        n_ho_r, bad_r = eng0.handover_status()
-        mine = [int(n_ho_r), int(bool(bad_r)), int(bool(eng0.handover_downgraded))]
+        mine = [0, 0, 0]
+        for r_ in replicas:                          # (--streams k: every sub-batch's engine)
+            e_ = r_.hip_engine()
+            lost = not e_.wait()                     # (the stream has drained above: verifies the last runs, recovers if one was lost)
+            n_ho_r, bad_r = e_.handover_status()
+            mine = [mine[0] + int(n_ho_r), int(mine[1] or bool(bad_r) or lost), int(mine[2] or bool(e_.handover_downgraded))]
         if world > 1:
             hv = torch.tensor(mine, device=dev, dtype=torch.int64)
             hall = torch.empty((world, 3), device=dev, dtype=torch.int64)
@@ -526,29 +577,25 @@ def main():
                     a[1] += fl
                     a[2] += ms
         n_launch, flops_fwd = eng.stats()
-        g = agg["gemm"]
         peak = PEAK_TFLOPS[args.precision]
-        # average GEMM launch duration: the schedule's 180 GEMM launches replayed back to back between ONE event pair on
-        # the launch stream (no per-launch event overhead; this is the figure rocprofv3's per-kernel average must match);
-        # the per-launch event pairs above (~+2.5 us each) give the per-family split and are reported beside it
-        gemm_us, gemm_n = eng.time_family("gemm", reps=10)
-        flops_gemm_fwd = g[1] / reps
-        fam = {}
+        # Average launch duration per MFMA kernel family: the family's launches of the schedule replayed back to back between ONE
+        # event pair on the launch stream (no per-launch event overhead; this is the figure rocprofv3's per-kernel average must
+        # match); the per-launch event pairs above (~+2.5 us each) give the per-kind split and are reported beside it.  FLOPs per
+        # family: the engine's own per-operation counts (2 M N K per contraction, 4 B H Tq Tk d per attention; a chain launch
+        # counts every contraction and the attention inside it), which sum to dv_unet_stats' total.
+        live = {}
         for kind in ("gemm", "chain", "attn"):
-            if kind not in agg:
-                continue
-            us_k, n_k = (gemm_us, gemm_n) if kind == "gemm" else eng.time_family(kind, reps=10)
-            fl_k = agg[kind][1] / reps
-            fam[kind] = {"launches_per_forward": n_k, "avg_launch_us": us_k, "gflop_per_forward": fl_k / 1e9,
-                         "ms_per_forward_back_to_back": us_k * n_k * 1e-3,
-                         "achieved": fl_k / (us_k * 1e-6 * n_k) / 1e12, "frac": fl_k / (us_k * 1e-6 * n_k) / 1e12 / peak}
-        achieved = flops_gemm_fwd / (gemm_us * 1e-6 * gemm_n) / 1e12
-        achieved_evpair = g[1] / (g[2] * 1e-3) / 1e12
+            if kind in agg:
+                us_k, n_k = eng.time_family(kind, reps=10)
+                live[kind] = (n_k, us_k, agg[kind][1] / reps / 1e9)
+        for kind, v in agg.items():                  # (kinds without an MFMA: no FLOPs are counted for them)
+            if kind not in live and v[1] > 0:
+                live[kind] = (v[0] // reps, 1e3 * v[2] / v[0], v[1] / reps / 1e9)
         fwd_ms = 1e3 * dt / args.steps / S
         # HBM-side bytes per launch, HBM GB/s and MFMA utilisation: PMC counters cannot be read from inside the process, so
         # these are the figures of the committed rocprofv3 --pmc passes over this same command (tools/pmc_roofline.py)
-        traffic = traffic_src = hbm_gbps = mfma_util = None
-        pmc_families = frac_rocprof = None
+        traffic_src = None
+        pmc_families = None
         # (the newest committed evidence file: profiles/rNN_pmc_roofline.json)
         import glob
         cands = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r[0-9][0-9]_pmc_roofline.json")))
@@ -562,31 +609,29 @@ def main():
             from diff_vits_amd import _lib
             traffic_src = ("stale: %s was collected on build %r, the loaded library is %r - PMC "
                            "fields withheld" % (tname, pj.get("build", {}).get("dv_version"), _lib.lib().dv_version().decode()))
+            pj = None
         elif pj is not None:
-            traffic, hbm_gbps, mfma_util = (pj["gemm"][k] for k in ("hbm_bytes_per_launch", "hbm_gbps", "mfma_util"))
             pmc_families = {k: {kk: v[kk] for kk in ("launches", "avg_us_kernel_trace", "hbm_bytes_per_launch", "hbm_gbps", "mfma_util")}
                             for k, v in pj.items() if isinstance(v, dict) and "launches" in v}
-            # the same family by rocprofv3's per-kernel average of the committed kernel trace (eager launches: ~5 % above the
-            # back-to-back replay the live figure uses) - VERDICT r4 #7
-            rp_us = pj["gemm"].get("avg_us_kernel_trace")
-            if rp_us:
-                frac_rocprof = {"avg_launch_us": rp_us, "achieved": flops_gemm_fwd / gemm_n / (rp_us * 1e-6) / 1e12,
-                                "frac": flops_gemm_fwd / gemm_n / (rp_us * 1e-6) / 1e12 / peak, "source": tname}
             traffic_src = ("%s (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, KiB; SQ_VALU_MFMA_BUSY_CYCLES / "
                            "(1024 SIMDs x kernel duration x 2.4 GHz); separate passes, eager launches; build %s, git %s)"
                            % (tname, pj["build"].get("dv_version"), pj["build"].get("git_head")))
+        fam, dom = roofline_families(live, pj, peak, flops_fwd / 1e9)
+        d = fam[dom]
+        rp = d["rocprofv3"]
+        g = agg[dom]
         result["roofline"] = {
-            "bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
-            "frac_rocprofv3": None if frac_rocprof is None else frac_rocprof["frac"], "rocprofv3": frac_rocprof,
-            "traffic": traffic, "traffic_source": traffic_src, "hbm_gbps": hbm_gbps, "mfma_util": mfma_util,
+            # the family with the most kernel time in the forward (it was the GEMM kind by habit)
+            "bound": "mfma", "family": dom, "kernel": d["kernel"], "time_share": d["time_share"],
+            "achieved": d["achieved"], "peak": peak, "unit": "TFLOP/s", "frac": d["frac"],
+            "frac_rocprofv3": d["frac_rocprofv3"], "rocprofv3": None if rp is None else dict(rp, source=tname),
+            "traffic": None if rp is None else rp["hbm_bytes_per_launch"], "traffic_source": traffic_src,
+            "hbm_gbps": None if rp is None else rp["hbm_gbps"], "mfma_util": None if rp is None else rp["mfma_util"],
             "pmc_per_kernel_family": pmc_families,
-            "kernel": "k_gemm<*> + k_conv3 / k_conv3s / k_conv3u (implicit-GEMM conv1d / linear: every launch of the engine's GEMM kind)",
-            "flops_per_launch": flops_gemm_fwd / gemm_n, "avg_launch_us": gemm_us, "launches_per_forward": gemm_n,
-            "avg_op_us_event_pair_per_operation": 1e3 * g[2] / g[0], "achieved_event_pair_per_launch": achieved_evpair,
-            # every MFMA kernel family the same way (live back-to-back replay of the family's launches between one event pair):
-            # round 5 moved the GEGLU / ffproj GEMMs of the C = 256 / 384 blocks - the family's most efficient launches - into
-            # k_ff_split, which is counted under "chain"; family averages are not comparable across that change, the whole-forward
-            # fraction below is
+            "flops_per_launch": d["gflop_per_forward"] * 1e9 / d["launches_per_forward"], "avg_launch_us": d["avg_launch_us"],
+            "launches_per_forward": d["launches_per_forward"],
+            "avg_op_us_event_pair_per_operation": 1e3 * g[2] / g[0], "achieved_event_pair_per_launch": g[1] / (g[2] * 1e-3) / 1e12,
+            # every MFMA kernel family the same way; their FLOPs sum to forward.engine_counted_gflop
             "families": fam,
             "per_kind_ms_per_forward": {k: v[2] / reps for k, v in agg.items()},
             "per_kind_operations": {k: v[0] // reps for k, v in agg.items()},   # a split-K GEMM pair is one operation

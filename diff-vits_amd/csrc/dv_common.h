@@ -107,6 +107,13 @@ struct GemmParams {
   // the same weights FRAGMENT-MAJOR (launch_relayout_frag of w_hi / w_lo), or null: with them a stride-1 three-tap convolution whose
   // input channels fit the LDS runs on k_conv3 (kernels_conv.hip, gemm_conv3_shape_ok) instead of k_gemm
   const bf16_t* wf_hi; const bf16_t* wf_lo;
+  // internal (launch_conv3 / launch_conv3_up): row tiles of the convolution kernels never span two utterances - every utterance has
+  // c3_tu = ceil(T_out / tile rows) of them, the last one short (a multiple of 32 rows) where the row pitch is no multiple of the
+  // tile; row-tile index i -> utterance umulhi(i, c3_tu_magic), tile i - utterance * c3_tu of it
+  int c3_tu; unsigned c3_tu_magic;
+  // planning aid (engine.hip conv3_takes -> gemm_gnx_plan): 1 = this launch will run on k_conv3 / k_conv3s (64 x 64 tiles),
+  // 2 = on k_conv3u (128 x 64 tiles); 0 = k_gemm's tile menu
+  int c3_route;
 #ifdef DV_GEMM_TRACE
   int trace;                    // development build (make trace): this launch stamps its phases (gemm_tile.h DV_TRACE)
 #endif
@@ -115,6 +122,8 @@ inline unsigned gemm_tout_magic(int T_out) { return T_out <= 1 ? 0u : (unsigned)
 // exchange words a GNX GEMM needs (M / 32 * N / 16), or 0 if launch_gemm would refuse it (tile shape vs T_out / groups,
 // more workgroups than `n_cu` compute units, unsupported epilogue)
 int gemm_gnx_plan(const GemmParams& p, int n_cu);
+// grids above the CU count may carry waiting hand-overs when one utterance's share of an XCD fits its CUs (kernels_gemm.hip)
+bool gemm_handover_rounds();
 // tile menu ids (kernels_gemm.hip); GT_BK64 is or-ed in when the tile runs 64-deep k-tiles
 enum { GT_AUTO = 0, GT_T0 = 1, GT_T1 = 2, GT_T2 = 3, GT_T2S = 4, GT_T2G = 5, GT_T3 = 6, GT_T4 = 7, GT_T4G = 8,
        GT_BK64 = 0x100 };
@@ -304,6 +313,8 @@ hipError_t gemm_init();   // one-time kernel attribute setup (call outside strea
 bool gemm_conv3_shape_ok(const GemmParams& p);   // shape / epilogue test only (weights and precision are the caller's)
 int gemm_conv3_k(const GemmParams& p);           // the packed K such a launch expects
 int gemm_conv3_split(const GemmParams& p, int n_cu);   // 2: run it as a fused split-K pair (sk_buf / sk_ticket needed), 0: one workgroup per tile
+size_t gemm_conv3_split_bytes(const GemmParams& p);    // ... the scratch of such a pair
+int gemm_conv3_row_tiles(const GemmParams& p, int bm); // row tiles of a launch on the convolution kernels (bm = 64; 128 for the upsampling form): per utterance
 hipError_t conv3_init();
 void conv3_env_refresh();                        // DVITS_CONV3=0: off
 hipError_t launch_conv3(const GemmParams& p, hipStream_t st);

@@ -594,7 +594,10 @@ struct Builder {
   // polls before an in-launch wait gives up; DVITS_GNX_SPIN=<n> is a test hook (1: every wait that is not satisfied at once
   // times out - exercises the fallback path of engine.py deterministically)
   int gnx_spin = [] { const char* e = getenv("DVITS_GNX_SPIN"); const int v = e ? atoi(e) : 0; return v != 0 ? v : (1 << 18); }();   // (-1: give up at the first unsatisfied poll)
-  int n_cu = [] { int d = 0, n = 0; if (hipGetDevice(&d) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, d) != hipSuccess) n = 0; return n; }();
+  // (DVITS_CU_BUDGET=<n>: plan as if the device had n CUs - for engines that are driven side by side on one device and still keep
+  // their in-launch hand-overs: k engines with a budget of CUs / k each are co-resident launch by launch; bench.py --streams)
+  int n_cu = [] { int d = 0, n = 0; if (hipGetDevice(&d) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, d) != hipSuccess) n = 0;
+                  const char* e = getenv("DVITS_CU_BUDGET"); const int b = e ? atoi(e) : 0; return b > 0 && b < n ? b : n; }();
   // `skip`: the consumer normalises [g's output | skip] (an up-path resnet block's norm1); the skip's share of the planes goes
   // to *sk_y (and *sk_raw, if the consumer's shortcut wants the raw tensor as planes).  DVITS_GNX_CONCAT=0: not planned.
   bool gnx_cat_on = [] { const char* e = getenv("DVITS_GNX_CONCAT"); return !(e && e[0] == '0'); }();
@@ -609,7 +612,8 @@ struct Builder {
     t.gnx.sk_c = skip ? skip->C : 0;
     int k_pad = 0;
     for (int s2 = 0; s2 < t.nseg; ++s2) k_pad += t.seg[s2].taps * (t.seg[s2].c0 + t.seg[s2].c1);
-    t.sk_split = conv3_takes(t) ? gemm_conv3_split(t, n_cu) : gemm_splitk_plan(t.M, t.N, k_pad, t.epi);
+    t.c3_route = conv3_route(t);
+    t.sk_split = t.c3_route ? gemm_conv3_split(t, n_cu) : gemm_splitk_plan(t.M, t.N, k_pad, t.epi);
     if (t.sk_split >= 2) {
       if (!sk_fused || ((t.M + 31) / 32) * ((t.N + 31) / 32) > 4096) return false;   // (two launches: see gemm())
       t.sk_buf = reinterpret_cast<float*>(0x1000); t.sk_ticket = reinterpret_cast<unsigned*>(0x1000);
@@ -732,27 +736,32 @@ struct Builder {
   // DVITS_CONV3=0: k_gemm): launch_gemm dispatches there when the fragment-major weights are given.  Such a launch is never split
   // over K (64 rows x all input channels are resident: the k-loop runs at the MFMA rate on the tiles there are).
   int conv3_min_tiles = [] { const char* e = getenv("DVITS_CONV3_MIN_TILES"); return e ? atoi(e) : 64; }();   // (below: k_gemm's 64x32 / 32x32 tiles spread the launch over more CUs; B = 4 / 2: 2.34 / 2.09 -> 2.24 / 2.06 ms per forward with 64 instead of 128, 32: the same)
-  bool conv3_takes(const GemmParams& g) const {
-    if (arena.exact || autotune_on() || prec != DV_PREC_BF16X3) return false;
+  // 0: k_gemm; 1: k_conv3 / k_conv3s (64 x 64 tiles); 2: k_conv3u (128 x 64 tiles) - GemmParams c3_route.  Any row pitch of whole
+  // 32-frame blocks (the padded row space of real utterance lengths included) and any grid size: the tiles are laid out per
+  // utterance, and whether the launch may also finish its consumer's GroupNorm is gemm_gnx_plan's business (round 6; rounds 5's
+  // window was 64-row multiples, 64-256 tiles).
+  int conv3_route(const GemmParams& g) const {
+    if (arena.exact || autotune_on() || prec != DV_PREC_BF16X3) return 0;
     GemmParams t = g;
     t.B = B;
-    if (gemm_conv3_up_ok(t)) {   // the upsampling form: 128 x 64 tiles, all resident when a GroupNorm is finished in the launch
-      const int tu = (t.M / 128) * (t.N / 64);
-      return tu >= (conv3_min_tiles < 64 ? conv3_min_tiles : 96) && (n_cu <= 0 || tu <= n_cu || !gnx_on);   // (a lowered DVITS_CONV3_MIN_TILES - tests - lowers this bound too)
+    if (gemm_conv3_up_ok(t)) {   // the upsampling form: 128 x 64 tiles
+      const int tu = gemm_conv3_row_tiles(t, 128) * (t.N / 64);
+      return tu >= (conv3_min_tiles < 64 ? conv3_min_tiles : 96) ? 2 : 0;   // (a lowered DVITS_CONV3_MIN_TILES - tests, one utterance - lowers this bound too)
     }
-    if (!gemm_conv3_shape_ok(t)) return false;
-    // (the tile the heuristic picks must be the 64x64 one - launch_gemm checks the same - and with an in-launch GroupNorm its tiles
-    // must all be resident: both hold when there are at most 256 of them and fewer than 192 128x64 tiles)
-    const int t64 = (t.M / 64) * (t.N / 64), t128 = ((t.M + 127) / 128) * (t.N / 64);
-    return t64 >= conv3_min_tiles && t128 < 192 && (n_cu <= 0 || t64 <= n_cu || !gnx_on);
+    if (!gemm_conv3_shape_ok(t)) return 0;
+    return gemm_conv3_row_tiles(t, 64) * (t.N / 64) >= conv3_min_tiles ? 1 : 0;
   }
+  bool conv3_takes(const GemmParams& g) const { return conv3_route(g) != 0; }
   void gemm(std::vector<OpFn>& ops, GemmParams g, const PackedW* pw, int k_real) {
     g.w_hi = pw->hi; g.w_lo = pw->lo; g.Kp = pw->Kp; g.N_pad = pw->N_pad;
     if (!g.bias) g.bias = pw->bias;
     g.B = B;
     g.zero_page = u->zero_page;
     const int p = prec;
-    const bool c3 = conv3_takes(g) && g.Kp == gemm_conv3_k(g) && frag(pw);   // (the upsampling form has one segment too: the same K)
+    const int route = conv3_route(g);
+    // (the planning pass packs nothing - its PackedW is a dummy - and must size the split-K scratch exactly as the real pass will)
+    const bool c3 = route != 0 && (dry || g.Kp == gemm_conv3_k(g)) && frag(pw);   // (the upsampling form has one segment too: the same K)
+    g.c3_route = c3 ? route : 0;
     if (c3) { g.wf_hi = dry ? reinterpret_cast<const bf16_t*>(0x1000) : pw->fhi; g.wf_lo = dry ? reinterpret_cast<const bf16_t*>(0x1000) : pw->flo; }
     cur_kind = "gemm"; cur_flops = 2.0 * (double)g.M * (double)g.N * (double)k_real;
     {
@@ -771,7 +780,7 @@ struct Builder {
     const bool offer = !arena.exact && autotune_on() && gemm_splitk_plan(64, 64, 1 << 20, EPI_STORE) != 0 && k_pad >= 768 && (g.epi == EPI_STORE || g.epi == EPI_RESIDUAL) &&
                        ((g.M + 63) / 64) * ((g.N + 63) / 64) <= 256;
     if (g.sk_split >= 2 || offer) {
-      g.sk_buf = alloc(gemm_splitk_bytes(g.M, g.N, g.sk_split > 2 ? g.sk_split : 2) / sizeof(float));
+      g.sk_buf = alloc((c3 && g.sk_split == 2 ? gemm_conv3_split_bytes(g) : gemm_splitk_bytes(g.M, g.N, g.sk_split > 2 ? g.sk_split : 2)) / sizeof(float));
       // null: two launches (DVITS_SPLITK_FUSED=0); the counters are indexed by tile id of any tile shape >= 32x32
       g.sk_ticket = (sk_fused && ((g.M + 31) / 32) * ((g.N + 31) / 32) <= 4096) ? u->sk_tickets : nullptr;
     }
@@ -1337,7 +1346,7 @@ struct Builder {
       const int ff_rows = fp.rows = ff_split_rows(C, M, Tp, fp.nspl, n_cu);   // 64 rows per workgroup; 32 at C = 512, odd pitches, small inputs
       const size_t n_flags = (size_t)(M / ff_rows) * fp.nspl * 8;       // one word per wave (kernels_ffsplit.hip)
       if (ff_split_on && merged_ffproj && chain_on && gnx_on && u->exclusive && !arena.exact && !autotune_on() && l3.stat && x.stat16 &&
-          n_cu > 0 && (C == 256 || C == 384 || C == 512) && ff_split_supported(fp, prec) && (M / ff_rows) * fp.nspl <= n_cu &&
+          n_cu > 0 && (C == 256 || C == 384 || C == 512) && ff_split_supported(fp, prec) && ((M / ff_rows) * fp.nspl <= n_cu || gemm_handover_rounds()) &&
           (M / ff_rows) * fp.nspl >= ff_split_min_wg &&
           gnx_used + n_flags <= dv_unet::GNX_POOL) {
         const std::string mw = tb + "__ffproj.weight", mb = tb + "__ffproj.bias";
@@ -1474,7 +1483,9 @@ struct Builder {
     if (down) { g.T_virt = x.T; g.stride = 2; g.up_mode = UP_NONE; T_new = (x.T + 2 - 3) / 2 + 1; }
     else {
       g.stride = 1; T_new = g.T_virt = T_target;
-      if (u->force_up) { g.up_mode = UP_SIZE; g.up_scale = (float)x.T / (float)T_target; }
+      // (interpolate(size=...) to exactly twice the length IS the x2 form - floor(t * 0.5f) = t >> 1 - and the x2 form has the
+      // resident-operand kernel: T = 300 upsamples 75 -> 150 -> 300 that way, only 38 -> 75 needs the general gather)
+      if (u->force_up && T_target != 2 * x.T) { g.up_mode = UP_SIZE; g.up_scale = (float)x.T / (float)T_target; }
       else g.up_mode = UP_X2;
     }
     g.Tv_out = T_new; g.T_out = pitch(T_new);
@@ -2164,11 +2175,15 @@ extern "C" int dv_penc_prepare(dv_penc* p, int32_t B, int32_t L, int32_t precisi
   return DV_OK;
 }
 
-static int run_ops(const std::vector<OpFn>& ops, hipStream_t st, const char* what) {
+// (DVITS_SYNC_OPS=1, development: every operation is announced on stderr and waited for - a device fault names its launch)
+static int run_ops(const std::vector<OpFn>& ops, hipStream_t st, const char* what, const std::vector<dv_unet::OpMeta>* meta = nullptr) {
+  static const bool sync_ops = [] { const char* e = getenv("DVITS_SYNC_OPS"); return e && e[0] == '1'; }();
   int i = 0;
   for (const OpFn& f : ops) {
+    if (sync_ops) fprintf(stderr, "[dvits] %s op %d %s %s\n", what, i, meta && i < (int)meta->size() ? (*meta)[i].kind : "", meta && i < (int)meta->size() ? (*meta)[i].desc.c_str() : "");
     hipError_t e = f(st);
     if (e != hipSuccess) return dv_fail(DV_ERR_HIP, "%s: op %d failed to launch: %s", what, i, hipGetErrorString(e));
+    if (sync_ops && (e = hipStreamSynchronize(st)) != hipSuccess) return dv_fail(DV_ERR_HIP, "%s: op %d failed: %s", what, i, hipGetErrorString(e));
     ++i;
   }
   return DV_OK;
@@ -2286,7 +2301,7 @@ int dv_unet_enqueue(dv_unet* u, const float* x, int cx, const float* cond, const
     }
     return DV_OK;
   }
-  if (!u->persist_on) return run_ops(u->step_ops, st, "forward");
+  if (!u->persist_on) return run_ops(u->step_ops, st, "forward", &u->step_meta);
   for (int i = 0; i < u->p_begin; ++i) {
     hipError_t e = u->step_ops[i](st);
     if (e != hipSuccess) return dv_fail(DV_ERR_HIP, "forward: op %d failed to launch: %s", i, hipGetErrorString(e));

@@ -1133,7 +1133,8 @@ int chain_ff_gnx_plan(const ChainFFParams& p, int n_cu) {
   if (!p.stats16 || gx.groups <= 0 || gx.groups > 64 || gx.sk_c < 0 || gx.sk_c > DV_GSK || gx.sk_c % 16 != 0 || gx.tscale) return 0;
   if ((p.C + gx.sk_c) % gx.groups != 0) return 0;
   const int cpg = (p.C + gx.sk_c) / gx.groups;
-  if (cpg % 16 != 0 || (p.T / 32) * (cpg / 16) > 256 || p.M / 32 > n_cu) return 0;
+  // (workgroup id = row block: an utterance's workgroups are consecutive ids - gemm_gnx_plan's launch-by-rounds rule)
+  if (cpg % 16 != 0 || (p.T / 32) * (cpg / 16) > 256 || (gemm_handover_rounds() ? p.T / 32 : p.M / 32) > n_cu) return 0;
   return (p.M / 32) * (p.C / 16);
 }
 hipError_t launch_chain_ff(const ChainFFParams& p, int precision, hipStream_t st) {

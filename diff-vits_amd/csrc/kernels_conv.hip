@@ -77,36 +77,47 @@ struct ConvGeom {
 
 }  // namespace
 
-// tile of this workgroup: k_gemm's XCD-aware order (workgroup b runs on XCD b % 8)
+// Tile of this workgroup: k_gemm's XCD-aware order (workgroup b runs on XCD b % 8) over a grid of ROW TILES THAT NEVER SPAN TWO
+// UTTERANCES.  The row space may be padded (GemmParams: row pitch T_out = a multiple of 32, Tv_out <= T_out frames exist - the real
+// inference call has any length, reference tts_infer.py:46-74): an utterance has c3_tu = ceil(T_out / bm) row tiles, the last one
+// `rows` < bm rows (a multiple of 32) where the pitch is no multiple of bm.
 // (ksel: the k-half of a fused split-K pair - GemmParams sk_mode 3 - else 0)
-__device__ __forceinline__ void conv3_tile(const GemmParams& p, int& m0, int& n0, int& ksel) {
+struct C3Tile { int m0, n0, t0, rows, ksel, bq; };   // first row, first column, frame of row m0 inside its utterance, rows of the tile, utterance
+__device__ __forceinline__ void conv3_tile(const GemmParams& p, C3Tile& t, const int bm) {
   const int n_tiles_n = p.N / BN, nwg = gridDim.x;
-  int bid = blockIdx.x;
-  ksel = 0;
+  int bid = blockIdx.x, tmi;
+  t.ksel = 0;
   if (p.xcd_n > 0) {
     const int x = bid & 7, i = bid >> 3;
     const int r = x & ((1 << p.xcd_sh_mn) - 1), xm_i = r >> p.xcd_sh_n, xn_i = r & (p.xcd_n - 1);
     const int lm = (i * p.xcd_inv_tn) >> 16, ln = i - lm * p.xcd_tn;
-    m0 = (xm_i * p.xcd_tm + lm) * BM; n0 = (xn_i * p.xcd_tn + ln) * BN; ksel = x >> p.xcd_sh_mn;
+    tmi = xm_i * p.xcd_tm + lm; t.n0 = (xn_i * p.xcd_tn + ln) * BN; t.ksel = x >> p.xcd_sh_mn;
   } else {
-    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
-    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    if (p.xcd_n == 0) {                              // (xcd_n < 0: plain order - an utterance's tiles spread over all XCDs)
+      const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+      bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    }
     if (p.sk_mode == 3) {                            // XCD-contiguous ids share a k-half
       const int tiles = nwg >> 1;
-      ksel = bid / tiles;
-      bid -= ksel * tiles;
+      t.ksel = bid / tiles;
+      bid -= t.ksel * tiles;
     }
-    m0 = (bid / n_tiles_n) * BM; n0 = (bid % n_tiles_n) * BN;
+    tmi = bid / n_tiles_n; t.n0 = (bid - tmi * n_tiles_n) * BN;
   }
+  t.bq = p.c3_tu_magic ? (int)__umulhi((unsigned)tmi, p.c3_tu_magic) : tmi;   // (magic 0: one tile per utterance)
+  t.t0 = (tmi - t.bq * p.c3_tu) * bm;
+  t.m0 = t.bq * p.T_out + t.t0;
+  t.rows = min(bm, p.T_out - t.t0);
 }
 
 // The part both kernels share: the four k-quarters' accumulators (wave = column fragment cf = wave & 1, quarter kq = wave >> 1, both
 // row fragments) are added through LDS - `smem` is free: the caller's waves are past their last operand read only after the barrier
 // here - and every wave finishes a 32-row x 16-column half fragment: the steps of gemm_tile.h's half-fragment epilogue.
 __device__ __forceinline__ void conv3_finish(const GemmParams& p, char* smem, const float* s_bias, GnxShared<BN>& s_gnx, f32x16 (&acc)[2],
-                                             const float (&rpre)[8], const int m0, const int n0, const int tid, const int lane, const int wave,
-                                             const int CIN, const int ksel) {
+                                             const float (&rpre)[8], const C3Tile& tl, const int tid, const int lane, const int wave,
+                                             const int CIN) {
   (void)CIN;                                         // (trace builds select launches by it)
+  const int m0 = tl.m0, n0 = tl.n0, ksel = tl.ksel;
   const int l31 = lane & 31, lh = lane >> 5;
   const int cf = wave & 1, kq = wave >> 1;
   const int e_wn = cf, e_wm = (wave >> 1) & 1, e_half = wave >> 2;   // epilogue role: fragment (e_wm, e_wn), its columns [16 e_half, +16)
@@ -135,7 +146,8 @@ __device__ __forceinline__ void conv3_finish(const GemmParams& p, char* smem, co
     // fused split-K pair (the protocol of gemm_tile.h's sk_mode 3): this workgroup multiplied one half of the chunks.  It writes
     // its half-fragment sums through and takes a ticket; the first of the pair to arrive leaves, the second adds the partner's
     // sums (a + b = b + a: the same bits whoever finishes) and runs the epilogue.  Nobody waits for anybody.
-    const int tile = (m0 / BM) * (p.N / BN) + n0 / BN, tiles = (p.M / BM) * (p.N / BN);
+    const int tmi = tl.bq * p.c3_tu + tl.t0 / BM;    // row-tile index
+    const int tile = tmi * (p.N / BN) + n0 / BN, tiles = (int)(gridDim.x >> 1);
     float4* const d0 = reinterpret_cast<float4*>(p.sk_buf) + ((size_t)(ksel * tiles + tile) * NWV + wave) * 128 + lane;
     st_handover16(d0, make_float4(vv[0], vv[1], vv[2], vv[3]));
     st_handover16(d0 + 64, make_float4(vv[4], vv[5], vv[6], vv[7]));
@@ -154,10 +166,16 @@ __device__ __forceinline__ void conv3_finish(const GemmParams& p, char* smem, co
   }
 
   // ---- epilogue of the half fragment (the steps of gemm_tile.h's half-fragment epilogue) ----
+  // Padded row space: a fragment beyond the tile's rows (the short last tile of an utterance) belongs to the NEXT utterance and is
+  // not touched; rows [Tv_out, T_out) of this one are stored as zeros and kept out of the statistics (dv_common.h GemmParams).
   const bool gnx_h = p.gnx.xchg != nullptr;
   const int coff = e_half * 16;                      // this wave's columns inside the fragment
   const int ncol = n0 + e_wn * 32 + coff;            // first of them
   const int m = m0 + e_wm * 32 + l31, mrow0 = m0 + e_wm * 32;
+  const bool live = e_wm * 32 < tl.rows;             // (wave-uniform)
+  const bool padded = p.Tv_out != p.T_out;
+  const int tfr = tl.t0 + e_wm * 32;                 // frame of the fragment's first row
+  const bool m_ok = tfr + l31 < p.Tv_out;
 #pragma unroll
   for (int g = 0; g < 2; ++g) {
     const float4 b4 = *reinterpret_cast<const float4*>(s_bias + e_wn * 32 + coff + 4 * lh + 8 * g);
@@ -167,7 +185,11 @@ __device__ __forceinline__ void conv3_finish(const GemmParams& p, char* smem, co
 #pragma unroll
     for (int r = 0; r < 8; ++r) vv[r] += rpre[r];
   }
-  {
+  if (padded) {
+#pragma unroll
+    for (int r = 0; r < 8; ++r) vv[r] = m_ok ? vv[r] : 0.f;
+  }
+  if (live) {
     const size_t ob = (size_t)m * p.ldo + ncol;
     if (p.out) {
 #pragma unroll
@@ -177,14 +199,14 @@ __device__ __forceinline__ void conv3_finish(const GemmParams& p, char* smem, co
     if (p.out_hi) store_planes8(p.out_hi, p.out_lo, ob, lh, vv);
   }
   DV_C3TRACE(5);
-  if (p.stats16) {                                   // this wave's 32 x 16 block: (sum, squared deviations about its own mean)
+  if (p.stats16 && live) {                           // this wave's 32 x 16 block: (sum, squared deviations about its own mean)
     float a1 = 0.f, a2 = 0.f;
 #pragma unroll
     for (int r = 0; r < 8; ++r) a1 += vv[r];
     a1 = wave_sum64(a1);
-    const float mb = a1 * (1.0f / 512.0f);
+    const float mb = padded ? a1 / (float)(16 * min(32, p.Tv_out - tfr)) : a1 * (1.0f / 512.0f);
 #pragma unroll
-    for (int r = 0; r < 8; ++r) { const float dv = vv[r] - mb; a2 = fmaf(dv, dv, a2); }
+    for (int r = 0; r < 8; ++r) { const float dv = (!padded || m_ok) ? vv[r] - mb : 0.f; a2 = fmaf(dv, dv, a2); }
     a2 = wave_sum64(a2);
     if (lane == 0) {
       const size_t e = (size_t)(mrow0 >> 5) * (p.N >> 4) + (ncol >> 4);
@@ -197,8 +219,8 @@ __device__ __forceinline__ void conv3_finish(const GemmParams& p, char* smem, co
   DV_C3TRACE(6);
   if (gnx_h) {
     GnxTile t;
-    t.M = p.M; t.N = p.N; t.T_out = p.T_out; t.Tv_out = p.Tv_out; t.m0 = m0; t.n0 = n0; t.bm = BM; t.bn = BN;
-    t.bq = (int)__umulhi((unsigned)m0, p.tout_magic);
+    t.M = p.M; t.N = p.N; t.T_out = p.T_out; t.Tv_out = p.Tv_out; t.m0 = m0; t.n0 = n0; t.bm = tl.rows; t.bn = BN;
+    t.bq = tl.bq;
     gnx_finish_table<BN>(p.gnx, t, s_gnx, tid, lane, wave, NWV, [&](int) {});
     DV_C3TRACE(7);
     float y[8];
@@ -214,7 +236,11 @@ __device__ __forceinline__ void conv3_finish(const GemmParams& p, char* smem, co
 #pragma unroll
       for (int r = 0; r < 8; ++r) y[r] = y[r] * __builtin_amdgcn_rcpf(1.0f + __expf(-y[r]));
     }
-    store_planes8(p.gnx.y_hi, p.gnx.y_lo, (size_t)m * p.N + ncol, lh, y);
+    if (padded) {                                    // (rows that do not exist: zeros, like every producer of planes)
+#pragma unroll
+      for (int r = 0; r < 8; ++r) y[r] = m_ok ? y[r] : 0.f;
+    }
+    if (live) store_planes8(p.gnx.y_hi, p.gnx.y_lo, (size_t)m * p.N + ncol, lh, y);
   }
   DV_C3TRACE(8);
 }
@@ -229,8 +255,9 @@ __global__ __launch_bounds__(NT) void k_conv3(const GemmParams p) {
   asm volatile("" ::"s"(p.seg[0].a0_hi), "s"(p.seg[1].a0_hi), "s"(p.seg[1].pad), "s"(p.T_in), "s"(p.w_hi), "s"(p.M), "s"(p.res),
                "s"(p.out_hi), "s"(p.zero_page), "s"(p.ln_u), "s"(p.gnx.xchg), "s"(p.gnx.y_hi), "s"(p.xcd_n), "s"(p.xcd_inv_tn), "s"(p.wf_lo));
   DV_C3TRACE(0);
-  int m0, n0, ksel;
-  conv3_tile(p, m0, n0, ksel);
+  C3Tile tl;
+  conv3_tile(p, tl, BM);
+  const int m0 = tl.m0, n0 = tl.n0, t0 = tl.t0;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l31 = lane & 31, lh = lane >> 5;
   const int cf = wave & 1, kq = wave >> 1;           // k-loop role: column fragment, k-quarter
@@ -238,12 +265,12 @@ __global__ __launch_bounds__(NT) void k_conv3(const GemmParams p) {
   const unsigned a_base = (unsigned)(size_t)smem;
   const GemmSeg& sg = p.seg[0];
   const int c0 = sg.c0, c1 = sg.c1;
-  const int t0 = m0 - (int)__umulhi((unsigned)m0, p.tout_magic) * p.T_out;   // frame of the tile's first row inside its utterance
+  const int m_last = p.M - 1;                        // (a short last tile: the rows behind it belong to the next utterance - read, never used - or lie beyond M)
 
   // ---- requests, oldest first: residual rows of this wave's half fragment, halo rows, bias, the tile's rows, first weights ----
   float rpre[8];
   if (p.epi == EPI_RESIDUAL) {
-    const float* rp = p.res + (size_t)(m0 + e_wm * 32 + l31) * p.ldres + n0 + e_wn * 32 + e_half * 16 + 4 * lh;
+    const float* rp = p.res + (size_t)min(m0 + e_wm * 32 + l31, m_last) * p.ldres + n0 + e_wn * 32 + e_half * 16 + 4 * lh;
 #pragma unroll
     for (int g = 0; g < 2; ++g) {
       const float4 a = *reinterpret_cast<const float4*>(rp + 8 * g);
@@ -257,7 +284,7 @@ __global__ __launch_bounds__(NT) void k_conv3(const GemmParams p) {
   if (tid < HITEMS) {
     const int pl = tid / (CIN / 4), rem = tid - pl * (CIN / 4), which = rem / (CIN / 8), piece = rem - which * (CIN / 8);
     const int ch = piece * 8, c = piece >> 3, slot = piece & 7;
-    const bool ok = which == 0 ? (t0 + BM < p.T_out) : (t0 > 0);                 // which 0: row m0 + 64 (LDS row 64), 1: row m0 - 1 (LDS row 65)
+    const bool ok = which == 0 ? (t0 + BM < p.Tv_out) : (t0 > 0);                // which 0: row m0 + 64 (LDS row 64), 1: row m0 - 1 (LDS row 65); frames that exist
     const long srow = which == 0 ? (long)m0 + BM : (long)m0 - 1;
     const bool first = ch < c0;
     const bf16_t* src = first ? (pl ? sg.a0_lo : sg.a0_hi) : (pl ? sg.a1_lo : sg.a1_hi);
@@ -273,7 +300,7 @@ __global__ __launch_bounds__(NT) void k_conv3(const GemmParams p) {
     for (int c = 0; c < G::NCH; ++c) {
       const int cb = c * 64;
       const bool first = cb < c0;
-      const size_t e = (size_t)(m0 + row) * (first ? c0 : c1) + (first ? cb : cb - c0) + sc8;
+      const size_t e = (size_t)min(m0 + row, m_last) * (first ? c0 : c1) + (first ? cb : cb - c0) + sc8;
       const unsigned dst = a_base + (unsigned)(c * CHP + wave * 1024);
       glds16((first ? sg.a0_hi : sg.a1_hi) + e, dst);
       glds16((first ? sg.a0_lo : sg.a1_lo) + e, dst + G::A_PL);
@@ -296,6 +323,19 @@ __global__ __launch_bounds__(NT) void k_conv3(const GemmParams p) {
   if (h_dst >= 0) *reinterpret_cast<uint4*>(smem + h_dst) = hv;
   DV_C3TRACE(1);
   wait_vmcnt<2 * G::DEPTH>();                        // everything older than the weight units: the tile's rows have landed
+  {
+    // padded row space: the first frame that does not exist (Tv_out) is read by the +1 tap of the last one that does and must be
+    // zeros (nothing else of the padding is ever used: the outputs of rows that do not exist are discarded).  Its producers write
+    // whatever their GroupNorm made of it, so the wave that brought that row clears it - behind ITS wait, ahead of the barrier.
+    const int zr = p.Tv_out - t0;                    // tile row of that frame (row 64 is the halo row: `ok` above)
+    if (zr < BM && (zr >> 3) == wave && (lane >> 3) == (zr & 7)) {
+#pragma unroll
+      for (int c = 0; c < G::NCH; ++c) {
+        *reinterpret_cast<uint4*>(smem + c * CHP + wave * 1024 + lane * 16) = make_uint4(0u, 0u, 0u, 0u);
+        *reinterpret_cast<uint4*>(smem + G::A_PL + c * CHP + wave * 1024 + lane * 16) = make_uint4(0u, 0u, 0u, 0u);
+      }
+    }
+  }
   __syncthreads();
   DV_C3TRACE(2);
 
@@ -352,7 +392,7 @@ __global__ __launch_bounds__(NT) void k_conv3(const GemmParams p) {
   else run(std::integral_constant<int, 3>{});
   DV_C3TRACE(3);
 
-  conv3_finish(p, smem, s_bias, s_gnx, acc, rpre, m0, n0, tid, lane, wave, CIN, 0);
+  conv3_finish(p, smem, s_bias, s_gnx, acc, rpre, tl, tid, lane, wave, CIN);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -385,23 +425,33 @@ __global__ __launch_bounds__(NT) void k_conv3u(const GemmParams p) {
   asm volatile("" ::"s"(p.seg[0].a0_hi), "s"(p.seg[1].a0_hi), "s"(p.seg[1].pad), "s"(p.T_in), "s"(p.w_hi), "s"(p.M), "s"(p.res),
                "s"(p.out_hi), "s"(p.zero_page), "s"(p.ln_u), "s"(p.gnx.xchg), "s"(p.gnx.y_hi), "s"(p.xcd_n), "s"(p.xcd_inv_tn), "s"(p.wf_lo));
   DV_C3TRACE(0);
-  // tile: XCD x takes a band of row tiles (all their column tiles: an L2 fetches its rows of the source once)
-  int m0, n0;
+  // tile: XCD x takes a band of row tiles (all their column tiles: an L2 fetches its rows of the source once); row tiles never span
+  // two utterances (C3Tile: the last one of an utterance may be short)
+  C3Tile tl;
   {
     const int n_tiles_n = p.N / BN, nwg = gridDim.x;
     int bid = blockIdx.x;
-    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
-    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-    m0 = (bid / n_tiles_n) * BMU; n0 = (bid % n_tiles_n) * BN;
+    if (p.xcd_n == 0) {                              // (xcd_n < 0: plain order)
+      const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+      bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    }
+    const int tmi = bid / n_tiles_n;
+    tl.n0 = (bid - tmi * n_tiles_n) * BN; tl.ksel = 0;
+    tl.bq = p.c3_tu_magic ? (int)__umulhi((unsigned)tmi, p.c3_tu_magic) : tmi;
+    tl.t0 = (tmi - tl.bq * p.c3_tu) * BMU;
+    tl.m0 = tl.bq * p.T_out + tl.t0;
+    tl.rows = min(BMU, p.T_out - tl.t0);
   }
+  const int m0 = tl.m0, n0 = tl.n0, t0 = tl.t0;      // t0: output frame of the tile's first row inside its utterance
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l31 = lane & 31, lh = lane >> 5;
   const int cf = wave & 1, kq = wave >> 1;           // k-loop role: column fragment, k-quarter; epilogue role: fragment (row kq, column cf)
   const unsigned a_base = (unsigned)(size_t)smem;
   const GemmSeg& sg = p.seg[0];
   const int c0 = sg.c0, c1 = sg.c1;
-  const int t0 = m0 - (int)__umulhi((unsigned)m0, p.tout_magic) * p.T_out;   // output frame of the tile's first row inside its utterance
-  const int ms0 = m0 >> 1;                           // source row of output row m0 (row pitches: T_out = 2 T_in)
+  const int ts0 = t0 >> 1;                           // source frame of output frame t0
+  const int ms0 = tl.bq * p.T_in + ts0;              // ... its row (the pitches of the two levels are independent)
+  const int ms_last = p.B * p.T_in - 1;              // (a short last tile: the source rows behind it are read, never used)
 
   // ---- requests, oldest first: halo rows, bias, the tile's 64 source rows, first weights ----
   constexpr int HITEMS = CIN / 2;
@@ -410,7 +460,7 @@ __global__ __launch_bounds__(NT) void k_conv3u(const GemmParams p) {
   if (tid < HITEMS) {
     const int pl = tid / (CIN / 4), rem = tid - pl * (CIN / 4), which = rem / (CIN / 8), piece = rem - which * (CIN / 8);
     const int ch = piece * 8, c = piece >> 3, slot = piece & 7;
-    const bool ok = which == 0 ? (t0 + BMU < p.T_out) : (t0 > 0);               // which 0: source row ms0 + 64 (LDS row 64), 1: row ms0 - 1 (LDS row 65)
+    const bool ok = which == 0 ? (ts0 + 64 < p.Tv_in) : (t0 > 0);               // which 0: source row ms0 + 64 (LDS row 64), 1: row ms0 - 1 (LDS row 65); frames that exist
     const long srow = which == 0 ? (long)ms0 + 64 : (long)ms0 - 1;
     const bool first = ch < c0;
     const bf16_t* src = first ? (pl ? sg.a0_lo : sg.a0_hi) : (pl ? sg.a1_lo : sg.a1_hi);
@@ -425,7 +475,7 @@ __global__ __launch_bounds__(NT) void k_conv3u(const GemmParams p) {
     for (int c = 0; c < G::NCH; ++c) {
       const int cb = c * 64;
       const bool first = cb < c0;
-      const size_t e = (size_t)(ms0 + row) * (first ? c0 : c1) + (first ? cb : cb - c0) + sc8;
+      const size_t e = (size_t)min(ms0 + row, ms_last) * (first ? c0 : c1) + (first ? cb : cb - c0) + sc8;
       const unsigned dst = a_base + (unsigned)(c * CHP + wave * 1024);
       glds16((first ? sg.a0_hi : sg.a1_hi) + e, dst);
       glds16((first ? sg.a0_lo : sg.a1_lo) + e, dst + G::A_PL);
@@ -447,6 +497,17 @@ __global__ __launch_bounds__(NT) void k_conv3u(const GemmParams p) {
   if (h_dst >= 0) *reinterpret_cast<uint4*>(smem + h_dst) = hv;
   DV_C3TRACE(1);
   wait_vmcnt<2 * G::DEPTH>();                        // everything older than the weight units: the source rows have landed
+  {
+    // padded row space (see k_conv3): the first source frame that does not exist is cleared by the wave that brought it
+    const int zr = p.Tv_in - ts0;
+    if (zr < 64 && (zr >> 3) == wave && (lane >> 3) == (zr & 7)) {
+#pragma unroll
+      for (int c = 0; c < G::NCH; ++c) {
+        *reinterpret_cast<uint4*>(smem + c * CHP + wave * 1024 + lane * 16) = make_uint4(0u, 0u, 0u, 0u);
+        *reinterpret_cast<uint4*>(smem + G::A_PL + c * CHP + wave * 1024 + lane * 16) = make_uint4(0u, 0u, 0u, 0u);
+      }
+    }
+  }
   __syncthreads();
   DV_C3TRACE(2);
 
@@ -525,23 +586,33 @@ __global__ __launch_bounds__(NT) void k_conv3u(const GemmParams p) {
   DV_C3TRACE(4);
 
   // ---- epilogue of the fragment: vv[4g + e] = column n0 + 32 e_wn + 8g + 4lh + e of row m0 + 32 e_wm + l31 ----
+  // (padded row space: a fragment beyond the tile's rows belongs to the next utterance and is not touched; rows that do not exist
+  // are stored as zeros and kept out of the statistics - conv3_finish)
   const bool gnx_h = p.gnx.xchg != nullptr;
   const int ncol0 = n0 + e_wn * 32;
   const int m = m0 + e_wm * 32 + l31, mrow0 = m0 + e_wm * 32;
+  const bool live = e_wm * 32 < tl.rows;             // (wave-uniform)
+  const bool padded = p.Tv_out != p.T_out;
+  const int tfr = t0 + e_wm * 32;
+  const bool m_ok = tfr + l31 < p.Tv_out;
 #pragma unroll
   for (int g = 0; g < 4; ++g) {
     const float4 b4 = *reinterpret_cast<const float4*>(s_bias + e_wn * 32 + 4 * lh + 8 * g);
     vv[4 * g] += b4.x; vv[4 * g + 1] += b4.y; vv[4 * g + 2] += b4.z; vv[4 * g + 3] += b4.w;
   }
   if (p.epi == EPI_RESIDUAL) {
-    const float* rp = p.res + (size_t)m * p.ldres + ncol0 + 4 * lh;
+    const float* rp = p.res + (size_t)min(m, p.M - 1) * p.ldres + ncol0 + 4 * lh;
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
       const float4 a = *reinterpret_cast<const float4*>(rp + 8 * g);
       vv[4 * g] += a.x; vv[4 * g + 1] += a.y; vv[4 * g + 2] += a.z; vv[4 * g + 3] += a.w;
     }
   }
-  {
+  if (padded) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) vv[r] = m_ok ? vv[r] : 0.f;
+  }
+  if (live) {
     const size_t ob = (size_t)m * p.ldo + ncol0;
     if (p.out) {
 #pragma unroll
@@ -551,16 +622,17 @@ __global__ __launch_bounds__(NT) void k_conv3u(const GemmParams p) {
     if (p.out_hi) store_planes16(p.out_hi, p.out_lo, ob, lh, vv);
   }
   DV_C3TRACE(5);
-  if (p.stats16) {
+  if (p.stats16 && live) {
     // per (32-row, 16-column) block: (sum, squared deviations from the block's own mean); registers 0-7 / 8-15 are the fragment's
     // first / second 16 columns
     float a1[2] = {0.f, 0.f}, a2[2] = {0.f, 0.f};
 #pragma unroll
     for (int r = 0; r < 16; ++r) a1[r >> 3] += vv[r];
     a1[0] = wave_sum64(a1[0]); a1[1] = wave_sum64(a1[1]);
-    const float mb[2] = {a1[0] * (1.0f / 512.0f), a1[1] * (1.0f / 512.0f)};
+    const float inv = padded ? 1.0f / (float)(16 * min(32, p.Tv_out - tfr)) : (1.0f / 512.0f);
+    const float mb[2] = {a1[0] * inv, a1[1] * inv};
 #pragma unroll
-    for (int r = 0; r < 16; ++r) { const float dv = vv[r] - mb[r >> 3]; a2[r >> 3] = fmaf(dv, dv, a2[r >> 3]); }
+    for (int r = 0; r < 16; ++r) { const float dv = (!padded || m_ok) ? vv[r] - mb[r >> 3] : 0.f; a2[r >> 3] = fmaf(dv, dv, a2[r >> 3]); }
     a2[0] = wave_sum64(a2[0]); a2[1] = wave_sum64(a2[1]);
     if (lane < 2) {
       const size_t e = (size_t)(mrow0 >> 5) * (p.N >> 4) + (ncol0 >> 4) + lane;
@@ -574,8 +646,8 @@ __global__ __launch_bounds__(NT) void k_conv3u(const GemmParams p) {
   DV_C3TRACE(6);
   if (gnx_h) {
     GnxTile t;
-    t.M = p.M; t.N = p.N; t.T_out = p.T_out; t.Tv_out = p.Tv_out; t.m0 = m0; t.n0 = n0; t.bm = BMU; t.bn = BN;
-    t.bq = (int)__umulhi((unsigned)m0, p.tout_magic);
+    t.M = p.M; t.N = p.N; t.T_out = p.T_out; t.Tv_out = p.Tv_out; t.m0 = m0; t.n0 = n0; t.bm = tl.rows; t.bn = BN;
+    t.bq = tl.bq;
     gnx_finish_table<BN>(p.gnx, t, s_gnx, tid, lane, wave, NWV, [&](int) {});
     DV_C3TRACE(7);
     float y[16];
@@ -591,7 +663,11 @@ __global__ __launch_bounds__(NT) void k_conv3u(const GemmParams p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) y[r] = y[r] * __builtin_amdgcn_rcpf(1.0f + __expf(-y[r]));
     }
-    store_planes16(p.gnx.y_hi, p.gnx.y_lo, (size_t)m * p.N + ncol0, lh, y);
+    if (padded) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) y[r] = m_ok ? y[r] : 0.f;
+    }
+    if (live) store_planes16(p.gnx.y_hi, p.gnx.y_lo, (size_t)m * p.N + ncol0, lh, y);
   }
   DV_C3TRACE(8);
 }
@@ -626,7 +702,8 @@ namespace {
 constexpr int RS = 8;                                // ring slots
 constexpr int SLOT_PL = BM * 128, SLOT = 2 * SLOT_PL;   // one plane / both planes of a 64-channel chunk: 16 KiB per slot
 constexpr int S_HALO = RS * SLOT;                    // halo rows: [16 chunks][row m0 + 64 | row m0 - 1][128 B], the lo plane SLOT_PL further on
-constexpr int S_TOTAL = S_HALO + SLOT_PL + 4096;
+constexpr int S_ZERO = S_HALO + 4096;                // 128 bytes of zeros (the lo plane's SLOT_PL further on, like everything else)
+constexpr int S_TOTAL = S_HALO + SLOT_PL + 4096 + 256;
 constexpr int DWS = 6;                               // weight units in flight per wave
 constexpr int NT_S = NT + 64;                        // + the producer wave
 static_assert(S_TOTAL + 4096 <= 160 * 1024 && RED_BYTES <= RS * SLOT && RS == 8, "ring geometry");
@@ -643,8 +720,10 @@ __global__ __launch_bounds__(NT_S) void k_conv3s(const GemmParams p) {
   const int c0 = sg.c0, c1 = sg.c1, CIN = c0 + c1;
   const int d0 = p.nseg > 1 ? sh.c0 : 0, d1 = p.nseg > 1 ? sh.c1 : 0;   // the one-tap segment's channels (0: none)
   DV_C3TRACE(0);
-  int m0, n0, ksel;
-  conv3_tile(p, m0, n0, ksel);
+  C3Tile tl;
+  conv3_tile(p, tl, BM);
+  const int m0 = tl.m0, n0 = tl.n0, ksel = tl.ksel, t0 = tl.t0;
+  const int rmax = min(BM - 1, p.M - 1 - m0);        // last tile row that is inside the tensor (a short last tile: the rows behind it are read, never used)
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const unsigned a_base = (unsigned)(size_t)smem;
   const int NCH_ALL = CIN >> 6, KPT = CIN >> 4;      // three-tap chunks of the whole contraction (even); 16-deep k-steps per tap
@@ -675,10 +754,9 @@ __global__ __launch_bounds__(NT_S) void k_conv3s(const GemmParams p) {
       const bf16_t* bl = seg0 ? (first ? sg.a0_lo : sg.a1_lo) : (first ? sh.a0_lo : sh.a1_lo);
       const size_t col = (size_t)(first ? cb : cb - e0);
       const unsigned dst = a_base + (unsigned)((cc & (RS - 1)) * SLOT);
-      const unsigned v0 = (unsigned)((size_t)(m0 + lr) * ld * 2);
 #pragma unroll
       for (int r8 = 0; r8 < 8; ++r8) {
-        const unsigned vo = v0 + (unsigned)(r8 * 8 * ld * 2) + ((r8 & 1) ? sw_o : sw_e);
+        const unsigned vo = (unsigned)((m0 + min(lr + 8 * r8, rmax)) * ld * 2) + ((r8 & 1) ? sw_o : sw_e);
         glds16_s(bh + col, vo, dst + r8 * 1024);
         glds16_s(bl + col, vo, dst + SLOT_PL + r8 * 1024);
       }
@@ -719,7 +797,7 @@ __global__ __launch_bounds__(NT_S) void k_conv3s(const GemmParams p) {
   const int e_wn = cf, e_wm = (wave >> 1) & 1, e_half = wave >> 2;   // epilogue role (conv3_finish): this wave's residual rows
   float rpre[8];
   if (p.epi == EPI_RESIDUAL) {
-    const float* rp = p.res + (size_t)(m0 + e_wm * 32 + l31) * p.ldres + n0 + e_wn * 32 + e_half * 16 + 4 * lh;
+    const float* rp = p.res + (size_t)(m0 + min(e_wm * 32 + l31, rmax)) * p.ldres + n0 + e_wn * 32 + e_half * 16 + 4 * lh;
 #pragma unroll
     for (int g = 0; g < 2; ++g) {
       const float4 a = *reinterpret_cast<const float4*>(rp + 8 * g);
@@ -729,15 +807,16 @@ __global__ __launch_bounds__(NT_S) void k_conv3s(const GemmParams p) {
   {
     // halo rows: one instruction per wave = one plane of four chunks, lane = (chunk, row m0 + 64 | row m0 - 1, 16-byte slot); rows
     // beyond the utterance's ends and chunks beyond the last come from the zero page
-    const int t0 = m0 - (int)__umulhi((unsigned)m0, p.tout_magic) * p.T_out;   // frame of the tile's first row inside its utterance
     const int pl = wave & 1, c = (wave >> 1) * 4 + (lane >> 4), which = (lane >> 3) & 1, slot = lane & 7;
-    const bool ok = c < NCH_ALL && (which == 0 ? (t0 + BM < p.T_out) : (t0 > 0));
+    const bool ok = c < NCH_ALL && (which == 0 ? (t0 + BM < p.Tv_out) : (t0 > 0));   // (frames that exist)
     const long srow = which == 0 ? (long)m0 + BM : (long)m0 - 1;
     const int ch = c * 64 + slot * 8;
     const bool first = ch < c0;
     const bf16_t* src = first ? (pl ? sg.a0_lo : sg.a0_hi) : (pl ? sg.a1_lo : sg.a1_hi);
     const void* g = ok ? (const void*)(src + (size_t)srow * (first ? c0 : c1) + (first ? ch : ch - c0)) : (const void*)p.zero_page;
     glds16(g, a_base + (unsigned)(S_HALO + pl * SLOT_PL + (wave >> 1) * 1024));
+    // (a row of zeros per plane: what the lanes of the first frame that does not exist read - see rb / sm below)
+    if (wave == 0 && lane < 16) *reinterpret_cast<uint4*>(smem + S_ZERO + (lane >> 3) * SLOT_PL + (lane & 7) * 16) = make_uint4(0u, 0u, 0u, 0u);
     // chunks 0 and 1 (both of the three-tap segment: NCH >= 2): wave w brings rows 8w .. 8w + 7, both planes
     const int d_row = wave * 8 + (lane >> 3);
     const unsigned d_sc = (unsigned)(((lane & 7) ^ swz(d_row)) << 4);
@@ -745,7 +824,7 @@ __global__ __launch_bounds__(NT_S) void k_conv3s(const GemmParams p) {
     for (int cc = 0; cc < 2; ++cc) {
       const int cb = (CA + cc) * 64;
       const bool f0 = cb < c0;
-      const unsigned vo = (unsigned)((size_t)(m0 + d_row) * (f0 ? c0 : c1) * 2) + d_sc;
+      const unsigned vo = (unsigned)((size_t)(m0 + min(d_row, rmax)) * (f0 ? c0 : c1) * 2) + d_sc;
       const unsigned dst = a_base + (unsigned)(cc * SLOT + wave * 1024);
       glds16_s((f0 ? sg.a0_hi : sg.a1_hi) + (f0 ? cb : cb - c0), vo, dst);
       glds16_s((f0 ? sg.a0_lo : sg.a1_lo) + (f0 ? cb : cb - c0), vo, dst + SLOT_PL);
@@ -778,15 +857,21 @@ __global__ __launch_bounds__(NT_S) void k_conv3s(const GemmParams p) {
 
   // operand reads: LDS byte offset of (row fragment rf, tap) inside a slot for this lane - frame rf * 32 + l31 + tap - 1, k-step kq
   // of the chunk, half lh - or, for the one lane pair whose frame is the row before / behind the tile, inside the halo area
-  int rb[2][3];
+  // Padded row space: the first frame that does not exist (tile row zr = Tv_out - t0, when it lies inside the tile) is read by the
+  // +1 tap of the last one that does and must be zeros - whatever its producers wrote there: the lane that would read it reads the
+  // row of zeros instead (sm = 0: no slot / halo offset is added).  Nothing else of the padding is ever used.
+  const int zr = p.Tv_out - t0;
+  int rb[2][3], sm[2][3];
   bool hs[2][3];
 #pragma unroll
   for (int rf = 0; rf < 2; ++rf)
 #pragma unroll
     for (int tap = 0; tap < 3; ++tap) {
       const int idx = rf * 32 + l31 + tap - 1, c16 = kq * 2 + lh;
+      const bool zero = idx == zr && zr < BM;
       hs[rf][tap] = idx < 0 || idx >= BM;
-      rb[rf][tap] = hs[rf][tap] ? S_HALO + (idx < 0 ? 128 : 0) + (c16 << 4) : idx * 128 + ((c16 ^ swz(idx)) << 4);
+      rb[rf][tap] = zero ? S_ZERO + (c16 << 4) : hs[rf][tap] ? S_HALO + (idx < 0 ? 128 : 0) + (c16 << 4) : idx * 128 + ((c16 ^ swz(idx)) << 4);
+      sm[rf][tap] = zero ? 0 : -1;
     }
   f32x16 acc[2];
 #pragma unroll
@@ -800,7 +885,7 @@ __global__ __launch_bounds__(NT_S) void k_conv3s(const GemmParams p) {
     for (int rf = 0; rf < 2; ++rf) {
       // (only (rf 0, tap 0) and (rf 1, tap 2) have a halo lane pair: the select folds away elsewhere)
       const bool any_halo = (rf == 0 && t == 0) || (rf == 1 && t == 2);
-      const int off = rb[rf][t] + ((any_halo && hs[rf][t]) ? s_halo : s_slot);
+      const int off = rb[rf][t] + (((any_halo && hs[rf][t]) ? s_halo : s_slot) & sm[rf][t]);
       h[rf] = *reinterpret_cast<const bf16x8*>(smem + off);
       l[rf] = *reinterpret_cast<const bf16x8*>(smem + off + SLOT_PL);
     }
@@ -863,7 +948,7 @@ __global__ __launch_bounds__(NT_S) void k_conv3s(const GemmParams p) {
     if (j2 + 2 < NS2) pair(j2 + 2, std::integral_constant<int, 2>{});
   }
   DV_C3TRACE(3);
-  conv3_finish(p, smem, s_bias, s_gnx, acc, rpre, m0, n0, tid, lane, wave, CIN, ksel);
+  conv3_finish(p, smem, s_bias, s_gnx, acc, rpre, tl, tid, lane, wave, CIN);
 }
 
 // ---- host side ----
@@ -876,9 +961,9 @@ void conv3_env_refresh() {
 static const bool g_conv3_env_once = [] { conv3_env_refresh(); return true; }();
 
 // Shapes these kernels take (everything else stays with k_gemm): one 3-tap segment over 128 .. 1024 input channels in steps of 128
-// (one tensor or the concatenation of two, each a multiple of 64 channels), stride 1, no resampling, no padded row space, whole
-// 64 x 64 tiles that never span two utterances, the plain / residual epilogue without LayerNorm, column-slab statistics, ReLU or
-// row mask.
+// (one tensor or the concatenation of two, each a multiple of 64 channels), stride 1, no resampling, a row pitch of whole 32-frame
+// blocks (padded row spaces included: Tv_out <= T_out frames exist; the row tiles are laid out per utterance - C3Tile), the plain /
+// residual epilogue without LayerNorm, column-slab statistics, ReLU or row mask.
 bool gemm_conv3_shape_ok(const GemmParams& p) {
   if (!g_conv3_on || p.nseg < 1 || p.nseg > 2 || p.seg[0].taps != 3 || p.seg[0].pad != 1 || p.stride != 1 || p.up_mode != UP_NONE) return false;
   const int cin = p.seg[0].c0 + p.seg[0].c1;
@@ -888,12 +973,15 @@ bool gemm_conv3_shape_ok(const GemmParams& p) {
     const GemmSeg& s1 = p.seg[1];
     if (s1.taps != 1 || s1.pad != 0 || s1.c0 <= 0 || s1.c0 % 64 != 0 || s1.c1 % 64 != 0 || (s1.c1 > 0 && !s1.a1_hi) || s1.c0 + s1.c1 > 2048) return false;
   }
-  if (p.T_in != p.T_out || p.T_virt != p.T_out || (p.Tv_out > 0 && p.Tv_out != p.T_out) || (p.Tv_in > 0 && p.Tv_in != p.T_in)) return false;
-  if (p.T_out % BM != 0 || p.M % BM != 0 || p.N % BN != 0 || p.B <= 0 || p.M != p.B * p.T_out) return false;
+  const int tv_out = p.Tv_out > 0 ? p.Tv_out : p.T_out, tv_in = p.Tv_in > 0 ? p.Tv_in : p.T_in;
+  if (p.T_in != p.T_out || tv_in != tv_out || p.T_virt != tv_out || tv_out > p.T_out || tv_out <= p.T_out - 32) return false;
+  if (p.T_out % 32 != 0 || p.N % BN != 0 || p.B <= 0 || p.M != p.B * p.T_out) return false;
   if ((p.epi != EPI_STORE && p.epi != EPI_RESIDUAL) || p.stats || p.rowstat_out || p.ln_stat || p.relu || p.rowmask) return false;
   if ((p.ldo & 7) != 0 || (p.epi == EPI_RESIDUAL && (p.ldres & 3) != 0) || p.force_tile != GT_AUTO) return false;
   return true;
 }
+// row tiles of such a launch (64 rows; 128 output rows for the upsampling form): per utterance, the last one may be short
+int gemm_conv3_row_tiles(const GemmParams& p, int bm) { return p.B * ((p.T_out + bm - 1) / bm); }
 // Fused split-K pair on the streaming kernel (GemmParams sk_buf / sk_ticket, sk_split 2): 2 when the launch should run as two
 // workgroups per tile - at most half the CUs' worth of tiles and a k-loop of at least eight steps (the 128-frame level's
 // K >= 1920 convolutions: 128 tiles) - else 0.  The three-tap list must split into two even halves.
@@ -902,17 +990,20 @@ int gemm_conv3_split(const GemmParams& p, int n_cu) {
   if (!on || n_cu <= 0 || !gemm_conv3_shape_ok(p)) return 0;
   const int cin = p.seg[0].c0 + p.seg[0].c1, nch = cin >> 6, nc2 = p.nseg > 1 ? (p.seg[1].c0 + p.seg[1].c1) >> 6 : 0;
   if (cin <= 512 && cin <= g_conv3_stream && p.nseg == 1) return 0;       // (the resident kernel has no split form)
-  if (2 * (p.M / BM) * (p.N / BN) > n_cu || nch < 4 || nch + ((nc2 + 1) >> 1) < 8) return 0;
+  if (2 * gemm_conv3_row_tiles(p, BM) * (p.N / BN) > n_cu || nch < 4 || nch + ((nc2 + 1) >> 1) < 8) return 0;
   return 2;
 }
+// scratch of such a pair: the half-fragment sums of every tile (the short tiles of a padded row space included)
+size_t gemm_conv3_split_bytes(const GemmParams& p) { return (size_t)2 * gemm_conv3_row_tiles(p, BM) * (p.N / BN) * BM * BN * sizeof(float); }
 // ... and the upsampling form (k_conv3u): nearest x2 folded into the row gather, 128 x 64 tiles, the widths the resident image fits
 bool gemm_conv3_up_ok(const GemmParams& p) {
   if (!g_conv3_on || p.nseg != 1 || p.seg[0].taps != 3 || p.seg[0].pad != 1 || p.stride != 1 || p.up_mode != UP_X2) return false;
   const int cin = p.seg[0].c0 + p.seg[0].c1;
   if (cin != 128 && cin != 256 && cin != 384 && cin != 512) return false;
   if (p.seg[0].c0 % 64 != 0 || p.seg[0].c1 % 64 != 0 || (p.seg[0].c1 > 0 && !p.seg[0].a1_hi)) return false;
-  if (p.T_out != 2 * p.T_in || p.T_virt != p.T_out || (p.Tv_out > 0 && p.Tv_out != p.T_out) || (p.Tv_in > 0 && p.Tv_in != p.T_in)) return false;
-  if (p.T_out % BMU != 0 || p.M % BMU != 0 || p.N % BN != 0 || p.B <= 0 || p.M != p.B * p.T_out) return false;
+  const int tv_out = p.Tv_out > 0 ? p.Tv_out : p.T_out, tv_in = p.Tv_in > 0 ? p.Tv_in : p.T_in;
+  if (tv_out != 2 * tv_in || p.T_virt != tv_out || tv_out > p.T_out || tv_out <= p.T_out - 32 || tv_in > p.T_in) return false;
+  if (p.T_out % 32 != 0 || p.N % BN != 0 || p.B <= 0 || p.M != p.B * p.T_out) return false;
   if ((p.epi != EPI_STORE && p.epi != EPI_RESIDUAL) || p.stats || p.rowstat_out || p.ln_stat || p.relu || p.rowmask) return false;
   if ((p.ldo & 7) != 0 || (p.epi == EPI_RESIDUAL && (p.ldres & 3) != 0) || p.force_tile != GT_AUTO || p.sk_buf) return false;
   return true;
@@ -921,11 +1012,16 @@ bool gemm_conv3_up_ok(const GemmParams& p) {
 int gemm_conv3_k(const GemmParams& p) {
   return 3 * (p.seg[0].c0 + p.seg[0].c1) + (p.nseg > 1 ? p.seg[1].c0 + p.seg[1].c1 : 0);
 }
+// the per-utterance row-tile geometry of a launch (GemmParams c3_tu / c3_tu_magic)
+static void conv3_geometry(GemmParams& p, int bm) {
+  p.c3_tu = (p.T_out + bm - 1) / bm;
+  p.c3_tu_magic = p.c3_tu <= 1 ? 0u : (unsigned)(((1ull << 32) + (unsigned)p.c3_tu - 1) / (unsigned)p.c3_tu);
+}
 
 template <int CIN>
 static hipError_t conv3_launch(const GemmParams& p, hipStream_t st) {
   constexpr int smem = ConvGeom<CIN>::SMEM;
-  hipLaunchKernelGGL((k_conv3<CIN>), dim3((p.M / BM) * (p.N / BN)), dim3(NT), smem, st, p);
+  hipLaunchKernelGGL((k_conv3<CIN>), dim3(gemm_conv3_row_tiles(p, BM) * (p.N / BN)), dim3(NT), smem, st, p);
   return hipGetLastError();
 }
 template <int CIN>
@@ -939,11 +1035,16 @@ static hipError_t conv3u_attr() {
 template <int CIN>
 static hipError_t conv3u_launch(const GemmParams& p, hipStream_t st) {
   constexpr int smem = ConvGeomU<CIN>::SMEM;
-  hipLaunchKernelGGL((k_conv3u<CIN>), dim3((p.M / BMU) * (p.N / BN)), dim3(NT), smem, st, p);
+  hipLaunchKernelGGL((k_conv3u<CIN>), dim3(gemm_conv3_row_tiles(p, BMU) * (p.N / BN)), dim3(NT), smem, st, p);
   return hipGetLastError();
 }
-hipError_t launch_conv3_up(const GemmParams& p, hipStream_t st) {
+hipError_t launch_conv3_up(const GemmParams& pin, hipStream_t st) {
+  GemmParams p = pin;
   if (!p.wf_hi || !p.wf_lo || !gemm_conv3_up_ok(p) || p.Kp != 3 * (p.seg[0].c0 + p.seg[0].c1) || p.sk_mode != 0) return hipErrorInvalidValue;
+  if (p.Tv_out <= 0) p.Tv_out = p.T_out;
+  if (p.Tv_in <= 0) p.Tv_in = p.T_in;
+  conv3_geometry(p, BMU);
+  if (p.xcd_n > 0) p.xcd_n = 0;                      // (row bands; launch_gemm's rectangle belongs to another tile)
   switch (p.seg[0].c0 + p.seg[0].c1) {
     case 128: return conv3u_launch<128>(p, st);
     case 256: return conv3u_launch<256>(p, st);
@@ -964,16 +1065,21 @@ hipError_t conv3_init() {
   return conv3_attr<512>();
 }
 // (called by launch_gemm with p validated, tout_magic and the XCD rectangle of the 64x64 tile grid set)
-hipError_t launch_conv3(const GemmParams& p, hipStream_t st) {
+hipError_t launch_conv3(const GemmParams& pin, hipStream_t st) {
+  GemmParams p = pin;
   if (!p.wf_hi || !p.wf_lo || !gemm_conv3_shape_ok(p) || p.Kp != gemm_conv3_k(p) || (p.sk_mode != 0 && p.sk_mode != 3)) return hipErrorInvalidValue;
+  if (p.Tv_out <= 0) p.Tv_out = p.T_out;
+  if (p.Tv_in <= 0) p.Tv_in = p.T_in;
+  conv3_geometry(p, BM);
+  const int tiles = gemm_conv3_row_tiles(p, BM) * (p.N / BN);
   if (p.sk_mode == 3) {
     if (!p.sk_buf || !p.sk_ticket || p.sk_split != 2 || p.seg[0].c0 + p.seg[0].c1 < 256) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(k_conv3s, dim3(2 * (p.M / BM) * (p.N / BN)), dim3(NT_S), S_TOTAL, st, p);
+    hipLaunchKernelGGL(k_conv3s, dim3(2 * tiles), dim3(NT_S), S_TOTAL, st, p);
     return hipGetLastError();
   }
   const int cin = p.seg[0].c0 + p.seg[0].c1;
   if (cin > 512 || cin > g_conv3_stream || p.nseg > 1) {
-    hipLaunchKernelGGL(k_conv3s, dim3((p.M / BM) * (p.N / BN)), dim3(NT_S), S_TOTAL, st, p);
+    hipLaunchKernelGGL(k_conv3s, dim3(tiles), dim3(NT_S), S_TOTAL, st, p);
     return hipGetLastError();
   }
   switch (cin) {

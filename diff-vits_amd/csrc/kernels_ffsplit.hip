@@ -592,7 +592,10 @@ int ff_split_gnx_plan(const FFSplitParams& p, int n_cu) {
   if (!p.stats16 || gx.groups <= 0 || gx.groups > 64 || gx.sk_c < 0 || gx.sk_c % 16 != 0 || gx.tscale) return 0;
   if ((p.C + gx.sk_c) % gx.groups != 0) return 0;
   const int cpg = (p.C + gx.sk_c) / gx.groups;
-  if (cpg % 16 != 0 || (p.T / 32) * (cpg / 16) > 256 || (p.M / p.rows) * p.nspl > n_cu) return 0;
+  // (workgroup id = row block * nspl + slice, plain order: an utterance's workgroups are consecutive ids, spread evenly over the
+  // XCDs - with the launch-by-rounds rule of gemm_gnx_plan the bound is one utterance's workgroups, not the grid)
+  const int wg_wait = gemm_handover_rounds() ? (p.T / p.rows) * p.nspl : (p.M / p.rows) * p.nspl;
+  if (cpg % 16 != 0 || (p.T / 32) * (cpg / 16) > 256 || wg_wait > n_cu) return 0;
   if (gx.sk_c > 0 && ((gx.sk_c / 16 + p.nspl - 1) / p.nspl) * 16 > DV_GSK) return 0;   // skip slice per workgroup
   return (p.M / 32) * (p.C / 16);
 }
@@ -603,7 +606,9 @@ hipError_t launch_ff_split(const FFSplitParams& p, int precision, hipStream_t st
       !p.flags || !p.status || (p.out_hi && !p.out_lo))
     return hipErrorInvalidValue;
   static const int n_cu = [] { int d = 0, n = 0; (void)hipGetDevice(&d); (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, d); return n; }();
-  if ((p.M / p.rows) * p.nspl > n_cu) return hipErrorInvalidValue;       // (every workgroup of the launch resident at once)
+  // (the partial-sum hand-over waits for the nspl <= 8 workgroups of its own row block - consecutive ids; kernels_gemm.hip
+  // gemm_handover_rounds - else every workgroup of the launch resident at once)
+  if (!gemm_handover_rounds() && (p.M / p.rows) * p.nspl > n_cu) return hipErrorInvalidValue;
   if (p.gnx.xchg) {
     if (!p.gnx.status || !p.gnx.y_hi || !p.gnx.y_lo || !p.gnx.gamma || !p.gnx.beta || ff_split_gnx_plan(p, n_cu) <= 0) return hipErrorInvalidValue;
     if (p.gnx.sk_c > 0 && (!p.gnx.sk_x || !p.gnx.sk_stat16 || !p.gnx.sk_y_hi || !p.gnx.sk_y_lo)) return hipErrorInvalidValue;

@@ -246,25 +246,79 @@ static void gemm_pick_tile(const GemmParams& p, int& bm, int& bn) {
   bm = 32; bn = 32;
 }
 
+// XCD rectangle of a tm x tn tile grid run as xs k-slices (fills p.xcd_*; xcd_n = 0: row bands of the tile grid)
+static void gemm_xcd_rect(GemmParams& p, int tm, int tn, int xs) {
+  const int env_xn = g_env_xn;
+  long chans = 0, ktot = 0;
+  for (int s2 = 0; s2 < p.nseg; ++s2) { chans += p.seg[s2].c0 + p.seg[s2].c1; ktot += (long)p.seg[s2].taps * (p.seg[s2].c0 + p.seg[s2].c1); }
+  double best = 0; int best_xn = 0;
+  p.xcd_n = 0;
+  for (int xn = 1; xn * xs <= 8; xn *= 2) {
+    const int xm = 8 / (xs * xn);
+    if ((tm * tn * xs) % 8 != 0 || tm % xm != 0 || tn % xn != 0 || (xs != 1 && xs != 2)) continue;
+    if (env_xn >= 0 && xn != env_xn) continue;
+    const double cost = (double)p.N / xn * ktot + (double)p.M / xm * chans;
+    if (best_xn == 0 || cost < best * 0.97) { best = cost; best_xn = xn; }
+  }
+  if (env_xn != 0 && best_xn > 0 && tm * tn * xs / 8 <= 1024) {
+    const int xm = 8 / (xs * best_xn);
+    auto lg2 = [](int v) { int s2 = 0; while ((1 << s2) < v) ++s2; return s2; };
+    p.xcd_n = best_xn; p.xcd_sh_n = lg2(best_xn); p.xcd_sh_mn = lg2(xm * best_xn);
+    p.xcd_tn = tn / best_xn; p.xcd_tm = tm / xm; p.xcd_inv_tn = (65536 + p.xcd_tn - 1) / p.xcd_tn;
+  }
+}
+// Most workgroups of ONE utterance that one XCD runs under the order the kernels map workgroup ids to tiles in (the rectangle / the
+// row bands above): tu row tiles per utterance, tm x tn tiles in all.  Workgroup b runs on XCD b % 8 and an XCD starts its workgroups
+// in id order; both mappings walk an XCD's tiles utterance by utterance.
+static int gemm_utt_tiles_per_xcd(const GemmParams& p, int tu, int tm, int tn) {
+  if (p.xcd_n > 0) return (tu < p.xcd_tm ? tu : p.xcd_tm) * p.xcd_tn;
+  const int q = (tm * tn + 7) / 8;                   // band of an XCD (row-major tiles)
+  return tu * tn < q ? tu * tn : q;
+}
+
+// In-launch hand-overs that WAIT (the GroupNorm exchange here, k_ff_split's partial sums) need the partners of a waiting workgroup
+// on the chip.  Rounds 2-5 asked for the whole grid to be resident (grid <= CUs): B = 16 or T = 2048 batches fell back to separate
+// GroupNorm launches.  What is actually needed is less: workgroup b runs on XCD b % 8 and every XCD starts its workgroups in id
+// order, a workgroup only waits for workgroups of ITS OWN utterance, and the kernels walk an XCD's tiles utterance by utterance - so
+// the unfinished utterance at the head of an XCD's list is always fully started as long as its share of ONE utterance fits the
+// XCD's CUs (one workgroup per CU is always possible), whatever the size of the grid: the utterances behind it simply run in later
+// rounds.  [The time-outs round 2 found at 2 x 192 workgroups were this rule broken - 48 tiles of one utterance on one XCD of 32
+// CUs - not the grid size.]  DVITS_GNX_ROUNDS=0 restores "whole grid resident".  The waits stay bounded and flagged either way.
+bool gemm_handover_rounds() {
+  static const bool on = [] { const char* e = getenv("DVITS_GNX_ROUNDS"); return !(e && e[0] == '0'); }();
+  return on;
+}
 int gemm_gnx_plan(const GemmParams& p, int n_cu) {
   if (p.force_tile != GT_AUTO || (p.epi != EPI_STORE && p.epi != EPI_RESIDUAL) || !p.stats16 || p.rowmask || p.relu) return 0;
   const int skc = p.gnx.sk_c;                          // concatenated consumer: groups of [output | skip]
   if (p.M != p.B * p.T_out || p.gnx.groups <= 0 || p.gnx.groups > 64 || skc < 0 || (p.N + skc) % p.gnx.groups != 0) return 0;
   const int cpg = (p.N + skc) / p.gnx.groups;
   if (cpg % 16 != 0 || p.N % 16 != 0 || skc % 16 != 0) return 0;
-  int bm, bn;
-  gemm_pick_tile(p, bm, bn);
-  if (p.T_out % bm != 0 || p.N % bn != 0) return 0;
-  if (skc > 0 && ((skc / 16 + p.N / bn - 1) / (p.N / bn)) * 16 > 128) return 0;   // skip slice per workgroup (gemm_tile.h GSK)
+  int bm, bn, tu;
+  if (p.c3_route) {                                    // the convolution kernels: row tiles per utterance, the last one may be short
+    bm = p.c3_route == 2 ? 128 : 64; bn = 64;
+    if (p.T_out % 32 != 0 || p.N % bn != 0) return 0;
+    tu = (p.T_out + bm - 1) / bm;
+  } else {
+    gemm_pick_tile(p, bm, bn);
+    if (p.T_out % bm != 0 || p.N % bn != 0) return 0;
+    tu = p.T_out / bm;
+  }
+  if (skc > 0 && ((skc / 16 + p.N / bn - 1) / (p.N / bn)) * 16 > 128) return 0;   // skip slice per workgroup (gnx_device.h DV_GSK)
   if ((p.T_out / 32) * (cpg / 16) > 256) return 0;     // entries of one group: four per lane of the reducing wave
-  // Every workgroup of the launch must be resident at once - INCLUDING both halves of a fused split-K pair, although the
-  // first arriver of a pair leaves without waiting: workgroups are bound to XCD id % 8, so a second round could only
-  // start on CUs freed on ITS XCD, and an XCD whose first-round workgroups all happen to be the waiting finishers frees
-  // none (found by the bounded poll at M = 1024, N = 384, 2 x 192 workgroups: flagged time-outs, not a hang).
-  const int tiles = (p.M / bm) * (p.N / bn);
+  const int tm = p.B * tu, tn = p.N / bn, tiles = tm * tn;
   const bool pair = p.sk_buf && p.sk_split == 2 && p.sk_ticket;
   if (p.sk_buf && !pair) return 0;                   // two-launch split-K: not supported with the in-epilogue GroupNorm
-  if ((pair ? 2 * tiles : tiles) > n_cu) return 0;
+  if (pair) {
+    // both halves of a fused split-K pair count, although the first arriver of a pair leaves without waiting; the ids of a pair's
+    // halves are far apart (an XCD holds one k-half): the plain bound
+    if (2 * tiles > n_cu) return 0;
+  } else if (tiles > n_cu) {
+    if (!gemm_handover_rounds() || n_cu < 8) return 0;
+    GemmParams t = p;
+    if (p.c3_route == 2) t.xcd_n = 0; else gemm_xcd_rect(t, tm, tn, 1);
+    if (gemm_utt_tiles_per_xcd(t, tu, tm, tn) > n_cu / 8) return 0;
+  }
   return (p.M / 32) * (p.N / 16);
 }
 
@@ -303,6 +357,12 @@ hipError_t launch_gemm(const GemmParams& pin, int precision, hipStream_t st) {
   if (p.ln_stat && (p.ln_nblk < 1 || p.ln_nblk > 16)) return hipErrorInvalidValue;   // (a row's LayerNorm partials are held in registers: gemm_tile.h)
   for (int s2 = 0; s2 < p.nseg; ++s2)     // (a lane on the zero page walks a row's k-tiles inside it: gemm_tile.h prep_a_next)
     if (2 * (size_t)p.seg[s2].c0 + 256 > DV_ZERO_PAGE_BYTES || 2 * (size_t)p.seg[s2].c1 + 256 > DV_ZERO_PAGE_BYTES) return hipErrorInvalidValue;
+  // which kernel family runs this launch (GemmParams c3_route: the in-launch GroupNorm is planned for ITS tile grid)
+  p.c3_route = 0;
+  if (x3 && p.wf_hi && p.wf_lo) {
+    if (gemm_conv3_shape_ok(p) && p.Kp == gemm_conv3_k(p)) p.c3_route = 1;
+    else if (gemm_conv3_up_ok(p) && p.Kp == 3 * (p.seg[0].c0 + p.seg[0].c1)) p.c3_route = 2;
+  }
   if (p.gnx.xchg && p.sk_mode == 0) {            // (checked once, before the split-K recursion)
     static const int n_cu = [] { int d = 0, n = 0; (void)hipGetDevice(&d); (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, d); return n; }();
     if (!p.gnx.status || !p.gnx.y_hi || !p.gnx.gamma || !p.gnx.beta || gemm_gnx_plan(p, n_cu) <= 0) return hipErrorInvalidValue;
@@ -322,41 +382,21 @@ hipError_t launch_gemm(const GemmParams& pin, int precision, hipStream_t st) {
   if (!p.sk_buf || p.sk_split < 2) { p.sk_buf = nullptr; p.sk_split = 0; p.sk_mode = 0; p.sk_ticket = nullptr; }
   // XCD rectangle (k_gemm): split the columns over xn of the 8 XCDs where that lowers what one L2 has to fetch -
   // (N / xn) x K of W plus (M / xm) x channels of A.  DVITS_XCD_N=<1|2|4|8> forces xn where it divides, 0 = row bands.
+  const bool c3 = p.c3_route == 1 && (p.sk_mode == 0 || p.sk_mode == 3);
   p.xcd_n = 0;
   if (p.force_tile == GT_AUTO) {
-    const int env_xn = g_env_xn;
     int bm, bn;
     gemm_pick_tile(p, bm, bn);
-    const int tm = (p.M + bm - 1) / bm, tn = (p.N + bn - 1) / bn;
+    // (the convolution kernels: 64 x 64 tiles laid out per utterance - kernels_conv.hip C3Tile)
+    const int tm = c3 ? gemm_conv3_row_tiles(p, 64) : (p.M + bm - 1) / bm, tn = c3 ? p.N / 64 : (p.N + bn - 1) / bn;
     const int xs = (p.sk_mode == 1 || p.sk_mode == 3) ? p.sk_split : 1;
-    long chans = 0, ktot = 0;
-    for (int s2 = 0; s2 < p.nseg; ++s2) { chans += p.seg[s2].c0 + p.seg[s2].c1; ktot += (long)p.seg[s2].taps * (p.seg[s2].c0 + p.seg[s2].c1); }
-    double best = 0; int best_xn = 0;
-    for (int xn = 1; xn * xs <= 8; xn *= 2) {
-      const int xm = 8 / (xs * xn);
-      if ((tm * tn * xs) % 8 != 0 || tm % xm != 0 || tn % xn != 0 || (xs != 1 && xs != 2)) continue;
-      if (env_xn >= 0 && xn != env_xn) continue;
-      const double cost = (double)p.N / xn * ktot + (double)p.M / xm * chans;
-      if (best_xn == 0 || cost < best * 0.97) { best = cost; best_xn = xn; }
-    }
-    if (env_xn != 0 && best_xn > 0 && tm * tn * xs / 8 <= 1024) {
-      const int xm = 8 / (xs * best_xn);
-      auto lg2 = [](int v) { int s2 = 0; while ((1 << s2) < v) ++s2; return s2; };
-      p.xcd_n = best_xn; p.xcd_sh_n = lg2(best_xn); p.xcd_sh_mn = lg2(xm * best_xn);
-      p.xcd_tn = tn / best_xn; p.xcd_tm = tm / xm; p.xcd_inv_tn = (65536 + p.xcd_tn - 1) / p.xcd_tn;
-    }
+    gemm_xcd_rect(p, tm, tn, xs);
   }
-  // stride-1 three-tap convolutions whose input channels fit the LDS: the resident-operand kernel (kernels_conv.hip), on the tile
-  // grid / XCD rectangle / exchange-word layout of the 64x64 tile the heuristic would have picked
-  // (the caller - engine.hip conv3_takes - gives the fragment-major weights only where this kernel's 64x64 grid is the better
-  // one: 128-256 tiles by default)
-  if (x3 && p.wf_hi && p.wf_lo && (p.sk_mode == 0 || p.sk_mode == 3) && gemm_conv3_shape_ok(p) && p.Kp == gemm_conv3_k(p)) {
-    int bm, bn;
-    gemm_pick_tile(p, bm, bn);
-    if (bm != 64 || bn != 64) p.xcd_n = 0;           // (the rectangle above was laid out for another tile: plain row bands)
-    return launch_conv3(p, st);
-  }
-  if (x3 && p.wf_hi && p.wf_lo && p.sk_mode == 0 && gemm_conv3_up_ok(p) && p.Kp == 3 * (p.seg[0].c0 + p.seg[0].c1)) return launch_conv3_up(p, st);
+  // stride-1 three-tap convolutions whose input channels fit the LDS: the resident-operand kernel (kernels_conv.hip), on its own
+  // per-utterance 64 x 64 tile grid with k_gemm's XCD rectangle / exchange-word layout
+  // (the caller - engine.hip conv3_takes - gives the fragment-major weights only where this kernel is the better one)
+  if (c3) return launch_conv3(p, st);
+  if (p.c3_route == 2 && p.sk_mode == 0) return launch_conv3_up(p, st);
   const GemmTune& tune = gemm_tune();
   const int big_tiles = ((p.M + 127) / 128) * ((p.N + 127) / 128);
   bool k64 = tune.bk64 != 0;

@@ -899,7 +899,9 @@ def test_resident_operand_convolution_matches_the_ring_kernel(B, T, L):
             os.environ.pop("DVITS_CONV3", None)
             os.environ.pop("DVITS_CONV3_STREAM", None)
     assert resident[0] == 0 and resident[1] >= 12 and resident[2] == resident[1], resident
-    assert launches[1] == launches[0] and launches[2] == launches[0], launches
+    # (the convolution kernels finish their consumer's GroupNorm wherever their per-utterance tile grid allows it - more often
+    # than k_gemm, whose tiles must divide the row pitch: never MORE launches)
+    assert launches[1] <= launches[0] and launches[2] == launches[1], launches
     for k in (1, 2):
         assert np.isfinite(outs[k]).all()
         assert rel_l2(outs[k], outs[0]) < 2e-5, (k, rel_l2(outs[k], outs[0]))
@@ -1666,19 +1668,24 @@ def test_timeout_in_the_last_forward_of_a_loop_without_wait_still_surfaces():
 import gc, os, time
 t = torch.full((B,), 500.0, device="cuda")
 inp = torch.cat([x, cond], 1)
-# (a) destruction
-os.environ["DVITS_GNX_SPIN"] = "-1"
+# (a) destruction: the time-out happens in the LAST forward of the loop (its schedule - another utterance length - was planned
+#     with waits that give up; the earlier forwards run a healthy schedule), nobody calls the engine again
+xb, cb, eb, kb = (torch.from_numpy(a).cuda() for a in synth.make_inputs(1, 80, 128, 40, seed=3))
+tb = torch.full((1,), 300.0, device="cuda")
 m = build()
 eng = m.hip_engine()
-eng.sync_weights(); eng.prepare(B, T, L)
-os.environ.pop("DVITS_GNX_SPIN")
-eng._probation = 0
 with warnings.catch_warnings(record=True) as w, torch.no_grad():
     warnings.simplefilter("always")
+    m(torch.cat([xb, cb], 1), tb, eb, encoder_attention_mask=kb)       # healthy schedule: planned, verified
+    os.environ["DVITS_GNX_SPIN"] = "-1"
+    eng.prepare(B, T, L)
+    os.environ.pop("DVITS_GNX_SPIN")
+    eng._probation = 0
     for k in range(3):
-        y = m(inp, t - k, enc, encoder_attention_mask=mask).sample     # every one of them times out; nobody looks
+        m(torch.cat([xb, cb], 1), tb - k, eb, encoder_attention_mask=kb)
         eng._last_call = time.monotonic()                              # (no pause between the calls)
-    assert eng.unverified_results == 3
+    y = m(inp, t, enc, encoder_attention_mask=mask).sample             # the last one times out; the loop ends without wait()
+    assert eng.unverified_results == 4
     del m, eng
     gc.collect()
 msgs = [str(i.message) for i in w if "INVALID" in str(i.message)]
@@ -1716,3 +1723,63 @@ assert e3.wait()
 print("ok")
 """)
     assert "ok" in out
+
+
+@pytest.mark.parametrize("case,B,T,L,env", [("cfg1", 8, 300, 150, {}), ("cfg1", 3, 300, 77, {"DVITS_CONV3_MIN_TILES": "1"}),
+                                            ("c100", 16, 99, 60, {}), ("cfg1", 16, 1024, 256, {}), ("cfg1", 4, 2048, 100, {}),
+                                            ("cfg1", 5, 1000, 256, {})])
+def test_convolution_kernels_outside_the_round5_window(case, B, T, L, env):
+    """VERDICT r5 #3 / next #1.  Round 5's convolution kernels (k_conv3 / k_conv3s / k_conv3u: reference resnet.py:591-641, 138-187)
+    refused the padded row space (any T that is no multiple of 64 per level) and every grid outside 64-256 tiles: the reference's
+    real call - utterances of arbitrary length (tts_infer.py:46-74), config 5's padded batch (T = 99, C = 100), B = 16 at
+    T = 1024 (512 tiles per launch) - ran ResnetBlock2D on the round-3 ring kernel.  Now their row tiles are laid out per
+    utterance (the last one short, the first frame that does not exist read as zeros) and the in-launch GroupNorm is planned by
+    "one utterance's share of an XCD fits its CUs" instead of "grid <= CUs".  Per shape: by default planning (except the one-tile
+    floor of the 3-utterance case) most GEMM-kind operations run on the convolution kernels, GroupNorms are finished in-launch with
+    no time-out, the result is repeatable bit for bit and matches the oracle at 2e-4 (the UNet is per-sample: the oracle runs the
+    first and the last utterance of the batch)."""
+    from diff_vits_amd import synth
+    from diff_vits_amd.unet1d.unet_1d_condition import UNet1DConditionModel
+    from oracle import unet_ref
+    kw = UNET_CASES[case][0]
+    cx = kw["out_channels"]
+    with torch.device("meta"):
+        shapes = {k: tuple(v.shape) for k, v in UNet1DConditionModel(**kw).state_dict().items()}
+    sd = {k: torch.from_numpy(v) for k, v in synth.make_state_dict(shapes, seed=1234).items()}
+    x = torch.from_numpy(synth.normal(61, "x", (B, cx, T)))
+    cond = torch.from_numpy(synth.normal(61, "c", (B, kw["in_channels"] - cx, T)))
+    enc = torch.from_numpy(synth.normal(61, "e", (B, L, kw["cross_attention_dim"])))
+    mask = torch.ones(B, L, dtype=torch.bool)
+    for b in range(B):
+        mask[b, max(1, L - 3 * b):] = False
+    t = torch.tensor([949.05 - 51.5 * b for b in range(B)])
+    sample = torch.cat([x, cond], 1)
+    pick = [0, B - 1]
+    with torch.no_grad():
+        y_ref = unet_ref.unet_forward(sd, oracle_cfg(kw), sample[pick], t[pick], enc[pick], mask[pick]).numpy()
+    os.environ.update(env)
+    try:
+        m = UNet1DConditionModel(backend="hip", **kw).eval()
+        m.load_state_dict(sd)
+        m = m.cuda()
+        with torch.no_grad():
+            y = m(sample.cuda(), t.cuda(), enc.cuda(), encoder_attention_mask=mask.cuda()).sample
+            y2 = m(sample.cuda(), t.cuda(), enc.cuda(), encoder_attention_mask=mask.cuda()).sample
+        torch.cuda.synchronize()
+        eng = m.hip_engine()
+        n_gnx, bad = eng.handover_status()
+        rows = eng.profile_forward(x.cuda(), cond.cuda(), t.cuda())
+    finally:
+        for k in env:
+            os.environ.pop(k, None)
+    assert torch.equal(y, y2)
+    assert bad == 0 and not eng.handover_downgraded
+    n_conv = sum(1 for r in rows if r[0] == "gemm" and " resident" in r[3])
+    n_conv_gnx = sum(1 for r in rows if r[0] == "gemm" and " resident" in r[3] and "+gnx" in r[3])
+    # 44 ResnetBlock2D convolutions + 3 Upsample2D convolutions per forward; the upsampling ones only where the target length is
+    # exactly twice the source's (T a multiple of 8), every level by default planning from 64 tiles
+    assert n_conv >= (47 if T % 8 == 0 else 44), (n_conv, [r[3] for r in rows if r[0] == "gemm"])
+    assert n_conv_gnx >= 20 and n_gnx >= 40, (n_conv_gnx, n_gnx)
+    got = y.cpu().numpy()[pick]
+    assert np.isfinite(got).all()
+    assert rel_l2(got, y_ref) < 2e-4, rel_l2(got, y_ref)
