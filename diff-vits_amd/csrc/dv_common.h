@@ -187,7 +187,15 @@ struct ChainParams {
   // amode 1: workgroups per row block (0 / 1: one).  2 or 3: the stage-2 passes are shared out between them, each
   // repeating stage 1 - for launches with fewer row blocks than CUs (every workgroup streams the weights it multiplies)
   int nsplit;
+  // k_qkv_split (kernels_qkv.hip: amode 1 with sa_*, 64-row blocks, the output columns split over C / 64 workgroups per row block):
+  // qkv_split_flags(p) exchange words, EMPTY (all ones) before the launch; time-out flag / bound of the wait (GnxParams)
+  unsigned long long* qs_flags; unsigned* qs_status; int qs_spin;
+  int qs_xcd;                    // internal (launcher): 1 = the slices of a row block share an XCD and hand h over through its L2
 };
+bool qkv_split_supported(const ChainParams& p, int precision);
+int qkv_split_flags(const ChainParams& p);
+hipError_t qkv_split_init();
+hipError_t launch_qkv_split(const ChainParams& p, int precision, hipStream_t st);
 // Feed-forward tail of a transformer block as ONE row-block launch (k_chain_ff, C = 128): LayerNorm3 (finished from the
 // producer's row partials) -> GEGLU (8C columns, packed [32 a | 32 gate] blocks; the 4C product stays in LDS as split
 // planes) -> merged ff.net.2 + proj_out over [h3 | product] (K = 5C) + bias + block residual -> fp32 output + 32x16

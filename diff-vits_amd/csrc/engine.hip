@@ -725,6 +725,8 @@ struct Builder {
     if (cat && nn.raw && !u->keep_intermediates && cat_drop_fp32) fp.out = nullptr;
   }
   bool ff_split_on = [] { const char* e = getenv("DVITS_FF_SPLIT"); return !(e && e[0] == '0'); }();
+  bool qkv_split_on = [] { const char* e = getenv("DVITS_QKV_SPLIT"); return !(e && e[0] == '0'); }();
+  int qkv_split_min_wg = [] { const char* e = getenv("DVITS_QKV_SPLIT_MIN_WG"); return e ? atoi(e) : 96; }();
   // ... from this many workgroups: one utterance (B = 1, T = 300 or 1024: 16-64 workgroups per launch) is bound by the chain of
   // dependent launches, and a launch with two in-launch hand-overs costs there what the two GEMM launches did (54.4 vs 53.6 ms per
   // 30-step run, 58.5 vs 57.6 at T = 1024: measured, round 5); from 128 workgroups (B = 4) the launch wins (+4.9 %)
@@ -1141,6 +1143,27 @@ struct Builder {
           const int rbs = M / 32, cus = n_cu > 0 ? n_cu : 256;
           cp.nsplit = off ? 1 : (rbs * 3 <= cus ? 3 : (rbs * 2 <= cus ? 2 : 1));
         }
+        // 64-row blocks with the output columns of both contractions split over C / 64 workgroups per row block (k_qkv_split,
+        // kernels_qkv.hip: an all-gather of h inside the launch - planned like k_ff_split's hand-over; DVITS_QKV_SPLIT=0: the
+        // 32-row chain above) wherever that gives the launch at least qkv_split_min_wg workgroups
+        const int n_qflags = qkv_split_flags(cp);
+        if (qkv_split_on && sa_frag && gnx_on && u->exclusive && !arena.exact && !autotune_on() && n_cu > 0 && qkv_split_supported(cp, prec) &&
+            (n_qflags <= n_cu || gemm_handover_rounds()) && n_qflags >= qkv_split_min_wg && gnx_used + (size_t)n_qflags <= dv_unet::GNX_POOL) {
+          cp.nsplit = 1;
+          cp.qs_flags = dry ? reinterpret_cast<unsigned long long*>(0x1000) : u->gnx_pool + gnx_used;
+          cp.qs_status = dry ? reinterpret_cast<unsigned*>(0x1000) : u->gnx_status;
+          cp.qs_spin = gnx_spin;
+          gnx_used += ((size_t)n_qflags + 1) & ~(size_t)1;
+          if (!dry) { u->gnx_words = gnx_used; u->gnx_ops++; }
+          cur_kind = "chain";
+          cur_flops = 2.0 * (double)cp.M * cp.C * cp.C * 4.0;
+          char buf[96];
+          snprintf(buf, sizeof(buf), "norm+proj_in+LN+q|Kfrag|Vfrag (%d wg / 64 rows) M=%d C=%d N2=%d", C / 64, cp.M, cp.C, 3 * cp.C);
+          cur_desc = buf;
+          if (!dry) u->flops += cur_flops;
+          const int pr = prec;
+          emit(ops, [cp, pr](hipStream_t st) { return launch_qkv_split(cp, pr, st); });
+        } else
         chain(ops, cp, sa_frag ? "norm+proj_in+LN+q|Kfrag|Vfrag" : "norm+proj_in+LN+qkv");
       }
       probe(p + "proj_in", h, Tn, C);
@@ -2035,6 +2058,7 @@ extern "C" int dv_unet_prepare(dv_unet* u, int32_t B, int32_t T, int32_t L, int3
   HIPCHK(attn_init());
   HIPCHK(chain_init());
   HIPCHK(ff_split_init());
+  HIPCHK(qkv_split_init());
   // a new shape re-plans the schedule; the packed weights survive unless the weights or the precision changed
   unet_release_prepared(u, !u->weights_dirty && u->packed_prec == precision);
   u->packed_prec = precision;

@@ -1783,3 +1783,50 @@ def test_convolution_kernels_outside_the_round5_window(case, B, T, L, env):
     got = y.cpu().numpy()[pick]
     assert np.isfinite(got).all()
     assert rel_l2(got, y_ref) < 2e-4, rel_l2(got, y_ref)
+
+
+@pytest.mark.parametrize("B,T,L", [(8, 1024, 64), (2, 256, 40), (3, 300, 77), (16, 512, 33), (1, 2048, 100)])
+def test_column_split_block_head_matches_the_row_block_chain(B, T, L):
+    """Round 6: the head of a transformer block - GroupNorm -> proj_in -> LayerNorm1 -> to_q | to_k | to_v (reference
+    transformer_1d.py:262-268, attention.py:157-160) - as ONE launch of 64-row blocks whose output columns are split over C / 64
+    workgroups per row block (k_qkv_split, kernels_qkv.hip: h all-gathered inside the launch) against the 32-row chain it replaces
+    (DVITS_QKV_SPLIT=0).  Same operands, same split-bf16 products, LayerNorm statistics from the fp32 rows instead of block partials:
+    float32-rounding agreement, the same number of launches, bit-repeatable, no hand-over timed out.  Shapes: the bench shape, a
+    small batch (forced with DVITS_QKV_SPLIT_MIN_WG=1), a padded row space (T = 300: pitch 320 at the first level - whole 64-row
+    blocks - and 160 / 96 / 64 below, where the pitch of 160 / 96 keeps the chain), grids above the CU count, one long utterance."""
+    from diff_vits_amd import synth
+    from diff_vits_amd.unet1d.unet_1d_condition import UNet1DConditionModel
+    kw = UNET_CASES["cfg1"][0]
+    with torch.device("meta"):
+        shapes = {k: tuple(v.shape) for k, v in UNet1DConditionModel(**kw).state_dict().items()}
+    sd = {k: torch.from_numpy(v) for k, v in synth.make_state_dict(shapes, seed=626).items()}
+    x = torch.from_numpy(synth.normal(26, "x", (B, 80, T))).cuda()
+    cond = torch.from_numpy(synth.normal(26, "c", (B, 128, T))).cuda()
+    enc = torch.from_numpy(synth.normal(26, "e", (B, L, 128))).cuda()
+    t = torch.linspace(900.0, 20.0, B, device="cuda")
+    outs, launches, split = [], [], []
+    os.environ["DVITS_QKV_SPLIT_MIN_WG"] = "1"
+    try:
+        for on in ("0", "1"):
+            os.environ["DVITS_QKV_SPLIT"] = on
+            m = UNet1DConditionModel(**kw).eval()
+            m.load_state_dict(sd)
+            eng = m.cuda().hip_engine()
+            eng.sync_weights()
+            eng.prepare(B, T, L)
+            eng.set_cond(enc, None)
+            y = eng.eval(x, cond, t).clone()
+            assert torch.equal(eng.eval(x, cond, t), y)
+            torch.cuda.synchronize()
+            n_ops, bad = eng.handover_status()
+            assert bad == 0 and n_ops > 0, (n_ops, bad)
+            outs.append(y.cpu().numpy())
+            launches.append(eng.stats()[0])
+            split.append(sum(1 for r in eng.profile_forward(x, cond, t) if r[0] == "chain" and "wg / 64 rows" in r[3] and "q|Kfrag" in r[3]))
+    finally:
+        os.environ.pop("DVITS_QKV_SPLIT", None)
+        os.environ.pop("DVITS_QKV_SPLIT_MIN_WG", None)
+    assert split[0] == 0 and split[1] >= (5 if T % 512 else 15), split
+    assert launches[1] == launches[0], launches
+    assert np.isfinite(outs[1]).all()
+    assert rel_l2(outs[1], outs[0]) < 2e-5, rel_l2(outs[1], outs[0])
