@@ -1148,7 +1148,7 @@ struct Builder {
         // 32-row chain above) wherever that gives the launch at least qkv_split_min_wg workgroups
         const int n_qflags = qkv_split_flags(cp);
         if (qkv_split_on && sa_frag && gnx_on && u->exclusive && !arena.exact && !autotune_on() && n_cu > 0 && qkv_split_supported(cp, prec) &&
-            (n_qflags <= n_cu || gemm_handover_rounds()) && n_qflags >= qkv_split_min_wg && gnx_used + (size_t)n_qflags <= dv_unet::GNX_POOL) {
+            n_qflags <= n_cu && n_qflags >= qkv_split_min_wg && gnx_used + (size_t)n_qflags <= dv_unet::GNX_POOL) {   // (one round of workgroups: at B = 16 - 384 / 512 of them - the 32-row chain is the faster one, 4.09 vs 4.19 ms per forward)
           cp.nsplit = 1;
           cp.qs_flags = dry ? reinterpret_cast<unsigned long long*>(0x1000) : u->gnx_pool + gnx_used;
           cp.qs_status = dry ? reinterpret_cast<unsigned*>(0x1000) : u->gnx_status;
@@ -1237,6 +1237,25 @@ struct Builder {
           const int rbs = M / 32, cus = n_cu > 0 ? n_cu : 256, nsg = C / 128;
           cp.nsplit = (!off && nsg >= 2 && rbs * nsg <= cus) ? nsg : 1;
         }
+        // (the same 64-row column-split launch as the block head - k_qkv_split, MODE 1: one round of workgroups)
+        const int n_qflags = qkv_split_flags(cp);
+        if (qkv_split_on && gnx_on && u->exclusive && !arena.exact && !autotune_on() && n_cu > 0 && qkv_split_supported(cp, prec) &&
+            n_qflags <= n_cu && n_qflags >= qkv_split_min_wg && gnx_used + (size_t)n_qflags <= dv_unet::GNX_POOL) {
+          cp.nsplit = 1;
+          cp.qs_flags = dry ? reinterpret_cast<unsigned long long*>(0x1000) : u->gnx_pool + gnx_used;
+          cp.qs_status = dry ? reinterpret_cast<unsigned*>(0x1000) : u->gnx_status;
+          cp.qs_spin = gnx_spin;
+          gnx_used += ((size_t)n_qflags + 1) & ~(size_t)1;
+          if (!dry) { u->gnx_words = gnx_used; u->gnx_ops++; }
+          cur_kind = "chain";
+          cur_flops = 2.0 * (double)cp.M * cp.C * cp.C * 2.0;
+          char buf[96];
+          snprintf(buf, sizeof(buf), "to_out+res+LN+to_q (%d wg / 64 rows) M=%d C=%d N2=%d", C / 64, cp.M, cp.C, cp.C);
+          cur_desc = buf;
+          if (!dry) u->flops += cur_flops;
+          const int pr = prec;
+          emit(ops, [cp, pr](hipStream_t st) { return launch_qkv_split(cp, pr, st); });
+        } else
         chain(ops, cp, "to_out+res+LN+to_q");
       }
       release(ao); release(h);

@@ -68,7 +68,10 @@ struct QGeom {
   static_assert(C % 128 == 0 && KS % 4 == 0 && SMEM + 8192 <= 160 * 1024, "geometry");
 };
 
-template <int C>
+// MODE 0: the block head (GroupNorm of the fp32 rows -> proj_in -> LN1 -> q | K | V fragments; ChainParams amode 1 with sa_*).
+// MODE 1: the self-attention tail (reference attention.py:157-189: attn1.to_out + residual -> LN2 -> attn2.to_q; ChainParams amode 0,
+//         one pass): the rows arrive as split planes (LDS-DMA), stage 1 adds the residual, stage 2 is the query contraction alone.
+template <int C, int MODE>
 __global__ __launch_bounds__(NT) void k_qkv_split(const ChainParams p) {
   using G = QGeom<C>;
   extern __shared__ __attribute__((aligned(1024))) char smem[];
@@ -188,9 +191,30 @@ __global__ __launch_bounds__(NT) void k_qkv_split(const ChainParams p) {
     *reinterpret_cast<uint2*>(a_reg + G::A_PL + off) = lw;
   };
 
+  // ================= the rows of the block -> LDS (MODE 0: GroupNorm of the fp32 rows; MODE 1: planes by DMA), stage-1 weights =================
+  float4 rv[G::JT];
+  float4 rres[2];                                    // MODE 1: the residual rows of this lane's finished pieces (cold: requested first)
+  if constexpr (MODE == 1) {
+    const int ncol_ = s * BN + cf * 32 + 8 * fg + 4 * lh;
+#pragma unroll
+    for (int rf = 0; rf < 2; ++rf)
+      rres[rf] = p.res ? *reinterpret_cast<const float4*>(p.res + (size_t)(m0 + rf * 32 + l31) * C + ncol_) : make_float4(0.f, 0.f, 0.f, 0.f);
+    // the rows as split planes by LDS-DMA: instruction = (64-channel chunk, 8 rows) of one plane, wave w sends rows 8 w .. 8 w + 7
+    const unsigned a_base = (unsigned)(size_t)a_reg;
+    const int d_row = wave * 8 + (lane >> 3), d_slot = lane & 7;
+#pragma unroll
+    for (int c = 0; c < G::A_CH; ++c) {
+      const size_t e = (size_t)(m0 + d_row) * C + c * 64 + ((d_slot ^ swz(d_row)) << 3);
+      const unsigned dst = a_base + (unsigned)(c * CHP + wave * 1024);
+      glds16(p.a_hi + e, dst);
+      glds16(p.a_lo + e, dst + G::A_PL);
+    }
+    job_prologue(p.w1_hi, p.w1_lo, s * 2 + cf);
+    DV_QTRACE(10);
+    wait_vmcnt<2 * G::DEPTH>();                      // everything older than the weight units: this wave's rows have landed
+  } else {
   // ================= rows of x, GroupNorm table of the utterance, stage-1 weights: requested together =================
   const int T = p.T, b_item = m0 / T, Tv = p.Tv > 0 ? p.Tv : T;   // row pitch / frames that exist (padded row spaces)
-  float4 rv[G::JT];
   {
     const float* xr = p.x + (size_t)(m0 + r_row) * C + 4 * r_e8;
 #pragma unroll
@@ -249,6 +273,7 @@ __global__ __launch_bounds__(NT) void k_qkv_split(const ChainParams p) {
     const float4 sh = *reinterpret_cast<const float4*>(s_gshift + ch);
     put_planes(j, fmaf(rv[j].x, sc.x, sh.x), fmaf(rv[j].y, sc.y, sh.y), fmaf(rv[j].z, sc.z, sh.z), fmaf(rv[j].w, sc.w, sh.w));
   }
+  }
   DV_QTRACE(1);
   __syncthreads();                                   // GN(x) complete in LDS
   DV_QTRACE(2);
@@ -263,6 +288,10 @@ __global__ __launch_bounds__(NT) void k_qkv_split(const ChainParams p) {
     for (int rf = 0; rf < 2; ++rf) {
       float4 v = quarter_sum(rf);
       v.x += b4.x; v.y += b4.y; v.z += b4.z; v.w += b4.w;
+      if constexpr (MODE == 1) {
+        const float4 r4 = rf == 0 ? rres[0] : rres[1];
+        v.x += r4.x; v.y += r4.y; v.z += r4.z; v.w += r4.w;
+      }
       // the other workgroups of the row block read it back below (XCD-local: from the shared L2 - a plain store reaches it, the
       // L1 is write-through; else written through to memory), later launches read it as the residual stream
       float4* const dst = reinterpret_cast<float4*>(p.out1 + (size_t)(m0 + rf * 32 + l31) * C + ncol);
@@ -280,9 +309,13 @@ __global__ __launch_bounds__(NT) void k_qkv_split(const ChainParams p) {
   DV_QTRACE(4);
   // LayerNorm vectors of this lane's finished columns (cold; independent of the hand-over)
   const float4 uq = *reinterpret_cast<const float4*>(p.u2 + ncol), bq4 = *reinterpret_cast<const float4*>(p.b2 + ncol);
-  const float4 uk = *reinterpret_cast<const float4*>(p.u2 + C + ncol), bk4 = *reinterpret_cast<const float4*>(p.b2 + C + ncol);
-  const int vch = s * BN + cf * 32 + l31;            // this lane's channel of a finished V piece (swapped orientation)
-  const float uvv = p.u2[2 * C + vch], bvv = p.b2[2 * C + vch];
+  float4 uk = uq, bk4 = bq4;
+  float uvv = 0.f, bvv = 0.f;
+  if constexpr (MODE == 0) {
+    uk = *reinterpret_cast<const float4*>(p.u2 + C + ncol); bk4 = *reinterpret_cast<const float4*>(p.b2 + C + ncol);
+    const int vch = s * BN + cf * 32 + l31;          // this lane's channel of a finished V piece (swapped orientation)
+    uvv = p.u2[2 * C + vch]; bvv = p.b2[2 * C + vch];
+  }
 
   // ================= all-gather of h: wait for the row block's flags (every wave polls for itself), rows back as fp32 =================
   {
@@ -360,7 +393,7 @@ __global__ __launch_bounds__(NT) void k_qkv_split(const ChainParams p) {
   const int nfq = s * 2 + cf, nfk = C / 32 + s * 2 + cf, nfv = 2 * (C / 32) + s * 2 + cf;
   // ---- q: fp32 [M, ldo2] ----
   job_loop(p.w2_hi, p.w2_lo, nfq, std::false_type{});
-  job_prologue(p.w2_hi, p.w2_lo, nfk);
+  if constexpr (MODE == 0) job_prologue(p.w2_hi, p.w2_lo, nfk);
 #pragma unroll
   for (int rf = 0; rf < 2; ++rf) {
     const float4 v = quarter_sum(rf);
@@ -371,6 +404,7 @@ __global__ __launch_bounds__(NT) void k_qkv_split(const ChainParams p) {
     dv_st16(p.out2 + (size_t)(m0 + rf * 32 + l31) * p.ldo2 + ncol, o);
   }
   DV_QTRACE(7);
+  if constexpr (MODE == 1) { DV_QTRACE(8); DV_QTRACE(9); return; }
   // ---- k: K fragments of the two 32-key tiles of this block (lane (half, key) holds 8 channels of a 16-channel group; this
   //      lane's four at byte 8 lh - k_chain2's layout) ----
   job_loop(p.w2_hi, p.w2_lo, nfk, std::false_type{});
@@ -419,14 +453,16 @@ __global__ __launch_bounds__(NT) void k_qkv_split(const ChainParams p) {
 
 template <int C>
 hipError_t qkv_init_one() {
-  return hipFuncSetAttribute(reinterpret_cast<const void*>(k_qkv_split<C>), hipFuncAttributeMaxDynamicSharedMemorySize, QGeom<C>::SMEM);
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_qkv_split<C, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, QGeom<C>::SMEM);
+  return e != hipSuccess ? e : hipFuncSetAttribute(reinterpret_cast<const void*>(k_qkv_split<C, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, QGeom<C>::SMEM);
 }
 template <int C>
 hipError_t qkv_launch_one(const ChainParams& pin, hipStream_t st) {
   ChainParams p = pin;
   static const bool xcd_on = [] { const char* e = getenv("DVITS_QKV_XCD"); return !(e && e[0] == '0'); }();
   p.qs_xcd = (xcd_on && (p.M / BM) % 8 == 0) ? 1 : 0;
-  hipLaunchKernelGGL((k_qkv_split<C>), dim3((p.M / BM) * QGeom<C>::NSPL), dim3(NT), QGeom<C>::SMEM, st, p);
+  if (p.amode == 1) hipLaunchKernelGGL((k_qkv_split<C, 0>), dim3((p.M / BM) * QGeom<C>::NSPL), dim3(NT), QGeom<C>::SMEM, st, p);
+  else hipLaunchKernelGGL((k_qkv_split<C, 1>), dim3((p.M / BM) * QGeom<C>::NSPL), dim3(NT), QGeom<C>::SMEM, st, p);
   return hipGetLastError();
 }
 
@@ -437,22 +473,26 @@ hipError_t qkv_split_init() {
   if (e == hipSuccess) e = qkv_init_one<256>();
   return e != hipSuccess ? e : qkv_init_one<384>();
 }
-// chain 1 with its self-attention operands as fragments (amode 1, passes q | k | v, sa_*), whole 64-row blocks per utterance
+// chain 1 with its self-attention operands as fragments (amode 1, passes q | k | v, sa_*) or chain 2 without the cross attention
+// inside (amode 0, one pass), whole 64-row blocks per utterance
 bool qkv_split_supported(const ChainParams& p, int precision) {
-  if (precision != 0 || p.amode != 1 || p.passes != 3 || !p.sa_kf_hi || !p.sa_kf_lo || !p.sa_vf_hi || !p.sa_vf_lo) return false;
+  if (precision != 0 || p.xa_kf_hi || !p.out1 || !p.out2 || p.ldo2 < p.C || (p.ldo2 & 3) != 0) return false;
   if (p.C != 128 && p.C != 256 && p.C != 384) return false;
-  if (p.res || p.xa_kf_hi || !p.out1 || !p.out2 || p.ldo2 < p.C || (p.ldo2 & 3) != 0) return false;
   if (p.T % BM != 0 || p.M % p.T != 0 || p.Tv < 0 || p.Tv > p.T || (p.Tv > 0 && p.Tv <= p.T - 32)) return false;
-  const int G = p.groups;
-  if (G <= 0 || G > 64 || (G & (G - 1)) != 0 || p.C % G != 0 || (p.C / G) % 16 != 0) return false;
-  if ((p.T / 32) * (p.C / 16) > 2 * 4 * 4 * 64 * 16 / 8) return false;   // the utterance's GroupNorm entries fit the exchange region
-  return true;
+  if (p.amode == 1) {
+    if (p.passes != 3 || !p.sa_kf_hi || !p.sa_kf_lo || !p.sa_vf_hi || !p.sa_vf_lo || p.res) return false;
+    const int G = p.groups;
+    if (G <= 0 || G > 64 || (G & (G - 1)) != 0 || p.C % G != 0 || (p.C / G) % 16 != 0) return false;
+    if ((p.T / 32) * (p.C / 16) > 2 * 4 * 4 * 64 * 16 / 8) return false;   // the utterance's GroupNorm entries fit the exchange region
+    return true;
+  }
+  return p.amode == 0 && p.passes == 1 && p.a_hi && p.a_lo && !p.sa_kf_hi;
 }
 int qkv_split_flags(const ChainParams& p) { return (p.M / BM) * (p.C / BN); }
 hipError_t launch_qkv_split(const ChainParams& p, int precision, hipStream_t st) {
   if (!qkv_split_supported(p, precision)) return hipErrorInvalidValue;
-  if (!p.x || !p.stat16 || !p.gamma || !p.beta || !p.w1_hi || !p.w1_lo || !p.b1 || !p.w2_hi || !p.w2_lo || !p.b2 || !p.u2 || !p.qs_flags ||
-      !p.qs_status)
+  if ((p.amode == 1 && (!p.x || !p.stat16 || !p.gamma || !p.beta)) || !p.w1_hi || !p.w1_lo || !p.b1 || !p.w2_hi || !p.w2_lo || !p.b2 || !p.u2 ||
+      !p.qs_flags || !p.qs_status)
     return hipErrorInvalidValue;
   if (!gemm_handover_rounds()) {                     // (else: the wait is for C / 64 consecutive workgroup ids)
     static const int n_cu = [] { int d = 0, n = 0; (void)hipGetDevice(&d); (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, d); return n; }();

@@ -1790,7 +1790,8 @@ def test_column_split_block_head_matches_the_row_block_chain(B, T, L):
     """Round 6: the head of a transformer block - GroupNorm -> proj_in -> LayerNorm1 -> to_q | to_k | to_v (reference
     transformer_1d.py:262-268, attention.py:157-160) - as ONE launch of 64-row blocks whose output columns are split over C / 64
     workgroups per row block (k_qkv_split, kernels_qkv.hip: h all-gathered inside the launch) against the 32-row chain it replaces
-    (DVITS_QKV_SPLIT=0).  Same operands, same split-bf16 products, LayerNorm statistics from the fp32 rows instead of block partials:
+    (DVITS_QKV_SPLIT=0); the same launch form runs the self-attention tail of the C = 384 blocks (attn1.to_out + residual -> LN2 ->
+    attn2.to_q, attention.py:157-189).  Same operands, same split-bf16 products, LayerNorm statistics from the fp32 rows instead of block partials:
     float32-rounding agreement, the same number of launches, bit-repeatable, no hand-over timed out.  Shapes: the bench shape, a
     small batch (forced with DVITS_QKV_SPLIT_MIN_WG=1), a padded row space (T = 300: pitch 320 at the first level - whole 64-row
     blocks - and 160 / 96 / 64 below, where the pitch of 160 / 96 keeps the chain), grids above the CU count, one long utterance."""
@@ -1804,7 +1805,7 @@ def test_column_split_block_head_matches_the_row_block_chain(B, T, L):
     cond = torch.from_numpy(synth.normal(26, "c", (B, 128, T))).cuda()
     enc = torch.from_numpy(synth.normal(26, "e", (B, L, 128))).cuda()
     t = torch.linspace(900.0, 20.0, B, device="cuda")
-    outs, launches, split = [], [], []
+    outs, launches, split, tails = [], [], [], []
     os.environ["DVITS_QKV_SPLIT_MIN_WG"] = "1"
     try:
         for on in ("0", "1"):
@@ -1822,11 +1823,16 @@ def test_column_split_block_head_matches_the_row_block_chain(B, T, L):
             assert bad == 0 and n_ops > 0, (n_ops, bad)
             outs.append(y.cpu().numpy())
             launches.append(eng.stats()[0])
-            split.append(sum(1 for r in eng.profile_forward(x, cond, t) if r[0] == "chain" and "wg / 64 rows" in r[3] and "q|Kfrag" in r[3]))
+            rows = eng.profile_forward(x, cond, t)
+            split.append(sum(1 for r in rows if r[0] == "chain" and "wg / 64 rows" in r[3] and "q|Kfrag" in r[3]))
+            tails.append(sum(1 for r in rows if r[0] == "chain" and "wg / 64 rows" in r[3] and r[3].startswith("to_out+res+LN+to_q (")))
     finally:
         os.environ.pop("DVITS_QKV_SPLIT", None)
         os.environ.pop("DVITS_QKV_SPLIT_MIN_WG", None)
     assert split[0] == 0 and split[1] >= (5 if T % 512 else 15), split
+    # ... and the self-attention tail of the C = 384 blocks (to_out + residual -> LN2 -> attn2.to_q: the same launch, MODE 1) where
+    # that level's row pitch is a multiple of 64
+    assert tails[0] == 0 and tails[1] == (5 if T % 256 == 0 else 0), tails
     assert launches[1] == launches[0], launches
     assert np.isfinite(outs[1]).all()
     assert rel_l2(outs[1], outs[0]) < 2e-5, rel_l2(outs[1], outs[0])
