@@ -61,8 +61,12 @@ struct QGeom {
   static constexpr int KS = C / 16, U = KS / 4;      // 16-deep k-steps of a contraction (K = C), per k-quarter (wave)
   static constexpr int DEPTH = U < 6 ? U : 6;        // weight units (hi + lo fragment: 8 VGPRs) in flight per wave
   static constexpr int A_CH = C / 64, A_PL = A_CH * CHP;
-  static constexpr int RED = 2 * 4 * 4 * 64 * 16;    // k-quarter exchange of ONE row fragment: [column fragment][quarter][register group][64 lanes] float4
+  // k-quarter exchange: [column fragment][quarter][row fragment][register group][64 lanes] float4 - both row fragments at once
+  // (64 KiB) where the resident rows leave room (C <= 256), one row fragment per round (32 KiB) at C = 384
+  static constexpr bool ONE = 2 * A_PL + 65536 + 8192 <= 160 * 1024;
+  static constexpr int RED = ONE ? 65536 : 32768;
   static constexpr int SMEM = 2 * A_PL + RED;
+  static constexpr int D3 = 3 * U < 9 ? 3 * U : 9;   // weight units in flight per wave in the merged q | k | v loop
   static constexpr int JT = C / 32;                  // float4 pieces of a row per thread (thread = (row, eighth): 8 threads per row)
   static constexpr int ENT_MAX = RED / 8;            // GroupNorm block-statistics entries of one utterance that fit the exchange region
   static_assert(C % 128 == 0 && KS % 4 == 0 && SMEM + 8192 <= 160 * 1024, "geometry");
@@ -161,23 +165,46 @@ __global__ __launch_bounds__(NT) void k_qkv_split(const ChainParams p) {
       __builtin_amdgcn_sched_barrier(0);
     }
   };
-  // The four k-quarters of row fragment rf are added through LDS (quarters in order: deterministic); wave (cf, fg) receives register
-  // group fg of fragment cf: v = rows l31 x columns 8 fg + 4 lh + e of the fragment (SWAP: column l31 x rows 8 fg + 4 lh + e)
+  // The four k-quarters are added through LDS (quarters in order: deterministic); wave (cf, fg) receives register group fg of
+  // fragment cf for both row fragments: v[rf] = rows l31 x columns 8 fg + 4 lh + e of the fragment (SWAP: column l31 x rows ...)
   float4* const red4 = reinterpret_cast<float4*>(red_reg);
-  auto quarter_sum = [&](int rf) __attribute__((always_inline)) {
-    __syncthreads();                                 // the exchange region is free (rf 0: every wave has left the k-loop)
+  auto pieces = [&](const f32x16& a0, const f32x16& a1, float4 (&v)[2]) __attribute__((always_inline)) {
+    if constexpr (G::ONE) {
+      __syncthreads();                               // the exchange region is free; every wave has left the k-loop
 #pragma unroll
-    for (int g = 0; g < 4; ++g)
-      red4[(((cf * 4 + kq) * 4 + g) << 6) + lane] = rf == 0 ? make_float4(acc[0][4 * g], acc[0][4 * g + 1], acc[0][4 * g + 2], acc[0][4 * g + 3])
-                                                             : make_float4(acc[1][4 * g], acc[1][4 * g + 1], acc[1][4 * g + 2], acc[1][4 * g + 3]);
-    __syncthreads();
-    float4 v = red4[(((cf * 4 + 0) * 4 + fg) << 6) + lane];
+      for (int g = 0; g < 4; ++g) {
+        red4[((((cf * 4 + kq) * 2 + 0) * 4 + g) << 6) + lane] = make_float4(a0[4 * g], a0[4 * g + 1], a0[4 * g + 2], a0[4 * g + 3]);
+        red4[((((cf * 4 + kq) * 2 + 1) * 4 + g) << 6) + lane] = make_float4(a1[4 * g], a1[4 * g + 1], a1[4 * g + 2], a1[4 * g + 3]);
+      }
+      __syncthreads();
 #pragma unroll
-    for (int k = 1; k < 4; ++k) {
-      const float4 w = red4[(((cf * 4 + k) * 4 + fg) << 6) + lane];
-      v.x += w.x; v.y += w.y; v.z += w.z; v.w += w.w;
+      for (int rf = 0; rf < 2; ++rf) {
+        float4 t = red4[((((cf * 4 + 0) * 2 + rf) * 4 + fg) << 6) + lane];
+#pragma unroll
+        for (int k = 1; k < 4; ++k) {
+          const float4 w = red4[((((cf * 4 + k) * 2 + rf) * 4 + fg) << 6) + lane];
+          t.x += w.x; t.y += w.y; t.z += w.z; t.w += w.w;
+        }
+        v[rf] = t;
+      }
+    } else {
+#pragma unroll
+      for (int rf = 0; rf < 2; ++rf) {
+        __syncthreads();
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+          red4[(((cf * 4 + kq) * 4 + g) << 6) + lane] = rf == 0 ? make_float4(a0[4 * g], a0[4 * g + 1], a0[4 * g + 2], a0[4 * g + 3])
+                                                                 : make_float4(a1[4 * g], a1[4 * g + 1], a1[4 * g + 2], a1[4 * g + 3]);
+        __syncthreads();
+        float4 t = red4[(((cf * 4 + 0) * 4 + fg) << 6) + lane];
+#pragma unroll
+        for (int k = 1; k < 4; ++k) {
+          const float4 w = red4[(((cf * 4 + k) * 4 + fg) << 6) + lane];
+          t.x += w.x; t.y += w.y; t.z += w.z; t.w += w.w;
+        }
+        v[rf] = t;
+      }
     }
-    return v;
   };
   // fp32 rows -> split planes of the resident operand: thread (r_row, r_e8) owns the float4 pieces 4 (r_e8 + 8 j) .. + 3 of its row
   auto put_planes = [&](int j, float v0, float v1, float v2, float v3) __attribute__((always_inline)) {
@@ -193,6 +220,8 @@ __global__ __launch_bounds__(NT) void k_qkv_split(const ChainParams p) {
 
   // ================= the rows of the block -> LDS (MODE 0: GroupNorm of the fp32 rows; MODE 1: planes by DMA), stage-1 weights =================
   float4 rv[G::JT];
+  // bias of this lane's finished stage-1 columns (cold: requested at the head, not in front of its use)
+  const float4 b1v = *reinterpret_cast<const float4*>(p.b1 + s * BN + cf * 32 + 8 * fg + 4 * lh);
   float4 rres[2];                                    // MODE 1: the residual rows of this lane's finished pieces (cold: requested first)
   if constexpr (MODE == 1) {
     const int ncol_ = s * BN + cf * 32 + 8 * fg + 4 * lh;
@@ -283,10 +312,12 @@ __global__ __launch_bounds__(NT) void k_qkv_split(const ChainParams p) {
   DV_QTRACE(3);
   const int ncol = s * BN + cf * 32 + 8 * fg + 4 * lh;   // this lane's four columns of a finished piece (normal orientation)
   {
-    const float4 b4 = *reinterpret_cast<const float4*>(p.b1 + ncol);
+    const float4 b4 = b1v;
+    float4 pv[2];
+    pieces(acc[0], acc[1], pv);
 #pragma unroll
     for (int rf = 0; rf < 2; ++rf) {
-      float4 v = quarter_sum(rf);
+      float4 v = pv[rf];
       v.x += b4.x; v.y += b4.y; v.z += b4.z; v.w += b4.w;
       if constexpr (MODE == 1) {
         const float4 r4 = rf == 0 ? rres[0] : rres[1];
@@ -305,7 +336,18 @@ __global__ __launch_bounds__(NT) void k_qkv_split(const ChainParams p) {
     if (xl) *reinterpret_cast<volatile unsigned long long*>(p.qs_flags + (size_t)rb * G::NSPL + s) = fv;
     else __hip_atomic_store(p.qs_flags + (size_t)rb * G::NSPL + s, fv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   }
-  job_prologue(p.w2_hi, p.w2_lo, s * 2 + cf);        // the q pass' first fragments fly during the hand-over
+  // stage 2's first weight fragments fly during the hand-over (MODE 0: of the merged q | k | v loop below)
+  const int nfq = s * 2 + cf, nfk = C / 32 + s * 2 + cf, nfv = 2 * (C / 32) + s * 2 + cf;
+  BFrag b3[MODE == 0 ? G::D3 : 1];
+  auto load_unit3 = [&](int j) {                     // unit j of the merged loop: k-step j / 3, pass j % 3 (q, k, v)
+    const int u = j / 3, ps = j - 3 * u;
+    return load_unit(p.w2_hi, p.w2_lo, ps == 0 ? nfq : (ps == 1 ? nfk : nfv), u);
+  };
+  if constexpr (MODE == 0) {
+#pragma unroll
+    for (int j = 0; j < G::D3; ++j) b3[j] = load_unit3(j);
+    __builtin_amdgcn_sched_barrier(0);
+  } else job_prologue(p.w2_hi, p.w2_lo, nfq);
   DV_QTRACE(4);
   // LayerNorm vectors of this lane's finished columns (cold; independent of the hand-over)
   const float4 uq = *reinterpret_cast<const float4*>(p.u2 + ncol), bq4 = *reinterpret_cast<const float4*>(p.b2 + ncol);
@@ -356,14 +398,31 @@ __global__ __launch_bounds__(NT) void k_qkv_split(const ChainParams p) {
   {
     const float4* hr = reinterpret_cast<const float4*>(p.out1 + (size_t)(m0 + r_row) * C + 4 * r_e8);
     if (xl) {
-      // L1-bypassing loads served by the XCD's L2, four in flight per wait (the destination registers of an asm load are only
-      // safe to read behind a wait inside the same block)
-#pragma unroll
-      for (int j = 0; j < G::JT; j += 4)
+      // L1-bypassing loads served by the XCD's L2, all of the row's pieces in flight behind ONE wait (the destination registers of an
+      // asm load are only safe to read behind a wait inside the same block)
+      if constexpr (G::JT == 4)
         asm volatile("global_load_dwordx4 %0, %4, off sc1\n\tglobal_load_dwordx4 %1, %4, off offset:128 sc1\n\t"
                      "global_load_dwordx4 %2, %4, off offset:256 sc1\n\tglobal_load_dwordx4 %3, %4, off offset:384 sc1\n\t"
                      "s_waitcnt vmcnt(0)"
-                     : "=&v"(rv[j]), "=&v"(rv[j + 1]), "=&v"(rv[j + 2]), "=&v"(rv[j + 3]) : "v"(hr + 8 * j) : "memory");
+                     : "=&v"(rv[0]), "=&v"(rv[1]), "=&v"(rv[2]), "=&v"(rv[3]) : "v"(hr) : "memory");
+      else if constexpr (G::JT == 8)
+        asm volatile("global_load_dwordx4 %0, %8, off sc1\n\tglobal_load_dwordx4 %1, %8, off offset:128 sc1\n\t"
+                     "global_load_dwordx4 %2, %8, off offset:256 sc1\n\tglobal_load_dwordx4 %3, %8, off offset:384 sc1\n\t"
+                     "global_load_dwordx4 %4, %8, off offset:512 sc1\n\tglobal_load_dwordx4 %5, %8, off offset:640 sc1\n\t"
+                     "global_load_dwordx4 %6, %8, off offset:768 sc1\n\tglobal_load_dwordx4 %7, %8, off offset:896 sc1\n\t"
+                     "s_waitcnt vmcnt(0)"
+                     : "=&v"(rv[0]), "=&v"(rv[1]), "=&v"(rv[2]), "=&v"(rv[3]), "=&v"(rv[4]), "=&v"(rv[5]), "=&v"(rv[6]), "=&v"(rv[7]) : "v"(hr) : "memory");
+      else
+        asm volatile("global_load_dwordx4 %0, %12, off sc1\n\tglobal_load_dwordx4 %1, %12, off offset:128 sc1\n\t"
+                     "global_load_dwordx4 %2, %12, off offset:256 sc1\n\tglobal_load_dwordx4 %3, %12, off offset:384 sc1\n\t"
+                     "global_load_dwordx4 %4, %12, off offset:512 sc1\n\tglobal_load_dwordx4 %5, %12, off offset:640 sc1\n\t"
+                     "global_load_dwordx4 %6, %12, off offset:768 sc1\n\tglobal_load_dwordx4 %7, %12, off offset:896 sc1\n\t"
+                     "global_load_dwordx4 %8, %12, off offset:1024 sc1\n\tglobal_load_dwordx4 %9, %12, off offset:1152 sc1\n\t"
+                     "global_load_dwordx4 %10, %12, off offset:1280 sc1\n\tglobal_load_dwordx4 %11, %12, off offset:1408 sc1\n\t"
+                     "s_waitcnt vmcnt(0)"
+                     : "=&v"(rv[0]), "=&v"(rv[1]), "=&v"(rv[2]), "=&v"(rv[3]), "=&v"(rv[4]), "=&v"(rv[5]), "=&v"(rv[6]), "=&v"(rv[7]),
+                       "=&v"(rv[8 % G::JT]), "=&v"(rv[9 % G::JT]), "=&v"(rv[10 % G::JT]), "=&v"(rv[11 % G::JT])
+                     : "v"(hr) : "memory");
     } else {
 #pragma unroll
       for (int j = 0; j < G::JT; ++j) rv[j] = ld_handover16(hr + 8 * j);
@@ -389,66 +448,128 @@ __global__ __launch_bounds__(NT) void k_qkv_split(const ChainParams p) {
   __syncthreads();                                   // h complete in LDS, row statistics visible
   DV_QTRACE(6);
 
-  // ================= stage 2: the same 64 columns of q, of k and of v =================
-  const int nfq = s * 2 + cf, nfk = C / 32 + s * 2 + cf, nfv = 2 * (C / 32) + s * 2 + cf;
-  // ---- q: fp32 [M, ldo2] ----
-  job_loop(p.w2_hi, p.w2_lo, nfq, std::false_type{});
-  if constexpr (MODE == 0) job_prologue(p.w2_hi, p.w2_lo, nfk);
+  // ================= stage 2: the same 64 columns of q (MODE 0: and of k and of v) =================
+  auto finish_q = [&](const float4 (&pv)[2]) __attribute__((always_inline)) {     // fp32 [M, ldo2]
 #pragma unroll
-  for (int rf = 0; rf < 2; ++rf) {
-    const float4 v = quarter_sum(rf);
-    const float2 st = s_ln[rf * 32 + l31];
-    float4 o;
-    o.x = st.y * (v.x - st.x * uq.x) + bq4.x; o.y = st.y * (v.y - st.x * uq.y) + bq4.y;
-    o.z = st.y * (v.z - st.x * uq.z) + bq4.z; o.w = st.y * (v.w - st.x * uq.w) + bq4.w;
-    dv_st16(p.out2 + (size_t)(m0 + rf * 32 + l31) * p.ldo2 + ncol, o);
-  }
-  DV_QTRACE(7);
-  if constexpr (MODE == 1) { DV_QTRACE(8); DV_QTRACE(9); return; }
-  // ---- k: K fragments of the two 32-key tiles of this block (lane (half, key) holds 8 channels of a 16-channel group; this
-  //      lane's four at byte 8 lh - k_chain2's layout) ----
-  job_loop(p.w2_hi, p.w2_lo, nfk, std::false_type{});
-  job_prologue(p.w2_hi, p.w2_lo, nfv);
-#pragma unroll
-  for (int rf = 0; rf < 2; ++rf) {
-    const float4 v = quarter_sum(rf);
-    const float2 st = s_ln[rf * 32 + l31];
-    const float o0 = st.y * (v.x - st.x * uk.x) + bk4.x, o1 = st.y * (v.y - st.x * uk.y) + bk4.y;
-    const float o2 = st.y * (v.z - st.x * uk.z) + bk4.z, o3 = st.y * (v.w - st.x * uk.w) + bk4.w;
-    uint2 hw, lw;
-    hw.x = pk(o0, o1); hw.y = pk(o2, o3);
-    lw.x = pk(o0 - __uint_as_float(hw.x << 16), o1 - __uint_as_float(hw.x & 0xffff0000u));
-    lw.y = pk(o2 - __uint_as_float(hw.y << 16), o3 - __uint_as_float(hw.y & 0xffff0000u));
-    const size_t eo = (((size_t)((m0 >> 5) + rf) * (C / 16) + (ncol >> 4)) * 64 + (fg & 1) * 32 + l31) * 8 + lh * 4;
-    dv_st8(p.sa_kf_hi + eo, hw);
-    dv_st8(p.sa_kf_lo + eo, lw);
-  }
-  DV_QTRACE(8);
-  // ---- v: swapped operands - lane = channel, registers = keys 8 fg + 4 lh + e: that register image is half of the lane's 16-byte
-  //      piece of the V^T fragment (channel block, k-block fg >> 1) of the tile ----
-  job_loop(p.w2_hi, p.w2_lo, nfv, std::true_type{});
-#pragma unroll
-  for (int rf = 0; rf < 2; ++rf) {
-    const float4 v = quarter_sum(rf);
-    // (mean, rstd) of the four key rows rf * 32 + 8 fg + 4 lh + e: 32 contiguous bytes of s_ln
-    const float4 s01 = *reinterpret_cast<const float4*>(&s_ln[rf * 32 + 8 * fg + 4 * lh]);
-    const float4 s23 = *reinterpret_cast<const float4*>(&s_ln[rf * 32 + 8 * fg + 4 * lh + 2]);
-    const float x0 = s01.y * (v.x - s01.x * uvv) + bvv, x1 = s01.w * (v.y - s01.z * uvv) + bvv;
-    const float x2 = s23.y * (v.z - s23.x * uvv) + bvv, x3 = s23.w * (v.w - s23.z * uvv) + bvv;
-    uint2 hw, lw;
-    if (DV_ATTN_PF16) {                              // V as split fp16 (dv_device.h)
-      dv_split_pk_f16(x0, x1, hw.x, lw.x);
-      dv_split_pk_f16(x2, x3, hw.y, lw.y);
-    } else {
-      hw.x = pk(x0, x1); hw.y = pk(x2, x3);
-      lw.x = pk(x0 - __uint_as_float(hw.x << 16), x1 - __uint_as_float(hw.x & 0xffff0000u));
-      lw.y = pk(x2 - __uint_as_float(hw.y << 16), x3 - __uint_as_float(hw.y & 0xffff0000u));
+    for (int rf = 0; rf < 2; ++rf) {
+      const float4 v = pv[rf];
+      const float2 st = s_ln[rf * 32 + l31];
+      float4 o;
+      o.x = st.y * (v.x - st.x * uq.x) + bq4.x; o.y = st.y * (v.y - st.x * uq.y) + bq4.y;
+      o.z = st.y * (v.z - st.x * uq.z) + bq4.z; o.w = st.y * (v.w - st.x * uq.w) + bq4.w;
+      dv_st16(p.out2 + (size_t)(m0 + rf * 32 + l31) * p.ldo2 + ncol, o);
     }
-    const size_t eo = (((((size_t)((m0 >> 5) + rf) * (C / 32) + s * 2 + cf) * 2 + (fg >> 1)) * 64 + lane) * 8) + (fg & 1) * 4;
-    dv_st8(p.sa_vf_hi + eo, hw);
-    dv_st8(p.sa_vf_lo + eo, lw);
+  };
+  if constexpr (MODE == 1) {
+    job_loop(p.w2_hi, p.w2_lo, nfq, std::false_type{});
+    float4 pv[2];
+    pieces(acc[0], acc[1], pv);
+    finish_q(pv);
+    DV_QTRACE(7); DV_QTRACE(8); DV_QTRACE(9);
+    return;
+  } else {
+    // ONE k-loop for the three contractions: the row fragments of a k-step are read from LDS once and meet the q, the k and the v
+    // fragment of this wave's columns (v with swapped operands: its accumulator is the transposed tile)
+    f32x16 aq[2], ak[2], av[2];
+#pragma unroll
+    for (int rf = 0; rf < 2; ++rf)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { aq[rf][r] = 0.f; ak[rf][r] = 0.f; av[rf][r] = 0.f; }
+    {
+      auto read_a = [&](int u, bf16x8 (&h)[2], bf16x8 (&l)[2]) {
+        const int c16 = (kq * G::U + u) * 2 + lh;
+#pragma unroll
+        for (int rf = 0; rf < 2; ++rf) {
+          const int row = rf * 32 + l31;
+          const int off = (c16 >> 3) * CHP + row * 128 + (((c16 & 7) ^ swz(row)) << 4);
+          h[rf] = *reinterpret_cast<const bf16x8*>(a_reg + off);
+          l[rf] = *reinterpret_cast<const bf16x8*>(a_reg + G::A_PL + off);
+        }
+      };
+      bf16x8 ah[2][2], al[2][2];
+      read_a(0, ah[0], al[0]);
+#pragma unroll
+      for (int j = 0; j < 3 * G::U; ++j) {
+        const int u = j / 3, ps = j - 3 * u, cur = u & 1;
+        if (ps == 0 && u + 1 < G::U) read_a(u + 1, ah[cur ^ 1], al[cur ^ 1]);
+        const BFrag f = b3[j % G::D3];
+        if (ps == 2) {
+#pragma unroll
+          for (int rf = 0; rf < 2; ++rf) av[rf] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[cur][rf], f.h, av[rf], 0, 0, 0);
+#pragma unroll
+          for (int rf = 0; rf < 2; ++rf) av[rf] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[cur][rf], f.l, av[rf], 0, 0, 0);
+#pragma unroll
+          for (int rf = 0; rf < 2; ++rf) av[rf] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[cur][rf], f.h, av[rf], 0, 0, 0);
+        } else if (ps == 1) {
+#pragma unroll
+          for (int rf = 0; rf < 2; ++rf) ak[rf] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.h, al[cur][rf], ak[rf], 0, 0, 0);
+#pragma unroll
+          for (int rf = 0; rf < 2; ++rf) ak[rf] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.l, ah[cur][rf], ak[rf], 0, 0, 0);
+#pragma unroll
+          for (int rf = 0; rf < 2; ++rf) ak[rf] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.h, ah[cur][rf], ak[rf], 0, 0, 0);
+        } else {
+#pragma unroll
+          for (int rf = 0; rf < 2; ++rf) aq[rf] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.h, al[cur][rf], aq[rf], 0, 0, 0);
+#pragma unroll
+          for (int rf = 0; rf < 2; ++rf) aq[rf] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.l, ah[cur][rf], aq[rf], 0, 0, 0);
+#pragma unroll
+          for (int rf = 0; rf < 2; ++rf) aq[rf] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.h, ah[cur][rf], aq[rf], 0, 0, 0);
+        }
+        // pinned: without the scheduling barriers hipcc sinks every prefetch down to its use (load -> vmcnt(0) -> MFMA)
+        __builtin_amdgcn_sched_barrier(0);
+        if (j + G::D3 < 3 * G::U) b3[j % G::D3] = load_unit3(j + G::D3);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    DV_QTRACE(7);
+    float4 pv[2];
+    // ---- q ----
+    pieces(aq[0], aq[1], pv);
+    finish_q(pv);
+    // ---- k: K fragments of the two 32-key tiles of this block (lane (half, key) holds 8 channels of a 16-channel group; this
+    //      lane's four at byte 8 lh - k_chain2's layout) ----
+    pieces(ak[0], ak[1], pv);
+#pragma unroll
+    for (int rf = 0; rf < 2; ++rf) {
+      const float4 v = pv[rf];
+      const float2 st = s_ln[rf * 32 + l31];
+      const float o0 = st.y * (v.x - st.x * uk.x) + bk4.x, o1 = st.y * (v.y - st.x * uk.y) + bk4.y;
+      const float o2 = st.y * (v.z - st.x * uk.z) + bk4.z, o3 = st.y * (v.w - st.x * uk.w) + bk4.w;
+      uint2 hw, lw;
+      hw.x = pk(o0, o1); hw.y = pk(o2, o3);
+      lw.x = pk(o0 - __uint_as_float(hw.x << 16), o1 - __uint_as_float(hw.x & 0xffff0000u));
+      lw.y = pk(o2 - __uint_as_float(hw.y << 16), o3 - __uint_as_float(hw.y & 0xffff0000u));
+      const size_t eo = (((size_t)((m0 >> 5) + rf) * (C / 16) + (ncol >> 4)) * 64 + (fg & 1) * 32 + l31) * 8 + lh * 4;
+      dv_st8(p.sa_kf_hi + eo, hw);
+      dv_st8(p.sa_kf_lo + eo, lw);
+    }
+    DV_QTRACE(8);
+    // ---- v: lane = channel, registers = keys 8 fg + 4 lh + e: that register image is half of the lane's 16-byte piece of the V^T
+    //      fragment (channel block, k-block fg >> 1) of the tile ----
+    pieces(av[0], av[1], pv);
+#pragma unroll
+    for (int rf = 0; rf < 2; ++rf) {
+      const float4 v = pv[rf];
+      // (mean, rstd) of the four key rows rf * 32 + 8 fg + 4 lh + e: 32 contiguous bytes of s_ln
+      const float4 s01 = *reinterpret_cast<const float4*>(&s_ln[rf * 32 + 8 * fg + 4 * lh]);
+      const float4 s23 = *reinterpret_cast<const float4*>(&s_ln[rf * 32 + 8 * fg + 4 * lh + 2]);
+      const float x0 = s01.y * (v.x - s01.x * uvv) + bvv, x1 = s01.w * (v.y - s01.z * uvv) + bvv;
+      const float x2 = s23.y * (v.z - s23.x * uvv) + bvv, x3 = s23.w * (v.w - s23.z * uvv) + bvv;
+      uint2 hw, lw;
+      if (DV_ATTN_PF16) {                            // V as split fp16 (dv_device.h)
+        dv_split_pk_f16(x0, x1, hw.x, lw.x);
+        dv_split_pk_f16(x2, x3, hw.y, lw.y);
+      } else {
+        hw.x = pk(x0, x1); hw.y = pk(x2, x3);
+        lw.x = pk(x0 - __uint_as_float(hw.x << 16), x1 - __uint_as_float(hw.x & 0xffff0000u));
+        lw.y = pk(x2 - __uint_as_float(hw.y << 16), x3 - __uint_as_float(hw.y & 0xffff0000u));
+      }
+      const size_t eo = (((((size_t)((m0 >> 5) + rf) * (C / 32) + s * 2 + cf) * 2 + (fg >> 1)) * 64 + lane) * 8) + (fg & 1) * 4;
+      dv_st8(p.sa_vf_hi + eo, hw);
+      dv_st8(p.sa_vf_lo + eo, lw);
+    }
+    DV_QTRACE(9);
   }
-  DV_QTRACE(9);
 }
 
 template <int C>
