@@ -25,8 +25,10 @@ import sys
 from collections import defaultdict
 
 # (the GEMM family = every launch of the engine's kind "gemm": k_gemm and, since round 5, the resident / streamed convolution kernels)
-FAMILIES = (("gemm", ("k_gemm", "k_conv3")), ("chain", ("k_chain",)), ("ff_split", ("k_ff_split",)), ("attention", ("k_attention",)), ("gn_apply", ("k_gn_apply",)),
-            ("conv3", ("k_conv3",)))
+# (the chain family = the row-block chains and, since round 6, the column-split launches k_qkv_split that replace two of them;
+# "qkv_split" lists those on their own as well)
+FAMILIES = (("gemm", ("k_gemm", "k_conv3")), ("chain", ("k_chain", "k_qkv_split")), ("ff_split", ("k_ff_split",)), ("attention", ("k_attention",)), ("gn_apply", ("k_gn_apply",)),
+            ("conv3", ("k_conv3",)), ("qkv_split", ("k_qkv_split",)))
 
 
 def counters(d):
