@@ -727,6 +727,8 @@ struct Builder {
   bool ff_split_on = [] { const char* e = getenv("DVITS_FF_SPLIT"); return !(e && e[0] == '0'); }();
   bool qkv_split_on = [] { const char* e = getenv("DVITS_QKV_SPLIT"); return !(e && e[0] == '0'); }();
   int qkv_split_min_wg = [] { const char* e = getenv("DVITS_QKV_SPLIT_MIN_WG"); return e ? atoi(e) : 96; }();
+  // (at C = 128 a workgroup of the 32-row chain streams 0.26 MB of weights: nothing to save - 18.1 us against 19.3 us on the split launch)
+  int qkv_split_min_c = [] { const char* e = getenv("DVITS_QKV_SPLIT_MIN_C"); return e ? atoi(e) : 256; }();
   // ... from this many workgroups: one utterance (B = 1, T = 300 or 1024: 16-64 workgroups per launch) is bound by the chain of
   // dependent launches, and a launch with two in-launch hand-overs costs there what the two GEMM launches did (54.4 vs 53.6 ms per
   // 30-step run, 58.5 vs 57.6 at T = 1024: measured, round 5); from 128 workgroups (B = 4) the launch wins (+4.9 %)
@@ -1147,7 +1149,7 @@ struct Builder {
         // kernels_qkv.hip: an all-gather of h inside the launch - planned like k_ff_split's hand-over; DVITS_QKV_SPLIT=0: the
         // 32-row chain above) wherever that gives the launch at least qkv_split_min_wg workgroups
         const int n_qflags = qkv_split_flags(cp);
-        if (qkv_split_on && sa_frag && gnx_on && u->exclusive && !arena.exact && !autotune_on() && n_cu > 0 && qkv_split_supported(cp, prec) &&
+        if (qkv_split_on && C >= qkv_split_min_c && sa_frag && gnx_on && u->exclusive && !arena.exact && !autotune_on() && n_cu > 0 && qkv_split_supported(cp, prec) &&
             n_qflags <= n_cu && n_qflags >= qkv_split_min_wg && gnx_used + (size_t)n_qflags <= dv_unet::GNX_POOL) {   // (one round of workgroups: at B = 16 - 384 / 512 of them - the 32-row chain is the faster one, 4.09 vs 4.19 ms per forward)
           cp.nsplit = 1;
           cp.qs_flags = dry ? reinterpret_cast<unsigned long long*>(0x1000) : u->gnx_pool + gnx_used;
@@ -1239,7 +1241,7 @@ struct Builder {
         }
         // (the same 64-row column-split launch as the block head - k_qkv_split, MODE 1: one round of workgroups)
         const int n_qflags = qkv_split_flags(cp);
-        if (qkv_split_on && gnx_on && u->exclusive && !arena.exact && !autotune_on() && n_cu > 0 && qkv_split_supported(cp, prec) &&
+        if (qkv_split_on && C >= qkv_split_min_c && gnx_on && u->exclusive && !arena.exact && !autotune_on() && n_cu > 0 && qkv_split_supported(cp, prec) &&
             n_qflags <= n_cu && n_qflags >= qkv_split_min_wg && gnx_used + (size_t)n_qflags <= dv_unet::GNX_POOL) {
           cp.nsplit = 1;
           cp.qs_flags = dry ? reinterpret_cast<unsigned long long*>(0x1000) : u->gnx_pool + gnx_used;

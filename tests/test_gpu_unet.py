@@ -1807,6 +1807,7 @@ def test_column_split_block_head_matches_the_row_block_chain(B, T, L):
     t = torch.linspace(900.0, 20.0, B, device="cuda")
     outs, launches, split, tails = [], [], [], []
     os.environ["DVITS_QKV_SPLIT_MIN_WG"] = "1"
+    os.environ["DVITS_QKV_SPLIT_MIN_C"] = "128"      # (default 256: at C = 128 the chain is as fast - every instantiation is tested)
     try:
         for on in ("0", "1"):
             os.environ["DVITS_QKV_SPLIT"] = on
@@ -1829,6 +1830,7 @@ def test_column_split_block_head_matches_the_row_block_chain(B, T, L):
     finally:
         os.environ.pop("DVITS_QKV_SPLIT", None)
         os.environ.pop("DVITS_QKV_SPLIT_MIN_WG", None)
+        os.environ.pop("DVITS_QKV_SPLIT_MIN_C", None)
     assert split[0] == 0 and split[1] >= (5 if T % 512 else 15), split
     # ... and the self-attention tail of the C = 384 blocks (to_out + residual -> LN2 -> attn2.to_q: the same launch, MODE 1) where
     # that level's row pitch is a multiple of 64
