@@ -190,6 +190,7 @@ struct ChainParams {
   // k_qkv_split (kernels_qkv.hip: amode 1 with sa_*, 64-row blocks, the output columns split over C / 64 workgroups per row block):
   // qkv_split_flags(p) exchange words, EMPTY (all ones) before the launch; time-out flag / bound of the wait (GnxParams)
   unsigned long long* qs_flags; unsigned* qs_status; int qs_spin;
+  bf16_t* qs_o_hi; bf16_t* qs_o_lo;   // MODE 2 (with xa_*): scratch planes [M, C] of the attention output (handed over between the slices)
   int qs_xcd;                    // internal (launcher): 1 = the slices of a row block share an XCD and hand h over through its L2
 };
 bool qkv_split_supported(const ChainParams& p, int precision);

@@ -729,6 +729,9 @@ struct Builder {
   int qkv_split_min_wg = [] { const char* e = getenv("DVITS_QKV_SPLIT_MIN_WG"); return e ? atoi(e) : 96; }();
   // (at C = 128 a workgroup of the 32-row chain streams 0.26 MB of weights: nothing to save - 18.1 us against 19.3 us on the split launch)
   int qkv_split_min_c = [] { const char* e = getenv("DVITS_QKV_SPLIT_MIN_C"); return e ? atoi(e) : 256; }();
+  bool qkv_xa_on = [] { const char* e = getenv("DVITS_QKV_XA"); return !(e && e[0] == '0'); }();   // the cross-attention chains on k_qkv_split (MODE 2)
+  // (C = 128: eight (head, row fragment) jobs walk all eight key tiles one after the other - 20 k cycles of key loop, 27.7 us against 24.2 us on the chain)
+  int qkv_xa_min_c = [] { const char* e = getenv("DVITS_QKV_XA_MIN_C"); return e ? atoi(e) : 256; }();
   // ... from this many workgroups: one utterance (B = 1, T = 300 or 1024: 16-64 workgroups per launch) is bound by the chain of
   // dependent launches, and a launch with two in-launch hand-overs costs there what the two GEMM launches did (54.4 vs 53.6 ms per
   // 30-step run, 58.5 vs 57.6 at T = 1024: measured, round 5); from 128 workgroups (B = 4) the launch wins (+4.9 %)
@@ -1214,9 +1217,44 @@ struct Builder {
               cp.xs_ticket = dry ? reinterpret_cast<unsigned*>(0x1000) : u->sk_tickets;
             }
           }
+          // The same block as ONE column-split launch of 64-row blocks (k_qkv_split MODE 2, kernels_qkv.hip: the slice's heads attend
+          // inside, h2 and the attention output handed over through the XCD's L2): one round of workgroups, whole multiples of 8
+          // row blocks (DVITS_QKV_XA=0: the row-block chain above)
+          ChainParams cq = cp;
+          cq.nsplit = 1; cq.xs_buf = nullptr; cq.xs_ticket = nullptr;
+          Planes oxa;
+          const int n_wg = (M / 64) * (C / 64);
+          bool split_xa = qkv_split_on && qkv_xa_on && C >= qkv_xa_min_c && gnx_on && u->exclusive && !arena.exact && !autotune_on() && n_cu > 0 &&
+                          Tp % 64 == 0 && (M / 64) % 8 == 0 && n_wg <= n_cu && n_wg >= qkv_split_min_wg && u->cfg.num_heads == 8 &&
+                          gnx_used + (size_t)2 * n_wg <= dv_unet::GNX_POOL;
+          if (split_xa) {
+            oxa = alloc_planes((size_t)M * C);
+            cq.qs_o_hi = oxa.hi; cq.qs_o_lo = oxa.lo;
+            split_xa = qkv_split_supported(cq, prec);
+            if (!split_xa) release(oxa);
+          }
+          if (split_xa) {
+            const int n_qflags = qkv_split_flags(cq);
+            cq.qs_flags = dry ? reinterpret_cast<unsigned long long*>(0x1000) : u->gnx_pool + gnx_used;
+            cq.qs_status = dry ? reinterpret_cast<unsigned*>(0x1000) : u->gnx_status;
+            cq.qs_spin = gnx_spin;
+            gnx_used += ((size_t)n_qflags + 1) & ~(size_t)1;
+            if (!dry) { u->gnx_words = gnx_used; u->gnx_ops++; }
+            if (cp.xs_buf) { release(cp.xs_buf); cp.xs_buf = nullptr; }
+            cur_kind = "chain";
+            cur_flops = 2.0 * (double)M * C * C * 2.0 + 4.0 * B * u->cfg.num_heads * (double)Tp * L * cq.xa_d + 2.0 * (double)M * C * C;
+            char buf[96];
+            snprintf(buf, sizeof(buf), "to_out+res+LN+to_q+xattn+to_out+res (%d wg / 64 rows) M=%d C=%d", C / 64, M, C);
+            cur_desc = buf;
+            if (!dry) u->flops += cur_flops;
+            const int pr = prec;
+            emit(ops, [cq, pr](hipStream_t st) { return launch_qkv_split(cq, pr, st); });
+            release(oxa);
+          } else {
           chain(ops, cp, cp.nsplit == 2 ? "to_out+res+LN+to_q+xattn(2 wg)+to_out+res" : "to_out+res+LN+to_q+xattn+to_out+res",
                 4.0 * B * u->cfg.num_heads * (double)Tp * L * cp.xa_d + 2.0 * (double)M * C * C);
           if (cp.xs_buf) release(cp.xs_buf);
+          }
         }
         release(ao); release(h);
         probe(tb + "attn1", h2, Tn, C);

@@ -222,8 +222,9 @@ __global__ __launch_bounds__(NT) void k_qkv_split(const ChainParams p) {
   float4 rv[G::JT];
   // bias of this lane's finished stage-1 columns (cold: requested at the head, not in front of its use)
   const float4 b1v = *reinterpret_cast<const float4*>(p.b1 + s * BN + cf * 32 + 8 * fg + 4 * lh);
-  float4 rres[2];                                    // MODE 1: the residual rows of this lane's finished pieces (cold: requested first)
-  if constexpr (MODE == 1) {
+  float4 rres[2];                                    // MODE 1 / 2: the residual rows of this lane's finished pieces (cold: requested first)
+  float4 h2v[2];                                     // MODE 2: this lane's finished columns of x1 = to_out + residual (stage 3 adds them)
+  if constexpr (MODE >= 1) {
     const int ncol_ = s * BN + cf * 32 + 8 * fg + 4 * lh;
 #pragma unroll
     for (int rf = 0; rf < 2; ++rf)
@@ -319,9 +320,10 @@ __global__ __launch_bounds__(NT) void k_qkv_split(const ChainParams p) {
     for (int rf = 0; rf < 2; ++rf) {
       float4 v = pv[rf];
       v.x += b4.x; v.y += b4.y; v.z += b4.z; v.w += b4.w;
-      if constexpr (MODE == 1) {
+      if constexpr (MODE >= 1) {
         const float4 r4 = rf == 0 ? rres[0] : rres[1];
         v.x += r4.x; v.y += r4.y; v.z += r4.z; v.w += r4.w;
+        if (rf == 0) h2v[0] = v; else h2v[1] = v;      // (MODE 2: the residual of stage 3 - this lane's own columns of x1)
       }
       // the other workgroups of the row block read it back below (XCD-local: from the shared L2 - a plain store reaches it, the
       // L1 is write-through; else written through to memory), later launches read it as the residual stream
@@ -360,8 +362,7 @@ __global__ __launch_bounds__(NT) void k_qkv_split(const ChainParams p) {
   }
 
   // ================= all-gather of h: wait for the row block's flags (every wave polls for itself), rows back as fp32 =================
-  {
-    const unsigned long long* fl = p.qs_flags + (size_t)rb * G::NSPL;
+  auto wait_flags = [&](const unsigned long long* fl, unsigned code) __attribute__((always_inline)) {
     for (int spins = 0;; ++spins) {
       bool ok = true;
       unsigned long long fv = 0;
@@ -385,7 +386,7 @@ __global__ __launch_bounds__(NT) void k_qkv_split(const ChainParams p) {
       if (lost) break;
       if (spins > p.qs_spin) {
         if (lane == 0) {
-          p.qs_status[1] = (unsigned)(size_t)p.qs_flags; p.qs_status[2] = blockIdx.x; p.qs_status[3] = 0xc1u; p.qs_status[4] = (unsigned)__builtin_popcountll(__ballot(!ok));
+          p.qs_status[1] = (unsigned)(size_t)p.qs_flags; p.qs_status[2] = blockIdx.x; p.qs_status[3] = code; p.qs_status[4] = (unsigned)__builtin_popcountll(__ballot(!ok));
           __hip_atomic_store(p.qs_status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         }
         break;
@@ -393,7 +394,8 @@ __global__ __launch_bounds__(NT) void k_qkv_split(const ChainParams p) {
       __builtin_amdgcn_s_sleep(1);
     }
     asm volatile("" ::: "memory");
-  }
+  };
+  wait_flags(p.qs_flags + (size_t)rb * G::NSPL, 0xc1u);
   DV_QTRACE(5);
   {
     const float4* hr = reinterpret_cast<const float4*>(p.out1 + (size_t)(m0 + r_row) * C + 4 * r_e8);
@@ -466,6 +468,234 @@ __global__ __launch_bounds__(NT) void k_qkv_split(const ChainParams p) {
     pieces(acc[0], acc[1], pv);
     finish_q(pv);
     DV_QTRACE(7); DV_QTRACE(8); DV_QTRACE(9);
+    return;
+  } else if constexpr (MODE == 2) {
+    // ================= MODE 2: the cross attention of the block inside the launch (reference attention.py:176-189: attn2 over the
+    // prompt's keys / values - hoisted by set_cond into MFMA-fragment order, ChainParams xa_* - then attn2.to_out + residual) =================
+    // The slice's 64 query columns are 64 / d whole heads (d = C / 8 = 16 / 32).  Jobs = (head of the slice, row fragment): eight at
+    // C = 128 - one per wave - four at C = 256, two waves per job on the key tiles of either parity, merged through LDS.  The
+    // arithmetic is k_chain2's (S^T = K Q^T and O^T += V^T P^T, split operands, scores in the log2 domain, online softmax lane-local).
+    constexpr int d = C / 8, KSq = d / 16, HS = BN / d, KP = (2 * HS < NWV) ? 2 : 1;    // head dim, k-steps of a score, heads per slice, key-parity waves per job
+    static_assert(C <= 256 && 2 * HS * KP == NWV, "MODE 2 geometry");
+    job_loop(p.w2_hi, p.w2_lo, nfq, std::false_type{});
+    job_prologue(p.w3_hi, p.w3_lo, s * 2 + cf);      // the output projection's first weight fragments fly under the attention
+    {
+      float4 pv[2];
+      pieces(acc[0], acc[1], pv);                    // (its barriers: every wave has left the k-loop - the rows of x1 are dead)
+      // the slice's queries, pre-scaled (d^-1/2 log2 e), as split planes in chunk 0 of the row region
+#pragma unroll
+      for (int rf = 0; rf < 2; ++rf) {
+        const float4 v = pv[rf];
+        const float2 st = s_ln[rf * 32 + l31];
+        const float q0 = (st.y * (v.x - st.x * uq.x) + bq4.x) * p.xa_qscale, q1 = (st.y * (v.y - st.x * uq.y) + bq4.y) * p.xa_qscale;
+        const float q2 = (st.y * (v.z - st.x * uq.z) + bq4.z) * p.xa_qscale, q3 = (st.y * (v.w - st.x * uq.w) + bq4.w) * p.xa_qscale;
+        uint2 hw, lw;
+        hw.x = pk(q0, q1); hw.y = pk(q2, q3);
+        lw.x = pk(q0 - __uint_as_float(hw.x << 16), q1 - __uint_as_float(hw.x & 0xffff0000u));
+        lw.y = pk(q2 - __uint_as_float(hw.y << 16), q3 - __uint_as_float(hw.y & 0xffff0000u));
+        const int nl = cf * 32 + 8 * fg + 4 * lh, row = rf * 32 + l31;        // column inside the slice
+        const int off = row * 128 + (((nl >> 3) ^ swz(row)) << 4) + ((nl & 7) >> 2) * 8;
+        *reinterpret_cast<uint2*>(a_reg + off) = hw;
+        *reinterpret_cast<uint2*>(a_reg + G::A_PL + off) = lw;
+      }
+    }
+    // this wave's job
+    const int job = KP == 2 ? (wave & 3) : wave, jh = job >> 1, jrf = job & 1, kh = KP == 2 ? wave >> 2 : 0;
+    const int head = s * HS + jh, nT = p.xa_nT;
+    const int b_item = m0 / p.T;
+    const size_t bh = (size_t)b_item * 8 + head;
+    const bf16x8* kfh = reinterpret_cast<const bf16x8*>(p.xa_kf_hi) + bh * nT * KSq * 64 + lane;
+    const bf16x8* kfl = reinterpret_cast<const bf16x8*>(p.xa_kf_lo) + bh * nT * KSq * 64 + lane;
+    const bf16x8* vfh = reinterpret_cast<const bf16x8*>(p.xa_vf_hi) + bh * nT * 2 * 64 + lane;
+    const bf16x8* vfl = reinterpret_cast<const bf16x8*>(p.xa_vf_lo) + bh * nT * 2 * 64 + lane;
+    const float* kbias = p.xa_bias + (size_t)b_item * nT * 32 + 4 * lh;
+    struct KVT { bf16x8 kh[KSq], kl[KSq], vh[2], vl[2]; float4 bv[4]; };
+    auto load_kv = [&](int t) {
+      KVT f;
+      const int tc = min(t, nT - 1);
+#pragma unroll
+      for (int ks = 0; ks < KSq; ++ks) { f.kh[ks] = kfh[(size_t)(tc * KSq + ks) * 64]; f.kl[ks] = kfl[(size_t)(tc * KSq + ks) * 64]; }
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb) { f.vh[kb] = vfh[(size_t)(tc * 2 + kb) * 64]; f.vl[kb] = vfl[(size_t)(tc * 2 + kb) * 64]; }
+#pragma unroll
+      for (int g = 0; g < 4; ++g) f.bv[g] = *reinterpret_cast<const float4*>(kbias + tc * 32 + 8 * g);
+      return f;
+    };
+    KVT cur = load_kv(kh);                           // (the prompt's fragments depend on nothing this launch computes)
+    __builtin_amdgcn_sched_barrier(0);
+    __syncthreads();                                 // query planes complete
+    bf16x8 qh[KSq], ql[KSq];
+#pragma unroll
+    for (int ks = 0; ks < KSq; ++ks) {
+      const int c16 = ((jh * d + ks * 16) >> 3) + lh, row = jrf * 32 + l31;
+      const int off = row * 128 + ((c16 ^ swz(row)) << 4);
+      qh[ks] = *reinterpret_cast<const bf16x8*>(a_reg + off);
+      ql[ks] = *reinterpret_cast<const bf16x8*>(a_reg + G::A_PL + off);
+    }
+    f32x16 o;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[r] = 0.f;
+    float m_run = -1e30f, l_run = 0.f;
+    DV_QTRACE(7);
+    for (int t = kh; t < nT; t += KP) {
+      __builtin_amdgcn_sched_barrier(0);
+      KVT nxt = load_kv(t + KP);
+      __builtin_amdgcn_sched_barrier(0);
+      f32x16 sc;
+      // (the key bias IS the initial accumulator)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) { sc[4 * g] = cur.bv[g].x; sc[4 * g + 1] = cur.bv[g].y; sc[4 * g + 2] = cur.bv[g].z; sc[4 * g + 3] = cur.bv[g].w; }
+#pragma unroll
+      for (int ks = 0; ks < KSq; ++ks) {
+        sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cur.kl[ks], qh[ks], sc, 0, 0, 0);
+        sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cur.kh[ks], ql[ks], sc, 0, 0, 0);
+        sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cur.kh[ks], qh[ks], sc, 0, 0, 0);
+      }
+      float tmax = m_run;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) tmax = fmaxf(tmax, sc[r]);
+      const float m_new = pair_max32(tmax);
+      const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+      m_run = m_new;
+      float psum = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { sc[r] = __builtin_amdgcn_exp2f(sc[r] - m_new); psum += sc[r]; }
+      l_run = l_run * alpha + psum;
+      if (__any(alpha != 1.0f)) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[r] *= alpha;
+      }
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb) {
+        typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+        u32x4 hw, lw;
+        if (DV_ATTN_PF16) {                          // P as one fp16 plane, V as split fp16: two products (dv_device.h)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) hw[e] = dv_cvt_pk_f16(sc[kb * 8 + 2 * e], sc[kb * 8 + 2 * e + 1]);
+          const dv_f16x8 ph16 = __builtin_bit_cast(dv_f16x8, hw);
+          o = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(dv_f16x8, cur.vl[kb]), ph16, o, 0, 0, 0);
+          o = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(dv_f16x8, cur.vh[kb]), ph16, o, 0, 0, 0);
+          continue;
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float x0 = sc[kb * 8 + 2 * e], x1 = sc[kb * 8 + 2 * e + 1];
+          const unsigned h2 = pk(x0, x1);
+          hw[e] = h2;
+          lw[e] = pk(x0 - __uint_as_float(h2 << 16), x1 - __uint_as_float(h2 & 0xffff0000u));
+        }
+        const bf16x8 ph = __builtin_bit_cast(bf16x8, hw), pl = __builtin_bit_cast(bf16x8, lw);
+        o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cur.vl[kb], ph, o, 0, 0, 0);
+        o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cur.vh[kb], pl, o, 0, 0, 0);
+        o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cur.vh[kb], ph, o, 0, 0, 0);
+      }
+      cur = nxt;
+    }
+    if constexpr (KP == 2) {
+      // merge the two key halves of a job: wave w + 4 hands (m, l, O) over, wave w combines (log2 domain)
+      float* mg = reinterpret_cast<float*>(red_reg);               // [4 jobs][2 + 16][64 lanes]
+      __syncthreads();                               // (the exchange region's last readers - the q pieces - are done)
+      if (kh == 1) {
+        float* q = mg + (size_t)job * 18 * 64 + lane;
+        q[0] = m_run; q[64] = l_run;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) q[(2 + r) * 64] = o[r];
+      }
+      __syncthreads();
+      if (kh == 0) {
+        const float* q = mg + (size_t)job * 18 * 64 + lane;
+        const float m1 = q[0], l1 = q[64];
+        const float mm = fmaxf(m_run, m1);
+        const float a0 = __builtin_amdgcn_exp2f(m_run - mm), a1 = __builtin_amdgcn_exp2f(m1 - mm);
+        l_run = l_run * a0 + l1 * a1;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[r] = o[r] * a0 + q[(2 + r) * 64] * a1;
+      }
+    }
+    DV_QTRACE(8);
+    // O (lane = query row, registers = channels 8g + 4lh + e of the head) -> split planes of the attention output in memory: the
+    // other slices of the row block need them (the output projection contracts over ALL heads) - the second hand-over of the launch
+    if (kh == 0) {
+      const float inv = 1.0f / pair_sum32(l_run);
+      const size_t ro = (size_t)(m0 + jrf * 32 + l31) * C + head * d + 4 * lh;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        if (8 * g < d) {
+          const float v0 = o[4 * g] * inv, v1 = o[4 * g + 1] * inv, v2 = o[4 * g + 2] * inv, v3 = o[4 * g + 3] * inv;
+          uint2 hw, lw;
+          hw.x = pk(v0, v1); hw.y = pk(v2, v3);
+          lw.x = pk(v0 - __uint_as_float(hw.x << 16), v1 - __uint_as_float(hw.x & 0xffff0000u));
+          lw.y = pk(v2 - __uint_as_float(hw.y << 16), v3 - __uint_as_float(hw.y & 0xffff0000u));
+          *reinterpret_cast<uint2*>(p.qs_o_hi + ro + 8 * g) = hw;       // (plain stores: the XCD's L2 - MODE 2 runs XCD-local only)
+          *reinterpret_cast<uint2*>(p.qs_o_lo + ro + 8 * g) = lw;
+        }
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    const unsigned long long* fl2 = p.qs_flags + (size_t)(p.M / BM) * G::NSPL + (size_t)rb * G::NSPL;
+    if (tid == 0) *reinterpret_cast<volatile unsigned long long*>(const_cast<unsigned long long*>(fl2) + s) = 1ull + xcc;
+    // stage-3 vectors of this lane's finished columns
+    const float4 b3v = *reinterpret_cast<const float4*>(p.b3 + ncol);
+    wait_flags(fl2, 0xc3u);
+    {
+      // the row block's attention output (all heads) -> the row region, by L1-bypassing LDS-DMA (served by the XCD's L2)
+      const unsigned a_base = (unsigned)(size_t)a_reg;
+      const int d_row = wave * 8 + (lane >> 3), d_slot = lane & 7;
+#pragma unroll
+      for (int c = 0; c < G::A_CH; ++c) {
+        const size_t e = (size_t)(m0 + d_row) * C + c * 64 + ((d_slot ^ swz(d_row)) << 3);
+        const unsigned dst = a_base + (unsigned)(c * CHP + wave * 1024);
+        glds16_sc1(p.qs_o_hi + e, dst);
+        glds16_sc1(p.qs_o_lo + e, dst + G::A_PL);
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __syncthreads();
+    DV_QTRACE(9);
+    // ================= stage 3: x3 = O W3^T + b3 + x1 -> fp32, raw planes and LayerNorm row partials (the GEGLU GEMM's inputs) =================
+    job_loop(p.w3_hi, p.w3_lo, s * 2 + cf, std::false_type{});
+    {
+      float4 pv[2];
+      pieces(acc[0], acc[1], pv);
+      __shared__ float2 s_rp[2 * 32 * 2 * 4];        // [row][column fragment][register group] (sum, M2) of 8 columns
+#pragma unroll
+      for (int rf = 0; rf < 2; ++rf) {
+        const float4 r4 = rf == 0 ? h2v[0] : h2v[1];
+        float4 v = pv[rf];
+        v.x += b3v.x + r4.x; v.y += b3v.y + r4.y; v.z += b3v.z + r4.z; v.w += b3v.w + r4.w;
+        const size_t ob = (size_t)(m0 + rf * 32 + l31) * C + ncol;
+        dv_st16(p.out3 + ob, v);
+        uint2 hw, lw;
+        hw.x = pk(v.x, v.y); hw.y = pk(v.z, v.w);
+        lw.x = pk(v.x - __uint_as_float(hw.x << 16), v.y - __uint_as_float(hw.x & 0xffff0000u));
+        lw.y = pk(v.z - __uint_as_float(hw.y << 16), v.w - __uint_as_float(hw.y & 0xffff0000u));
+        dv_st8(p.out3_hi + ob, hw);
+        dv_st8(p.out3_lo + ob, lw);
+        // this wave's 8 columns of the row: (sum, M2 about their own mean); the 32-column block's partial is combined below
+        const float a = pair_sum32((v.x + v.y) + (v.z + v.w));
+        const float mb = a * (1.0f / 8.0f);
+        const float q = pair_sum32((v.x - mb) * (v.x - mb) + (v.y - mb) * (v.y - mb) + (v.z - mb) * (v.z - mb) + (v.w - mb) * (v.w - mb));
+        if (lh == 0) s_rp[((rf * 32 + l31) * 2 + cf) * 4 + fg] = make_float2(a, q);
+      }
+      __syncthreads();
+      if (tid < 2 * BM) {                            // (row, column fragment): LayerNorm3's row partial of the 32-column block (parallel-variance form)
+        const int row = tid >> 1, f = tid & 1;
+        float s1 = 0.f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) s1 += s_rp[(row * 2 + f) * 4 + k].x;
+        const float mean = s1 * (1.0f / 32.0f);
+        float m2 = 0.f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const float2 t2 = s_rp[(row * 2 + f) * 4 + k];
+          const float dm = t2.x * (1.0f / 8.0f) - mean;
+          m2 += t2.y + 8.0f * dm * dm;
+        }
+        reinterpret_cast<float2*>(p.rowstat3)[(size_t)(m0 + row) * (C / 32) + s * 2 + f] = make_float2(s1, m2);
+      }
+    }
+    DV_QTRACE(13);
     return;
   } else {
     // ONE k-loop for the three contractions: the row fragments of a k-step are read from LDS once and meet the q, the k and the v
@@ -575,7 +805,11 @@ __global__ __launch_bounds__(NT) void k_qkv_split(const ChainParams p) {
 template <int C>
 hipError_t qkv_init_one() {
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_qkv_split<C, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, QGeom<C>::SMEM);
-  return e != hipSuccess ? e : hipFuncSetAttribute(reinterpret_cast<const void*>(k_qkv_split<C, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, QGeom<C>::SMEM);
+  if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_qkv_split<C, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, QGeom<C>::SMEM);
+  if constexpr (C <= 256) {
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_qkv_split<C, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, QGeom<C>::SMEM);
+  }
+  return e;
 }
 template <int C>
 hipError_t qkv_launch_one(const ChainParams& pin, hipStream_t st) {
@@ -583,7 +817,13 @@ hipError_t qkv_launch_one(const ChainParams& pin, hipStream_t st) {
   static const bool xcd_on = [] { const char* e = getenv("DVITS_QKV_XCD"); return !(e && e[0] == '0'); }();
   p.qs_xcd = (xcd_on && (p.M / BM) % 8 == 0) ? 1 : 0;
   if (p.amode == 1) hipLaunchKernelGGL((k_qkv_split<C, 0>), dim3((p.M / BM) * QGeom<C>::NSPL), dim3(NT), QGeom<C>::SMEM, st, p);
-  else hipLaunchKernelGGL((k_qkv_split<C, 1>), dim3((p.M / BM) * QGeom<C>::NSPL), dim3(NT), QGeom<C>::SMEM, st, p);
+  else if (!p.xa_kf_hi) hipLaunchKernelGGL((k_qkv_split<C, 1>), dim3((p.M / BM) * QGeom<C>::NSPL), dim3(NT), QGeom<C>::SMEM, st, p);
+  else {
+    if constexpr (C <= 256) {
+      if (!p.qs_xcd) return hipErrorInvalidValue;    // (the cross-attention form hands over through the XCD's L2 only)
+      hipLaunchKernelGGL((k_qkv_split<C, 2>), dim3((p.M / BM) * QGeom<C>::NSPL), dim3(NT), QGeom<C>::SMEM, st, p);
+    } else return hipErrorInvalidValue;
+  }
   return hipGetLastError();
 }
 
@@ -597,19 +837,23 @@ hipError_t qkv_split_init() {
 // chain 1 with its self-attention operands as fragments (amode 1, passes q | k | v, sa_*) or chain 2 without the cross attention
 // inside (amode 0, one pass), whole 64-row blocks per utterance
 bool qkv_split_supported(const ChainParams& p, int precision) {
-  if (precision != 0 || p.xa_kf_hi || !p.out1 || !p.out2 || p.ldo2 < p.C || (p.ldo2 & 3) != 0) return false;
+  if (precision != 0 || !p.out1 || (p.ldo2 & 3) != 0) return false;
   if (p.C != 128 && p.C != 256 && p.C != 384) return false;
   if (p.T % BM != 0 || p.M % p.T != 0 || p.Tv < 0 || p.Tv > p.T || (p.Tv > 0 && p.Tv <= p.T - 32)) return false;
   if (p.amode == 1) {
-    if (p.passes != 3 || !p.sa_kf_hi || !p.sa_kf_lo || !p.sa_vf_hi || !p.sa_vf_lo || p.res) return false;
+    if (p.passes != 3 || !p.sa_kf_hi || !p.sa_kf_lo || !p.sa_vf_hi || !p.sa_vf_lo || p.res || p.xa_kf_hi || !p.out2 || p.ldo2 < p.C) return false;
     const int G = p.groups;
     if (G <= 0 || G > 64 || (G & (G - 1)) != 0 || p.C % G != 0 || (p.C / G) % 16 != 0) return false;
     if ((p.T / 32) * (p.C / 16) > 2 * 4 * 4 * 64 * 16 / 8) return false;   // the utterance's GroupNorm entries fit the exchange region
     return true;
   }
-  return p.amode == 0 && p.passes == 1 && p.a_hi && p.a_lo && !p.sa_kf_hi;
+  if (p.amode != 0 || p.passes != 1 || !p.a_hi || !p.a_lo || p.sa_kf_hi) return false;
+  if (!p.xa_kf_hi) return p.out2 && p.ldo2 >= p.C;                         // MODE 1: the query leaves as fp32
+  // MODE 2: the cross attention inside (8 heads of d = C / 8 = 16 / 32, whole multiples of 8 row blocks: XCD-local hand-overs only)
+  return p.C <= 256 && p.xa_kf_lo && p.xa_vf_hi && p.xa_vf_lo && p.xa_bias && p.xa_nT > 0 && p.xa_d == p.C / 8 && p.w3_hi && p.w3_lo && p.b3 &&
+         p.out3 && p.out3_hi && p.out3_lo && p.rowstat3 && p.qs_o_hi && p.qs_o_lo && (p.M / BM) % 8 == 0;
 }
-int qkv_split_flags(const ChainParams& p) { return (p.M / BM) * (p.C / BN); }
+int qkv_split_flags(const ChainParams& p) { return (p.M / BM) * (p.C / BN) * (p.xa_kf_hi ? 2 : 1); }   // (the cross-attention form hands over twice)
 hipError_t launch_qkv_split(const ChainParams& p, int precision, hipStream_t st) {
   if (!qkv_split_supported(p, precision)) return hipErrorInvalidValue;
   if ((p.amode == 1 && (!p.x || !p.stat16 || !p.gamma || !p.beta)) || !p.w1_hi || !p.w1_lo || !p.b1 || !p.w2_hi || !p.w2_lo || !p.b2 || !p.u2 ||
@@ -617,7 +861,7 @@ hipError_t launch_qkv_split(const ChainParams& p, int precision, hipStream_t st)
     return hipErrorInvalidValue;
   if (!gemm_handover_rounds()) {                     // (else: the wait is for C / 64 consecutive workgroup ids)
     static const int n_cu = [] { int d = 0, n = 0; (void)hipGetDevice(&d); (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, d); return n; }();
-    if (qkv_split_flags(p) > n_cu) return hipErrorInvalidValue;
+    if ((p.M / BM) * (p.C / BN) > n_cu) return hipErrorInvalidValue;
   }
   if (p.C == 128) return qkv_launch_one<128>(p, st);
   if (p.C == 256) return qkv_launch_one<256>(p, st);

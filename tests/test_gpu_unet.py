@@ -1805,9 +1805,10 @@ def test_column_split_block_head_matches_the_row_block_chain(B, T, L):
     cond = torch.from_numpy(synth.normal(26, "c", (B, 128, T))).cuda()
     enc = torch.from_numpy(synth.normal(26, "e", (B, L, 128))).cuda()
     t = torch.linspace(900.0, 20.0, B, device="cuda")
-    outs, launches, split, tails = [], [], [], []
+    outs, launches, split, tails, xas = [], [], [], [], []
     os.environ["DVITS_QKV_SPLIT_MIN_WG"] = "1"
     os.environ["DVITS_QKV_SPLIT_MIN_C"] = "128"      # (default 256: at C = 128 the chain is as fast - every instantiation is tested)
+    os.environ["DVITS_QKV_XA_MIN_C"] = "128"
     try:
         for on in ("0", "1"):
             os.environ["DVITS_QKV_SPLIT"] = on
@@ -1827,14 +1828,20 @@ def test_column_split_block_head_matches_the_row_block_chain(B, T, L):
             rows = eng.profile_forward(x, cond, t)
             split.append(sum(1 for r in rows if r[0] == "chain" and "wg / 64 rows" in r[3] and "q|Kfrag" in r[3]))
             tails.append(sum(1 for r in rows if r[0] == "chain" and "wg / 64 rows" in r[3] and r[3].startswith("to_out+res+LN+to_q (")))
+            xas.append(sum(1 for r in rows if r[0] == "chain" and "wg / 64 rows" in r[3] and r[3].startswith("to_out+res+LN+to_q+xattn+to_out+res (")))
     finally:
         os.environ.pop("DVITS_QKV_SPLIT", None)
         os.environ.pop("DVITS_QKV_SPLIT_MIN_WG", None)
         os.environ.pop("DVITS_QKV_SPLIT_MIN_C", None)
+        os.environ.pop("DVITS_QKV_XA_MIN_C", None)
     assert split[0] == 0 and split[1] >= (5 if T % 512 else 15), split
     # ... and the self-attention tail of the C = 384 blocks (to_out + residual -> LN2 -> attn2.to_q: the same launch, MODE 1) where
     # that level's row pitch is a multiple of 64
     assert tails[0] == 0 and tails[1] == (5 if T % 256 == 0 else 0), tails
+    # ... and the cross-attention chains of the C = 128 / 256 blocks (MODE 2: the slice's heads attend inside the launch, two
+    # hand-overs through the XCD's L2) wherever a level has whole multiples of 8 row blocks of 64 rows
+    want_xa = sum(5 for Tl in (T, T // 2) if Tl % 64 == 0 and (B * Tl // 64) % 8 == 0)
+    assert xas[0] == 0 and xas[1] == want_xa, (xas, want_xa)
     assert launches[1] == launches[0], launches
     assert np.isfinite(outs[1]).all()
     assert rel_l2(outs[1], outs[0]) < 2e-5, rel_l2(outs[1], outs[0])

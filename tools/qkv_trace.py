@@ -51,5 +51,11 @@ for Csel in CS:
     for a, b, nm in ((0, 10, "  start -> requests issued"), (10, 11, "  -> GroupNorm entries in LDS (everything requested has landed)"), (11, 12, "  -> table ready"), (12, 1, "  -> rows converted")):
         d = tt[:, b] - tt[:, a]
         print("   %-58s median %6d  p10 %6d  p90 %6d" % (nm, np.median(d), np.percentile(d, 10), np.percentile(d, 90)))
+    if (tt[:, 13] > 0).all():      # the cross-attention form (MODE 2): stamps 6-9 and 13 mean something else
+        for a, b, nm in ((6, 7, "  MODE 2: q pass, query planes, first key tile requested"), (7, 8, "  MODE 2: key loop (+ merge of the key halves)"),
+                         (8, 9, "  MODE 2: O stored, flag, wait, O of the row block by DMA"), (9, 13, "  MODE 2: stage 3 (to_out + residual, planes, LN3 partials)")):
+            d = tt[:, b] - tt[:, a]
+            print("   %-58s median %6d  p10 %6d  p90 %6d" % (nm, np.median(d), np.percentile(d, 10), np.percentile(d, 90)))
+        print("   %-58s median %6d" % ("  MODE 2: whole workgroup", np.median(tt[:, 13] - tt[:, 0])))
     print("   %-58s median %6d  max %6d" % ("whole workgroup", np.median(tt[:, 9] - tt[:, 0]), np.max(tt[:, 9] - tt[:, 0])))
     print("   %-58s %6d" % ("first start -> last end over the launch", int(tt[:, 9].max() - tt[:, 0].min())))
