@@ -194,6 +194,7 @@ struct ChainParams {
   int qs_xcd;                    // internal (launcher): 1 = the slices of a row block share an XCD and hand h over through its L2
 };
 bool qkv_split_supported(const ChainParams& p, int precision);
+bool qkv_split_xcd_local(int M);   // the slices of a row block share an XCD (required by the cross-attention form)
 int qkv_split_flags(const ChainParams& p);
 hipError_t qkv_split_init();
 hipError_t launch_qkv_split(const ChainParams& p, int precision, hipStream_t st);

@@ -814,8 +814,7 @@ hipError_t qkv_init_one() {
 template <int C>
 hipError_t qkv_launch_one(const ChainParams& pin, hipStream_t st) {
   ChainParams p = pin;
-  static const bool xcd_on = [] { const char* e = getenv("DVITS_QKV_XCD"); return !(e && e[0] == '0'); }();
-  p.qs_xcd = (xcd_on && (p.M / BM) % 8 == 0) ? 1 : 0;
+  p.qs_xcd = qkv_split_xcd_local(p.M) ? 1 : 0;
   if (p.amode == 1) hipLaunchKernelGGL((k_qkv_split<C, 0>), dim3((p.M / BM) * QGeom<C>::NSPL), dim3(NT), QGeom<C>::SMEM, st, p);
   else if (!p.xa_kf_hi) hipLaunchKernelGGL((k_qkv_split<C, 1>), dim3((p.M / BM) * QGeom<C>::NSPL), dim3(NT), QGeom<C>::SMEM, st, p);
   else {
@@ -829,6 +828,11 @@ hipError_t qkv_launch_one(const ChainParams& pin, hipStream_t st) {
 
 }  // namespace
 
+// Do the slices of a row block share an XCD (hand-overs through its L2)?  Whole multiples of 8 row blocks; DVITS_QKV_XCD=0: never
+bool qkv_split_xcd_local(int M) {
+  static const bool xcd_on = [] { const char* e = getenv("DVITS_QKV_XCD"); return !(e && e[0] == '0'); }();
+  return xcd_on && (M / BM) % 8 == 0;
+}
 hipError_t qkv_split_init() {
   hipError_t e = qkv_init_one<128>();
   if (e == hipSuccess) e = qkv_init_one<256>();
@@ -851,7 +855,7 @@ bool qkv_split_supported(const ChainParams& p, int precision) {
   if (!p.xa_kf_hi) return p.out2 && p.ldo2 >= p.C;                         // MODE 1: the query leaves as fp32
   // MODE 2: the cross attention inside (8 heads of d = C / 8 = 16 / 32, whole multiples of 8 row blocks: XCD-local hand-overs only)
   return p.C <= 256 && p.xa_kf_lo && p.xa_vf_hi && p.xa_vf_lo && p.xa_bias && p.xa_nT > 0 && p.xa_d == p.C / 8 && p.w3_hi && p.w3_lo && p.b3 &&
-         p.out3 && p.out3_hi && p.out3_lo && p.rowstat3 && p.qs_o_hi && p.qs_o_lo && (p.M / BM) % 8 == 0;
+         p.out3 && p.out3_hi && p.out3_lo && p.rowstat3 && p.qs_o_hi && p.qs_o_lo && qkv_split_xcd_local(p.M);
 }
 int qkv_split_flags(const ChainParams& p) { return (p.M / BM) * (p.C / BN) * (p.xa_kf_hi ? 2 : 1); }   // (the cross-attention form hands over twice)
 hipError_t launch_qkv_split(const ChainParams& p, int precision, hipStream_t st) {

@@ -1845,3 +1845,48 @@ def test_column_split_block_head_matches_the_row_block_chain(B, T, L):
     assert launches[1] == launches[0], launches
     assert np.isfinite(outs[1]).all()
     assert rel_l2(outs[1], outs[0]) < 2e-5, rel_l2(outs[1], outs[0])
+
+
+def test_column_split_launch_with_its_hand_over_through_memory():
+    """k_qkv_split's fallback form (DVITS_QKV_XCD=0 - read once per process, hence the child - or a level whose row blocks are no
+    multiple of 8): the slices of a row block sit on different XCDs and h goes through memory (write-through stores, system-scope
+    loads).  Against the 32-row chains at float32 rounding; the cross-attention form, which hands over through the L2 only, is not
+    planned then."""
+    out = _handover_child(r"""
+import os, sys
+sys.path.insert(0, "tests")
+import numpy as np, torch
+from conftest import UNET_CASES
+import diff_vits_amd
+from diff_vits_amd import synth
+from diff_vits_amd.unet1d.unet_1d_condition import UNet1DConditionModel
+kw = UNET_CASES["cfg1"][0]
+with torch.device("meta"):
+    shapes = {k: tuple(v.shape) for k, v in UNet1DConditionModel(**kw).state_dict().items()}
+sd = {k: torch.from_numpy(v) for k, v in synth.make_state_dict(shapes, seed=636).items()}
+B, T, L = 8, 512, 50
+x = torch.from_numpy(synth.normal(36, "x", (B, 80, T))).cuda()
+cond = torch.from_numpy(synth.normal(36, "c", (B, 128, T))).cuda()
+enc = torch.from_numpy(synth.normal(36, "e", (B, L, 128))).cuda()
+t = torch.linspace(900.0, 20.0, B, device="cuda")
+outs = []
+for on in ("0", "1"):
+    os.environ["DVITS_QKV_SPLIT"] = on
+    m = UNet1DConditionModel(**kw).eval()
+    m.load_state_dict(sd)
+    eng = m.cuda().hip_engine()
+    eng.sync_weights(); eng.prepare(B, T, L); eng.set_cond(enc, None)
+    y = eng.eval(x, cond, t).clone()
+    assert torch.equal(eng.eval(x, cond, t), y)
+    torch.cuda.synchronize()
+    assert eng.handover_status()[1] == 0
+    rows = eng.profile_forward(x, cond, t)
+    n_head = sum(1 for r in rows if "q|Kfrag|Vfrag (" in r[3])
+    n_xa = sum(1 for r in rows if "xattn+to_out+res (" in r[3])
+    assert n_xa == 0 and n_head == (10 if on == "1" else 0), (on, n_head, n_xa)
+    outs.append(y)
+err = float((outs[1] - outs[0]).norm() / outs[0].norm())
+assert err < 2e-5, err
+print("ok", err)
+""", DVITS_QKV_XCD="0", DVITS_QKV_SPLIT_MIN_WG="1")
+    assert "ok" in out
