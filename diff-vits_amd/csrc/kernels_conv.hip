@@ -22,7 +22,8 @@
 //     statistics, the consumer's GroupNorm finished in the launch (gnx_device.h).
 // The tile grid, the XCD rectangle and the exchange-word layout are those of k_gemm's 64x64 tile: launch_gemm (kernels_gemm.hip)
 // dispatches here when gemm_conv3_shape_ok() / gemm_conv3_up_ok() hold and the caller gives the fragment-major weights (GemmParams
-// wf_hi / wf_lo; engine.hip conv3_takes: grids of 64-256 tiles).  Measured (profiles/r05_*conv3*): the resident k-loops run AT the
+// wf_hi / wf_lo, c3_route; engine.hip conv3_route: from 64 tiles, any grid size).  Round 6: the row tiles are laid out PER UTTERANCE
+// (C3Tile below) - any row pitch of whole 32-frame blocks, the padded row space of real utterance lengths included.  Measured (profiles/r05_*conv3*): the resident k-loops run AT the
 // MFMA rate, the streamed one at ~1900 cycles per 64-channel chunk (1152 of MFMA: the per-CU vector-memory path carries the rows AND
 // the weights); 48 of the forward's 62 GEMM launches, family 1.24 -> 1.06 ms per forward, +4.9 % on the 50-step run.
 #include "dv_common.h"

@@ -1,7 +1,10 @@
 // Head of a transformer block at C = 128 / 256 / 384 for gfx950 (MI355X) as ONE launch of 64-row blocks whose COLUMNS are split over
 // the workgroups: GroupNorm -> proj_in -> LayerNorm1 -> to_q | to_k | to_v (reference unet1d/transformer_1d.py:262-268: norm, proj_in;
 // attention.py:157-160: norm1, attn1's projections) - the work of k_chain2<NS, 1, false, true> (kernels_chain.hip, "chain 1"), same
-// ChainParams, same results layout (h fp32, q fp32, K / V^T as MFMA fragments of 32-key tiles).
+// ChainParams, same results layout (h fp32, q fp32, K / V^T as MFMA fragments of 32-key tiles).  The same launch form also runs the
+// two tails of the self attention (template parameter MODE, below): attn1.to_out + residual -> LN2 -> attn2.to_q (MODE 1, C = 384) and
+// the whole cross-attention chain ... -> cross attention -> attn2.to_out + residual -> LN3 partials (MODE 2, C = 256: the slice's heads
+// attend inside the launch, the attention output is a second hand-over).
 //
 // Why.  The row-block chain owns 32 rows and ALL channels: a workgroup streams every weight of both contractions - 4 C^2 x 4 bytes,
 // 2.4 MB at C = 384 - for 32 rows, each weight fragment feeds ONE row fragment, and the k-loops run at the rate the weights arrive

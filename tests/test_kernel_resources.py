@@ -40,6 +40,7 @@ def test_config2_schedule_kernels_are_present_and_spill_free(kernels):
             "k_conv3<128>", "k_conv3<256>", "k_conv3<384>", "k_conv3<512>", "k_conv3s(", "k_conv3u<256>", "k_conv3u<384>", "k_conv3u<512>",
             "k_chain2<1, 0, true, false, false>", "k_chain2<2, 0, true, false, false>", "k_chain2<1, 1, false, true, false>",
             "k_chain2<2, 1, false, true, false>", "k_chain2<3, 1, false, true, false>", "k_chain2<3, 0, false, false, true>",
+            "k_qkv_split<256, 0>", "k_qkv_split<384, 0>", "k_qkv_split<384, 1>", "k_qkv_split<256, 2>", "k_qkv_split<128, 0>",   # (round 6)
             "k_chain_ff(", "k_gn_apply(", "k_pack_input(", "k_lincomb("]
     for w in want:
         hit = [k for k in kernels if w in k["name"]]
