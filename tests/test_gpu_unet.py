@@ -1785,7 +1785,7 @@ def test_convolution_kernels_outside_the_round5_window(case, B, T, L, env):
     assert rel_l2(got, y_ref) < 2e-4, rel_l2(got, y_ref)
 
 
-@pytest.mark.parametrize("B,T,L", [(8, 1024, 64), (2, 256, 40), (3, 300, 77), (16, 512, 33), (1, 2048, 100)])
+@pytest.mark.parametrize("B,T,L", [(8, 1024, 64), (2, 256, 40), (3, 300, 77), (16, 512, 33), (1, 2048, 100), (4, 512, 20)])
 def test_column_split_block_head_matches_the_row_block_chain(B, T, L):
     """Round 6: the head of a transformer block - GroupNorm -> proj_in -> LayerNorm1 -> to_q | to_k | to_v (reference
     transformer_1d.py:262-268, attention.py:157-160) - as ONE launch of 64-row blocks whose output columns are split over C / 64
@@ -1794,7 +1794,8 @@ def test_column_split_block_head_matches_the_row_block_chain(B, T, L):
     attn2.to_q, attention.py:157-189).  Same operands, same split-bf16 products, LayerNorm statistics from the fp32 rows instead of block partials:
     float32-rounding agreement, the same number of launches, bit-repeatable, no hand-over timed out.  Shapes: the bench shape, a
     small batch (forced with DVITS_QKV_SPLIT_MIN_WG=1), a padded row space (T = 300: pitch 320 at the first level - whole 64-row
-    blocks - and 160 / 96 / 64 below, where the pitch of 160 / 96 keeps the chain), grids above the CU count, one long utterance."""
+    blocks - and 160 / 96 / 64 below, where the pitch of 160 / 96 keeps the chain), grids above the CU count, one long utterance, a
+    prompt of a single 32-key tile (one of the two key-parity waves of a cross-attention job then has no tile at all)."""
     from diff_vits_amd import synth
     from diff_vits_amd.unet1d.unet_1d_condition import UNet1DConditionModel
     kw = UNET_CASES["cfg1"][0]
