@@ -2,11 +2,12 @@
 """Where a B = 1 sampler run spends its time: busy (kernel durations) vs idle (gaps between dependent kernels) from a
 rocprofv3 kernel trace of tools/b1_latency.py.
 Usage (GPU box):  cd /tmp && rocprofv3 --kernel-trace --output-format csv -d $R/gpurun_out/b1tr -- python3 $R/tools/b1_latency.py 300
-                  python3 tools/b1_timeline.py gpurun_out/b1tr [launches per forward]"""
+                  python3 tools/b1_timeline.py gpurun_out/b1tr [launches per forward] [forwards of the last run to cover: default 20, 30 = the whole 30-step run]"""
 import csv, glob, os, sys, collections
 
 d = sys.argv[1]
 per_fwd = int(sys.argv[2]) if len(sys.argv) > 2 else 146
+n_fwd = int(sys.argv[3]) if len(sys.argv) > 3 else 20
 f = sorted(glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True))[-1]
 rows = []
 with open(f) as fh:
@@ -14,7 +15,7 @@ with open(f) as fh:
         rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]))
 rows.sort()
 # the last complete sampler run: 30 forwards (+ a few sampler-update kernels); take the last 20 forwards' worth of launches
-tail = rows[-20 * (per_fwd + 2):]
+tail = rows[-n_fwd * (per_fwd + 2):]
 span = tail[-1][1] - tail[0][0]
 busy = sum(e - s for s, e, _ in tail)
 gaps = [max(0, tail[i + 1][0] - tail[i][1]) for i in range(len(tail) - 1)]
